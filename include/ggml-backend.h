@@ -1,0 +1,117 @@
+// ggml-backend.h — C-ABI drop-in boundary, part 2 of 4 (devices, buffers, graph submission).
+//
+// Restates the ggml backend API subset the reference calls. Protocol as the reference
+// drives it (src/context.h:520-544, 628-653):
+//   buffer = ggml_backend_alloc_ctx_tensors(ctx, backend)   every non-view tensor gets its own storage
+//   ggml_backend_tensor_set(t, host, off, n)                 uploads (inputs, constants, weights)
+//   ggml_backend_graph_compute(backend, graph)               synchronous: results visible on return
+//   ggml_backend_tensor_get(t, host, off, n)                 blocking read-back
+// All calls come from one thread.
+#pragma once
+
+#include "ggml.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ggml_backend_buffer_type * ggml_backend_buffer_type_t;
+typedef struct ggml_backend_buffer      * ggml_backend_buffer_t;
+typedef struct ggml_backend             * ggml_backend_t;
+typedef struct ggml_backend_reg         * ggml_backend_reg_t;
+typedef struct ggml_backend_device      * ggml_backend_dev_t;
+
+enum ggml_backend_dev_type {
+    GGML_BACKEND_DEVICE_TYPE_CPU,    // src/moshi.cpp:98-110 asserts a CPU-type backend exists
+    GGML_BACKEND_DEVICE_TYPE_GPU,
+    GGML_BACKEND_DEVICE_TYPE_ACCEL,
+};
+
+struct ggml_backend_dev_caps {
+    bool async;
+    bool host_buffer;
+    bool buffer_from_host_ptr;
+    bool events;
+};
+
+// tools/common_ggml.h:15-19 reads props.memory_free
+struct ggml_backend_dev_props {
+    const char * name;
+    const char * description;
+    size_t memory_free;
+    size_t memory_total;
+    enum ggml_backend_dev_type type;
+    struct ggml_backend_dev_caps caps;
+};
+
+// ---- registry / devices (tools/common_ggml.h:21-79, tools/common_utils.h:9-19) ---------------------
+GGML_API void   ggml_backend_load_all(void);
+GGML_API size_t ggml_backend_reg_count(void);
+GGML_API ggml_backend_reg_t ggml_backend_reg_get(size_t index);
+GGML_API const char * ggml_backend_reg_name(ggml_backend_reg_t reg);
+GGML_API void * ggml_backend_reg_get_proc_address(ggml_backend_reg_t reg, const char * name);
+
+GGML_API size_t             ggml_backend_dev_count(void);
+GGML_API ggml_backend_dev_t ggml_backend_dev_get(size_t index);
+GGML_API ggml_backend_dev_t ggml_backend_dev_by_name(const char * name);
+GGML_API ggml_backend_dev_t ggml_backend_dev_by_type(enum ggml_backend_dev_type type);
+GGML_API const char *       ggml_backend_dev_name(ggml_backend_dev_t device);
+GGML_API const char *       ggml_backend_dev_description(ggml_backend_dev_t device);
+GGML_API enum ggml_backend_dev_type ggml_backend_dev_type(ggml_backend_dev_t device);
+GGML_API void               ggml_backend_dev_memory(ggml_backend_dev_t device, size_t * free, size_t * total);
+GGML_API void               ggml_backend_dev_get_props(ggml_backend_dev_t device, struct ggml_backend_dev_props * props);
+GGML_API ggml_backend_reg_t ggml_backend_dev_backend_reg(ggml_backend_dev_t device);
+GGML_API ggml_backend_t     ggml_backend_dev_init(ggml_backend_dev_t device, const char * params);
+
+// returns NULL when no such device exists; the tools print and exit(1) (tools/common_ggml.h:30-34)
+GGML_API ggml_backend_t ggml_backend_init_by_name(const char * name, const char * params);
+GGML_API ggml_backend_t ggml_backend_init_by_type(enum ggml_backend_dev_type type, const char * params);
+GGML_API ggml_backend_t ggml_backend_init_best(void);   // first GPU device, else CPU
+
+GGML_API const char *       ggml_backend_name(ggml_backend_t backend);
+GGML_API void               ggml_backend_free(ggml_backend_t backend);
+GGML_API ggml_backend_dev_t ggml_backend_get_device(ggml_backend_t backend);
+GGML_API void               ggml_backend_synchronize(ggml_backend_t backend);
+
+// proc-address "ggml_backend_set_n_threads" (tools/common_ggml.h:35-44)
+typedef void (*ggml_backend_set_n_threads_t)(ggml_backend_t backend, int n_threads);
+
+// ---- buffers -------------------------------------------------------------------------------------
+// the only allocator the reference uses (src/context.h:522); caller frees the returned buffer
+GGML_API ggml_backend_buffer_t ggml_backend_alloc_ctx_tensors(struct ggml_context * ctx, ggml_backend_t backend);
+GGML_API void    ggml_backend_buffer_free    (ggml_backend_buffer_t buffer);   // src/context.h:192
+GGML_API size_t  ggml_backend_buffer_get_size(ggml_backend_buffer_t buffer);
+GGML_API void *  ggml_backend_buffer_get_base(ggml_backend_buffer_t buffer);
+GGML_API const char * ggml_backend_buffer_name(ggml_backend_buffer_t buffer);
+GGML_API void    ggml_backend_buffer_clear   (ggml_backend_buffer_t buffer, uint8_t value);
+GGML_API bool    ggml_backend_buffer_is_host (ggml_backend_buffer_t buffer);
+
+// ---- data movement (src/context.h:308, 643) ------------------------------------------------------
+GGML_API void ggml_backend_tensor_set   (      struct ggml_tensor * tensor, const void * data, size_t offset, size_t size);
+GGML_API void ggml_backend_tensor_get   (const struct ggml_tensor * tensor,       void * data, size_t offset, size_t size);
+GGML_API void ggml_backend_tensor_memset(      struct ggml_tensor * tensor, uint8_t value,     size_t offset, size_t size);
+GGML_API void ggml_backend_tensor_copy  (struct ggml_tensor * src, struct ggml_tensor * dst);
+
+// ---- compute (src/context.h:542, 635) ------------------------------------------------------------
+GGML_API enum ggml_status ggml_backend_graph_compute(ggml_backend_t backend, struct ggml_cgraph * cgraph);
+GGML_API bool ggml_backend_supports_op(ggml_backend_t backend, const struct ggml_tensor * op);
+
+// ---- MI355X backend extras (not part of upstream ggml; optional for callers) ------------------------
+// counters for tests / bench: how the last graph was executed
+struct ggml_mi355x_stats {
+    int64_t graphs_computed;     // ggml_backend_graph_compute calls
+    int64_t graph_replays;       // of which were hipGraph replays of a cached plan
+    int64_t kernels_in_last_plan;
+    int64_t fused_nodes_in_last_plan;
+    int64_t nodes_in_last_plan;
+    int64_t uploads_batched;     // small tensor_set calls folded into one scatter launch
+};
+GGML_API void ggml_backend_mi355x_get_stats(ggml_backend_t backend, struct ggml_mi355x_stats * stats);
+// bit flags, default 0: 1 = disable fusion (one kernel per node), 2 = disable hipGraph capture, 4 = disable upload batching
+GGML_API void ggml_backend_mi355x_set_flags(ggml_backend_t backend, int flags);
+// HIP stream the backend launches on (void* = hipStream_t) so callers can bracket it with HIP events
+GGML_API void * ggml_backend_mi355x_get_stream(ggml_backend_t backend);
+
+#ifdef __cplusplus
+}
+#endif

@@ -1,0 +1,247 @@
+// ggml_backend.cpp — backend registry, the host ("CPU") device and the backend-generic entry points of
+// include/ggml-backend.h. The MI355X device lives in hip_backend.hip and registers itself here.
+#include "ggml_impl.h"
+#include "ggml-cpu.h"
+
+#include <stdlib.h>
+#include <string.h>
+#include <strings.h>
+#include <unistd.h>
+
+#include <string>
+#include <vector>
+
+// ---------------------------------------------------------------------------------------------------
+// registry
+// ---------------------------------------------------------------------------------------------------
+static std::vector<ggml_backend_reg_t> & regs() { static std::vector<ggml_backend_reg_t> v; return v; }
+static std::vector<ggml_backend_dev_t> & devs() { static std::vector<ggml_backend_dev_t> v; return v; }
+
+extern "C" void ggml_backend_register(ggml_backend_reg_t reg) {
+    if (!reg) return;
+    for (auto r : regs()) if (r == reg) return;
+    regs().push_back(reg);
+    for (size_t i = 0; i < reg->iface.get_device_count(reg); i++) devs().push_back(reg->iface.get_device(reg, i));
+}
+
+// GPU devices are listed first so that ggml_backend_dev_get(0) / init_best pick the accelerator
+extern "C" void ggml_backend_load_all(void) {
+    static bool loaded = false;
+    if (loaded) return;
+    loaded = true;
+    ggml_backend_register(ggml_backend_mi355x_reg());
+    ggml_backend_register(ggml_backend_cpu_reg());
+}
+
+extern "C" size_t ggml_backend_reg_count(void) { ggml_backend_load_all(); return regs().size(); }
+extern "C" ggml_backend_reg_t ggml_backend_reg_get(size_t i) { ggml_backend_load_all(); GGML_ASSERT(i < regs().size()); return regs()[i]; }
+extern "C" const char * ggml_backend_reg_name(ggml_backend_reg_t reg) { return reg->iface.get_name(reg); }
+extern "C" void * ggml_backend_reg_get_proc_address(ggml_backend_reg_t reg, const char * name) {
+    if (!reg || !reg->iface.get_proc_address) return NULL;
+    return reg->iface.get_proc_address(reg, name);
+}
+
+extern "C" size_t ggml_backend_dev_count(void) { ggml_backend_load_all(); return devs().size(); }
+extern "C" ggml_backend_dev_t ggml_backend_dev_get(size_t i) { ggml_backend_load_all(); GGML_ASSERT(i < devs().size()); return devs()[i]; }
+extern "C" ggml_backend_dev_t ggml_backend_dev_by_name(const char * name) {
+    ggml_backend_load_all();
+    for (auto d : devs()) if (strcasecmp(d->iface.get_name(d), name) == 0) return d;
+    return NULL;
+}
+extern "C" ggml_backend_dev_t ggml_backend_dev_by_type(enum ggml_backend_dev_type type) {
+    ggml_backend_load_all();
+    for (auto d : devs()) if (d->iface.get_type(d) == type) return d;
+    return NULL;
+}
+extern "C" const char * ggml_backend_dev_name(ggml_backend_dev_t d) { return d->iface.get_name(d); }
+extern "C" const char * ggml_backend_dev_description(ggml_backend_dev_t d) { return d->iface.get_description(d); }
+extern "C" enum ggml_backend_dev_type ggml_backend_dev_type(ggml_backend_dev_t d) { return d->iface.get_type(d); }
+extern "C" void ggml_backend_dev_memory(ggml_backend_dev_t d, size_t * free, size_t * total) { d->iface.get_memory(d, free, total); }
+extern "C" void ggml_backend_dev_get_props(ggml_backend_dev_t d, struct ggml_backend_dev_props * props) {
+    memset(props, 0, sizeof(*props));
+    props->name = d->iface.get_name(d);
+    props->description = d->iface.get_description(d);
+    props->type = d->iface.get_type(d);
+    d->iface.get_memory(d, &props->memory_free, &props->memory_total);
+    props->caps.host_buffer = props->type == GGML_BACKEND_DEVICE_TYPE_CPU;
+}
+extern "C" ggml_backend_reg_t ggml_backend_dev_backend_reg(ggml_backend_dev_t d) { return d->reg; }
+extern "C" ggml_backend_t ggml_backend_dev_init(ggml_backend_dev_t d, const char * params) { return d->iface.init_backend(d, params); }
+
+extern "C" ggml_backend_t ggml_backend_init_by_name(const char * name, const char * params) {
+    ggml_backend_dev_t d = ggml_backend_dev_by_name(name);
+    return d ? ggml_backend_dev_init(d, params) : NULL;
+}
+extern "C" ggml_backend_t ggml_backend_init_by_type(enum ggml_backend_dev_type type, const char * params) {
+    ggml_backend_dev_t d = ggml_backend_dev_by_type(type);
+    return d ? ggml_backend_dev_init(d, params) : NULL;
+}
+extern "C" ggml_backend_t ggml_backend_init_best(void) {
+    ggml_backend_dev_t d = ggml_backend_dev_by_type(GGML_BACKEND_DEVICE_TYPE_GPU);
+    if (!d) d = ggml_backend_dev_by_type(GGML_BACKEND_DEVICE_TYPE_CPU);
+    return d ? ggml_backend_dev_init(d, NULL) : NULL;
+}
+
+extern "C" const char * ggml_backend_name(ggml_backend_t b) { return b->iface.get_name(b); }
+extern "C" void ggml_backend_free(ggml_backend_t b) { if (b) b->iface.free(b); }
+extern "C" ggml_backend_dev_t ggml_backend_get_device(ggml_backend_t b) { return b->device; }
+extern "C" void ggml_backend_synchronize(ggml_backend_t b) { if (b->iface.synchronize) b->iface.synchronize(b); }
+extern "C" bool ggml_backend_supports_op(ggml_backend_t b, const struct ggml_tensor * op) {
+    return b->iface.supports_op ? b->iface.supports_op(b, op) : false;
+}
+extern "C" enum ggml_status ggml_backend_graph_compute(ggml_backend_t b, struct ggml_cgraph * g) {
+    return b->iface.graph_compute(b, g);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// buffers and data movement
+// ---------------------------------------------------------------------------------------------------
+extern "C" ggml_backend_buffer_t ggml_backend_alloc_ctx_tensors(struct ggml_context * ctx, ggml_backend_t backend) {
+    GGML_ASSERT(ggml_get_no_alloc(ctx));
+    // pass 1: size of everything that needs storage (each tensor aligned on its own)
+    size_t total = 0;
+    for (struct ggml_tensor * t = ggml_get_first_tensor(ctx); t; t = ggml_get_next_tensor(ctx, t)) {
+        if (t->data == NULL && t->view_src == NULL) total += GGML_PAD(ggml_nbytes(t), GGML_TENSOR_ALIGN);
+    }
+    ggml_backend_buffer_t buffer = backend->iface.alloc_buffer(backend, total);
+    if (!buffer) return NULL;
+    // pass 2: hand out addresses in context order; views resolve against their (already placed) root
+    size_t offs = 0;
+    for (struct ggml_tensor * t = ggml_get_first_tensor(ctx); t; t = ggml_get_next_tensor(ctx, t)) {
+        if (t->data != NULL) continue;
+        if (t->view_src == NULL) {
+            t->buffer = buffer;
+            t->data = (char *) buffer->base + offs;
+            offs += GGML_PAD(ggml_nbytes(t), GGML_TENSOR_ALIGN);
+        } else if (t->buffer == NULL) {
+            GGML_ASSERT(t->view_src->data != NULL && "view of a tensor that has no storage yet");
+            t->buffer = t->view_src->buffer;
+            t->data = (char *) t->view_src->data + t->view_offs;
+        }
+    }
+    return buffer;
+}
+
+extern "C" void ggml_backend_buffer_free(ggml_backend_buffer_t buffer) { if (buffer) buffer->iface.free_buffer(buffer); }
+extern "C" size_t ggml_backend_buffer_get_size(ggml_backend_buffer_t buffer) { return buffer->size; }
+extern "C" void * ggml_backend_buffer_get_base(ggml_backend_buffer_t buffer) { return buffer->base; }
+extern "C" const char * ggml_backend_buffer_name(ggml_backend_buffer_t buffer) { return buffer->device->iface.get_name(buffer->device); }
+extern "C" void ggml_backend_buffer_clear(ggml_backend_buffer_t buffer, uint8_t value) { if (buffer->size) buffer->iface.clear(buffer, value); }
+extern "C" bool ggml_backend_buffer_is_host(ggml_backend_buffer_t buffer) { return buffer->is_host; }
+
+static ggml_backend_buffer_t tensor_buffer(const struct ggml_tensor * t) {
+    return t->view_src ? t->view_src->buffer : t->buffer;
+}
+
+extern "C" void ggml_backend_tensor_set(struct ggml_tensor * tensor, const void * data, size_t offset, size_t size) {
+    if (size == 0) return;
+    ggml_backend_buffer_t buf = tensor_buffer(tensor);
+    GGML_ASSERT(buf != NULL && "tensor buffer not set");
+    GGML_ASSERT(tensor->data != NULL && "tensor not allocated");
+    GGML_ASSERT(offset + size <= ggml_nbytes(tensor) && "tensor write out of bounds");
+    buf->iface.set_tensor(buf, tensor, data, offset, size);
+}
+extern "C" void ggml_backend_tensor_get(const struct ggml_tensor * tensor, void * data, size_t offset, size_t size) {
+    if (size == 0) return;
+    ggml_backend_buffer_t buf = tensor_buffer(tensor);
+    GGML_ASSERT(buf != NULL && "tensor buffer not set");
+    GGML_ASSERT(tensor->data != NULL && "tensor not allocated");
+    GGML_ASSERT(offset + size <= ggml_nbytes(tensor) && "tensor read out of bounds");
+    buf->iface.get_tensor(buf, tensor, data, offset, size);
+}
+extern "C" void ggml_backend_tensor_memset(struct ggml_tensor * tensor, uint8_t value, size_t offset, size_t size) {
+    if (size == 0) return;
+    ggml_backend_buffer_t buf = tensor_buffer(tensor);
+    GGML_ASSERT(buf != NULL && tensor->data != NULL);
+    GGML_ASSERT(offset + size <= ggml_nbytes(tensor));
+    buf->iface.memset_tensor(buf, tensor, value, offset, size);
+}
+// staged through the host, like the reference's own device<->device path (src/context.h:645-650)
+extern "C" void ggml_backend_tensor_copy(struct ggml_tensor * src, struct ggml_tensor * dst) {
+    const size_t n = ggml_nbytes(src);
+    GGML_ASSERT(n == ggml_nbytes(dst));
+    std::vector<uint8_t> tmp(n);
+    ggml_backend_tensor_get(src, tmp.data(), 0, n);
+    ggml_backend_tensor_set(dst, tmp.data(), 0, n);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// host ("CPU") device: buffers in host memory; graph execution only through an attached executor
+// ---------------------------------------------------------------------------------------------------
+static ggml_backend_cpu_graph_compute_t g_cpu_compute = NULL;
+struct cpu_backend_ctx { int n_threads; };
+
+extern "C" void ggml_backend_cpu_set_graph_compute(ggml_backend_cpu_graph_compute_t fn) { g_cpu_compute = fn; }
+
+static void cpu_buf_free(ggml_backend_buffer_t b) { free(b->base); delete b; }
+static void cpu_buf_memset(ggml_backend_buffer_t, struct ggml_tensor * t, uint8_t v, size_t off, size_t n) { memset((char *) t->data + off, v, n); }
+static void cpu_buf_set(ggml_backend_buffer_t, struct ggml_tensor * t, const void * d, size_t off, size_t n) { memcpy((char *) t->data + off, d, n); }
+static void cpu_buf_get(ggml_backend_buffer_t, const struct ggml_tensor * t, void * d, size_t off, size_t n) { memcpy(d, (const char *) t->data + off, n); }
+static void cpu_buf_clear(ggml_backend_buffer_t b, uint8_t v) { memset(b->base, v, b->size); }
+
+static ggml_backend_dev_t cpu_device();
+
+static ggml_backend_buffer_t cpu_alloc_buffer(ggml_backend_t, size_t size) {
+    void * p = NULL;
+    if (posix_memalign(&p, GGML_TENSOR_ALIGN, size ? size : GGML_TENSOR_ALIGN) != 0) return NULL;
+    auto * b = new ggml_backend_buffer;
+    b->iface = { cpu_buf_free, cpu_buf_memset, cpu_buf_set, cpu_buf_get, cpu_buf_clear };
+    b->device = cpu_device();
+    b->base = p;
+    b->size = size;
+    b->context = NULL;
+    b->is_host = true;
+    return b;
+}
+
+static const char * cpu_backend_name(ggml_backend_t) { return "CPU"; }
+static void cpu_backend_free(ggml_backend_t b) { delete (cpu_backend_ctx *) b->context; delete b; }
+static enum ggml_status cpu_graph_compute(ggml_backend_t b, struct ggml_cgraph * g) {
+    if (!g_cpu_compute) {
+        fprintf(stderr, "ggml (mi355x build): the CPU device has no graph executor; the decode hot path runs on the "
+                        "MI355X device only. Attach one with ggml_backend_cpu_set_graph_compute() (tests use oracle/).\n");
+        return GGML_STATUS_FAILED;
+    }
+    return g_cpu_compute(g, ((cpu_backend_ctx *) b->context)->n_threads);
+}
+static bool cpu_supports_op(ggml_backend_t, const struct ggml_tensor *) { return g_cpu_compute != NULL; }
+
+static const char * cpu_dev_name(ggml_backend_dev_t) { return "CPU"; }
+static const char * cpu_dev_desc(ggml_backend_dev_t) { return "host memory device"; }
+static void cpu_dev_memory(ggml_backend_dev_t, size_t * free, size_t * total) {
+    const long pages = sysconf(_SC_PHYS_PAGES), avail = sysconf(_SC_AVPHYS_PAGES), psz = sysconf(_SC_PAGE_SIZE);
+    *total = (size_t) pages * (size_t) psz;
+    *free  = (size_t) avail * (size_t) psz;
+}
+static enum ggml_backend_dev_type cpu_dev_type(ggml_backend_dev_t) { return GGML_BACKEND_DEVICE_TYPE_CPU; }
+static ggml_backend_t cpu_dev_init(ggml_backend_dev_t dev, const char *) {
+    auto * b = new ggml_backend;
+    b->iface = { cpu_backend_name, cpu_backend_free, NULL, cpu_alloc_buffer, cpu_graph_compute, cpu_supports_op };
+    b->device = dev;
+    b->context = new cpu_backend_ctx{ 4 };
+    return b;
+}
+
+extern "C" void ggml_backend_cpu_set_n_threads(ggml_backend_t b, int n_threads) {
+    if (b && ggml_backend_is_cpu(b)) ((cpu_backend_ctx *) b->context)->n_threads = n_threads;
+}
+extern "C" bool ggml_backend_is_cpu(ggml_backend_t b) { return b && b->iface.get_name == cpu_backend_name; }
+
+static const char * cpu_reg_name(ggml_backend_reg_t) { return "CPU"; }
+static size_t cpu_reg_dev_count(ggml_backend_reg_t) { return 1; }
+static ggml_backend_dev_t cpu_reg_get_dev(ggml_backend_reg_t, size_t) { return cpu_device(); }
+static void * cpu_reg_proc(ggml_backend_reg_t, const char * name) {
+    if (strcmp(name, "ggml_backend_set_n_threads") == 0) return (void *) ggml_backend_cpu_set_n_threads;
+    if (strcmp(name, "ggml_backend_cpu_set_graph_compute") == 0) return (void *) ggml_backend_cpu_set_graph_compute;
+    return NULL;
+}
+
+extern "C" ggml_backend_reg_t ggml_backend_cpu_reg(void) {
+    static ggml_backend_reg reg = { { cpu_reg_name, cpu_reg_dev_count, cpu_reg_get_dev, cpu_reg_proc }, NULL };
+    return &reg;
+}
+static ggml_backend_dev_t cpu_device() {
+    static ggml_backend_device dev = { { cpu_dev_name, cpu_dev_desc, cpu_dev_memory, cpu_dev_type, cpu_dev_init }, ggml_backend_cpu_reg(), NULL };
+    return &dev;
+}
+extern "C" ggml_backend_t ggml_backend_cpu_init(void) { return cpu_dev_init(cpu_device(), NULL); }

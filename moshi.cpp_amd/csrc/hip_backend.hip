@@ -1,0 +1,855 @@
+// hip_backend.hip — the MI355X ("ROCm<N>") ggml backend: device registry, pooled device buffers,
+// batched small uploads, and the graph planner / executor.
+//
+// Execution model (SURVEY.md §7 "hard parts": ~4.5 k ggml nodes per frame vs. a sub-millisecond roofline
+// budget, so per-node dispatch is impossible):
+//   * ggml_backend_graph_compute() turns a cgraph into a *plan*: an ordered list of kernel launches in
+//     which the hot node sequences (norm -> mat-vec, gated FFN, residual add, the whole single-token
+//     attention block, the 17-stream embedding sum) are matched and replaced by the fused kernels of
+//     hip_kernels_fused.hip; everything else falls back to one generic kernel per node.
+//   * plans of cached graphs (Temporal / Depth / Mimi graphs are built once by the caller and replayed
+//     every frame, src/context.h:538-544) are captured into a hipGraph and replayed with one
+//     hipGraphLaunch; throw-away scratch graphs (src/context.h:628-653) are launched directly.
+//   * the ~40 scalar tensor_set calls per frame (lm_utils.h:172-182) are queued in pinned host memory
+//     and scattered by one kernel at the next compute / read-back.
+// ggml semantics preserved: every non-view tensor has its own storage, execution order = node order,
+// results are visible to tensor_get when graph_compute returns (stream-ordered, tensor_get synchronises).
+#include "hip_common.h"
+#include "ggml-cpu.h"
+
+#include <string.h>
+
+#include <functional>
+#include <map>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+// ---------------------------------------------------------------------------------------------------
+// per-device context
+// ---------------------------------------------------------------------------------------------------
+#define UPLOAD_SLOTS       8
+#define UPLOAD_BLOB_BYTES  (64 * 1024)
+#define UPLOAD_MAX_DESCS   1024
+#define UPLOAD_SMALL_MAX   4096
+
+struct plan_t;
+
+struct upload_slot {
+    char * blob = nullptr;            // pinned, device-mapped
+    upload_desc * descs = nullptr;    // pinned, device-mapped
+    hipEvent_t done = nullptr;
+    bool in_flight = false;
+};
+
+struct hip_ctx {
+    int device = 0;
+    std::string name, description;
+    hipStream_t stream = nullptr;
+    int flags = 0;
+    ggml_mi355x_stats stats = {};
+    // pooled allocations: size class -> free pointers
+    std::map<size_t, std::vector<void *>> pool;
+    // batched uploads
+    upload_slot slots[UPLOAD_SLOTS];
+    int cur_slot = 0;
+    int n_pending = 0;
+    size_t pending_bytes = 0;
+    // cached plans keyed by cgraph pointer
+    std::unordered_map<const ggml_cgraph *, plan_t *> plans;
+    ggml_backend_device dev_obj;
+};
+
+static std::vector<hip_ctx *> & contexts() { static std::vector<hip_ctx *> v; return v; }
+
+static void set_device(hip_ctx * c) { HIP_CHECK(hipSetDevice(c->device)); }
+
+static void ctx_init_lazy(hip_ctx * c) {
+    if (c->stream) return;
+    set_device(c);
+    HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    for (auto & s : c->slots) {
+        HIP_CHECK(hipHostMalloc((void **) &s.blob, UPLOAD_BLOB_BYTES, hipHostMallocMapped));
+        HIP_CHECK(hipHostMalloc((void **) &s.descs, UPLOAD_MAX_DESCS * sizeof(upload_desc), hipHostMallocMapped));
+        HIP_CHECK(hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
+    }
+}
+
+// ---- pool -----------------------------------------------------------------------------------------
+static size_t size_class(size_t n) {
+    if (n > ((size_t) 64 << 20)) return 0;   // large: not pooled
+    size_t c = 256;
+    while (c < n) c <<= 1;
+    return c;
+}
+static void * pool_alloc(hip_ctx * c, size_t n, size_t * actual) {
+    set_device(c);
+    const size_t cls = size_class(n ? n : 1);
+    if (cls) {
+        auto & fl = c->pool[cls];
+        *actual = cls;
+        if (!fl.empty()) { void * p = fl.back(); fl.pop_back(); return p; }
+    } else *actual = n;
+    void * p = nullptr;
+    hipError_t e = hipMalloc(&p, *actual);
+    if (e != hipSuccess) { fprintf(stderr, "mi355x: hipMalloc(%zu) failed: %s\n", *actual, hipGetErrorString(e)); return nullptr; }
+    return p;
+}
+static void pool_free(hip_ctx * c, void * p, size_t actual) {
+    if (!p) return;
+    const size_t cls = size_class(actual);
+    if (cls && cls == actual) { c->pool[cls].push_back(p); return; }
+    set_device(c);
+    HIP_CHECK(hipStreamSynchronize(c->stream));
+    HIP_CHECK(hipFree(p));
+}
+
+// ---- batched uploads -------------------------------------------------------------------------------
+static void flush_uploads(hip_ctx * c) {
+    if (c->n_pending == 0) return;
+    upload_slot & s = c->slots[c->cur_slot];
+    k_scatter_uploads(c->stream, s.descs, s.blob, c->n_pending);
+    HIP_CHECK(hipEventRecord(s.done, c->stream));
+    s.in_flight = true;
+    c->stats.uploads_batched += c->n_pending;
+    c->n_pending = 0;
+    c->pending_bytes = 0;
+    c->cur_slot = (c->cur_slot + 1) % UPLOAD_SLOTS;
+    upload_slot & n = c->slots[c->cur_slot];
+    if (n.in_flight) { HIP_CHECK(hipEventSynchronize(n.done)); n.in_flight = false; }
+}
+
+static void queue_upload(hip_ctx * c, void * dst, const void * src, size_t size) {
+    const size_t padded = GGML_PAD(size, 16);
+    if (c->n_pending >= UPLOAD_MAX_DESCS || c->pending_bytes + padded > UPLOAD_BLOB_BYTES) flush_uploads(c);
+    upload_slot & s = c->slots[c->cur_slot];
+    memcpy(s.blob + c->pending_bytes, src, size);
+    s.descs[c->n_pending] = { (char *) dst, (uint32_t) c->pending_bytes, (uint32_t) size };
+    c->n_pending++;
+    c->pending_bytes += padded;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// buffers
+// ---------------------------------------------------------------------------------------------------
+struct hip_buffer_ctx { hip_ctx * c; size_t actual; };
+
+static void hip_buf_free(ggml_backend_buffer_t b) {
+    hip_buffer_ctx * bc = (hip_buffer_ctx *) b->context;
+    flush_uploads(bc->c);
+    pool_free(bc->c, b->base, bc->actual);
+    delete bc;
+    delete b;
+}
+static void hip_buf_set(ggml_backend_buffer_t b, struct ggml_tensor * t, const void * data, size_t offset, size_t size) {
+    hip_ctx * c = ((hip_buffer_ctx *) b->context)->c;
+    set_device(c);
+    if (size <= UPLOAD_SMALL_MAX && !(c->flags & 4)) { queue_upload(c, (char *) t->data + offset, data, size); return; }
+    flush_uploads(c);
+    HIP_CHECK(hipMemcpyAsync((char *) t->data + offset, data, size, hipMemcpyHostToDevice, c->stream));
+    HIP_CHECK(hipStreamSynchronize(c->stream));
+}
+static void hip_buf_get(ggml_backend_buffer_t b, const struct ggml_tensor * t, void * data, size_t offset, size_t size) {
+    hip_ctx * c = ((hip_buffer_ctx *) b->context)->c;
+    set_device(c);
+    flush_uploads(c);
+    HIP_CHECK(hipMemcpyAsync(data, (const char *) t->data + offset, size, hipMemcpyDeviceToHost, c->stream));
+    HIP_CHECK(hipStreamSynchronize(c->stream));
+}
+static void hip_buf_memset(ggml_backend_buffer_t b, struct ggml_tensor * t, uint8_t v, size_t offset, size_t size) {
+    hip_ctx * c = ((hip_buffer_ctx *) b->context)->c;
+    set_device(c);
+    flush_uploads(c);
+    HIP_CHECK(hipMemsetAsync((char *) t->data + offset, v, size, c->stream));
+}
+static void hip_buf_clear(ggml_backend_buffer_t b, uint8_t v) {
+    hip_ctx * c = ((hip_buffer_ctx *) b->context)->c;
+    set_device(c);
+    flush_uploads(c);
+    HIP_CHECK(hipMemsetAsync(b->base, v, b->size, c->stream));
+}
+
+static ggml_backend_buffer_t hip_alloc_buffer(ggml_backend_t backend, size_t size) {
+    hip_ctx * c = (hip_ctx *) backend->context;
+    ctx_init_lazy(c);
+    size_t actual = 0;
+    void * p = pool_alloc(c, size, &actual);
+    if (!p) return NULL;
+    auto * b = new ggml_backend_buffer;
+    b->iface = { hip_buf_free, hip_buf_memset, hip_buf_set, hip_buf_get, hip_buf_clear };
+    b->device = &c->dev_obj;
+    b->base = p;
+    b->size = size;
+    b->context = new hip_buffer_ctx{ c, actual };
+    b->is_host = false;
+    return b;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// plans
+// ---------------------------------------------------------------------------------------------------
+typedef std::function<void(hipStream_t)> step_fn;
+
+struct plan_t {
+    std::vector<step_fn> steps;
+    std::vector<std::pair<void *, size_t>> workspaces;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    uint64_t hash = 0;
+    int n_nodes = 0, n_fused = 0;
+};
+
+static void plan_free(hip_ctx * c, plan_t * p) {
+    if (p->exec) (void) hipGraphExecDestroy(p->exec);
+    if (p->graph) (void) hipGraphDestroy(p->graph);
+    for (auto & w : p->workspaces) pool_free(c, w.first, w.second);
+    delete p;
+}
+
+static uint64_t graph_hash(const ggml_cgraph * g) {
+    uint64_t h = 0xcbf29ce484222325ull ^ (uint64_t) g->n_nodes;
+    for (int i = 0; i < g->n_nodes; i++) {
+        const ggml_tensor * n = g->nodes[i];
+        h = (h ^ (uint64_t) (uintptr_t) n) * 0x100000001b3ull;
+        h = (h ^ (uint64_t) (uintptr_t) n->data) * 0x100000001b3ull;
+        h = (h ^ (uint64_t) n->op) * 0x100000001b3ull;
+        h = (h ^ (uint64_t) (uint32_t) n->op_params[0] ^ ((uint64_t) (uint32_t) n->op_params[1] << 32)) * 0x100000001b3ull;
+        h = (h ^ (uint64_t) n->ne[0] ^ ((uint64_t) n->ne[1] << 24) ^ ((uint64_t) n->nb[1] << 40)) * 0x100000001b3ull;
+        for (int s = 0; s < 3; s++) if (n->src[s]) h = (h ^ (uint64_t) (uintptr_t) n->src[s]->data) * 0x100000001b3ull;
+    }
+    return h;
+}
+
+// ---- graph analysis helpers --------------------------------------------------------------------------
+struct analysis {
+    const ggml_cgraph * g;
+    std::unordered_map<const ggml_tensor *, int> index;          // node -> position
+    std::unordered_map<const ggml_tensor *, int> uses;           // tensor -> number of consuming nodes
+    std::unordered_map<const ggml_tensor *, int> last_consumer;  // tensor -> position of its (last) consumer
+    std::vector<char> skip;
+};
+
+static void analyse(analysis & an, const ggml_cgraph * g) {
+    an.g = g;
+    an.skip.assign((size_t) g->n_nodes, 0);
+    for (int i = 0; i < g->n_nodes; i++) {
+        const ggml_tensor * n = g->nodes[i];
+        an.index[n] = i;
+        for (int s = 0; s < GGML_MAX_SRC; s++) {
+            const ggml_tensor * src = n->src[s];
+            if (!src || src == n) continue;
+            bool dup = false;
+            for (int s2 = 0; s2 < s; s2++) if (n->src[s2] == src) dup = true;
+            if (dup) continue;
+            an.uses[src]++;
+            an.last_consumer[src] = i;
+        }
+    }
+}
+static int uses_of(const analysis & an, const ggml_tensor * t) { auto it = an.uses.find(t); return it == an.uses.end() ? 0 : it->second; }
+static int pos_of(const analysis & an, const ggml_tensor * t) { auto it = an.index.find(t); return it == an.index.end() ? -1 : it->second; }
+static const ggml_tensor * sole_consumer(const analysis & an, const ggml_tensor * t) {
+    if (uses_of(an, t) != 1) return nullptr;
+    return an.g->nodes[an.last_consumer.at(t)];
+}
+
+static bool is_view_op(enum ggml_op op) { return op == GGML_OP_VIEW || op == GGML_OP_RESHAPE || op == GGML_OP_PERMUTE || op == GGML_OP_TRANSPOSE || op == GGML_OP_NONE; }
+static bool is_f32_vec(const ggml_tensor * t, int64_t n) {
+    return t->type == GGML_TYPE_F32 && ggml_nelements(t) == n && ggml_is_contiguous(t);
+}
+static bool dense_rows(const ggml_tensor * w) {
+    return w->nb[0] == ggml_type_size(w->type) && w->nb[1] == ggml_row_size(w->type, w->ne[0]) && w->ne[2] == 1 && w->ne[3] == 1;
+}
+
+// pointer from which nelements(t) values can be read in t's logical order, looking through layout-only
+// nodes and plain dense copies (cont of an already contiguous tensor); NULL when t is not contiguous
+static const char * resolve_dense(const ggml_tensor * t) {
+    if (!t->data || !ggml_is_contiguous(t)) return nullptr;
+    const ggml_tensor * cur = t;
+    int64_t delta = 0;
+    while (cur->op == GGML_OP_VIEW || cur->op == GGML_OP_RESHAPE || cur->op == GGML_OP_PERMUTE || cur->op == GGML_OP_TRANSPOSE) {
+        const ggml_tensor * s = cur->src[0];
+        if (!s->data) return nullptr;
+        delta += (const char *) cur->data - (const char *) s->data;
+        cur = s;
+    }
+    // cur owns the storage; t's contents are the contiguous byte range cur->data + delta
+    if ((cur->op == GGML_OP_CONT || cur->op == GGML_OP_DUP) && cur->src[0]->type == cur->type && ggml_is_contiguous(cur) &&
+        ggml_is_contiguous(cur->src[0]) && ggml_nelements(cur->src[0]) == ggml_nelements(cur)) {
+        const char * base = resolve_dense(cur->src[0]);   // same bytes, one copy earlier
+        if (base) return base + delta;
+    }
+    return (const char *) cur->data + delta;
+}
+
+// ---- emission ------------------------------------------------------------------------------------------
+struct emitter {
+    hip_ctx * c;
+    plan_t * p;
+    void * ws(size_t n) {
+        size_t actual = 0;
+        void * w = pool_alloc(c, n, &actual);
+        GGML_ASSERT(w);
+        p->workspaces.push_back({ w, actual });
+        return w;
+    }
+    void push(step_fn f) { p->steps.push_back(std::move(f)); }
+};
+
+static bool fill_matvec_base(mv_args & a, const ggml_tensor * mm) {
+    const ggml_tensor * w = mm->src[0], * b = mm->src[1];
+    if (!dense_rows(w) || !k_matvec_supported(w->type, w->ne[0], w->ne[1])) return false;
+    if (b->type != GGML_TYPE_F32 || b->ne[1] != 1 || b->ne[2] != 1 || b->ne[3] != 1) return false;
+    memset(&a, 0, sizeof(a));
+    a.wtype = w->type;
+    a.w = (const char *) w->data;
+    a.row_bytes = (int64_t) w->nb[1];
+    a.K = w->ne[0];
+    a.M = w->ne[1];
+    a.prologue = MV_PLAIN;
+    a.y = (float *) mm->data;
+    return true;
+}
+
+static void emit_generic(emitter & em, ggml_tensor * n) {
+    const tdesc d = make_tdesc(n);
+    switch (n->op) {
+        case GGML_OP_NONE: case GGML_OP_VIEW: case GGML_OP_RESHAPE: case GGML_OP_PERMUTE: case GGML_OP_TRANSPOSE: return;
+        case GGML_OP_ADD: case GGML_OP_SUB: case GGML_OP_MUL: case GGML_OP_DIV: {
+            const tdesc a = make_tdesc(n->src[0]), b = make_tdesc(n->src[1]); const int op = n->op;
+            em.push([=](hipStream_t s) { k_binary(s, op, d, a, b); });
+        } return;
+        case GGML_OP_UNARY: {
+            const tdesc a = make_tdesc(n->src[0]); const int uop = n->op_params[0];
+            em.push([=](hipStream_t s) { k_unary(s, uop, d, a); });
+        } return;
+        case GGML_OP_SCALE: {
+            const tdesc a = make_tdesc(n->src[0]); const float sc = ggml_get_op_params_f32(n, 0), bi = ggml_get_op_params_f32(n, 1);
+            em.push([=](hipStream_t s) { k_scale(s, d, a, sc, bi); });
+        } return;
+        case GGML_OP_CLAMP: {
+            const tdesc a = make_tdesc(n->src[0]); const float mn = ggml_get_op_params_f32(n, 0), mx = ggml_get_op_params_f32(n, 1);
+            em.push([=](hipStream_t s) { k_clamp(s, d, a, mn, mx); });
+        } return;
+        case GGML_OP_SUM: { const tdesc a = make_tdesc(n->src[0]); em.push([=](hipStream_t s) { k_sum_all(s, d, a); }); } return;
+        case GGML_OP_SUM_ROWS: { const tdesc a = make_tdesc(n->src[0]); em.push([=](hipStream_t s) { k_sum_rows(s, d, a); }); } return;
+        case GGML_OP_ARGMAX: { const tdesc a = make_tdesc(n->src[0]); em.push([=](hipStream_t s) { k_argmax(s, d, a); }); } return;
+        case GGML_OP_ARGSORT: case GGML_OP_TOP_K: {
+            const tdesc a = make_tdesc(n->src[0]); const int desc = n->op_params[0] == GGML_SORT_ORDER_DESC;
+            em.push([=](hipStream_t s) { k_argsort(s, d, a, desc); });
+        } return;
+        case GGML_OP_ARANGE: {
+            const float st = ggml_get_op_params_f32(n, 0), step = ggml_get_op_params_f32(n, 2);
+            em.push([=](hipStream_t s) { k_arange(s, d, st, step); });
+        } return;
+        case GGML_OP_REPEAT: { const tdesc a = make_tdesc(n->src[0]); em.push([=](hipStream_t s) { k_repeat(s, d, a); }); } return;
+        case GGML_OP_PAD: { const tdesc a = make_tdesc(n->src[0]); em.push([=](hipStream_t s) { k_pad(s, d, a); }); } return;
+        case GGML_OP_CONCAT: {
+            const tdesc a = make_tdesc(n->src[0]), b = make_tdesc(n->src[1]); const int dim = n->op_params[0];
+            em.push([=](hipStream_t s) { k_concat(s, d, a, b, dim); });
+        } return;
+        case GGML_OP_NORM: case GGML_OP_RMS_NORM: {
+            const tdesc a = make_tdesc(n->src[0]); const float eps = ggml_get_op_params_f32(n, 0); const int rms = n->op == GGML_OP_RMS_NORM;
+            em.push([=](hipStream_t s) { k_norm(s, d, a, eps, rms); });
+        } return;
+        case GGML_OP_SOFT_MAX: {
+            const tdesc a = make_tdesc(n->src[0]); const int has_mask = n->src[1] != NULL;
+            const tdesc m = has_mask ? make_tdesc(n->src[1]) : a; const float sc = ggml_get_op_params_f32(n, 0);
+            GGML_ASSERT(ggml_get_op_params_f32(n, 1) == 0.0f && "ALiBi (max_bias) is not used by moshi.cpp");
+            em.push([=](hipStream_t s) { k_soft_max(s, d, a, m, has_mask, sc); });
+        } return;
+        case GGML_OP_CPY: case GGML_OP_CONT: case GGML_OP_DUP: {
+            const tdesc a = make_tdesc(n->src[0]);
+            em.push([=](hipStream_t s) { k_cpy(s, d, a); });
+        } return;
+        case GGML_OP_GET_ROWS: {
+            const tdesc a = make_tdesc(n->src[0]), idx = make_tdesc(n->src[1]);
+            em.push([=](hipStream_t s) { k_get_rows(s, d, a, idx); });
+        } return;
+        case GGML_OP_SET_ROWS: {
+            const tdesc src = make_tdesc(n->src[0]), idx = make_tdesc(n->src[1]);
+            em.push([=](hipStream_t s) { k_set_rows(s, d, src, idx); });
+        } return;
+        case GGML_OP_IM2COL: {
+            const tdesc x = make_tdesc(n->src[1]); const int64_t K = n->src[0]->ne[0];
+            const int s0 = n->op_params[0], p0 = n->op_params[2], d0 = n->op_params[4];
+            em.push([=](hipStream_t s) { k_im2col(s, d, x, K, s0, p0, d0); });
+        } return;
+        case GGML_OP_CONV_TRANSPOSE_1D: {
+            const tdesc w = make_tdesc(n->src[0]), x = make_tdesc(n->src[1]); const int s0 = n->op_params[0];
+            em.push([=](hipStream_t s) { k_conv_transpose_1d(s, d, w, x, s0); });
+        } return;
+        case GGML_OP_TIMESTEP_EMBEDDING: {
+            const tdesc ts = make_tdesc(n->src[0]); const int dim = n->op_params[0], mp = n->op_params[1];
+            em.push([=](hipStream_t s) { k_timestep_embedding(s, d, ts, dim, mp); });
+        } return;
+        case GGML_OP_MUL_MAT: {
+            mv_args mv;
+            if (!(em.c->flags & 1) && fill_matvec_base(mv, n) && ggml_is_contiguous(n->src[1])) {
+                mv.x = (const float *) n->src[1]->data;
+                em.push([=](hipStream_t s) { k_matvec(s, mv); });
+                return;
+            }
+            const tdesc a = make_tdesc(n->src[0]), b = make_tdesc(n->src[1]);
+            void * w = em.ws(k_mul_mat_ws_size(n->src[0], n->src[1]));
+            em.push([=](hipStream_t s) { k_mul_mat(s, d, a, b, w); });
+        } return;
+        default:
+            GGML_ABORT("mi355x backend: unsupported op %s (node %s)", ggml_op_name(n->op), n->name);
+    }
+}
+
+// ---- fusion matchers --------------------------------------------------------------------------------------
+
+// A. mat-vec with fused activation prologue and residual epilogue. Returns the position at which the
+//    fused kernel must be emitted (the last node of the group), or -1.
+struct mv_group { mv_args a; int emit_pos; std::vector<int> members; };
+
+static bool writes_through_alias(const ggml_tensor * n) {
+    return n->view_src != NULL && !is_view_op(n->op);
+}
+
+static bool match_matvec(const analysis & an, int pos, mv_group & grp) {
+    ggml_tensor * mm = an.g->nodes[pos];
+    if (mm->op != GGML_OP_MUL_MAT || !fill_matvec_base(grp.a, mm)) return false;
+    mv_args & a = grp.a;
+    const ggml_tensor * b = mm->src[1];
+    const int64_t K = a.K;
+    grp.members.clear();
+    grp.members.push_back(pos);
+    grp.emit_pos = pos;
+    bool have_x = false;
+
+    // prologue 1: b = alpha * rms_norm(x), private to this mat-vec
+    if (b->op == GGML_OP_MUL && is_f32_vec(b, K) && uses_of(an, b) == 1) {
+        const ggml_tensor * al = b->src[0], * nr = b->src[1];
+        if (nr->op != GGML_OP_RMS_NORM) std::swap(al, nr);
+        if (nr->op == GGML_OP_RMS_NORM && uses_of(an, nr) == 1 && is_f32_vec(al, K) && is_f32_vec(nr->src[0], K)) {
+            a.prologue = MV_RMSNORM;
+            a.x = (const float *) nr->src[0]->data;
+            a.alpha = (const float *) al->data;
+            a.eps = ggml_get_op_params_f32(nr, 0);
+            grp.members.push_back(pos_of(an, b)); grp.members.push_back(pos_of(an, nr));
+            have_x = true;
+        }
+    }
+    // prologue 2: b = silu(left(h)) * right(h)
+    if (!have_x && b->op == GGML_OP_MUL && uses_of(an, b) == 1 && ggml_nelements(b) == K) {
+        const ggml_tensor * sl = b->src[0], * r = b->src[1];
+        if (sl->op == GGML_OP_UNARY && sl->op_params[0] == GGML_UNARY_OP_SILU && uses_of(an, sl) == 1 &&
+            sl->src[0]->op == GGML_OP_VIEW && r->op == GGML_OP_VIEW && uses_of(an, sl->src[0]) == 1 && uses_of(an, r) == 1) {
+            const ggml_tensor * l = sl->src[0];
+            const ggml_tensor * h = l->src[0];
+            if (r->src[0] == h && is_f32_vec(h, 2 * K) && l->data == h->data && (const char *) r->data == (const char *) h->data + K * 4 &&
+                ggml_is_contiguous(l) && ggml_is_contiguous(r)) {
+                a.prologue = MV_GATE_SILU;
+                a.x = (const float *) h->data;
+                grp.members.push_back(pos_of(an, b)); grp.members.push_back(pos_of(an, sl));
+                have_x = true;
+            }
+        }
+    }
+    if (!have_x) {
+        if (!ggml_is_contiguous(b)) return false;
+        a.x = (const float *) b->data;
+    }
+    // epilogue: the only consumer adds a same-shaped F32 vector
+    const ggml_tensor * cons = sole_consumer(an, mm);
+    if (cons && cons->op == GGML_OP_ADD && cons->view_src == NULL) {
+        const ggml_tensor * other = cons->src[0] == mm ? cons->src[1] : cons->src[0];
+        if (other != mm && is_f32_vec(other, a.M) && is_f32_vec(cons, a.M)) {
+            const int cpos = pos_of(an, cons);
+            bool hazard = false;
+            for (int i = pos + 1; i < cpos; i++) if (writes_through_alias(an.g->nodes[i])) hazard = true;
+            if (!hazard) {
+                a.residual = (const float *) other->data;
+                a.y = (float *) cons->data;
+                grp.members.push_back(cpos);
+                grp.emit_pos = cpos;
+            }
+        }
+    }
+    return true;
+}
+
+// B. single-token attention block
+struct attn_group { attn_args a; int emit_pos; std::vector<int> members; };
+
+static const ggml_tensor * strip_views(const ggml_tensor * t) {
+    while (t && (t->op == GGML_OP_RESHAPE || t->op == GGML_OP_VIEW || t->op == GGML_OP_PERMUTE || t->op == GGML_OP_TRANSPOSE)) t = t->src[0];
+    return t;
+}
+
+// rotated = concat(sub(mul(r, rotr), mul(i, roti)), add(mul(r, roti), mul(i, rotr))); returns the un-rotated source
+static bool match_rope(const ggml_tensor * rotated, const ggml_tensor ** src_out, const ggml_tensor ** rotr_out, const ggml_tensor ** roti_out) {
+    if (rotated->op != GGML_OP_CONCAT || rotated->op_params[0] != 0) return false;
+    const ggml_tensor * re = rotated->src[0], * im = rotated->src[1];
+    if (re->op != GGML_OP_SUB || im->op != GGML_OP_ADD) return false;
+    const ggml_tensor * m0 = re->src[0], * m1 = re->src[1], * m2 = im->src[0], * m3 = im->src[1];
+    if (m0->op != GGML_OP_MUL || m1->op != GGML_OP_MUL || m2->op != GGML_OP_MUL || m3->op != GGML_OP_MUL) return false;
+    const ggml_tensor * xr = m0->src[0], * rotr = m0->src[1], * xi = m1->src[0], * roti = m1->src[1];
+    if (m2->src[0] != xr || m2->src[1] != roti || m3->src[0] != xi || m3->src[1] != rotr) return false;
+    // xr / xi = reshape(view(Z, half 0 / 1)), Z = cont(permute(reshape(cont(src), 2, D/2, T, BH), 3, 0, 1, 2))
+    if (xr->op != GGML_OP_RESHAPE || xi->op != GGML_OP_RESHAPE) return false;
+    const ggml_tensor * vr = xr->src[0], * vi = xi->src[0];
+    if (vr->op != GGML_OP_VIEW || vi->op != GGML_OP_VIEW || vr->src[0] != vi->src[0]) return false;
+    const ggml_tensor * Z = vr->src[0];
+    if (Z->op != GGML_OP_CONT || vr->data != Z->data || (const char *) vi->data != (const char *) Z->data + ggml_nbytes(Z) / 2) return false;
+    const ggml_tensor * P = Z->src[0];
+    if (P->op != GGML_OP_PERMUTE || P->op_params[0] != 3 || P->op_params[1] != 0 || P->op_params[2] != 1 || P->op_params[3] != 2) return false;
+    const ggml_tensor * R = P->src[0];
+    if (R->op != GGML_OP_RESHAPE || R->ne[0] != 2 || R->ne[2] != 1) return false;   // T == 1
+    *src_out = R->src[0];
+    *rotr_out = rotr;
+    *roti_out = roti;
+    return true;
+}
+
+static bool match_attention(const analysis & an, int pos, attn_group & grp) {
+    const ggml_tensor * sm = an.g->nodes[pos];
+    if (sm->op != GGML_OP_SOFT_MAX || !sm->src[1]) return false;
+    const ggml_tensor * kq = sm->src[0], * mask = sm->src[1];
+    if (kq->op != GGML_OP_MUL_MAT || uses_of(an, kq) != 1 || uses_of(an, sm) != 1) return false;
+    const ggml_tensor * kc = kq->src[0], * qo = kq->src[1];
+    if (kc->op != GGML_OP_SET_ROWS || kc->type != GGML_TYPE_BF16) return false;
+    const ggml_tensor * pv = sole_consumer(an, sm);
+    if (!pv || pv->op != GGML_OP_MUL_MAT || pv->src[1] != sm) return false;
+    const ggml_tensor * vt = pv->src[0];
+    if (vt->op != GGML_OP_CONT || vt->src[0]->op != GGML_OP_TRANSPOSE) return false;
+    const ggml_tensor * vc = vt->src[0]->src[0];
+    if (vc->op != GGML_OP_SET_ROWS || vc->type != GGML_TYPE_BF16) return false;
+    const ggml_tensor * x1 = sole_consumer(an, pv);
+    if (!x1 || x1->op != GGML_OP_PERMUTE) return false;
+    const ggml_tensor * x2 = sole_consumer(an, x1);
+    if (!x2 || x2->op != GGML_OP_CONT) return false;
+
+    const int64_t D = kc->ne[0], C = kc->ne[1], H = kc->ne[2];
+    if (qo->ne[0] != D || qo->ne[1] != 1 || qo->ne[2] != H || qo->ne[3] != 1) return false;   // T == 1, B == 1
+    if (vc->ne[0] != D || vc->ne[1] != C || vc->ne[2] != H) return false;
+    if (mask->type != GGML_TYPE_F32 || mask->ne[0] != C || !ggml_is_contiguous(mask)) return false;
+    if (D % 8 != 0 || 64 % (D / 8) != 0 || D > 256) return false;
+    if (kc->src[1] != vc->src[1]) return false;
+    const ggml_tensor * idx = kc->src[1];
+    if (idx->type != GGML_TYPE_I32 || ggml_nelements(idx) != 1) return false;
+    if (kc->nb[0] != 2 || vc->nb[0] != 2) return false;
+
+    const ggml_tensor * ko = kc->src[0], * vrow = vc->src[0];
+    const ggml_tensor * qsrc = qo, * ksrc = ko, * rotr = nullptr, * roti = nullptr;
+    if (qo->op == GGML_OP_CONCAT) {
+        const ggml_tensor * rotr2, * roti2;
+        if (!match_rope(qo, &qsrc, &rotr, &roti) || !match_rope(ko, &ksrc, &rotr2, &roti2) || rotr != rotr2 || roti != roti2) return false;
+        if (rotr->type != GGML_TYPE_F32 || rotr->ne[0] != D / 2 || (const char *) roti->data != (const char *) rotr->data + D / 2 * 4) return false;
+    }
+    const char * qp = resolve_dense(qsrc), * kp = resolve_dense(ksrc), * vp = resolve_dense(vrow);
+    if (!qp || !kp || !vp) return false;
+    if (qsrc->type != GGML_TYPE_F32 || ksrc->type != GGML_TYPE_F32 || vrow->type != GGML_TYPE_F32) return false;
+    if (ggml_nelements(qsrc) != H * D || ggml_nelements(ksrc) != H * D || ggml_nelements(vrow) != H * D) return false;
+
+    // collect the interior of the block: everything reachable from x2 down to the block inputs
+    std::vector<const ggml_tensor *> stack = { x2 };
+    std::vector<int> members;
+    std::unordered_map<const ggml_tensor *, bool> seen;
+    int n_mm = 0, n_sm = 0, n_sr = 0;
+    const int lo = pos - 200 > 0 ? pos - 200 : 0;
+    while (!stack.empty()) {
+        const ggml_tensor * t = stack.back(); stack.pop_back();
+        if (seen[t]) continue;
+        seen[t] = true;
+        const int p = pos_of(an, t);
+        if (p < 0) continue;                                  // leaf: cache, mask, indices, weights
+        if (t == mask || t == idx || t == rotr || t == roti) continue;
+        if ((const char *) t->data == nullptr) return false;
+        // the projection output (and anything before it) is an input of the block, not part of it
+        const bool is_input = (t->op == GGML_OP_MUL_MAT && t != kq && t != pv) || t->op == GGML_OP_TIMESTEP_EMBEDDING;
+        if (is_input) continue;
+        if (p < lo) return false;                              // wandered out of the layer: refuse
+        switch (t->op) {
+            case GGML_OP_MUL_MAT: n_mm++; break;
+            case GGML_OP_SOFT_MAX: n_sm++; break;
+            case GGML_OP_SET_ROWS: n_sr++; break;
+            case GGML_OP_VIEW: case GGML_OP_RESHAPE: case GGML_OP_PERMUTE: case GGML_OP_TRANSPOSE: case GGML_OP_CONT:
+            case GGML_OP_MUL: case GGML_OP_SUB: case GGML_OP_ADD: case GGML_OP_CONCAT: break;
+            default: return false;
+        }
+        members.push_back(p);
+        for (int s = 0; s < GGML_MAX_SRC; s++) if (t->src[s]) stack.push_back(t->src[s]);
+    }
+    if (n_mm != 2 || n_sm != 1 || n_sr != 2) return false;
+    // no interior value may be consumed outside the block (x2 is the block's output)
+    std::unordered_map<int, bool> inside;
+    for (int p : members) inside[p] = true;
+    for (int i = 0; i < an.g->n_nodes; i++) {
+        if (inside.count(i)) continue;
+        const ggml_tensor * c = an.g->nodes[i];
+        for (int s = 0; s < GGML_MAX_SRC; s++) {
+            const ggml_tensor * t = c->src[s];
+            if (!t || t == x2) continue;
+            const int tp = pos_of(an, t);
+            if (tp >= 0 && inside.count(tp)) return false;
+        }
+    }
+    attn_args & a = grp.a;
+    memset(&a, 0, sizeof(a));
+    a.q = (const float *) qp; a.k = (const float *) kp; a.v = (const float *) vp;
+    a.rot = rotr ? (const float *) rotr->data : nullptr;
+    a.mask = (const float *) mask->data;
+    a.index = (const int32_t *) idx->data;
+    a.kcache = (char *) kc->data; a.vcache = (char *) vc->data;
+    a.k_nb1 = (int64_t) kc->nb[1]; a.k_nb2 = (int64_t) kc->nb[2];
+    a.v_nb1 = (int64_t) vc->nb[1]; a.v_nb2 = (int64_t) vc->nb[2];
+    a.H = (int) H; a.D = (int) D; a.C = (int) C;
+    a.scale = ggml_get_op_params_f32(sm, 0);
+    a.out = (float *) x2->data;
+    grp.members = members;
+    grp.emit_pos = pos_of(an, x2);
+    return true;
+}
+
+// C. left-deep sum of (scaled) embedding rows ending at node `pos`
+struct embed_group { embed_sum_args a; std::vector<int> members; };
+
+static bool match_embed_term(const analysis & an, const ggml_tensor * e, embed_src & out, std::vector<int> & members) {
+    const ggml_tensor * gr = e, * scale = nullptr;
+    if (e->op == GGML_OP_MUL) {
+        gr = e->src[0]; scale = e->src[1];
+        if (scale->type != GGML_TYPE_F32 || ggml_nelements(scale) != 1 || uses_of(an, gr) != 1) return false;
+    }
+    if (gr->op != GGML_OP_GET_ROWS) return false;
+    const ggml_tensor * tab = gr->src[0], * idx = gr->src[1];
+    if (ggml_nelements(idx) != 1 || idx->type != GGML_TYPE_I32 || !dense_rows(tab)) return false;
+    switch (tab->type) { case GGML_TYPE_F32: case GGML_TYPE_F16: case GGML_TYPE_BF16: case GGML_TYPE_Q4_0: case GGML_TYPE_Q8_0: case GGML_TYPE_Q4_K: break; default: return false; }
+    out = { (const char *) tab->data, (int64_t) tab->nb[1], tab->ne[1], (int) tab->type, (const int32_t *) idx->data, scale ? (const float *) scale->data : nullptr };
+    members.push_back(pos_of(an, gr));
+    if (e != gr) members.push_back(pos_of(an, e));
+    return true;
+}
+
+static bool match_embed_sum(const analysis & an, int pos, embed_group & grp) {
+    const ggml_tensor * top = an.g->nodes[pos];
+    if (top->op != GGML_OP_ADD || top->view_src || top->type != GGML_TYPE_F32 || top->ne[1] != 1 || !ggml_is_contiguous(top)) return false;
+    // must be the top of the chain: its consumer is not another link
+    std::vector<const ggml_tensor *> terms;
+    std::vector<int> members;
+    const ggml_tensor * cur = top;
+    while (cur->op == GGML_OP_ADD && cur->view_src == NULL) {
+        const ggml_tensor * l = cur->src[0], * r = cur->src[1];
+        if (cur != top && uses_of(an, cur) != 1) return false;
+        if (uses_of(an, r) != 1 || !ggml_are_same_shape(l, r) || !ggml_are_same_shape(cur, l)) return false;
+        terms.push_back(r);
+        members.push_back(pos_of(an, cur));
+        cur = l;
+    }
+    terms.push_back(cur);
+    if (uses_of(an, cur) != 1) return false;
+    if (terms.size() < 3 || terms.size() > EMBED_SUM_MAX) return false;
+    memset(&grp.a, 0, sizeof(grp.a));
+    grp.a.n = (int) terms.size();
+    grp.a.K = top->ne[0];
+    grp.a.out = (float *) top->data;
+    for (size_t i = 0; i < terms.size(); i++) {
+        // terms were collected right-to-left; the kernel adds left-to-right
+        if (!match_embed_term(an, terms[terms.size() - 1 - i], grp.a.src[i], members)) return false;
+    }
+    grp.members = members;
+    return true;
+}
+
+// ---- plan construction --------------------------------------------------------------------------------------
+static plan_t * build_plan(hip_ctx * c, ggml_cgraph * g) {
+    plan_t * p = new plan_t;
+    p->n_nodes = g->n_nodes;
+    emitter em = { c, p };
+    analysis an;
+    analyse(an, g);
+    const bool fuse = !(c->flags & 1);
+
+    // fused groups, keyed by the position at which they are emitted
+    std::map<int, std::vector<step_fn>> at_pos;
+    if (fuse) {
+        // attention blocks first (they swallow set_rows / soft_max / two mul_mats)
+        for (int i = 0; i < g->n_nodes; i++) {
+            if (an.skip[(size_t) i] || g->nodes[i]->op != GGML_OP_SOFT_MAX) continue;
+            attn_group grp;
+            if (!match_attention(an, i, grp)) continue;
+            bool clash = false;
+            for (int m : grp.members) if (an.skip[(size_t) m]) clash = true;
+            if (clash) continue;
+            for (int m : grp.members) an.skip[(size_t) m] = 1;
+            const attn_args a = grp.a;
+            at_pos[grp.emit_pos].push_back([=](hipStream_t s) { k_attn_decode(s, a); });
+            p->n_fused += (int) grp.members.size();
+        }
+        // embedding sums
+        for (int i = g->n_nodes - 1; i >= 0; i--) {
+            if (an.skip[(size_t) i] || g->nodes[i]->op != GGML_OP_ADD) continue;
+            embed_group grp;
+            if (!match_embed_sum(an, i, grp)) continue;
+            bool clash = false;
+            for (int m : grp.members) if (m < 0 || an.skip[(size_t) m]) clash = true;
+            if (clash) continue;
+            for (int m : grp.members) an.skip[(size_t) m] = 1;
+            const embed_sum_args a = grp.a;
+            at_pos[i].push_back([=](hipStream_t s) { k_embed_sum(s, a); });
+            p->n_fused += (int) grp.members.size();
+        }
+        // mat-vecs with prologue / epilogue
+        for (int i = 0; i < g->n_nodes; i++) {
+            if (an.skip[(size_t) i] || g->nodes[i]->op != GGML_OP_MUL_MAT) continue;
+            mv_group grp;
+            if (!match_matvec(an, i, grp)) continue;
+            bool clash = false;
+            for (int m : grp.members) if (m < 0 || (m != i && an.skip[(size_t) m])) clash = true;
+            if (clash) continue;
+            for (int m : grp.members) an.skip[(size_t) m] = 1;
+            const mv_args a = grp.a;
+            at_pos[grp.emit_pos].push_back([=](hipStream_t s) { k_matvec(s, a); });
+            if (grp.members.size() > 1) p->n_fused += (int) grp.members.size();
+        }
+    }
+    for (int i = 0; i < g->n_nodes; i++) {
+        if (!an.skip[(size_t) i]) emit_generic(em, g->nodes[i]);
+        auto it = at_pos.find(i);
+        if (it != at_pos.end()) for (auto & f : it->second) p->steps.push_back(f);
+    }
+    return p;
+}
+
+static void run_steps(hip_ctx * c, plan_t * p) { for (auto & f : p->steps) f(c->stream); }
+
+static enum ggml_status hip_graph_compute(ggml_backend_t backend, struct ggml_cgraph * g) {
+    hip_ctx * c = (hip_ctx *) backend->context;
+    ctx_init_lazy(c);
+    set_device(c);
+    flush_uploads(c);
+    c->stats.graphs_computed++;
+    if (g->n_nodes == 0) return GGML_STATUS_SUCCESS;
+
+    const bool cacheable = g->n_nodes >= 32;
+    if (!cacheable) {
+        plan_t * p = build_plan(c, g);
+        run_steps(c, p);
+        c->stats.kernels_in_last_plan = (int64_t) p->steps.size();
+        c->stats.nodes_in_last_plan = p->n_nodes;
+        c->stats.fused_nodes_in_last_plan = p->n_fused;
+        plan_free(c, p);   // workspaces return to the pool; reuse is stream-ordered
+        return GGML_STATUS_SUCCESS;
+    }
+
+    const uint64_t h = graph_hash(g);
+    plan_t * p = nullptr;
+    auto it = c->plans.find(g);
+    if (it != c->plans.end()) {
+        if (it->second->hash == h) p = it->second;
+        else { HIP_CHECK(hipStreamSynchronize(c->stream)); plan_free(c, it->second); c->plans.erase(it); }
+    }
+    if (!p) {
+        p = build_plan(c, g);
+        p->hash = h;
+        c->plans[g] = p;
+        if (!(c->flags & 2)) {
+            // capture the launch sequence once; replays cost one hipGraphLaunch
+            HIP_CHECK(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+            run_steps(c, p);
+            HIP_CHECK(hipStreamEndCapture(c->stream, &p->graph));
+            HIP_CHECK(hipGraphInstantiate(&p->exec, p->graph, nullptr, nullptr, 0));
+        }
+    }
+    if (p->exec) { HIP_CHECK(hipGraphLaunch(p->exec, c->stream)); c->stats.graph_replays++; }
+    else run_steps(c, p);
+    c->stats.kernels_in_last_plan = (int64_t) p->steps.size();
+    c->stats.nodes_in_last_plan = p->n_nodes;
+    c->stats.fused_nodes_in_last_plan = p->n_fused;
+    return GGML_STATUS_SUCCESS;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// backend / device / registry objects
+// ---------------------------------------------------------------------------------------------------
+static const char * hip_backend_name(ggml_backend_t b) { return ((hip_ctx *) b->context)->name.c_str(); }
+static void hip_backend_free(ggml_backend_t b) {
+    hip_ctx * c = (hip_ctx *) b->context;
+    if (c->stream) {
+        set_device(c);
+        (void) hipStreamSynchronize(c->stream);
+        for (auto & kv : c->plans) plan_free(c, kv.second);
+        c->plans.clear();
+    }
+    delete b;
+}
+static void hip_backend_sync(ggml_backend_t b) {
+    hip_ctx * c = (hip_ctx *) b->context;
+    if (!c->stream) return;
+    set_device(c);
+    flush_uploads(c);
+    HIP_CHECK(hipStreamSynchronize(c->stream));
+}
+static bool hip_supports_op(ggml_backend_t, const struct ggml_tensor * op) {
+    switch (op->op) {
+        case GGML_OP_CPY: case GGML_OP_CONT: case GGML_OP_DUP:
+            if (ggml_is_quantized(op->type) || ggml_is_quantized(op->src[0]->type)) return op->type == op->src[0]->type;
+            return true;
+        case GGML_OP_MUL_MAT:
+            switch (op->src[0]->type) { case GGML_TYPE_F32: case GGML_TYPE_F16: case GGML_TYPE_BF16: case GGML_TYPE_Q4_0: case GGML_TYPE_Q8_0: case GGML_TYPE_Q4_K: return true; default: return false; }
+        default: return op->op < GGML_OP_COUNT;
+    }
+}
+
+static const char * hip_dev_name(ggml_backend_dev_t d) { return ((hip_ctx *) d->context)->name.c_str(); }
+static const char * hip_dev_desc(ggml_backend_dev_t d) { return ((hip_ctx *) d->context)->description.c_str(); }
+static void hip_dev_memory(ggml_backend_dev_t d, size_t * free, size_t * total) {
+    hip_ctx * c = (hip_ctx *) d->context;
+    set_device(c);
+    if (hipMemGetInfo(free, total) != hipSuccess) { *free = 0; *total = 0; }
+}
+static enum ggml_backend_dev_type hip_dev_type(ggml_backend_dev_t) { return GGML_BACKEND_DEVICE_TYPE_GPU; }
+static ggml_backend_t hip_dev_init(ggml_backend_dev_t d, const char *) {
+    hip_ctx * c = (hip_ctx *) d->context;
+    ctx_init_lazy(c);
+    auto * b = new ggml_backend;
+    b->iface = { hip_backend_name, hip_backend_free, hip_backend_sync, hip_alloc_buffer, hip_graph_compute, hip_supports_op };
+    b->device = d;
+    b->context = c;
+    return b;
+}
+
+static const char * hip_reg_name(ggml_backend_reg_t) { return "ROCm"; }
+static size_t hip_reg_dev_count(ggml_backend_reg_t) { return contexts().size(); }
+static ggml_backend_dev_t hip_reg_get_dev(ggml_backend_reg_t, size_t i) { return &contexts()[i]->dev_obj; }
+static void * hip_reg_proc(ggml_backend_reg_t, const char *) { return NULL; }   // no thread count on a GPU
+
+extern "C" ggml_backend_reg_t ggml_backend_mi355x_reg(void) {
+    static ggml_backend_reg reg = { { hip_reg_name, hip_reg_dev_count, hip_reg_get_dev, hip_reg_proc }, NULL };
+    static bool init = false;
+    if (!init) {
+        init = true;
+        int n = 0;
+        if (hipGetDeviceCount(&n) != hipSuccess) n = 0;
+        for (int i = 0; i < n; i++) {
+            hipDeviceProp_t prop;
+            if (hipGetDeviceProperties(&prop, i) != hipSuccess) continue;
+            hip_ctx * c = new hip_ctx;
+            c->device = i;
+            c->name = "ROCm" + std::to_string(i);
+            c->description = std::string(prop.name) + " (" + prop.gcnArchName + ")";
+            c->dev_obj.iface = { hip_dev_name, hip_dev_desc, hip_dev_memory, hip_dev_type, hip_dev_init };
+            c->dev_obj.reg = &reg;
+            c->dev_obj.context = c;
+            contexts().push_back(c);
+        }
+    }
+    return contexts().empty() ? NULL : &reg;
+}
+
+static hip_ctx * ctx_of(ggml_backend_t b) {
+    GGML_ASSERT(b && b->iface.get_name == hip_backend_name && "not an MI355X backend");
+    return (hip_ctx *) b->context;
+}
+extern "C" void ggml_backend_mi355x_get_stats(ggml_backend_t b, struct ggml_mi355x_stats * stats) { *stats = ctx_of(b)->stats; }
+extern "C" void ggml_backend_mi355x_set_flags(ggml_backend_t b, int flags) {
+    hip_ctx * c = ctx_of(b);
+    if (c->stream) { flush_uploads(c); HIP_CHECK(hipStreamSynchronize(c->stream)); }
+    for (auto & kv : c->plans) plan_free(c, kv.second);
+    c->plans.clear();
+    c->flags = flags;
+}
+extern "C" void * ggml_backend_mi355x_get_stream(ggml_backend_t b) { hip_ctx * c = ctx_of(b); ctx_init_lazy(c); return (void *) c->stream; }

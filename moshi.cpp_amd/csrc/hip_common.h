@@ -1,0 +1,98 @@
+// hip_common.h — shared declarations of the MI355X (gfx950) backend: tensor descriptors passed by
+// value to kernels, and the host-side launch wrappers the planner (hip_backend.hip) calls.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "ggml_impl.h"
+
+#define HIP_CHECK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) \
+    GGML_ABORT("HIP error %s at %s: %s", hipGetErrorName(e_), #expr, hipGetErrorString(e_)); } while (0)
+
+// strided tensor view as seen by a kernel
+struct tdesc {
+    char *  data;
+    int64_t ne[4];
+    int64_t nb[4];
+    int     type;
+};
+
+static inline tdesc make_tdesc(const struct ggml_tensor * t) {
+    tdesc d;
+    d.data = (char *) t->data;
+    for (int i = 0; i < 4; i++) { d.ne[i] = t->ne[i]; d.nb[i] = (int64_t) t->nb[i]; }
+    d.type = (int) t->type;
+    return d;
+}
+
+static inline int64_t td_nelements(const tdesc & t) { return t.ne[0] * t.ne[1] * t.ne[2] * t.ne[3]; }
+
+// ---- generic (one kernel per ggml node) ------------------------------------------------------------
+void k_binary(hipStream_t s, int op, tdesc dst, tdesc a, tdesc b);
+void k_unary(hipStream_t s, int uop, tdesc dst, tdesc a);
+void k_scale(hipStream_t s, tdesc dst, tdesc a, float scale, float bias);
+void k_clamp(hipStream_t s, tdesc dst, tdesc a, float mn, float mx);
+void k_cpy(hipStream_t s, tdesc dst, tdesc src);                 // type converting, logical order
+void k_concat(hipStream_t s, tdesc dst, tdesc a, tdesc b, int dim);
+void k_repeat(hipStream_t s, tdesc dst, tdesc a);
+void k_pad(hipStream_t s, tdesc dst, tdesc a);
+void k_arange(hipStream_t s, tdesc dst, float start, float step);
+void k_sum_rows(hipStream_t s, tdesc dst, tdesc a);              // also used for ggml_sum on a flattened view
+void k_sum_all(hipStream_t s, tdesc dst, tdesc a);
+void k_argmax(hipStream_t s, tdesc dst, tdesc a);
+void k_argsort(hipStream_t s, tdesc dst, tdesc a, int desc);
+void k_norm(hipStream_t s, tdesc dst, tdesc a, float eps, int rms);
+void k_soft_max(hipStream_t s, tdesc dst, tdesc a, tdesc mask, int has_mask, float scale);
+void k_get_rows(hipStream_t s, tdesc dst, tdesc a, tdesc idx);
+void k_set_rows(hipStream_t s, tdesc dst, tdesc src, tdesc idx);
+void k_im2col(hipStream_t s, tdesc dst, tdesc x, int64_t K, int s0, int p0, int d0);
+void k_conv_transpose_1d(hipStream_t s, tdesc dst, tdesc w, tdesc x, int s0);
+void k_timestep_embedding(hipStream_t s, tdesc dst, tdesc ts, int dim, int max_period);
+// generic matrix product: activation rows are first converted to the weight type's dot type
+// (q8_K / q8_0 / f16 / bf16) into `ws` (size from k_mul_mat_ws_size), then dotted
+size_t k_mul_mat_ws_size(const struct ggml_tensor * a, const struct ggml_tensor * b);
+void k_mul_mat(hipStream_t s, tdesc dst, tdesc a, tdesc b, void * ws);
+// scatter of batched small uploads: descs/blob live in pinned host memory mapped into the device
+struct upload_desc { char * dst; uint32_t offset; uint32_t size; };
+void k_scatter_uploads(hipStream_t s, const upload_desc * descs, const char * blob, int n);
+
+// ---- fused hot-path kernels --------------------------------------------------------------------------
+// y = W x (+ residual), x produced on the fly by an optional prologue, for one activation row (T = 1)
+enum mv_prologue { MV_PLAIN = 0, MV_RMSNORM = 1, MV_GATE_SILU = 2 };
+struct mv_args {
+    int         wtype;          // ggml_type of W
+    const char * w;             // [K, M] rows of `row_bytes`
+    int64_t     row_bytes;
+    int64_t     K, M;
+    int         prologue;
+    const float * x;            // PLAIN: x[K]; RMSNORM: raw x[K]; GATE_SILU: h[2K] (left|right halves)
+    const float * alpha;        // RMSNORM: alpha[K]
+    float       eps;
+    const float * residual;     // optional, [M]
+    float *     y;              // [M]
+    float *     x_out;          // optional: prologue result written by block 0 (keeps the ggml node materialised)
+};
+bool k_matvec_supported(int wtype, int64_t K, int64_t M);
+void k_matvec(hipStream_t s, const mv_args & a);
+
+// single-token self-attention over a ring KV cache (T = 1): RoPE(q,k) -> cache write -> masked
+// softmax(K q) V restricted to un-masked slots; see hip_kernels_fused.hip
+struct attn_args {
+    const float * q; const float * k; const float * v;   // [H*D] each, F32 (slices of the in_proj output)
+    const float * rot;          // timestep embedding [D] = cos(D/2) | sin(D/2), or NULL (no RoPE)
+    const float * mask;         // [C] additive mask (0 / -inf)
+    const int32_t * index;      // [1] ring slot to write
+    char * kcache; char * vcache;   // BF16 [D, C, H]
+    int64_t k_nb1, k_nb2, v_nb1, v_nb2;
+    int H, D, C;
+    float scale;
+    float * out;                // [H*D]
+};
+void k_attn_decode(hipStream_t s, const attn_args & a);
+
+// sum of (scaled) embedding rows, left-to-right
+struct embed_src { const char * table; int64_t row_bytes; int64_t n_rows; int type; const int32_t * index; const float * scale; };
+#define EMBED_SUM_MAX 24
+struct embed_sum_args { embed_src src[EMBED_SUM_MAX]; int n; int64_t K; float * out; };
+void k_embed_sum(hipStream_t s, const embed_sum_args & a);

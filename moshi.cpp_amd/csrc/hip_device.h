@@ -1,0 +1,165 @@
+// hip_device.h — device-side helpers shared by the gfx950 kernels: strided addressing, scalar type
+// conversion with ggml's rounding rules, wave64 reductions, block-format decoding.
+#pragma once
+
+#include "hip_common.h"
+
+__device__ __forceinline__ char * at(const tdesc & t, int64_t i0, int64_t i1, int64_t i2, int64_t i3) {
+    return t.data + i0 * t.nb[0] + i1 * t.nb[1] + i2 * t.nb[2] + i3 * t.nb[3];
+}
+__device__ __forceinline__ void unravel(const tdesc & t, int64_t i, int64_t & i0, int64_t & i1, int64_t & i2, int64_t & i3) {
+    i0 = i % t.ne[0]; i /= t.ne[0];
+    i1 = i % t.ne[1]; i /= t.ne[1];
+    i2 = i % t.ne[2]; i3 = i / t.ne[2];
+}
+__device__ __forceinline__ void row_coords(const tdesc & t, int64_t r, int64_t & i1, int64_t & i2, int64_t & i3) {
+    i1 = r % t.ne[1]; r /= t.ne[1];
+    i2 = r % t.ne[2]; i3 = r / t.ne[2];
+}
+__host__ __device__ __forceinline__ int elem_size(int type) {
+    switch (type) {
+        case GGML_TYPE_F32: case GGML_TYPE_I32: return 4;
+        case GGML_TYPE_F16: case GGML_TYPE_BF16: case GGML_TYPE_I16: return 2;
+        case GGML_TYPE_I64: case GGML_TYPE_F64: return 8;
+        default: return 1;
+    }
+}
+
+// ---- scalar conversions -------------------------------------------------------------------------------
+__device__ __forceinline__ float h2f(uint16_t h) { _Float16 v; __builtin_memcpy(&v, &h, 2); return (float) v; }
+__device__ __forceinline__ uint16_t f2h(float f) { _Float16 v = (_Float16) f; uint16_t h; __builtin_memcpy(&h, &v, 2); return h; }
+__device__ __forceinline__ float bf2f(uint16_t h) { return __uint_as_float((uint32_t) h << 16); }
+// round-to-nearest-even, NaN stays NaN (same integer recipe as the oracle)
+__device__ __forceinline__ uint16_t f2bf(float f) {
+    const uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t) ((u >> 16) | 64);
+    return (uint16_t) ((u + (0x7fffu + ((u >> 16) & 1u))) >> 16);
+}
+__device__ __forceinline__ int nearest_int_dev(float fval) {
+    const float val = fval + 12582912.f;
+    return (int) (__float_as_uint(val) & 0x007fffffu) - 0x00400000;
+}
+__device__ __forceinline__ float ld_as_f32(const char * p, int type) {
+    switch (type) {
+        case GGML_TYPE_F32:  return *(const float *) p;
+        case GGML_TYPE_F16:  return h2f(*(const uint16_t *) p);
+        case GGML_TYPE_BF16: return bf2f(*(const uint16_t *) p);
+        case GGML_TYPE_I32:  return (float) *(const int32_t *) p;
+        default:             return NAN;
+    }
+}
+__device__ __forceinline__ void st_from_f32(char * p, int type, float v) {
+    switch (type) {
+        case GGML_TYPE_F32:  *(float *) p = v; break;
+        case GGML_TYPE_F16:  *(uint16_t *) p = f2h(v); break;
+        case GGML_TYPE_BF16: *(uint16_t *) p = f2bf(v); break;
+        case GGML_TYPE_I32:  *(int32_t *) p = (int32_t) v; break;
+        default: break;
+    }
+}
+
+// ---- activations ---------------------------------------------------------------------------------------
+__device__ __forceinline__ float gelu_f32(float x) {
+    return 0.5f * x * (1.0f + tanhf(0.79788456080286535587989211986876f * x * (1.0f + 0.044715f * x * x)));
+}
+// ggml's CPU backend evaluates gelu through an F16 lookup table: f16(gelu(f16(x)))
+__device__ __forceinline__ float gelu_table(float x) {
+    if (x <= -10.0f) return 0.0f;
+    if (x >= 10.0f) return x;
+    return h2f(f2h(gelu_f32(h2f(f2h(x)))));
+}
+__device__ __forceinline__ float apply_unary(int uop, float x) {
+    switch (uop) {
+        case GGML_UNARY_OP_NEG:  return -x;
+        case GGML_UNARY_OP_SILU: return x / (1.0f + expf(-x));
+        case GGML_UNARY_OP_ELU:  return x > 0.f ? x : expm1f(x);
+        case GGML_UNARY_OP_GELU: return gelu_table(x);
+        case GGML_UNARY_OP_RELU: return x > 0.f ? x : 0.f;
+        case GGML_UNARY_OP_TANH: return tanhf(x);
+        case GGML_UNARY_OP_SIGMOID: return 1.f / (1.f + expf(-x));
+        case GGML_UNARY_OP_EXP:  return expf(x);
+        default: return NAN;
+    }
+}
+
+// ---- wave64 reductions ---------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum_f32(float v) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_sum_f64(double v) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max_f32(float v) {
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// ---- block formats -------------------------------------------------------------------------------------
+// 6-bit (scale, min) pairs of a Q4_K super-block -> sc[0..7] in the bytes of s01, mins in the bytes of m01
+__device__ __forceinline__ void q4k_unpack_scales(const uint8_t * scales, uint32_t sc[2], uint32_t mn[2]) {
+    const uint32_t kmask1 = 0x3f3f3f3fu, kmask2 = 0x0f0f0f0fu, kmask3 = 0x03030303u;
+    const uint32_t u0 = ((const uint32_t *) scales)[0], u1 = ((const uint32_t *) scales)[1], u2 = ((const uint32_t *) scales)[2];
+    sc[0] = u0 & kmask1;
+    sc[1] = (u2 & kmask2) | (((u0 >> 6) & kmask3) << 4);
+    mn[0] = u1 & kmask1;
+    mn[1] = ((u2 >> 4) & kmask2) | (((u1 >> 6) & kmask3) << 4);
+}
+
+__device__ __forceinline__ float dequant_elem(const char * row, int type, int64_t i) {
+    switch (type) {
+        case GGML_TYPE_F32:  return ((const float *) row)[i];
+        case GGML_TYPE_F16:  return h2f(((const uint16_t *) row)[i]);
+        case GGML_TYPE_BF16: return bf2f(((const uint16_t *) row)[i]);
+        case GGML_TYPE_Q8_0: { const block_q8_0 * b = (const block_q8_0 *) row + i / 32; return b->qs[i % 32] * h2f(b->d); }
+        case GGML_TYPE_Q4_0: {
+            const block_q4_0 * b = (const block_q4_0 *) row + i / 32;
+            const int j = (int) (i % 32);
+            const int q = j < 16 ? (b->qs[j] & 0x0F) : (b->qs[j - 16] >> 4);
+            return (q - 8) * h2f(b->d);
+        }
+        case GGML_TYPE_Q4_K: {
+            const block_q4_K * b = (const block_q4_K *) row + i / 256;
+            const int j = (int) (i % 256);
+            const int sub = j / 32, l = j % 32;
+            uint32_t sc[2], mn[2];
+            q4k_unpack_scales(b->scales, sc, mn);
+            const uint32_t s = (sc[sub >> 2] >> (8 * (sub & 3))) & 0xff, m = (mn[sub >> 2] >> (8 * (sub & 3))) & 0xff;
+            const uint8_t qb = b->qs[(sub >> 1) * 32 + l];
+            const int q = (sub & 1) ? (qb >> 4) : (qb & 0xF);
+            const float d = h2f(b->d) * (float) s, mm = h2f(b->dmin) * (float) m;
+            return d * (float) q - mm;
+        }
+        default: return NAN;
+    }
+}
+
+// signed 4x8-bit dot with 32-bit accumulate (v_dot4_i32_i8)
+__device__ __forceinline__ int dot4_i8(int a, int b, int c) { return __builtin_amdgcn_sdot4(a, b, c, false); }
+
+// one Q4_K super-block against 256 q8_K-quantised activations: d8*(d*sum_j sc_j*<q4_j,q8_j> - dmin*sum_j m_j*bsum_j)
+// q8 must be 4-byte aligned, bsums 2-byte aligned
+__device__ __forceinline__ float q4k_q8k_block_dot(const block_q4_K * xb, const int8_t * q8, const int16_t * bsums, float d8) {
+    uint32_t sc[2], mn[2];
+    q4k_unpack_scales(xb->scales, sc, mn);
+    const uint32_t * qs = (const uint32_t *) xb->qs;
+    const int * y = (const int *) q8;
+    int isum = 0, msum = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        int lo = 0, hi = 0;
+#pragma unroll
+        for (int t = 0; t < 8; t++) {
+            const uint32_t q = qs[j * 8 + t];
+            lo = dot4_i8((int) (q & 0x0F0F0F0Fu), y[j * 16 + t], lo);
+            hi = dot4_i8((int) ((q >> 4) & 0x0F0F0F0Fu), y[j * 16 + 8 + t], hi);
+        }
+        const int s0 = (int) ((sc[j >> 1] >> (16 * (j & 1))) & 0xff), s1 = (int) ((sc[j >> 1] >> (16 * (j & 1) + 8)) & 0xff);
+        const int m0 = (int) ((mn[j >> 1] >> (16 * (j & 1))) & 0xff), m1 = (int) ((mn[j >> 1] >> (16 * (j & 1) + 8)) & 0xff);
+        isum += s0 * lo + s1 * hi;
+        msum += m0 * ((int) bsums[4 * j] + (int) bsums[4 * j + 1]) + m1 * ((int) bsums[4 * j + 2] + (int) bsums[4 * j + 3]);
+    }
+    const float d = h2f(xb->d) * d8, dmin = h2f(xb->dmin) * d8;
+    return d * (float) isum - dmin * (float) msum;
+}

@@ -1,0 +1,406 @@
+// hip_kernels_fused.hip — the per-frame hot path of moshi.cpp's streaming decode as hand-written gfx950
+// kernels: block-quantised mat-vec with fused prologue / epilogue,
+// single-token ring-cache attention, and the 17-stream embedding sum.
+//
+// Roofline: every kernel here is HBM-bound (batch-1 mat-vec = 2 flop per 0.5625 B of Q4_K weights), so the
+// design rules are the bandwidth ones: 16-byte fully coalesced loads of the raw block stream, enough
+// bytes in flight per CU, weights read exactly once, no materialised intermediates.
+//
+// Q4_K mat-vec data flow (matvec_q4k_kernel):
+//   HBM  --16 B/lane coalesced, 9 loads = one 64-super-block tile (9216 B) per wave-->  VGPR
+//   VGPR --ds_write_b128, linear image-->  LDS (wave-private 9216 B)
+//   LDS  --lane l reads super-block l (9 x ds_read_b128 at a 144 B stride: conflict-free)--> VGPR
+//   activations: quantised once per workgroup to Q8_K in LDS (padded 304 B blocks: conflict-free),
+//   integer sub-block dots with v_dot4_i32_i8, one float term per super-block, fixed-order row sums.
+// The activation rounding (Q8_K) and the per-super-block arithmetic are ggml's CPU semantics, so results
+// agree with the oracle to float-summation-order noise.
+#include "hip_common.h"
+#include "hip_device.h"
+
+// ---------------------------------------------------------------------------------------------------
+// activation prologues
+// ---------------------------------------------------------------------------------------------------
+struct x_src {
+    int prologue;
+    const float * x;
+    const float * alpha;
+    float scale;      // rms scale (RMSNORM)
+    int64_t K;
+};
+
+__device__ __forceinline__ float x_value(const x_src & s, int64_t i) {
+    switch (s.prologue) {
+        case MV_RMSNORM:   return s.alpha[i] * (s.x[i] * s.scale);
+        case MV_GATE_SILU: { const float l = s.x[i], r = s.x[s.K + i]; return (l / (1.0f + expf(-l))) * r; }
+        default:           return s.x[i];
+    }
+}
+
+// 1/sqrt(mean(x^2) + eps) over K elements, all threads of the block participate (double accumulation)
+__device__ float block_rms_scale(const float * x, int64_t K, float eps, double * sh) {
+    double acc = 0;
+    for (int64_t i = threadIdx.x; i < K; i += blockDim.x) { const float v = x[i]; acc += (double) (v * v); }
+    acc = wave_sum_f64(acc);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    double tot = 0;
+    for (int w = 0; w < (int) (blockDim.x >> 6); w++) tot += sh[w];
+    const float mean = (float) (tot / (double) K);
+    return 1.0f / sqrtf(mean + eps);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Q4_K mat-vec
+// ---------------------------------------------------------------------------------------------------
+#define XBLK_BYTES 304   // 256 q8 + 16 bsums (int16) + d (f32) + pad: 76-dword stride => conflict-free b128 reads
+#define TILE_BYTES 9216  // 64 super-blocks of 144 B = 9 wave-wide 16-byte loads
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+struct xblk { int8_t q[256]; int16_t bsums[16]; float d; float pad[3]; };
+static_assert(sizeof(xblk) == XBLK_BYTES, "xblk layout");
+
+__global__ void __launch_bounds__(256) matvec_q4k_kernel(mv_args a, int rows_per_wg) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ double sh_red[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
+    const int nb = (int) (a.K / 256);
+    xblk * xs = (xblk *) smem;
+    char * stage = smem + nb * XBLK_BYTES + wave * TILE_BYTES;
+    float * part = (float *) (smem + nb * XBLK_BYTES + nwaves * TILE_BYTES);
+
+    const int64_t row0 = (int64_t) blockIdx.x * rows_per_wg;
+    const int rows = (int) (a.M - row0 < rows_per_wg ? a.M - row0 : rows_per_wg);
+    const int nblk = rows * nb;
+    const int ntiles = (nblk + 63) >> 6;
+    const int nchunks = nblk * 9;
+    const u32x4 * wsrc = (const u32x4 *) (a.w + row0 * a.row_bytes);
+
+    // 1. put the first weight tile of this wave in flight before touching the activations
+    u32x4 r[9];
+    int t = wave;
+    if (t < ntiles) {
+#pragma unroll
+        for (int i = 0; i < 9; i++) {
+            const int g = t * 576 + i * 64 + lane;
+            r[i] = g < nchunks ? __builtin_nontemporal_load(wsrc + g) : (u32x4) (0u);
+        }
+    }
+
+    // 2. activations -> Q8_K blocks in LDS (each wave quantises whole 256-element blocks)
+    x_src xsrc = { a.prologue, a.x, a.alpha, 1.0f, a.K };
+    if (a.prologue == MV_RMSNORM) xsrc.scale = block_rms_scale(a.x, a.K, a.eps, sh_red);
+    for (int b = wave; b < nb; b += nwaves) {
+        const int64_t e0 = (int64_t) b * 256 + lane * 4;
+        float v[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) v[k] = x_value(xsrc, e0 + k);
+        if (a.x_out != nullptr && blockIdx.x == 0) *(float4 *) (a.x_out + e0) = make_float4(v[0], v[1], v[2], v[3]);
+        float mx = v[0];
+#pragma unroll
+        for (int k = 1; k < 4; k++) if (fabsf(v[k]) > fabsf(mx)) mx = v[k];
+        for (int o = 32; o > 0; o >>= 1) { const float other = __shfl_xor(mx, o, 64); if (fabsf(other) > fabsf(mx)) mx = other; }
+        int q[4] = { 0, 0, 0, 0 };
+        float d = 0.f;
+        if (mx != 0.f) {
+            const float iscale = -127.f / mx;
+#pragma unroll
+            for (int k = 0; k < 4; k++) { const int qi = nearest_int_dev(iscale * v[k]); q[k] = qi < 127 ? qi : 127; }
+            d = 1.f / iscale;
+        }
+        *(uint32_t *) (xs[b].q + lane * 4) = (uint32_t) (q[0] & 0xff) | ((uint32_t) (q[1] & 0xff) << 8) | ((uint32_t) (q[2] & 0xff) << 16) | ((uint32_t) (q[3] & 0xff) << 24);
+        int s4 = q[0] + q[1] + q[2] + q[3];
+        s4 += __shfl_xor(s4, 1, 64);
+        s4 += __shfl_xor(s4, 2, 64);
+        if ((lane & 3) == 0) xs[b].bsums[lane >> 2] = (int16_t) s4;
+        if (lane == 0) xs[b].d = d;
+    }
+    __syncthreads();
+
+    // 3. stream the tiles: registers -> LDS image -> one super-block per lane
+    for (; t < ntiles; t += nwaves) {
+#pragma unroll
+        for (int i = 0; i < 9; i++) ((u32x4 *) stage)[i * 64 + lane] = r[i];
+        const int tn = t + nwaves;
+        if (tn < ntiles) {
+#pragma unroll
+            for (int i = 0; i < 9; i++) {
+                const int g = tn * 576 + i * 64 + lane;
+                r[i] = g < nchunks ? __builtin_nontemporal_load(wsrc + g) : (u32x4) (0u);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const int bi = t * 64 + lane;
+        if (bi < nblk) {
+            const block_q4_K * wb = (const block_q4_K *) (stage + lane * 144);
+            const xblk * xb = xs + (bi % nb);
+            part[bi] = q4k_q8k_block_dot(wb, xb->q, xb->bsums, xb->d);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    __syncthreads();
+
+    // 4. fixed-order row sums (+ residual)
+    for (int rr = tid; rr < rows; rr += blockDim.x) {
+        float sum = 0.f;
+        for (int j = 0; j < nb; j++) sum += part[rr * nb + j];
+        const int64_t row = row0 + rr;
+        a.y[row] = a.residual ? a.residual[row] + sum : sum;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// float-weight mat-vec (F32 / F16 / BF16 weights; 1..MV_MAX_COLS activation columns)
+// ---------------------------------------------------------------------------------------------------
+template <int WT>
+__global__ void __launch_bounds__(256) matvec_f_kernel(mv_args a, int rows_per_wave) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ double sh_red[4];
+    float * xs = (float *) smem;   // [K]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
+    x_src xsrc = { a.prologue, a.x, a.alpha, 1.0f, a.K };
+    if (a.prologue == MV_RMSNORM) xsrc.scale = block_rms_scale(a.x, a.K, a.eps, sh_red);
+    for (int64_t i = tid; i < a.K; i += blockDim.x) {
+        float v = x_value(xsrc, i);
+        if (a.x_out != nullptr && blockIdx.x == 0) a.x_out[i] = v;
+        if (WT == GGML_TYPE_F16) v = h2f(f2h(v));
+        if (WT == GGML_TYPE_BF16) v = bf2f(f2bf(v));
+        xs[i] = v;
+    }
+    __syncthreads();
+    constexpr int VEC = WT == GGML_TYPE_F32 ? 4 : 8;
+    const int64_t rbase = ((int64_t) blockIdx.x * nwaves + wave) * rows_per_wave;
+    for (int rr = 0; rr < rows_per_wave; rr++) {
+        const int64_t row = rbase + rr;
+        if (row >= a.M) break;
+        const char * w = a.w + row * a.row_bytes;
+        double acc = 0;
+        for (int64_t k = (int64_t) lane * VEC; k < a.K; k += 64 * VEC) {
+            if (WT == GGML_TYPE_F32) {
+                const float4 wv = *(const float4 *) (w + k * 4);
+                const float4 xv = *(const float4 *) (xs + k);
+                acc += (double) (wv.x * xv.x); acc += (double) (wv.y * xv.y); acc += (double) (wv.z * xv.z); acc += (double) (wv.w * xv.w);
+            } else {
+                const uint4 wv = *(const uint4 *) (w + k * 2);
+                const uint32_t ww[4] = { wv.x, wv.y, wv.z, wv.w };
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const uint16_t lo = (uint16_t) (ww[j] & 0xffff), hi = (uint16_t) (ww[j] >> 16);
+                    const float w0 = WT == GGML_TYPE_F16 ? h2f(lo) : bf2f(lo), w1 = WT == GGML_TYPE_F16 ? h2f(hi) : bf2f(hi);
+                    acc += (double) (w0 * xs[k + 2 * j]);
+                    acc += (double) (w1 * xs[k + 2 * j + 1]);
+                }
+            }
+        }
+        acc = wave_sum_f64(acc);
+        if (lane == 0) { const float s = (float) acc; a.y[row] = a.residual ? a.residual[row] + s : s; }
+    }
+}
+
+bool k_matvec_supported(int wtype, int64_t K, int64_t M) {
+    if (M <= 0) return false;
+    switch (wtype) {
+        case GGML_TYPE_Q4_K: return K % 256 == 0 && K <= 16384;
+        case GGML_TYPE_F32:  return K % 4 == 0 && K <= 16384;
+        case GGML_TYPE_F16: case GGML_TYPE_BF16: return K % 8 == 0 && K <= 16384;
+        default: return false;
+    }
+}
+
+void k_matvec(hipStream_t s, const mv_args & a) {
+    if (a.wtype == GGML_TYPE_Q4_K) {
+        const int nb = (int) (a.K / 256);
+        // rows per workgroup: keep the per-row partial table small and the grid >= ~2 workgroups per CU
+        int rows = 1024 / nb;
+        if (rows > 64) rows = 64;
+        while (rows > 4 && (a.M + rows - 1) / rows < 512) rows >>= 1;
+        if (rows < 1) rows = 1;
+        const int ntiles = (rows * nb + 63) / 64;
+        const int threads = ntiles >= 4 ? 256 : ntiles >= 2 ? 128 : 64;
+        const int nwaves = threads / 64;
+        const size_t smem = (size_t) nb * XBLK_BYTES + (size_t) nwaves * TILE_BYTES + (size_t) rows * nb * 4;
+        const int grid = (int) ((a.M + rows - 1) / rows);
+        matvec_q4k_kernel<<<grid, threads, smem, s>>>(a, rows);
+        return;
+    }
+    const int rows_per_wave = a.K <= 1024 ? 4 : 2;
+    const int grid = (int) ((a.M + 4 * rows_per_wave - 1) / (4 * rows_per_wave));
+    const size_t smem = (size_t) a.K * 4;
+    switch (a.wtype) {
+        case GGML_TYPE_F32:  matvec_f_kernel<GGML_TYPE_F32><<<grid, 256, smem, s>>>(a, rows_per_wave); break;
+        case GGML_TYPE_F16:  matvec_f_kernel<GGML_TYPE_F16><<<grid, 256, smem, s>>>(a, rows_per_wave); break;
+        case GGML_TYPE_BF16: matvec_f_kernel<GGML_TYPE_BF16><<<grid, 256, smem, s>>>(a, rows_per_wave); break;
+        default: GGML_ABORT("k_matvec: unsupported weight type");
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// single-token attention over the ring KV cache (one workgroup per head)
+//
+// Reproduces the node sequence of moshi_streaming_multihead_attention for T = 1
+// (src/moshi/modules/transformer.h:543-576, rope.h:33-128, torch.h:225-237) with ggml's CPU numerics:
+//   q, k interleaved pairs -> rotated, stored de-interleaved [re | im];
+//   K, V rows written as BF16 at ring slot index[0];
+//   scores = <bf16 K, bf16(q)> (double accumulate) ; softmax(score * scale + mask) ; p rounded to BF16;
+//   out = sum_c bf16 V[c] * p[c] (double accumulate).
+// Masked slots (mask = -inf) contribute exactly 0, so only un-masked slots are read from HBM; the
+// result equals the reference's full-capacity soft_max (README.md:55-57).
+// ---------------------------------------------------------------------------------------------------
+#define ATTN_THREADS 256
+
+__global__ void __launch_bounds__(ATTN_THREADS) attn_decode_kernel(attn_args a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int D = a.D, C = a.C, h = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float * sc   = (float *) smem;          // [C] scores -> probabilities
+    float * qf   = sc + C;                  // [D] bf16-rounded rotated q
+    float * knew = qf + D;                  // [D] bf16-rounded new k row
+    float * vnew = knew + D;                // [D] bf16-rounded new v row
+    double * red = (double *) (vnew + D);   // [ATTN_THREADS/64 * D] partial outputs, also reduction scratch
+    __shared__ float sh_f[4];
+    __shared__ double sh_d[4];
+
+    const int slot = a.index[0];
+    const float * q = a.q + (int64_t) h * D, * k = a.k + (int64_t) h * D, * v = a.v + (int64_t) h * D;
+    char * kc = a.kcache + (int64_t) h * a.k_nb2, * vc = a.vcache + (int64_t) h * a.v_nb2;
+
+    // 1. RoPE + cache write
+    const int half = D / 2;
+    for (int j = tid; j < D; j += ATTN_THREADS) {
+        float qo, ko;
+        if (a.rot) {
+            const int p = j < half ? j : j - half;
+            const float c = a.rot[p], sn = a.rot[half + p];
+            const float qr = q[2 * p], qi = q[2 * p + 1], kr = k[2 * p], ki = k[2 * p + 1];
+            if (j < half) { qo = qr * c - qi * sn; ko = kr * c - ki * sn; }
+            else          { qo = qr * sn + qi * c; ko = kr * sn + ki * c; }
+        } else { qo = q[j]; ko = k[j]; }
+        const uint16_t kb = f2bf(ko), vb = f2bf(v[j]);
+        qf[j] = bf2f(f2bf(qo));
+        knew[j] = bf2f(kb);
+        vnew[j] = bf2f(vb);
+        if (slot >= 0 && slot < C) {
+            ((uint16_t *) (kc + (int64_t) slot * a.k_nb1))[j] = kb;
+            ((uint16_t *) (vc + (int64_t) slot * a.v_nb1))[j] = vb;
+        }
+    }
+    __syncthreads();
+
+    // 2. scores: LPS lanes per slot, 8 dims (16 B) per lane
+    const int LPS = D / 8;              // lanes per slot (16 for D=128, 8 for D=64)
+    const int SPW = 64 / LPS;           // slots per wave-instruction
+    const int sub = lane / LPS, dl = (lane % LPS) * 8;
+    float qv[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) qv[i] = qf[dl + i];
+    float lmax = -INFINITY;
+    for (int c0 = wave * SPW; c0 < C; c0 += 4 * SPW) {
+        const int c = c0 + sub;
+        const float m = c < C ? a.mask[c] : -INFINITY;
+        const bool live = m > -INFINITY;
+        double acc = 0;
+        if (live) {
+            if (c == slot) {
+#pragma unroll
+                for (int i = 0; i < 8; i++) acc += (double) (knew[dl + i] * qv[i]);
+            } else {
+                const uint4 kv = *(const uint4 *) (kc + (int64_t) c * a.k_nb1 + dl * 2);
+                const uint32_t kw[4] = { kv.x, kv.y, kv.z, kv.w };
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    acc += (double) (bf2f((uint16_t) (kw[i] & 0xffff)) * qv[2 * i]);
+                    acc += (double) (bf2f((uint16_t) (kw[i] >> 16)) * qv[2 * i + 1]);
+                }
+            }
+        }
+        for (int o = LPS >> 1; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+        if (c < C && (lane % LPS) == 0) {
+            const float sv = live ? (float) acc * a.scale + m : -INFINITY;
+            sc[c] = sv;
+            lmax = fmaxf(lmax, sv);
+        }
+    }
+    lmax = wave_max_f32(lmax);
+    if (lane == 0) sh_f[wave] = lmax;
+    __syncthreads();
+    const float gmax = fmaxf(fmaxf(sh_f[0], sh_f[1]), fmaxf(sh_f[2], sh_f[3]));
+
+    // 3. soft_max: exp in float, sum in double, scale by (float)(1/sum), round to BF16 for the V product
+    double lsum = 0;
+    for (int c = tid; c < C; c += ATTN_THREADS) {
+        const float sv = sc[c];
+        const float e = sv > -INFINITY ? expf(sv - gmax) : 0.f;
+        sc[c] = e;
+        lsum += (double) e;
+    }
+    lsum = wave_sum_f64(lsum);
+    if (lane == 0) sh_d[wave] = lsum;
+    __syncthreads();
+    const float inv = (float) (1.0 / (sh_d[0] + sh_d[1] + sh_d[2] + sh_d[3]));
+    for (int c = tid; c < C; c += ATTN_THREADS) sc[c] = bf2f(f2bf(sc[c] * inv));
+    __syncthreads();
+
+    // 4. out[d] = sum_c V[d, c] * p[c]
+    double o8[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) o8[i] = 0;
+    for (int c0 = wave * SPW; c0 < C; c0 += 4 * SPW) {
+        const int c = c0 + sub;
+        const float p = c < C ? sc[c] : 0.f;
+        if (p != 0.f) {
+            if (c == slot) {
+#pragma unroll
+                for (int i = 0; i < 8; i++) o8[i] += (double) (vnew[dl + i] * p);
+            } else {
+                const uint4 vv = *(const uint4 *) (vc + (int64_t) c * a.v_nb1 + dl * 2);
+                const uint32_t vw[4] = { vv.x, vv.y, vv.z, vv.w };
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    o8[2 * i]     += (double) (bf2f((uint16_t) (vw[i] & 0xffff)) * p);
+                    o8[2 * i + 1] += (double) (bf2f((uint16_t) (vw[i] >> 16)) * p);
+                }
+            }
+        }
+    }
+    // reduce over the SPW slot groups of the wave, then over the 4 waves
+#pragma unroll
+    for (int i = 0; i < 8; i++) for (int o = LPS; o < 64; o <<= 1) o8[i] += __shfl_xor(o8[i], o, 64);
+    if (sub == 0) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) red[wave * D + dl + i] = o8[i];
+    }
+    __syncthreads();
+    for (int j = tid; j < D; j += ATTN_THREADS)
+        a.out[(int64_t) h * D + j] = (float) (red[j] + red[D + j] + red[2 * D + j] + red[3 * D + j]);
+}
+
+void k_attn_decode(hipStream_t s, const attn_args & a) {
+    GGML_ASSERT(a.D % 8 == 0 && 64 % (a.D / 8) == 0 && a.D <= 512);
+    const size_t smem = (size_t) a.C * 4 + (size_t) a.D * 4 * 3 + (size_t) (ATTN_THREADS / 64) * a.D * 8 + 16;
+    GGML_ASSERT(smem <= 160 * 1024);
+    attn_decode_kernel<<<a.H, ATTN_THREADS, smem, s>>>(a);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// embedding sum: out = (((e_0 + e_1) + e_2) + ...), e_i = dequant(table_i[row idx_i]) * scale_i
+// (src/moshi/models/lm.h:555-584, lm_utils.h:157-170); same left-to-right float order as the graph
+// ---------------------------------------------------------------------------------------------------
+__global__ void embed_sum_kernel(embed_sum_args a) {
+    const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.K) return;
+    float acc = 0.f;
+    for (int t = 0; t < a.n; t++) {
+        const embed_src & e = a.src[t];
+        int64_t r = *e.index;
+        if (r < 0 || r >= e.n_rows) r = 0;
+        float v = dequant_elem(e.table + r * e.row_bytes, e.type, i);
+        if (e.scale) v = v * *e.scale;
+        acc = t == 0 ? v : acc + v;
+    }
+    a.out[i] = acc;
+}
+void k_embed_sum(hipStream_t s, const embed_sum_args & a) {
+    embed_sum_kernel<<<(int) ((a.K + 255) / 256), 256, 0, s>>>(a);
+}

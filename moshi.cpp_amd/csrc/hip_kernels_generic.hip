@@ -1,0 +1,585 @@
+// hip_kernels_generic.hip — one gfx950 kernel per ggml operator, covering every op the
+// moshi.cpp graphs emit with arbitrary strides. These are the always-correct fallbacks; the per-frame
+// hot path goes through the fused kernels in hip_kernels_fused.hip wherever the planner matches.
+//
+// Numerics follow the ggml CPU semantics the oracle restates (oracle/oracle.cpp): double accumulators
+// for norms / soft_max / sums / float dots, activations rounded to the weight's dot type in mul_mat.
+#include "hip_common.h"
+#include "hip_device.h"
+
+#define BLOCK 256
+
+static inline int nblocks(int64_t n, int bs = BLOCK) { return (int) ((n + bs - 1) / bs); }
+
+// ---------------------------------------------------------------------------------------------------
+// elementwise
+// ---------------------------------------------------------------------------------------------------
+__global__ void binary_kernel(int op, tdesc dst, tdesc a, tdesc b, int64_t n) {
+    const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int64_t i0, i1, i2, i3;
+    unravel(dst, i, i0, i1, i2, i3);
+    const float x = *(const float *) at(a, i0, i1, i2, i3);
+    const float y = *(const float *) at(b, i0 % b.ne[0], i1 % b.ne[1], i2 % b.ne[2], i3 % b.ne[3]);
+    float r;
+    switch (op) {
+        case GGML_OP_ADD: r = x + y; break;
+        case GGML_OP_SUB: r = x - y; break;
+        case GGML_OP_MUL: r = x * y; break;
+        default:          r = x / y; break;
+    }
+    *(float *) at(dst, i0, i1, i2, i3) = r;
+}
+void k_binary(hipStream_t s, int op, tdesc dst, tdesc a, tdesc b) {
+    const int64_t n = td_nelements(dst);
+    if (n == 0) return;
+    GGML_ASSERT(dst.type == GGML_TYPE_F32 && a.type == GGML_TYPE_F32 && b.type == GGML_TYPE_F32);
+    binary_kernel<<<nblocks(n), BLOCK, 0, s>>>(op, dst, a, b, n);
+}
+
+__global__ void unary_kernel(int uop, tdesc dst, tdesc a, int64_t n) {
+    const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int64_t i0, i1, i2, i3;
+    unravel(dst, i, i0, i1, i2, i3);
+    const float x = *(const float *) at(a, i0, i1, i2, i3);
+    *(float *) at(dst, i0, i1, i2, i3) = apply_unary(uop, x);
+}
+void k_unary(hipStream_t s, int uop, tdesc dst, tdesc a) {
+    const int64_t n = td_nelements(dst);
+    if (n == 0) return;
+    GGML_ASSERT(dst.type == GGML_TYPE_F32 && a.type == GGML_TYPE_F32);
+    unary_kernel<<<nblocks(n), BLOCK, 0, s>>>(uop, dst, a, n);
+}
+
+__global__ void scale_kernel(tdesc dst, tdesc a, float sc, float bias, float mn, float mx, int clamp, int64_t n) {
+    const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int64_t i0, i1, i2, i3;
+    unravel(dst, i, i0, i1, i2, i3);
+    const float x = *(const float *) at(a, i0, i1, i2, i3);
+    *(float *) at(dst, i0, i1, i2, i3) = clamp ? (x < mn ? mn : x > mx ? mx : x) : x * sc + bias;
+}
+void k_scale(hipStream_t s, tdesc dst, tdesc a, float scale, float bias) {
+    const int64_t n = td_nelements(dst);
+    if (n) scale_kernel<<<nblocks(n), BLOCK, 0, s>>>(dst, a, scale, bias, 0, 0, 0, n);
+}
+void k_clamp(hipStream_t s, tdesc dst, tdesc a, float mn, float mx) {
+    const int64_t n = td_nelements(dst);
+    if (n) scale_kernel<<<nblocks(n), BLOCK, 0, s>>>(dst, a, 0, 0, mn, mx, 1, n);
+}
+
+// logical-order, type-converting copy; shapes may differ as long as the element counts match
+__global__ void cpy_kernel(tdesc dst, tdesc src, int64_t n) {
+    const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int64_t s0, s1, s2, s3, d0, d1, d2, d3;
+    unravel(src, i, s0, s1, s2, s3);
+    unravel(dst, i, d0, d1, d2, d3);
+    const char * sp = at(src, s0, s1, s2, s3);
+    char * dp = at(dst, d0, d1, d2, d3);
+    if (src.type == dst.type) {
+        switch (elem_size(src.type)) {
+            case 4: *(uint32_t *) dp = *(const uint32_t *) sp; break;
+            case 2: *(uint16_t *) dp = *(const uint16_t *) sp; break;
+            case 8: *(uint64_t *) dp = *(const uint64_t *) sp; break;
+            default: *dp = *sp; break;
+        }
+    } else {
+        st_from_f32(dp, dst.type, ld_as_f32(sp, src.type));
+    }
+}
+void k_cpy(hipStream_t s, tdesc dst, tdesc src) {
+    const int64_t n = td_nelements(src);
+    if (n == 0) return;
+    GGML_ASSERT(n == td_nelements(dst));
+    const bool q = ggml_is_quantized((enum ggml_type) src.type) || ggml_is_quantized((enum ggml_type) dst.type);
+    if (q) {
+        // only the byte-identical contiguous case is needed on-device (weights are quantised at load time)
+        GGML_ASSERT(src.type == dst.type && "on-device (re)quantisation is not implemented; quantise on the host");
+        const size_t bytes = ggml_row_size((enum ggml_type) src.type, src.ne[0]) * (size_t) (src.ne[1] * src.ne[2] * src.ne[3]);
+        HIP_CHECK(hipMemcpyAsync(dst.data, src.data, bytes, hipMemcpyDeviceToDevice, s));
+        return;
+    }
+    cpy_kernel<<<nblocks(n), BLOCK, 0, s>>>(dst, src, n);
+}
+
+__global__ void concat_kernel(tdesc dst, tdesc a, tdesc b, int dim, int es, int64_t n) {
+    const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int64_t c[4];
+    unravel(dst, i, c[0], c[1], c[2], c[3]);
+    const bool in_a = c[dim] < a.ne[dim];
+    const char * sp;
+    if (in_a) sp = at(a, c[0], c[1], c[2], c[3]);
+    else { c[dim] -= a.ne[dim]; sp = at(b, c[0], c[1], c[2], c[3]); c[dim] += a.ne[dim]; }
+    char * dp = at(dst, c[0], c[1], c[2], c[3]);
+    if (es == 4) *(uint32_t *) dp = *(const uint32_t *) sp; else if (es == 2) *(uint16_t *) dp = *(const uint16_t *) sp; else *dp = *sp;
+}
+void k_concat(hipStream_t s, tdesc dst, tdesc a, tdesc b, int dim) {
+    const int64_t n = td_nelements(dst);
+    if (n) concat_kernel<<<nblocks(n), BLOCK, 0, s>>>(dst, a, b, dim, (int) ggml_type_size((enum ggml_type) dst.type), n);
+}
+
+__global__ void repeat_kernel(tdesc dst, tdesc a, int es, int pad, int64_t n) {
+    const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int64_t i0, i1, i2, i3;
+    unravel(dst, i, i0, i1, i2, i3);
+    char * dp = at(dst, i0, i1, i2, i3);
+    if (pad) {
+        const bool in = i0 < a.ne[0] && i1 < a.ne[1] && i2 < a.ne[2] && i3 < a.ne[3];
+        *(float *) dp = in ? *(const float *) at(a, i0, i1, i2, i3) : 0.f;
+        return;
+    }
+    const char * sp = at(a, i0 % a.ne[0], i1 % a.ne[1], i2 % a.ne[2], i3 % a.ne[3]);
+    if (es == 4) *(uint32_t *) dp = *(const uint32_t *) sp; else if (es == 2) *(uint16_t *) dp = *(const uint16_t *) sp; else *dp = *sp;
+}
+void k_repeat(hipStream_t s, tdesc dst, tdesc a) {
+    const int64_t n = td_nelements(dst);
+    if (n) repeat_kernel<<<nblocks(n), BLOCK, 0, s>>>(dst, a, (int) ggml_type_size((enum ggml_type) dst.type), 0, n);
+}
+void k_pad(hipStream_t s, tdesc dst, tdesc a) {
+    const int64_t n = td_nelements(dst);
+    if (n) repeat_kernel<<<nblocks(n), BLOCK, 0, s>>>(dst, a, 4, 1, n);
+}
+
+__global__ void arange_kernel(float * dst, float start, float step, int64_t n) {
+    const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = start + step * (float) i;
+}
+void k_arange(hipStream_t s, tdesc dst, float start, float step) {
+    const int64_t n = dst.ne[0];
+    if (n) arange_kernel<<<nblocks(n), BLOCK, 0, s>>>((float *) dst.data, start, step, n);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// reductions (one block per row)
+// ---------------------------------------------------------------------------------------------------
+__device__ inline double block_sum_f64(double v, double * sh) {
+    const int tid = threadIdx.x;
+    v = wave_sum_f64(v);
+    __syncthreads();
+    if ((tid & 63) == 0) sh[tid >> 6] = v;
+    __syncthreads();
+    double r = 0;
+    for (int w = 0; w < (int) (blockDim.x >> 6); w++) r += sh[w];
+    return r;
+}
+__device__ inline float block_max_f32(float v, float * sh) {
+    const int tid = threadIdx.x;
+    v = wave_max_f32(v);
+    __syncthreads();
+    if ((tid & 63) == 0) sh[tid >> 6] = v;
+    __syncthreads();
+    float r = -INFINITY;
+    for (int w = 0; w < (int) (blockDim.x >> 6); w++) r = fmaxf(r, sh[w]);
+    return r;
+}
+
+__global__ void sum_rows_kernel(tdesc dst, tdesc a) {
+    __shared__ double sh[BLOCK / 64];
+    int64_t i1, i2, i3;
+    row_coords(a, blockIdx.x, i1, i2, i3);
+    double acc = 0;
+    for (int64_t i0 = threadIdx.x; i0 < a.ne[0]; i0 += blockDim.x) acc += (double) *(const float *) at(a, i0, i1, i2, i3);
+    acc = block_sum_f64(acc, sh);
+    if (threadIdx.x == 0) *(float *) at(dst, 0, i1, i2, i3) = (float) acc;
+}
+void k_sum_rows(hipStream_t s, tdesc dst, tdesc a) {
+    const int64_t rows = a.ne[1] * a.ne[2] * a.ne[3];
+    if (rows) sum_rows_kernel<<<(int) rows, BLOCK, 0, s>>>(dst, a);
+}
+__global__ void sum_all_kernel(tdesc dst, tdesc a, int64_t n) {
+    __shared__ double sh[BLOCK / 64];
+    double acc = 0;
+    for (int64_t i = threadIdx.x; i < n; i += blockDim.x) {
+        int64_t i0, i1, i2, i3;
+        unravel(a, i, i0, i1, i2, i3);
+        acc += (double) *(const float *) at(a, i0, i1, i2, i3);
+    }
+    acc = block_sum_f64(acc, sh);
+    if (threadIdx.x == 0) *(float *) dst.data = (float) acc;
+}
+void k_sum_all(hipStream_t s, tdesc dst, tdesc a) { sum_all_kernel<<<1, BLOCK, 0, s>>>(dst, a, td_nelements(a)); }
+
+__global__ void argmax_kernel(tdesc dst, tdesc a) {
+    __shared__ float shv[BLOCK];
+    __shared__ int shi[BLOCK];
+    const int64_t i1 = blockIdx.x;
+    float best = -INFINITY; int bi = 0x7fffffff;
+    for (int64_t i0 = threadIdx.x; i0 < a.ne[0]; i0 += blockDim.x) {
+        const float v = *(const float *) at(a, i0, i1, 0, 0);
+        if (v > best) { best = v; bi = (int) i0; }
+    }
+    shv[threadIdx.x] = best; shi[threadIdx.x] = bi;
+    __syncthreads();
+    for (int st = BLOCK / 2; st > 0; st >>= 1) {
+        if ((int) threadIdx.x < st) {
+            const float v = shv[threadIdx.x + st]; const int j = shi[threadIdx.x + st];
+            if (v > shv[threadIdx.x] || (v == shv[threadIdx.x] && j < shi[threadIdx.x])) { shv[threadIdx.x] = v; shi[threadIdx.x] = j; }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) ((int32_t *) dst.data)[i1] = shi[0] == 0x7fffffff ? 0 : shi[0];
+}
+void k_argmax(hipStream_t s, tdesc dst, tdesc a) { if (a.ne[1]) argmax_kernel<<<(int) a.ne[1], BLOCK, 0, s>>>(dst, a); }
+
+// rank-by-counting sort: rank_i = #{j : v_j before v_i}; ties keep the lower index first (stable)
+__global__ void argsort_kernel(tdesc dst, tdesc a, int desc) {
+    __shared__ float tile[BLOCK];
+    int64_t i1, i2, i3;
+    row_coords(a, blockIdx.y, i1, i2, i3);
+    const int64_t n = a.ne[0];
+    const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    const float vi = i < n ? *(const float *) at(a, i, i1, i2, i3) : 0.f;
+    int rank = 0;
+    for (int64_t base = 0; base < n; base += BLOCK) {
+        const int64_t j = base + threadIdx.x;
+        __syncthreads();
+        tile[threadIdx.x] = j < n ? *(const float *) at(a, j, i1, i2, i3) : 0.f;
+        __syncthreads();
+        const int lim = (int) (n - base < BLOCK ? n - base : BLOCK);
+        for (int t = 0; t < lim; t++) {
+            const float vj = tile[t];
+            const bool before = desc ? (vj > vi) : (vj < vi);
+            rank += (before || (vj == vi && base + t < i)) ? 1 : 0;
+        }
+    }
+    if (i < n) *(int32_t *) at(dst, rank, i1, i2, i3) = (int32_t) i;
+}
+void k_argsort(hipStream_t s, tdesc dst, tdesc a, int desc) {
+    const int64_t rows = a.ne[1] * a.ne[2] * a.ne[3];
+    if (rows == 0 || a.ne[0] == 0) return;
+    argsort_kernel<<<dim3(nblocks(a.ne[0]), (unsigned) rows), BLOCK, 0, s>>>(dst, a, desc);
+}
+
+__global__ void norm_kernel(tdesc dst, tdesc a, float eps, int rms) {
+    __shared__ double sh[BLOCK / 64];
+    int64_t i1, i2, i3;
+    row_coords(a, blockIdx.x, i1, i2, i3);
+    const float * x = (const float *) at(a, 0, i1, i2, i3);
+    float * y = (float *) at(dst, 0, i1, i2, i3);
+    const int64_t n = a.ne[0];
+    float mean = 0.f;
+    if (!rms) {
+        double acc = 0;
+        for (int64_t i = threadIdx.x; i < n; i += blockDim.x) acc += (double) x[i];
+        mean = (float) (block_sum_f64(acc, sh) / (double) n);
+    }
+    double acc2 = 0;
+    for (int64_t i = threadIdx.x; i < n; i += blockDim.x) { const float v = x[i] - mean; acc2 += (double) (v * v); }
+    const float var = (float) (block_sum_f64(acc2, sh) / (double) n);
+    const float scale = 1.0f / sqrtf(var + eps);
+    for (int64_t i = threadIdx.x; i < n; i += blockDim.x) y[i] = (x[i] - mean) * scale;
+}
+void k_norm(hipStream_t s, tdesc dst, tdesc a, float eps, int rms) {
+    const int64_t rows = a.ne[1] * a.ne[2] * a.ne[3];
+    GGML_ASSERT(a.nb[0] == 4 && dst.nb[0] == 4);
+    if (rows) norm_kernel<<<(int) rows, BLOCK, 0, s>>>(dst, a, eps, rms);
+}
+
+__global__ void soft_max_kernel(tdesc dst, tdesc a, tdesc mask, int has_mask, float scale) {
+    __shared__ double shd[BLOCK / 64];
+    __shared__ float shf[BLOCK / 64];
+    int64_t i1, i2, i3;
+    row_coords(a, blockIdx.x, i1, i2, i3);
+    const float * x = (const float *) at(a, 0, i1, i2, i3);
+    float * y = (float *) at(dst, 0, i1, i2, i3);
+    const char * mp = has_mask ? at(mask, 0, i1, i2 % mask.ne[2], i3 % mask.ne[3]) : nullptr;
+    const int64_t n = a.ne[0];
+    float mx = -INFINITY;
+    for (int64_t i = threadIdx.x; i < n; i += blockDim.x) {
+        float v = x[i] * scale;
+        if (has_mask) v += mask.type == GGML_TYPE_F16 ? h2f(((const uint16_t *) mp)[i]) : ((const float *) mp)[i];
+        mx = fmaxf(mx, v);
+    }
+    mx = block_max_f32(mx, shf);
+    double sum = 0;
+    for (int64_t i = threadIdx.x; i < n; i += blockDim.x) {
+        float v = x[i] * scale;
+        if (has_mask) v += mask.type == GGML_TYPE_F16 ? h2f(((const uint16_t *) mp)[i]) : ((const float *) mp)[i];
+        const float e = expf(v - mx);
+        y[i] = e;
+        sum += (double) e;
+    }
+    sum = block_sum_f64(sum, shd);
+    const float inv = (float) (1.0 / sum);
+    for (int64_t i = threadIdx.x; i < n; i += blockDim.x) y[i] *= inv;
+}
+void k_soft_max(hipStream_t s, tdesc dst, tdesc a, tdesc mask, int has_mask, float scale) {
+    const int64_t rows = a.ne[1] * a.ne[2] * a.ne[3];
+    if (rows) soft_max_kernel<<<(int) rows, BLOCK, 0, s>>>(dst, a, mask, has_mask, scale);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// gather / scatter of rows
+// ---------------------------------------------------------------------------------------------------
+__global__ void get_rows_kernel(tdesc dst, tdesc a, tdesc idx) {
+    const int64_t i10 = blockIdx.x, i11 = blockIdx.y, i12 = blockIdx.z;
+    const int64_t r = *(const int32_t *) at(idx, i10, i11, i12, 0);
+    const char * row = at(a, 0, r, i11, i12);
+    float * out = (float *) at(dst, 0, i10, i11, i12);
+    const int64_t n = a.ne[0];
+    if (r < 0 || r >= a.ne[1]) { for (int64_t i = threadIdx.x; i < n; i += blockDim.x) out[i] = NAN; return; }
+    for (int64_t i = threadIdx.x; i < n; i += blockDim.x) {
+        if (a.type == GGML_TYPE_I32) ((int32_t *) out)[i] = ((const int32_t *) row)[i];
+        else out[i] = dequant_elem(row, a.type, i);
+    }
+}
+void k_get_rows(hipStream_t s, tdesc dst, tdesc a, tdesc idx) {
+    if (td_nelements(idx) == 0) return;
+    get_rows_kernel<<<dim3((unsigned) idx.ne[0], (unsigned) idx.ne[1], (unsigned) idx.ne[2]), BLOCK, 0, s>>>(dst, a, idx);
+}
+
+__global__ void set_rows_kernel(tdesc dst, tdesc src, tdesc idx) {
+    const int64_t i = blockIdx.x, i02 = blockIdx.y, i03 = blockIdx.z;
+    const char * ip = at(idx, i, i02 % idx.ne[1], i03 % idx.ne[2], 0);
+    const int64_t r = idx.type == GGML_TYPE_I64 ? *(const int64_t *) ip : (int64_t) *(const int32_t *) ip;
+    if (r < 0 || r >= dst.ne[1]) return;
+    const float * sp = (const float *) at(src, 0, i, i02, i03);
+    char * out = at(dst, 0, r, i02, i03);
+    const int es = elem_size(dst.type);
+    for (int64_t k = threadIdx.x; k < src.ne[0]; k += blockDim.x) st_from_f32(out + k * es, dst.type, sp[k]);
+}
+void k_set_rows(hipStream_t s, tdesc dst, tdesc src, tdesc idx) {
+    if (td_nelements(src) == 0) return;
+    GGML_ASSERT(!ggml_is_quantized((enum ggml_type) dst.type));
+    const int bs = src.ne[0] >= 256 ? 256 : 64;
+    set_rows_kernel<<<dim3((unsigned) src.ne[1], (unsigned) src.ne[2], (unsigned) src.ne[3]), bs, 0, s>>>(dst, src, idx);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// convolution helpers and positional embedding
+// ---------------------------------------------------------------------------------------------------
+__global__ void im2col_kernel(tdesc dst, tdesc x, int64_t K, int s0, int p0, int d0, int64_t n) {
+    const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int64_t c, iow, in, z;
+    unravel(dst, i, c, iow, in, z);
+    const int64_t ic = c / K, ik = c % K;
+    const int64_t iiw = iow * s0 + ik * d0 - p0;
+    const float v = (iiw < 0 || iiw >= x.ne[0]) ? 0.f : *(const float *) at(x, iiw, ic, in, 0);
+    st_from_f32(at(dst, c, iow, in, 0), dst.type, v);
+}
+void k_im2col(hipStream_t s, tdesc dst, tdesc x, int64_t K, int s0, int p0, int d0) {
+    const int64_t n = td_nelements(dst);
+    GGML_ASSERT(x.type == GGML_TYPE_F32);
+    if (n) im2col_kernel<<<nblocks(n), BLOCK, 0, s>>>(dst, x, K, s0, p0, d0, n);
+}
+
+// one thread per output sample (t, oc); contributions are added in ascending input position, which is
+// the order the CPU reference accumulates them in
+__global__ void conv_transpose_1d_kernel(tdesc dst, tdesc w, tdesc x, int s0, int64_t n) {
+    const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int64_t t = i % dst.ne[0], oc = i / dst.ne[0];
+    const int64_t K = w.ne[0], IC = w.ne[2], L = x.ne[0];
+    const bool f16 = w.type == GGML_TYPE_F16;
+    float acc = 0.f;
+    int64_t l0 = (t - (K - 1) + s0 - 1) / s0;
+    if (l0 < 0) l0 = 0;
+    for (int64_t l = l0; l < L && l * s0 <= t; l++) {
+        const int64_t k = t - l * s0;
+        if (k >= K) continue;
+        double v = 0;
+        for (int64_t ic = 0; ic < IC; ic++) {
+            float xv = *(const float *) at(x, l, ic, 0, 0);
+            float wv;
+            if (f16) { xv = h2f(f2h(xv)); wv = h2f(*(const uint16_t *) at(w, k, oc, ic, 0)); }
+            else wv = *(const float *) at(w, k, oc, ic, 0);
+            v += (double) (xv * wv);
+        }
+        acc += (float) v;
+    }
+    *(float *) at(dst, t, oc, 0, 0) = acc;
+}
+void k_conv_transpose_1d(hipStream_t s, tdesc dst, tdesc w, tdesc x, int s0) {
+    const int64_t n = dst.ne[0] * dst.ne[1];
+    GGML_ASSERT(x.type == GGML_TYPE_F32 && (w.type == GGML_TYPE_F32 || w.type == GGML_TYPE_F16));
+    if (n) conv_transpose_1d_kernel<<<nblocks(n), BLOCK, 0, s>>>(dst, w, x, s0, n);
+}
+
+__global__ void timestep_embedding_kernel(tdesc dst, tdesc ts, int dim, int max_period) {
+    const int64_t i = blockIdx.x;
+    const int half = dim / 2;
+    float * e = (float *) at(dst, 0, i, 0, 0);
+    const float t = *(const float *) at(ts, i, 0, 0, 0);
+    for (int j = threadIdx.x; j < half; j += blockDim.x) {
+        const float freq = expf(-logf((float) max_period) * j / half);
+        const float arg = t * freq;
+        e[j] = cosf(arg);
+        e[j + half] = sinf(arg);
+    }
+    if (threadIdx.x == 0 && (dim & 1)) e[2 * half] = 0.f;
+}
+void k_timestep_embedding(hipStream_t s, tdesc dst, tdesc ts, int dim, int max_period) {
+    if (ts.ne[0]) timestep_embedding_kernel<<<(int) ts.ne[0], 64, 0, s>>>(dst, ts, dim, max_period);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// generic matrix product
+// ---------------------------------------------------------------------------------------------------
+static int vec_dot_type(int t) {
+    switch (t) {
+        case GGML_TYPE_F32: return GGML_TYPE_F32;
+        case GGML_TYPE_F16: return GGML_TYPE_F16;
+        case GGML_TYPE_BF16: return GGML_TYPE_BF16;
+        case GGML_TYPE_Q4_0: case GGML_TYPE_Q8_0: return GGML_TYPE_Q8_0;
+        case GGML_TYPE_Q4_K: return GGML_TYPE_Q8_K;
+        default: GGML_ABORT("mul_mat: unsupported weight type %s", ggml_type_name((enum ggml_type) t));
+    }
+}
+
+size_t k_mul_mat_ws_size(const struct ggml_tensor * a, const struct ggml_tensor * b) {
+    const int vt = vec_dot_type(a->type);
+    return ggml_row_size((enum ggml_type) vt, b->ne[0]) * (size_t) (b->ne[1] * b->ne[2] * b->ne[3]) + 256;
+}
+
+// converts one activation row per block to the dot type (dense rows in ws)
+__global__ void convert_rows_kernel(tdesc b, int vt, char * ws, int64_t row_bytes) {
+    __shared__ float shf[BLOCK / 64];
+    int64_t i1, i2, i3;
+    row_coords(b, blockIdx.x, i1, i2, i3);
+    char * out = ws + (int64_t) blockIdx.x * row_bytes;
+    const int64_t K = b.ne[0];
+    if (vt == GGML_TYPE_F32 || vt == GGML_TYPE_F16 || vt == GGML_TYPE_BF16) {
+        const int es = elem_size(vt);
+        for (int64_t i = threadIdx.x; i < K; i += blockDim.x) st_from_f32(out + i * es, vt, ld_as_f32(at(b, i, i1, i2, i3), b.type));
+        return;
+    }
+    if (vt == GGML_TYPE_Q8_0) {
+        // one wave-lane group of 32 per block: thread t handles element t of block (t/32)
+        for (int64_t base = 0; base < K; base += blockDim.x) {
+            const int64_t i = base + threadIdx.x;
+            const float v = i < K ? *(const float *) at(b, i, i1, i2, i3) : 0.f;
+            float amax = fabsf(v);
+            for (int o = 16; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
+            const float d = amax / 127.f;
+            const float id = d ? 1.0f / d : 0.0f;
+            if (i < K) {
+                block_q8_0 * blk = (block_q8_0 *) out + i / 32;
+                blk->qs[i % 32] = (int8_t) roundf(v * id);
+                if (i % 32 == 0) blk->d = f2h(d);
+            }
+        }
+        return;
+    }
+    // Q8_K: 256 threads = one super-block per iteration
+    for (int64_t base = 0; base < K; base += 256) {
+        const int tid = threadIdx.x;
+        const float v = *(const float *) at(b, base + tid, i1, i2, i3);
+        // signed value of the element with the largest magnitude (first one on ties)
+        float amax = fabsf(v); int ai = tid;
+        for (int o = 32; o > 0; o >>= 1) {
+            const float oa = __shfl_xor(amax, o, 64); const int oi = __shfl_xor(ai, o, 64);
+            if (oa > amax || (oa == amax && oi < ai)) { amax = oa; ai = oi; }
+        }
+        __shared__ float s_amax[4]; __shared__ int s_ai[4]; __shared__ float s_vals[256]; __shared__ int s_q[256];
+        __syncthreads();
+        s_vals[tid] = v;
+        if ((tid & 63) == 0) { s_amax[tid >> 6] = amax; s_ai[tid >> 6] = ai; }
+        __syncthreads();
+        float bm = s_amax[0]; int bi = s_ai[0];
+        for (int w = 1; w < 4; w++) if (s_amax[w] > bm || (s_amax[w] == bm && s_ai[w] < bi)) { bm = s_amax[w]; bi = s_ai[w]; }
+        block_q8_K * blk = (block_q8_K *) out + base / 256;
+        int q = 0;
+        float dd = 0.f;
+        if (bm != 0.f) {
+            const float iscale = -127.f / s_vals[bi];
+            q = nearest_int_dev(iscale * v);
+            q = q < 127 ? q : 127;
+            dd = 1.f / iscale;
+        }
+        blk->qs[tid] = (int8_t) q;
+        s_q[tid] = q;
+        __syncthreads();
+        if (tid < 16) { int sum = 0; for (int l = 0; l < 16; l++) sum += s_q[tid * 16 + l]; blk->bsums[tid] = (int16_t) sum; }
+        if (tid == 0) blk->d = dd;
+        (void) shf;
+    }
+}
+
+// one wave per output element; lanes stride the K dimension (in blocks for quantised types)
+__global__ void mul_mat_kernel(tdesc dst, tdesc a, tdesc b, const char * ws, int64_t ws_row_bytes, int vt, int64_t total) {
+    const int lane = threadIdx.x & 63;
+    const int64_t o = (int64_t) blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (o >= total) return;
+    int64_t m, n, i2, i3;
+    unravel(dst, o, m, n, i2, i3);
+    const int64_t r2 = b.ne[2] / a.ne[2], r3 = b.ne[3] / a.ne[3];
+    const char * w = at(a, 0, m, i2 / r2, i3 / r3);
+    const char * y = ws + (n + b.ne[1] * (i2 + b.ne[2] * i3)) * ws_row_bytes;
+    const int64_t K = a.ne[0];
+    float result;
+    if (a.type == GGML_TYPE_F32 || a.type == GGML_TYPE_F16 || a.type == GGML_TYPE_BF16) {
+        double acc = 0;
+        if (a.type == GGML_TYPE_F32)       for (int64_t k = lane; k < K; k += 64) acc += (double) (((const float *) w)[k] * ((const float *) y)[k]);
+        else if (a.type == GGML_TYPE_F16)  for (int64_t k = lane; k < K; k += 64) acc += (double) (h2f(((const uint16_t *) w)[k]) * h2f(((const uint16_t *) y)[k]));
+        else                               for (int64_t k = lane; k < K; k += 64) acc += (double) (bf2f(((const uint16_t *) w)[k]) * bf2f(((const uint16_t *) y)[k]));
+        result = (float) wave_sum_f64(acc);
+    } else if (a.type == GGML_TYPE_Q8_0) {
+        float acc = 0;
+        for (int64_t ib = lane; ib < K / 32; ib += 64) {
+            const block_q8_0 * xb = (const block_q8_0 *) w + ib; const block_q8_0 * yb = (const block_q8_0 *) y + ib;
+            int sumi = 0;
+            for (int j = 0; j < 32; j++) sumi += xb->qs[j] * yb->qs[j];
+            acc += sumi * (h2f(xb->d) * h2f(yb->d));
+        }
+        result = wave_sum_f32(acc);
+    } else if (a.type == GGML_TYPE_Q4_0) {
+        float acc = 0;
+        for (int64_t ib = lane; ib < K / 32; ib += 64) {
+            const block_q4_0 * xb = (const block_q4_0 *) w + ib; const block_q8_0 * yb = (const block_q8_0 *) y + ib;
+            int sumi = 0;
+            for (int j = 0; j < 16; j++) {
+                const int v0 = (xb->qs[j] & 0x0F) - 8, v1 = (xb->qs[j] >> 4) - 8;
+                sumi += v0 * yb->qs[j] + v1 * yb->qs[j + 16];
+            }
+            acc += sumi * h2f(xb->d) * h2f(yb->d);
+        }
+        result = wave_sum_f32(acc);
+    } else {   // Q4_K x Q8_K
+        float acc = 0;
+        for (int64_t ib = lane; ib < K / 256; ib += 64) {
+            const block_q4_K * xb = (const block_q4_K *) w + ib; const block_q8_K * yb = (const block_q8_K *) y + ib;
+            acc += q4k_q8k_block_dot(xb, yb->qs, yb->bsums, yb->d);
+        }
+        result = wave_sum_f32(acc);
+    }
+    if (lane == 0) *(float *) at(dst, m, n, i2, i3) = result;
+}
+
+void k_mul_mat(hipStream_t s, tdesc dst, tdesc a, tdesc b, void * ws) {
+    const int64_t total = td_nelements(dst);
+    if (total == 0) return;
+    const int vt = vec_dot_type(a.type);
+    GGML_ASSERT(a.nb[0] == (int64_t) ggml_type_size((enum ggml_type) a.type));
+    GGML_ASSERT(b.type == GGML_TYPE_F32 || b.type == vt);
+    if (vt == GGML_TYPE_Q8_0 || vt == GGML_TYPE_Q8_K) GGML_ASSERT(b.type == GGML_TYPE_F32);
+    if (vt == GGML_TYPE_Q8_K) GGML_ASSERT(a.ne[0] % 256 == 0);
+    const int64_t row_bytes = (int64_t) ggml_row_size((enum ggml_type) vt, b.ne[0]);
+    const int64_t rows = b.ne[1] * b.ne[2] * b.ne[3];
+    const char * y = (const char *) ws;
+    const bool direct = b.type == vt && b.nb[0] == (int64_t) ggml_type_size((enum ggml_type) vt) && b.nb[1] == row_bytes &&
+                        b.nb[2] == row_bytes * b.ne[1] && b.nb[3] == b.nb[2] * b.ne[2];
+    if (direct) y = b.data;
+    else convert_rows_kernel<<<(int) rows, BLOCK, 0, s>>>(b, vt, (char *) ws, row_bytes);
+    mul_mat_kernel<<<nblocks(total, 4), 256, 0, s>>>(dst, a, b, y, row_bytes, vt, total);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// batched small uploads
+// ---------------------------------------------------------------------------------------------------
+__global__ void scatter_uploads_kernel(const upload_desc * descs, const char * blob) {
+    const upload_desc d = descs[blockIdx.x];
+    const char * src = blob + d.offset;
+    if (((uintptr_t) d.dst & 3) == 0 && (d.size & 3) == 0) {
+        for (uint32_t i = threadIdx.x; i < d.size / 4; i += blockDim.x) ((uint32_t *) d.dst)[i] = ((const uint32_t *) src)[i];
+    } else {
+        for (uint32_t i = threadIdx.x; i < d.size; i += blockDim.x) d.dst[i] = src[i];
+    }
+}
+void k_scatter_uploads(hipStream_t s, const upload_desc * descs, const char * blob, int n) {
+    if (n > 0) scatter_uploads_kernel<<<n, 64, 0, s>>>(descs, blob);
+}

@@ -1,0 +1,266 @@
+"""-m gpu: every ggml op the moshi.cpp graphs emit, MI355X backend vs the CPU oracle on
+the same seeded inputs, through the C-ABI. F32 tolerance: |a-b| <= 1e-5 * max|ref| (the reference's own
+replay tolerance for ggml_graph_compute_with_ctx, src/replay.h:333-341); I32 exact."""
+import numpy as np
+import pytest
+
+import ggml_util as gu
+from ggml_util import BF16, F16, F32, I32, Q4_0, Q4_K, Q8_0
+
+pytestmark = pytest.mark.gpu
+
+rng = np.random.default_rng(7)
+
+
+def rnd(*shape):
+    return rng.standard_normal(shape).astype(np.float32)
+
+
+@pytest.mark.parametrize("op", ["add", "sub", "mul", "div"])
+def test_binary_broadcast(op):
+    a, b = rnd(3, 5, 33), rnd(1, 5, 1) + 3.0
+
+    def build(g):
+        return [getattr(g, op)(g.input(a), g.input(b))]
+    gu.compare(build, atol_rel=0, rtol=0)
+
+
+def test_binary_strided_views():
+    a, w = rnd(1, 512, 1), rnd(512, 1, 4)
+
+    def build(g):
+        x = g.input(a)            # [1, 512]
+        wt = g.input(w)           # [4, 1, 512]
+        outs = []
+        for i in range(4):        # the depthwise upsample trick of conv.h:262-278
+            sub = g.view_3d(wt, 1, 512, 1, wt.contents.nb[2], wt.contents.nb[2], wt.contents.nb[0] * i)
+            outs.append(g.mul(x, sub))
+        y = outs[0]
+        for o in outs[1:]:
+            y = g.concat(y, o, 0)
+        return [y]
+    gu.compare(build, atol_rel=0, rtol=0)
+
+
+@pytest.mark.parametrize("uop", ["neg", "silu", "gelu", "elu"])
+def test_unary(uop):
+    a = rnd(7, 129) * 3
+
+    def build(g):
+        return [getattr(g, uop)(g.input(a))]
+    gu.compare(build, atol_rel=2e-3 if uop == "gelu" else 1e-6)   # gelu: one f16 ulp of the table semantics
+
+
+def test_scale_clamp_inplace():
+    a = rnd(4, 100)
+
+    def build(g):
+        x = g.input(a)
+        y = g.scale(x, 0.37)
+        c = g.clamp(y, -0.2, 0.3)     # in place on y
+        z = g.add(c, y)               # y already clamped (order semantics)
+        return [z]
+    gu.compare(build, atol_rel=0, rtol=0)
+
+
+def test_sum_sumrows_argmax():
+    a = rnd(3, 4, 1000)
+    m = rnd(5, 2048)
+    m[2, 7] = m[2, 900] = 50.0      # tie: first index wins
+
+    def build(g):
+        x = g.input(a)
+        return [g.sum(x), g.sum_rows(x), g.argmax(g.input(m))]
+    gu.compare(build, atol_rel=1e-6)
+
+
+def test_argsort_topk():
+    a = rnd(3, 300)
+    a[1, 10] = a[1, 200]            # tie: lower index first
+
+    def build(g):
+        x = g.input(a)
+        return [g.cont(g.argsort_top_k(x, 25)), g.argsort(x, 0)]
+    gu.compare(build)
+
+
+def test_norm_rmsnorm():
+    a = rnd(2, 4096) * 2 + 0.5
+
+    def build(g):
+        x = g.input(a)
+        return [g.rms_norm(x, 1e-8), g.norm(x, 1e-5)]
+    gu.compare(build, atol_rel=1e-6)
+
+
+def test_soft_max_ext_mask():
+    a = rnd(4, 2, 300)
+    mask = np.zeros((2, 300), np.float32)
+    mask[0, 100:] = -np.inf
+    mask[1, 250:] = -np.inf
+
+    def build(g):
+        return [g.soft_max_ext(g.input(a), g.input(mask), 0.125, 0.0), g.soft_max(g.input(a))]
+    gu.compare(build, atol_rel=1e-6)
+
+
+def test_cpy_cast_cont_permute():
+    a = rnd(2, 3, 4, 8)
+    idx = rng.integers(0, 100, (6,)).astype(np.int32)
+
+    def build(g):
+        x = g.input(a)
+        p = g.cont(g.permute(x, 0, 2, 1, 3))
+        t = g.cont(g.transpose(x))
+        h = g.cast(g.cast(x, F16), F32)
+        b = g.cast(g.cast(x, BF16), F32)
+        i = g.cast(g.cast(g.input(idx, I32), F32), I32)
+        dst = g.input(np.zeros((2, 3, 4, 8), np.float32))
+        c = g.cpy(g.scale(x, 2.0), dst)
+        return [p, t, h, b, i, c]
+    gu.compare(build, atol_rel=0, rtol=0)
+
+
+def test_concat_repeat_arange_views():
+    a, b = rnd(2, 3, 5), rnd(2, 4, 5)
+
+    def build(g):
+        x, y = g.input(a), g.input(b)
+        c1 = g.concat(x, y, 1)
+        c0 = g.concat(x, x, 0)
+        r = g.repeat_4d(g.input(rnd(1, 7)), 7, 5, 2, 1)
+        ar = g.arange(0.0, 10.0, 1.0)
+        v = g.cont(g.view_2d(c1, 3, 7, c1.contents.nb[1], 4))
+        return [c1, c0, r, ar, v]
+    gu.compare(build, atol_rel=0, rtol=0)
+
+
+@pytest.mark.parametrize("ttype", [F32, F16, BF16, Q4_0, Q8_0, Q4_K])
+def test_get_rows(ttype):
+    k, rows = 512, 40
+    idx = np.array([3, 0, 39, 17], np.int32)
+
+    def build(g):
+        if ttype == Q4_0:
+            tab = g.input_raw(gu.random_q4_0(np.random.default_rng(1), rows, k), ttype, k, rows)
+        elif ttype == Q8_0:
+            tab = g.input_raw(gu.random_q8_0(np.random.default_rng(1), rows, k), ttype, k, rows)
+        elif ttype == Q4_K:
+            tab = g.input_raw(gu.random_q4_K(np.random.default_rng(1), rows, k), ttype, k, rows)
+        else:
+            tab = g.input(np.random.default_rng(1).standard_normal((rows, k)).astype(np.float32), ttype)
+        return [g.get_rows(tab, g.input(idx, I32))]
+    gu.compare(build, atol_rel=0, rtol=0)
+
+
+def test_set_rows_bf16_cache():
+    cache0 = rnd(4, 10, 64)
+    rows = rnd(4, 2, 64)
+    idx = np.array([9, 3], np.int32)
+
+    def build(g):
+        cache = g.input(cache0, BF16)
+        k = g.set_rows(cache, g.input(rows), g.input(idx, I32))
+        full = g.cast(k, F32)
+        return [full]
+    gu.compare(build, atol_rel=0, rtol=0)
+
+
+@pytest.mark.parametrize("wtype,K,M,N", [(F32, 512, 96, 2), (F16, 256, 64, 3), (BF16, 128, 50, 1), (Q8_0, 256, 33, 2),
+                                         (Q4_0, 512, 17, 1), (Q4_K, 1024, 40, 2), (Q4_K, 4096, 64, 1), (Q4_K, 2816, 48, 1),
+                                         (F32, 512, 1536, 1), (BF16, 4096, 256, 1), (F16, 1024, 100, 1)])
+def test_mul_mat_types(wtype, K, M, N):
+    r = np.random.default_rng(K + M)
+    x = r.standard_normal((N, K)).astype(np.float32)
+
+    def build(g):
+        if wtype == Q4_K:
+            w = g.input_raw(gu.random_q4_K(r, M, K), wtype, K, M)
+        elif wtype == Q8_0:
+            w = g.input_raw(gu.random_q8_0(r, M, K), wtype, K, M)
+        elif wtype == Q4_0:
+            w = g.input_raw(gu.random_q4_0(r, M, K), wtype, K, M)
+        else:
+            w = g.input((r.standard_normal((M, K)) / np.sqrt(K)).astype(np.float32), wtype)
+        return [g.mul_mat(w, g.input(x))]
+    gu.compare(build, atol_rel=2e-6)
+
+
+def test_mul_mat_batched_heads_bf16():
+    # K.q and V^T.p shapes of torch.h:232-235 with head broadcast
+    D, Cc, H, T = 64, 50, 8, 2
+    kc, q = rnd(H, Cc, D), rnd(H, T, D)
+
+    def build(g):
+        k = g.input(kc, BF16)
+        s = g.mul_mat(k, g.input(q))                        # [C, T, H]
+        vt = g.cont(g.transpose(k))                          # [C, D, H]
+        o = g.mul_mat(vt, g.soft_max(s))                     # [D, T, H]
+        return [s, o]
+    gu.compare(build, atol_rel=2e-6)
+
+
+@pytest.mark.parametrize("Cin,Cout,K,s,L", [(1, 64, 7, 1, 40), (64, 128, 8, 4, 64), (512, 1024, 7, 1, 8), (256, 512, 1, 1, 3)])
+def test_conv_1d(Cin, Cout, K, s, L):
+    r = np.random.default_rng(Cin + K)
+    w = (r.standard_normal((Cout, Cin, K)) / np.sqrt(Cin * K)).astype(np.float32)
+    x = r.standard_normal((Cin, L)).astype(np.float32)
+    bias = r.standard_normal((Cout, 1)).astype(np.float32)
+
+    def build(g):
+        y = g.conv_1d(g.input(w, F16), g.input(x), s, 0, 1)
+        return [g.add(y, g.input(bias))]
+    gu.compare(build, atol_rel=2e-6)
+
+
+@pytest.mark.parametrize("Cin,Cout,K,s,L,wt", [(1024, 512, 16, 8, 2, F32), (128, 64, 8, 4, 30, F32), (64, 32, 4, 2, 5, F16)])
+def test_conv_transpose_1d(Cin, Cout, K, s, L, wt):
+    r = np.random.default_rng(Cin + K)
+    w = (r.standard_normal((Cin, Cout, K)) / np.sqrt(Cin)).astype(np.float32)
+    x = r.standard_normal((Cin, L)).astype(np.float32)
+
+    def build(g):
+        return [g.conv_transpose_1d(g.input(w, wt), g.input(x), s, 0, 1)]
+    gu.compare(build, atol_rel=1e-6)
+
+
+def test_timestep_embedding():
+    def build(g):
+        ts = g.input(np.array([0.0, 1.0, 57.0, 2999.0], np.float32))
+        return [g.timestep_embedding(ts, 128, 10000)]
+    gu.compare(build, atol_rel=2e-6)
+
+
+def test_add_inplace_and_negative_view_offsets():
+    # conv.h:282-297: lower = add_inplace(view(y), partial); y = view(lower, full, offset 0); cpy into state
+    y0, prev0 = rnd(4, 24), rnd(4, 24)
+
+    def build(g):
+        y = g.scale(g.input(y0), 1.0)
+        prev = g.input(prev0)
+        PT = 8
+        partial = g.view_3d(prev, PT, 4, 1, prev.contents.nb[1], prev.contents.nb[2], prev.contents.nb[0] * (24 - PT))
+        lower = g.view_3d(y, PT, 4, 1, y.contents.nb[1], y.contents.nb[2], 0)
+        lower = g.add_inplace(lower, partial)
+        full = g.view_3d(lower, 24, 4, 1, y.contents.nb[1], y.contents.nb[2], 0)
+        st = g.cpy(full, prev)
+        out = g.cont(g.view_3d(st, 24 - PT, 4, 1, st.contents.nb[1], st.contents.nb[2], 0))
+        # lm.h:509-527: chained 1-element views then a negative offset back to the start
+        toks = g.input(np.zeros(4, np.int32), I32)
+        v = g.view_1d(toks, 1, 0)
+        c0 = g.cpy(g.input(np.array([11], np.int32), I32), v)
+        v = g.view_1d(v, 1, 4)
+        c1 = g.cpy(g.input(np.array([22], np.int32), I32), v)
+        allv = g.view_1d(v, 4, (1 << 64) - 4)
+        return [out, g.cont(st)], [], [c0, c1, allv]
+
+    def build2(g):
+        outs, _, extra = build(g)
+        for e in extra:
+            pass
+        return outs + [extra[2]] if False else (outs, [])
+    # run with explicit expansion order: c0, c1 first, then the view read
+    def build3(g):
+        outs, _, extra = build(g)
+        return [extra[0], extra[1], g.cont(extra[2])] + outs
+    gu.compare(build3, atol_rel=0, rtol=0)
