@@ -1,0 +1,198 @@
+#!/usr/bin/env python3
+"""bench.py — audio frames/s of the moshika-7B q4_k streaming decode hot path on MI355X.
+
+A "step" is one iteration of the reference's `moshi-sts --bench` loop (tools/moshi-sts.cpp:770-808):
+mimi_encode(1920 samples) -> Temporal transformer step -> 8 chained Depth steps -> mimi_decode, single
+stream, greedy sampling, synthetic weights of the shapes/types a `-q q4_k` load of tools/moshi-config.json
+produces (no model files can reach the box), all weights / KV rings / codec state resident in HBM before
+the timed region starts.
+
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1 is launched by `python -m torch.distributed.run --nproc-per-node N`: one process per GPU, each
+running an independent stream replica ("replicas only"); barrier + device
+synchronise on both sides of the timed region, MAX over ranks, rank 0 prints ONE JSON line.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+from __graft_entry__ import load_oracle, load_package  # noqa: E402
+
+HBM_PEAK_GBPS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+
+
+def device_sync():
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipDeviceSynchronize()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=125)    # the reference bench length (README.md:353)
+    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--context-fill", type=int, default=0, help="start the Temporal KV ring at this fill level")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--cpu-frames", type=int, default=2)
+    ap.add_argument("--backend-flags", type=int, default=0, help="ggml_backend_mi355x_set_flags bits (2 = no hipGraph: use under rocprofv3)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    pkg = load_package()
+    L = pkg.load()
+    from moshi_cpp_amd import hot
+
+    L.ggml_backend_load_all()
+    be = L.ggml_backend_init_by_name(f"ROCm{local_rank}".encode(), None)
+    if not be:
+        raise SystemExit("bench.py: no MI355X device 'ROCm%d' (the hot path has no CPU fallback)" % local_rank)
+    dev = L.ggml_backend_get_device(be)
+    dev_desc = L.ggml_backend_dev_description(dev).decode()
+
+    if args.backend_flags:
+        L.ggml_backend_mi355x_set_flags(be, args.backend_flags)
+    cfg = hot.moshika(L)
+    t0 = time.time()
+    m = L.moshi_hot_create(be, C.byref(cfg), 0)
+    t_load = time.time() - t0
+    if args.context_fill:
+        L.moshi_hot_set_context_fill(m, args.context_fill)
+
+    pcm = np.zeros(1920, np.float32)     # --bench feeds silence (tools/moshi-sts.cpp:764-767)
+    out = np.zeros(1920, np.float32)
+    txt = C.c_int32()
+    aud = (C.c_int32 * 32)()
+
+    def frame():
+        return L.moshi_hot_sts_frame(m, pcm.ctypes.data, C.byref(txt), aud, out.ctypes.data)
+
+    def barrier():
+        L.ggml_backend_synchronize(be)
+        device_sync()
+        if dist is not None:
+            import torch
+            torch.cuda.synchronize()
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        frame()
+    tokens = []
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        frame()
+        tokens.append(txt.value)
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        import torch
+        tt = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    fps = world * args.steps / dt
+    offset_end = L.moshi_hot_offset(m)
+
+    # algorithmic HBM bytes per frame: every weight byte once + the filled KV slots
+    wb = [L.moshi_hot_weight_bytes(m, p) for p in range(5)]
+    n_fill_avg = min(cfg.context, args.context_fill + args.warmup + args.steps / 2.0)
+    kv_bytes = 2 * cfg.num_layers * n_fill_avg * cfg.dim * 2
+    emb_rows = (cfg.n_q + 1) * cfg.dim * 18 / 32 + cfg.dep_q * cfg.dep_dim * 18 / 32
+    frame_bytes = wb[0] + wb[1] + wb[2] + wb[3] + kv_bytes + emb_rows
+
+    st = pkg.Stats()
+    L.ggml_backend_mi355x_get_stats(be, C.byref(st))
+
+    result = {
+        "metric": "audio frames/sec (12.5 Hz target) moshika-7B q4_k decode",
+        "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "q4_K weights x q8_K activations (int8 dot, f32 accumulate); bf16 KV; f32 elsewhere",
+        "data": "synthetic",
+        "config": {"workload": "moshi-sts --bench loop: mimi encode + Temporal step + 8 Depth steps + mimi decode, "
+                               "moshika-7B q4_k, 1 stream per GPU, greedy, ctx capacity 3000",
+                   "context_fill_start": args.context_fill, "parallelism": "independent stream replica per GPU" if world > 1 else "1 GPU",
+                   "device": dev_desc},
+        "realtime_factor": round(fps / world / 12.5, 1),
+        "frame_bytes": int(frame_bytes),
+        "hbm_gbps_whole_frame": round(frame_bytes * fps / world / 1e9, 1),
+        "hbm_frac_whole_frame": round(frame_bytes * fps / world / 1e9 / HBM_PEAK_GBPS, 4),
+        "load_seconds": round(t_load, 1),
+        "graph_replays": int(st.graph_replays), "uploads_batched": int(st.uploads_batched),
+    }
+
+    if rank == 0 and not args.no_roofline:
+        # dominant kernel = matvec_q4k_kernel (3.77 of 4.4 GB per frame). Its launches are timed in situ with HIP
+        # start/stop events attached to each dispatch (flag 8: same plan, launched eagerly on the backend stream).
+        L.ggml_backend_mi355x_set_flags(be, 8)
+        for _ in range(3):
+            frame()
+        L.ggml_backend_synchronize(be)
+        kp = pkg.KernelProfile()
+        L.ggml_backend_mi355x_get_kernel_profile(be, C.byref(kp))
+        L.ggml_backend_mi355x_set_flags(be, args.backend_flags)
+        if kp.launches:
+            gbps = kp.bytes / kp.seconds / 1e9
+            result["roofline"] = {"bound": "hbm", "achieved": round(gbps, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                                  "frac": round(gbps / HBM_PEAK_GBPS, 4), "traffic": None,
+                                  "kernel": "matvec_q4k_kernel", "launches_per_frame": int(kp.launches // 3),
+                                  "avg_launch_us": round(1e6 * kp.seconds / kp.launches, 3),
+                                  "algorithmic_bytes_per_launch": int(kp.bytes // kp.launches)}
+
+    if rank == 0 and not args.no_cpu_baseline:
+        # the same frame loop on the host cores through the CPU oracle (a port of ggml's CPU semantics; the reference's
+        # own ggml CPU backend cannot be built here or on the box). Bounded sample.
+        try:
+            olib = load_oracle().load()
+            L.ggml_backend_cpu_set_graph_compute(C.cast(olib.oracle_graph_compute, C.c_void_p))
+            cores = os.cpu_count() or 1
+            cbe = L.ggml_backend_init_by_type(pkg.DEV_CPU, None)
+            L.ggml_backend_cpu_set_n_threads(cbe, cores)
+            cm = L.moshi_hot_create(cbe, C.byref(cfg), 0)
+            cpcm, cout = np.zeros(1920, np.float32), np.zeros(1920, np.float32)
+            ctxt, caud = C.c_int32(), (C.c_int32 * 32)()
+            ctoks = []
+            for _ in range(2):   # frame 0 builds the graphs and produces nothing (max_delay = 1)
+                L.moshi_hot_sts_frame(cm, cpcm.ctypes.data, C.byref(ctxt), caud, cout.ctypes.data)
+            t0 = time.perf_counter()
+            n = 0
+            while n < args.cpu_frames or (time.perf_counter() - t0 < 10 and n < 8):
+                L.moshi_hot_sts_frame(cm, cpcm.ctypes.data, C.byref(ctxt), caud, cout.ctypes.data)
+                ctoks.append(ctxt.value)
+                n += 1
+            cdt = time.perf_counter() - t0
+            L.moshi_hot_free(cm)
+            result["cpu_baseline"] = {"value": round(n / cdt, 4), "unit": "frames/s", "cores": cores, "kind": "port",
+                                      "sample": f"{n} frames of the same moshika-7B q4_k sts loop after 2 warm-up frames, "
+                                                "oracle/liboracle.so (scalar ggml-CPU semantics, OpenMP over mat-vec rows)"}
+        except Exception as e:  # the baseline is auxiliary; never lose the GPU number over it
+            result["cpu_baseline"] = {"value": None, "unit": "frames/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e}"}
+
+    L.moshi_hot_free(m)
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -107,7 +107,15 @@ struct ggml_mi355x_stats {
     int64_t uploads_batched;     // small tensor_set calls folded into one scatter launch
 };
 GGML_API void ggml_backend_mi355x_get_stats(ggml_backend_t backend, struct ggml_mi355x_stats * stats);
-// bit flags, default 0: 1 = disable fusion (one kernel per node), 2 = disable hipGraph capture, 4 = disable upload batching
+// accumulated HIP-event timings of the dominant kernel (Q4_K mat-vec), collected while flag 8 is set
+struct ggml_mi355x_kernel_profile {
+    double  seconds;    // sum of per-dispatch kernel begin -> end times
+    int64_t launches;
+    int64_t bytes;      // algorithmic bytes: weight bytes each launch streams (rows x row size)
+};
+GGML_API void ggml_backend_mi355x_get_kernel_profile(ggml_backend_t backend, struct ggml_mi355x_kernel_profile * out);
+// bit flags, default 0: 1 = disable fusion (one kernel per node), 2 = disable hipGraph capture, 4 = disable upload batching,
+// 8 = profile mode (eager launches, per-dispatch HIP events on matvec_q4k_kernel)
 GGML_API void ggml_backend_mi355x_set_flags(ggml_backend_t backend, int flags);
 // HIP stream the backend launches on (void* = hipStream_t) so callers can bracket it with HIP events
 GGML_API void * ggml_backend_mi355x_get_stream(ggml_backend_t backend);

@@ -1,0 +1,72 @@
+// moshi_hot.h — C-ABI of the host-side driver of the streaming-decode hot path.
+//
+// In the reference this layer is libmoshi's C++ API (include/moshi/moshi.h:24-203): it builds the ggml
+// graphs of the Temporal transformer, the chained Depth transformer and the Mimi codec once, then
+// submits them every 80 ms frame. libmoshi itself stays the caller in a real
+// deployment (it links this library's ggml surface unchanged); it cannot be built in
+// this environment (SentencePiece / FFmpeg / model files are absent), so this driver restates the same
+// graph construction and frame protocol — same op sequences, same upload / compute / read-back order —
+// over synthetic weights, for the parity tests and for bench.py. Every function cites what it mirrors.
+//
+// Everything here runs on whichever ggml backend it is handed: the MI355X device, or the host device
+// with the parity oracle attached (tests only).
+#pragma once
+
+#include "ggml.h"
+#include "ggml-backend.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MOSHI_HOT_MAX_CODEBOOKS 33
+
+// model hyper-parameters (tools/moshi-config.json keys; src/config.h:148-346)
+struct moshi_hot_config {
+    // Temporal transformer
+    int32_t dim, num_heads, num_layers, ffn_hidden, context, max_period;
+    int32_t text_card, card, n_q, dep_q;
+    int32_t delays[MOSHI_HOT_MAX_CODEBOOKS];      // n_q + 1 entries
+    // Depth transformer ("depformer")
+    int32_t dep_dim, dep_heads, dep_layers, dep_ffn_hidden, dep_context;
+    // weight storage types (ggml_type): linear layers / embedding tables
+    int32_t linear_type, embed_type;
+    // Mimi codec
+    int32_t mimi_n_q;            // RVQ levels used by encoder and decoder (8 for moshi-sts)
+    int32_t mimi_codebook_size;  // 2048
+    int32_t enable_lm, enable_mimi_encoder, enable_mimi_decoder;
+    // sampling: temp <= 0 -> greedy argmax (the parity mode, sampling.h:57-63)
+    float   temp, temp_text;
+    int32_t top_k, top_k_text;
+};
+
+typedef struct moshi_hot_model moshi_hot_model_t;
+
+// fills cfg with tools/moshi-config.json (moshika-7B) under `-q q4_k`: Q4_K linears, Q4_0 embeddings
+GGML_API void moshi_hot_config_moshika(struct moshi_hot_config * cfg);
+
+// allocates weights (synthetic, deterministic in `seed`), persistent state (KV rings, conv tails) and
+// the scratch contexts on `backend` (moshi_alloc / mimi_alloc / moshi_lm_load / moshi_lm_start,
+// src/moshi.cpp:88-130, 851-898)
+GGML_API moshi_hot_model_t * moshi_hot_create(ggml_backend_t backend, const struct moshi_hot_config * cfg, uint64_t seed);
+GGML_API void moshi_hot_free(moshi_hot_model_t * m);
+
+// mimi_encode_send + mimi_encode_receive (src/moshi.cpp:215-234): 1920 samples -> mimi_n_q codes
+GGML_API void moshi_hot_mimi_encode(moshi_hot_model_t * m, const float * pcm, int32_t * codes);
+// mimi_decode_send + mimi_decode_receive (src/moshi.cpp:273-292): mimi_n_q codes -> 1920 samples
+GGML_API void moshi_hot_mimi_decode(moshi_hot_model_t * m, const int32_t * codes, float * pcm);
+// moshi_lm_send2 + moshi_lm_receive (src/moshi.cpp:904-926) = one moshi_lmgen_step (lm.h:778-979):
+// in_audio = the (n_q - dep_q) codes of the other speaker; returns 1 when text/out_audio are valid
+GGML_API int moshi_hot_lm_step(moshi_hot_model_t * m, const int32_t * in_audio, int32_t * text_token, int32_t * out_audio);
+// one iteration of the moshi-sts --bench loop (tools/moshi-sts.cpp:770-808); returns 1 when a frame was produced
+GGML_API int moshi_hot_sts_frame(moshi_hot_model_t * m, const float * pcm_in, int32_t * text_token, int32_t * audio_tokens, float * pcm_out);
+
+// introspection for tests / bench
+GGML_API int64_t moshi_hot_offset(moshi_hot_model_t * m);                      // frames stepped so far
+GGML_API size_t  moshi_hot_weight_bytes(moshi_hot_model_t * m, int part);     // 0 temporal, 1 depth, 2 mimi enc, 3 mimi dec, 4 embeddings
+GGML_API int     moshi_hot_read_last(moshi_hot_model_t * m, const char * what, float * out, int64_t n);  // "text_logits", "transformer_out", "dep_logits"
+GGML_API void    moshi_hot_set_context_fill(moshi_hot_model_t * m, int64_t offset); // jump the Temporal ring to a given fill level (bench only)
+
+#ifdef __cplusplus
+}
+#endif

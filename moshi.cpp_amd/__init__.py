@@ -58,6 +58,10 @@ class Stats(C.Structure):
                                          "fused_nodes_in_last_plan", "nodes_in_last_plan", "uploads_batched")]
 
 
+class KernelProfile(C.Structure):
+    _fields_ = [("seconds", C.c_double), ("launches", C.c_int64), ("bytes", C.c_int64)]
+
+
 class GGUFInitParams(C.Structure):
     _fields_ = [("no_alloc", C.c_bool), ("ctx", C.POINTER(C.c_void_p))]
 
@@ -129,6 +133,7 @@ SIGNATURES = {
     "ggml_backend_graph_compute": (I, [P, P]), "ggml_backend_supports_op": (B, [P, TP]),
     "ggml_backend_mi355x_get_stats": (None, [P, C.POINTER(Stats)]), "ggml_backend_mi355x_set_flags": (None, [P, I]),
     "ggml_backend_mi355x_get_stream": (P, [P]),
+    "ggml_backend_mi355x_get_kernel_profile": (None, [P, C.POINTER(KernelProfile)]),
     # ggml-cpu.h
     "ggml_backend_cpu_init": (P, []), "ggml_backend_is_cpu": (B, [P]), "ggml_backend_cpu_set_n_threads": (None, [P, I]),
     "ggml_backend_cpu_reg": (P, []), "ggml_backend_cpu_set_graph_compute": (None, [P]),
@@ -164,11 +169,8 @@ def load():
         fn.restype, fn.argtypes = res, args
     if missing:
         raise RuntimeError(f"libggml-mi355x.so lacks symbols declared in include/*.h: {missing}")
-    try:
-        from . import hot as _hot  # noqa: F401  (host-side hot-path driver bindings)
-        _hot.attach(lib)
-    except ImportError:
-        pass
+    from . import hot as _hot  # host-side hot-path driver bindings (include/moshi_hot.h)
+    _hot.attach(lib)
     _lib = lib
     return lib
 

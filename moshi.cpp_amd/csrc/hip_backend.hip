@@ -55,6 +55,9 @@ struct hip_ctx {
     int cur_slot = 0;
     int n_pending = 0;
     size_t pending_bytes = 0;
+    // flag 8: per-launch timing of the dominant kernel
+    mv_profile prof = { nullptr, 0, 0 };
+    double prof_seconds = 0; int64_t prof_launches = 0, prof_bytes = 0;
     // cached plans keyed by cgraph pointer
     std::unordered_map<const ggml_cgraph *, plan_t *> plans;
     ggml_backend_device dev_obj;
@@ -716,6 +719,27 @@ static plan_t * build_plan(hip_ctx * c, ggml_cgraph * g) {
 
 static void run_steps(hip_ctx * c, plan_t * p) { for (auto & f : p->steps) f(c->stream); }
 
+// flag 8: launch eagerly with start/stop events on every matvec_q4k_kernel dispatch and accumulate
+static void run_steps_profiled(hip_ctx * c, plan_t * p) {
+    if (!c->prof.recs) {
+        c->prof.capacity = 4096;
+        c->prof.recs = new mv_profile::rec[(size_t) c->prof.capacity];
+        for (int i = 0; i < c->prof.capacity; i++) { HIP_CHECK(hipEventCreate(&c->prof.recs[i].start)); HIP_CHECK(hipEventCreate(&c->prof.recs[i].stop)); }
+    }
+    c->prof.used = 0;
+    k_matvec_set_profile(&c->prof);
+    run_steps(c, p);
+    k_matvec_set_profile(nullptr);
+    HIP_CHECK(hipStreamSynchronize(c->stream));
+    for (int i = 0; i < c->prof.used; i++) {
+        float ms = 0;
+        HIP_CHECK(hipEventElapsedTime(&ms, c->prof.recs[i].start, c->prof.recs[i].stop));
+        c->prof_seconds += (double) ms * 1e-3;
+        c->prof_launches++;
+        c->prof_bytes += c->prof.recs[i].bytes;
+    }
+}
+
 static enum ggml_status hip_graph_compute(ggml_backend_t backend, struct ggml_cgraph * g) {
     hip_ctx * c = (hip_ctx *) backend->context;
     ctx_init_lazy(c);
@@ -724,6 +748,12 @@ static enum ggml_status hip_graph_compute(ggml_backend_t backend, struct ggml_cg
     c->stats.graphs_computed++;
     if (g->n_nodes == 0) return GGML_STATUS_SUCCESS;
 
+    if (c->flags & 8) {
+        plan_t * p = build_plan(c, g);
+        run_steps_profiled(c, p);
+        plan_free(c, p);
+        return GGML_STATUS_SUCCESS;
+    }
     const bool cacheable = g->n_nodes >= 32;
     if (!cacheable) {
         plan_t * p = build_plan(c, g);
@@ -851,5 +881,9 @@ extern "C" void ggml_backend_mi355x_set_flags(ggml_backend_t b, int flags) {
     for (auto & kv : c->plans) plan_free(c, kv.second);
     c->plans.clear();
     c->flags = flags;
+}
+extern "C" void ggml_backend_mi355x_get_kernel_profile(ggml_backend_t b, struct ggml_mi355x_kernel_profile * out) {
+    hip_ctx * c = ctx_of(b);
+    out->seconds = c->prof_seconds; out->launches = c->prof_launches; out->bytes = c->prof_bytes;
 }
 extern "C" void * ggml_backend_mi355x_get_stream(ggml_backend_t b) { hip_ctx * c = ctx_of(b); ctx_init_lazy(c); return (void *) c->stream; }

@@ -74,6 +74,13 @@ struct mv_args {
     float *     x_out;          // optional: prologue result written by block 0 (keeps the ggml node materialised)
 };
 bool k_matvec_supported(int wtype, int64_t K, int64_t M);
+// optional per-launch timing of the dominant kernel (matvec_q4k_kernel) with HIP start/stop events that are
+// attached to the dispatch itself (hipExtLaunchKernelGGL), i.e. kernel begin -> kernel end like a profiler
+struct mv_profile {
+    struct rec { hipEvent_t start, stop; int64_t bytes; };
+    rec * recs; int capacity; int used;
+};
+void k_matvec_set_profile(mv_profile * p);
 void k_matvec(hipStream_t s, const mv_args & a);
 
 // single-token self-attention over a ring KV cache (T = 1): RoPE(q,k) -> cache write -> masked

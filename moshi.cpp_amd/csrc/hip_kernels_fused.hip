@@ -16,6 +16,7 @@
 // agree with the oracle to float-summation-order noise.
 #include "hip_common.h"
 #include "hip_device.h"
+#include <hip/hip_ext.h>
 
 // ---------------------------------------------------------------------------------------------------
 // activation prologues
@@ -209,6 +210,9 @@ bool k_matvec_supported(int wtype, int64_t K, int64_t M) {
     }
 }
 
+static mv_profile * g_mv_profile = nullptr;
+void k_matvec_set_profile(mv_profile * p) { g_mv_profile = p; }
+
 void k_matvec(hipStream_t s, const mv_args & a) {
     if (a.wtype == GGML_TYPE_Q4_K) {
         const int nb = (int) (a.K / 256);
@@ -222,6 +226,12 @@ void k_matvec(hipStream_t s, const mv_args & a) {
         const int nwaves = threads / 64;
         const size_t smem = (size_t) nb * XBLK_BYTES + (size_t) nwaves * TILE_BYTES + (size_t) rows * nb * 4;
         const int grid = (int) ((a.M + rows - 1) / rows);
+        if (g_mv_profile && g_mv_profile->used < g_mv_profile->capacity) {
+            mv_profile::rec & r = g_mv_profile->recs[g_mv_profile->used++];
+            r.bytes = a.M * a.row_bytes;
+            hipExtLaunchKernelGGL(matvec_q4k_kernel, dim3(grid), dim3(threads), smem, s, r.start, r.stop, 0, a, rows);
+            return;
+        }
         matvec_q4k_kernel<<<grid, threads, smem, s>>>(a, rows);
         return;
     }

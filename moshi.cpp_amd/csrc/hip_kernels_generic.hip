@@ -406,10 +406,13 @@ __global__ void timestep_embedding_kernel(tdesc dst, tdesc ts, int dim, int max_
     float * e = (float *) at(dst, 0, i, 0, 0);
     const float t = *(const float *) at(ts, i, 0, 0, 0);
     for (int j = threadIdx.x; j < half; j += blockDim.x) {
-        const float freq = expf(-logf((float) max_period) * j / half);
+        // float transcendentals evaluated in double and rounded once: the 1-ulp differences between the
+        // device's expf and a host libm would otherwise be amplified by t (up to the context length)
+        const float lf = (float) log((double) max_period);
+        const float freq = (float) exp((double) (-lf * j / half));
         const float arg = t * freq;
-        e[j] = cosf(arg);
-        e[j + half] = sinf(arg);
+        e[j] = (float) cos((double) arg);
+        e[j + half] = (float) sin((double) arg);
     }
     if (threadIdx.x == 0 && (dim & 1)) e[2 * half] = 0.f;
 }

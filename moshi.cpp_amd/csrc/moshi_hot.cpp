@@ -1,0 +1,971 @@
+// moshi_hot.cpp — host-side driver of the streaming-decode hot path behind include/moshi_hot.h.
+//
+// Restates, over the ggml C-ABI only, the graph construction and per-frame protocol of the reference's
+// libmoshi for this path: Temporal transformer graph (lm.h:659-677, 853-879), chained Depth transformer
+// graph (lm.h:446-553), Mimi decode / encode graphs (compression.h:149-204, 277-325) and the delay-ring
+// frame driver (lm.h:778-979). The op sequences are the reference's (they are what the backend's fusion
+// matchers key on and what the oracle executes node by node); the C++ around them is this project's own.
+// Weights are synthetic and deterministic (no model files can reach the build or the GPU box).
+#include "moshi_hot.h"
+#include "ggml-cpu.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <functional>
+#include <string>
+#include <vector>
+
+typedef struct ggml_tensor * T;
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------------
+// deterministic generator (splitmix64) for synthetic weights
+// ---------------------------------------------------------------------------------------------------
+struct Rng {
+    uint64_t s;
+    explicit Rng(uint64_t seed) : s(seed) {}
+    uint64_t next() { uint64_t z = (s += 0x9E3779B97F4A7C15ull); z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; return z ^ (z >> 31); }
+    float uniform() { return (float) ((next() >> 40) + 1) * (1.0f / 16777217.0f); }   // (0, 1)
+    float normal() { const float u1 = uniform(), u2 = uniform(); return sqrtf(-2.0f * logf(u1)) * cosf(6.28318530718f * u2); }
+};
+uint64_t name_seed(uint64_t seed, const std::string & name) {
+    uint64_t h = seed ^ 0xcbf29ce484222325ull;
+    for (char c : name) h = (h ^ (uint8_t) c) * 0x100000001b3ull;
+    return h;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// graph context: persistent (built once, replayed) or scratch (rebuilt every frame)
+// mirrors the upload / alloc / compute protocol of src/context.h:227-653
+// ---------------------------------------------------------------------------------------------------
+struct Builder {
+    ggml_backend_t be;
+    struct ggml_context * ctx;
+    struct ggml_cgraph * gf = nullptr;
+    ggml_backend_buffer_t buf = nullptr;
+    struct upload { T t; std::vector<uint8_t> data; };
+    std::vector<upload> consts;
+    struct noise { T t; float lambd; };
+    std::vector<noise> exponentials;
+    std::vector<float> noise_tmp;
+
+    Builder(ggml_backend_t be_, size_t mb) : be(be_) { ctx = ggml_init({ mb * 1024 * 1024, NULL, true }); }
+    ~Builder() { if (buf) ggml_backend_buffer_free(buf); ggml_free(ctx); }
+    operator struct ggml_context * () { return ctx; }
+
+    T tensor(enum ggml_type type, int64_t n0, int64_t n1 = 1, int64_t n2 = 1, int64_t n3 = 1) { return ggml_new_tensor_4d(ctx, type, n0, n1, n2, n3); }
+    T constant(T t, const void * data) {
+        consts.push_back({ t, std::vector<uint8_t>((const uint8_t *) data, (const uint8_t *) data + ggml_nbytes(t)) });
+        return t;
+    }
+    T f32(float v) { return constant(ggml_new_tensor_1d(ctx, GGML_TYPE_F32, 1), &v); }
+    T i32s(const std::vector<int32_t> & v) { return constant(ggml_new_tensor_1d(ctx, GGML_TYPE_I32, (int64_t) v.size()), v.data()); }
+    T arange(int n) { std::vector<float> v((size_t) n); for (int i = 0; i < n; i++) v[(size_t) i] = (float) i; return constant(ggml_new_tensor_1d(ctx, GGML_TYPE_F32, n), v.data()); }
+    T fill(const int64_t * ne, float val) {
+        T t = ggml_new_tensor(ctx, GGML_TYPE_F32, 4, ne);
+        std::vector<float> v((size_t) ggml_nelements(t), val);
+        return constant(t, v.data());
+    }
+    T exponential(int64_t n0, int64_t n1, float lambd) { T t = tensor(GGML_TYPE_F32, n0, n1); exponentials.push_back({ t, lambd }); return t; }
+    // deferred scalar sets of a scratch context (src/context.h:562-586)
+    void set_later(T t, const void * data, size_t n) { consts.push_back({ t, std::vector<uint8_t>((const uint8_t *) data, (const uint8_t *) data + n) }); }
+
+    void expand(T t) {
+        if (!gf) gf = ggml_new_graph_custom(ctx, GGML_DEFAULT_GRAPH_SIZE * 4, false);
+        ggml_build_forward_expand(gf, t);
+    }
+    void alloc() {
+        buf = ggml_backend_alloc_ctx_tensors(ctx, be);
+        GGML_ASSERT(buf);
+        for (auto & c : consts) ggml_backend_tensor_set(c.t, c.data.data(), 0, c.data.size());
+    }
+    void upload_noise() {
+        for (auto & e : exponentials) {
+            const int64_t n = ggml_nelements(e.t);
+            noise_tmp.resize((size_t) n);
+            for (int64_t i = 0; i < n; i++) noise_tmp[(size_t) i] = -logf(rand() / (float) RAND_MAX) / e.lambd;   // src/context.h:475-476
+            ggml_backend_tensor_set(e.t, noise_tmp.data(), 0, (size_t) n * 4);
+        }
+    }
+    void compute() { upload_noise(); if (gf) ggml_backend_graph_compute(be, gf); }
+    // scratch protocol: alloc -> upload -> compute -> free -> reset (src/context.h:628-653)
+    void compute_scratch() {
+        alloc();
+        compute();
+        consts.clear();
+        exponentials.clear();
+        ggml_backend_buffer_free(buf);
+        buf = nullptr;
+        ggml_reset(ctx);
+        gf = nullptr;
+    }
+};
+
+// ---------------------------------------------------------------------------------------------------
+// weights: one context + one backend buffer, filled after allocation
+// ---------------------------------------------------------------------------------------------------
+struct Weights {
+    ggml_backend_t be;
+    struct ggml_context * ctx;
+    ggml_backend_buffer_t buf = nullptr;
+    uint64_t seed;
+    struct pending { T t; std::function<void(T, Rng &, std::vector<uint8_t> &)> gen; std::string name; };
+    std::vector<pending> todo;
+    size_t bytes[5] = { 0, 0, 0, 0, 0 };
+    int part = 0;
+
+    Weights(ggml_backend_t be_, uint64_t seed_, int max_tensors) : be(be_), seed(seed_) {
+        ctx = ggml_init({ ggml_tensor_overhead() * (size_t) max_tensors, NULL, true });
+    }
+    ~Weights() { if (buf) ggml_backend_buffer_free(buf); ggml_free(ctx); }
+
+    T add(const std::string & name, enum ggml_type type, int64_t n0, int64_t n1, int64_t n2, std::function<void(T, Rng &, std::vector<uint8_t> &)> gen) {
+        T t = ggml_new_tensor_3d(ctx, type, n0, n1, n2);
+        ggml_set_name(t, name.size() < GGML_MAX_NAME ? name.c_str() : name.substr(name.size() - GGML_MAX_NAME + 1).c_str());
+        todo.push_back({ t, gen, name });
+        bytes[part] += ggml_nbytes(t);
+        return t;
+    }
+    void load() {
+        buf = ggml_backend_alloc_ctx_tensors(ctx, be);
+        GGML_ASSERT(buf);
+        std::vector<uint8_t> tmp;
+        for (auto & p : todo) {
+            Rng r(name_seed(seed, p.name));
+            tmp.resize(ggml_nbytes(p.t));
+            p.gen(p.t, r, tmp);
+            ggml_backend_tensor_set(p.t, tmp.data(), 0, tmp.size());
+        }
+        todo.clear();
+    }
+};
+
+// generators ------------------------------------------------------------------------------------------------
+void gen_const(T t, float v, std::vector<uint8_t> & out) { float * f = (float *) out.data(); for (int64_t i = 0; i < ggml_nelements(t); i++) f[i] = v; }
+
+// N(0, std) in F32 / F16 / BF16
+void gen_normal(T t, Rng & r, std::vector<uint8_t> & out, float std_) {
+    const int64_t n = ggml_nelements(t);
+    if (t->type == GGML_TYPE_F32) { float * f = (float *) out.data(); for (int64_t i = 0; i < n; i++) f[i] = r.normal() * std_; }
+    else if (t->type == GGML_TYPE_F16) { ggml_fp16_t * h = (ggml_fp16_t *) out.data(); for (int64_t i = 0; i < n; i++) h[i] = ggml_fp32_to_fp16(r.normal() * std_); }
+    else if (t->type == GGML_TYPE_BF16) { ggml_bf16_t * h = (ggml_bf16_t *) out.data(); for (int64_t i = 0; i < n; i++) h[i] = ggml_fp32_to_bf16(r.normal() * std_); }
+    else GGML_ABORT("gen_normal: type");
+}
+
+// block-quantised weights with zero-mean values of standard deviation ~std_ (DESIGN.md "synthetic weights"):
+//   Q4_K: w = d*sc*q - dmin*m with dmin = 7.5 d and m = sc  =>  w = d*sc*(q - 7.5), q uniform[0,15], sc uniform[1,63]
+//   Q4_0: w = d*(q - 8);  Q8_0: w = d*q, q uniform[-127,127]
+void gen_quant(T t, Rng & r, std::vector<uint8_t> & out, float std_) {
+    const int64_t n = ggml_nelements(t);
+    if (t->type == GGML_TYPE_Q4_K) {
+        block_q4_K * b = (block_q4_K *) out.data();
+        const float base = std_ / (4.61f * 36.9f);   // std(q-7.5) = 4.61, rms(sc) = 36.9
+        for (int64_t i = 0; i < n / 256; i++) {
+            const float d = fabsf(r.normal()) * base * 1.25f;   // E|N| = 0.8
+            b[i].d = ggml_fp32_to_fp16(d);
+            b[i].dmin = ggml_fp32_to_fp16(7.5f * ggml_fp16_to_fp32(b[i].d));
+            uint8_t sc[8];
+            const uint64_t z = r.next();
+            for (int j = 0; j < 8; j++) sc[j] = (uint8_t) (1 + ((z >> (8 * j)) & 0xff) % 63);
+            for (int j = 0; j < 4; j++) {
+                b[i].scales[j]     = (uint8_t) ((sc[j] & 63) | ((sc[j + 4] >> 4) << 6));
+                b[i].scales[j + 4] = (uint8_t) ((sc[j] & 63) | ((sc[j + 4] >> 4) << 6));   // mins = scales
+                b[i].scales[j + 8] = (uint8_t) ((sc[j + 4] & 0xF) | ((sc[j + 4] & 0xF) << 4));
+            }
+            uint64_t * q = (uint64_t *) b[i].qs;
+            for (int j = 0; j < 16; j++) q[j] = r.next();
+        }
+    } else if (t->type == GGML_TYPE_Q4_0) {
+        block_q4_0 * b = (block_q4_0 *) out.data();
+        for (int64_t i = 0; i < n / 32; i++) {
+            b[i].d = ggml_fp32_to_fp16(fabsf(r.normal()) * std_ * 1.25f / 4.61f);
+            uint64_t z0 = r.next(), z1 = r.next();
+            memcpy(b[i].qs, &z0, 8); memcpy(b[i].qs + 8, &z1, 8);
+        }
+    } else if (t->type == GGML_TYPE_Q8_0) {
+        block_q8_0 * b = (block_q8_0 *) out.data();
+        for (int64_t i = 0; i < n / 32; i++) {
+            b[i].d = ggml_fp32_to_fp16(fabsf(r.normal()) * std_ * 1.25f / 73.3f);
+            for (int j = 0; j < 4; j++) { uint64_t z = r.next(); for (int k = 0; k < 8; k++) { int v = (int) ((z >> (8 * k)) & 0xff) - 128; b[i].qs[j * 8 + k] = (int8_t) (v < -127 ? -127 : v); } }
+        }
+    } else gen_normal(t, r, out, std_);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// modules (each builder emits the reference's op sequence; citations are to /root/reference/src)
+// ---------------------------------------------------------------------------------------------------
+struct Norm { bool rms; float eps; T w = nullptr, b = nullptr; };
+
+// moshi_rms_norm (moshi/modules/transformer.h:15-23) / torch_nn_layer_norm (torch.h:49-60)
+T apply_norm(Builder & c, const Norm & n, T x) {
+    if (n.rms) return ggml_mul(c, n.w, ggml_rms_norm(c, x, n.eps));
+    x = ggml_norm(c, x, n.eps);
+    x = ggml_mul(c, x, n.w);
+    if (n.b) x = ggml_add(c, x, n.b);
+    return x;
+}
+
+T linear(Builder & c, T w, T x) { return ggml_mul_mat(c, w, x); }   // torch_nn_linear, no bias on this path (torch.h:79-87)
+
+struct Rot { T rotr = nullptr, roti = nullptr; };
+
+// moshi_get_timestep_embedding (moshi/modules/rope.h:8-20)
+Rot timestep_embedding(Builder & c, int Tn, int D, T offset, int max_period) {
+    T ts = c.arange(Tn);
+    ts = ggml_add(c, ts, offset);
+    T rot = ggml_timestep_embedding(c, ts, D, max_period);
+    Rot r;
+    r.rotr = ggml_view_2d(c, rot, D / 2, Tn, rot->nb[1], 0);
+    r.roti = ggml_view_2d(c, rot, D / 2, Tn, rot->nb[1], rot->nb[0] * (size_t) (D / 2));
+    return r;
+}
+
+// one operand of moshi_apply_rope (rope.h:58-76): split interleaved (re, im) pairs into two [D/2, T, H, B] halves
+void rope_split(Builder & c, T q, int64_t D_half, int64_t Tn, int64_t H, int64_t B, T & qr, T & qi) {
+    const int64_t BH = B * H;
+    q = ggml_cont(c, q);
+    q = ggml_reshape_4d(c, q, 2, D_half, Tn, BH);
+    q = ggml_cont(c, ggml_permute(c, q, 3, 0, 1, 2));
+    qr = ggml_view_3d(c, q, D_half, Tn, BH, q->nb[1], q->nb[2], 0);
+    qi = ggml_view_3d(c, q, D_half, Tn, BH, q->nb[1], q->nb[2], q->nb[2] * (size_t) BH);
+    qr = ggml_reshape_4d(c, qr, D_half, Tn, H, B);
+    qi = ggml_reshape_4d(c, qi, D_half, Tn, H, B);
+}
+
+// moshi_apply_rope (rope.h:33-128), time_before_heads = false
+void apply_rope(Builder & c, T & q, T & k, const Rot & rot) {
+    const int64_t B = q->ne[3], H = q->ne[2], Tn = q->ne[1], D = q->ne[0];
+    T qr, qi, kr, ki;
+    rope_split(c, q, D / 2, Tn, H, B, qr, qi);
+    rope_split(c, k, D / 2, Tn, H, B, kr, ki);
+    T qor = ggml_sub(c, ggml_mul(c, qr, rot.rotr), ggml_mul(c, qi, rot.roti));
+    T qoi = ggml_add(c, ggml_mul(c, qr, rot.roti), ggml_mul(c, qi, rot.rotr));
+    T kor = ggml_sub(c, ggml_mul(c, kr, rot.rotr), ggml_mul(c, ki, rot.roti));
+    T koi = ggml_add(c, ggml_mul(c, kr, rot.roti), ggml_mul(c, ki, rot.rotr));
+    q = ggml_concat(c, qor, qoi, 0);
+    k = ggml_concat(c, kor, koi, 0);
+}
+
+struct Layer {
+    Norm norm1, norm2;
+    std::vector<T> in_proj, out_proj;          // one per step weight set (Depth) or a single entry
+    std::vector<T> gate_in, gate_out;          // gated FFN (silu) weight sets
+    T linear1 = nullptr, linear2 = nullptr;    // plain FFN (gelu)
+    T layer_scale_1 = nullptr, layer_scale_2 = nullptr;
+    T kcache = nullptr, vcache = nullptr;      // state: BF16 [D, C, H]
+};
+
+struct Transformer {
+    int dim = 0, heads = 0, capacity = 0, max_period = 0;
+    std::vector<Layer> layers;
+    // bias-mask lookup table (torch.h:162-223)
+    struct ggml_context * pat_ctx = nullptr; ggml_backend_buffer_t pat_buf = nullptr; T pattern = nullptr; int pat_T = 0;
+    // cached-graph inputs (transformer.h:1101-1109)
+    T g_bias = nullptr, g_offset = nullptr, g_indices = nullptr;
+    int offset = 0;
+    ~Transformer() { if (pat_buf) ggml_backend_buffer_free(pat_buf); if (pat_ctx) ggml_free(pat_ctx); }
+};
+
+// create_bias_pattern(capacity, t, hi = 0, lo = -inf) (torch.h:170-203)
+void create_bias_pattern(ggml_backend_t be, Transformer & tr, int Tn) {
+    if (tr.pattern) { GGML_ASSERT(tr.pat_T == Tn); return; }
+    const int C = tr.capacity, start = C * 2 - Tn, width = start + C;
+    tr.pat_ctx = ggml_init({ ggml_tensor_overhead(), NULL, true });
+    tr.pattern = ggml_new_tensor_2d(tr.pat_ctx, GGML_TYPE_F32, width, Tn);
+    tr.pat_buf = ggml_backend_alloc_ctx_tensors(tr.pat_ctx, be);
+    tr.pat_T = Tn;
+    std::vector<float> v((size_t) width * (size_t) Tn);
+    for (int j = 0; j < Tn; j++) {
+        float * row = v.data() + (size_t) j * (size_t) width;
+        const int right = start + 1 + j;
+        for (int i = 0; i < width; i++) row[i] = i < right ? 0.0f : -INFINITY;
+        for (int i = 0; i < Tn - j - 1; i++) row[C - 1 - i] = -INFINITY;
+    }
+    ggml_backend_tensor_set(tr.pattern, v.data(), 0, v.size() * 4);
+}
+
+// bias_pattern_index (torch.h:205-223)
+T bias_pattern_index(Builder & c, Transformer & tr, int offset) {
+    const int C = tr.capacity, start = C * 2 - tr.pat_T;
+    const int col = offset <= C ? start - offset : C - (offset % C);
+    T view = ggml_view_2d(c, tr.pattern, C, tr.pat_T, tr.pattern->nb[1], (size_t) col * tr.pattern->nb[0]);
+    return ggml_cont(c, view);
+}
+
+// moshi_streaming_multihead_attention (transformer.h:449-583): self-attention, ring cache via set_rows
+T attention(Builder & c, const Transformer & tr, Layer & L, int wi, T indices, T x, T attn_bias, const Rot * rot, bool per_step_views) {
+    const int H = tr.heads;
+    T xin = x;
+    if (per_step_views)   // moshi_apply_weights_per_step_linear takes a per-timestep view first (transformer.h:85-91)
+        xin = ggml_view_3d(c, x, x->ne[0], 1, x->ne[2], x->nb[1], x->nb[2], 0);
+    T projected = linear(c, L.in_proj[(size_t) wi], xin);
+    T q = ggml_view_3d(c, projected, projected->ne[0] / 3, projected->ne[1], projected->ne[2], projected->nb[1], projected->nb[2], 0);
+    q = ggml_cont(c, q);
+    T k = ggml_view_3d(c, projected, projected->ne[0] / 3, projected->ne[1], projected->ne[2], projected->nb[1], projected->nb[2], projected->nb[1] / 3);
+    k = ggml_cont(c, k);
+    k = ggml_reshape_4d(c, k, k->ne[0] / H, H, k->ne[1], k->ne[2]);
+    k = ggml_permute(c, k, 0, 2, 1, 3);
+    T v = ggml_view_3d(c, projected, projected->ne[0] / 3, projected->ne[1], projected->ne[2], projected->nb[1], projected->nb[2], projected->nb[1] * 2 / 3);
+    v = ggml_cont(c, v);
+    v = ggml_reshape_4d(c, v, v->ne[0] / H, H, v->ne[1], v->ne[2]);
+    v = ggml_permute(c, v, 0, 2, 1, 3);
+    q = ggml_reshape_4d(c, q, q->ne[0] / H, H, q->ne[1], q->ne[2]);
+    q = ggml_permute(c, q, 0, 2, 1, 3);
+    if (rot) apply_rope(c, q, k, *rot);
+    // moshi_kv_cache_insert_kv, tensor-index overload (transformer.h:238-249)
+    k = ggml_set_rows(c, L.kcache, k, indices);
+    v = ggml_set_rows(c, L.vcache, v, indices);
+    // torch_nn_functional_scaled_dot_product_attention_custom (torch.h:225-237)
+    const float scale = 1.f / sqrtf((float) q->ne[0]);
+    T w = ggml_mul_mat(c, k, q);
+    w = ggml_soft_max_ext(c, w, attn_bias, scale, 0.0f);
+    v = ggml_cont(c, ggml_transpose(c, v));
+    T o = ggml_mul_mat(c, v, w);
+    T o2 = ggml_cont(c, ggml_permute(c, o, 0, 2, 1, 3));
+    o = ggml_reshape_3d(c, o2, o2->ne[0] * o2->ne[1], o2->ne[2], o2->ne[3]);
+    if (per_step_views) o = ggml_view_3d(c, o, o->ne[0], 1, o->ne[2], o->nb[1], o->nb[2], 0);
+    return linear(c, L.out_proj[(size_t) wi], o);
+}
+
+// moshi_activation_gating (gating.h:11-37)
+T gating(Builder & c, T w_in, T w_out, T x) {
+    x = linear(c, w_in, x);
+    T left = ggml_view_4d(c, x, x->ne[0] / 2, 1, x->ne[1], x->ne[2], x->nb[1] / 2, x->nb[1], x->nb[2], 0);
+    T right = ggml_view_4d(c, x, x->ne[0] / 2, 1, x->ne[1], x->ne[2], x->nb[1] / 2, x->nb[1], x->nb[2], x->nb[1] / 2);
+    left = ggml_silu(c, left);
+    x = ggml_mul(c, left, right);
+    return linear(c, w_out, x);
+}
+
+// moshi_streaming_transformer_layer (transformer.h:910-1039)
+T transformer_layer(Builder & c, const Transformer & tr, Layer & L, int wi, T indices, T x, T attn_bias, const Rot * rot, bool per_step_views) {
+    T nx = apply_norm(c, L.norm1, x);
+    T update = attention(c, tr, L, wi, indices, nx, attn_bias, rot, per_step_views);
+    if (L.layer_scale_1) update = ggml_mul(c, update, L.layer_scale_1);
+    x = ggml_add(c, x, update);
+    nx = apply_norm(c, L.norm2, x);
+    if (L.gate_in.empty()) {
+        T h = linear(c, L.linear1, nx);
+        h = ggml_gelu(c, h);
+        update = linear(c, L.linear2, h);
+    } else {
+        T gx = nx;
+        if (per_step_views) gx = ggml_view_3d(c, nx, nx->ne[0], 1, nx->ne[2], nx->nb[1], nx->nb[2], 0);   // transformer.h:132-138
+        update = gating(c, L.gate_in[(size_t) wi], L.gate_out[(size_t) wi], gx);
+    }
+    if (L.layer_scale_2) update = ggml_mul(c, update, L.layer_scale_2);
+    return ggml_add(c, x, update);
+}
+
+// moshi_streaming_transformer_graph_build (transformer.h:1217-1257): inputs live in the cached graph
+T transformer_graph_build(Builder & g, Transformer & tr, T x) {
+    const int Tn = (int) x->ne[1];
+    create_bias_pattern(g.be, tr, Tn);
+    tr.g_bias = g.tensor(GGML_TYPE_F32, tr.capacity, Tn);
+    Rot rot;
+    if (tr.max_period) {
+        tr.g_offset = g.tensor(GGML_TYPE_F32, 1);
+        rot = timestep_embedding(g, Tn, tr.dim / tr.heads, tr.g_offset, tr.max_period);
+    }
+    tr.g_indices = g.tensor(GGML_TYPE_I32, Tn);
+    for (auto & L : tr.layers) x = transformer_layer(g, tr, L, 0, tr.g_indices, x, tr.g_bias, tr.max_period ? &rot : nullptr, false);
+    return x;
+}
+
+// moshi_streaming_transformer_graph_step (transformer.h:1259-1289): refresh mask, rope offset, ring slots
+void transformer_graph_step(Builder & scratch, Transformer & tr, int Tn) {
+    const int offset = tr.offset;
+    tr.offset += Tn;
+    T bias = bias_pattern_index(scratch, tr, offset);
+    scratch.expand(ggml_cpy(scratch, bias, tr.g_bias));
+    if (tr.g_offset) { const float f = (float) offset; ggml_backend_tensor_set(tr.g_offset, &f, 0, 4); }
+    std::vector<int32_t> idx((size_t) Tn);
+    for (int i = 0; i < Tn; i++) idx[(size_t) i] = (offset + i) % tr.capacity;
+    ggml_backend_tensor_set(tr.g_indices, idx.data(), 0, idx.size() * 4);
+}
+
+// moshi_streaming_transformer, non-graph overload with offsets baked at build time (transformer.h:1182-1215);
+// this is how the Depth steps sit inside one cached graph (lm.h:469-470)
+T transformer_inline(Builder & g, Transformer & tr, T x) {
+    const int Tn = (int) x->ne[1];
+    const int offset = tr.offset;
+    create_bias_pattern(g.be, tr, Tn);
+    T attn_bias = bias_pattern_index(g, tr, offset);
+    Rot rot;
+    if (tr.max_period) rot = timestep_embedding(g, Tn, tr.dim / tr.heads, g.f32((float) offset), tr.max_period);
+    std::vector<int32_t> idx((size_t) Tn);
+    for (int i = 0; i < Tn; i++) idx[(size_t) i] = (offset + i) % tr.capacity;
+    T indices = g.i32s(idx);
+    const bool multi = tr.layers[0].in_proj.size() > 1;
+    for (auto & L : tr.layers) x = transformer_layer(g, tr, L, multi ? offset : 0, indices, x, attn_bias, tr.max_period ? &rot : nullptr, multi);
+    tr.offset += Tn;
+    return x;
+}
+
+// moshi_sample_token (moshi/utils/sampling.h:4-64)
+T sample_token(Builder & g, T logits, float temp, int top_k) {
+    if (!(temp > 0.f)) return ggml_argmax(g, logits);
+    T probs = ggml_soft_max(g, ggml_scale(g, logits, 1.f / temp));
+    const int k = (int) probs->ne[0] < top_k ? (int) probs->ne[0] : top_k;
+    T indices = ggml_argsort_top_k(g, probs, k);
+    T rows = ggml_permute(g, probs, 1, 0, 2, 3);
+    rows = ggml_get_rows(g, ggml_cont(g, rows), indices);
+    probs = ggml_permute(g, rows, 1, 0, 2, 3);
+    T in2 = ggml_reshape_2d(g, probs, probs->ne[0], probs->ne[1] * probs->ne[2] * probs->ne[3]);
+    T q = ggml_div(g, in2, g.exponential(in2->ne[0], in2->ne[1], 1.f));
+    T next = ggml_argmax(g, q);
+    next = ggml_reshape_4d(g, next, next->ne[0], probs->ne[1], probs->ne[2], probs->ne[3]);
+    T irows = ggml_permute(g, indices, 1, 0, 2, 3);
+    return ggml_get_rows(g, ggml_cont(g, irows), next);
+}
+
+// ---- Mimi ---------------------------------------------------------------------------------------------------
+struct Conv { int cin, cout, k, stride; T w = nullptr, b = nullptr; T prev = nullptr; };          // streaming / stateless conv1d
+struct ConvTr { int cin, cout, k, stride, groups; T w = nullptr, b = nullptr; T prev = nullptr; };
+struct ResBlock { Conv block1, block3; };
+
+// moshi_streaming_conv_1d (moshi/modules/conv.h:50-96)
+T streaming_conv(Builder & g, Conv & cv, T x) {
+    const int TP = cv.k - cv.stride;
+    x = ggml_concat(g, cv.prev, x, 0);
+    T tail = ggml_view_3d(g, x, TP, x->ne[1], x->ne[2], x->nb[1], x->nb[2], x->nb[0] * (size_t) (x->ne[0] - TP));
+    g.expand(ggml_cpy(g, tail, cv.prev));
+    T y = ggml_conv_1d(g, cv.w, x, cv.stride, 0, 1);
+    if (cv.b) y = ggml_add(g, y, cv.b);
+    return y;
+}
+// moshi_stateless_conv_1d (conv.h:137-161)
+T stateless_conv(Builder & g, Conv & cv, T x) {
+    T y = ggml_conv_1d(g, cv.w, x, 1, 0, 1);
+    if (cv.b) y = ggml_add(g, y, cv.b);
+    return y;
+}
+// moshi_streaming_conv_transpose_1d (conv.h:240-310)
+T streaming_conv_transpose(Builder & g, ConvTr & ct, T x) {
+    const int PT = ct.k - ct.stride;
+    T y = nullptr;
+    if (ct.groups == 1) y = ggml_conv_transpose_1d(g, ct.w, x, ct.stride, 0, 1);
+    else {
+        for (int i = 0; i < ct.w->ne[0]; i++) {   // depthwise: one multiply per kernel tap (conv.h:262-278)
+            T sub = ggml_view_3d(g, ct.w, 1, ct.w->ne[2], ct.w->ne[1], ct.w->nb[2], ct.w->nb[2], ct.w->nb[0] * (size_t) i);
+            T piece = ggml_mul(g, x, sub);
+            y = y ? ggml_concat(g, y, piece, 0) : piece;
+        }
+    }
+    T prev = ct.prev;
+    T partial = ggml_view_3d(g, prev, PT, prev->ne[1], prev->ne[2], prev->nb[1], prev->nb[2], prev->nb[0] * (size_t) (prev->ne[0] - PT));
+    T lower = ggml_view_3d(g, y, PT, y->ne[1], y->ne[2], y->nb[1], y->nb[2], 0);
+    lower = ggml_add_inplace(g, lower, partial);
+    y = ggml_view_3d(g, lower, y->ne[0], y->ne[1], y->ne[2], y->nb[1], y->nb[2], 0);
+    y = ggml_cpy(g, y, prev);
+    if (ct.b) y = ggml_add(g, y, ct.b);
+    y = ggml_view_3d(g, y, y->ne[0] - PT, y->ne[1], y->ne[2], y->nb[1], y->nb[2], 0);
+    return ggml_cont(g, y);
+}
+// moshi_seanet_resnet_block (moshi/modules/seanet.h:14-27)
+T resnet_block(Builder & g, ResBlock & rb, T x) {
+    T v = ggml_elu(g, x);
+    v = streaming_conv(g, rb.block1, v);
+    v = ggml_elu(g, v);
+    v = stateless_conv(g, rb.block3, v);
+    return ggml_add(g, x, v);
+}
+
+struct Codebook { T embedding = nullptr; };
+struct Rvq { std::vector<Codebook> layers; T input_proj = nullptr, output_proj = nullptr; int n_q = 0; };
+
+// moshi_vq_decode (moshi/quantization/core_vq.h:100-109)
+T vq_decode(Builder & g, Codebook & cb, T codes) {
+    T q = ggml_get_rows(g, cb.embedding, ggml_cont(g, codes));
+    q = ggml_permute(g, q, 1, 0, 2, 3);
+    return ggml_cont(g, q);
+}
+// moshi_rvq_decode + moshi_residual_vq_decode (vq.h:18-30, core_vq.h:139-169)
+T rvq_decode(Builder & g, Rvq & rvq, T codes) {
+    codes = ggml_permute(g, codes, 0, 2, 1, 3);
+    const int64_t Tn = codes->ne[0], B = codes->ne[1], K = codes->ne[2];
+    T quantized = nullptr;
+    for (size_t i = 0; i < rvq.layers.size() && (int64_t) i < K; i++) {
+        T lc = ggml_view_3d(g, codes, Tn, B, 1, codes->nb[1], codes->nb[2], codes->nb[2] * i);
+        T dec = vq_decode(g, rvq.layers[i], lc);
+        quantized = quantized ? ggml_add(g, quantized, dec) : dec;
+    }
+    if (rvq.output_proj) quantized = ggml_conv_1d(g, rvq.output_proj, quantized, 1, 0, 1);
+    return quantized;
+}
+// moshi_EuclideanCodebook_encode (core_vq.h:27-56): nearest centroid via the materialised difference
+T codebook_encode(Builder & g, Codebook & cb, T x) {
+    T a = ggml_cont(g, x);
+    T b = cb.embedding;
+    const int64_t ane1 = a->ne[1], bne1 = b->ne[1];
+    a = ggml_reshape_3d(g, a, a->ne[0], 1, a->ne[1]);
+    a = ggml_repeat_4d(g, a, a->ne[0], bne1, a->ne[2], 1);
+    a = ggml_reshape_3d(g, a, a->ne[0], a->ne[1] * a->ne[2], a->ne[3]);
+    b = ggml_repeat_4d(g, b, b->ne[0], b->ne[1] * ane1, b->ne[2], b->ne[3]);
+    T d = ggml_sub(g, b, a);
+    d = ggml_mul(g, d, d);
+    d = ggml_sum_rows(g, d);
+    d = ggml_reshape_3d(g, d, bne1, ane1, 1);
+    d = ggml_add(g, d, g.f32(1.f));
+    d = ggml_div(g, g.fill(d->ne, 1.f), d);
+    return ggml_argmax(g, d);
+}
+// moshi_rvq_encode + moshi_residual_vq_encode (vq.h:32-45, core_vq.h:171-194)
+T rvq_encode(Builder & g, Rvq & rvq, T x) {
+    x = ggml_conv_1d(g, rvq.input_proj, x, 1, 0, 1);
+    T residual = x, out = nullptr;
+    for (int i = 0; i < rvq.n_q; i++) {
+        T xp = ggml_permute(g, residual, 1, 0, 2, 3);
+        T idx = codebook_encode(g, rvq.layers[(size_t) i], xp);
+        T quant = vq_decode(g, rvq.layers[(size_t) i], idx);
+        idx = ggml_cast(g, idx, GGML_TYPE_F32);
+        residual = ggml_sub(g, residual, quant);
+        out = out ? ggml_concat(g, out, idx, 2) : idx;
+    }
+    return ggml_permute(g, out, 0, 2, 1, 3);
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------------
+// model
+// ---------------------------------------------------------------------------------------------------
+struct moshi_hot_model {
+    moshi_hot_config cfg;
+    ggml_backend_t be;
+    Weights * W = nullptr;
+    // persistent state (StateContext, src/context.h:656-780)
+    struct ggml_context * st_ctx = nullptr; ggml_backend_buffer_t st_buf = nullptr;
+    std::vector<std::pair<T, std::vector<uint8_t>>> st_init;
+    Builder * scratch = nullptr;
+
+    // LM
+    Transformer temporal, depth;
+    Norm out_norm;
+    T text_emb = nullptr, text_linear = nullptr;
+    std::vector<T> emb, depformer_in, depformer_emb, linears;
+    T depformer_text_emb = nullptr;
+    T transformer_out = nullptr;   // state F32[dim] (lm.h:434)
+    Builder * g_temporal = nullptr; std::vector<T> emb_idx, emb_scale; T sampler_out = nullptr, text_logits = nullptr, g_transformer_out = nullptr;
+    Builder * g_depth = nullptr; T dep_text_idx = nullptr, dep_text_scale = nullptr, dep_tokens = nullptr; std::vector<T> dep_logits;
+    // delay ring (lm.h:715-743)
+    int offset = 0; std::vector<std::vector<int>> cache; std::vector<int> initial; int max_delay = 0;
+
+    // Mimi
+    Rvq rvq_first, rvq_rest;
+    ConvTr upsample; Conv downsample;
+    Transformer dec_tr, enc_tr;
+    std::vector<Conv> dec_convs; std::vector<ConvTr> dec_convtrs; std::vector<ResBlock> dec_res;
+    std::vector<Conv> enc_convs; std::vector<ResBlock> enc_res;
+    Builder * g_dec = nullptr; T dec_codes = nullptr, dec_frame = nullptr; int dec_T = 0;
+    Builder * g_enc = nullptr; T enc_frame = nullptr, enc_codes = nullptr; int enc_T = 0;
+
+    std::vector<int32_t> tokens_tmp;
+};
+
+namespace {
+
+T state(moshi_hot_model * m, enum ggml_type type, int64_t n0, int64_t n1 = 1, int64_t n2 = 1) {
+    T t = ggml_new_tensor_3d(m->st_ctx, type, n0, n1, n2);
+    m->st_init.push_back({ t, std::vector<uint8_t>(ggml_nbytes(t), 0) });   // zero-filled (transformer.h:164-166, conv.h:112)
+    return t;
+}
+
+void make_transformer(moshi_hot_model * m, Transformer & tr, const std::string & name, int dim, int heads, int n_layers, int ffn_hidden,
+                      int capacity, int max_period, int n_weight_sets, bool mimi_style, enum ggml_type wtype) {
+    Weights & W = *m->W;
+    tr.dim = dim; tr.heads = heads; tr.capacity = capacity; tr.max_period = max_period;
+    tr.layers.resize((size_t) n_layers);
+    const float s_in = 1.f / sqrtf((float) dim);
+    auto qgen = [](float sd) { return [sd](T t, Rng & r, std::vector<uint8_t> & o) { gen_quant(t, r, o, sd); }; };
+    auto ones = [](T t, Rng &, std::vector<uint8_t> & o) { gen_const(t, 1.f, o); };
+    auto zeros = [](T t, Rng &, std::vector<uint8_t> & o) { gen_const(t, 0.f, o); };
+    for (int l = 0; l < n_layers; l++) {
+        Layer & L = tr.layers[(size_t) l];
+        const std::string p = name + ".layers." + std::to_string(l) + ".";
+        if (mimi_style) {
+            L.norm1 = { false, 1e-5f, W.add(p + "norm1.weight", GGML_TYPE_F32, dim, 1, 1, ones), W.add(p + "norm1.bias", GGML_TYPE_F32, dim, 1, 1, zeros) };
+            L.norm2 = { false, 1e-5f, W.add(p + "norm2.weight", GGML_TYPE_F32, dim, 1, 1, ones), W.add(p + "norm2.bias", GGML_TYPE_F32, dim, 1, 1, zeros) };
+            L.layer_scale_1 = W.add(p + "layer_scale_1.scale", GGML_TYPE_F32, dim, 1, 1, [](T t, Rng &, std::vector<uint8_t> & o) { gen_const(t, 0.5f, o); });
+            L.layer_scale_2 = W.add(p + "layer_scale_2.scale", GGML_TYPE_F32, dim, 1, 1, [](T t, Rng &, std::vector<uint8_t> & o) { gen_const(t, 0.5f, o); });
+            L.linear1 = W.add(p + "linear1.weight", wtype, dim, ffn_hidden, 1, qgen(s_in));
+            L.linear2 = W.add(p + "linear2.weight", wtype, ffn_hidden, dim, 1, qgen(1.f / sqrtf((float) ffn_hidden)));
+        } else {
+            L.norm1 = { true, 1e-8f, W.add(p + "norm1.alpha", GGML_TYPE_F32, dim, 1, 1, ones), nullptr };
+            L.norm2 = { true, 1e-8f, W.add(p + "norm2.alpha", GGML_TYPE_F32, dim, 1, 1, ones), nullptr };
+        }
+        for (int w = 0; w < n_weight_sets; w++) {
+            const std::string ws = n_weight_sets > 1 ? "." + std::to_string(w) : "";
+            L.in_proj.push_back(W.add(p + "self_attn.in_projs" + ws + ".weight", wtype, dim, 3 * dim, 1, qgen(s_in)));
+            L.out_proj.push_back(W.add(p + "self_attn.out_projs" + ws + ".weight", wtype, dim, dim, 1, qgen(s_in)));
+            if (!mimi_style) {
+                L.gate_in.push_back(W.add(p + "gating" + ws + ".linear_in.weight", wtype, dim, 2 * ffn_hidden, 1, qgen(s_in)));
+                L.gate_out.push_back(W.add(p + "gating" + ws + ".linear_out.weight", wtype, ffn_hidden, dim, 1, qgen(1.f / sqrtf((float) ffn_hidden))));
+            }
+        }
+        L.kcache = state(m, GGML_TYPE_BF16, dim / heads, capacity, heads);
+        L.vcache = state(m, GGML_TYPE_BF16, dim / heads, capacity, heads);
+    }
+}
+
+Conv make_conv(moshi_hot_model * m, const std::string & name, int cin, int cout, int k, int stride, bool bias, bool stateful) {
+    Weights & W = *m->W;
+    Conv c = { cin, cout, k, stride };
+    const float sd = 1.f / sqrtf((float) (cin * k));
+    c.w = W.add(name + ".weight", GGML_TYPE_F16, k, cin, cout, [sd](T t, Rng & r, std::vector<uint8_t> & o) { gen_normal(t, r, o, sd); });   // loader.h:209: conv weights are F16
+    if (bias) c.b = W.add(name + ".bias", GGML_TYPE_F32, 1, cout, 1, [](T t, Rng & r, std::vector<uint8_t> & o) { gen_normal(t, r, o, 0.02f); });
+    if (stateful && k - stride > 0) c.prev = state(m, GGML_TYPE_F32, k - stride, cin);
+    return c;
+}
+ConvTr make_convtr(moshi_hot_model * m, const std::string & name, int cin, int cout, int k, int stride, int groups, bool bias, int64_t in_len) {
+    Weights & W = *m->W;
+    ConvTr c = { cin, cout, k, stride, groups };
+    const float sd = 1.f / sqrtf((float) (cin / groups));
+    c.w = W.add(name + ".weight", GGML_TYPE_F32, k, cout / groups, cin, [sd](T t, Rng & r, std::vector<uint8_t> & o) { gen_normal(t, r, o, sd); });
+    if (bias) c.b = W.add(name + ".bias", GGML_TYPE_F32, 1, cout, 1, [](T t, Rng & r, std::vector<uint8_t> & o) { gen_normal(t, r, o, 0.02f); });
+    c.prev = state(m, GGML_TYPE_F32, (in_len - 1) * stride + k, cout);   // conv.h:205-217
+    return c;
+}
+ResBlock make_res(moshi_hot_model * m, const std::string & name, int dim) {
+    ResBlock rb;
+    rb.block1 = make_conv(m, name + ".block.1.conv", dim, dim / 2, 3, 1, true, true);
+    rb.block3 = make_conv(m, name + ".block.3.conv", dim / 2, dim, 1, 1, true, false);
+    return rb;
+}
+void make_rvq(moshi_hot_model * m, Rvq & rvq, const std::string & name, int n_layers, int card) {
+    Weights & W = *m->W;
+    rvq.n_q = n_layers;
+    for (int i = 0; i < n_layers; i++) {
+        Codebook cb;
+        cb.embedding = W.add(name + ".vq.layers." + std::to_string(i) + "._codebook.embedding", GGML_TYPE_F32, 256, card, 1,
+                             [](T t, Rng & r, std::vector<uint8_t> & o) { gen_normal(t, r, o, 1.f); });
+        rvq.layers.push_back(cb);
+    }
+    rvq.input_proj = W.add(name + ".input_proj.weight", GGML_TYPE_F16, 1, 512, 256, [](T t, Rng & r, std::vector<uint8_t> & o) { gen_normal(t, r, o, 1.f / sqrtf(512.f)); });
+    rvq.output_proj = W.add(name + ".output_proj.weight", GGML_TYPE_F16, 1, 256, 512, [](T t, Rng & r, std::vector<uint8_t> & o) { gen_normal(t, r, o, 1.f / 16.f); });
+}
+
+// moshi_lmmodel_forward_text_build + sampler (lm.h:555-584, 659-677, 853-869)
+void build_temporal_graph(moshi_hot_model * m) {
+    const moshi_hot_config & c = m->cfg;
+    m->g_temporal = new Builder(m->be, 256);
+    Builder & g = *m->g_temporal;
+    auto embed = [&](T table) {   // moshi_scaled_embedding_build (lm_utils.h:157-170)
+        T idx = g.tensor(GGML_TYPE_I32, 1), scale = g.tensor(GGML_TYPE_F32, 1);
+        m->emb_idx.push_back(idx); m->emb_scale.push_back(scale);
+        return ggml_mul(g, ggml_get_rows(g, table, idx), scale);
+    };
+    T input = embed(m->text_emb);
+    for (int k = 0; k < c.n_q; k++) input = ggml_add(g, input, embed(m->emb[(size_t) k]));
+    T x = transformer_graph_build(g, m->temporal, input);
+    x = apply_norm(g, m->out_norm, x);
+    m->g_transformer_out = x;
+    m->text_logits = linear(g, m->text_linear, x);
+    g.expand(ggml_cpy(g, x, m->transformer_out));
+    m->sampler_out = sample_token(g, m->text_logits, c.temp_text, c.top_k_text);
+    g.expand(m->sampler_out);
+    g.alloc();
+}
+
+// moshi_lmmodel_depformer_step, graph part (lm.h:489-531)
+void build_depth_graph(moshi_hot_model * m) {
+    const moshi_hot_config & c = m->cfg;
+    m->g_depth = new Builder(m->be, 256);
+    Builder & g = *m->g_depth;
+    m->dep_text_idx = g.tensor(GGML_TYPE_I32, 1);
+    m->dep_text_scale = g.tensor(GGML_TYPE_F32, 1);
+    T last = ggml_mul(g, ggml_get_rows(g, m->depformer_text_emb, m->dep_text_idx), m->dep_text_scale);
+    T tokens = g.tensor(GGML_TYPE_I32, c.dep_q);
+    T view = nullptr, next = nullptr;
+    for (int k = 0; k < c.dep_q; k++) {
+        if (k > 0) last = ggml_get_rows(g, m->depformer_emb[(size_t) (k - 1)], next);   // moshi_scaled_embedding_chained
+        // moshi_lmmodel_forward_depformer_transform (lm.h:446-475)
+        T din = linear(g, m->depformer_in[(size_t) k], m->transformer_out);
+        last = ggml_cast(g, last, GGML_TYPE_F32);
+        din = ggml_add(g, din, last);
+        T dout = transformer_inline(g, m->depth, din);
+        T logits = linear(g, m->linears[(size_t) k], dout);
+        m->dep_logits.push_back(logits);
+        next = sample_token(g, logits, c.temp, c.top_k);
+        view = k == 0 ? ggml_view_1d(g, tokens, 1, 0) : ggml_view_1d(g, view, 1, 4);
+        g.expand(ggml_cpy(g, next, view));
+    }
+    m->dep_tokens = ggml_view_1d(g, view, tokens->ne[0], (size_t) (-(int64_t) (c.dep_q - 1) * 4));
+    g.expand(m->dep_tokens);
+    g.alloc();
+}
+
+// mimi_decode, graph part (compression.h:156-187)
+void build_decode_graph(moshi_hot_model * m) {
+    const moshi_hot_config & c = m->cfg;
+    m->g_dec = new Builder(m->be, 256);
+    Builder & g = *m->g_dec;
+    T codes = ggml_new_tensor_2d(g, GGML_TYPE_I32, 1, c.mimi_n_q);
+    m->dec_codes = codes;
+    // moshi_split_rvq_decode (vq.h:62-95)
+    const int64_t B = codes->ne[2], K = codes->ne[1], Tn = codes->ne[0];
+    T first = ggml_view_3d(g, codes, Tn, 1, B, codes->nb[1], codes->nb[2], 0);
+    T emb = rvq_decode(g, m->rvq_first, first);
+    if (K > 1) {
+        T rest = ggml_view_3d(g, codes, Tn, K - 1, B, codes->nb[1], codes->nb[2], codes->nb[1] * 1);
+        emb = ggml_add(g, emb, rvq_decode(g, m->rvq_rest, rest));
+    }
+    emb = streaming_conv_transpose(g, m->upsample, emb);
+    m->dec_T = (int) emb->ne[0];
+    // moshi_projected_transformer_graph_build (transformer.h:1356-1365)
+    T x = ggml_cont(g, ggml_transpose(g, emb));
+    x = transformer_graph_build(g, m->dec_tr, x);
+    x = ggml_transpose(g, x);
+    // moshi_seanet_decoder (seanet.h:179-211)
+    x = streaming_conv(g, m->dec_convs[0], x);
+    x = ggml_elu(g, x);
+    for (int i = 0; i < 4; i++) {
+        x = streaming_conv_transpose(g, m->dec_convtrs[(size_t) i], x);
+        x = resnet_block(g, m->dec_res[(size_t) i], x);
+        x = ggml_elu(g, x);
+    }
+    x = streaming_conv(g, m->dec_convs[1], x);
+    m->dec_frame = x;
+    g.expand(x);
+    g.alloc();
+}
+
+// mimi_encode, graph part (compression.h:284-308)
+void build_encode_graph(moshi_hot_model * m) {
+    const moshi_hot_config & c = m->cfg;
+    m->g_enc = new Builder(m->be, 256);
+    Builder & g = *m->g_enc;
+    T x = ggml_new_tensor_1d(g, GGML_TYPE_F32, 1920);
+    m->enc_frame = x;
+    // moshi_seanet_encoder (seanet.h:88-113)
+    x = streaming_conv(g, m->enc_convs[0], x);
+    for (int i = 0; i < 4; i++) {
+        x = resnet_block(g, m->enc_res[(size_t) i], x);
+        x = ggml_elu(g, x);
+        x = streaming_conv(g, m->enc_convs[(size_t) (1 + i)], x);
+    }
+    x = ggml_elu(g, x);
+    x = streaming_conv(g, m->enc_convs[5], x);
+    m->enc_T = (int) x->ne[0];
+    x = ggml_cont(g, ggml_transpose(g, x));
+    x = transformer_graph_build(g, m->enc_tr, x);
+    x = ggml_transpose(g, x);
+    x = streaming_conv(g, m->downsample, x);
+    // moshi_split_rvq_encode (vq.h:97-114)
+    T codes = rvq_encode(g, m->rvq_first, x);
+    if (c.mimi_n_q > 1) codes = ggml_concat(g, codes, rvq_encode(g, m->rvq_rest, x), 1);
+    codes = ggml_cast(g, codes, GGML_TYPE_I32);
+    m->enc_codes = codes;
+    g.expand(codes);
+    g.alloc();
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------------
+// C-ABI
+// ---------------------------------------------------------------------------------------------------
+extern "C" void moshi_hot_config_moshika(struct moshi_hot_config * c) {
+    memset(c, 0, sizeof(*c));
+    c->dim = 4096; c->num_heads = 32; c->num_layers = 32; c->ffn_hidden = 11264; c->context = 3000; c->max_period = 10000;
+    c->text_card = 32000; c->card = 2048; c->n_q = 16; c->dep_q = 8;
+    const int d[17] = { 0, 0, 1, 1, 1, 1, 1, 1, 1, 0, 1, 1, 1, 1, 1, 1, 1 };
+    for (int i = 0; i < 17; i++) c->delays[i] = d[i];
+    c->dep_dim = 1024; c->dep_heads = 16; c->dep_layers = 6; c->dep_ffn_hidden = 2816; c->dep_context = 8;
+    c->linear_type = GGML_TYPE_Q4_K; c->embed_type = GGML_TYPE_Q4_0;
+    c->mimi_n_q = 8; c->mimi_codebook_size = 2048;
+    c->enable_lm = 1; c->enable_mimi_encoder = 1; c->enable_mimi_decoder = 1;
+    c->temp = 0.f; c->temp_text = 0.f; c->top_k = 250; c->top_k_text = 25;
+}
+
+extern "C" moshi_hot_model_t * moshi_hot_create(ggml_backend_t backend, const struct moshi_hot_config * cfg, uint64_t seed) {
+    moshi_hot_model * m = new moshi_hot_model;
+    m->cfg = *cfg;
+    m->be = backend;
+    const moshi_hot_config & c = m->cfg;
+    m->W = new Weights(backend, seed, 4096);
+    m->st_ctx = ggml_init({ ggml_tensor_overhead() * 1024, NULL, true });
+    m->scratch = new Builder(backend, 16);
+    Weights & W = *m->W;
+    const enum ggml_type lt = (enum ggml_type) c.linear_type, et = (enum ggml_type) c.embed_type;
+    auto qgen = [](float sd) { return [sd](T t, Rng & r, std::vector<uint8_t> & o) { gen_quant(t, r, o, sd); }; };
+    auto ones = [](T t, Rng &, std::vector<uint8_t> & o) { gen_const(t, 1.f, o); };
+
+    if (c.enable_lm) {
+        W.part = 4;
+        m->text_emb = W.add("lm.text_emb.weight", et, c.dim, c.text_card + 1, 1, qgen(1.f));
+        for (int k = 0; k < c.n_q; k++) m->emb.push_back(W.add("lm.emb." + std::to_string(k) + ".weight", et, c.dim, c.card + 1, 1, qgen(1.f)));
+        W.part = 0;
+        make_transformer(m, m->temporal, "lm.transformer", c.dim, c.num_heads, c.num_layers, c.ffn_hidden, c.context, c.max_period, 1, false, lt);
+        m->out_norm = { true, 1e-8f, W.add("lm.out_norm.alpha", GGML_TYPE_F32, c.dim, 1, 1, ones), nullptr };
+        m->text_linear = W.add("lm.text_linear.weight", lt, c.dim, c.text_card, 1, qgen(1.f / sqrtf((float) c.dim)));
+        m->transformer_out = state(m, GGML_TYPE_F32, c.dim);
+        if (c.dep_q > 0) {
+            W.part = 1;
+            for (int k = 0; k < c.dep_q; k++) {
+                m->depformer_in.push_back(W.add("lm.depformer_in." + std::to_string(k) + ".weight", lt, c.dim, c.dep_dim, 1, qgen(1.f / sqrtf((float) c.dim))));
+                m->linears.push_back(W.add("lm.linears." + std::to_string(k) + ".weight", lt, c.dep_dim, c.card, 1, qgen(1.f / sqrtf((float) c.dep_dim))));
+                W.part = 4;
+                if (k > 0) m->depformer_emb.push_back(W.add("lm.depformer_emb." + std::to_string(k - 1) + ".weight", et, c.dep_dim, c.card + 1, 1, qgen(1.f)));
+                W.part = 1;
+            }
+            W.part = 4;
+            m->depformer_text_emb = W.add("lm.depformer_text_emb.weight", et, c.dep_dim, c.text_card + 1, 1, qgen(1.f));
+            W.part = 1;
+            make_transformer(m, m->depth, "lm.depformer", c.dep_dim, c.dep_heads, c.dep_layers, c.dep_ffn_hidden, c.dep_context, 0, c.dep_q, false, lt);
+        }
+        // moshi_lmgen_state (lm.h:722-743)
+        const int ncb = c.n_q + 1;
+        for (int i = 0; i < ncb; i++) if (c.delays[i] > m->max_delay) m->max_delay = c.delays[i];
+        m->cache.assign((size_t) (m->max_delay + 2), std::vector<int>((size_t) ncb, -2));
+        m->initial.assign((size_t) ncb, c.card);
+        m->initial[0] = c.text_card;
+    }
+    if (c.enable_mimi_decoder || c.enable_mimi_encoder) {
+        W.part = c.enable_mimi_decoder ? 3 : 2;
+        make_rvq(m, m->rvq_first, "mimi.quantizer.rvq_first", 1, c.mimi_codebook_size);
+        make_rvq(m, m->rvq_rest, "mimi.quantizer.rvq_rest", c.mimi_n_q > 1 ? c.mimi_n_q - 1 : 0, c.mimi_codebook_size);
+    }
+    if (c.enable_mimi_decoder) {   // moshi_mimi_alloc_default, decoder half (lm_default.h:229-415); states: src/moshi.cpp:244-262
+        W.part = 3;
+        m->upsample = make_convtr(m, "mimi.upsample.convtr", 512, 512, 4, 2, 512, false, 1);
+        make_transformer(m, m->dec_tr, "mimi.decoder_transformer.transformer", 512, 8, 8, 2048, 250, 10000, 1, true, GGML_TYPE_F32);
+        m->dec_convs.push_back(make_conv(m, "mimi.decoder.model.0.conv", 512, 1024, 7, 1, true, true));
+        const int ch[5] = { 1024, 512, 256, 128, 64 }, ks[4] = { 16, 12, 10, 8 }, st[4] = { 8, 6, 5, 4 };
+        int64_t len = 2;
+        for (int i = 0; i < 4; i++) {
+            m->dec_convtrs.push_back(make_convtr(m, "mimi.decoder.model." + std::to_string(2 + 3 * i) + ".convtr", ch[i], ch[i + 1], ks[i], st[i], 1, true, len));
+            len = len * st[i];
+            m->dec_res.push_back(make_res(m, "mimi.decoder.model." + std::to_string(3 + 3 * i), ch[i + 1]));
+        }
+        m->dec_convs.push_back(make_conv(m, "mimi.decoder.model.14.conv", 64, 1, 3, 1, true, true));
+    }
+    if (c.enable_mimi_encoder) {   // encoder half (lm_default.h:416-560)
+        W.part = 2;
+        m->enc_convs.push_back(make_conv(m, "mimi.encoder.model.0.conv", 1, 64, 7, 1, true, true));
+        const int ch[5] = { 64, 128, 256, 512, 1024 }, ks[4] = { 8, 10, 12, 16 }, st[4] = { 4, 5, 6, 8 };
+        for (int i = 0; i < 4; i++) {
+            m->enc_res.push_back(make_res(m, "mimi.encoder.model." + std::to_string(1 + 3 * i), ch[i]));
+            m->enc_convs.push_back(make_conv(m, "mimi.encoder.model." + std::to_string(3 + 3 * i) + ".conv", ch[i], ch[i + 1], ks[i], st[i], true, true));
+        }
+        m->enc_convs.push_back(make_conv(m, "mimi.encoder.model.14.conv", 1024, 512, 3, 1, true, true));
+        make_transformer(m, m->enc_tr, "mimi.encoder_transformer.transformer", 512, 8, 8, 2048, 250, 10000, 1, true, GGML_TYPE_F32);
+        m->downsample = make_conv(m, "mimi.downsample.conv", 512, 512, 4, 2, false, true);
+    }
+    W.load();
+    m->st_buf = ggml_backend_alloc_ctx_tensors(m->st_ctx, backend);
+    GGML_ASSERT(m->st_buf);
+    for (auto & s : m->st_init) ggml_backend_tensor_set(s.first, s.second.data(), 0, s.second.size());
+    m->st_init.clear();
+    m->tokens_tmp.resize((size_t) (c.n_q + 1));
+    return m;
+}
+
+extern "C" void moshi_hot_free(moshi_hot_model_t * m) {
+    if (!m) return;
+    delete m->g_temporal; delete m->g_depth; delete m->g_dec; delete m->g_enc; delete m->scratch;
+    if (m->st_buf) ggml_backend_buffer_free(m->st_buf);
+    ggml_free(m->st_ctx);
+    delete m->W;
+    delete m;
+}
+
+// mimi_decode, per-frame part (compression.h:189-203)
+extern "C" void moshi_hot_mimi_decode(moshi_hot_model_t * m, const int32_t * codes, float * pcm) {
+    if (!m->g_dec) build_decode_graph(m);
+    ggml_backend_tensor_set(m->dec_codes, codes, 0, ggml_nbytes(m->dec_codes));
+    transformer_graph_step(*m->scratch, m->dec_tr, m->dec_T);
+    m->scratch->compute_scratch();
+    m->g_dec->compute();
+    if (pcm) ggml_backend_tensor_get(m->dec_frame, pcm, 0, ggml_nbytes(m->dec_frame));
+    else { float tmp; ggml_backend_tensor_get(m->dec_frame, &tmp, 0, 4); }
+}
+
+// mimi_encode, per-frame part (compression.h:310-324)
+extern "C" void moshi_hot_mimi_encode(moshi_hot_model_t * m, const float * pcm, int32_t * codes) {
+    if (!m->g_enc) build_encode_graph(m);
+    ggml_backend_tensor_set(m->enc_frame, pcm, 0, ggml_nbytes(m->enc_frame));
+    transformer_graph_step(*m->scratch, m->enc_tr, m->enc_T);
+    m->scratch->compute_scratch();
+    m->g_enc->compute();
+    ggml_backend_tensor_get(m->enc_codes, codes, 0, ggml_nbytes(m->enc_codes));
+}
+
+// moshi_lmgen_step (lm.h:778-979) for the plain moshi model: no state machine, no prefixes
+extern "C" int moshi_hot_lm_step(moshi_hot_model_t * m, const int32_t * in_audio, int32_t * text_token_out, int32_t * out_audio) {
+    const moshi_hot_config & c = m->cfg;
+    const int ncb = c.n_q + 1, CT = (int) m->cache.size();
+    const int dep_q = c.dep_q, dep_q_1 = dep_q + 1;
+    const int needed = ncb - dep_q - 1;
+    for (int i = 0; i < needed; i++) {   // other speaker's codes enter the delay ring (lm.h:819-824)
+        const int wp = (m->offset + c.delays[dep_q_1 + i]) % CT;
+        m->cache[(size_t) wp][(size_t) (dep_q_1 + i)] = in_audio[i];
+    }
+    const int pos = m->offset % CT;
+    std::vector<int> input((size_t) ncb);
+    for (int i = 0; i < ncb; i++) input[(size_t) i] = m->offset <= c.delays[i] ? m->initial[(size_t) i] : m->cache[(size_t) pos][(size_t) i];
+
+    if (!m->g_temporal) build_temporal_graph(m);
+    // moshi_lmmodel_text_token_embed_step (lm.h:586-607): -1 -> scale 0, negative ids -> row 0
+    for (int i = 0; i < ncb; i++) {
+        int32_t id = input[(size_t) i];
+        const float sc = id == -1 ? 0.f : 1.f;
+        if (id < 0) id = 0;
+        ggml_backend_tensor_set(m->emb_idx[(size_t) i], &id, 0, 4);
+        ggml_backend_tensor_set(m->emb_scale[(size_t) i], &sc, 0, 4);
+    }
+    transformer_graph_step(*m->scratch, m->temporal, 1);
+    m->scratch->compute_scratch();
+    m->g_temporal->compute();
+    int32_t text_token = 0;
+    ggml_backend_tensor_get(m->sampler_out, &text_token, 0, 4);
+
+    std::vector<int32_t> audio((size_t) dep_q, 0);
+    if (dep_q > 0) {   // moshi_lmmodel_depformer_step (lm.h:532-552)
+        if (!m->g_depth) build_depth_graph(m);
+        int32_t id = text_token; const float sc = id == -1 ? 0.f : 1.f;
+        if (id < 0) id = 0;
+        ggml_backend_tensor_set(m->dep_text_idx, &id, 0, 4);
+        ggml_backend_tensor_set(m->dep_text_scale, &sc, 0, 4);
+        m->g_depth->compute();
+        ggml_backend_tensor_get(m->dep_tokens, audio.data(), 0, (size_t) dep_q * 4);
+    }
+    m->offset++;
+    const int wpos = m->offset % CT;   // lm.h:935-943
+    m->cache[(size_t) wpos][0] = text_token;
+    for (int q = 0; q < dep_q; q++) m->cache[(size_t) wpos][(size_t) (q + 1)] = audio[(size_t) q];
+    if (m->offset <= m->max_delay) return 0;
+    int idx = (m->offset - m->max_delay + c.delays[0]) % CT;   // lm.h:954-959
+    *text_token_out = m->cache[(size_t) idx][0];
+    for (int i = 1; i < dep_q_1; i++) {
+        idx = (m->offset - m->max_delay + c.delays[i]) % CT;
+        out_audio[i - 1] = m->cache[(size_t) idx][(size_t) i];
+    }
+    for (int i = 0; i < dep_q; i++) if (out_audio[i] == -1) return 0;
+    return 1;
+}
+
+// one iteration of the moshi-sts --bench loop (tools/moshi-sts.cpp:770-808)
+extern "C" int moshi_hot_sts_frame(moshi_hot_model_t * m, const float * pcm_in, int32_t * text_token, int32_t * audio_tokens, float * pcm_out) {
+    int32_t * codes = m->tokens_tmp.data();
+    moshi_hot_mimi_encode(m, pcm_in, codes);
+    if (!moshi_hot_lm_step(m, codes, text_token, audio_tokens)) return 0;
+    moshi_hot_mimi_decode(m, audio_tokens, pcm_out);
+    return 1;
+}
+
+extern "C" int64_t moshi_hot_offset(moshi_hot_model_t * m) { return m->offset; }
+extern "C" size_t moshi_hot_weight_bytes(moshi_hot_model_t * m, int part) { return part >= 0 && part < 5 ? m->W->bytes[part] : 0; }
+extern "C" int moshi_hot_read_last(moshi_hot_model_t * m, const char * what, float * out, int64_t n) {
+    T t = nullptr;
+    if (!strcmp(what, "text_logits")) t = m->text_logits;
+    else if (!strcmp(what, "transformer_out")) t = m->transformer_out;
+    else if (!strncmp(what, "dep_logits", 10)) { const int k = atoi(what + 10); if (k >= 0 && k < (int) m->dep_logits.size()) t = m->dep_logits[(size_t) k]; }
+    if (!t || ggml_nelements(t) < n) return -1;
+    ggml_backend_tensor_get(t, out, 0, (size_t) n * 4);
+    return 0;
+}
+extern "C" void moshi_hot_set_context_fill(moshi_hot_model_t * m, int64_t offset) { m->temporal.offset = (int) offset; }

@@ -1,0 +1,58 @@
+"""ctypes binding of include/moshi_hot.h (the host-side hot-path driver inside libggml-mi355x.so)."""
+import ctypes as C
+
+MAX_CB = 33
+
+
+class Config(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("dim", "num_heads", "num_layers", "ffn_hidden", "context", "max_period",
+                                         "text_card", "card", "n_q", "dep_q")] + \
+               [("delays", C.c_int32 * MAX_CB)] + \
+               [(n, C.c_int32) for n in ("dep_dim", "dep_heads", "dep_layers", "dep_ffn_hidden", "dep_context",
+                                         "linear_type", "embed_type", "mimi_n_q", "mimi_codebook_size",
+                                         "enable_lm", "enable_mimi_encoder", "enable_mimi_decoder")] + \
+               [("temp", C.c_float), ("temp_text", C.c_float), ("top_k", C.c_int32), ("top_k_text", C.c_int32)]
+
+
+P = C.c_void_p
+SIGNATURES = {
+    "moshi_hot_config_moshika": (None, [C.POINTER(Config)]),
+    "moshi_hot_create": (P, [P, C.POINTER(Config), C.c_uint64]),
+    "moshi_hot_free": (None, [P]),
+    "moshi_hot_mimi_encode": (None, [P, P, P]),
+    "moshi_hot_mimi_decode": (None, [P, P, P]),
+    "moshi_hot_lm_step": (C.c_int, [P, P, P, P]),
+    "moshi_hot_sts_frame": (C.c_int, [P, P, P, P, P]),
+    "moshi_hot_offset": (C.c_int64, [P]),
+    "moshi_hot_weight_bytes": (C.c_size_t, [P, C.c_int]),
+    "moshi_hot_read_last": (C.c_int, [P, C.c_char_p, P, C.c_int64]),
+    "moshi_hot_set_context_fill": (None, [P, C.c_int64]),
+}
+
+
+def attach(lib):
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)   # AttributeError -> loud failure in load()
+        fn.restype, fn.argtypes = res, args
+
+
+def moshika(lib):
+    cfg = Config()
+    lib.moshi_hot_config_moshika(C.byref(cfg))
+    return cfg
+
+
+def tiny(lib, linear_type=12, embed_type=2, layers=2, dep_q=3, n_q=6, context=24):
+    """A small model with the same structure as moshika (for parity tests that the oracle finishes in seconds)."""
+    cfg = moshika(lib)
+    cfg.dim, cfg.num_heads, cfg.num_layers, cfg.ffn_hidden, cfg.context = 512, 4, layers, 768, context
+    cfg.text_card, cfg.card, cfg.n_q, cfg.dep_q = 500, 64, n_q, dep_q
+    for i in range(MAX_CB):
+        cfg.delays[i] = 0
+    d = [0, 0] + [1] * (dep_q - 1) + [0] + [1] * (n_q - dep_q - 1)
+    for i, v in enumerate(d[:n_q + 1]):
+        cfg.delays[i] = v
+    cfg.dep_dim, cfg.dep_heads, cfg.dep_layers, cfg.dep_ffn_hidden, cfg.dep_context = 256, 4, 2, 512, dep_q
+    cfg.linear_type, cfg.embed_type = linear_type, embed_type
+    cfg.mimi_n_q, cfg.mimi_codebook_size = n_q - dep_q, 64
+    return cfg

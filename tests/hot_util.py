@@ -1,0 +1,80 @@
+"""Helpers to drive the host-side hot-path driver (include/moshi_hot.h) on a backend."""
+import ctypes as C
+
+import numpy as np
+
+import ggml_util as gu
+
+L = gu.lib()
+pkg = gu.pkg
+from moshi_cpp_amd import hot  # noqa: E402
+
+
+def make_backend(kind, threads=8):
+    L.ggml_backend_load_all()
+    if kind == "hip":
+        be = L.ggml_backend_init_by_type(pkg.DEV_GPU, None)
+        if not be:
+            raise RuntimeError("no MI355X device (the hot path has no CPU fallback)")
+        return be
+    gu.attach_oracle()
+    be = L.ggml_backend_init_by_type(pkg.DEV_CPU, None)
+    L.ggml_backend_cpu_set_n_threads(be, threads)
+    return be
+
+
+class Model:
+    def __init__(self, kind, cfg, seed=0, flags=0):
+        self.cfg = cfg
+        self.be = make_backend(kind)
+        if kind == "hip" and flags:
+            L.ggml_backend_mi355x_set_flags(self.be, flags)
+        self.kind = kind
+        self.m = L.moshi_hot_create(self.be, C.byref(cfg), seed)
+        assert self.m
+
+    def sts_frame(self, pcm):
+        pcm = np.ascontiguousarray(pcm, np.float32)
+        txt = C.c_int32(-7)
+        aud = (C.c_int32 * 32)()
+        out = np.zeros(1920, np.float32)
+        r = L.moshi_hot_sts_frame(self.m, pcm.ctypes.data, C.byref(txt), aud, out.ctypes.data)
+        return r, txt.value, list(aud)[:self.cfg.dep_q], out
+
+    def lm_step(self, in_audio):
+        ia = (C.c_int32 * 32)(*in_audio)
+        txt = C.c_int32(-7)
+        aud = (C.c_int32 * 32)()
+        r = L.moshi_hot_lm_step(self.m, ia, C.byref(txt), aud)
+        return r, txt.value, list(aud)[:self.cfg.dep_q]
+
+    def mimi_decode(self, codes):
+        cc = (C.c_int32 * 32)(*codes)
+        out = np.zeros(1920, np.float32)
+        L.moshi_hot_mimi_decode(self.m, cc, out.ctypes.data)
+        return out
+
+    def mimi_encode(self, pcm):
+        pcm = np.ascontiguousarray(pcm, np.float32)
+        codes = (C.c_int32 * 32)()
+        L.moshi_hot_mimi_encode(self.m, pcm.ctypes.data, codes)
+        return list(codes)[:self.cfg.mimi_n_q]
+
+    def read(self, what, n):
+        out = np.zeros(n, np.float32)
+        assert L.moshi_hot_read_last(self.m, what.encode(), out.ctypes.data, n) == 0
+        return out
+
+    def stats(self):
+        s = pkg.Stats()
+        L.ggml_backend_mi355x_get_stats(self.be, C.byref(s))
+        return s
+
+    def free(self):
+        L.moshi_hot_free(self.m)
+        L.ggml_backend_free(self.be)
+
+
+def rel_err(ref, got):
+    scale = max(float(np.max(np.abs(ref))), 1e-30)
+    return float(np.max(np.abs(ref - got))) / scale

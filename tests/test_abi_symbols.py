@@ -1,0 +1,67 @@
+"""CPU: the C-ABI library loads without a GPU and exports every symbol include/*.h declares (no compute calls)."""
+import ctypes as C
+import os
+import re
+
+import ggml_util as gu
+
+ROOT = gu.ROOT
+HEADERS = ["ggml.h", "ggml-backend.h", "ggml-cpu.h", "gguf.h", "moshi_hot.h"]
+
+
+def declared_in_headers():
+    names = set()
+    for h in HEADERS:
+        src = open(os.path.join(ROOT, "include", h)).read()
+        for m in re.finditer(r"GGML_API[^;{]*?\b([A-Za-z_][A-Za-z0-9_]*)\s*\(", src):
+            names.add(m.group(1))
+    names.discard("__attribute__")
+    return names
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    lib = gu.lib()
+    missing = [n for n in sorted(declared_in_headers()) if not hasattr(lib, n)]
+    assert not missing, f"declared in include/*.h but not exported: {missing}"
+
+
+def test_python_signature_table_covers_the_headers():
+    from moshi_cpp_amd import hot
+    table = set(gu.pkg.SIGNATURES) | set(hot.SIGNATURES)
+    hdr = declared_in_headers()
+    assert not (hdr - table - {"ggml_abort"}), f"headers declare symbols the binding table lacks: {sorted(hdr - table)}"
+    assert not (table - hdr), f"binding table lists symbols no header declares: {sorted(table - hdr)}"
+
+
+def test_devices_and_cpu_backend_without_gpu_compute():
+    L = gu.lib()
+    L.ggml_backend_load_all()
+    assert L.ggml_backend_dev_count() >= 1
+    cpu = L.ggml_backend_init_by_type(gu.pkg.DEV_CPU, None)
+    assert cpu and L.ggml_backend_is_cpu(cpu)
+    dev = L.ggml_backend_get_device(cpu)
+    props = gu.pkg.DevProps()
+    L.ggml_backend_dev_get_props(dev, C.byref(props))
+    assert props.name == b"CPU" and props.type == gu.pkg.DEV_CPU and props.memory_total > 0
+    reg = L.ggml_backend_dev_backend_reg(dev)
+    assert L.ggml_backend_reg_get_proc_address(reg, b"ggml_backend_set_n_threads")
+    assert L.ggml_backend_init_by_name(b"no-such-device", None) is None
+    L.ggml_backend_free(cpu)
+
+
+def test_cpu_device_has_no_builtin_executor():
+    """The product never computes on the CPU by itself: without the oracle attached graph_compute fails loudly."""
+    L = gu.lib()
+    L.ggml_backend_cpu_set_graph_compute(None)
+    gu._oracle_attached = False
+    cpu = L.ggml_backend_init_by_type(gu.pkg.DEV_CPU, None)
+    ctx = L.ggml_init(gu.pkg.InitParams(1 << 20, None, True))
+    a = L.ggml_new_tensor_1d(ctx, gu.F32, 4)
+    y = L.ggml_scale(ctx, a, 2.0)
+    g = L.ggml_new_graph(ctx)
+    L.ggml_build_forward_expand(g, y)
+    buf = L.ggml_backend_alloc_ctx_tensors(ctx, cpu)
+    assert L.ggml_backend_graph_compute(cpu, g) == -1   # GGML_STATUS_FAILED
+    L.ggml_backend_buffer_free(buf)
+    L.ggml_free(ctx)
+    L.ggml_backend_free(cpu)

@@ -122,13 +122,13 @@ def test_cpy_cast_cont_permute():
 
 
 def test_concat_repeat_arange_views():
-    a, b = rnd(2, 3, 5), rnd(2, 4, 5)
+    a, b, rr = rnd(2, 3, 5), rnd(2, 4, 5), rnd(1, 7)
 
     def build(g):
         x, y = g.input(a), g.input(b)
         c1 = g.concat(x, y, 1)
         c0 = g.concat(x, x, 0)
-        r = g.repeat_4d(g.input(rnd(1, 7)), 7, 5, 2, 1)
+        r = g.repeat_4d(g.input(rr), 7, 5, 2, 1)
         ar = g.arange(0.0, 10.0, 1.0)
         v = g.cont(g.view_2d(c1, 3, 7, c1.contents.nb[1], 4))
         return [c1, c0, r, ar, v]
@@ -172,16 +172,17 @@ def test_set_rows_bf16_cache():
 def test_mul_mat_types(wtype, K, M, N):
     r = np.random.default_rng(K + M)
     x = r.standard_normal((N, K)).astype(np.float32)
+    if wtype == Q4_K:
+        wraw = gu.random_q4_K(r, M, K)
+    elif wtype == Q8_0:
+        wraw = gu.random_q8_0(r, M, K)
+    elif wtype == Q4_0:
+        wraw = gu.random_q4_0(r, M, K)
+    else:
+        wraw = (r.standard_normal((M, K)) / np.sqrt(K)).astype(np.float32)
 
     def build(g):
-        if wtype == Q4_K:
-            w = g.input_raw(gu.random_q4_K(r, M, K), wtype, K, M)
-        elif wtype == Q8_0:
-            w = g.input_raw(gu.random_q8_0(r, M, K), wtype, K, M)
-        elif wtype == Q4_0:
-            w = g.input_raw(gu.random_q4_0(r, M, K), wtype, K, M)
-        else:
-            w = g.input((r.standard_normal((M, K)) / np.sqrt(K)).astype(np.float32), wtype)
+        w = g.input_raw(wraw, wtype, K, M) if wtype in (Q4_K, Q8_0, Q4_0) else g.input(wraw, wtype)
         return [g.mul_mat(w, g.input(x))]
     gu.compare(build, atol_rel=2e-6)
 

@@ -1,0 +1,127 @@
+"""CPU: the oracle (oracle/liboracle.so, run through the host device) against the PyTorch-made fixture
+tests/golden/ops.npz (generator: tests/golden/make_golden.py). This is what pins the oracle: the reference
+ships no vectors of its own for this path."""
+import os
+
+import numpy as np
+import pytest
+
+import ggml_util as gu
+from ggml_util import BF16, F16, F32, I32
+
+G = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ops.npz"))
+
+
+def oracle(build):
+    res, _ = gu.run_graph("oracle", build)
+    return res
+
+
+def close(a, b, tol):
+    a, b = np.asarray(a, np.float32), np.asarray(b, np.float32)
+    a = a.reshape(b.shape)   # ggml results come back 4-D
+    scale = max(float(np.abs(b).max()), 1e-30)
+    assert float(np.abs(a - b).max()) <= tol * scale, f"max err {np.abs(a - b).max():.3e} vs scale {scale:.3e}"
+
+
+def test_rms_norm_and_layer_norm():
+    def build(g):
+        x = g.input(G["rms_x"])
+        rms = g.mul(g.rms_norm(x, 1e-8), g.input(G["rms_alpha"]))   # 3 rows: alpha is the broadcast operand
+        ln = g.add(g.mul(g.norm(x, 1e-5), g.input(G["ln_w"])), g.input(G["ln_b"]))
+        return [rms, ln]
+    rms, ln = oracle(build)
+    close(rms, G["rms_y"], 2e-6)
+    close(ln, G["ln_y"], 2e-6)
+
+
+def test_activations():
+    def build(g):
+        x = g.input(G["act_x"])
+        return [g.silu(x), g.elu(x), g.gelu(x)]
+    silu, elu, gelu = oracle(build)
+    close(silu, G["silu_y"], 1e-6)
+    close(elu, G["elu_y"], 1e-6)
+    close(gelu, G["gelu_y"], 1.5e-3)   # ggml evaluates gelu through an F16 table: one f16 ulp
+
+
+def test_masked_softmax():
+    def build(g):
+        return [g.soft_max_ext(g.input(G["sm_x"]), g.input(G["sm_mask"]), 0.125, 0.0)]
+    close(oracle(build)[0], G["sm_y"], 1e-6)
+
+
+@pytest.mark.parametrize("stride,key", [(1, "conv_y_s1"), (2, "conv_y_s2")])
+def test_conv1d(stride, key):
+    def build(g):
+        y = g.conv_1d(g.input(G["conv_w"], F16), g.input(G["conv_x"]), stride, 0, 1)   # -> [OL, Cout]
+        return [g.cont(y)]
+    close(oracle(build)[0], G[key], 2e-6)
+
+
+def test_conv_transpose1d():
+    def build(g):
+        return [g.conv_transpose_1d(g.input(G["convtr_w"]), g.input(G["convtr_x"]), 2, 0, 1)]
+    close(oracle(build)[0], G["convtr_y"], 2e-6)
+
+
+def test_timestep_embedding():
+    def build(g):
+        return [g.timestep_embedding(g.input(G["ts_t"]), 64, 10000)]
+    close(oracle(build)[0], G["ts_y"], 5e-5)   # arguments up to 250 rad amplify 1-ulp frequency differences
+
+
+def test_rope_interleaved_to_split():
+    # the node sequence of moshi_apply_rope (src/moshi/modules/rope.h:33-128) on q [D, T, H]
+    q = G["rope_q"]
+    H, T, D = q.shape
+
+    def build(g):
+        x = g.input(q)                                        # ne = [D, T, H]
+        ts = g.add(g.input(np.arange(T, dtype=np.float32)), g.input(np.array([G["rope_offset"]], np.float32)))
+        rot = g.timestep_embedding(ts, D, 10000)
+        rotr = g.view_2d(rot, D // 2, T, rot.contents.nb[1], 0)
+        roti = g.view_2d(rot, D // 2, T, rot.contents.nb[1], rot.contents.nb[0] * (D // 2))
+        xc = g.reshape_4d(g.cont(x), 2, D // 2, T, H)
+        xc = g.cont(g.permute(xc, 3, 0, 1, 2))
+        xr = g.view_3d(xc, D // 2, T, H, xc.contents.nb[1], xc.contents.nb[2], 0)
+        xi = g.view_3d(xc, D // 2, T, H, xc.contents.nb[1], xc.contents.nb[2], xc.contents.nb[2] * H)
+        re = g.sub(g.mul(xr, rotr), g.mul(xi, roti))
+        im = g.add(g.mul(xr, roti), g.mul(xi, rotr))
+        return [g.concat(re, im, 0)]
+    close(oracle(build)[0], G["rope_y"], 2e-6)
+
+
+def test_attention_over_cache_matches_sdpa():
+    k, v, q, mask = G["att_k"], G["att_v"], G["att_q"], G["att_mask"]
+    Dh = k.shape[-1]
+
+    def build(g):
+        kk, vv = g.input(k), g.input(v)                       # F32 cache here: no bf16 rounding in the torch fixture
+        w = g.mul_mat(kk, g.input(q))
+        w = g.soft_max_ext(w, g.input(mask), 1.0 / np.sqrt(Dh), 0.0)
+        vt = g.cont(g.transpose(vv))
+        return [g.mul_mat(vt, w)]
+    close(oracle(build)[0], G["att_y"], 2e-6)
+
+
+def test_rvq_nearest_centroid():
+    # node sequence of moshi_EuclideanCodebook_encode (src/moshi/quantization/core_vq.h:27-56)
+    cb, xv = G["vq_cb"], G["vq_x"]
+    n, d = cb.shape
+
+    def build(g):
+        a = g.input(xv)                                       # [d, 5]
+        b = g.input(cb)                                       # [d, n]
+        ne1 = xv.shape[0]
+        a3 = g.reshape_3d(a, d, 1, ne1)
+        a3 = g.repeat_4d(a3, d, n, ne1, 1)
+        a3 = g.reshape_3d(a3, d, n * ne1, 1)
+        b3 = g.repeat_4d(b, d, n * ne1, 1, 1)
+        c = g.sub(b3, a3)
+        c = g.sum_rows(g.mul(c, c))
+        c = g.reshape_3d(c, n, ne1, 1)
+        c = g.add(c, g.input(np.array([1.0], np.float32)))
+        c = g.div(g.input(np.ones((1, ne1, n), np.float32)), c)
+        return [g.argmax(c)]
+    assert np.array_equal(oracle(build)[0].reshape(-1), G["vq_idx"])

@@ -1,0 +1,59 @@
+"""CPU, build container only: the reference's own runtime and graph-builder headers compile unchanged against
+include/{ggml,ggml-backend,ggml-cpu,gguf}.h — i.e. the C-ABI surface libmoshi touches (function signatures,
+struct fields, enums, brace-initialised params) is all there. Syntax-only; nothing from /root/reference is copied
+or linked. Skipped where /root/reference does not exist (the GPU box)."""
+import os
+import shutil
+import subprocess
+import tempfile
+
+import pytest
+
+import ggml_util as gu
+
+REF = "/root/reference"
+
+TU = r'''
+#include <assert.h>
+#include <math.h>
+#include <string.h>
+#include <deque>
+#include <string>
+#include <vector>
+#include <map>
+#include <iostream>
+#include <moshi/ptrs.h>
+#include <moshi/safetensor.h>
+#include <ggml.h>
+#include <ggml-backend.h>
+#include <ggml-cpu.h>
+#define CAPTURE(...)
+#define CAPTURE_GROUP(...)
+#define ONCE(code) {static bool once=false; if (!once) {{code;}; once=true;}}
+#define ON_NTH(nth, code) {static int count=0; if (count++ == (nth)) {code;}}
+#include "src/context.h"
+#include "src/loader.h"
+#include "src/torch.h"
+#include "src/moshi/modules/transformer.h"
+#include "src/moshi/utils/sampling.h"
+#include "src/moshi/models/lm_utils.h"
+#include "src/moshi/quantization/core_vq.h"
+#include "src/moshi/quantization/vq.h"
+#include "src/moshi/modules/conv.h"
+#include "src/moshi/modules/seanet.h"
+#include "src/moshi/models/compression.h"
+#include "tools/common_ggml.h"
+int main() { return 0; }
+'''
+# src/moshi/models/lm.h is left out only because it needs `Entry` from include/moshi/moshi.h, which includes
+# <sentencepiece_processor.h> (absent from this image); its ggml calls are the same ones lm_utils.h/transformer.h make.
+
+
+@pytest.mark.skipif(not os.path.isdir(REF) or shutil.which("g++") is None, reason="reference checkout / g++ not available")
+def test_reference_graph_builders_compile_against_our_headers():
+    with tempfile.TemporaryDirectory() as d:
+        src = os.path.join(d, "tu.cpp")
+        open(src, "w").write(TU)
+        r = subprocess.run(["g++", "-std=c++20", "-fsyntax-only", "-I" + os.path.join(gu.ROOT, "include"),
+                            "-I" + os.path.join(REF, "include"), "-I" + REF, src], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
