@@ -29,6 +29,21 @@ from __graft_entry__ import load_oracle, load_package  # noqa: E402
 HBM_PEAK_GBPS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 
 
+def reduce_max_time(dist, dt, device="cuda"):
+    """MAX over ranks of the timed-region duration (every rank must have finished its K steps)."""
+    if dist is None:
+        return dt
+    import torch
+    tt = torch.tensor([dt], device=device, dtype=torch.float64)
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    return float(tt.item())
+
+
+def whole_job_rate(world, steps, seconds):
+    """Replicas: every rank processed `steps` frames of its own stream; the job rate is all of them over the slowest rank."""
+    return world * steps / seconds
+
+
 def device_sync():
     hip = C.CDLL("libamdhip64.so")
     hip.hipDeviceSynchronize()
@@ -102,13 +117,8 @@ def main():
         tokens.append(txt.value)
     barrier()
     dt = time.perf_counter() - t0
-    if dist is not None:
-        import torch
-        tt = torch.tensor([dt], device="cuda", dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
-
-    fps = world * args.steps / dt
+    dt = reduce_max_time(dist, dt)
+    fps = whole_job_rate(world, args.steps, dt)
     offset_end = L.moshi_hot_offset(m)
 
     # algorithmic HBM bytes per frame: every weight byte once + the filled KV slots
@@ -138,6 +148,16 @@ def main():
         "load_seconds": round(t_load, 1),
         "graph_replays": int(st.graph_replays), "uploads_batched": int(st.uploads_batched),
     }
+
+    if rank == 0:
+        # where the frame goes (separate pass, synchronising around each phase; not part of the timed region)
+        L.moshi_hot_set_timing(m, 1)
+        for _ in range(10):
+            frame()
+        ph = (C.c_double * 4)()
+        L.moshi_hot_get_timing(m, ph)
+        L.moshi_hot_set_timing(m, 0)
+        result["phase_us"] = {"mimi_encode": round(ph[0], 1), "temporal": round(ph[1], 1), "depth": round(ph[2], 1), "mimi_decode": round(ph[3], 1)}
 
     if rank == 0 and not args.no_roofline:
         # dominant kernel = matvec_q4k_kernel (3.77 of 4.4 GB per frame). Its launches are timed in situ with HIP

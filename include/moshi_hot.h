@@ -63,8 +63,14 @@ GGML_API int moshi_hot_sts_frame(moshi_hot_model_t * m, const float * pcm_in, in
 
 // introspection for tests / bench
 GGML_API int64_t moshi_hot_offset(moshi_hot_model_t * m);                      // frames stepped so far
+GGML_API void    moshi_hot_last_raw_tokens(moshi_hot_model_t * m, int32_t * text_token, int32_t * audio_tokens);  // sampled this step, before the delay ring
 GGML_API size_t  moshi_hot_weight_bytes(moshi_hot_model_t * m, int part);     // 0 temporal, 1 depth, 2 mimi enc, 3 mimi dec, 4 embeddings
 GGML_API int     moshi_hot_read_last(moshi_hot_model_t * m, const char * what, float * out, int64_t n);  // "text_logits", "transformer_out", "dep_logits"
+// per-phase wall clock (synchronises around each phase while on): us_per_call[4] = mimi encode, temporal, depth, mimi decode
+GGML_API void    moshi_hot_set_timing(moshi_hot_model_t * m, int on);
+GGML_API void    moshi_hot_get_timing(moshi_hot_model_t * m, double * us_per_call);
+// teacher forcing for parity runs: overwrite the tokens the last moshi_hot_lm_step wrote into the delay ring
+GGML_API void    moshi_hot_force_last(moshi_hot_model_t * m, int32_t text_token, const int32_t * audio_tokens);
 GGML_API void    moshi_hot_set_context_fill(moshi_hot_model_t * m, int64_t offset); // jump the Temporal ring to a given fill level (bench only)
 
 #ifdef __cplusplus

@@ -422,9 +422,12 @@ static bool match_matvec(const analysis & an, int pos, mv_group & grp) {
     grp.members.push_back(pos);
     grp.emit_pos = pos;
     bool have_x = false;
+    // per-step weight selection wraps the activation in a whole-tensor view (transformer.h:85-91): look through it
+    while ((b->op == GGML_OP_VIEW || b->op == GGML_OP_RESHAPE) && uses_of(an, b) == 1 && b->src[0]->data == b->data &&
+           ggml_nelements(b->src[0]) == ggml_nelements(b) && ggml_is_contiguous(b->src[0])) b = b->src[0];
 
     // prologue 1: b = alpha * rms_norm(x), private to this mat-vec
-    if (b->op == GGML_OP_MUL && is_f32_vec(b, K) && uses_of(an, b) == 1) {
+    if (b->op == GGML_OP_MUL && is_f32_vec(b, K) && uses_of(an, b) == 1 && (mm->src[0]->type != GGML_TYPE_Q4_K || K <= 4096)) {
         const ggml_tensor * al = b->src[0], * nr = b->src[1];
         if (nr->op != GGML_OP_RMS_NORM) std::swap(al, nr);
         if (nr->op == GGML_OP_RMS_NORM && uses_of(an, nr) == 1 && is_f32_vec(al, K) && is_f32_vec(nr->src[0], K)) {

@@ -17,6 +17,7 @@
 #include "hip_common.h"
 #include "hip_device.h"
 #include <hip/hip_ext.h>
+#include <stdlib.h>
 
 // ---------------------------------------------------------------------------------------------------
 // activation prologues
@@ -61,10 +62,41 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 struct xblk { int8_t q[256]; int16_t bsums[16]; float d; float pad[3]; };
 static_assert(sizeof(xblk) == XBLK_BYTES, "xblk layout");
 
+// quantise the 256 values held by one wave (4 per lane, contiguous) to a Q8_K block in LDS
+__device__ __forceinline__ void quantize_block_q8k(xblk * dst, const float v[4], int lane) {
+    float mx = v[0];
+#pragma unroll
+    for (int k = 1; k < 4; k++) if (fabsf(v[k]) > fabsf(mx)) mx = v[k];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const float other = __shfl_xor(mx, o, 64); if (fabsf(other) > fabsf(mx)) mx = other; }
+    int q[4] = { 0, 0, 0, 0 };
+    float d = 0.f;
+    if (mx != 0.f) {
+        const float iscale = -127.f / mx;
+#pragma unroll
+        for (int k = 0; k < 4; k++) { const int qi = nearest_int_dev(iscale * v[k]); q[k] = qi < 127 ? qi : 127; }
+        d = 1.f / iscale;
+    }
+    *(uint32_t *) (dst->q + lane * 4) = (uint32_t) (q[0] & 0xff) | ((uint32_t) (q[1] & 0xff) << 8) | ((uint32_t) (q[2] & 0xff) << 16) | ((uint32_t) (q[3] & 0xff) << 24);
+    int s4 = q[0] + q[1] + q[2] + q[3];
+    s4 += __shfl_xor(s4, 1, 64);
+    s4 += __shfl_xor(s4, 2, 64);
+    if ((lane & 3) == 0) dst->bsums[lane >> 2] = (int16_t) s4;
+    if (lane == 0) dst->d = d;
+}
+
+// One workgroup = 4 waves = `rows_per_wg` output rows.
+//  phase 1: every wave puts its first weight tile in flight (9 x 16 B per lane, nontemporal)
+//  phase 2: the activation vector is produced (prologue) and quantised to Q8_K in LDS; all loads of a
+//           16-block batch are issued before any of them is used, so the phase costs ~one L2 round trip
+//  phase 3: tiles stream registers -> LDS image -> one super-block per lane (next tile prefetched first)
+//  phase 4: fixed-order row sums (+ residual)
+template <int PRO>
 __global__ void __launch_bounds__(256) matvec_q4k_kernel(mv_args a, int rows_per_wg) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ double sh_red[4];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int nwaves = 4;
     const int nb = (int) (a.K / 256);
     xblk * xs = (xblk *) smem;
     char * stage = smem + nb * XBLK_BYTES + wave * TILE_BYTES;
@@ -77,7 +109,6 @@ __global__ void __launch_bounds__(256) matvec_q4k_kernel(mv_args a, int rows_per
     const int nchunks = nblk * 9;
     const u32x4 * wsrc = (const u32x4 *) (a.w + row0 * a.row_bytes);
 
-    // 1. put the first weight tile of this wave in flight before touching the activations
     u32x4 r[9];
     int t = wave;
     if (t < ntiles) {
@@ -88,37 +119,62 @@ __global__ void __launch_bounds__(256) matvec_q4k_kernel(mv_args a, int rows_per
         }
     }
 
-    // 2. activations -> Q8_K blocks in LDS (each wave quantises whole 256-element blocks)
-    x_src xsrc = { a.prologue, a.x, a.alpha, 1.0f, a.K };
-    if (a.prologue == MV_RMSNORM) xsrc.scale = block_rms_scale(a.x, a.K, a.eps, sh_red);
-    for (int b = wave; b < nb; b += nwaves) {
-        const int64_t e0 = (int64_t) b * 256 + lane * 4;
-        float v[4];
+    // phase 2: batches of 16 blocks; thread owns elements base + j*1024 + tid*4 .. +3  (block = base/256 + 4j + wave)
+    const int K = (int) a.K;
+    for (int base = 0; base < K; base += 4096) {
+        float v[4][4];
+        float4 aux[4];
+        bool ok[4];
 #pragma unroll
-        for (int k = 0; k < 4; k++) v[k] = x_value(xsrc, e0 + k);
-        if (a.x_out != nullptr && blockIdx.x == 0) *(float4 *) (a.x_out + e0) = make_float4(v[0], v[1], v[2], v[3]);
-        float mx = v[0];
-#pragma unroll
-        for (int k = 1; k < 4; k++) if (fabsf(v[k]) > fabsf(mx)) mx = v[k];
-        for (int o = 32; o > 0; o >>= 1) { const float other = __shfl_xor(mx, o, 64); if (fabsf(other) > fabsf(mx)) mx = other; }
-        int q[4] = { 0, 0, 0, 0 };
-        float d = 0.f;
-        if (mx != 0.f) {
-            const float iscale = -127.f / mx;
-#pragma unroll
-            for (int k = 0; k < 4; k++) { const int qi = nearest_int_dev(iscale * v[k]); q[k] = qi < 127 ? qi : 127; }
-            d = 1.f / iscale;
+        for (int j = 0; j < 4; j++) {
+            const int e = base + j * 1024 + tid * 4;
+            ok[j] = e < K;
+            float4 x4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            aux[j] = x4;
+            if (ok[j]) {
+                x4 = *(const float4 *) (a.x + e);
+                if (PRO == MV_RMSNORM) aux[j] = *(const float4 *) (a.alpha + e);
+                if (PRO == MV_GATE_SILU) aux[j] = *(const float4 *) (a.x + K + e);
+            }
+            v[j][0] = x4.x; v[j][1] = x4.y; v[j][2] = x4.z; v[j][3] = x4.w;
         }
-        *(uint32_t *) (xs[b].q + lane * 4) = (uint32_t) (q[0] & 0xff) | ((uint32_t) (q[1] & 0xff) << 8) | ((uint32_t) (q[2] & 0xff) << 16) | ((uint32_t) (q[3] & 0xff) << 24);
-        int s4 = q[0] + q[1] + q[2] + q[3];
-        s4 += __shfl_xor(s4, 1, 64);
-        s4 += __shfl_xor(s4, 2, 64);
-        if ((lane & 3) == 0) xs[b].bsums[lane >> 2] = (int16_t) s4;
-        if (lane == 0) xs[b].d = d;
+        if (PRO == MV_RMSNORM) {   // K <= 4096 (checked on the host): the whole vector is in registers
+            double acc = 0;
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+#pragma unroll
+                for (int k = 0; k < 4; k++) acc += (double) (v[j][k] * v[j][k]);
+            acc = wave_sum_f64(acc);
+            if (lane == 0) sh_red[wave] = acc;
+            __syncthreads();
+            const float mean = (float) ((sh_red[0] + sh_red[1] + sh_red[2] + sh_red[3]) / (double) K);
+            const float scale = 1.0f / sqrtf(mean + a.eps);
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const float al[4] = { aux[j].x, aux[j].y, aux[j].z, aux[j].w };
+#pragma unroll
+                for (int k = 0; k < 4; k++) v[j][k] = al[k] * (v[j][k] * scale);
+            }
+        }
+        if (PRO == MV_GATE_SILU) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const float rr[4] = { aux[j].x, aux[j].y, aux[j].z, aux[j].w };
+#pragma unroll
+                for (int k = 0; k < 4; k++) { const float l = v[j][k]; v[j][k] = (l / (1.0f + expf(-l))) * rr[k]; }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            if (!ok[j]) continue;   // wave-uniform: a wave always holds one whole block
+            const int b = base / 256 + j * 4 + wave;
+            if (a.x_out != nullptr && blockIdx.x == 0) *(float4 *) (a.x_out + base + j * 1024 + tid * 4) = make_float4(v[j][0], v[j][1], v[j][2], v[j][3]);
+            quantize_block_q8k(xs + b, v[j], lane);
+        }
     }
     __syncthreads();
 
-    // 3. stream the tiles: registers -> LDS image -> one super-block per lane
+    // phase 3
     for (; t < ntiles; t += nwaves) {
 #pragma unroll
         for (int i = 0; i < 9; i++) ((u32x4 *) stage)[i * 64 + lane] = r[i];
@@ -143,8 +199,8 @@ __global__ void __launch_bounds__(256) matvec_q4k_kernel(mv_args a, int rows_per
     }
     __syncthreads();
 
-    // 4. fixed-order row sums (+ residual)
-    for (int rr = tid; rr < rows; rr += blockDim.x) {
+    // phase 4
+    for (int rr = tid; rr < rows; rr += 256) {
         float sum = 0.f;
         for (int j = 0; j < nb; j++) sum += part[rr * nb + j];
         const int64_t row = row0 + rr;
@@ -213,26 +269,31 @@ bool k_matvec_supported(int wtype, int64_t K, int64_t M) {
 static mv_profile * g_mv_profile = nullptr;
 void k_matvec_set_profile(mv_profile * p) { g_mv_profile = p; }
 
+static int env_int(const char * name, int def) { const char * v = getenv(name); return v ? atoi(v) : def; }
+
 void k_matvec(hipStream_t s, const mv_args & a) {
     if (a.wtype == GGML_TYPE_Q4_K) {
         const int nb = (int) (a.K / 256);
-        // rows per workgroup: keep the per-row partial table small and the grid >= ~2 workgroups per CU
-        int rows = 1024 / nb;
-        if (rows > 64) rows = 64;
-        while (rows > 4 && (a.M + rows - 1) / rows < 512) rows >>= 1;
+        // tiles (64 super-blocks) per workgroup: one per wave, more for long rows so that the activation prologue
+        // (cost ~K per workgroup) is amortised; rows are halved while the grid would leave CUs idle
+        static const int tpw_min = env_int("MI355X_MV_TPW", 4), grid_min = env_int("MI355X_MV_GRID_MIN", 256);
+        int tpw = tpw_min > nb / 4 ? tpw_min : nb / 4;
+        int rows = (tpw * 64 + nb - 1) / nb;
+        if (rows * nb > 4096) rows = 4096 / nb;
+        while (rows > 1 && (a.M + rows - 1) / rows < grid_min && (rows / 2) * nb >= 64) rows >>= 1;
         if (rows < 1) rows = 1;
-        const int ntiles = (rows * nb + 63) / 64;
-        const int threads = ntiles >= 4 ? 256 : ntiles >= 2 ? 128 : 64;
-        const int nwaves = threads / 64;
-        const size_t smem = (size_t) nb * XBLK_BYTES + (size_t) nwaves * TILE_BYTES + (size_t) rows * nb * 4;
+        const size_t smem = (size_t) nb * XBLK_BYTES + (size_t) 4 * TILE_BYTES + (size_t) rows * nb * 4;
         const int grid = (int) ((a.M + rows - 1) / rows);
+        GGML_ASSERT(a.prologue != MV_RMSNORM || a.K <= 4096);
+        void (*kern)(mv_args, int) = a.prologue == MV_RMSNORM ? matvec_q4k_kernel<MV_RMSNORM>
+                                   : a.prologue == MV_GATE_SILU ? matvec_q4k_kernel<MV_GATE_SILU> : matvec_q4k_kernel<MV_PLAIN>;
         if (g_mv_profile && g_mv_profile->used < g_mv_profile->capacity) {
             mv_profile::rec & r = g_mv_profile->recs[g_mv_profile->used++];
             r.bytes = a.M * a.row_bytes;
-            hipExtLaunchKernelGGL(matvec_q4k_kernel, dim3(grid), dim3(threads), smem, s, r.start, r.stop, 0, a, rows);
+            hipExtLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, s, r.start, r.stop, 0, a, rows);
             return;
         }
-        matvec_q4k_kernel<<<grid, threads, smem, s>>>(a, rows);
+        kern<<<grid, 256, smem, s>>>(a, rows);
         return;
     }
     const int rows_per_wave = a.K <= 1024 ? 4 : 2;
@@ -298,6 +359,20 @@ __global__ void __launch_bounds__(ATTN_THREADS) attn_decode_kernel(attn_args a) 
     }
     __syncthreads();
 
+    // live range of the mask: everything at or beyond n_end is masked (-inf) and contributes exactly 0
+    int last_live = -1;
+    for (int c = tid; c < C; c += ATTN_THREADS) if (a.mask[c] > -INFINITY) last_live = c;
+    last_live = max(last_live, __shfl_xor(last_live, 32, 64));
+    last_live = max(last_live, __shfl_xor(last_live, 16, 64));
+    last_live = max(last_live, __shfl_xor(last_live, 8, 64));
+    last_live = max(last_live, __shfl_xor(last_live, 4, 64));
+    last_live = max(last_live, __shfl_xor(last_live, 2, 64));
+    last_live = max(last_live, __shfl_xor(last_live, 1, 64));
+    __shared__ int sh_i[4];
+    if (lane == 0) sh_i[wave] = last_live;
+    __syncthreads();
+    const int n_end = max(max(sh_i[0], sh_i[1]), max(sh_i[2], sh_i[3])) + 1;
+
     // 2. scores: LPS lanes per slot, 8 dims (16 B) per lane
     const int LPS = D / 8;              // lanes per slot (16 for D=128, 8 for D=64)
     const int SPW = 64 / LPS;           // slots per wave-instruction
@@ -306,9 +381,9 @@ __global__ void __launch_bounds__(ATTN_THREADS) attn_decode_kernel(attn_args a) 
 #pragma unroll
     for (int i = 0; i < 8; i++) qv[i] = qf[dl + i];
     float lmax = -INFINITY;
-    for (int c0 = wave * SPW; c0 < C; c0 += 4 * SPW) {
+    for (int c0 = wave * SPW; c0 < n_end; c0 += 4 * SPW) {
         const int c = c0 + sub;
-        const float m = c < C ? a.mask[c] : -INFINITY;
+        const float m = c < n_end ? a.mask[c] : -INFINITY;
         const bool live = m > -INFINITY;
         double acc = 0;
         if (live) {
@@ -326,7 +401,7 @@ __global__ void __launch_bounds__(ATTN_THREADS) attn_decode_kernel(attn_args a) 
             }
         }
         for (int o = LPS >> 1; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
-        if (c < C && (lane % LPS) == 0) {
+        if (c < n_end && (lane % LPS) == 0) {
             const float sv = live ? (float) acc * a.scale + m : -INFINITY;
             sc[c] = sv;
             lmax = fmaxf(lmax, sv);
@@ -339,7 +414,7 @@ __global__ void __launch_bounds__(ATTN_THREADS) attn_decode_kernel(attn_args a) 
 
     // 3. soft_max: exp in float, sum in double, scale by (float)(1/sum), round to BF16 for the V product
     double lsum = 0;
-    for (int c = tid; c < C; c += ATTN_THREADS) {
+    for (int c = tid; c < n_end; c += ATTN_THREADS) {
         const float sv = sc[c];
         const float e = sv > -INFINITY ? expf(sv - gmax) : 0.f;
         sc[c] = e;
@@ -349,16 +424,16 @@ __global__ void __launch_bounds__(ATTN_THREADS) attn_decode_kernel(attn_args a) 
     if (lane == 0) sh_d[wave] = lsum;
     __syncthreads();
     const float inv = (float) (1.0 / (sh_d[0] + sh_d[1] + sh_d[2] + sh_d[3]));
-    for (int c = tid; c < C; c += ATTN_THREADS) sc[c] = bf2f(f2bf(sc[c] * inv));
+    for (int c = tid; c < n_end; c += ATTN_THREADS) sc[c] = bf2f(f2bf(sc[c] * inv));
     __syncthreads();
 
     // 4. out[d] = sum_c V[d, c] * p[c]
     double o8[8];
 #pragma unroll
     for (int i = 0; i < 8; i++) o8[i] = 0;
-    for (int c0 = wave * SPW; c0 < C; c0 += 4 * SPW) {
+    for (int c0 = wave * SPW; c0 < n_end; c0 += 4 * SPW) {
         const int c = c0 + sub;
-        const float p = c < C ? sc[c] : 0.f;
+        const float p = c < n_end ? sc[c] : 0.f;
         if (p != 0.f) {
             if (c == slot) {
 #pragma unroll

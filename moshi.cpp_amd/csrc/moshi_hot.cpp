@@ -564,6 +564,9 @@ struct moshi_hot_model {
     Builder * g_enc = nullptr; T enc_frame = nullptr, enc_codes = nullptr; int enc_T = 0;
 
     std::vector<int32_t> tokens_tmp;
+    int32_t last_text = 0; std::vector<int32_t> last_audio;   // raw (un-delayed) tokens of the last step
+    // optional per-phase wall-clock (moshi_hot_set_timing): 0 mimi encode, 1 temporal, 2 depth, 3 mimi decode
+    bool timing = false; double phase_us[4] = { 0, 0, 0, 0 }; int64_t phase_n[4] = { 0, 0, 0, 0 };
 };
 
 namespace {
@@ -873,9 +876,18 @@ extern "C" void moshi_hot_free(moshi_hot_model_t * m) {
     delete m;
 }
 
+namespace {
+struct PhaseTimer {
+    moshi_hot_model * m; int phase; int64_t t0;
+    PhaseTimer(moshi_hot_model * m_, int p) : m(m_), phase(p), t0(0) { if (m->timing) { ggml_backend_synchronize(m->be); t0 = ggml_time_us(); } }
+    ~PhaseTimer() { if (m->timing) { ggml_backend_synchronize(m->be); m->phase_us[phase] += (double) (ggml_time_us() - t0); m->phase_n[phase]++; } }
+};
+}
+
 // mimi_decode, per-frame part (compression.h:189-203)
 extern "C" void moshi_hot_mimi_decode(moshi_hot_model_t * m, const int32_t * codes, float * pcm) {
     if (!m->g_dec) build_decode_graph(m);
+    PhaseTimer pt(m, 3);
     ggml_backend_tensor_set(m->dec_codes, codes, 0, ggml_nbytes(m->dec_codes));
     transformer_graph_step(*m->scratch, m->dec_tr, m->dec_T);
     m->scratch->compute_scratch();
@@ -887,6 +899,7 @@ extern "C" void moshi_hot_mimi_decode(moshi_hot_model_t * m, const int32_t * cod
 // mimi_encode, per-frame part (compression.h:310-324)
 extern "C" void moshi_hot_mimi_encode(moshi_hot_model_t * m, const float * pcm, int32_t * codes) {
     if (!m->g_enc) build_encode_graph(m);
+    PhaseTimer pt(m, 0);
     ggml_backend_tensor_set(m->enc_frame, pcm, 0, ggml_nbytes(m->enc_frame));
     transformer_graph_step(*m->scratch, m->enc_tr, m->enc_T);
     m->scratch->compute_scratch();
@@ -909,6 +922,10 @@ extern "C" int moshi_hot_lm_step(moshi_hot_model_t * m, const int32_t * in_audio
     for (int i = 0; i < ncb; i++) input[(size_t) i] = m->offset <= c.delays[i] ? m->initial[(size_t) i] : m->cache[(size_t) pos][(size_t) i];
 
     if (!m->g_temporal) build_temporal_graph(m);
+    if (dep_q > 0 && !m->g_depth) build_depth_graph(m);
+    int32_t text_token = 0;
+    {
+    PhaseTimer pt(m, 1);
     // moshi_lmmodel_text_token_embed_step (lm.h:586-607): -1 -> scale 0, negative ids -> row 0
     for (int i = 0; i < ncb; i++) {
         int32_t id = input[(size_t) i];
@@ -920,12 +937,12 @@ extern "C" int moshi_hot_lm_step(moshi_hot_model_t * m, const int32_t * in_audio
     transformer_graph_step(*m->scratch, m->temporal, 1);
     m->scratch->compute_scratch();
     m->g_temporal->compute();
-    int32_t text_token = 0;
     ggml_backend_tensor_get(m->sampler_out, &text_token, 0, 4);
+    }
 
     std::vector<int32_t> audio((size_t) dep_q, 0);
     if (dep_q > 0) {   // moshi_lmmodel_depformer_step (lm.h:532-552)
-        if (!m->g_depth) build_depth_graph(m);
+        PhaseTimer pt(m, 2);
         int32_t id = text_token; const float sc = id == -1 ? 0.f : 1.f;
         if (id < 0) id = 0;
         ggml_backend_tensor_set(m->dep_text_idx, &id, 0, 4);
@@ -933,6 +950,7 @@ extern "C" int moshi_hot_lm_step(moshi_hot_model_t * m, const int32_t * in_audio
         m->g_depth->compute();
         ggml_backend_tensor_get(m->dep_tokens, audio.data(), 0, (size_t) dep_q * 4);
     }
+    m->last_text = text_token; m->last_audio = audio;
     m->offset++;
     const int wpos = m->offset % CT;   // lm.h:935-943
     m->cache[(size_t) wpos][0] = text_token;
@@ -958,6 +976,10 @@ extern "C" int moshi_hot_sts_frame(moshi_hot_model_t * m, const float * pcm_in, 
 }
 
 extern "C" int64_t moshi_hot_offset(moshi_hot_model_t * m) { return m->offset; }
+extern "C" void moshi_hot_last_raw_tokens(moshi_hot_model_t * m, int32_t * text_token, int32_t * audio_tokens) {
+    *text_token = m->last_text;
+    for (size_t i = 0; i < m->last_audio.size(); i++) audio_tokens[i] = m->last_audio[i];
+}
 extern "C" size_t moshi_hot_weight_bytes(moshi_hot_model_t * m, int part) { return part >= 0 && part < 5 ? m->W->bytes[part] : 0; }
 extern "C" int moshi_hot_read_last(moshi_hot_model_t * m, const char * what, float * out, int64_t n) {
     T t = nullptr;
@@ -967,5 +989,12 @@ extern "C" int moshi_hot_read_last(moshi_hot_model_t * m, const char * what, flo
     if (!t || ggml_nelements(t) < n) return -1;
     ggml_backend_tensor_get(t, out, 0, (size_t) n * 4);
     return 0;
+}
+extern "C" void moshi_hot_set_timing(moshi_hot_model_t * m, int on) { m->timing = on != 0; for (int i = 0; i < 4; i++) { m->phase_us[i] = 0; m->phase_n[i] = 0; } }
+extern "C" void moshi_hot_get_timing(moshi_hot_model_t * m, double * us_per_call) { for (int i = 0; i < 4; i++) us_per_call[i] = m->phase_n[i] ? m->phase_us[i] / (double) m->phase_n[i] : 0.0; }
+extern "C" void moshi_hot_force_last(moshi_hot_model_t * m, int32_t text_token, const int32_t * audio_tokens) {
+    const int wpos = m->offset % (int) m->cache.size();
+    m->cache[(size_t) wpos][0] = text_token;
+    for (int q = 0; q < m->cfg.dep_q; q++) m->cache[(size_t) wpos][(size_t) (q + 1)] = audio_tokens[q];
 }
 extern "C" void moshi_hot_set_context_fill(moshi_hot_model_t * m, int64_t offset) { m->temporal.offset = (int) offset; }

@@ -48,6 +48,15 @@ class Model:
         r = L.moshi_hot_lm_step(self.m, ia, C.byref(txt), aud)
         return r, txt.value, list(aud)[:self.cfg.dep_q]
 
+    def last_raw(self):
+        txt = C.c_int32()
+        aud = (C.c_int32 * 32)()
+        L.moshi_hot_last_raw_tokens(self.m, C.byref(txt), aud)
+        return txt.value, list(aud)[:self.cfg.dep_q]
+
+    def force_last(self, txt, aud):
+        L.moshi_hot_force_last(self.m, txt, (C.c_int32 * 32)(*aud))
+
     def mimi_decode(self, codes):
         cc = (C.c_int32 * 32)(*codes)
         out = np.zeros(1920, np.float32)
