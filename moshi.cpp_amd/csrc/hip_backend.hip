@@ -285,6 +285,48 @@ static const char * resolve_dense(const ggml_tensor * t) {
     return (const char *) cur->data + delta;
 }
 
+// Strided view of a tensor's elements in the storage of the earliest tensor that still holds the same values:
+// walks through layout-only nodes and through cont/dup copies (mapping strides across the copy). On return element
+// (i0,i1,i2,i3) of `t` lives at base + sum i_k * nb[k].
+struct sview { const char * base; int64_t ne[4]; int64_t nb[4]; };
+
+static bool strided_resolve(const ggml_tensor * t, sview & sv) {
+    if (!t->data) return false;
+    sv.base = (const char *) t->data;
+    for (int i = 0; i < 4; i++) { sv.ne[i] = t->ne[i]; sv.nb[i] = (int64_t) t->nb[i]; }
+    const int64_t es = (int64_t) ggml_type_size(t->type);
+    const ggml_tensor * cur = t;
+    for (int guard = 0; guard < 8; guard++) {
+        while (cur->op == GGML_OP_VIEW || cur->op == GGML_OP_RESHAPE || cur->op == GGML_OP_PERMUTE || cur->op == GGML_OP_TRANSPOSE) cur = cur->src[0];
+        if (!(cur->op == GGML_OP_CONT || cur->op == GGML_OP_DUP) || cur->src[0]->type != cur->type || !ggml_is_contiguous(cur) || !cur->data || !cur->src[0]->data) break;
+        const ggml_tensor * src = cur->src[0];
+        // position of our base inside the dense copy -> logical coordinates of the copy
+        int64_t eo = (sv.base - (const char *) cur->data) / es;
+        if (eo < 0 || eo >= ggml_nelements(cur)) break;
+        int64_t P[5] = { 1, cur->ne[0], cur->ne[0] * cur->ne[1], cur->ne[0] * cur->ne[1] * cur->ne[2], ggml_nelements(cur) };
+        int64_t c[4];
+        for (int j = 3; j >= 0; j--) { c[j] = eo / P[j]; eo -= c[j] * P[j]; }
+        int64_t nb2[4];
+        bool ok = true;
+        for (int k = 0; k < 4 && ok; k++) {
+            nb2[k] = 0;
+            if (sv.ne[k] <= 1) continue;
+            if (sv.nb[k] % es != 0) { ok = false; break; }
+            const int64_t E = sv.nb[k] / es;
+            int j = 3;
+            while (j > 0 && (P[j] > E || E % P[j] != 0)) j--;
+            const int64_t m = E / P[j];
+            if (c[j] + m * (sv.ne[k] - 1) >= cur->ne[j]) { ok = false; break; }   // the dim must stay inside one dim of the copy
+            nb2[k] = m * (int64_t) src->nb[j];
+        }
+        if (!ok) break;
+        sv.base = (const char *) src->data + c[0] * (int64_t) src->nb[0] + c[1] * (int64_t) src->nb[1] + c[2] * (int64_t) src->nb[2] + c[3] * (int64_t) src->nb[3];
+        for (int k = 0; k < 4; k++) sv.nb[k] = nb2[k];
+        cur = src;
+    }
+    return true;
+}
+
 // ---- emission ------------------------------------------------------------------------------------------
 struct emitter {
     hip_ctx * c;
@@ -302,8 +344,13 @@ struct emitter {
 static bool fill_matvec_base(mv_args & a, const ggml_tensor * mm) {
     const ggml_tensor * w = mm->src[0], * b = mm->src[1];
     if (!dense_rows(w) || !k_matvec_supported(w->type, w->ne[0], w->ne[1])) return false;
-    if (b->type != GGML_TYPE_F32 || b->ne[1] != 1 || b->ne[2] != 1 || b->ne[3] != 1) return false;
+    if (b->type != GGML_TYPE_F32 || b->ne[2] != 1 || b->ne[3] != 1 || b->ne[1] < 1) return false;
+    if (b->ne[1] > (w->type == GGML_TYPE_Q4_K ? 1 : MV_MAX_COLS)) return false;
+    if (b->nb[0] != 4 || mm->nb[0] != 4) return false;
     memset(&a, 0, sizeof(a));
+    a.ncols = (int) b->ne[1];
+    a.x_cs = (int64_t) b->nb[1] / 4;
+    a.y_cs = (int64_t) mm->nb[1] / 4;
     a.wtype = w->type;
     a.w = (const char *) w->data;
     a.row_bytes = (int64_t) w->nb[1];
@@ -380,7 +427,8 @@ static void emit_generic(emitter & em, ggml_tensor * n) {
         } return;
         case GGML_OP_CONV_TRANSPOSE_1D: {
             const tdesc w = make_tdesc(n->src[0]), x = make_tdesc(n->src[1]); const int s0 = n->op_params[0];
-            em.push([=](hipStream_t s) { k_conv_transpose_1d(s, d, w, x, s0); });
+            void * ws = em.ws(k_conv_transpose_1d_ws_size(n->src[0], n->src[1]));
+            em.push([=](hipStream_t s) { k_conv_transpose_1d(s, d, w, x, s0, ws); });
         } return;
         case GGML_OP_TIMESTEP_EMBEDDING: {
             const tdesc ts = make_tdesc(n->src[0]); const int dim = n->op_params[0], mp = n->op_params[1];
@@ -388,7 +436,7 @@ static void emit_generic(emitter & em, ggml_tensor * n) {
         } return;
         case GGML_OP_MUL_MAT: {
             mv_args mv;
-            if (!(em.c->flags & 1) && fill_matvec_base(mv, n) && ggml_is_contiguous(n->src[1])) {
+            if (!(em.c->flags & 1) && fill_matvec_base(mv, n)) {
                 mv.x = (const float *) n->src[1]->data;
                 em.push([=](hipStream_t s) { k_matvec(s, mv); });
                 return;
@@ -427,7 +475,7 @@ static bool match_matvec(const analysis & an, int pos, mv_group & grp) {
            ggml_nelements(b->src[0]) == ggml_nelements(b) && ggml_is_contiguous(b->src[0])) b = b->src[0];
 
     // prologue 1: b = alpha * rms_norm(x), private to this mat-vec
-    if (b->op == GGML_OP_MUL && is_f32_vec(b, K) && uses_of(an, b) == 1 && (mm->src[0]->type != GGML_TYPE_Q4_K || K <= 4096)) {
+    if (a.ncols == 1 && b->op == GGML_OP_MUL && is_f32_vec(b, K) && uses_of(an, b) == 1 && (mm->src[0]->type != GGML_TYPE_Q4_K || K <= 4096)) {
         const ggml_tensor * al = b->src[0], * nr = b->src[1];
         if (nr->op != GGML_OP_RMS_NORM) std::swap(al, nr);
         if (nr->op == GGML_OP_RMS_NORM && uses_of(an, nr) == 1 && is_f32_vec(al, K) && is_f32_vec(nr->src[0], K)) {
@@ -439,8 +487,39 @@ static bool match_matvec(const analysis & an, int pos, mv_group & grp) {
             have_x = true;
         }
     }
+    // prologue 1b: b = norm(x) * w (+ bias) (torch_nn_layer_norm, torch.h:49-60), any column count
+    if (!have_x && mm->src[0]->type != GGML_TYPE_Q4_K && uses_of(an, b) == 1 && (b->op == GGML_OP_ADD || b->op == GGML_OP_MUL)) {
+        const ggml_tensor * mulw = b, * bias = nullptr;
+        if (b->op == GGML_OP_ADD && b->src[0]->op == GGML_OP_MUL && uses_of(an, b->src[0]) == 1) { mulw = b->src[0]; bias = b->src[1]; }
+        if (mulw->op == GGML_OP_MUL && mulw->src[0]->op == GGML_OP_NORM && uses_of(an, mulw->src[0]) == 1) {
+            const ggml_tensor * nr = mulw->src[0], * wgt = mulw->src[1], * xin = nr->src[0];
+            if (is_f32_vec(wgt, K) && (!bias || is_f32_vec(bias, K)) && xin->type == GGML_TYPE_F32 && xin->ne[0] == K && xin->ne[1] == a.ncols &&
+                xin->nb[0] == 4 && ggml_nelements(xin) == K * a.ncols && ggml_are_same_shape(b, xin)) {
+                a.prologue = MV_LAYERNORM;
+                a.x = (const float *) xin->data;
+                a.x_cs = (int64_t) xin->nb[1] / 4;
+                a.alpha = (const float *) wgt->data;
+                a.beta = bias ? (const float *) bias->data : nullptr;
+                a.eps = ggml_get_op_params_f32(nr, 0);
+                grp.members.push_back(pos_of(an, nr)); grp.members.push_back(pos_of(an, mulw));
+                if (bias) grp.members.push_back(pos_of(an, b));
+                have_x = true;
+            }
+        }
+    }
+    // prologue 1c: b = gelu(h)
+    if (!have_x && mm->src[0]->type != GGML_TYPE_Q4_K && b->op == GGML_OP_UNARY && b->op_params[0] == GGML_UNARY_OP_GELU && uses_of(an, b) == 1) {
+        const ggml_tensor * hin = b->src[0];
+        if (hin->type == GGML_TYPE_F32 && hin->nb[0] == 4 && ggml_are_same_shape(hin, b) && hin->ne[2] == 1 && hin->ne[3] == 1) {
+            a.prologue = MV_GELU;
+            a.x = (const float *) hin->data;
+            a.x_cs = (int64_t) hin->nb[1] / 4;
+            grp.members.push_back(pos_of(an, b));
+            have_x = true;
+        }
+    }
     // prologue 2: b = silu(left(h)) * right(h)
-    if (!have_x && b->op == GGML_OP_MUL && uses_of(an, b) == 1 && ggml_nelements(b) == K) {
+    if (!have_x && a.ncols == 1 && b->op == GGML_OP_MUL && uses_of(an, b) == 1 && ggml_nelements(b) == K) {
         const ggml_tensor * sl = b->src[0], * r = b->src[1];
         if (sl->op == GGML_OP_UNARY && sl->op_params[0] == GGML_UNARY_OP_SILU && uses_of(an, sl) == 1 &&
             sl->src[0]->op == GGML_OP_VIEW && r->op == GGML_OP_VIEW && uses_of(an, sl->src[0]) == 1 && uses_of(an, r) == 1) {
@@ -455,21 +534,33 @@ static bool match_matvec(const analysis & an, int pos, mv_group & grp) {
             }
         }
     }
-    if (!have_x) {
-        if (!ggml_is_contiguous(b)) return false;
-        a.x = (const float *) b->data;
+    if (!have_x) {   // plain activation: address it through the mat-vec's own operand (a looked-through view may be shaped differently)
+        a.x = (const float *) mm->src[1]->data;
+        a.x_cs = (int64_t) mm->src[1]->nb[1] / 4;
     }
-    // epilogue: the only consumer adds a same-shaped F32 vector
+    // epilogue: (optional per-row layer_scale, then) the only consumer adds a same-shaped F32 tensor
     const ggml_tensor * cons = sole_consumer(an, mm);
+    const ggml_tensor * scaled = nullptr;
+    if (cons && cons->op == GGML_OP_MUL && cons->view_src == NULL && cons->src[0] == mm && mm->src[0]->type != GGML_TYPE_Q4_K &&
+        is_f32_vec(cons->src[1], a.M) && ggml_are_same_shape(cons, mm) && cons->nb[0] == 4) {
+        const ggml_tensor * c2 = sole_consumer(an, cons);
+        if (c2 && c2->op == GGML_OP_ADD) { scaled = cons; cons = c2; }
+    }
+    const ggml_tensor * prod = scaled ? scaled : mm;
     if (cons && cons->op == GGML_OP_ADD && cons->view_src == NULL) {
-        const ggml_tensor * other = cons->src[0] == mm ? cons->src[1] : cons->src[0];
-        if (other != mm && is_f32_vec(other, a.M) && is_f32_vec(cons, a.M)) {
+        const ggml_tensor * other = cons->src[0] == prod ? cons->src[1] : cons->src[0];
+        const bool shapes = other != prod && other->type == GGML_TYPE_F32 && ggml_are_same_shape(other, mm) && ggml_are_same_shape(cons, mm) &&
+                            other->nb[0] == 4 && cons->nb[0] == 4 && cons->type == GGML_TYPE_F32;
+        if (shapes) {
             const int cpos = pos_of(an, cons);
             bool hazard = false;
             for (int i = pos + 1; i < cpos; i++) if (writes_through_alias(an.g->nodes[i])) hazard = true;
             if (!hazard) {
                 a.residual = (const float *) other->data;
+                a.r_cs = (int64_t) other->nb[1] / 4;
                 a.y = (float *) cons->data;
+                a.y_cs = (int64_t) cons->nb[1] / 4;
+                if (scaled) { a.out_scale = (const float *) scaled->src[1]->data; grp.members.push_back(pos_of(an, scaled)); }
                 grp.members.push_back(cpos);
                 grp.emit_pos = cpos;
             }
@@ -504,7 +595,7 @@ static bool match_rope(const ggml_tensor * rotated, const ggml_tensor ** src_out
     const ggml_tensor * P = Z->src[0];
     if (P->op != GGML_OP_PERMUTE || P->op_params[0] != 3 || P->op_params[1] != 0 || P->op_params[2] != 1 || P->op_params[3] != 2) return false;
     const ggml_tensor * R = P->src[0];
-    if (R->op != GGML_OP_RESHAPE || R->ne[0] != 2 || R->ne[2] != 1) return false;   // T == 1
+    if (R->op != GGML_OP_RESHAPE || R->ne[0] != 2) return false;
     *src_out = R->src[0];
     *rotr_out = rotr;
     *roti_out = roti;
@@ -529,14 +620,14 @@ static bool match_attention(const analysis & an, int pos, attn_group & grp) {
     const ggml_tensor * x2 = sole_consumer(an, x1);
     if (!x2 || x2->op != GGML_OP_CONT) return false;
 
-    const int64_t D = kc->ne[0], C = kc->ne[1], H = kc->ne[2];
-    if (qo->ne[0] != D || qo->ne[1] != 1 || qo->ne[2] != H || qo->ne[3] != 1) return false;   // T == 1, B == 1
+    const int64_t D = kc->ne[0], C = kc->ne[1], H = kc->ne[2], Tn = qo->ne[1];
+    if (qo->ne[0] != D || Tn < 1 || Tn > 4 || qo->ne[2] != H || qo->ne[3] != 1) return false;   // B == 1
     if (vc->ne[0] != D || vc->ne[1] != C || vc->ne[2] != H) return false;
-    if (mask->type != GGML_TYPE_F32 || mask->ne[0] != C || !ggml_is_contiguous(mask)) return false;
+    if (mask->type != GGML_TYPE_F32 || mask->ne[0] != C || mask->ne[1] != Tn || !ggml_is_contiguous(mask)) return false;
     if (D % 8 != 0 || 64 % (D / 8) != 0 || D > 256) return false;
     if (kc->src[1] != vc->src[1]) return false;
     const ggml_tensor * idx = kc->src[1];
-    if (idx->type != GGML_TYPE_I32 || ggml_nelements(idx) != 1) return false;
+    if (idx->type != GGML_TYPE_I32 || ggml_nelements(idx) != Tn || !ggml_is_contiguous(idx)) return false;
     if (kc->nb[0] != 2 || vc->nb[0] != 2) return false;
 
     const ggml_tensor * ko = kc->src[0], * vrow = vc->src[0];
@@ -544,12 +635,16 @@ static bool match_attention(const analysis & an, int pos, attn_group & grp) {
     if (qo->op == GGML_OP_CONCAT) {
         const ggml_tensor * rotr2, * roti2;
         if (!match_rope(qo, &qsrc, &rotr, &roti) || !match_rope(ko, &ksrc, &rotr2, &roti2) || rotr != rotr2 || roti != roti2) return false;
-        if (rotr->type != GGML_TYPE_F32 || rotr->ne[0] != D / 2 || (const char *) roti->data != (const char *) rotr->data + D / 2 * 4) return false;
+        if (rotr->type != GGML_TYPE_F32 || rotr->ne[0] != D / 2 || rotr->ne[1] != Tn || (const char *) roti->data != (const char *) rotr->data + D / 2 * 4) return false;
+        if (rotr->nb[0] != 4 || (Tn > 1 && (int64_t) rotr->nb[1] != D * 4)) return false;
     }
-    const char * qp = resolve_dense(qsrc), * kp = resolve_dense(ksrc), * vp = resolve_dense(vrow);
-    if (!qp || !kp || !vp) return false;
     if (qsrc->type != GGML_TYPE_F32 || ksrc->type != GGML_TYPE_F32 || vrow->type != GGML_TYPE_F32) return false;
-    if (ggml_nelements(qsrc) != H * D || ggml_nelements(ksrc) != H * D || ggml_nelements(vrow) != H * D) return false;
+    for (const ggml_tensor * t : { qsrc, ksrc, vrow }) if (t->ne[0] != D || t->ne[1] != Tn || t->ne[2] != H || t->ne[3] != 1) return false;
+    sview qs, ks, vs;
+    if (!strided_resolve(qsrc, qs) || !strided_resolve(ksrc, ks) || !strided_resolve(vrow, vs)) return false;
+    for (const sview * v : { &qs, &ks, &vs }) if (v->nb[0] != 4 || v->nb[1] % 4 != 0 || v->nb[2] % 4 != 0) return false;
+    const ggml_tensor * out_t = x2;
+    if (out_t->ne[0] != D || out_t->ne[1] != H || out_t->ne[2] != Tn || !ggml_is_contiguous(out_t)) return false;
 
     // collect the interior of the block: everything reachable from x2 down to the block inputs
     std::vector<const ggml_tensor *> stack = { x2 };
@@ -596,16 +691,18 @@ static bool match_attention(const analysis & an, int pos, attn_group & grp) {
     }
     attn_args & a = grp.a;
     memset(&a, 0, sizeof(a));
-    a.q = (const float *) qp; a.k = (const float *) kp; a.v = (const float *) vp;
+    a.q = (const float *) qs.base; a.k = (const float *) ks.base; a.v = (const float *) vs.base;
+    a.q_ts = qs.nb[1] / 4; a.q_hs = qs.nb[2] / 4; a.k_ts = ks.nb[1] / 4; a.k_hs = ks.nb[2] / 4; a.v_ts = vs.nb[1] / 4; a.v_hs = vs.nb[2] / 4;
     a.rot = rotr ? (const float *) rotr->data : nullptr;
     a.mask = (const float *) mask->data;
     a.index = (const int32_t *) idx->data;
     a.kcache = (char *) kc->data; a.vcache = (char *) vc->data;
     a.k_nb1 = (int64_t) kc->nb[1]; a.k_nb2 = (int64_t) kc->nb[2];
     a.v_nb1 = (int64_t) vc->nb[1]; a.v_nb2 = (int64_t) vc->nb[2];
-    a.H = (int) H; a.D = (int) D; a.C = (int) C;
+    a.H = (int) H; a.D = (int) D; a.C = (int) C; a.T = (int) Tn;
     a.scale = ggml_get_op_params_f32(sm, 0);
     a.out = (float *) x2->data;
+    a.out_ts = H * D;
     grp.members = members;
     grp.emit_pos = pos_of(an, x2);
     return true;
@@ -838,6 +935,9 @@ static enum ggml_backend_dev_type hip_dev_type(ggml_backend_dev_t) { return GGML
 static ggml_backend_t hip_dev_init(ggml_backend_dev_t d, const char *) {
     hip_ctx * c = (hip_ctx *) d->context;
     ctx_init_lazy(c);
+    // a fresh backend handle starts from default flags and zeroed counters (the device context is shared)
+    if (c->flags != 0) { HIP_CHECK(hipStreamSynchronize(c->stream)); for (auto & kv : c->plans) plan_free(c, kv.second); c->plans.clear(); c->flags = 0; }
+    c->stats = {};
     auto * b = new ggml_backend;
     b->iface = { hip_backend_name, hip_backend_free, hip_backend_sync, hip_alloc_buffer, hip_graph_compute, hip_supports_op };
     b->device = d;

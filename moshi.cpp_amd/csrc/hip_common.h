@@ -47,7 +47,8 @@ void k_soft_max(hipStream_t s, tdesc dst, tdesc a, tdesc mask, int has_mask, flo
 void k_get_rows(hipStream_t s, tdesc dst, tdesc a, tdesc idx);
 void k_set_rows(hipStream_t s, tdesc dst, tdesc src, tdesc idx);
 void k_im2col(hipStream_t s, tdesc dst, tdesc x, int64_t K, int s0, int p0, int d0);
-void k_conv_transpose_1d(hipStream_t s, tdesc dst, tdesc w, tdesc x, int s0);
+size_t k_conv_transpose_1d_ws_size(const struct ggml_tensor * w, const struct ggml_tensor * x);
+void k_conv_transpose_1d(hipStream_t s, tdesc dst, tdesc w, tdesc x, int s0, void * ws);
 void k_timestep_embedding(hipStream_t s, tdesc dst, tdesc ts, int dim, int max_period);
 // generic matrix product: activation rows are first converted to the weight type's dot type
 // (q8_K / q8_0 / f16 / bf16) into `ws` (size from k_mul_mat_ws_size), then dotted
@@ -59,7 +60,8 @@ void k_scatter_uploads(hipStream_t s, const upload_desc * descs, const char * bl
 
 // ---- fused hot-path kernels --------------------------------------------------------------------------
 // y = W x (+ residual), x produced on the fly by an optional prologue, for one activation row (T = 1)
-enum mv_prologue { MV_PLAIN = 0, MV_RMSNORM = 1, MV_GATE_SILU = 2 };
+enum mv_prologue { MV_PLAIN = 0, MV_RMSNORM = 1, MV_GATE_SILU = 2, MV_LAYERNORM = 3, MV_GELU = 4 };
+#define MV_MAX_COLS 4
 struct mv_args {
     int         wtype;          // ggml_type of W
     const char * w;             // [K, M] rows of `row_bytes`
@@ -67,10 +69,14 @@ struct mv_args {
     int64_t     K, M;
     int         prologue;
     const float * x;            // PLAIN: x[K]; RMSNORM: raw x[K]; GATE_SILU: h[2K] (left|right halves)
-    const float * alpha;        // RMSNORM: alpha[K]
+    const float * alpha;        // RMSNORM: alpha[K]; LAYERNORM: weight[K]
+    const float * beta;         // LAYERNORM: bias[K] or NULL
     float       eps;
-    const float * residual;     // optional, [M]
-    float *     y;              // [M]
+    int         ncols;          // activation columns (1 for quantised weights, <= MV_MAX_COLS otherwise)
+    int64_t     x_cs, y_cs, r_cs;   // column strides of x / y / residual in floats
+    const float * out_scale;    // optional per-row scale applied to W x before the residual (layer_scale)
+    const float * residual;     // optional, [M, ncols]
+    float *     y;              // [M, ncols]
     float *     x_out;          // optional: prologue result written by block 0 (keeps the ggml node materialised)
 };
 bool k_matvec_supported(int wtype, int64_t K, int64_t M);
@@ -83,18 +89,20 @@ struct mv_profile {
 void k_matvec_set_profile(mv_profile * p);
 void k_matvec(hipStream_t s, const mv_args & a);
 
-// single-token self-attention over a ring KV cache (T = 1): RoPE(q,k) -> cache write -> masked
+// streaming self-attention over a ring KV cache (T <= 4 new tokens): RoPE(q,k) -> cache write -> masked
 // softmax(K q) V restricted to un-masked slots; see hip_kernels_fused.hip
 struct attn_args {
-    const float * q; const float * k; const float * v;   // [H*D] each, F32 (slices of the in_proj output)
-    const float * rot;          // timestep embedding [D] = cos(D/2) | sin(D/2), or NULL (no RoPE)
-    const float * mask;         // [C] additive mask (0 / -inf)
-    const int32_t * index;      // [1] ring slot to write
+    const float * q; const float * k; const float * v;   // element (d, t, h) at base[d + t*ts + h*hs], F32 (slices of the in_proj output)
+    int64_t q_ts, q_hs, k_ts, k_hs, v_ts, v_hs;          // strides in floats
+    const float * rot;          // timestep embedding [D, T]: cos(D/2) | sin(D/2) per row, or NULL (no RoPE)
+    const float * mask;         // [C, T] additive mask (0 / -inf)
+    const int32_t * index;      // [T] ring slots to write
     char * kcache; char * vcache;   // BF16 [D, C, H]
     int64_t k_nb1, k_nb2, v_nb1, v_nb2;
-    int H, D, C;
+    int H, D, C, T;
     float scale;
-    float * out;                // [H*D]
+    float * out;                // element (d, h, t) at out[t*out_ts + h*D + d]
+    int64_t out_ts;
 };
 void k_attn_decode(hipStream_t s, const attn_args & a);
 

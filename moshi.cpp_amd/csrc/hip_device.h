@@ -7,15 +7,21 @@
 __device__ __forceinline__ char * at(const tdesc & t, int64_t i0, int64_t i1, int64_t i2, int64_t i3) {
     return t.data + i0 * t.nb[0] + i1 * t.nb[1] + i2 * t.nb[2] + i3 * t.nb[3];
 }
+// element counts on this path are far below 2^31 (checked on the host): 32-bit division is ~5x cheaper than 64-bit
 __device__ __forceinline__ void unravel(const tdesc & t, int64_t i, int64_t & i0, int64_t & i1, int64_t & i2, int64_t & i3) {
-    i0 = i % t.ne[0]; i /= t.ne[0];
-    i1 = i % t.ne[1]; i /= t.ne[1];
-    i2 = i % t.ne[2]; i3 = i / t.ne[2];
+    uint32_t r = (uint32_t) i;
+    const uint32_t n0 = (uint32_t) t.ne[0], n1 = (uint32_t) t.ne[1], n2 = (uint32_t) t.ne[2];
+    uint32_t q = r / n0; i0 = r - q * n0; r = q;
+    q = r / n1; i1 = r - q * n1; r = q;
+    q = r / n2; i2 = r - q * n2; i3 = q;
 }
-__device__ __forceinline__ void row_coords(const tdesc & t, int64_t r, int64_t & i1, int64_t & i2, int64_t & i3) {
-    i1 = r % t.ne[1]; r /= t.ne[1];
-    i2 = r % t.ne[2]; i3 = r / t.ne[2];
+__device__ __forceinline__ void row_coords(const tdesc & t, int64_t rr, int64_t & i1, int64_t & i2, int64_t & i3) {
+    uint32_t r = (uint32_t) rr;
+    const uint32_t n1 = (uint32_t) t.ne[1], n2 = (uint32_t) t.ne[2];
+    uint32_t q = r / n1; i1 = r - q * n1; r = q;
+    q = r / n2; i2 = r - q * n2; i3 = q;
 }
+__device__ __forceinline__ int64_t wrap(int64_t i, int64_t n) { return n == 1 ? 0 : (i < n ? i : (int64_t) ((uint32_t) i % (uint32_t) n)); }
 __host__ __device__ __forceinline__ int elem_size(int type) {
     switch (type) {
         case GGML_TYPE_F32: case GGML_TYPE_I32: return 4;

@@ -211,48 +211,96 @@ __global__ void __launch_bounds__(256) matvec_q4k_kernel(mv_args a, int rows_per
 // ---------------------------------------------------------------------------------------------------
 // float-weight mat-vec (F32 / F16 / BF16 weights; 1..MV_MAX_COLS activation columns)
 // ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double block_sum4_f64(double v, double * sh) {
+    v = wave_sum_f64(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+// y[:, c] = (W x[:, c]) (* out_scale) (+ residual[:, c]) for up to MV_MAX_COLS activation columns; the weights are
+// streamed once (16 B per lane), the prologue (rms / layer norm, silu gate, gelu) is applied while staging x in LDS
 template <int WT>
 __global__ void __launch_bounds__(256) matvec_f_kernel(mv_args a, int rows_per_wave) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ double sh_red[4];
-    float * xs = (float *) smem;   // [K]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
-    x_src xsrc = { a.prologue, a.x, a.alpha, 1.0f, a.K };
-    if (a.prologue == MV_RMSNORM) xsrc.scale = block_rms_scale(a.x, a.K, a.eps, sh_red);
-    for (int64_t i = tid; i < a.K; i += blockDim.x) {
-        float v = x_value(xsrc, i);
-        if (a.x_out != nullptr && blockIdx.x == 0) a.x_out[i] = v;
-        if (WT == GGML_TYPE_F16) v = h2f(f2h(v));
-        if (WT == GGML_TYPE_BF16) v = bf2f(f2bf(v));
-        xs[i] = v;
+    float * xs = (float *) smem;   // [ncols][K]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int K = (int) a.K, nc = a.ncols;
+    for (int c = 0; c < nc; c++) {
+        const float * x = a.x + (int64_t) c * a.x_cs;
+        float mean = 0.f, scale = 1.f;
+        if (a.prologue == MV_RMSNORM || a.prologue == MV_LAYERNORM) {
+            if (a.prologue == MV_LAYERNORM) {
+                double acc = 0;
+                for (int i = tid; i < K; i += 256) acc += (double) x[i];
+                mean = (float) (block_sum4_f64(acc, sh_red) / (double) K);
+            }
+            double acc2 = 0;
+            for (int i = tid; i < K; i += 256) { const float v = x[i] - mean; acc2 += (double) (v * v); }
+            const float var = (float) (block_sum4_f64(acc2, sh_red) / (double) K);
+            scale = 1.0f / sqrtf(var + a.eps);
+        }
+        for (int i = tid; i < K; i += 256) {
+            float v;
+            switch (a.prologue) {
+                case MV_RMSNORM:   v = a.alpha[i] * (x[i] * scale); break;
+                case MV_LAYERNORM: v = ((x[i] - mean) * scale) * a.alpha[i]; if (a.beta) v = v + a.beta[i]; break;
+                case MV_GATE_SILU: { const float l = x[i], r = x[K + i]; v = (l / (1.0f + expf(-l))) * r; } break;
+                case MV_GELU:      v = gelu_table(x[i]); break;
+                default:           v = x[i]; break;
+            }
+            if (a.x_out != nullptr && blockIdx.x == 0) a.x_out[(int64_t) c * K + i] = v;
+            if (WT == GGML_TYPE_F16) v = h2f(f2h(v));
+            if (WT == GGML_TYPE_BF16) v = bf2f(f2bf(v));
+            xs[c * K + i] = v;
+        }
     }
     __syncthreads();
     constexpr int VEC = WT == GGML_TYPE_F32 ? 4 : 8;
-    const int64_t rbase = ((int64_t) blockIdx.x * nwaves + wave) * rows_per_wave;
+    const int64_t rbase = ((int64_t) blockIdx.x * 4 + wave) * rows_per_wave;
     for (int rr = 0; rr < rows_per_wave; rr++) {
         const int64_t row = rbase + rr;
         if (row >= a.M) break;
         const char * w = a.w + row * a.row_bytes;
-        double acc = 0;
-        for (int64_t k = (int64_t) lane * VEC; k < a.K; k += 64 * VEC) {
+        double acc[MV_MAX_COLS];
+#pragma unroll
+        for (int c = 0; c < MV_MAX_COLS; c++) acc[c] = 0;
+        for (int k = lane * VEC; k < K; k += 64 * VEC) {
+            float wf[VEC];
             if (WT == GGML_TYPE_F32) {
-                const float4 wv = *(const float4 *) (w + k * 4);
-                const float4 xv = *(const float4 *) (xs + k);
-                acc += (double) (wv.x * xv.x); acc += (double) (wv.y * xv.y); acc += (double) (wv.z * xv.z); acc += (double) (wv.w * xv.w);
+                const float4 wv = *(const float4 *) (w + (int64_t) k * 4);
+                wf[0] = wv.x; wf[1] = wv.y; wf[2] = wv.z; wf[3] = wv.w;
             } else {
-                const uint4 wv = *(const uint4 *) (w + k * 2);
+                const uint4 wv = *(const uint4 *) (w + (int64_t) k * 2);
                 const uint32_t ww[4] = { wv.x, wv.y, wv.z, wv.w };
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
                     const uint16_t lo = (uint16_t) (ww[j] & 0xffff), hi = (uint16_t) (ww[j] >> 16);
-                    const float w0 = WT == GGML_TYPE_F16 ? h2f(lo) : bf2f(lo), w1 = WT == GGML_TYPE_F16 ? h2f(hi) : bf2f(hi);
-                    acc += (double) (w0 * xs[k + 2 * j]);
-                    acc += (double) (w1 * xs[k + 2 * j + 1]);
+                    wf[2 * j]     = WT == GGML_TYPE_F16 ? h2f(lo) : bf2f(lo);
+                    wf[2 * j + 1] = WT == GGML_TYPE_F16 ? h2f(hi) : bf2f(hi);
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < MV_MAX_COLS; c++) {
+                if (c < nc) {
+#pragma unroll
+                    for (int j = 0; j < VEC; j++) acc[c] += (double) (wf[j] * xs[c * K + k + j]);
                 }
             }
         }
-        acc = wave_sum_f64(acc);
-        if (lane == 0) { const float s = (float) acc; a.y[row] = a.residual ? a.residual[row] + s : s; }
+#pragma unroll
+        for (int c = 0; c < MV_MAX_COLS; c++) {
+            if (c < nc) {
+                const double tot = wave_sum_f64(acc[c]);
+                if (lane == 0) {
+                    float sres = (float) tot;
+                    if (a.out_scale) sres = sres * a.out_scale[row];
+                    a.y[(int64_t) c * a.y_cs + row] = a.residual ? a.residual[(int64_t) c * a.r_cs + row] + sres : sres;
+                }
+            }
+        }
     }
 }
 
@@ -285,6 +333,7 @@ void k_matvec(hipStream_t s, const mv_args & a) {
         const size_t smem = (size_t) nb * XBLK_BYTES + (size_t) 4 * TILE_BYTES + (size_t) rows * nb * 4;
         const int grid = (int) ((a.M + rows - 1) / rows);
         GGML_ASSERT(a.prologue != MV_RMSNORM || a.K <= 4096);
+        GGML_ASSERT(a.ncols == 1 && a.out_scale == nullptr && a.prologue <= MV_GATE_SILU);
         void (*kern)(mv_args, int) = a.prologue == MV_RMSNORM ? matvec_q4k_kernel<MV_RMSNORM>
                                    : a.prologue == MV_GATE_SILU ? matvec_q4k_kernel<MV_GATE_SILU> : matvec_q4k_kernel<MV_PLAIN>;
         if (g_mv_profile && g_mv_profile->used < g_mv_profile->capacity) {
@@ -296,9 +345,11 @@ void k_matvec(hipStream_t s, const mv_args & a) {
         kern<<<grid, 256, smem, s>>>(a, rows);
         return;
     }
-    const int rows_per_wave = a.K <= 1024 ? 4 : 2;
+    GGML_ASSERT(a.ncols >= 1 && a.ncols <= MV_MAX_COLS);
+    int rows_per_wave = a.K <= 1024 ? 4 : 2;
+    while (rows_per_wave > 1 && (a.M + 4 * rows_per_wave - 1) / (4 * rows_per_wave) < 256) rows_per_wave >>= 1;
     const int grid = (int) ((a.M + 4 * rows_per_wave - 1) / (4 * rows_per_wave));
-    const size_t smem = (size_t) a.K * 4;
+    const size_t smem = (size_t) a.K * 4 * (size_t) a.ncols;
     switch (a.wtype) {
         case GGML_TYPE_F32:  matvec_f_kernel<GGML_TYPE_F32><<<grid, 256, smem, s>>>(a, rows_per_wave); break;
         case GGML_TYPE_F16:  matvec_f_kernel<GGML_TYPE_F16><<<grid, 256, smem, s>>>(a, rows_per_wave); break;
@@ -320,150 +371,158 @@ void k_matvec(hipStream_t s, const mv_args & a) {
 // result equals the reference's full-capacity soft_max (README.md:55-57).
 // ---------------------------------------------------------------------------------------------------
 #define ATTN_THREADS 256
+#define ATTN_MAX_T 4
 
 __global__ void __launch_bounds__(ATTN_THREADS) attn_decode_kernel(attn_args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int D = a.D, C = a.C, h = blockIdx.x;
+    const int D = a.D, C = a.C, T = a.T, h = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    float * sc   = (float *) smem;          // [C] scores -> probabilities
-    float * qf   = sc + C;                  // [D] bf16-rounded rotated q
-    float * knew = qf + D;                  // [D] bf16-rounded new k row
-    float * vnew = knew + D;                // [D] bf16-rounded new v row
-    double * red = (double *) (vnew + D);   // [ATTN_THREADS/64 * D] partial outputs, also reduction scratch
+    float * sc   = (float *) smem;          // [C] scores -> probabilities of the current query row
+    float * qf   = sc + C;                  // [T][D] bf16-rounded rotated q
+    float * knew = qf + T * D;              // [T][D] bf16-rounded new k rows
+    float * vnew = knew + T * D;            // [T][D] bf16-rounded new v rows
+    double * red = (double *) (vnew + T * D);   // [4][D] partial outputs
     __shared__ float sh_f[4];
     __shared__ double sh_d[4];
+    __shared__ int sh_i[4];
+    __shared__ int sh_slot[ATTN_MAX_T];
 
-    const int slot = a.index[0];
-    const float * q = a.q + (int64_t) h * D, * k = a.k + (int64_t) h * D, * v = a.v + (int64_t) h * D;
     char * kc = a.kcache + (int64_t) h * a.k_nb2, * vc = a.vcache + (int64_t) h * a.v_nb2;
+    if (tid < T) sh_slot[tid] = a.index[tid];
 
-    // 1. RoPE + cache write
+    // 1. RoPE + cache write for all T new rows (the reference's set_rows precede the attention of every row)
     const int half = D / 2;
-    for (int j = tid; j < D; j += ATTN_THREADS) {
+    for (int e = tid; e < T * D; e += ATTN_THREADS) {
+        const int t = e / D, j = e - t * D;
+        const float * q = a.q + (int64_t) t * a.q_ts + (int64_t) h * a.q_hs;
+        const float * k = a.k + (int64_t) t * a.k_ts + (int64_t) h * a.k_hs;
+        const float * v = a.v + (int64_t) t * a.v_ts + (int64_t) h * a.v_hs;
         float qo, ko;
         if (a.rot) {
             const int p = j < half ? j : j - half;
-            const float c = a.rot[p], sn = a.rot[half + p];
+            const float c = a.rot[t * D + p], sn = a.rot[t * D + half + p];
             const float qr = q[2 * p], qi = q[2 * p + 1], kr = k[2 * p], ki = k[2 * p + 1];
             if (j < half) { qo = qr * c - qi * sn; ko = kr * c - ki * sn; }
             else          { qo = qr * sn + qi * c; ko = kr * sn + ki * c; }
         } else { qo = q[j]; ko = k[j]; }
         const uint16_t kb = f2bf(ko), vb = f2bf(v[j]);
-        qf[j] = bf2f(f2bf(qo));
-        knew[j] = bf2f(kb);
-        vnew[j] = bf2f(vb);
+        qf[e] = bf2f(f2bf(qo));
+        knew[e] = bf2f(kb);
+        vnew[e] = bf2f(vb);
+        const int slot = a.index[t];
         if (slot >= 0 && slot < C) {
             ((uint16_t *) (kc + (int64_t) slot * a.k_nb1))[j] = kb;
             ((uint16_t *) (vc + (int64_t) slot * a.v_nb1))[j] = vb;
         }
     }
-    __syncthreads();
-
-    // live range of the mask: everything at or beyond n_end is masked (-inf) and contributes exactly 0
+    // live range over all query rows: everything at or beyond n_end is masked (-inf) and contributes exactly 0
     int last_live = -1;
-    for (int c = tid; c < C; c += ATTN_THREADS) if (a.mask[c] > -INFINITY) last_live = c;
-    last_live = max(last_live, __shfl_xor(last_live, 32, 64));
-    last_live = max(last_live, __shfl_xor(last_live, 16, 64));
-    last_live = max(last_live, __shfl_xor(last_live, 8, 64));
-    last_live = max(last_live, __shfl_xor(last_live, 4, 64));
-    last_live = max(last_live, __shfl_xor(last_live, 2, 64));
-    last_live = max(last_live, __shfl_xor(last_live, 1, 64));
-    __shared__ int sh_i[4];
+    for (int e = tid; e < T * C; e += ATTN_THREADS) if (a.mask[e] > -INFINITY) { const int c = e % C; last_live = c > last_live ? c : last_live; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) last_live = max(last_live, __shfl_xor(last_live, o, 64));
     if (lane == 0) sh_i[wave] = last_live;
     __syncthreads();
     const int n_end = max(max(sh_i[0], sh_i[1]), max(sh_i[2], sh_i[3])) + 1;
 
-    // 2. scores: LPS lanes per slot, 8 dims (16 B) per lane
-    const int LPS = D / 8;              // lanes per slot (16 for D=128, 8 for D=64)
+    const int LPS = D / 8;              // lanes per slot (16 for D=128, 8 for D=64): 8 dims (16 B) per lane
     const int SPW = 64 / LPS;           // slots per wave-instruction
     const int sub = lane / LPS, dl = (lane % LPS) * 8;
-    float qv[8];
+
+    for (int t = 0; t < T; t++) {
+        const float * mask = a.mask + (int64_t) t * C;
+        // 2. scores
+        float qv[8];
 #pragma unroll
-    for (int i = 0; i < 8; i++) qv[i] = qf[dl + i];
-    float lmax = -INFINITY;
-    for (int c0 = wave * SPW; c0 < n_end; c0 += 4 * SPW) {
-        const int c = c0 + sub;
-        const float m = c < n_end ? a.mask[c] : -INFINITY;
-        const bool live = m > -INFINITY;
-        double acc = 0;
-        if (live) {
-            if (c == slot) {
+        for (int i = 0; i < 8; i++) qv[i] = qf[t * D + dl + i];
+        float lmax = -INFINITY;
+        for (int c0 = wave * SPW; c0 < n_end; c0 += 4 * SPW) {
+            const int c = c0 + sub;
+            const float m = c < n_end ? mask[c] : -INFINITY;
+            const bool live = m > -INFINITY;
+            double acc = 0;
+            if (live) {
+                int fresh = -1;
+                for (int tt = 0; tt < T; tt++) if (sh_slot[tt] == c) fresh = tt;   // last writer wins, like set_rows
+                if (fresh >= 0) {
 #pragma unroll
-                for (int i = 0; i < 8; i++) acc += (double) (knew[dl + i] * qv[i]);
-            } else {
-                const uint4 kv = *(const uint4 *) (kc + (int64_t) c * a.k_nb1 + dl * 2);
-                const uint32_t kw[4] = { kv.x, kv.y, kv.z, kv.w };
+                    for (int i = 0; i < 8; i++) acc += (double) (knew[fresh * D + dl + i] * qv[i]);
+                } else {
+                    const uint4 kv = *(const uint4 *) (kc + (int64_t) c * a.k_nb1 + dl * 2);
+                    const uint32_t kw[4] = { kv.x, kv.y, kv.z, kv.w };
 #pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    acc += (double) (bf2f((uint16_t) (kw[i] & 0xffff)) * qv[2 * i]);
-                    acc += (double) (bf2f((uint16_t) (kw[i] >> 16)) * qv[2 * i + 1]);
+                    for (int i = 0; i < 4; i++) {
+                        acc += (double) (bf2f((uint16_t) (kw[i] & 0xffff)) * qv[2 * i]);
+                        acc += (double) (bf2f((uint16_t) (kw[i] >> 16)) * qv[2 * i + 1]);
+                    }
+                }
+            }
+            for (int o = LPS >> 1; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+            if (c < n_end && (lane % LPS) == 0) {
+                const float sv = live ? (float) acc * a.scale + m : -INFINITY;
+                sc[c] = sv;
+                lmax = fmaxf(lmax, sv);
+            }
+        }
+        lmax = wave_max_f32(lmax);
+        if (lane == 0) sh_f[wave] = lmax;
+        __syncthreads();
+        const float gmax = fmaxf(fmaxf(sh_f[0], sh_f[1]), fmaxf(sh_f[2], sh_f[3]));
+
+        // 3. soft_max: exp in float, sum in double, scale by (float)(1/sum), round to BF16 for the V product
+        double lsum = 0;
+        for (int c = tid; c < n_end; c += ATTN_THREADS) {
+            const float sv = sc[c];
+            const float e = sv > -INFINITY ? expf(sv - gmax) : 0.f;
+            sc[c] = e;
+            lsum += (double) e;
+        }
+        lsum = wave_sum_f64(lsum);
+        if (lane == 0) sh_d[wave] = lsum;
+        __syncthreads();
+        const float inv = (float) (1.0 / (sh_d[0] + sh_d[1] + sh_d[2] + sh_d[3]));
+        for (int c = tid; c < n_end; c += ATTN_THREADS) sc[c] = bf2f(f2bf(sc[c] * inv));
+        __syncthreads();
+
+        // 4. out[d] = sum_c V[d, c] * p[c]
+        double o8[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) o8[i] = 0;
+        for (int c0 = wave * SPW; c0 < n_end; c0 += 4 * SPW) {
+            const int c = c0 + sub;
+            const float p = c < n_end ? sc[c] : 0.f;
+            if (p != 0.f) {
+                int fresh = -1;
+                for (int tt = 0; tt < T; tt++) if (sh_slot[tt] == c) fresh = tt;
+                if (fresh >= 0) {
+#pragma unroll
+                    for (int i = 0; i < 8; i++) o8[i] += (double) (vnew[fresh * D + dl + i] * p);
+                } else {
+                    const uint4 vv = *(const uint4 *) (vc + (int64_t) c * a.v_nb1 + dl * 2);
+                    const uint32_t vw[4] = { vv.x, vv.y, vv.z, vv.w };
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        o8[2 * i]     += (double) (bf2f((uint16_t) (vw[i] & 0xffff)) * p);
+                        o8[2 * i + 1] += (double) (bf2f((uint16_t) (vw[i] >> 16)) * p);
+                    }
                 }
             }
         }
-        for (int o = LPS >> 1; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
-        if (c < n_end && (lane % LPS) == 0) {
-            const float sv = live ? (float) acc * a.scale + m : -INFINITY;
-            sc[c] = sv;
-            lmax = fmaxf(lmax, sv);
+#pragma unroll
+        for (int i = 0; i < 8; i++) for (int o = LPS; o < 64; o <<= 1) o8[i] += __shfl_xor(o8[i], o, 64);
+        if (sub == 0) {
+#pragma unroll
+            for (int i = 0; i < 8; i++) red[wave * D + dl + i] = o8[i];
         }
+        __syncthreads();
+        for (int j = tid; j < D; j += ATTN_THREADS)
+            a.out[(int64_t) t * a.out_ts + (int64_t) h * D + j] = (float) (red[j] + red[D + j] + red[2 * D + j] + red[3 * D + j]);
+        __syncthreads();
     }
-    lmax = wave_max_f32(lmax);
-    if (lane == 0) sh_f[wave] = lmax;
-    __syncthreads();
-    const float gmax = fmaxf(fmaxf(sh_f[0], sh_f[1]), fmaxf(sh_f[2], sh_f[3]));
-
-    // 3. soft_max: exp in float, sum in double, scale by (float)(1/sum), round to BF16 for the V product
-    double lsum = 0;
-    for (int c = tid; c < n_end; c += ATTN_THREADS) {
-        const float sv = sc[c];
-        const float e = sv > -INFINITY ? expf(sv - gmax) : 0.f;
-        sc[c] = e;
-        lsum += (double) e;
-    }
-    lsum = wave_sum_f64(lsum);
-    if (lane == 0) sh_d[wave] = lsum;
-    __syncthreads();
-    const float inv = (float) (1.0 / (sh_d[0] + sh_d[1] + sh_d[2] + sh_d[3]));
-    for (int c = tid; c < n_end; c += ATTN_THREADS) sc[c] = bf2f(f2bf(sc[c] * inv));
-    __syncthreads();
-
-    // 4. out[d] = sum_c V[d, c] * p[c]
-    double o8[8];
-#pragma unroll
-    for (int i = 0; i < 8; i++) o8[i] = 0;
-    for (int c0 = wave * SPW; c0 < n_end; c0 += 4 * SPW) {
-        const int c = c0 + sub;
-        const float p = c < n_end ? sc[c] : 0.f;
-        if (p != 0.f) {
-            if (c == slot) {
-#pragma unroll
-                for (int i = 0; i < 8; i++) o8[i] += (double) (vnew[dl + i] * p);
-            } else {
-                const uint4 vv = *(const uint4 *) (vc + (int64_t) c * a.v_nb1 + dl * 2);
-                const uint32_t vw[4] = { vv.x, vv.y, vv.z, vv.w };
-#pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    o8[2 * i]     += (double) (bf2f((uint16_t) (vw[i] & 0xffff)) * p);
-                    o8[2 * i + 1] += (double) (bf2f((uint16_t) (vw[i] >> 16)) * p);
-                }
-            }
-        }
-    }
-    // reduce over the SPW slot groups of the wave, then over the 4 waves
-#pragma unroll
-    for (int i = 0; i < 8; i++) for (int o = LPS; o < 64; o <<= 1) o8[i] += __shfl_xor(o8[i], o, 64);
-    if (sub == 0) {
-#pragma unroll
-        for (int i = 0; i < 8; i++) red[wave * D + dl + i] = o8[i];
-    }
-    __syncthreads();
-    for (int j = tid; j < D; j += ATTN_THREADS)
-        a.out[(int64_t) h * D + j] = (float) (red[j] + red[D + j] + red[2 * D + j] + red[3 * D + j]);
 }
 
 void k_attn_decode(hipStream_t s, const attn_args & a) {
-    GGML_ASSERT(a.D % 8 == 0 && 64 % (a.D / 8) == 0 && a.D <= 512);
-    const size_t smem = (size_t) a.C * 4 + (size_t) a.D * 4 * 3 + (size_t) (ATTN_THREADS / 64) * a.D * 8 + 16;
+    GGML_ASSERT(a.D % 8 == 0 && 64 % (a.D / 8) == 0 && a.D <= 512 && a.T >= 1 && a.T <= ATTN_MAX_T);
+    const size_t smem = (size_t) a.C * 4 + (size_t) a.T * a.D * 4 * 3 + (size_t) (ATTN_THREADS / 64) * a.D * 8 + 16;
     GGML_ASSERT(smem <= 160 * 1024);
     attn_decode_kernel<<<a.H, ATTN_THREADS, smem, s>>>(a);
 }

@@ -20,7 +20,7 @@ __global__ void binary_kernel(int op, tdesc dst, tdesc a, tdesc b, int64_t n) {
     int64_t i0, i1, i2, i3;
     unravel(dst, i, i0, i1, i2, i3);
     const float x = *(const float *) at(a, i0, i1, i2, i3);
-    const float y = *(const float *) at(b, i0 % b.ne[0], i1 % b.ne[1], i2 % b.ne[2], i3 % b.ne[3]);
+    const float y = *(const float *) at(b, wrap(i0, b.ne[0]), wrap(i1, b.ne[1]), wrap(i2, b.ne[2]), wrap(i3, b.ne[3]));
     float r;
     switch (op) {
         case GGML_OP_ADD: r = x + y; break;
@@ -132,7 +132,7 @@ __global__ void repeat_kernel(tdesc dst, tdesc a, int es, int pad, int64_t n) {
         *(float *) dp = in ? *(const float *) at(a, i0, i1, i2, i3) : 0.f;
         return;
     }
-    const char * sp = at(a, i0 % a.ne[0], i1 % a.ne[1], i2 % a.ne[2], i3 % a.ne[3]);
+    const char * sp = at(a, wrap(i0, a.ne[0]), wrap(i1, a.ne[1]), wrap(i2, a.ne[2]), wrap(i3, a.ne[3]));
     if (es == 4) *(uint32_t *) dp = *(const uint32_t *) sp; else if (es == 2) *(uint16_t *) dp = *(const uint16_t *) sp; else *dp = *sp;
 }
 void k_repeat(hipStream_t s, tdesc dst, tdesc a) {
@@ -368,36 +368,70 @@ void k_im2col(hipStream_t s, tdesc dst, tdesc x, int64_t K, int s0, int p0, int 
     if (n) im2col_kernel<<<nblocks(n), BLOCK, 0, s>>>(dst, x, K, s0, p0, d0, n);
 }
 
-// one thread per output sample (t, oc); contributions are added in ascending input position, which is
-// the order the CPU reference accumulates them in
-__global__ void conv_transpose_1d_kernel(tdesc dst, tdesc w, tdesc x, int s0, int64_t n) {
-    const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const int64_t t = i % dst.ne[0], oc = i / dst.ne[0];
-    const int64_t K = w.ne[0], IC = w.ne[2], L = x.ne[0];
+// conv_transpose_1d in two steps (the weight tensor is read exactly once, coalesced):
+//  A. P[s][l][n] = sum over the s-th slice of ic of x[l, ic] * w[ic][n], n = oc*K + k (w's memory order), double partials
+//  B. y[t, oc] = sum over l ascending of (float) sum_s P[s][l][oc*K + (t - l*s0)]  — the CPU reference's accumulation order
+#define CT_LT 8
+__global__ void convtr_partial_kernel(tdesc w, tdesc x, double * P, int N, int L, int IC, int ic_per_split) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    const int l0 = blockIdx.y * CT_LT;
+    const int split = blockIdx.z;
+    if (n >= N) return;
+    const int ic0 = split * ic_per_split, ic1 = min(IC, ic0 + ic_per_split);
     const bool f16 = w.type == GGML_TYPE_F16;
+    double acc[CT_LT];
+#pragma unroll
+    for (int i = 0; i < CT_LT; i++) acc[i] = 0;
+    const char * wp = w.data + (int64_t) n * w.nb[0];   // (k, oc) are contiguous: n-th element of an ic slab
+    for (int ic = ic0; ic < ic1; ic++) {
+        const char * wq = wp + (int64_t) ic * w.nb[2];
+        const float wv = f16 ? h2f(*(const uint16_t *) wq) : *(const float *) wq;
+#pragma unroll
+        for (int i = 0; i < CT_LT; i++) {
+            const int l = l0 + i;
+            if (l < L) {
+                float xv = *(const float *) (x.data + (int64_t) l * x.nb[0] + (int64_t) ic * x.nb[1]);
+                if (f16) xv = h2f(f2h(xv));
+                acc[i] += (double) (xv * wv);
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < CT_LT; i++) { const int l = l0 + i; if (l < L) P[((int64_t) split * L + l) * N + n] = acc[i]; }
+}
+__global__ void convtr_overlap_add_kernel(tdesc dst, const double * P, int N, int L, int K, int s0, int nsplit, int64_t n_out) {
+    const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_out) return;
+    const int t = (int) (i % dst.ne[0]), oc = (int) (i / dst.ne[0]);
     float acc = 0.f;
-    int64_t l0 = (t - (K - 1) + s0 - 1) / s0;
+    int l0 = (t - (K - 1) + s0 - 1) / s0;
     if (l0 < 0) l0 = 0;
-    for (int64_t l = l0; l < L && l * s0 <= t; l++) {
-        const int64_t k = t - l * s0;
+    for (int l = l0; l < L && l * s0 <= t; l++) {
+        const int k = t - l * s0;
         if (k >= K) continue;
         double v = 0;
-        for (int64_t ic = 0; ic < IC; ic++) {
-            float xv = *(const float *) at(x, l, ic, 0, 0);
-            float wv;
-            if (f16) { xv = h2f(f2h(xv)); wv = h2f(*(const uint16_t *) at(w, k, oc, ic, 0)); }
-            else wv = *(const float *) at(w, k, oc, ic, 0);
-            v += (double) (xv * wv);
-        }
+        for (int sp = 0; sp < nsplit; sp++) v += P[((int64_t) sp * L + l) * N + oc * K + k];
         acc += (float) v;
     }
     *(float *) at(dst, t, oc, 0, 0) = acc;
 }
-void k_conv_transpose_1d(hipStream_t s, tdesc dst, tdesc w, tdesc x, int s0) {
-    const int64_t n = dst.ne[0] * dst.ne[1];
+size_t k_conv_transpose_1d_ws_size(const struct ggml_tensor * w, const struct ggml_tensor * x) {
+    return (size_t) 16 * (size_t) x->ne[0] * (size_t) (w->ne[0] * w->ne[1]) * 8 + 256;
+}
+void k_conv_transpose_1d(hipStream_t s, tdesc dst, tdesc w, tdesc x, int s0, void * ws) {
     GGML_ASSERT(x.type == GGML_TYPE_F32 && (w.type == GGML_TYPE_F32 || w.type == GGML_TYPE_F16));
-    if (n) conv_transpose_1d_kernel<<<nblocks(n), BLOCK, 0, s>>>(dst, w, x, s0, n);
+    const int K = (int) w.ne[0], OC = (int) w.ne[1], IC = (int) w.ne[2], L = (int) x.ne[0];
+    GGML_ASSERT(w.nb[1] == w.nb[0] * K && "kernel taps and output channels must be contiguous");
+    const int N = OC * K;
+    const int nb = (N + 255) / 256, lt = (L + CT_LT - 1) / CT_LT;
+    int nsplit = 512 / (nb * lt);
+    if (nsplit > 16) nsplit = 16;
+    if (nsplit > IC / 32) nsplit = IC / 32;
+    if (nsplit < 1) nsplit = 1;
+    const int per = (IC + nsplit - 1) / nsplit;
+    convtr_partial_kernel<<<dim3(nb, lt, nsplit), 256, 0, s>>>(w, x, (double *) ws, N, L, IC, per);
+    const int64_t n_out = dst.ne[0] * dst.ne[1];
+    convtr_overlap_add_kernel<<<nblocks(n_out), BLOCK, 0, s>>>(dst, (const double *) ws, N, L, K, s0, nsplit, n_out);
 }
 
 __global__ void timestep_embedding_kernel(tdesc dst, tdesc ts, int dim, int max_period) {
@@ -553,9 +587,74 @@ __global__ void mul_mat_kernel(tdesc dst, tdesc a, tdesc b, const char * ws, int
     if (lane == 0) *(float *) at(dst, m, n, i2, i3) = result;
 }
 
+// ---- dense f16 x f16 contraction on the matrix cores (Mimi conv stacks: dst[ow, co] = sum_k A[ow][k] * B[co][k]) ----
+// Both operands are K-contiguous, which is exactly the 16x16x32 MFMA fragment order: lane l holds 8 consecutive k
+// of row (l & 15), so fragments are plain 16-byte global loads - no LDS, one wave per 16x16 output tile.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+__global__ void __launch_bounds__(256) mul_mat_f16_mfma_kernel(tdesc dst, tdesc a, tdesc b, int mt, int nt) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int tile = blockIdx.x * 4 + wave;
+    if (tile >= mt * nt) return;
+    const int tm = tile % mt, tn = tile / mt;
+    const int r = lane & 15, kq = lane >> 4;
+    const char * ap = a.data + (int64_t) (tm * 16 + r) * a.nb[1] + kq * 16;
+    const char * bp = b.data + (int64_t) (tn * 16 + r) * b.nb[1] + kq * 16;
+    f32x4 acc = { 0.f, 0.f, 0.f, 0.f };
+    const int K = (int) a.ne[0];
+    for (int k = 0; k < K; k += 32) {
+        const f16x8 av = *(const f16x8 *) (ap + k * 2);
+        const f16x8 bv = *(const f16x8 *) (bp + k * 2);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, bv, acc, 0, 0, 0);
+    }
+    // C[row = 4*(lane>>4) + j][col = lane & 15]: rows are `a` rows (dst dim 0), cols are `b` rows (dst dim 1)
+    float * out = (float *) (dst.data + (int64_t) (tn * 16 + r) * dst.nb[1]) + tm * 16 + kq * 4;
+    *(f32x4 *) out = acc;
+}
+
+// few activation rows (M = a.ne1 <= 8) against many weight rows in `b`: one wave per b row, b read once
+__global__ void __launch_bounds__(256) mul_mat_smallm_kernel(tdesc dst, tdesc a, tdesc b, int M, int N) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + wave;
+    if (n >= N) return;
+    const int K = (int) a.ne[0];
+    const char * bp = b.data + (int64_t) n * b.nb[1];
+    double acc[8];
+#pragma unroll
+    for (int m = 0; m < 8; m++) acc[m] = 0;
+    for (int k = lane * 8; k < K; k += 512) {
+        const f16x8 bv = *(const f16x8 *) (bp + k * 2);
+#pragma unroll
+        for (int m = 0; m < 8; m++) {
+            if (m < M) {
+                const f16x8 av = *(const f16x8 *) (a.data + (int64_t) m * a.nb[1] + k * 2);
+#pragma unroll
+                for (int j = 0; j < 8; j++) acc[m] += (double) ((float) av[j] * (float) bv[j]);
+            }
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < 8; m++) {
+        if (m < M) {
+            const double v = wave_sum_f64(acc[m]);
+            if (lane == 0) *(float *) (dst.data + (int64_t) m * dst.nb[0] + (int64_t) n * dst.nb[1]) = (float) v;
+        }
+    }
+}
+
 void k_mul_mat(hipStream_t s, tdesc dst, tdesc a, tdesc b, void * ws) {
     const int64_t total = td_nelements(dst);
     if (total == 0) return;
+    if (a.type == GGML_TYPE_F16 && b.type == GGML_TYPE_F16 && a.nb[0] == 2 && b.nb[0] == 2 && a.ne[2] * a.ne[3] * b.ne[2] * b.ne[3] == 1 &&
+        dst.nb[0] == 4 && a.ne[0] % 8 == 0 && (a.nb[1] % 16) == 0 && (b.nb[1] % 16) == 0 && ((uintptr_t) a.data % 16) == 0 && ((uintptr_t) b.data % 16) == 0) {
+        const int M = (int) a.ne[1], N = (int) b.ne[1];
+        if (M <= 8) { mul_mat_smallm_kernel<<<(N + 3) / 4, 256, 0, s>>>(dst, a, b, M, N); return; }
+        if (M % 16 == 0 && N % 16 == 0 && a.ne[0] % 32 == 0 && (dst.nb[1] % 16) == 0 && ((uintptr_t) dst.data % 16) == 0) {
+            const int mt = M / 16, nt = N / 16;
+            mul_mat_f16_mfma_kernel<<<(mt * nt + 3) / 4, 256, 0, s>>>(dst, a, b, mt, nt);
+            return;
+        }
+    }
     const int vt = vec_dot_type(a.type);
     GGML_ASSERT(a.nb[0] == (int64_t) ggml_type_size((enum ggml_type) a.type));
     GGML_ASSERT(b.type == GGML_TYPE_F32 || b.type == vt);

@@ -201,7 +201,7 @@ def test_mul_mat_batched_heads_bf16():
     gu.compare(build, atol_rel=2e-6)
 
 
-@pytest.mark.parametrize("Cin,Cout,K,s,L", [(1, 64, 7, 1, 40), (64, 128, 8, 4, 64), (512, 1024, 7, 1, 8), (256, 512, 1, 1, 3)])
+@pytest.mark.parametrize("Cin,Cout,K,s,L", [(1, 64, 7, 1, 40), (64, 128, 8, 4, 64), (512, 1024, 7, 1, 8), (256, 512, 1, 1, 3), (64, 32, 3, 1, 50), (128, 64, 3, 1, 482), (32, 64, 1, 1, 1920)])
 def test_conv_1d(Cin, Cout, K, s, L):
     r = np.random.default_rng(Cin + K)
     w = (r.standard_normal((Cout, Cin, K)) / np.sqrt(Cin * K)).astype(np.float32)
