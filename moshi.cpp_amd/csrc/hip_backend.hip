@@ -804,7 +804,15 @@ static plan_t * build_plan(hip_ctx * c, ggml_cgraph * g) {
             for (int m : grp.members) if (m < 0 || (m != i && an.skip[(size_t) m])) clash = true;
             if (clash) continue;
             for (int m : grp.members) an.skip[(size_t) m] = 1;
-            const mv_args a = grp.a;
+            mv_args a = grp.a;
+            if (a.prologue == MV_GATE_SILU && a.wtype == GGML_TYPE_Q4_K && a.K > 4096) {
+                // long gated rows: quantise the activation once, not once per workgroup
+                void * blocks = em.ws((size_t) (a.K / 256) * MV_XBLK_BYTES);
+                const float * h = a.x; const int64_t K = a.K;
+                at_pos[grp.emit_pos].push_back([=](hipStream_t s) { k_gate_quant_q8k(s, h, K, blocks); });
+                a.prologue = MV_PREQ8K;
+                a.x = (const float *) blocks;
+            }
             at_pos[grp.emit_pos].push_back([=](hipStream_t s) { k_matvec(s, a); });
             if (grp.members.size() > 1) p->n_fused += (int) grp.members.size();
         }

@@ -60,7 +60,7 @@ void k_scatter_uploads(hipStream_t s, const upload_desc * descs, const char * bl
 
 // ---- fused hot-path kernels --------------------------------------------------------------------------
 // y = W x (+ residual), x produced on the fly by an optional prologue, for one activation row (T = 1)
-enum mv_prologue { MV_PLAIN = 0, MV_RMSNORM = 1, MV_GATE_SILU = 2, MV_LAYERNORM = 3, MV_GELU = 4 };
+enum mv_prologue { MV_PLAIN = 0, MV_RMSNORM = 1, MV_GATE_SILU = 2, MV_LAYERNORM = 3, MV_GELU = 4, MV_PREQ8K = 5 };
 #define MV_MAX_COLS 4
 struct mv_args {
     int         wtype;          // ggml_type of W
@@ -88,6 +88,9 @@ struct mv_profile {
 };
 void k_matvec_set_profile(mv_profile * p);
 void k_matvec(hipStream_t s, const mv_args & a);
+// gated-FFN activation silu(h[:K]) * h[K:] quantised to padded Q8_K blocks (K/256 x 304 B) for a following MV_PREQ8K mat-vec
+#define MV_XBLK_BYTES 304
+void k_gate_quant_q8k(hipStream_t s, const float * h, int64_t K, void * out_blocks);
 
 // streaming self-attention over a ring KV cache (T <= 4 new tokens): RoPE(q,k) -> cache write -> masked
 // softmax(K q) V restricted to un-masked slots; see hip_kernels_fused.hip

@@ -88,6 +88,57 @@ __device__ __forceinline__ float apply_unary(int uop, float x) {
     }
 }
 
+// ---- wave64 all-reduce on the DPP path (no LDS round trips: __shfl_xor lowers to ds_bpermute, ~100 cycles a step) ----
+#define DPP_QUAD_XOR1   0xB1   // quad_perm [1,0,3,2]
+#define DPP_QUAD_XOR2   0x4E   // quad_perm [2,3,0,1]
+#define DPP_HALF_MIRROR 0x141  // lane i <-> 7 - i inside each group of 8
+#define DPP_ROW_MIRROR  0x140  // lane i <-> 15 - i inside each row of 16
+template <int CTRL> __device__ __forceinline__ float dpp_f32(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+template <int CTRL> __device__ __forceinline__ int dpp_i32(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, false); }
+template <int CTRL> __device__ __forceinline__ double dpp_f64(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+// max over the 64 lanes, result in every lane
+__device__ __forceinline__ float wave_allmax_f32(float v) {
+    v = fmaxf(v, dpp_f32<DPP_QUAD_XOR1>(v));
+    v = fmaxf(v, dpp_f32<DPP_QUAD_XOR2>(v));
+    v = fmaxf(v, dpp_f32<DPP_HALF_MIRROR>(v));
+    v = fmaxf(v, dpp_f32<DPP_ROW_MIRROR>(v));
+    const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
+    const float r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
+    const float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32));
+    const float r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+    return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
+}
+// sum over the 64 lanes in double, result in every lane (fixed order)
+__device__ __forceinline__ double wave_allsum_f64(double v) {
+    v += dpp_f64<DPP_QUAD_XOR1>(v);
+    v += dpp_f64<DPP_QUAD_XOR2>(v);
+    v += dpp_f64<DPP_HALF_MIRROR>(v);
+    v += dpp_f64<DPP_ROW_MIRROR>(v);
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    const double r0 = __hiloint2double(__builtin_amdgcn_readlane(hi, 0), __builtin_amdgcn_readlane(lo, 0));
+    const double r1 = __hiloint2double(__builtin_amdgcn_readlane(hi, 16), __builtin_amdgcn_readlane(lo, 16));
+    const double r2 = __hiloint2double(__builtin_amdgcn_readlane(hi, 32), __builtin_amdgcn_readlane(lo, 32));
+    const double r3 = __hiloint2double(__builtin_amdgcn_readlane(hi, 48), __builtin_amdgcn_readlane(lo, 48));
+    return (r0 + r1) + (r2 + r3);
+}
+// sum over each aligned group of 4 lanes, result in all 4
+__device__ __forceinline__ int quad_allsum_i32(int v) { v += dpp_i32<DPP_QUAD_XOR1>(v); v += dpp_i32<DPP_QUAD_XOR2>(v); return v; }
+// sum over each aligned group of 16 lanes (one DPP row), result in all 16
+__device__ __forceinline__ float row16_allsum_f32(float v) {
+    v += dpp_f32<DPP_QUAD_XOR1>(v);
+    v += dpp_f32<DPP_QUAD_XOR2>(v);
+    v += dpp_f32<DPP_HALF_MIRROR>(v);
+    v += dpp_f32<DPP_ROW_MIRROR>(v);
+    return v;
+}
+
 // ---- wave64 reductions ---------------------------------------------------------------------------------
 __device__ __forceinline__ float wave_sum_f32(float v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

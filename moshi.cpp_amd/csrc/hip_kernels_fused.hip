@@ -18,6 +18,7 @@
 #include "hip_device.h"
 #include <hip/hip_ext.h>
 #include <stdlib.h>
+#include <map>
 
 // ---------------------------------------------------------------------------------------------------
 // activation prologues
@@ -59,28 +60,37 @@ __device__ float block_rms_scale(const float * x, int64_t K, float eps, double *
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
+// diagnostic build only (-DMV_STAMPS, tests/microbench/mv_bench.hip): per-phase s_memtime stamps of wave 0 of each workgroup
+#ifdef MV_STAMPS
+__device__ unsigned long long g_mv_stamps[4096][8];
+__device__ unsigned long long g_mv_real[4096][2];
+#define MV_STAMP(i) do { if (lane == 0 && wave == 0 && blockIdx.x < 4096) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); g_mv_stamps[blockIdx.x][i] = t_; \
+    if ((i) == 0 || (i) == 7) { unsigned long long r_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(r_) :: "memory"); g_mv_real[blockIdx.x][(i) == 7] = r_; } } } while (0)
+#else
+#define MV_STAMP(i) do {} while (0)
+#endif
+
 struct xblk { int8_t q[256]; int16_t bsums[16]; float d; float pad[3]; };
 static_assert(sizeof(xblk) == XBLK_BYTES, "xblk layout");
 
 // quantise the 256 values held by one wave (4 per lane, contiguous) to a Q8_K block in LDS
 __device__ __forceinline__ void quantize_block_q8k(xblk * dst, const float v[4], int lane) {
-    float mx = v[0];
-#pragma unroll
-    for (int k = 1; k < 4; k++) if (fabsf(v[k]) > fabsf(mx)) mx = v[k];
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { const float other = __shfl_xor(mx, o, 64); if (fabsf(other) > fabsf(mx)) mx = other; }
+    // the signed value of largest magnitude (ggml: iscale = -127 / max); when +a and -a tie the sign is immaterial
+    float amax = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
+    float smax = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
+    amax = wave_allmax_f32(amax);
+    smax = wave_allmax_f32(smax);
+    const float mx = smax == amax ? amax : -amax;
     int q[4] = { 0, 0, 0, 0 };
     float d = 0.f;
-    if (mx != 0.f) {
+    if (amax != 0.f) {
         const float iscale = -127.f / mx;
 #pragma unroll
         for (int k = 0; k < 4; k++) { const int qi = nearest_int_dev(iscale * v[k]); q[k] = qi < 127 ? qi : 127; }
         d = 1.f / iscale;
     }
     *(uint32_t *) (dst->q + lane * 4) = (uint32_t) (q[0] & 0xff) | ((uint32_t) (q[1] & 0xff) << 8) | ((uint32_t) (q[2] & 0xff) << 16) | ((uint32_t) (q[3] & 0xff) << 24);
-    int s4 = q[0] + q[1] + q[2] + q[3];
-    s4 += __shfl_xor(s4, 1, 64);
-    s4 += __shfl_xor(s4, 2, 64);
+    const int s4 = quad_allsum_i32(q[0] + q[1] + q[2] + q[3]);
     if ((lane & 3) == 0) dst->bsums[lane >> 2] = (int16_t) s4;
     if (lane == 0) dst->d = d;
 }
@@ -91,12 +101,12 @@ __device__ __forceinline__ void quantize_block_q8k(xblk * dst, const float v[4],
 //           16-block batch are issued before any of them is used, so the phase costs ~one L2 round trip
 //  phase 3: tiles stream registers -> LDS image -> one super-block per lane (next tile prefetched first)
 //  phase 4: fixed-order row sums (+ residual)
-template <int PRO>
-__global__ void __launch_bounds__(256) matvec_q4k_kernel(mv_args a, int rows_per_wg) {
+template <int PRO, int NW>
+__global__ void __launch_bounds__(NW * 64) matvec_q4k_kernel(mv_args a, int rows_per_wg) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    __shared__ double sh_red[4];
+    __shared__ double sh_red[NW];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    constexpr int nwaves = 4;
+    constexpr int nwaves = NW;
     const int nb = (int) (a.K / 256);
     xblk * xs = (xblk *) smem;
     char * stage = smem + nb * XBLK_BYTES + wave * TILE_BYTES;
@@ -109,81 +119,108 @@ __global__ void __launch_bounds__(256) matvec_q4k_kernel(mv_args a, int rows_per
     const int nchunks = nblk * 9;
     const u32x4 * wsrc = (const u32x4 *) (a.w + row0 * a.row_bytes);
 
+    MV_STAMP(0);
+    const int K = (int) a.K;
+    // activation loads of the first 16-block batch go out BEFORE the weight tile: vector-memory loads return in order,
+    // so this lets the prologue finish while the (much larger, HBM-bound) weight tile is still in flight
+    float4 xv[4], aux[4];
+    bool ok[4];
+    auto load_batch = [&](int base) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            // loads are unconditional (index clamped, result discarded through ok[]): a branch around a load makes hipcc
+            // fall back to s_waitcnt vmcnt(0)-style waits, which would serialise the prologue behind the weight tile
+            const int e0 = base + j * (NW * 256) + tid * 4;
+            ok[j] = e0 < K;
+            const int e = ok[j] ? e0 : K - 4;
+            xv[j] = *(const float4 *) (a.x + e);
+            aux[j] = xv[j];
+            if (PRO == MV_RMSNORM) aux[j] = *(const float4 *) (a.alpha + e);
+            if (PRO == MV_GATE_SILU) aux[j] = *(const float4 *) (a.x + K + e);
+        }
+    };
+    if (PRO != MV_PREQ8K) load_batch(0);
+    __builtin_amdgcn_sched_barrier(0);   // keep the activation loads ahead of the weight tile in program (= return) order
+
     u32x4 r[9];
     int t = wave;
-    if (t < ntiles) {
+    {   // unconditional, clamped: chunks past the end re-read the last valid chunk and are never consumed
+        const int tt = t < ntiles ? t : ntiles - 1;
 #pragma unroll
         for (int i = 0; i < 9; i++) {
-            const int g = t * 576 + i * 64 + lane;
-            r[i] = g < nchunks ? __builtin_nontemporal_load(wsrc + g) : (u32x4) (0u);
+            const int g = tt * 576 + i * 64 + lane;
+            r[i] = __builtin_nontemporal_load(wsrc + (g < nchunks ? g : nchunks - 1));
         }
     }
+    __builtin_amdgcn_sched_barrier(0);
+    MV_STAMP(1);
 
-    // phase 2: batches of 16 blocks; thread owns elements base + j*1024 + tid*4 .. +3  (block = base/256 + 4j + wave)
-    const int K = (int) a.K;
-    for (int base = 0; base < K; base += 4096) {
-        float v[4][4];
-        float4 aux[4];
-        bool ok[4];
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const int e = base + j * 1024 + tid * 4;
-            ok[j] = e < K;
-            float4 x4 = make_float4(0.f, 0.f, 0.f, 0.f);
-            aux[j] = x4;
-            if (ok[j]) {
-                x4 = *(const float4 *) (a.x + e);
-                if (PRO == MV_RMSNORM) aux[j] = *(const float4 *) (a.alpha + e);
-                if (PRO == MV_GATE_SILU) aux[j] = *(const float4 *) (a.x + K + e);
-            }
-            v[j][0] = x4.x; v[j][1] = x4.y; v[j][2] = x4.z; v[j][3] = x4.w;
-        }
-        if (PRO == MV_RMSNORM) {   // K <= 4096 (checked on the host): the whole vector is in registers
-            double acc = 0;
-#pragma unroll
-            for (int j = 0; j < 4; j++)
-#pragma unroll
-                for (int k = 0; k < 4; k++) acc += (double) (v[j][k] * v[j][k]);
-            acc = wave_sum_f64(acc);
-            if (lane == 0) sh_red[wave] = acc;
-            __syncthreads();
-            const float mean = (float) ((sh_red[0] + sh_red[1] + sh_red[2] + sh_red[3]) / (double) K);
-            const float scale = 1.0f / sqrtf(mean + a.eps);
+    if (PRO == MV_PREQ8K) {
+        // activations were quantised by gate_quant_q8k_kernel: copy the padded Q8_K blocks (304 B each) into LDS
+        const u32x4 * src = (const u32x4 *) a.x;
+        for (int i = tid; i < nb * (XBLK_BYTES / 16); i += NW * 64) ((u32x4 *) xs)[i] = src[i];
+    } else {
+        for (int base = 0; base < K; base += NW * 1024) {
+            if (base > 0) load_batch(base);
+            float v[4][4];
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-                const float al[4] = { aux[j].x, aux[j].y, aux[j].z, aux[j].w };
-#pragma unroll
-                for (int k = 0; k < 4; k++) v[j][k] = al[k] * (v[j][k] * scale);
+                const float z = ok[j] ? 1.f : 0.f;   // clamped (out-of-range) chunks contribute nothing to the norm
+                v[j][0] = xv[j].x * z; v[j][1] = xv[j].y * z; v[j][2] = xv[j].z * z; v[j][3] = xv[j].w * z;
             }
-        }
-        if (PRO == MV_GATE_SILU) {
+            if (PRO == MV_RMSNORM) {   // K <= 4096 (checked on the host): the whole vector is in registers
+                double acc = 0;
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+#pragma unroll
+                    for (int k = 0; k < 4; k++) acc += (double) (v[j][k] * v[j][k]);
+                acc = wave_allsum_f64(acc);
+                if (lane == 0) sh_red[wave] = acc;
+                __syncthreads();
+                double tot = 0;
+#pragma unroll
+                for (int w = 0; w < NW; w++) tot += sh_red[w];
+                const float mean = (float) (tot / (double) K);
+                const float scale = 1.0f / sqrtf(mean + a.eps);
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const float al[4] = { aux[j].x, aux[j].y, aux[j].z, aux[j].w };
+#pragma unroll
+                    for (int k = 0; k < 4; k++) v[j][k] = al[k] * (v[j][k] * scale);
+                }
+            }
+            if (PRO == MV_GATE_SILU) {
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const float rr[4] = { aux[j].x, aux[j].y, aux[j].z, aux[j].w };
+#pragma unroll
+                    for (int k = 0; k < 4; k++) { const float l = v[j][k]; v[j][k] = (l / (1.0f + expf(-l))) * rr[k]; }
+                }
+            }
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-                const float rr[4] = { aux[j].x, aux[j].y, aux[j].z, aux[j].w };
-#pragma unroll
-                for (int k = 0; k < 4; k++) { const float l = v[j][k]; v[j][k] = (l / (1.0f + expf(-l))) * rr[k]; }
+                if (!ok[j]) continue;   // wave-uniform: a wave always holds one whole block
+                const int b = base / 256 + j * NW + wave;
+                if (a.x_out != nullptr && blockIdx.x == 0) *(float4 *) (a.x_out + base + j * (NW * 256) + tid * 4) = make_float4(v[j][0], v[j][1], v[j][2], v[j][3]);
+                quantize_block_q8k(xs + b, v[j], lane);
             }
-        }
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            if (!ok[j]) continue;   // wave-uniform: a wave always holds one whole block
-            const int b = base / 256 + j * 4 + wave;
-            if (a.x_out != nullptr && blockIdx.x == 0) *(float4 *) (a.x_out + base + j * 1024 + tid * 4) = make_float4(v[j][0], v[j][1], v[j][2], v[j][3]);
-            quantize_block_q8k(xs + b, v[j], lane);
         }
     }
+    MV_STAMP(2);
     __syncthreads();
+    MV_STAMP(3);
 
     // phase 3
     for (; t < ntiles; t += nwaves) {
 #pragma unroll
         for (int i = 0; i < 9; i++) ((u32x4 *) stage)[i * 64 + lane] = r[i];
-        const int tn = t + nwaves;
-        if (tn < ntiles) {
+        MV_STAMP(4);
+        {
+            const int tn = t + nwaves < ntiles ? t + nwaves : ntiles - 1;
 #pragma unroll
             for (int i = 0; i < 9; i++) {
                 const int g = tn * 576 + i * 64 + lane;
-                r[i] = g < nchunks ? __builtin_nontemporal_load(wsrc + g) : (u32x4) (0u);
+                r[i] = __builtin_nontemporal_load(wsrc + (g < nchunks ? g : nchunks - 1));
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -197,15 +234,21 @@ __global__ void __launch_bounds__(256) matvec_q4k_kernel(mv_args a, int rows_per
         }
         __builtin_amdgcn_wave_barrier();
     }
+    MV_STAMP(5);
     __syncthreads();
+    MV_STAMP(6);
 
-    // phase 4
-    for (int rr = tid; rr < rows; rr += 256) {
+    // phase 4: row sums (+ residual): 16 lanes per row, strided partials then a 4-step butterfly
+    for (int rr = tid >> 4; rr < rows; rr += NW * 4) {
         float sum = 0.f;
-        for (int j = 0; j < nb; j++) sum += part[rr * nb + j];
-        const int64_t row = row0 + rr;
-        a.y[row] = a.residual ? a.residual[row] + sum : sum;
+        for (int j = tid & 15; j < nb; j += 16) sum += part[rr * nb + j];
+        sum = row16_allsum_f32(sum);
+        if ((tid & 15) == 0) {
+            const int64_t row = row0 + rr;
+            a.y[row] = a.residual ? a.residual[row] + sum : sum;
+        }
     }
+    MV_STAMP(7);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -314,6 +357,23 @@ bool k_matvec_supported(int wtype, int64_t K, int64_t M) {
     }
 }
 
+// silu(left) * right of the gated FFN, quantised to padded Q8_K blocks in global memory: one wave per 256-element block.
+// Used for long rows (K > 4096), where redoing this in every mat-vec workgroup would dominate the kernel.
+__global__ void __launch_bounds__(64) gate_quant_q8k_kernel(const float * h, int K, xblk * out, float * g_out) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const int e = b * 256 + lane * 4;
+    const float4 l4 = *(const float4 *) (h + e), r4 = *(const float4 *) (h + K + e);
+    const float l[4] = { l4.x, l4.y, l4.z, l4.w }, r[4] = { r4.x, r4.y, r4.z, r4.w };
+    float v[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) v[k] = (l[k] / (1.0f + expf(-l[k]))) * r[k];
+    if (g_out) *(float4 *) (g_out + e) = make_float4(v[0], v[1], v[2], v[3]);
+    quantize_block_q8k(out + b, v, lane);
+}
+void k_gate_quant_q8k(hipStream_t s, const float * h, int64_t K, void * out_blocks) {
+    gate_quant_q8k_kernel<<<(int) (K / 256), 64, 0, s>>>(h, (int) K, (xblk *) out_blocks, nullptr);
+}
+
 static mv_profile * g_mv_profile = nullptr;
 void k_matvec_set_profile(mv_profile * p) { g_mv_profile = p; }
 
@@ -322,27 +382,44 @@ static int env_int(const char * name, int def) { const char * v = getenv(name); 
 void k_matvec(hipStream_t s, const mv_args & a) {
     if (a.wtype == GGML_TYPE_Q4_K) {
         const int nb = (int) (a.K / 256);
-        // tiles (64 super-blocks) per workgroup: one per wave, more for long rows so that the activation prologue
-        // (cost ~K per workgroup) is amortised; rows are halved while the grid would leave CUs idle
-        static const int tpw_min = env_int("MI355X_MV_TPW", 4), grid_min = env_int("MI355X_MV_GRID_MIN", 256);
-        int tpw = tpw_min > nb / 4 ? tpw_min : nb / 4;
-        int rows = (tpw * 64 + nb - 1) / nb;
-        if (rows * nb > 4096) rows = 4096 / nb;
-        while (rows > 1 && (a.M + rows - 1) / rows < grid_min && (rows / 2) * nb >= 64) rows >>= 1;
+        // Workgroup shape. Large matrices (>= ~8 tiles per CU): ONE workgroup of 8 or 12 waves per CU, so the activation
+        // prologue (cost ~K, identical in every workgroup) runs once per CU and every wave keeps a 9 KB tile in flight.
+        // Small matrices: 4-wave workgroups of >= 1 tile each, as many as there are tiles (latency-bound anyway).
+        static const int force_nw = env_int("MI355X_MV_NW", 0), tpw_min = env_int("MI355X_MV_TPW", 4), grid_min = env_int("MI355X_MV_GRID_MIN", 256);
+        const int64_t tiles_total = (a.M * nb + 63) / 64;
+        int nw = 4, rows;
+        if (force_nw ? force_nw > 4 : tiles_total >= 256 * 6) {
+            nw = force_nw ? force_nw : (tiles_total >= 256 * 10 ? 12 : 8);
+            rows = (int) ((a.M + 255) / 256);
+            while (rows * nb > 4096) rows = (rows + 1) / 2;
+        } else {
+            int tpw = tpw_min > nb / 4 ? tpw_min : nb / 4;
+            rows = (tpw * 64 + nb - 1) / nb;
+            if (rows * nb > 4096) rows = 4096 / nb;
+            while (rows > 1 && (a.M + rows - 1) / rows < grid_min && (rows / 2) * nb >= 64) rows >>= 1;
+        }
         if (rows < 1) rows = 1;
-        const size_t smem = (size_t) nb * XBLK_BYTES + (size_t) 4 * TILE_BYTES + (size_t) rows * nb * 4;
+        const size_t smem = (size_t) nb * XBLK_BYTES + (size_t) nw * TILE_BYTES + (size_t) rows * nb * 4;
         const int grid = (int) ((a.M + rows - 1) / rows);
-        GGML_ASSERT(a.prologue != MV_RMSNORM || a.K <= 4096);
-        GGML_ASSERT(a.ncols == 1 && a.out_scale == nullptr && a.prologue <= MV_GATE_SILU);
-        void (*kern)(mv_args, int) = a.prologue == MV_RMSNORM ? matvec_q4k_kernel<MV_RMSNORM>
-                                   : a.prologue == MV_GATE_SILU ? matvec_q4k_kernel<MV_GATE_SILU> : matvec_q4k_kernel<MV_PLAIN>;
+        GGML_ASSERT(a.prologue != MV_RMSNORM || a.K <= nw * 1024);
+        GGML_ASSERT(a.ncols == 1 && a.out_scale == nullptr && (a.prologue <= MV_GATE_SILU || a.prologue == MV_PREQ8K));
+        void (*kern)(mv_args, int) = nullptr;
+#define MV_PICK(NWV) (a.prologue == MV_RMSNORM ? matvec_q4k_kernel<MV_RMSNORM, NWV> : a.prologue == MV_GATE_SILU ? matvec_q4k_kernel<MV_GATE_SILU, NWV> \
+                      : a.prologue == MV_PREQ8K ? matvec_q4k_kernel<MV_PREQ8K, NWV> : matvec_q4k_kernel<MV_PLAIN, NWV>)
+        kern = nw == 12 ? MV_PICK(12) : nw == 8 ? MV_PICK(8) : MV_PICK(4);
+        if (smem > 64 * 1024) {   // > 64 KB of dynamic LDS needs a one-time opt-in per kernel
+            static std::map<const void *, size_t> granted;
+            size_t & g = granted[(const void *) kern];
+            if (g < smem) { HIP_CHECK(hipFuncSetAttribute((const void *) kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int) smem)); g = smem; }
+        }
+        const int threads = nw * 64;
         if (g_mv_profile && g_mv_profile->used < g_mv_profile->capacity) {
             mv_profile::rec & r = g_mv_profile->recs[g_mv_profile->used++];
             r.bytes = a.M * a.row_bytes;
-            hipExtLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, s, r.start, r.stop, 0, a, rows);
+            hipExtLaunchKernelGGL(kern, dim3(grid), dim3(threads), smem, s, r.start, r.stop, 0, a, rows);
             return;
         }
-        kern<<<grid, 256, smem, s>>>(a, rows);
+        kern<<<grid, threads, smem, s>>>(a, rows);
         return;
     }
     GGML_ASSERT(a.ncols >= 1 && a.ncols <= MV_MAX_COLS);
