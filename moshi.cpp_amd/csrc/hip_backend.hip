@@ -508,7 +508,8 @@ static bool match_matvec(const analysis & an, int pos, mv_group & grp) {
         }
     }
     // prologue 1c: b = gelu(h)
-    if (!have_x && mm->src[0]->type != GGML_TYPE_Q4_K && b->op == GGML_OP_UNARY && b->op_params[0] == GGML_UNARY_OP_GELU && uses_of(an, b) == 1) {
+    if (!have_x && mm->src[0]->type != GGML_TYPE_Q4_K && b->op == GGML_OP_UNARY && b->op_params[0] == GGML_UNARY_OP_GELU && uses_of(an, b) == 1 &&
+        !an.skip[(size_t) pos_of(an, b)]) {   // (already produced by the previous mat-vec's epilogue otherwise)
         const ggml_tensor * hin = b->src[0];
         if (hin->type == GGML_TYPE_F32 && hin->nb[0] == 4 && ggml_are_same_shape(hin, b) && hin->ne[2] == 1 && hin->ne[3] == 1) {
             a.prologue = MV_GELU;
@@ -537,6 +538,19 @@ static bool match_matvec(const analysis & an, int pos, mv_group & grp) {
     if (!have_x) {   // plain activation: address it through the mat-vec's own operand (a looked-through view may be shaped differently)
         a.x = (const float *) mm->src[1]->data;
         a.x_cs = (int64_t) mm->src[1]->nb[1] / 4;
+    }
+    // epilogue 0: gelu(W x) (the activation is evaluated once per output element here, not once per consuming workgroup)
+    {
+        const ggml_tensor * g = sole_consumer(an, mm);
+        if (g && g->op == GGML_OP_UNARY && g->op_params[0] == GGML_UNARY_OP_GELU && mm->src[0]->type != GGML_TYPE_Q4_K && g->view_src == NULL &&
+            ggml_are_same_shape(g, mm) && g->nb[0] == 4 && g->type == GGML_TYPE_F32) {
+            a.out_act = 1;
+            a.y = (float *) g->data;
+            a.y_cs = (int64_t) g->nb[1] / 4;
+            grp.members.push_back(pos_of(an, g));
+            grp.emit_pos = pos_of(an, g);
+            return true;
+        }
     }
     // epilogue: (optional per-row layer_scale, then) the only consumer adds a same-shaped F32 tensor
     const ggml_tensor * cons = sole_consumer(an, mm);
@@ -757,6 +771,134 @@ static bool match_embed_sum(const analysis & an, int pos, embed_group & grp) {
     return true;
 }
 
+// D. streaming / stateless conv1d (conv.h:50-96, 137-161): [elu] -> concat(prev, x) -> {tail cpy, im2col} -> mul_mat -> reshape
+//    [-> + bias] [-> residual + y]  becomes  stream_im2col + conv_tail + one product with the bias/residual epilogue.
+struct step_group { std::vector<step_fn> steps; int emit_pos; std::vector<int> members; };
+
+static bool is_elu(const ggml_tensor * t) { return t->op == GGML_OP_UNARY && t->op_params[0] == GGML_UNARY_OP_ELU && t->view_src == NULL; }
+
+static bool match_conv(const analysis & an, int pos, step_group & grp) {
+    const ggml_tensor * mm = an.g->nodes[pos];
+    if (mm->op != GGML_OP_MUL_MAT) return false;
+    const ggml_tensor * ra = mm->src[0], * rw = mm->src[1];
+    if (ra->op != GGML_OP_RESHAPE || rw->op != GGML_OP_RESHAPE) return false;
+    const ggml_tensor * im = ra->src[0], * w = rw->src[0];
+    if (im->op != GGML_OP_IM2COL || im->src[0] != w || im->type != GGML_TYPE_F16 || w->type != GGML_TYPE_F16 || !ggml_is_contiguous(w)) return false;
+    if (uses_of(an, im) != 1 || uses_of(an, ra) != 1 || uses_of(an, mm) != 1) return false;
+    const int s0 = im->op_params[0], p0 = im->op_params[2], d0 = im->op_params[4];
+    if (p0 != 0 || d0 != 1 || im->ne[2] != 1 || im->ne[3] != 1) return false;
+    const ggml_tensor * cat = im->src[1];
+    const int Kw = (int) w->ne[0], Cin = (int) w->ne[1];
+    std::vector<int> members = { pos_of(an, im), pos_of(an, ra), pos_of(an, rw), pos };
+    const ggml_tensor * prev = nullptr, * xin = cat;
+    int TP = 0;
+    if (cat->op == GGML_OP_CONCAT && cat->op_params[0] == 0 && cat->src[0]->op == GGML_OP_NONE) {
+        prev = cat->src[0]; xin = cat->src[1];
+        TP = (int) prev->ne[0];
+        if (prev->type != GGML_TYPE_F32 || !ggml_is_contiguous(prev) || prev->ne[1] != Cin || ggml_nelements(prev) != (int64_t) TP * Cin || !prev->data) return false;
+        if (TP > 32 || uses_of(an, cat) != 2) return false;
+        // the tail update: cpy(view(cat, last TP), prev)
+        const ggml_tensor * tv = nullptr, * tc = nullptr;
+        for (int i = pos_of(an, cat) + 1; i < pos; i++) {
+            const ggml_tensor * n = an.g->nodes[i];
+            if (n->op == GGML_OP_VIEW && n->src[0] == cat) tv = n;
+            if (n->op == GGML_OP_CPY && tv && n->src[0] == tv && n->src[1] == prev) tc = n;
+        }
+        if (!tv || !tc || uses_of(an, tv) != 1 || uses_of(an, tc) != 0) return false;
+        if (tv->ne[0] != TP || tv->ne[1] != Cin || (const char *) tv->data - (const char *) cat->data != (int64_t) (cat->ne[0] - TP) * 4) return false;
+        members.push_back(pos_of(an, cat)); members.push_back(pos_of(an, tv)); members.push_back(pos_of(an, tc));
+    }
+    if (xin->type != GGML_TYPE_F32 || xin->ne[1] != Cin || xin->ne[2] != 1 || xin->ne[3] != 1) return false;
+    int pre_elu = 0;
+    if (is_elu(xin) && uses_of(an, xin) == 1 && pos_of(an, xin) >= 0) { pre_elu = 1; members.push_back(pos_of(an, xin)); xin = xin->src[0]; }
+    if (!xin->data) return false;
+    // epilogue
+    const ggml_tensor * out = sole_consumer(an, mm);
+    if (!out || out->op != GGML_OP_RESHAPE || out->ne[2] != 1) return false;
+    members.push_back(pos_of(an, out));
+    const int64_t OL = out->ne[0], Cout = out->ne[1];
+    mm_epilogue epi = { nullptr, nullptr, 0, 0 };
+    const ggml_tensor * nx = sole_consumer(an, out);
+    if (nx && nx->op == GGML_OP_ADD && !nx->view_src && nx->src[0] == out && nx->src[1]->type == GGML_TYPE_F32 && nx->src[1]->ne[0] == 1 &&
+        nx->src[1]->ne[1] == Cout && ggml_nelements(nx->src[1]) == Cout && ggml_is_contiguous(nx->src[1])) {
+        epi.bias = (const float *) nx->src[1]->data;
+        out = nx; members.push_back(pos_of(an, out));
+        nx = sole_consumer(an, out);
+    }
+    if (nx && nx->op == GGML_OP_ADD && !nx->view_src && nx->src[1] == out && nx->src[0] != out && nx->src[0]->type == GGML_TYPE_F32 &&
+        ggml_are_same_shape(nx->src[0], out) && nx->src[0]->data) {
+        epi.residual = (const char *) nx->src[0]->data; epi.res_nb0 = (int64_t) nx->src[0]->nb[0]; epi.res_nb1 = (int64_t) nx->src[0]->nb[1];
+        out = nx; members.push_back(pos_of(an, out));
+    }
+    if (!ggml_is_contiguous(out) || !out->data || !im->data) return false;
+    for (int m : members) if (m < 0) return false;
+    tdesc d_im = make_tdesc(ra), d_w = make_tdesc(rw), d_x = make_tdesc(xin), d_out = make_tdesc(out);
+    d_out.ne[0] = OL; d_out.ne[1] = Cout; d_out.ne[2] = d_out.ne[3] = 1;
+    float * pv = prev ? (float *) prev->data : nullptr;
+    grp.steps.clear();
+    grp.steps.push_back([=](hipStream_t s) { k_stream_im2col(s, d_im, pv, TP, d_x, Kw, s0, pre_elu); });
+    if (TP > 0) grp.steps.push_back([=](hipStream_t s) { k_conv_tail(s, pv, TP, d_x, pre_elu); });
+    grp.steps.push_back([=](hipStream_t s) { k_mul_mat(s, d_out, d_im, d_w, nullptr, &epi); });
+    grp.members = members;
+    grp.emit_pos = pos_of(an, out);
+    return true;
+}
+
+// E. streaming conv_transpose_1d (conv.h:240-310): [elu] -> conv_transpose_1d -> add_inplace(view lower, view prev tail) -> view full
+//    -> cpy(., prev) [-> + bias] -> view(window) -> cont  becomes the partial products + one finishing kernel.
+static bool match_convtr(const analysis & an, int pos, step_group & grp, emitter & em) {
+    const ggml_tensor * ct = an.g->nodes[pos];
+    if (ct->op != GGML_OP_CONV_TRANSPOSE_1D || uses_of(an, ct) != 1) return false;
+    const ggml_tensor * w = ct->src[0], * xin = ct->src[1];
+    const int K = (int) w->ne[0], OC = (int) w->ne[1], s0 = ct->op_params[0], L = (int) xin->ne[0], PT = K - s0;
+    if (PT <= 0 || PT > L * s0 || xin->type != GGML_TYPE_F32 || !(w->type == GGML_TYPE_F16 || w->type == GGML_TYPE_F32)) return false;
+    if ((int64_t) w->nb[1] != (int64_t) w->nb[0] * K) return false;
+    const int64_t OLf = ct->ne[0];
+    std::vector<int> members = { pos };
+    const ggml_tensor * lower = sole_consumer(an, ct);
+    if (!lower || lower->op != GGML_OP_VIEW || lower->data != ct->data || lower->ne[0] != PT || lower->ne[1] != OC) return false;
+    const ggml_tensor * ai = sole_consumer(an, lower);
+    if (!ai || ai->op != GGML_OP_ADD || ai->src[0] != lower || ai->data != lower->data) return false;
+    const ggml_tensor * partial = ai->src[1];
+    if (partial->op != GGML_OP_VIEW || partial->src[0]->op != GGML_OP_NONE) return false;
+    const ggml_tensor * prev = partial->src[0];
+    if (prev->type != GGML_TYPE_F32 || !ggml_is_contiguous(prev) || prev->ne[0] != OLf || prev->ne[1] != OC || ggml_nelements(prev) != OLf * OC) return false;
+    if (partial->ne[0] != PT || partial->ne[1] != OC || (const char *) partial->data - (const char *) prev->data != (OLf - PT) * 4 || partial->nb[1] != prev->nb[1]) return false;
+    const ggml_tensor * full = sole_consumer(an, ai);
+    if (!full || full->op != GGML_OP_VIEW || full->data != ct->data || full->ne[0] != OLf || full->ne[1] != OC) return false;
+    const ggml_tensor * cp = sole_consumer(an, full);
+    if (!cp || cp->op != GGML_OP_CPY || cp->src[1] != prev) return false;
+    const ggml_tensor * cur = sole_consumer(an, cp);
+    const float * bias = nullptr;
+    members.insert(members.end(), { pos_of(an, lower), pos_of(an, partial), pos_of(an, ai), pos_of(an, full), pos_of(an, cp) });
+    if (cur && cur->op == GGML_OP_ADD && !cur->view_src && cur->src[0] == cp && cur->src[1]->type == GGML_TYPE_F32 && cur->src[1]->ne[0] == 1 &&
+        ggml_nelements(cur->src[1]) == OC && ggml_is_contiguous(cur->src[1])) {
+        bias = (const float *) cur->src[1]->data;
+        members.push_back(pos_of(an, cur));
+        cur = sole_consumer(an, cur);
+    }
+    if (!cur || cur->op != GGML_OP_VIEW || cur->ne[0] != OLf - PT || cur->ne[1] != OC || cur->data != cur->src[0]->data) return false;
+    const ggml_tensor * out = sole_consumer(an, cur);
+    if (!out || out->op != GGML_OP_CONT || !ggml_is_contiguous(out) || !out->data) return false;
+    members.push_back(pos_of(an, cur)); members.push_back(pos_of(an, out));
+    if (uses_of(an, partial) != 1) return false;
+    int pre_elu = 0;
+    if (is_elu(xin) && uses_of(an, xin) == 1 && pos_of(an, xin) >= 0) { pre_elu = 1; members.push_back(pos_of(an, xin)); xin = xin->src[0]; }
+    if (!xin->data) return false;
+    for (int m : members) if (m < 0) return false;
+    void * ws = em.ws(k_conv_transpose_1d_ws_size(w, xin));
+    const tdesc d_w = make_tdesc(w), d_x = make_tdesc(xin), d_out = make_tdesc(out);
+    float * pv = (float *) prev->data;
+    grp.steps.clear();
+    grp.steps.push_back([=](hipStream_t s) {
+        const int nsplit = k_conv_transpose_1d_partial(s, d_w, d_x, ws, pre_elu);
+        k_convtr_finish(s, d_out, pv, bias, ws, K, OC, L, s0, nsplit);
+    });
+    grp.members = members;
+    grp.emit_pos = pos_of(an, out);
+    return true;
+}
+
 // ---- plan construction --------------------------------------------------------------------------------------
 static plan_t * build_plan(hip_ctx * c, ggml_cgraph * g) {
     plan_t * p = new plan_t;
@@ -780,6 +922,20 @@ static plan_t * build_plan(hip_ctx * c, ggml_cgraph * g) {
             for (int m : grp.members) an.skip[(size_t) m] = 1;
             const attn_args a = grp.a;
             at_pos[grp.emit_pos].push_back([=](hipStream_t s) { k_attn_decode(s, a); });
+            p->n_fused += (int) grp.members.size();
+        }
+        // codec convolutions
+        for (int i = 0; i < g->n_nodes; i++) {
+            if (an.skip[(size_t) i]) continue;
+            step_group grp;
+            if (g->nodes[i]->op == GGML_OP_MUL_MAT) { if (!match_conv(an, i, grp)) continue; }
+            else if (g->nodes[i]->op == GGML_OP_CONV_TRANSPOSE_1D) { if (!match_convtr(an, i, grp, em)) continue; }
+            else continue;
+            bool clash = false;
+            for (int m : grp.members) if (an.skip[(size_t) m]) clash = true;
+            if (clash) continue;
+            for (int m : grp.members) an.skip[(size_t) m] = 1;
+            for (auto & f : grp.steps) at_pos[grp.emit_pos].push_back(f);
             p->n_fused += (int) grp.members.size();
         }
         // embedding sums

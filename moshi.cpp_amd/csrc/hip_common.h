@@ -53,7 +53,16 @@ void k_timestep_embedding(hipStream_t s, tdesc dst, tdesc ts, int dim, int max_p
 // generic matrix product: activation rows are first converted to the weight type's dot type
 // (q8_K / q8_0 / f16 / bf16) into `ws` (size from k_mul_mat_ws_size), then dotted
 size_t k_mul_mat_ws_size(const struct ggml_tensor * a, const struct ggml_tensor * b);
-void k_mul_mat(hipStream_t s, tdesc dst, tdesc a, tdesc b, void * ws);
+// optional fused epilogue of the dense product: dst[m, n] = residual[m, n] + (dot + bias[n])  (ggml order: add(y, bias) then add(u, y))
+struct mm_epilogue { const float * bias; const char * residual; int64_t res_nb0, res_nb1; };
+void k_mul_mat(hipStream_t s, tdesc dst, tdesc a, tdesc b, void * ws, const mm_epilogue * epi = nullptr);
+// streaming conv1d helpers (moshi_streaming_conv_1d, conv.h:50-96): F16 im2col straight from (carried tail, new samples) with an
+// optional ELU on the new samples, and the tail update
+void k_stream_im2col(hipStream_t s, tdesc dst, const float * prev, int TP, tdesc x, int Kw, int s0, int pre_elu);
+void k_conv_tail(hipStream_t s, float * prev, int TP, tdesc x, int pre_elu);
+// streaming conv_transpose_1d tail (conv.h:282-309): overlap-add with the carried partial, state update, bias, window
+void k_convtr_finish(hipStream_t s, tdesc out, float * prev, const float * bias, const void * ws, int K, int OC, int L, int s0, int nsplit);
+int  k_conv_transpose_1d_partial(hipStream_t s, tdesc w, tdesc x, void * ws, int pre_elu);   // returns the number of ic splits written to ws
 // scatter of batched small uploads: descs/blob live in pinned host memory mapped into the device
 struct upload_desc { char * dst; uint32_t offset; uint32_t size; };
 void k_scatter_uploads(hipStream_t s, const upload_desc * descs, const char * blob, int n);
@@ -74,6 +83,7 @@ struct mv_args {
     float       eps;
     int         ncols;          // activation columns (1 for quantised weights, <= MV_MAX_COLS otherwise)
     int64_t     x_cs, y_cs, r_cs;   // column strides of x / y / residual in floats
+    int         out_act;        // 0 none, 1 gelu (ggml's F16-table gelu) applied to W x first
     const float * out_scale;    // optional per-row scale applied to W x before the residual (layer_scale)
     const float * residual;     // optional, [M, ncols]
     float *     y;              // [M, ncols]

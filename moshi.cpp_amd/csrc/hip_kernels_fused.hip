@@ -254,42 +254,61 @@ __global__ void __launch_bounds__(NW * 64) matvec_q4k_kernel(mv_args a, int rows
 // ---------------------------------------------------------------------------------------------------
 // float-weight mat-vec (F32 / F16 / BF16 weights; 1..MV_MAX_COLS activation columns)
 // ---------------------------------------------------------------------------------------------------
-__device__ __forceinline__ double block_sum4_f64(double v, double * sh) {
-    v = wave_sum_f64(v);
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
-    __syncthreads();
-    return sh[0] + sh[1] + sh[2] + sh[3];
-}
-
 // y[:, c] = (W x[:, c]) (* out_scale) (+ residual[:, c]) for up to MV_MAX_COLS activation columns; the weights are
 // streamed once (16 B per lane), the prologue (rms / layer norm, silu gate, gelu) is applied while staging x in LDS
 template <int WT>
 __global__ void __launch_bounds__(256) matvec_f_kernel(mv_args a, int rows_per_wave) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    __shared__ double sh_red[4];
     float * xs = (float *) smem;   // [ncols][K]
+    __shared__ double sh_cols[4][MV_MAX_COLS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int K = (int) a.K, nc = a.ncols;
-    for (int c = 0; c < nc; c++) {
-        const float * x = a.x + (int64_t) c * a.x_cs;
-        float mean = 0.f, scale = 1.f;
-        if (a.prologue == MV_RMSNORM || a.prologue == MV_LAYERNORM) {
-            if (a.prologue == MV_LAYERNORM) {
-                double acc = 0;
-                for (int i = tid; i < K; i += 256) acc += (double) x[i];
-                mean = (float) (block_sum4_f64(acc, sh_red) / (double) K);
+    float mean[MV_MAX_COLS], scale[MV_MAX_COLS];
+#pragma unroll
+    for (int c = 0; c < MV_MAX_COLS; c++) { mean[c] = 0.f; scale[c] = 1.f; }
+    if (a.prologue == MV_RMSNORM || a.prologue == MV_LAYERNORM) {
+        // statistics of all columns in one reduction each (double accumulators, wave all-reduce on the DPP path)
+        auto block_sum_cols = [&](double v[MV_MAX_COLS]) {
+#pragma unroll
+            for (int c = 0; c < MV_MAX_COLS; c++) if (c < nc) v[c] = wave_allsum_f64(v[c]);
+            __syncthreads();
+            if (lane == 0) {
+#pragma unroll
+                for (int c = 0; c < MV_MAX_COLS; c++) sh_cols[wave][c] = v[c];
             }
-            double acc2 = 0;
-            for (int i = tid; i < K; i += 256) { const float v = x[i] - mean; acc2 += (double) (v * v); }
-            const float var = (float) (block_sum4_f64(acc2, sh_red) / (double) K);
-            scale = 1.0f / sqrtf(var + a.eps);
+            __syncthreads();
+#pragma unroll
+            for (int c = 0; c < MV_MAX_COLS; c++) v[c] = sh_cols[0][c] + sh_cols[1][c] + sh_cols[2][c] + sh_cols[3][c];
+        };
+        double acc[MV_MAX_COLS];
+        if (a.prologue == MV_LAYERNORM) {
+#pragma unroll
+            for (int c = 0; c < MV_MAX_COLS; c++) acc[c] = 0;
+            for (int i = tid; i < K; i += 256)
+#pragma unroll
+                for (int c = 0; c < MV_MAX_COLS; c++) if (c < nc) acc[c] += (double) a.x[(int64_t) c * a.x_cs + i];
+            block_sum_cols(acc);
+#pragma unroll
+            for (int c = 0; c < MV_MAX_COLS; c++) mean[c] = (float) (acc[c] / (double) K);
         }
+#pragma unroll
+        for (int c = 0; c < MV_MAX_COLS; c++) acc[c] = 0;
+        for (int i = tid; i < K; i += 256)
+#pragma unroll
+            for (int c = 0; c < MV_MAX_COLS; c++) if (c < nc) { const float v = a.x[(int64_t) c * a.x_cs + i] - mean[c]; acc[c] += (double) (v * v); }
+        block_sum_cols(acc);
+#pragma unroll
+        for (int c = 0; c < MV_MAX_COLS; c++) scale[c] = 1.0f / sqrtf((float) (acc[c] / (double) K) + a.eps);
+    }
+#pragma unroll
+    for (int c = 0; c < MV_MAX_COLS; c++) {
+        if (c >= nc) break;
+        const float * x = a.x + (int64_t) c * a.x_cs;
         for (int i = tid; i < K; i += 256) {
             float v;
             switch (a.prologue) {
-                case MV_RMSNORM:   v = a.alpha[i] * (x[i] * scale); break;
-                case MV_LAYERNORM: v = ((x[i] - mean) * scale) * a.alpha[i]; if (a.beta) v = v + a.beta[i]; break;
+                case MV_RMSNORM:   v = a.alpha[i] * (x[i] * scale[c]); break;
+                case MV_LAYERNORM: v = ((x[i] - mean[c]) * scale[c]) * a.alpha[i]; if (a.beta) v = v + a.beta[i]; break;
                 case MV_GATE_SILU: { const float l = x[i], r = x[K + i]; v = (l / (1.0f + expf(-l))) * r; } break;
                 case MV_GELU:      v = gelu_table(x[i]); break;
                 default:           v = x[i]; break;
@@ -336,9 +355,10 @@ __global__ void __launch_bounds__(256) matvec_f_kernel(mv_args a, int rows_per_w
 #pragma unroll
         for (int c = 0; c < MV_MAX_COLS; c++) {
             if (c < nc) {
-                const double tot = wave_sum_f64(acc[c]);
+                const double tot = wave_allsum_f64(acc[c]);
                 if (lane == 0) {
                     float sres = (float) tot;
+                    if (a.out_act == 1) sres = gelu_table(sres);
                     if (a.out_scale) sres = sres * a.out_scale[row];
                     a.y[(int64_t) c * a.y_cs + row] = a.residual ? a.residual[(int64_t) c * a.r_cs + row] + sres : sres;
                 }

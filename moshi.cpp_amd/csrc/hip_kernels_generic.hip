@@ -372,7 +372,7 @@ void k_im2col(hipStream_t s, tdesc dst, tdesc x, int64_t K, int s0, int p0, int 
 //  A. P[s][l][n] = sum over the s-th slice of ic of x[l, ic] * w[ic][n], n = oc*K + k (w's memory order), double partials
 //  B. y[t, oc] = sum over l ascending of (float) sum_s P[s][l][oc*K + (t - l*s0)]  — the CPU reference's accumulation order
 #define CT_LT 8
-__global__ void convtr_partial_kernel(tdesc w, tdesc x, double * P, int N, int L, int IC, int ic_per_split) {
+__global__ void convtr_partial_kernel(tdesc w, tdesc x, double * P, int N, int L, int IC, int ic_per_split, int pre_elu) {
     const int n = blockIdx.x * blockDim.x + threadIdx.x;
     const int l0 = blockIdx.y * CT_LT;
     const int split = blockIdx.z;
@@ -391,6 +391,7 @@ __global__ void convtr_partial_kernel(tdesc w, tdesc x, double * P, int N, int L
             const int l = l0 + i;
             if (l < L) {
                 float xv = *(const float *) (x.data + (int64_t) l * x.nb[0] + (int64_t) ic * x.nb[1]);
+                if (pre_elu) xv = xv > 0.f ? xv : expm1f(xv);
                 if (f16) xv = h2f(f2h(xv));
                 acc[i] += (double) (xv * wv);
             }
@@ -418,7 +419,7 @@ __global__ void convtr_overlap_add_kernel(tdesc dst, const double * P, int N, in
 size_t k_conv_transpose_1d_ws_size(const struct ggml_tensor * w, const struct ggml_tensor * x) {
     return (size_t) 16 * (size_t) x->ne[0] * (size_t) (w->ne[0] * w->ne[1]) * 8 + 256;
 }
-void k_conv_transpose_1d(hipStream_t s, tdesc dst, tdesc w, tdesc x, int s0, void * ws) {
+int k_conv_transpose_1d_partial(hipStream_t s, tdesc w, tdesc x, void * ws, int pre_elu) {
     GGML_ASSERT(x.type == GGML_TYPE_F32 && (w.type == GGML_TYPE_F32 || w.type == GGML_TYPE_F16));
     const int K = (int) w.ne[0], OC = (int) w.ne[1], IC = (int) w.ne[2], L = (int) x.ne[0];
     GGML_ASSERT(w.nb[1] == w.nb[0] * K && "kernel taps and output channels must be contiguous");
@@ -429,9 +430,90 @@ void k_conv_transpose_1d(hipStream_t s, tdesc dst, tdesc w, tdesc x, int s0, voi
     if (nsplit > IC / 32) nsplit = IC / 32;
     if (nsplit < 1) nsplit = 1;
     const int per = (IC + nsplit - 1) / nsplit;
-    convtr_partial_kernel<<<dim3(nb, lt, nsplit), 256, 0, s>>>(w, x, (double *) ws, N, L, IC, per);
+    convtr_partial_kernel<<<dim3(nb, lt, nsplit), 256, 0, s>>>(w, x, (double *) ws, N, L, IC, per, pre_elu);
+    return nsplit;
+}
+void k_conv_transpose_1d(hipStream_t s, tdesc dst, tdesc w, tdesc x, int s0, void * ws) {
+    const int nsplit = k_conv_transpose_1d_partial(s, w, x, ws, 0);
+    const int K = (int) w.ne[0], OC = (int) w.ne[1], L = (int) x.ne[0];
     const int64_t n_out = dst.ne[0] * dst.ne[1];
-    convtr_overlap_add_kernel<<<nblocks(n_out), BLOCK, 0, s>>>(dst, (const double *) ws, N, L, K, s0, nsplit, n_out);
+    convtr_overlap_add_kernel<<<nblocks(n_out), BLOCK, 0, s>>>(dst, (const double *) ws, OC * K, L, K, s0, nsplit, n_out);
+}
+
+// streaming tail of conv_transpose_1d: y = convtr(x); y[:PT] += prev[-PT:]; prev = y; out = (y + bias)[: len - PT]
+// (moshi_streaming_conv_transpose_1d, conv.h:282-309). Thread t (< L*s0) also owns position t + L*s0 when t < PT, so the old
+// tail value it needs is read before the same thread overwrites it.
+__global__ void convtr_finish_kernel(tdesc out, float * prev, const float * bias, const double * P, int K, int OC, int L, int s0, int nsplit) {
+    const int N = OC * K, OLf = (L - 1) * s0 + K, PT = K - s0, keep = OLf - PT;   // keep == L * s0
+    const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t) keep * OC) return;
+    const int t = (int) (i % keep), oc = (int) (i / keep);
+    auto conv_at = [&](int tt) {
+        float acc = 0.f;
+        int l0 = (tt - (K - 1) + s0 - 1) / s0;
+        if (l0 < 0) l0 = 0;
+        for (int l = l0; l < L && l * s0 <= tt; l++) {
+            const int k = tt - l * s0;
+            if (k >= K) continue;
+            double v = 0;
+            for (int sp = 0; sp < nsplit; sp++) v += P[((int64_t) sp * L + l) * N + oc * K + k];
+            acc += (float) v;
+        }
+        return acc;
+    };
+    float * pv = prev + (int64_t) oc * OLf;
+    float y = conv_at(t);
+    float y2 = 0.f;
+    const bool has2 = t < PT;               // position t + keep lies in the carried tail
+    if (has2) { y = y + pv[keep + t]; y2 = conv_at(t + keep); }
+    pv[t] = y;
+    if (has2) pv[t + keep] = y2;
+    *(float *) at(out, t, oc, 0, 0) = bias ? y + bias[oc] : y;
+}
+void k_convtr_finish(hipStream_t s, tdesc out, float * prev, const float * bias, const void * ws, int K, int OC, int L, int s0, int nsplit) {
+    GGML_ASSERT(K - s0 <= L * s0 && "tail longer than the new window is not expected on this path");
+    const int64_t n = (int64_t) L * s0 * OC;
+    convtr_finish_kernel<<<nblocks(n), BLOCK, 0, s>>>(out, prev, bias, (const double *) ws, K, OC, L, s0, nsplit);
+}
+
+// F16 im2col of concat(prev, act(x)) without materialising the concat: dst[ci*Kw + k, ol] = xc[ol*s0 + k, ci]
+__global__ void stream_im2col_kernel(tdesc dst, const float * prev, int TP, tdesc x, int Kw, int s0, int pre_elu, int64_t n) {
+    const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t CK = (uint32_t) dst.ne[0];
+    const uint32_t ol = (uint32_t) i / CK, c = (uint32_t) i - ol * CK;
+    const uint32_t ci = c / (uint32_t) Kw, k = c - ci * (uint32_t) Kw;
+    const int l = (int) (ol * (uint32_t) s0 + k);
+    float v;
+    if (l < TP) v = prev[l + (int64_t) ci * TP];
+    else { v = *(const float *) (x.data + (int64_t) (l - TP) * x.nb[0] + (int64_t) ci * x.nb[1]); if (pre_elu) v = v > 0.f ? v : expm1f(v); }
+    ((uint16_t *) dst.data)[i] = f2h(v);
+}
+void k_stream_im2col(hipStream_t s, tdesc dst, const float * prev, int TP, tdesc x, int Kw, int s0, int pre_elu) {
+    const int64_t n = dst.ne[0] * dst.ne[1];
+    GGML_ASSERT(dst.type == GGML_TYPE_F16 && x.type == GGML_TYPE_F32 && dst.nb[1] == dst.ne[0] * 2);
+    if (n) stream_im2col_kernel<<<nblocks(n), BLOCK, 0, s>>>(dst, prev, TP, x, Kw, s0, pre_elu, n);
+}
+// prev <- last TP samples of concat(prev, act(x)), one thread per channel (reads complete before its writes)
+__global__ void conv_tail_kernel(float * prev, int TP, tdesc x, int pre_elu) {
+    const int ci = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ci >= (int) x.ne[1]) return;
+    const int L = (int) x.ne[0];
+    float v[32];
+#pragma unroll
+    for (int j = 0; j < 32; j++) {
+        if (j < TP) {
+            const int l = L + j;   // index into the concatenation
+            if (l < TP) v[j] = prev[l + (int64_t) ci * TP];
+            else { float t = *(const float *) (x.data + (int64_t) (l - TP) * x.nb[0] + (int64_t) ci * x.nb[1]); v[j] = pre_elu ? (t > 0.f ? t : expm1f(t)) : t; }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 32; j++) if (j < TP) prev[j + (int64_t) ci * TP] = v[j];
+}
+void k_conv_tail(hipStream_t s, float * prev, int TP, tdesc x, int pre_elu) {
+    GGML_ASSERT(TP <= 32);
+    if (TP > 0) conv_tail_kernel<<<(int) ((x.ne[1] + 63) / 64), 64, 0, s>>>(prev, TP, x, pre_elu);
 }
 
 __global__ void timestep_embedding_kernel(tdesc dst, tdesc ts, int dim, int max_period) {
@@ -538,7 +620,7 @@ __global__ void convert_rows_kernel(tdesc b, int vt, char * ws, int64_t row_byte
 }
 
 // one wave per output element; lanes stride the K dimension (in blocks for quantised types)
-__global__ void mul_mat_kernel(tdesc dst, tdesc a, tdesc b, const char * ws, int64_t ws_row_bytes, int vt, int64_t total) {
+__global__ void mul_mat_kernel(tdesc dst, tdesc a, tdesc b, const char * ws, int64_t ws_row_bytes, int vt, int64_t total, mm_epilogue epi) {
     const int lane = threadIdx.x & 63;
     const int64_t o = (int64_t) blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (o >= total) return;
@@ -584,7 +666,11 @@ __global__ void mul_mat_kernel(tdesc dst, tdesc a, tdesc b, const char * ws, int
         }
         result = wave_sum_f32(acc);
     }
-    if (lane == 0) *(float *) at(dst, m, n, i2, i3) = result;
+    if (lane == 0) {
+        if (epi.bias) result = result + epi.bias[n];
+        if (epi.residual) result = *(const float *) (epi.residual + m * epi.res_nb0 + n * epi.res_nb1) + result;
+        *(float *) at(dst, m, n, i2, i3) = result;
+    }
 }
 
 // ---- dense f16 x f16 contraction on the matrix cores (Mimi conv stacks: dst[ow, co] = sum_k A[ow][k] * B[co][k]) ----
@@ -592,7 +678,7 @@ __global__ void mul_mat_kernel(tdesc dst, tdesc a, tdesc b, const char * ws, int
 // of row (l & 15), so fragments are plain 16-byte global loads - no LDS, one wave per 16x16 output tile.
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-__global__ void __launch_bounds__(256) mul_mat_f16_mfma_kernel(tdesc dst, tdesc a, tdesc b, int mt, int nt) {
+__global__ void __launch_bounds__(256) mul_mat_f16_mfma_kernel(tdesc dst, tdesc a, tdesc b, int mt, int nt, mm_epilogue epi) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int tile = blockIdx.x * 4 + wave;
     if (tile >= mt * nt) return;
@@ -609,11 +695,17 @@ __global__ void __launch_bounds__(256) mul_mat_f16_mfma_kernel(tdesc dst, tdesc 
     }
     // C[row = 4*(lane>>4) + j][col = lane & 15]: rows are `a` rows (dst dim 0), cols are `b` rows (dst dim 1)
     float * out = (float *) (dst.data + (int64_t) (tn * 16 + r) * dst.nb[1]) + tm * 16 + kq * 4;
+    if (epi.bias) { const float bv = epi.bias[tn * 16 + r]; acc[0] = acc[0] + bv; acc[1] = acc[1] + bv; acc[2] = acc[2] + bv; acc[3] = acc[3] + bv; }
+    if (epi.residual) {
+        const char * rp = epi.residual + (int64_t) (tn * 16 + r) * epi.res_nb1 + (int64_t) (tm * 16 + kq * 4) * epi.res_nb0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[j] = *(const float *) (rp + (int64_t) j * epi.res_nb0) + acc[j];
+    }
     *(f32x4 *) out = acc;
 }
 
 // few activation rows (M = a.ne1 <= 8) against many weight rows in `b`: one wave per b row, b read once
-__global__ void __launch_bounds__(256) mul_mat_smallm_kernel(tdesc dst, tdesc a, tdesc b, int M, int N) {
+__global__ void __launch_bounds__(256) mul_mat_smallm_kernel(tdesc dst, tdesc a, tdesc b, int M, int N, mm_epilogue epi) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int n = blockIdx.x * 4 + wave;
     if (n >= N) return;
@@ -637,21 +729,28 @@ __global__ void __launch_bounds__(256) mul_mat_smallm_kernel(tdesc dst, tdesc a,
     for (int m = 0; m < 8; m++) {
         if (m < M) {
             const double v = wave_sum_f64(acc[m]);
-            if (lane == 0) *(float *) (dst.data + (int64_t) m * dst.nb[0] + (int64_t) n * dst.nb[1]) = (float) v;
+            if (lane == 0) {
+                float r = (float) v;
+                if (epi.bias) r = r + epi.bias[n];
+                if (epi.residual) r = *(const float *) (epi.residual + (int64_t) m * epi.res_nb0 + (int64_t) n * epi.res_nb1) + r;
+                *(float *) (dst.data + (int64_t) m * dst.nb[0] + (int64_t) n * dst.nb[1]) = r;
+            }
         }
     }
 }
 
-void k_mul_mat(hipStream_t s, tdesc dst, tdesc a, tdesc b, void * ws) {
+void k_mul_mat(hipStream_t s, tdesc dst, tdesc a, tdesc b, void * ws, const mm_epilogue * epi_) {
     const int64_t total = td_nelements(dst);
     if (total == 0) return;
+    mm_epilogue epi = { nullptr, nullptr, 0, 0 };
+    if (epi_) epi = *epi_;
     if (a.type == GGML_TYPE_F16 && b.type == GGML_TYPE_F16 && a.nb[0] == 2 && b.nb[0] == 2 && a.ne[2] * a.ne[3] * b.ne[2] * b.ne[3] == 1 &&
         dst.nb[0] == 4 && a.ne[0] % 8 == 0 && (a.nb[1] % 16) == 0 && (b.nb[1] % 16) == 0 && ((uintptr_t) a.data % 16) == 0 && ((uintptr_t) b.data % 16) == 0) {
         const int M = (int) a.ne[1], N = (int) b.ne[1];
-        if (M <= 8) { mul_mat_smallm_kernel<<<(N + 3) / 4, 256, 0, s>>>(dst, a, b, M, N); return; }
+        if (M <= 8) { mul_mat_smallm_kernel<<<(N + 3) / 4, 256, 0, s>>>(dst, a, b, M, N, epi); return; }
         if (M % 16 == 0 && N % 16 == 0 && a.ne[0] % 32 == 0 && (dst.nb[1] % 16) == 0 && ((uintptr_t) dst.data % 16) == 0) {
             const int mt = M / 16, nt = N / 16;
-            mul_mat_f16_mfma_kernel<<<(mt * nt + 3) / 4, 256, 0, s>>>(dst, a, b, mt, nt);
+            mul_mat_f16_mfma_kernel<<<(mt * nt + 3) / 4, 256, 0, s>>>(dst, a, b, mt, nt, epi);
             return;
         }
     }
@@ -667,7 +766,7 @@ void k_mul_mat(hipStream_t s, tdesc dst, tdesc a, tdesc b, void * ws) {
                         b.nb[2] == row_bytes * b.ne[1] && b.nb[3] == b.nb[2] * b.ne[2];
     if (direct) y = b.data;
     else convert_rows_kernel<<<(int) rows, BLOCK, 0, s>>>(b, vt, (char *) ws, row_bytes);
-    mul_mat_kernel<<<nblocks(total, 4), 256, 0, s>>>(dst, a, b, y, row_bytes, vt, total);
+    mul_mat_kernel<<<nblocks(total, 4), 256, 0, s>>>(dst, a, b, y, row_bytes, vt, total, epi);
 }
 
 // ---------------------------------------------------------------------------------------------------
