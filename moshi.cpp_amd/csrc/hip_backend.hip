@@ -819,7 +819,7 @@ static bool match_conv(const analysis & an, int pos, step_group & grp) {
     const int64_t OL = out->ne[0], Cout = out->ne[1];
     mm_epilogue epi = { nullptr, nullptr, 0, 0 };
     const ggml_tensor * nx = sole_consumer(an, out);
-    if (nx && nx->op == GGML_OP_ADD && !nx->view_src && nx->src[0] == out && nx->src[1]->type == GGML_TYPE_F32 && nx->src[1]->ne[0] == 1 &&
+    if (nx && nx->op == GGML_OP_ADD && !nx->view_src && nx->src[0] == out && nx->src[1]->op == GGML_OP_NONE && nx->src[1]->type == GGML_TYPE_F32 && nx->src[1]->ne[0] == 1 &&
         nx->src[1]->ne[1] == Cout && ggml_nelements(nx->src[1]) == Cout && ggml_is_contiguous(nx->src[1])) {
         epi.bias = (const float *) nx->src[1]->data;
         out = nx; members.push_back(pos_of(an, out));
@@ -899,6 +899,99 @@ static bool match_convtr(const analysis & an, int pos, step_group & grp, emitter
     return true;
 }
 
+// F. one level of the residual-VQ encoder (core_vq.h:27-56 + 171-194): the whole distance / argmax / gather / residual chain
+static const ggml_tensor * find_consumer(const analysis & an, const ggml_tensor * t, enum ggml_op op, int nth = 0) {
+    for (int i = pos_of(an, t) + 1; i < an.g->n_nodes; i++) {
+        const ggml_tensor * n = an.g->nodes[i];
+        if (n->op != op) continue;
+        bool uses = false;
+        for (int s = 0; s < GGML_MAX_SRC; s++) if (n->src[s] == t && n != t) uses = true;
+        if (uses && nth-- == 0) return n;
+    }
+    return nullptr;
+}
+
+static bool match_vq_level(const analysis & an, int pos, step_group & grp, emitter & em) {
+    const ggml_tensor * am = an.g->nodes[pos];
+    if (am->op != GGML_OP_ARGMAX || ggml_nelements(am) != 1) return false;
+    auto one_use = [&](const ggml_tensor * t, enum ggml_op op) { return t && t->op == op && !t->view_src && uses_of(an, t) == 1; };
+    const ggml_tensor * dv = am->src[0];
+    if (!one_use(dv, GGML_OP_DIV)) return false;
+    const ggml_tensor * num = dv->src[0], * ad = dv->src[1];
+    if (!one_use(ad, GGML_OP_ADD)) return false;
+    const ggml_tensor * rs = ad->src[0], * addc = ad->src[1];
+    if (rs->op != GGML_OP_RESHAPE || uses_of(an, rs) != 1) return false;
+    const ggml_tensor * sr = rs->src[0];
+    if (!one_use(sr, GGML_OP_SUM_ROWS)) return false;
+    const ggml_tensor * sq = sr->src[0];
+    if (!one_use(sq, GGML_OP_MUL) || sq->src[0] != sq->src[1]) return false;
+    const ggml_tensor * df = sq->src[0];
+    if (!one_use(df, GGML_OP_SUB)) return false;
+    const ggml_tensor * rb = df->src[0], * ra2 = df->src[1];
+    if (!one_use(rb, GGML_OP_REPEAT) || ra2->op != GGML_OP_RESHAPE || uses_of(an, ra2) != 1) return false;
+    const ggml_tensor * emb = rb->src[0], * ra = ra2->src[0];
+    if (!one_use(ra, GGML_OP_REPEAT)) return false;
+    const ggml_tensor * ra0 = ra->src[0];
+    if (ra0->op != GGML_OP_RESHAPE || uses_of(an, ra0) != 1) return false;
+    const ggml_tensor * ac = ra0->src[0];
+    if (!one_use(ac, GGML_OP_CONT)) return false;
+    const ggml_tensor * xp = ac->src[0];
+    if (xp->op != GGML_OP_PERMUTE || uses_of(an, xp) != 1) return false;
+    const ggml_tensor * resid = xp->src[0];
+    const int64_t D = emb->ne[0], NC = emb->ne[1];
+    if (emb->op != GGML_OP_NONE || emb->type != GGML_TYPE_F32 || !dense_rows(emb) || D != 256 || NC > 4096) return false;
+    if (resid->type != GGML_TYPE_F32 || resid->ne[0] != 1 || resid->ne[1] != D || ggml_nelements(resid) != D || !resid->data) return false;
+    if (ggml_nelements(rb) != D * NC || ggml_nelements(ra) != D * NC || ggml_nelements(dv) != NC) return false;
+    if (num->op != GGML_OP_NONE || num->type != GGML_TYPE_F32 || ggml_nelements(num) != NC || !ggml_is_contiguous(num)) return false;
+    if (addc->op != GGML_OP_NONE || addc->type != GGML_TYPE_F32 || ggml_nelements(addc) != 1) return false;
+    std::vector<int> members = { pos, pos_of(an, dv), pos_of(an, ad), pos_of(an, rs), pos_of(an, sr), pos_of(an, sq), pos_of(an, df), pos_of(an, rb),
+                                 pos_of(an, ra2), pos_of(an, ra), pos_of(an, ra0), pos_of(an, ac), pos_of(an, xp) };
+    // consumers of the code: the F32 cast (always) and the centroid gather feeding the next residual (all but the last level)
+    const ggml_tensor * cs = find_consumer(an, am, GGML_OP_CPY);
+    if (!cs || cs->type != GGML_TYPE_F32 || cs->src[0] != am || cs->view_src) return false;
+    members.push_back(pos_of(an, cs));
+    int last = pos_of(an, cs);
+    float * resid_out = nullptr;
+    const ggml_tensor * ci = find_consumer(an, am, GGML_OP_CONT);
+    if (ci) {
+        if (uses_of(an, am) != 2 || uses_of(an, ci) != 1) return false;
+        const ggml_tensor * gr = sole_consumer(an, ci);
+        if (!one_use(gr, GGML_OP_GET_ROWS) || gr->src[0] != emb || gr->src[1] != ci) return false;
+        const ggml_tensor * pm = sole_consumer(an, gr);
+        if (!pm || pm->op != GGML_OP_PERMUTE || uses_of(an, pm) != 1) return false;
+        const ggml_tensor * qc = sole_consumer(an, pm);
+        if (!one_use(qc, GGML_OP_CONT)) return false;
+        const ggml_tensor * sb = sole_consumer(an, qc);
+        if (!sb || sb->op != GGML_OP_SUB || sb->view_src || sb->src[0] != resid || sb->src[1] != qc || !ggml_is_contiguous(sb) || !sb->data) return false;
+        if (uses_of(an, resid) != 2) return false;
+        resid_out = (float *) sb->data;
+        for (const ggml_tensor * t : { ci, gr, pm, qc, sb }) members.push_back(pos_of(an, t));
+        if (pos_of(an, sb) > last) last = pos_of(an, sb);
+    } else if (uses_of(an, am) != 1) return false;
+    for (int m : members) if (m < 0) return false;
+    // nothing outside the group may read a group output before the group is emitted
+    for (int i = pos + 1; i <= last; i++) {
+        const ggml_tensor * n = an.g->nodes[i];
+        bool member = false;
+        for (int m : members) if (m == i) member = true;
+        if (member) continue;
+        for (int s = 0; s < GGML_MAX_SRC; s++) if (n->src[s] == cs || n->src[s] == am) return false;
+    }
+    char * ws = (char *) em.ws(VQ_LEVEL_WS_BYTES);
+    HIP_CHECK(hipMemset(ws, 0, VQ_LEVEL_WS_BYTES));
+    vq_level_args a;
+    a.emb = (const char *) emb->data; a.emb_row_bytes = (int64_t) emb->nb[1]; a.D = (int) D; a.NC = (int) NC;
+    a.resid = (const char *) resid->data; a.resid_stride = (int64_t) resid->nb[1];
+    a.add_c = (const float *) addc->data; a.num = (const float *) num->data;
+    a.resid_out = resid_out; a.idx_f = (float *) cs->data; a.idx_i = (int32_t *) am->data;
+    a.cand_val = (float *) ws; a.cand_idx = (int32_t *) (ws + 1024); a.counter = (unsigned *) (ws + 2048);
+    grp.steps.clear();
+    grp.steps.push_back([=](hipStream_t s) { k_vq_level(s, a); });
+    grp.members = members;
+    grp.emit_pos = last;
+    return true;
+}
+
 // ---- plan construction --------------------------------------------------------------------------------------
 static plan_t * build_plan(hip_ctx * c, ggml_cgraph * g) {
     plan_t * p = new plan_t;
@@ -930,6 +1023,7 @@ static plan_t * build_plan(hip_ctx * c, ggml_cgraph * g) {
             step_group grp;
             if (g->nodes[i]->op == GGML_OP_MUL_MAT) { if (!match_conv(an, i, grp)) continue; }
             else if (g->nodes[i]->op == GGML_OP_CONV_TRANSPOSE_1D) { if (!match_convtr(an, i, grp, em)) continue; }
+            else if (g->nodes[i]->op == GGML_OP_ARGMAX) { if (!match_vq_level(an, i, grp, em)) continue; }
             else continue;
             bool clash = false;
             for (int m : grp.members) if (an.skip[(size_t) m]) clash = true;
@@ -973,7 +1067,16 @@ static plan_t * build_plan(hip_ctx * c, ggml_cgraph * g) {
             if (grp.members.size() > 1) p->n_fused += (int) grp.members.size();
         }
     }
+    const bool dump = getenv("MI355X_DUMP_PLAN") != nullptr;
     for (int i = 0; i < g->n_nodes; i++) {
+        if (dump) {
+            const ggml_tensor * n = g->nodes[i];
+            const bool layout = n->op == GGML_OP_VIEW || n->op == GGML_OP_RESHAPE || n->op == GGML_OP_PERMUTE || n->op == GGML_OP_TRANSPOSE;
+            auto itd = at_pos.find(i);
+            if (!layout || itd != at_pos.end())
+                fprintf(stderr, "plan %4d %-18s [%5lld %5lld %4lld %2lld] %s%s%s\n", i, ggml_op_name(n->op), (long long) n->ne[0], (long long) n->ne[1], (long long) n->ne[2],
+                        (long long) n->ne[3], an.skip[(size_t) i] ? "fused" : (layout ? "-" : "GENERIC"), itd != at_pos.end() ? " <emit group>" : "", n->view_src ? " (alias)" : "");
+        }
         if (!an.skip[(size_t) i]) emit_generic(em, g->nodes[i]);
         auto it = at_pos.find(i);
         if (it != at_pos.end()) for (auto & f : it->second) p->steps.push_back(f);

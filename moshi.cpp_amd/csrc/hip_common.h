@@ -124,3 +124,13 @@ struct embed_src { const char * table; int64_t row_bytes; int64_t n_rows; int ty
 #define EMBED_SUM_MAX 24
 struct embed_sum_args { embed_src src[EMBED_SUM_MAX]; int n; int64_t K; float * out; };
 void k_embed_sum(hipStream_t s, const embed_sum_args & a);
+// one residual-VQ encode level (core_vq.h:27-56, 171-194): nearest centroid of `resid`, its index, and resid - centroid
+struct vq_level_args {
+    const char * emb; int64_t emb_row_bytes; int D, NC;      // F32 codebook [D, NC]
+    const char * resid; int64_t resid_stride;                // element j at resid + j * resid_stride
+    const float * add_c; const float * num;                  // score = num[c] / (dist + add_c[0])
+    float * resid_out; float * idx_f; int32_t * idx_i;        // resid_out may be NULL (last level)
+    float * cand_val; int32_t * cand_idx; unsigned * counter; // workspace: one candidate per workgroup + arrival counter (zeroed once)
+};
+#define VQ_LEVEL_WS_BYTES 4096
+void k_vq_level(hipStream_t s, const vq_level_args & a);

@@ -59,6 +59,7 @@ __device__ float block_rms_scale(const float * x, int64_t K, float eps, double *
 #define TILE_BYTES 9216  // 64 super-blocks of 144 B = 9 wave-wide 16-byte loads
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // diagnostic build only (-DMV_STAMPS, tests/microbench/mv_bench.hip): per-phase s_memtime stamps of wave 0 of each workgroup
 #ifdef MV_STAMPS
@@ -367,6 +368,133 @@ __global__ void __launch_bounds__(256) matvec_f_kernel(mv_args a, int rows_per_w
     }
 }
 
+// Register-resident variant for the codec transformer's F32 linears (K = 256 * KV, KV <= 8): the weight rows of this wave are
+// requested before anything else, the activation columns are read from global memory exactly once (statistics, normalisation
+// and staging all work from registers), so the only serial latencies left are one weight fetch and two block reductions.
+template <int KV, int RPW>
+__global__ void __launch_bounds__(256) matvec_f32_reg_kernel(mv_args a) {
+    __shared__ __attribute__((aligned(16))) float xs[MV_MAX_COLS * KV * 256];
+    __shared__ double sh_cols[2][4][MV_MAX_COLS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int K = KV * 256;
+    const int nc = a.ncols;
+    const int64_t rbase = ((int64_t) blockIdx.x * 4 + wave) * RPW;
+    f32x4 wreg[RPW][KV];
+#pragma unroll
+    for (int rr = 0; rr < RPW; rr++) {
+        int64_t row = rbase + rr;
+        if (row >= a.M) row = a.M - 1;
+        const char * w = a.w + row * a.row_bytes;
+#pragma unroll
+        for (int it = 0; it < KV; it++) wreg[rr][it] = __builtin_nontemporal_load((const f32x4 *) (w + ((int64_t) it * 256 + lane * 4) * 4));
+    }
+    float xr[MV_MAX_COLS][KV], al[KV], be[KV];
+#pragma unroll
+    for (int c = 0; c < MV_MAX_COLS; c++)
+#pragma unroll
+        for (int j = 0; j < KV; j++) xr[c][j] = a.x[(int64_t) (c < nc ? c : 0) * a.x_cs + tid + 256 * j];
+    if (a.prologue == MV_GATE_SILU) {
+#pragma unroll
+        for (int c = 0; c < MV_MAX_COLS; c++)
+#pragma unroll
+            for (int j = 0; j < KV; j++) { const float l = xr[c][j], r = a.x[(int64_t) (c < nc ? c : 0) * a.x_cs + K + tid + 256 * j]; xr[c][j] = (l / (1.0f + expf(-l))) * r; }
+    }
+    if (a.prologue == MV_RMSNORM || a.prologue == MV_LAYERNORM) {
+#pragma unroll
+        for (int j = 0; j < KV; j++) { al[j] = a.alpha[tid + 256 * j]; be[j] = a.beta ? a.beta[tid + 256 * j] : 0.f; }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (a.prologue == MV_RMSNORM || a.prologue == MV_LAYERNORM) {
+        auto block_sum_cols = [&](double v[MV_MAX_COLS], int slot) {
+#pragma unroll
+            for (int c = 0; c < MV_MAX_COLS; c++) if (c < nc) v[c] = wave_allsum_f64(v[c]);
+            if (lane == 0) {
+#pragma unroll
+                for (int c = 0; c < MV_MAX_COLS; c++) sh_cols[slot][wave][c] = v[c];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int c = 0; c < MV_MAX_COLS; c++) v[c] = sh_cols[slot][0][c] + sh_cols[slot][1][c] + sh_cols[slot][2][c] + sh_cols[slot][3][c];
+        };
+        float mean[MV_MAX_COLS];
+        double acc[MV_MAX_COLS];
+#pragma unroll
+        for (int c = 0; c < MV_MAX_COLS; c++) mean[c] = 0.f;
+        if (a.prologue == MV_LAYERNORM) {
+#pragma unroll
+            for (int c = 0; c < MV_MAX_COLS; c++) { acc[c] = 0; 
+#pragma unroll
+                for (int j = 0; j < KV; j++) acc[c] += (double) xr[c][j]; }
+            block_sum_cols(acc, 0);
+#pragma unroll
+            for (int c = 0; c < MV_MAX_COLS; c++) mean[c] = (float) (acc[c] / (double) K);
+        }
+#pragma unroll
+        for (int c = 0; c < MV_MAX_COLS; c++) { acc[c] = 0;
+#pragma unroll
+            for (int j = 0; j < KV; j++) { const float v = xr[c][j] - mean[c]; acc[c] += (double) (v * v); } }
+        block_sum_cols(acc, 1);
+#pragma unroll
+        for (int c = 0; c < MV_MAX_COLS; c++) {
+            const float scale = 1.0f / sqrtf((float) (acc[c] / (double) K) + a.eps);
+#pragma unroll
+            for (int j = 0; j < KV; j++) {
+                if (a.prologue == MV_RMSNORM) xr[c][j] = al[j] * (xr[c][j] * scale);
+                else { float v = ((xr[c][j] - mean[c]) * scale) * al[j]; if (a.beta) v = v + be[j]; xr[c][j] = v; }
+            }
+        }
+    } else if (a.prologue == MV_GELU) {
+#pragma unroll
+        for (int c = 0; c < MV_MAX_COLS; c++)
+#pragma unroll
+            for (int j = 0; j < KV; j++) xr[c][j] = gelu_table(xr[c][j]);
+    }
+#pragma unroll
+    for (int c = 0; c < MV_MAX_COLS; c++) {
+        if (c < nc) {
+#pragma unroll
+            for (int j = 0; j < KV; j++) {
+                xs[c * K + tid + 256 * j] = xr[c][j];
+                if (a.x_out != nullptr && blockIdx.x == 0) a.x_out[(int64_t) c * K + tid + 256 * j] = xr[c][j];
+            }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int rr = 0; rr < RPW; rr++) {
+        const int64_t row = rbase + rr;
+        double acc[MV_MAX_COLS];
+#pragma unroll
+        for (int c = 0; c < MV_MAX_COLS; c++) acc[c] = 0;
+#pragma unroll
+        for (int it = 0; it < KV; it++) {
+            const int k = it * 256 + lane * 4;
+#pragma unroll
+            for (int c = 0; c < MV_MAX_COLS; c++) {
+                if (c < nc) {
+                    const float4 xv = *(const float4 *) (xs + c * K + k);
+                    acc[c] += (double) (wreg[rr][it][0] * xv.x);
+                    acc[c] += (double) (wreg[rr][it][1] * xv.y);
+                    acc[c] += (double) (wreg[rr][it][2] * xv.z);
+                    acc[c] += (double) (wreg[rr][it][3] * xv.w);
+                }
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < MV_MAX_COLS; c++) {
+            if (c < nc) {
+                const double tot = wave_allsum_f64(acc[c]);
+                if (lane == 0 && row < a.M) {
+                    float sres = (float) tot;
+                    if (a.out_act == 1) sres = gelu_table(sres);
+                    if (a.out_scale) sres = sres * a.out_scale[row];
+                    a.y[(int64_t) c * a.y_cs + row] = a.residual ? a.residual[(int64_t) c * a.r_cs + row] + sres : sres;
+                }
+            }
+        }
+    }
+}
+
 bool k_matvec_supported(int wtype, int64_t K, int64_t M) {
     if (M <= 0) return false;
     switch (wtype) {
@@ -443,6 +571,16 @@ void k_matvec(hipStream_t s, const mv_args & a) {
         return;
     }
     GGML_ASSERT(a.ncols >= 1 && a.ncols <= MV_MAX_COLS);
+    static const int no_reg = env_int("MI355X_MV_NOREG", 0);
+    if (a.wtype == GGML_TYPE_F32 && !no_reg && (a.K == 512 || a.K == 1024 || a.K == 2048) && a.row_bytes % 16 == 0 && ((uintptr_t) a.w % 16) == 0) {
+        // one row per wave until every CU has a workgroup, then two
+        const bool two = a.K <= 1024 && a.M >= 4 * 2 * 256;
+        const int grid = (int) ((a.M + (two ? 8 : 4) - 1) / (two ? 8 : 4));
+        if (a.K == 512)       { if (two) matvec_f32_reg_kernel<2, 2><<<grid, 256, 0, s>>>(a); else matvec_f32_reg_kernel<2, 1><<<grid, 256, 0, s>>>(a); }
+        else if (a.K == 1024) { if (two) matvec_f32_reg_kernel<4, 2><<<grid, 256, 0, s>>>(a); else matvec_f32_reg_kernel<4, 1><<<grid, 256, 0, s>>>(a); }
+        else                  matvec_f32_reg_kernel<8, 1><<<grid, 256, 0, s>>>(a);
+        return;
+    }
     int rows_per_wave = a.K <= 1024 ? 4 : 2;
     while (rows_per_wave > 1 && (a.M + 4 * rows_per_wave - 1) / (4 * rows_per_wave) < 256) rows_per_wave >>= 1;
     const int grid = (int) ((a.M + 4 * rows_per_wave - 1) / (4 * rows_per_wave));
@@ -644,4 +782,84 @@ __global__ void embed_sum_kernel(embed_sum_args a) {
 }
 void k_embed_sum(hipStream_t s, const embed_sum_args & a) {
     embed_sum_kernel<<<(int) ((a.K + 255) / 256), 256, 0, s>>>(a);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// residual-VQ encode level: argmax_c 1 / (||e_c - x||^2 + 1), then x <- x - e_best
+// ---------------------------------------------------------------------------------------------------
+// The reference materialises (e - x) for all 2048 centroids, squares, sum_rows (double accumulate), adds 1, takes the
+// reciprocal and argmaxes (first maximum wins). Here every wave scores VQ_CPW centroids (row loads requested up front), the
+// workgroup keeps its best candidate, and the last workgroup to arrive (device-scope counter) merges the candidates, writes
+// the code and updates the residual - one launch per level instead of fifteen.
+#define VQ_CPW 4
+__global__ void __launch_bounds__(256) vq_level_kernel(vq_level_args a) {
+    __shared__ float sv[4];
+    __shared__ int si[4];
+    __shared__ int s_last;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int D = a.D;   // 256: one float4 per lane
+    const int c0 = (blockIdx.x * 4 + wave) * VQ_CPW;
+    f32x4 e[VQ_CPW];
+#pragma unroll
+    for (int u = 0; u < VQ_CPW; u++) {
+        const int c = c0 + u < a.NC ? c0 + u : a.NC - 1;
+        e[u] = *(const f32x4 *) (a.emb + (int64_t) c * a.emb_row_bytes + lane * 16);
+    }
+    float x[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) x[j] = *(const float *) (a.resid + (int64_t) (lane * 4 + j) * a.resid_stride);
+    const float addc = a.add_c[0];
+    float best = -INFINITY; int bi = 0x7fffffff;
+#pragma unroll
+    for (int u = 0; u < VQ_CPW; u++) {
+        double acc = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) { const float d = e[u][j] - x[j]; acc += (double) (d * d); }
+        acc = wave_allsum_f64(acc);
+        const int c = c0 + u;
+        if (c < a.NC) {
+            const float v = a.num[c] / ((float) acc + addc);
+            if (v > best) { best = v; bi = c; }
+        }
+    }
+    if (lane == 0) { sv[wave] = best; si[wave] = bi; }
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < 4; w++) if (sv[w] > best || (sv[w] == best && si[w] < bi)) { best = sv[w]; bi = si[w]; }
+        a.cand_val[blockIdx.x] = best; a.cand_idx[blockIdx.x] = bi;
+        __threadfence();
+        const unsigned ticket = atomicAdd(a.counter, 1u);
+        s_last = ticket == gridDim.x - 1;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    // merge: candidates are few (<= 256), one per thread
+    best = -INFINITY; bi = 0x7fffffff;
+    if (tid < (int) gridDim.x) { best = __builtin_nontemporal_load(a.cand_val + tid); bi = __builtin_nontemporal_load(a.cand_idx + tid); }
+    __shared__ float mv[256];
+    __shared__ int mi[256];
+    mv[tid] = best; mi[tid] = bi;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if (tid < st) {
+            const float v = mv[tid + st]; const int j = mi[tid + st];
+            if (v > mv[tid] || (v == mv[tid] && j < mi[tid])) { mv[tid] = v; mi[tid] = j; }
+        }
+        __syncthreads();
+    }
+    const int code = mi[0] == 0x7fffffff ? 0 : mi[0];
+    if (tid == 0) { *a.idx_i = code; *a.idx_f = (float) code; *a.counter = 0u; }
+    if (a.resid_out) {
+        for (int j = tid; j < D; j += 256) {
+            const float q = *(const float *) (a.emb + (int64_t) code * a.emb_row_bytes + j * 4);
+            a.resid_out[j] = *(const float *) (a.resid + (int64_t) j * a.resid_stride) - q;
+        }
+    }
+}
+void k_vq_level(hipStream_t s, const vq_level_args & a) {
+    GGML_ASSERT(a.D == 256);
+    const int grid = (a.NC + 4 * VQ_CPW - 1) / (4 * VQ_CPW);
+    GGML_ASSERT(grid <= 256);
+    vq_level_kernel<<<grid, 256, 0, s>>>(a);
 }

@@ -372,30 +372,47 @@ void k_im2col(hipStream_t s, tdesc dst, tdesc x, int64_t K, int s0, int p0, int 
 //  A. P[s][l][n] = sum over the s-th slice of ic of x[l, ic] * w[ic][n], n = oc*K + k (w's memory order), double partials
 //  B. y[t, oc] = sum over l ascending of (float) sum_s P[s][l][oc*K + (t - l*s0)]  — the CPU reference's accumulation order
 #define CT_LT 8
-__global__ void convtr_partial_kernel(tdesc w, tdesc x, double * P, int N, int L, int IC, int ic_per_split, int pre_elu) {
+__global__ void __launch_bounds__(256) convtr_partial_kernel(tdesc w, tdesc x, double * P, int N, int L, int IC, int ic_per_split, int pre_elu) {
+    extern __shared__ float ct_xs[];   // [ic in this split][CT_LT]: the activation tile, already rounded the way the dot sees it
     const int n = blockIdx.x * blockDim.x + threadIdx.x;
     const int l0 = blockIdx.y * CT_LT;
     const int split = blockIdx.z;
-    if (n >= N) return;
-    const int ic0 = split * ic_per_split, ic1 = min(IC, ic0 + ic_per_split);
+    const int ic0 = split * ic_per_split, ic1 = min(IC, ic0 + ic_per_split), nic = ic1 - ic0;
     const bool f16 = w.type == GGML_TYPE_F16;
+    for (int idx = threadIdx.x; idx < nic * CT_LT; idx += blockDim.x) {
+        const int i = idx % CT_LT, icl = idx / CT_LT, l = l0 + i;
+        float xv = 0.f;
+        if (l < L) {
+            xv = *(const float *) (x.data + (int64_t) l * x.nb[0] + (int64_t) (ic0 + icl) * x.nb[1]);
+            if (pre_elu) xv = xv > 0.f ? xv : expm1f(xv);
+            if (f16) xv = h2f(f2h(xv));
+        }
+        ct_xs[idx] = xv;
+    }
+    __syncthreads();
+    if (n >= N) return;
     double acc[CT_LT];
 #pragma unroll
     for (int i = 0; i < CT_LT; i++) acc[i] = 0;
-    const char * wp = w.data + (int64_t) n * w.nb[0];   // (k, oc) are contiguous: n-th element of an ic slab
-    for (int ic = ic0; ic < ic1; ic++) {
-        const char * wq = wp + (int64_t) ic * w.nb[2];
+    const char * wp = w.data + (int64_t) n * w.nb[0] + (int64_t) ic0 * w.nb[2];   // (k, oc) are contiguous: n-th element of an ic slab
+    int icl = 0;
+    for (; icl + 8 <= nic; icl += 8) {
+        float wv[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const char * wq = wp + (int64_t) (icl + u) * w.nb[2];
+            wv[u] = f16 ? h2f(*(const uint16_t *) wq) : *(const float *) wq;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++)
+#pragma unroll
+            for (int i = 0; i < CT_LT; i++) acc[i] += (double) (ct_xs[(icl + u) * CT_LT + i] * wv[u]);
+    }
+    for (; icl < nic; icl++) {
+        const char * wq = wp + (int64_t) icl * w.nb[2];
         const float wv = f16 ? h2f(*(const uint16_t *) wq) : *(const float *) wq;
 #pragma unroll
-        for (int i = 0; i < CT_LT; i++) {
-            const int l = l0 + i;
-            if (l < L) {
-                float xv = *(const float *) (x.data + (int64_t) l * x.nb[0] + (int64_t) ic * x.nb[1]);
-                if (pre_elu) xv = xv > 0.f ? xv : expm1f(xv);
-                if (f16) xv = h2f(f2h(xv));
-                acc[i] += (double) (xv * wv);
-            }
-        }
+        for (int i = 0; i < CT_LT; i++) acc[i] += (double) (ct_xs[icl * CT_LT + i] * wv);
     }
 #pragma unroll
     for (int i = 0; i < CT_LT; i++) { const int l = l0 + i; if (l < L) P[((int64_t) split * L + l) * N + n] = acc[i]; }
@@ -430,7 +447,7 @@ int k_conv_transpose_1d_partial(hipStream_t s, tdesc w, tdesc x, void * ws, int 
     if (nsplit > IC / 32) nsplit = IC / 32;
     if (nsplit < 1) nsplit = 1;
     const int per = (IC + nsplit - 1) / nsplit;
-    convtr_partial_kernel<<<dim3(nb, lt, nsplit), 256, 0, s>>>(w, x, (double *) ws, N, L, IC, per, pre_elu);
+    convtr_partial_kernel<<<dim3(nb, lt, nsplit), 256, (size_t) per * CT_LT * 4, s>>>(w, x, (double *) ws, N, L, IC, per, pre_elu);
     return nsplit;
 }
 void k_conv_transpose_1d(hipStream_t s, tdesc dst, tdesc w, tdesc x, int s0, void * ws) {
@@ -456,6 +473,7 @@ __global__ void convtr_finish_kernel(tdesc out, float * prev, const float * bias
             const int k = tt - l * s0;
             if (k >= K) continue;
             double v = 0;
+#pragma unroll 8
             for (int sp = 0; sp < nsplit; sp++) v += P[((int64_t) sp * L + l) * N + oc * K + k];
             acc += (float) v;
         }
@@ -678,21 +696,43 @@ __global__ void mul_mat_kernel(tdesc dst, tdesc a, tdesc b, const char * ws, int
 // of row (l & 15), so fragments are plain 16-byte global loads - no LDS, one wave per 16x16 output tile.
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-__global__ void __launch_bounds__(256) mul_mat_f16_mfma_kernel(tdesc dst, tdesc a, tdesc b, int mt, int nt, mm_epilogue epi) {
+// Few tiles (deep conv layers at 12.5-50 Hz) would leave the chip empty and the K loop latency-bound, so a tile can be split
+// over SK waves of the workgroup (contiguous K slices, partial tiles summed through LDS in slice order); the K loop requests
+// four fragment pairs before the first MFMA.
+__global__ void __launch_bounds__(1024) mul_mat_f16_mfma_kernel(tdesc dst, tdesc a, tdesc b, int mt, int nt, int SK, int TPW, mm_epilogue epi) {
+    __shared__ f32x4 red[16][64];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int tile = blockIdx.x * 4 + wave;
-    if (tile >= mt * nt) return;
-    const int tm = tile % mt, tn = tile / mt;
+    const int slice = wave % SK, tw = wave / SK;
+    const int tile = blockIdx.x * TPW + tw;
+    const bool live = tile < mt * nt;
+    const int tm = live ? tile % mt : 0, tn = live ? tile / mt : 0;
     const int r = lane & 15, kq = lane >> 4;
+    const int K = (int) a.ne[0];
+    const int steps = K / 32, per = (steps + SK - 1) / SK;
+    const int s_begin = slice * per, s_end = min(steps, s_begin + per);
     const char * ap = a.data + (int64_t) (tm * 16 + r) * a.nb[1] + kq * 16;
     const char * bp = b.data + (int64_t) (tn * 16 + r) * b.nb[1] + kq * 16;
     f32x4 acc = { 0.f, 0.f, 0.f, 0.f };
-    const int K = (int) a.ne[0];
-    for (int k = 0; k < K; k += 32) {
-        const f16x8 av = *(const f16x8 *) (ap + k * 2);
-        const f16x8 bv = *(const f16x8 *) (bp + k * 2);
+    int st = s_begin;
+    for (; st + 4 <= s_end; st += 4) {
+        f16x8 av[4], bv[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) { av[u] = *(const f16x8 *) (ap + (st + u) * 64); bv[u] = *(const f16x8 *) (bp + (st + u) * 64); }
+#pragma unroll
+        for (int u = 0; u < 4; u++) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(av[u], bv[u], acc, 0, 0, 0);
+    }
+    for (; st < s_end; st++) {
+        const f16x8 av = *(const f16x8 *) (ap + st * 64);
+        const f16x8 bv = *(const f16x8 *) (bp + st * 64);
         acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, bv, acc, 0, 0, 0);
     }
+    if (SK > 1) {
+        if (slice > 0) red[wave][lane] = acc;
+        __syncthreads();
+        if (slice > 0) return;
+        for (int sl = 1; sl < SK; sl++) { const f32x4 o = red[wave + sl][lane]; acc[0] += o[0]; acc[1] += o[1]; acc[2] += o[2]; acc[3] += o[3]; }
+    }
+    if (!live) return;
     // C[row = 4*(lane>>4) + j][col = lane & 15]: rows are `a` rows (dst dim 0), cols are `b` rows (dst dim 1)
     float * out = (float *) (dst.data + (int64_t) (tn * 16 + r) * dst.nb[1]) + tm * 16 + kq * 4;
     if (epi.bias) { const float bv = epi.bias[tn * 16 + r]; acc[0] = acc[0] + bv; acc[1] = acc[1] + bv; acc[2] = acc[2] + bv; acc[3] = acc[3] + bv; }
@@ -704,7 +744,8 @@ __global__ void __launch_bounds__(256) mul_mat_f16_mfma_kernel(tdesc dst, tdesc 
     *(f32x4 *) out = acc;
 }
 
-// few activation rows (M = a.ne1 <= 8) against many weight rows in `b`: one wave per b row, b read once
+// few activation rows (M = a.ne1 <= 8) against many weight rows in `b`: one wave per b row, b read once; four 16-byte chunks
+// of the b row are requested before any arithmetic
 __global__ void __launch_bounds__(256) mul_mat_smallm_kernel(tdesc dst, tdesc a, tdesc b, int M, int N, mm_epilogue epi) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int n = blockIdx.x * 4 + wave;
@@ -714,14 +755,20 @@ __global__ void __launch_bounds__(256) mul_mat_smallm_kernel(tdesc dst, tdesc a,
     double acc[8];
 #pragma unroll
     for (int m = 0; m < 8; m++) acc[m] = 0;
-    for (int k = lane * 8; k < K; k += 512) {
-        const f16x8 bv = *(const f16x8 *) (bp + k * 2);
+    for (int k0 = lane * 8; k0 < K; k0 += 2048) {
+        f16x8 bv[4];
+        int kk[4];
 #pragma unroll
-        for (int m = 0; m < 8; m++) {
-            if (m < M) {
-                const f16x8 av = *(const f16x8 *) (a.data + (int64_t) m * a.nb[1] + k * 2);
+        for (int u = 0; u < 4; u++) { kk[u] = k0 + u * 512; const bool ok = kk[u] < K; if (!ok) kk[u] = lane * 8; bv[u] = *(const f16x8 *) (bp + kk[u] * 2); if (!ok) bv[u] = (f16x8) (_Float16) 0; }
 #pragma unroll
-                for (int j = 0; j < 8; j++) acc[m] += (double) ((float) av[j] * (float) bv[j]);
+        for (int u = 0; u < 4; u++) {
+#pragma unroll
+            for (int m = 0; m < 8; m++) {
+                if (m < M) {
+                    const f16x8 av = *(const f16x8 *) (a.data + (int64_t) m * a.nb[1] + kk[u] * 2);
+#pragma unroll
+                    for (int j = 0; j < 8; j++) acc[m] += (double) ((float) av[j] * (float) bv[u][j]);
+                }
             }
         }
     }
@@ -739,18 +786,41 @@ __global__ void __launch_bounds__(256) mul_mat_smallm_kernel(tdesc dst, tdesc a,
     }
 }
 
+// short rows (K <= 64, e.g. the first SEANet conv: 1 input channel x 7 taps): one thread per output element
+__global__ void mul_mat_f16_shortk_kernel(tdesc dst, tdesc a, tdesc b, int K, int M, int64_t total, mm_epilogue epi) {
+    const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int m = (int) (i % M), n = (int) (i / M);
+    const uint16_t * ap = (const uint16_t *) (a.data + (int64_t) m * a.nb[1]);
+    const uint16_t * bp = (const uint16_t *) (b.data + (int64_t) n * b.nb[1]);
+    double acc = 0;
+    for (int k = 0; k < K; k++) acc += (double) (h2f(ap[k]) * h2f(bp[k]));
+    float r = (float) acc;
+    if (epi.bias) r = r + epi.bias[n];
+    if (epi.residual) r = *(const float *) (epi.residual + (int64_t) m * epi.res_nb0 + (int64_t) n * epi.res_nb1) + r;
+    *(float *) (dst.data + (int64_t) m * dst.nb[0] + (int64_t) n * dst.nb[1]) = r;
+}
+
 void k_mul_mat(hipStream_t s, tdesc dst, tdesc a, tdesc b, void * ws, const mm_epilogue * epi_) {
     const int64_t total = td_nelements(dst);
     if (total == 0) return;
     mm_epilogue epi = { nullptr, nullptr, 0, 0 };
     if (epi_) epi = *epi_;
     if (a.type == GGML_TYPE_F16 && b.type == GGML_TYPE_F16 && a.nb[0] == 2 && b.nb[0] == 2 && a.ne[2] * a.ne[3] * b.ne[2] * b.ne[3] == 1 &&
+        a.ne[0] <= 64 && a.ne[1] >= 256) {
+        mul_mat_f16_shortk_kernel<<<nblocks(total), BLOCK, 0, s>>>(dst, a, b, (int) a.ne[0], (int) a.ne[1], total, epi);
+        return;
+    }
+    if (a.type == GGML_TYPE_F16 && b.type == GGML_TYPE_F16 && a.nb[0] == 2 && b.nb[0] == 2 && a.ne[2] * a.ne[3] * b.ne[2] * b.ne[3] == 1 &&
         dst.nb[0] == 4 && a.ne[0] % 8 == 0 && (a.nb[1] % 16) == 0 && (b.nb[1] % 16) == 0 && ((uintptr_t) a.data % 16) == 0 && ((uintptr_t) b.data % 16) == 0) {
         const int M = (int) a.ne[1], N = (int) b.ne[1];
         if (M <= 8) { mul_mat_smallm_kernel<<<(N + 3) / 4, 256, 0, s>>>(dst, a, b, M, N, epi); return; }
         if (M % 16 == 0 && N % 16 == 0 && a.ne[0] % 32 == 0 && (dst.nb[1] % 16) == 0 && ((uintptr_t) dst.data % 16) == 0) {
-            const int mt = M / 16, nt = N / 16;
-            mul_mat_f16_mfma_kernel<<<(mt * nt + 3) / 4, 256, 0, s>>>(dst, a, b, mt, nt, epi);
+            const int mt = M / 16, nt = N / 16, tiles = mt * nt, steps = (int) a.ne[0] / 32;
+            int SK = 1;
+            while (SK < 16 && tiles * SK < 512 && steps / (SK * 2) >= 4) SK *= 2;
+            const int TPW = SK >= 4 ? 1 : 4 / SK;
+            mul_mat_f16_mfma_kernel<<<(tiles + TPW - 1) / TPW, 64 * SK * TPW, 0, s>>>(dst, a, b, mt, nt, SK, TPW, epi);
             return;
         }
     }
