@@ -730,20 +730,32 @@ static bool match_embed_term(const analysis & an, const ggml_tensor * e, embed_s
     if (e->op == GGML_OP_MUL) {
         gr = e->src[0]; scale = e->src[1];
         if (scale->type != GGML_TYPE_F32 || ggml_nelements(scale) != 1 || uses_of(an, gr) != 1) return false;
+        members.push_back(pos_of(an, e));
+    } else if (e->op == GGML_OP_CONT && e->src[0]->op == GGML_OP_PERMUTE && e->src[0]->src[0]->op == GGML_OP_GET_ROWS) {
+        // a single gathered row viewed as [1, K] (moshi_vq_decode, core_vq.h:100-109): same bytes
+        const ggml_tensor * pm = e->src[0];
+        gr = pm->src[0];
+        if (gr->ne[1] != 1 || ggml_nelements(gr) != gr->ne[0] || uses_of(an, pm) != 1 || uses_of(an, gr) != 1) return false;
+        members.push_back(pos_of(an, e)); members.push_back(pos_of(an, pm));
     }
     if (gr->op != GGML_OP_GET_ROWS) return false;
     const ggml_tensor * tab = gr->src[0], * idx = gr->src[1];
     if (ggml_nelements(idx) != 1 || idx->type != GGML_TYPE_I32 || !dense_rows(tab)) return false;
     switch (tab->type) { case GGML_TYPE_F32: case GGML_TYPE_F16: case GGML_TYPE_BF16: case GGML_TYPE_Q4_0: case GGML_TYPE_Q8_0: case GGML_TYPE_Q4_K: break; default: return false; }
-    out = { (const char *) tab->data, (int64_t) tab->nb[1], tab->ne[1], (int) tab->type, (const int32_t *) idx->data, scale ? (const float *) scale->data : nullptr };
+    const int32_t * ip = (const int32_t *) idx->data;
+    if (idx->op == GGML_OP_CONT && uses_of(an, idx) == 1 && idx->src[0]->type == GGML_TYPE_I32 && idx->src[0]->data && pos_of(an, idx) >= 0) {
+        ip = (const int32_t *) idx->src[0]->data;   // a one-element copy: read the source
+        members.push_back(pos_of(an, idx));
+    }
+    out = { (const char *) tab->data, (int64_t) tab->nb[1], tab->ne[1], (int) tab->type, ip, scale ? (const float *) scale->data : nullptr };
     members.push_back(pos_of(an, gr));
-    if (e != gr) members.push_back(pos_of(an, e));
     return true;
 }
 
 static bool match_embed_sum(const analysis & an, int pos, embed_group & grp) {
     const ggml_tensor * top = an.g->nodes[pos];
-    if (top->op != GGML_OP_ADD || top->view_src || top->type != GGML_TYPE_F32 || top->ne[1] != 1 || !ggml_is_contiguous(top)) return false;
+    if (top->op != GGML_OP_ADD || top->view_src || top->type != GGML_TYPE_F32 || !ggml_is_contiguous(top)) return false;
+    if (!(top->ne[1] == 1 || top->ne[0] == 1) || top->ne[2] != 1 || top->ne[3] != 1) return false;
     // must be the top of the chain: its consumer is not another link
     std::vector<const ggml_tensor *> terms;
     std::vector<int> members;
@@ -761,7 +773,7 @@ static bool match_embed_sum(const analysis & an, int pos, embed_group & grp) {
     if (terms.size() < 3 || terms.size() > EMBED_SUM_MAX) return false;
     memset(&grp.a, 0, sizeof(grp.a));
     grp.a.n = (int) terms.size();
-    grp.a.K = top->ne[0];
+    grp.a.K = ggml_nelements(top);
     grp.a.out = (float *) top->data;
     for (size_t i = 0; i < terms.size(); i++) {
         // terms were collected right-to-left; the kernel adds left-to-right
@@ -846,56 +858,113 @@ static bool match_conv(const analysis & an, int pos, step_group & grp) {
 
 // E. streaming conv_transpose_1d (conv.h:240-310): [elu] -> conv_transpose_1d -> add_inplace(view lower, view prev tail) -> view full
 //    -> cpy(., prev) [-> + bias] -> view(window) -> cont  becomes the partial products + one finishing kernel.
-static bool match_convtr(const analysis & an, int pos, step_group & grp, emitter & em) {
-    const ggml_tensor * ct = an.g->nodes[pos];
-    if (ct->op != GGML_OP_CONV_TRANSPOSE_1D || uses_of(an, ct) != 1) return false;
-    const ggml_tensor * w = ct->src[0], * xin = ct->src[1];
-    const int K = (int) w->ne[0], OC = (int) w->ne[1], s0 = ct->op_params[0], L = (int) xin->ne[0], PT = K - s0;
-    if (PT <= 0 || PT > L * s0 || xin->type != GGML_TYPE_F32 || !(w->type == GGML_TYPE_F16 || w->type == GGML_TYPE_F32)) return false;
-    if ((int64_t) w->nb[1] != (int64_t) w->nb[0] * K) return false;
-    const int64_t OLf = ct->ne[0];
-    std::vector<int> members = { pos };
-    const ggml_tensor * lower = sole_consumer(an, ct);
-    if (!lower || lower->op != GGML_OP_VIEW || lower->data != ct->data || lower->ne[0] != PT || lower->ne[1] != OC) return false;
+struct convtr_tail { const ggml_tensor * prev, * out; const float * bias; int PT; std::vector<int> members; };
+
+// the streaming tail shared by the dense and the depthwise transposed conv: y is the freshly computed [OLf, OC] block
+static bool match_convtr_tail(const analysis & an, const ggml_tensor * y, convtr_tail & t) {
+    if (uses_of(an, y) != 1) return false;
+    const int64_t OLf = y->ne[0], OC = y->ne[1];
+    const ggml_tensor * lower = sole_consumer(an, y);
+    if (!lower || lower->op != GGML_OP_VIEW || lower->data != y->data || lower->ne[1] != OC) return false;
+    const int64_t PT = lower->ne[0];
     const ggml_tensor * ai = sole_consumer(an, lower);
     if (!ai || ai->op != GGML_OP_ADD || ai->src[0] != lower || ai->data != lower->data) return false;
     const ggml_tensor * partial = ai->src[1];
-    if (partial->op != GGML_OP_VIEW || partial->src[0]->op != GGML_OP_NONE) return false;
+    if (partial->op != GGML_OP_VIEW || partial->src[0]->op != GGML_OP_NONE || uses_of(an, partial) != 1) return false;
     const ggml_tensor * prev = partial->src[0];
     if (prev->type != GGML_TYPE_F32 || !ggml_is_contiguous(prev) || prev->ne[0] != OLf || prev->ne[1] != OC || ggml_nelements(prev) != OLf * OC) return false;
     if (partial->ne[0] != PT || partial->ne[1] != OC || (const char *) partial->data - (const char *) prev->data != (OLf - PT) * 4 || partial->nb[1] != prev->nb[1]) return false;
     const ggml_tensor * full = sole_consumer(an, ai);
-    if (!full || full->op != GGML_OP_VIEW || full->data != ct->data || full->ne[0] != OLf || full->ne[1] != OC) return false;
+    if (!full || full->op != GGML_OP_VIEW || full->data != y->data || full->ne[0] != OLf || full->ne[1] != OC) return false;
     const ggml_tensor * cp = sole_consumer(an, full);
     if (!cp || cp->op != GGML_OP_CPY || cp->src[1] != prev) return false;
     const ggml_tensor * cur = sole_consumer(an, cp);
-    const float * bias = nullptr;
-    members.insert(members.end(), { pos_of(an, lower), pos_of(an, partial), pos_of(an, ai), pos_of(an, full), pos_of(an, cp) });
-    if (cur && cur->op == GGML_OP_ADD && !cur->view_src && cur->src[0] == cp && cur->src[1]->type == GGML_TYPE_F32 && cur->src[1]->ne[0] == 1 &&
-        ggml_nelements(cur->src[1]) == OC && ggml_is_contiguous(cur->src[1])) {
-        bias = (const float *) cur->src[1]->data;
-        members.push_back(pos_of(an, cur));
+    t.bias = nullptr;
+    t.members = { pos_of(an, lower), pos_of(an, partial), pos_of(an, ai), pos_of(an, full), pos_of(an, cp) };
+    if (cur && cur->op == GGML_OP_ADD && !cur->view_src && cur->src[0] == cp && cur->src[1]->op == GGML_OP_NONE && cur->src[1]->type == GGML_TYPE_F32 &&
+        cur->src[1]->ne[0] == 1 && ggml_nelements(cur->src[1]) == OC && ggml_is_contiguous(cur->src[1])) {
+        t.bias = (const float *) cur->src[1]->data;
+        t.members.push_back(pos_of(an, cur));
         cur = sole_consumer(an, cur);
     }
     if (!cur || cur->op != GGML_OP_VIEW || cur->ne[0] != OLf - PT || cur->ne[1] != OC || cur->data != cur->src[0]->data) return false;
     const ggml_tensor * out = sole_consumer(an, cur);
     if (!out || out->op != GGML_OP_CONT || !ggml_is_contiguous(out) || !out->data) return false;
-    members.push_back(pos_of(an, cur)); members.push_back(pos_of(an, out));
-    if (uses_of(an, partial) != 1) return false;
+    t.members.push_back(pos_of(an, cur)); t.members.push_back(pos_of(an, out));
+    t.prev = prev; t.out = out; t.PT = (int) PT;
+    return true;
+}
+
+static bool match_convtr(const analysis & an, int pos, step_group & grp, emitter & em) {
+    const ggml_tensor * ct = an.g->nodes[pos];
+    if (ct->op != GGML_OP_CONV_TRANSPOSE_1D) return false;
+    const ggml_tensor * w = ct->src[0], * xin = ct->src[1];
+    const int K = (int) w->ne[0], OC = (int) w->ne[1], s0 = ct->op_params[0], L = (int) xin->ne[0], PT = K - s0;
+    if (PT <= 0 || PT > L * s0 || xin->type != GGML_TYPE_F32 || !(w->type == GGML_TYPE_F16 || w->type == GGML_TYPE_F32)) return false;
+    if ((int64_t) w->nb[1] != (int64_t) w->nb[0] * K) return false;
+    convtr_tail t;
+    if (!match_convtr_tail(an, ct, t) || t.PT != PT) return false;
+    std::vector<int> members = t.members;
+    members.push_back(pos);
     int pre_elu = 0;
     if (is_elu(xin) && uses_of(an, xin) == 1 && pos_of(an, xin) >= 0) { pre_elu = 1; members.push_back(pos_of(an, xin)); xin = xin->src[0]; }
     if (!xin->data) return false;
     for (int m : members) if (m < 0) return false;
     void * ws = em.ws(k_conv_transpose_1d_ws_size(w, xin));
-    const tdesc d_w = make_tdesc(w), d_x = make_tdesc(xin), d_out = make_tdesc(out);
-    float * pv = (float *) prev->data;
+    const tdesc d_w = make_tdesc(w), d_x = make_tdesc(xin), d_out = make_tdesc(t.out);
+    float * pv = (float *) t.prev->data;
+    const float * bias = t.bias;
     grp.steps.clear();
     grp.steps.push_back([=](hipStream_t s) {
         const int nsplit = k_conv_transpose_1d_partial(s, d_w, d_x, ws, pre_elu);
         k_convtr_finish(s, d_out, pv, bias, ws, K, OC, L, s0, nsplit);
     });
     grp.members = members;
-    grp.emit_pos = pos_of(an, out);
+    grp.emit_pos = pos_of(an, t.out);
+    return true;
+}
+
+// E2. depthwise streaming conv_transpose_1d on a single frame (the 12.5 -> 25 Hz upsampler, conv.h:262-278): one multiply per
+//     kernel tap, concatenated, then the same streaming tail
+static bool match_dw_convtr(const analysis & an, int pos, step_group & grp) {
+    const ggml_tensor * y = an.g->nodes[pos];
+    if (y->op != GGML_OP_CONCAT || y->op_params[0] != 0 || y->type != GGML_TYPE_F32) return false;
+    std::vector<const ggml_tensor *> pieces;
+    std::vector<int> members;
+    const ggml_tensor * cur = y;
+    while (cur->op == GGML_OP_CONCAT && cur->op_params[0] == 0) {
+        if (cur != y && uses_of(an, cur) != 1) return false;
+        pieces.insert(pieces.begin(), cur->src[1]);
+        members.push_back(pos_of(an, cur));
+        cur = cur->src[0];
+    }
+    pieces.insert(pieces.begin(), cur);
+    const int K = (int) pieces.size();
+    if (K < 2 || K > 16 || y->ne[0] != K) return false;
+    const int64_t C = y->ne[1];
+    const ggml_tensor * x = nullptr, * w = nullptr;
+    for (int k = 0; k < K; k++) {
+        const ggml_tensor * pc = pieces[(size_t) k];
+        if (pc->op != GGML_OP_MUL || pc->view_src || uses_of(an, pc) != 1 || pc->ne[0] != 1 || pc->ne[1] != C) return false;
+        const ggml_tensor * sub = pc->src[1];
+        if (sub->op != GGML_OP_VIEW || sub->type != GGML_TYPE_F32 || sub->ne[0] != 1 || sub->ne[1] != C) return false;
+        if (k == 0) { x = pc->src[0]; w = sub->src[0]; }
+        if (pc->src[0] != x || sub->src[0] != w || (const char *) sub->data - (const char *) w->data != (int64_t) k * (int64_t) w->nb[0] || sub->nb[1] != w->nb[2]) return false;
+        members.push_back(pos_of(an, pc)); members.push_back(pos_of(an, sub));
+    }
+    if (!x || x->type != GGML_TYPE_F32 || x->ne[0] != 1 || x->ne[1] != C || !x->data || w->ne[0] != K || w->nb[0] != 4) return false;
+    convtr_tail t;
+    if (!match_convtr_tail(an, y, t) || t.PT >= K) return false;
+    for (int m : t.members) members.push_back(m);
+    for (int m : members) if (m < 0) return false;
+    const char * xp = (const char *) x->data; const int64_t x_cs = (int64_t) x->nb[1];
+    const char * wp = (const char *) w->data; const int64_t w_cs = (int64_t) w->nb[2];
+    float * pv = (float *) t.prev->data; const float * bias = t.bias; float * out = (float *) t.out->data;
+    const int PT = t.PT, Cn = (int) C;
+    grp.steps.clear();
+    grp.steps.push_back([=](hipStream_t s) { k_dw_convtr_frame(s, out, pv, bias, xp, x_cs, wp, w_cs, K, PT, Cn); });
+    grp.members = members;
+    grp.emit_pos = pos_of(an, t.out);
     return true;
 }
 
@@ -969,14 +1038,10 @@ static bool match_vq_level(const analysis & an, int pos, step_group & grp, emitt
         if (pos_of(an, sb) > last) last = pos_of(an, sb);
     } else if (uses_of(an, am) != 1) return false;
     for (int m : members) if (m < 0) return false;
-    // nothing outside the group may read a group output before the group is emitted
-    for (int i = pos + 1; i <= last; i++) {
-        const ggml_tensor * n = an.g->nodes[i];
-        bool member = false;
-        for (int m : members) if (m == i) member = true;
-        if (member) continue;
-        for (int s = 0; s < GGML_MAX_SRC; s++) if (n->src[s] == cs || n->src[s] == am) return false;
-    }
+    // Emitted where the F32 code is produced: everything the kernel reads precedes the argmax, and the next residual is
+    // only consumed after its own (later) position; tensors never share storage (ggml_backend_alloc_ctx_tensors).
+    last = pos_of(an, cs);
+    if (last < pos) return false;
     char * ws = (char *) em.ws(VQ_LEVEL_WS_BYTES);
     HIP_CHECK(hipMemset(ws, 0, VQ_LEVEL_WS_BYTES));
     vq_level_args a;
@@ -1024,6 +1089,7 @@ static plan_t * build_plan(hip_ctx * c, ggml_cgraph * g) {
             if (g->nodes[i]->op == GGML_OP_MUL_MAT) { if (!match_conv(an, i, grp)) continue; }
             else if (g->nodes[i]->op == GGML_OP_CONV_TRANSPOSE_1D) { if (!match_convtr(an, i, grp, em)) continue; }
             else if (g->nodes[i]->op == GGML_OP_ARGMAX) { if (!match_vq_level(an, i, grp, em)) continue; }
+            else if (g->nodes[i]->op == GGML_OP_CONCAT) { if (!match_dw_convtr(an, i, grp)) continue; }
             else continue;
             bool clash = false;
             for (int m : grp.members) if (an.skip[(size_t) m]) clash = true;

@@ -62,6 +62,8 @@ void k_stream_im2col(hipStream_t s, tdesc dst, const float * prev, int TP, tdesc
 void k_conv_tail(hipStream_t s, float * prev, int TP, tdesc x, int pre_elu);
 // streaming conv_transpose_1d tail (conv.h:282-309): overlap-add with the carried partial, state update, bias, window
 void k_convtr_finish(hipStream_t s, tdesc out, float * prev, const float * bias, const void * ws, int K, int OC, int L, int s0, int nsplit);
+// depthwise transposed conv of one input frame + streaming tail: y[k, c] = x[c] * w[k, c]
+void k_dw_convtr_frame(hipStream_t s, float * out, float * prev, const float * bias, const char * x, int64_t x_cs, const char * w, int64_t w_cs, int K, int PT, int C);
 int  k_conv_transpose_1d_partial(hipStream_t s, tdesc w, tdesc x, void * ws, int pre_elu);   // returns the number of ic splits written to ws
 // scatter of batched small uploads: descs/blob live in pinned host memory mapped into the device
 struct upload_desc { char * dst; uint32_t offset; uint32_t size; };

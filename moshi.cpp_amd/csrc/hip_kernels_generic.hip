@@ -494,6 +494,24 @@ void k_convtr_finish(hipStream_t s, tdesc out, float * prev, const float * bias,
     convtr_finish_kernel<<<nblocks(n), BLOCK, 0, s>>>(out, prev, bias, (const double *) ws, K, OC, L, s0, nsplit);
 }
 
+// depthwise variant for one input frame: y[k, c] = x[c] * w[k, c]; y[:PT] += prev[K-PT:]; prev = y; out = (y + bias)[:K-PT]
+__global__ void dw_convtr_frame_kernel(float * out, float * prev, const float * bias, const char * x, int64_t x_cs, const char * w, int64_t w_cs, int K, int PT, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float xv = *(const float *) (x + (int64_t) c * x_cs);
+    const float * wc = (const float *) (w + (int64_t) c * w_cs);
+    float * pv = prev + (int64_t) c * K;
+    const int keep = K - PT;
+    float y[16];
+    for (int k = 0; k < K; k++) { y[k] = xv * wc[k]; if (k < PT) y[k] = y[k] + pv[keep + k]; }
+    for (int k = 0; k < K; k++) pv[k] = y[k];
+    for (int k = 0; k < keep; k++) out[(int64_t) c * keep + k] = bias ? y[k] + bias[c] : y[k];
+}
+void k_dw_convtr_frame(hipStream_t s, float * out, float * prev, const float * bias, const char * x, int64_t x_cs, const char * w, int64_t w_cs, int K, int PT, int C) {
+    GGML_ASSERT(K <= 16);
+    dw_convtr_frame_kernel<<<(C + 63) / 64, 64, 0, s>>>(out, prev, bias, x, x_cs, w, w_cs, K, PT, C);
+}
+
 // F16 im2col of concat(prev, act(x)) without materialising the concat: dst[ci*Kw + k, ol] = xc[ol*s0 + k, ci]
 __global__ void stream_im2col_kernel(tdesc dst, const float * prev, int TP, tdesc x, int Kw, int s0, int pre_elu, int64_t n) {
     const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
