@@ -21,6 +21,7 @@
 
 #include <functional>
 #include <map>
+#include <memory>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -196,6 +197,7 @@ typedef std::function<void(hipStream_t)> step_fn;
 struct plan_t {
     std::vector<step_fn> steps;
     std::vector<std::pair<void *, size_t>> workspaces;
+    std::vector<std::unique_ptr<attn_args>> attn_copies;
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
     uint64_t hash = 0;
@@ -1068,8 +1070,11 @@ static plan_t * build_plan(hip_ctx * c, ggml_cgraph * g) {
 
     // fused groups, keyed by the position at which they are emitted
     std::map<int, std::vector<step_fn>> at_pos;
+    std::vector<attn_group> attn_groups;
+    static const bool no_attn_prologue = getenv("MI355X_NO_ATTN_PROLOGUE") != nullptr;
     if (fuse) {
-        // attention blocks first (they swallow set_rows / soft_max / two mul_mats)
+        // attention blocks first (they swallow set_rows / soft_max / two mul_mats); emitted after the mat-vec pass, which may
+        // absorb a short-ring attention into the projection that consumes it
         for (int i = 0; i < g->n_nodes; i++) {
             if (an.skip[(size_t) i] || g->nodes[i]->op != GGML_OP_SOFT_MAX) continue;
             attn_group grp;
@@ -1078,8 +1083,7 @@ static plan_t * build_plan(hip_ctx * c, ggml_cgraph * g) {
             for (int m : grp.members) if (an.skip[(size_t) m]) clash = true;
             if (clash) continue;
             for (int m : grp.members) an.skip[(size_t) m] = 1;
-            const attn_args a = grp.a;
-            at_pos[grp.emit_pos].push_back([=](hipStream_t s) { k_attn_decode(s, a); });
+            attn_groups.push_back(grp);
             p->n_fused += (int) grp.members.size();
         }
         // codec convolutions
@@ -1121,6 +1125,20 @@ static plan_t * build_plan(hip_ctx * c, ggml_cgraph * g) {
             if (clash) continue;
             for (int m : grp.members) an.skip[(size_t) m] = 1;
             mv_args a = grp.a;
+            if (a.prologue == MV_PLAIN && a.wtype == GGML_TYPE_Q4_K && a.ncols == 1 && !no_attn_prologue) {
+                // x is the output of a single-token attention over a short ring (Depth transformer): recompute it in every
+                // workgroup of this projection instead of launching it on its own (16 heads x 8 slots is ~nothing)
+                for (auto & ag : attn_groups) {
+                    const attn_args & at = ag.a;
+                    if (ag.emit_pos < 0 || (const float *) at.out != a.x || at.T != 1 || at.D != 64 || at.C > 8 || (int64_t) at.H * at.D != a.K) continue;
+                    if (!(a.K == 1024 || a.K == 2048 || a.K == 3072) || ag.emit_pos > grp.emit_pos || uses_of(an, g->nodes[ag.emit_pos]) != 1) continue;
+                    p->attn_copies.emplace_back(new attn_args(at));   // owned by the plan, passed by value at launch
+                    a.prologue = MV_ATTN;
+                    a.attn = p->attn_copies.back().get();
+                    ag.emit_pos = -1;
+                    break;
+                }
+            }
             if (a.prologue == MV_GATE_SILU && a.wtype == GGML_TYPE_Q4_K && a.K > 4096) {
                 // long gated rows: quantise the activation once, not once per workgroup
                 void * blocks = em.ws((size_t) (a.K / 256) * MV_XBLK_BYTES);
@@ -1132,6 +1150,11 @@ static plan_t * build_plan(hip_ctx * c, ggml_cgraph * g) {
             at_pos[grp.emit_pos].push_back([=](hipStream_t s) { k_matvec(s, a); });
             if (grp.members.size() > 1) p->n_fused += (int) grp.members.size();
         }
+    }
+    for (auto & ag : attn_groups) {
+        if (ag.emit_pos < 0) continue;
+        const attn_args a = ag.a;
+        at_pos[ag.emit_pos].insert(at_pos[ag.emit_pos].begin(), [=](hipStream_t s) { k_attn_decode(s, a); });
     }
     const bool dump = getenv("MI355X_DUMP_PLAN") != nullptr;
     for (int i = 0; i < g->n_nodes; i++) {

@@ -71,7 +71,8 @@ void k_scatter_uploads(hipStream_t s, const upload_desc * descs, const char * bl
 
 // ---- fused hot-path kernels --------------------------------------------------------------------------
 // y = W x (+ residual), x produced on the fly by an optional prologue, for one activation row (T = 1)
-enum mv_prologue { MV_PLAIN = 0, MV_RMSNORM = 1, MV_GATE_SILU = 2, MV_LAYERNORM = 3, MV_GELU = 4, MV_PREQ8K = 5 };
+enum mv_prologue { MV_PLAIN = 0, MV_RMSNORM = 1, MV_GATE_SILU = 2, MV_LAYERNORM = 3, MV_GELU = 4, MV_PREQ8K = 5, MV_ATTN = 6 };
+struct attn_args;
 #define MV_MAX_COLS 4
 struct mv_args {
     int         wtype;          // ggml_type of W
@@ -90,6 +91,7 @@ struct mv_args {
     const float * residual;     // optional, [M, ncols]
     float *     y;              // [M, ncols]
     float *     x_out;          // optional: prologue result written by block 0 (keeps the ggml node materialised)
+    const attn_args * attn;     // MV_ATTN: (host pointer) the attention whose output is x; short ring, recomputed per workgroup
 };
 bool k_matvec_supported(int wtype, int64_t K, int64_t M);
 // optional per-launch timing of the dominant kernel (matvec_q4k_kernel) with HIP start/stop events that are

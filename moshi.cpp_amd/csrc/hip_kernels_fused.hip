@@ -96,6 +96,112 @@ __device__ __forceinline__ void quantize_block_q8k(xblk * dst, const float v[4],
     if (lane == 0) dst->d = d;
 }
 
+// Attention of FOUR consecutive heads by ONE wave, for a single new token over a short ring (C <= 8 slots of D = 64): the Depth
+// transformer's shape. Same arithmetic, in the same order, as attn_decode_kernel below restricted to the one wave that has work
+// there (lane = (slot, 8-dim chunk)). Every global load of all four heads (q/k/v, ring rows) is requested before the first use, so
+// the whole thing costs about one memory round trip. 256 outputs land in xa (LDS); `wbuf` is >= 768 floats of wave-private LDS.
+__device__ __forceinline__ void attn_small_wave4(const attn_args & a, int h0, int lane, float * wbuf, float * xa, bool write_cache) {
+    constexpr int LPS = 8, half = 32;
+    const int C = a.C;
+    const int sub = lane / LPS, dl = (lane % LPS) * 8;
+    const int c = sub, cc = c < C ? c : C - 1;
+    const int j = lane, p = j < half ? j : j - half;
+    // ---- loads
+    const int slot = a.index[0];
+    const float m = a.mask[cc];
+    float rc = 1.f, rs = 0.f;
+    if (a.rot) { rc = a.rot[p]; rs = a.rot[half + p]; }
+    float qr[4], qi[4], kr[4], ki[4], vv[4];
+    uint4 kq[4], vq[4];
+#pragma unroll
+    for (int hh = 0; hh < 4; hh++) {
+        const int h = h0 + hh;
+        const float * q = a.q + (int64_t) h * a.q_hs, * k = a.k + (int64_t) h * a.k_hs, * v = a.v + (int64_t) h * a.v_hs;
+        if (a.rot) { qr[hh] = q[2 * p]; qi[hh] = q[2 * p + 1]; kr[hh] = k[2 * p]; ki[hh] = k[2 * p + 1]; }
+        else { qr[hh] = q[j]; qi[hh] = 0.f; kr[hh] = k[j]; ki[hh] = 0.f; }
+        vv[hh] = v[j];
+        kq[hh] = *(const uint4 *) (a.kcache + (int64_t) h * a.k_nb2 + (int64_t) cc * a.k_nb1 + dl * 2);
+        vq[hh] = *(const uint4 *) (a.vcache + (int64_t) h * a.v_nb2 + (int64_t) cc * a.v_nb1 + dl * 2);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    const bool live = c < C && m > -INFINITY;
+    const bool fresh = slot == c;
+    // ---- RoPE, BF16 rounding, ring write
+#pragma unroll
+    for (int hh = 0; hh < 4; hh++) {
+        float qo, ko;
+        if (a.rot) {
+            if (j < half) { qo = qr[hh] * rc - qi[hh] * rs; ko = kr[hh] * rc - ki[hh] * rs; }
+            else          { qo = qr[hh] * rs + qi[hh] * rc; ko = kr[hh] * rs + ki[hh] * rc; }
+        } else { qo = qr[hh]; ko = kr[hh]; }
+        const uint16_t kb = f2bf(ko), vb = f2bf(vv[hh]);
+        float * wb = wbuf + hh * 192;
+        wb[j] = bf2f(f2bf(qo)); wb[64 + j] = bf2f(kb); wb[128 + j] = bf2f(vb);
+        if (write_cache && slot >= 0 && slot < C) {
+            const int h = h0 + hh;
+            ((uint16_t *) (a.kcache + (int64_t) h * a.k_nb2 + (int64_t) slot * a.k_nb1))[j] = kb;
+            ((uint16_t *) (a.vcache + (int64_t) h * a.v_nb2 + (int64_t) slot * a.v_nb1))[j] = vb;
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int hh = 0; hh < 4; hh++) {
+        const float * qf = wbuf + hh * 192, * knew = qf + 64, * vnew = qf + 128;
+        float qv[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) qv[i] = qf[dl + i];
+        double acc = 0;
+        if (live) {
+            if (fresh) {
+#pragma unroll
+                for (int i = 0; i < 8; i++) acc += (double) (knew[dl + i] * qv[i]);
+            } else {
+                const uint32_t kw[4] = { kq[hh].x, kq[hh].y, kq[hh].z, kq[hh].w };
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    acc += (double) (bf2f((uint16_t) (kw[i] & 0xffff)) * qv[2 * i]);
+                    acc += (double) (bf2f((uint16_t) (kw[i] >> 16)) * qv[2 * i + 1]);
+                }
+            }
+        }
+        for (int o = LPS >> 1; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+        const float sv = live ? (float) acc * a.scale + m : -INFINITY;
+        const float gmax = wave_allmax_f32(sv);
+        const float e = sv > -INFINITY ? expf(sv - gmax) : 0.f;
+        double lsum = (lane % LPS) == 0 ? (double) e : 0.0;   // one representative per slot
+        lsum = wave_allsum_f64(lsum);
+        const float inv = (float) (1.0 / lsum);
+        const float pr = bf2f(f2bf(e * inv));
+        double o8[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) o8[i] = 0;
+        if (pr != 0.f) {
+            if (fresh) {
+#pragma unroll
+                for (int i = 0; i < 8; i++) o8[i] += (double) (vnew[dl + i] * pr);
+            } else {
+                const uint32_t vw[4] = { vq[hh].x, vq[hh].y, vq[hh].z, vq[hh].w };
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    o8[2 * i]     += (double) (bf2f((uint16_t) (vw[i] & 0xffff)) * pr);
+                    o8[2 * i + 1] += (double) (bf2f((uint16_t) (vw[i] >> 16)) * pr);
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 8; i++) for (int o = LPS; o < 64; o <<= 1) o8[i] += __shfl_xor(o8[i], o, 64);
+        if (sub == 0) {
+#pragma unroll
+            for (int i = 0; i < 8; i++) xa[hh * 64 + dl + i] = (float) o8[i];
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // One workgroup = 4 waves = `rows_per_wg` output rows.
 //  phase 1: every wave puts its first weight tile in flight (9 x 16 B per lane, nontemporal)
 //  phase 2: the activation vector is produced (prologue) and quantised to Q8_K in LDS; all loads of a
@@ -103,7 +209,7 @@ __device__ __forceinline__ void quantize_block_q8k(xblk * dst, const float v[4],
 //  phase 3: tiles stream registers -> LDS image -> one super-block per lane (next tile prefetched first)
 //  phase 4: fixed-order row sums (+ residual)
 template <int PRO, int NW>
-__global__ void __launch_bounds__(NW * 64) matvec_q4k_kernel(mv_args a, int rows_per_wg) {
+__global__ void __launch_bounds__(NW * 64) matvec_q4k_kernel(mv_args a, int rows_per_wg, attn_args at) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ double sh_red[NW];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -140,7 +246,7 @@ __global__ void __launch_bounds__(NW * 64) matvec_q4k_kernel(mv_args a, int rows
             if (PRO == MV_GATE_SILU) aux[j] = *(const float4 *) (a.x + K + e);
         }
     };
-    if (PRO != MV_PREQ8K) load_batch(0);
+    if (PRO != MV_PREQ8K && PRO != MV_ATTN) load_batch(0);
     __builtin_amdgcn_sched_barrier(0);   // keep the activation loads ahead of the weight tile in program (= return) order
 
     u32x4 r[9];
@@ -156,7 +262,17 @@ __global__ void __launch_bounds__(NW * 64) matvec_q4k_kernel(mv_args a, int rows
     __builtin_amdgcn_sched_barrier(0);
     MV_STAMP(1);
 
-    if (PRO == MV_PREQ8K) {
+    if (PRO == MV_ATTN) {
+        // x = attention output (H heads of 64, K = NW * 256): wave w computes heads 4w..4w+3 = its own Q8_K block, entirely in
+        // its (still unused) tile-staging LDS; workgroup 0 also performs the ring write the attention node implies
+        float * wbuf = (float *) stage, * xa = wbuf + 768;
+        attn_small_wave4(at, wave * 4, lane, wbuf, xa, blockIdx.x == 0);
+        float v[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) v[k] = xa[lane * 4 + k];
+        if (a.x_out != nullptr && blockIdx.x == 0) *(float4 *) (a.x_out + wave * 256 + lane * 4) = make_float4(v[0], v[1], v[2], v[3]);
+        quantize_block_q8k(xs + wave, v, lane);
+    } else if (PRO == MV_PREQ8K) {
         // activations were quantised by gate_quant_q8k_kernel: copy the padded Q8_K blocks (304 B each) into LDS
         const u32x4 * src = (const u32x4 *) a.x;
         for (int i = tid; i < nb * (XBLK_BYTES / 16); i += NW * 64) ((u32x4 *) xs)[i] = src[i];
@@ -546,13 +662,21 @@ void k_matvec(hipStream_t s, const mv_args & a) {
             if (rows * nb > 4096) rows = 4096 / nb;
             while (rows > 1 && (a.M + rows - 1) / rows < grid_min && (rows / 2) * nb >= 64) rows >>= 1;
         }
+        if (a.prologue == MV_ATTN) {   // one Q8_K block (4 heads of 64) per wave
+            GGML_ASSERT(a.K == 1024 || a.K == 2048 || a.K == 3072);
+            nw = (int) (a.K / 256);
+            int tpw = 4;
+            rows = (tpw * 64 + nb - 1) / nb;
+            while (rows > 1 && (a.M + rows - 1) / rows < grid_min && (rows / 2) * nb >= 64) rows >>= 1;
+        }
         if (rows < 1) rows = 1;
         const size_t smem = (size_t) nb * XBLK_BYTES + (size_t) nw * TILE_BYTES + (size_t) rows * nb * 4;
         const int grid = (int) ((a.M + rows - 1) / rows);
         GGML_ASSERT(a.prologue != MV_RMSNORM || a.K <= nw * 1024);
-        GGML_ASSERT(a.ncols == 1 && a.out_scale == nullptr && (a.prologue <= MV_GATE_SILU || a.prologue == MV_PREQ8K));
-        void (*kern)(mv_args, int) = nullptr;
+        GGML_ASSERT(a.ncols == 1 && a.out_scale == nullptr && (a.prologue <= MV_GATE_SILU || a.prologue == MV_PREQ8K || a.prologue == MV_ATTN));
+        void (*kern)(mv_args, int, attn_args) = nullptr;
 #define MV_PICK(NWV) (a.prologue == MV_RMSNORM ? matvec_q4k_kernel<MV_RMSNORM, NWV> : a.prologue == MV_GATE_SILU ? matvec_q4k_kernel<MV_GATE_SILU, NWV> \
+                      : a.prologue == MV_ATTN ? matvec_q4k_kernel<MV_ATTN, NWV> \
                       : a.prologue == MV_PREQ8K ? matvec_q4k_kernel<MV_PREQ8K, NWV> : matvec_q4k_kernel<MV_PLAIN, NWV>)
         kern = nw == 12 ? MV_PICK(12) : nw == 8 ? MV_PICK(8) : MV_PICK(4);
         if (smem > 64 * 1024) {   // > 64 KB of dynamic LDS needs a one-time opt-in per kernel
@@ -561,13 +685,16 @@ void k_matvec(hipStream_t s, const mv_args & a) {
             if (g < smem) { HIP_CHECK(hipFuncSetAttribute((const void *) kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int) smem)); g = smem; }
         }
         const int threads = nw * 64;
+        attn_args at;
+        memset(&at, 0, sizeof(at));
+        if (a.prologue == MV_ATTN) at = *a.attn;   // host copy, passed by value
         if (g_mv_profile && g_mv_profile->used < g_mv_profile->capacity) {
             mv_profile::rec & r = g_mv_profile->recs[g_mv_profile->used++];
             r.bytes = a.M * a.row_bytes;
-            hipExtLaunchKernelGGL(kern, dim3(grid), dim3(threads), smem, s, r.start, r.stop, 0, a, rows);
+            hipExtLaunchKernelGGL(kern, dim3(grid), dim3(threads), smem, s, r.start, r.stop, 0, a, rows, at);
             return;
         }
-        kern<<<grid, threads, smem, s>>>(a, rows);
+        kern<<<grid, threads, smem, s>>>(a, rows, at);
         return;
     }
     GGML_ASSERT(a.ncols >= 1 && a.ncols <= MV_MAX_COLS);
