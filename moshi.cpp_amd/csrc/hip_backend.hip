@@ -457,6 +457,7 @@ static void emit_generic(emitter & em, ggml_tensor * n) {
 // A. mat-vec with fused activation prologue and residual epilogue. Returns the position at which the
 //    fused kernel must be emitted (the last node of the group), or -1.
 struct mv_group { mv_args a; int emit_pos; std::vector<int> members; };
+static bool match_embed_term(const analysis & an, const ggml_tensor * e, embed_src & out, std::vector<int> & members);
 
 static bool writes_through_alias(const ggml_tensor * n) {
     return n->view_src != NULL && !is_view_op(n->op);
@@ -567,7 +568,29 @@ static bool match_matvec(const analysis & an, int pos, mv_group & grp) {
         const ggml_tensor * other = cons->src[0] == prod ? cons->src[1] : cons->src[0];
         const bool shapes = other != prod && other->type == GGML_TYPE_F32 && ggml_are_same_shape(other, mm) && ggml_are_same_shape(cons, mm) &&
                             other->nb[0] == 4 && cons->nb[0] == 4 && cons->type == GGML_TYPE_F32;
-        if (shapes) {
+        // the addend is one embedding row (moshi_scaled_embedding_chained + cast, lm.h:446-475): gather it in the epilogue
+        std::vector<int> emb_members;
+        embed_src es;
+        const ggml_tensor * term = other;
+        bool embed = false;
+        if (shapes && !scaled && a.wtype == GGML_TYPE_Q4_K && a.ncols == 1 && uses_of(an, other) == 1) {
+            if (term->op == GGML_OP_CPY && term->view_src == NULL && term->src[0]->type == GGML_TYPE_F32 && ggml_are_same_shape(term->src[0], term) && uses_of(an, term->src[0]) == 1) {
+                emb_members.push_back(pos_of(an, term));
+                term = term->src[0];
+            }
+            embed = (term->op == GGML_OP_GET_ROWS || term->op == GGML_OP_MUL) && term->ne[1] == 1 && match_embed_term(an, term, es, emb_members);
+            for (int m : emb_members) if (m < 0 || an.skip[(size_t) m]) embed = false;
+        }
+        if (shapes && embed) for (int i = pos + 1; i < pos_of(an, cons); i++) if (writes_through_alias(an.g->nodes[i])) embed = false;
+        if (shapes && embed) {
+            const int cpos = pos_of(an, cons);
+            a.res_embed = es;
+            a.y = (float *) cons->data;
+            a.y_cs = (int64_t) cons->nb[1] / 4;
+            for (int m : emb_members) grp.members.push_back(m);
+            grp.members.push_back(cpos);
+            grp.emit_pos = cpos;
+        } else if (shapes) {
             const int cpos = pos_of(an, cons);
             bool hazard = false;
             for (int i = pos + 1; i < cpos; i++) if (writes_through_alias(an.g->nodes[i])) hazard = true;
@@ -586,7 +609,7 @@ static bool match_matvec(const analysis & an, int pos, mv_group & grp) {
 }
 
 // B. single-token attention block
-struct attn_group { attn_args a; int emit_pos; std::vector<int> members; };
+struct attn_group { attn_args a; int emit_pos; std::vector<int> members; const ggml_tensor * mask_node; };
 
 static const ggml_tensor * strip_views(const ggml_tensor * t) {
     while (t && (t->op == GGML_OP_RESHAPE || t->op == GGML_OP_VIEW || t->op == GGML_OP_PERMUTE || t->op == GGML_OP_TRANSPOSE)) t = t->src[0];
@@ -711,6 +734,11 @@ static bool match_attention(const analysis & an, int pos, attn_group & grp) {
     a.q_ts = qs.nb[1] / 4; a.q_hs = qs.nb[2] / 4; a.k_ts = ks.nb[1] / 4; a.k_hs = ks.nb[2] / 4; a.v_ts = vs.nb[1] / 4; a.v_hs = vs.nb[2] / 4;
     a.rot = rotr ? (const float *) rotr->data : nullptr;
     a.mask = (const float *) mask->data;
+    grp.mask_node = nullptr;
+    if (mask->op == GGML_OP_CONT && pos_of(an, mask) >= 0) {   // a dense copy of an already dense row: read the source
+        const char * base = resolve_dense(mask);
+        if (base && base != (const char *) mask->data) { a.mask = (const float *) base; grp.mask_node = mask; }
+    }
     a.index = (const int32_t *) idx->data;
     a.kcache = (char *) kc->data; a.vcache = (char *) vc->data;
     a.k_nb1 = (int64_t) kc->nb[1]; a.k_nb2 = (int64_t) kc->nb[2];
@@ -1072,6 +1100,7 @@ static plan_t * build_plan(hip_ctx * c, ggml_cgraph * g) {
     std::map<int, std::vector<step_fn>> at_pos;
     std::vector<attn_group> attn_groups;
     static const bool no_attn_prologue = getenv("MI355X_NO_ATTN_PROLOGUE") != nullptr;
+    static const bool no_argmax_epilogue = getenv("MI355X_NO_ARGMAX_EPILOGUE") != nullptr;
     if (fuse) {
         // attention blocks first (they swallow set_rows / soft_max / two mul_mats); emitted after the mat-vec pass, which may
         // absorb a short-ring attention into the projection that consumes it
@@ -1085,6 +1114,11 @@ static plan_t * build_plan(hip_ctx * c, ggml_cgraph * g) {
             for (int m : grp.members) an.skip[(size_t) m] = 1;
             attn_groups.push_back(grp);
             p->n_fused += (int) grp.members.size();
+        }
+        {   // mask copies that every consumer now bypasses
+            std::map<const ggml_tensor *, int> bypass;
+            for (auto & ag : attn_groups) if (ag.mask_node) bypass[ag.mask_node]++;
+            for (auto & kv : bypass) if (uses_of(an, kv.first) == kv.second) { an.skip[(size_t) pos_of(an, kv.first)] = 1; p->n_fused++; }
         }
         // codec convolutions
         for (int i = 0; i < g->n_nodes; i++) {
@@ -1125,6 +1159,26 @@ static plan_t * build_plan(hip_ctx * c, ggml_cgraph * g) {
             if (clash) continue;
             for (int m : grp.members) an.skip[(size_t) m] = 1;
             mv_args a = grp.a;
+            if (a.wtype == GGML_TYPE_Q4_K && a.ncols == 1 && !no_argmax_epilogue) {
+                // greedy sampling (sampling.h:57-63): argmax of the logits, optionally copied into the token buffer
+                const ggml_tensor * ynode = g->nodes[grp.emit_pos];
+                const ggml_tensor * am = nullptr;
+                int n_am = 0;
+                for (int j = grp.emit_pos + 1; j < g->n_nodes; j++) if (g->nodes[j]->op == GGML_OP_ARGMAX && g->nodes[j]->src[0] == ynode) { am = g->nodes[j]; n_am++; }
+                if (am && n_am == 1 && !an.skip[(size_t) pos_of(an, am)] && (float *) ynode->data == a.y && ggml_nelements(ynode) == a.M && am->data) {
+                    a.argmax_out[0] = (int32_t *) am->data;
+                    an.skip[(size_t) pos_of(an, am)] = 1;
+                    // a copy of the token into an I32 slot
+                    const ggml_tensor * cp = nullptr;
+                    for (int j = pos_of(an, am) + 1; j < g->n_nodes; j++)
+                        if (g->nodes[j]->op == GGML_OP_CPY && g->nodes[j]->src[0] == am && g->nodes[j]->type == GGML_TYPE_I32 && ggml_nelements(g->nodes[j]) == 1) { cp = g->nodes[j]; break; }
+                    if (cp && !an.skip[(size_t) pos_of(an, cp)]) { a.argmax_out[1] = (int32_t *) cp->data; an.skip[(size_t) pos_of(an, cp)] = 1; }
+                    unsigned * tk = (unsigned *) em.ws(256);
+                    HIP_CHECK(hipMemset(tk, 0, 256));
+                    a.ticket = tk;
+                    p->n_fused += 1 + (cp ? 1 : 0);
+                }
+            }
             if (a.prologue == MV_PLAIN && a.wtype == GGML_TYPE_Q4_K && a.ncols == 1 && !no_attn_prologue) {
                 // x is the output of a single-token attention over a short ring (Depth transformer): recompute it in every
                 // workgroup of this projection instead of launching it on its own (16 heads x 8 slots is ~nothing)

@@ -73,6 +73,8 @@ void k_scatter_uploads(hipStream_t s, const upload_desc * descs, const char * bl
 // y = W x (+ residual), x produced on the fly by an optional prologue, for one activation row (T = 1)
 enum mv_prologue { MV_PLAIN = 0, MV_RMSNORM = 1, MV_GATE_SILU = 2, MV_LAYERNORM = 3, MV_GELU = 4, MV_PREQ8K = 5, MV_ATTN = 6 };
 struct attn_args;
+// one (scaled) embedding row: dequant(table[*index]) * *scale
+struct embed_src { const char * table; int64_t row_bytes; int64_t n_rows; int type; const int32_t * index; const float * scale; };
 #define MV_MAX_COLS 4
 struct mv_args {
     int         wtype;          // ggml_type of W
@@ -91,6 +93,9 @@ struct mv_args {
     const float * residual;     // optional, [M, ncols]
     float *     y;              // [M, ncols]
     float *     x_out;          // optional: prologue result written by block 0 (keeps the ggml node materialised)
+    embed_src   res_embed;      // optional (table != NULL, instead of `residual`): y = W x + one embedding row (Q4_K path)
+    int32_t *   argmax_out[2];  // optional (Q4_K path): index of the first maximum of y, written by the last workgroup to finish
+    unsigned *  ticket;         //   ... arrival counter for that (zero between launches)
     const attn_args * attn;     // MV_ATTN: (host pointer) the attention whose output is x; short ring, recomputed per workgroup
 };
 bool k_matvec_supported(int wtype, int64_t K, int64_t M);
@@ -124,7 +129,6 @@ struct attn_args {
 void k_attn_decode(hipStream_t s, const attn_args & a);
 
 // sum of (scaled) embedding rows, left-to-right
-struct embed_src { const char * table; int64_t row_bytes; int64_t n_rows; int type; const int32_t * index; const float * scale; };
 #define EMBED_SUM_MAX 24
 struct embed_sum_args { embed_src src[EMBED_SUM_MAX]; int n; int64_t K; float * out; };
 void k_embed_sum(hipStream_t s, const embed_sum_args & a);

@@ -362,10 +362,49 @@ __global__ void __launch_bounds__(NW * 64) matvec_q4k_kernel(mv_args a, int rows
         sum = row16_allsum_f32(sum);
         if ((tid & 15) == 0) {
             const int64_t row = row0 + rr;
-            a.y[row] = a.residual ? a.residual[row] + sum : sum;
+            if (a.residual) sum = a.residual[row] + sum;
+            else if (a.res_embed.table) {
+                int64_t r = *a.res_embed.index;
+                if (r < 0 || r >= a.res_embed.n_rows) r = 0;
+                float e = dequant_elem(a.res_embed.table + r * a.res_embed.row_bytes, a.res_embed.type, row);
+                if (a.res_embed.scale) e = e * *a.res_embed.scale;
+                sum = sum + e;
+            }
+            a.y[row] = sum;
         }
     }
     MV_STAMP(7);
+    if (a.ticket) {
+        // greedy sampling fused in: the last workgroup to finish scans y for its first maximum (ggml argmax semantics)
+        __shared__ int s_last;
+        __shared__ float am_v[NW];
+        __shared__ int am_i[NW];
+        __threadfence();
+        __syncthreads();
+        if (tid == 0) s_last = atomicAdd(a.ticket, 1u) == gridDim.x - 1;
+        __syncthreads();
+        if (!s_last) return;
+        __threadfence();
+        float best = -INFINITY; int bi = 0x7fffffff;
+        for (int i = tid; i < (int) a.M; i += NW * 64) {
+            const float v = __builtin_nontemporal_load(a.y + i);
+            if (v > best) { best = v; bi = i; }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(best, o, 64); const int oi = __shfl_xor(bi, o, 64);
+            if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+        }
+        if (lane == 0) { am_v[wave] = best; am_i[wave] = bi; }
+        __syncthreads();
+        if (tid == 0) {
+            for (int w = 1; w < NW; w++) if (am_v[w] > best || (am_v[w] == best && am_i[w] < bi)) { best = am_v[w]; bi = am_i[w]; }
+            const int code = bi == 0x7fffffff ? 0 : bi;
+            if (a.argmax_out[0]) *a.argmax_out[0] = code;
+            if (a.argmax_out[1]) *a.argmax_out[1] = code;
+            *a.ticket = 0u;
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------
