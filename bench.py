@@ -22,6 +22,7 @@ import time
 
 import numpy as np
 
+os.environ.setdefault("OMP_WAIT_POLICY", "passive")   # the CPU baseline's OpenMP team must not spin between mat-vecs
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 from __graft_entry__ import load_oracle, load_package  # noqa: E402
@@ -57,7 +58,8 @@ def main():
     ap.add_argument("--context-fill", type=int, default=0, help="start the Temporal KV ring at this fill level")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--cpu-frames", type=int, default=2)
+    ap.add_argument("--cpu-frames", type=int, default=1)
+    ap.add_argument("--cpu-threads", type=int, default=32, help="OpenMP threads of the CPU baseline (capped by the affinity mask)")
     ap.add_argument("--backend-flags", type=int, default=0, help="ggml_backend_mi355x_set_flags bits (2 = no hipGraph: use under rocprofv3)")
     args = ap.parse_args()
 
@@ -169,39 +171,51 @@ def main():
         kp = pkg.KernelProfile()
         L.ggml_backend_mi355x_get_kernel_profile(be, C.byref(kp))
         L.ggml_backend_mi355x_set_flags(be, args.backend_flags)
+        # HBM bytes per launch from the PMC pass committed under profiles/ (rocprofv3 --pmc FETCH_SIZE on this same command,
+        # corrected as MI355X_MICROARCH.md prescribes); counters cannot be read from inside the timed process
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_pmc_fetch_size.json")) as f:
+                traffic = json.load(f)["matvec_q4k_kernel"]["fetch_bytes_per_launch"]
+        except Exception:
+            pass
         if kp.launches:
             gbps = kp.bytes / kp.seconds / 1e9
             result["roofline"] = {"bound": "hbm", "achieved": round(gbps, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                                  "frac": round(gbps / HBM_PEAK_GBPS, 4), "traffic": None,
+                                  "frac": round(gbps / HBM_PEAK_GBPS, 4), "traffic": traffic,
                                   "kernel": "matvec_q4k_kernel", "launches_per_frame": int(kp.launches // 3),
                                   "avg_launch_us": round(1e6 * kp.seconds / kp.launches, 3),
                                   "algorithmic_bytes_per_launch": int(kp.bytes // kp.launches)}
 
     if rank == 0 and not args.no_cpu_baseline:
         # the same frame loop on the host cores through the CPU oracle (a port of ggml's CPU semantics; the reference's
-        # own ggml CPU backend cannot be built here or on the box). Bounded sample.
+        # own ggml CPU backend cannot be built here or on the box). Bounded sample: ~10-30 s of CPU work.
         try:
             olib = load_oracle().load()
             L.ggml_backend_cpu_set_graph_compute(C.cast(olib.oracle_graph_compute, C.c_void_p))
-            cores = os.cpu_count() or 1
+            try:
+                avail = len(os.sched_getaffinity(0))
+            except AttributeError:
+                avail = os.cpu_count() or 1
+            cores = max(1, min(avail, args.cpu_threads))
             cbe = L.ggml_backend_init_by_type(pkg.DEV_CPU, None)
             L.ggml_backend_cpu_set_n_threads(cbe, cores)
             cm = L.moshi_hot_create(cbe, C.byref(cfg), 0)
             cpcm, cout = np.zeros(1920, np.float32), np.zeros(1920, np.float32)
             ctxt, caud = C.c_int32(), (C.c_int32 * 32)()
-            ctoks = []
-            for _ in range(2):   # frame 0 builds the graphs and produces nothing (max_delay = 1)
-                L.moshi_hot_sts_frame(cm, cpcm.ctypes.data, C.byref(ctxt), caud, cout.ctypes.data)
+            # frame 0 builds the graphs and produces nothing (max_delay = 1): untimed warm-up
+            L.moshi_hot_sts_frame(cm, cpcm.ctypes.data, C.byref(ctxt), caud, cout.ctypes.data)
             t0 = time.perf_counter()
             n = 0
-            while n < args.cpu_frames or (time.perf_counter() - t0 < 10 and n < 8):
+            while n < args.cpu_frames or (time.perf_counter() - t0 < 10 and n < 16):
                 L.moshi_hot_sts_frame(cm, cpcm.ctypes.data, C.byref(ctxt), caud, cout.ctypes.data)
-                ctoks.append(ctxt.value)
                 n += 1
+                if time.perf_counter() - t0 > 30:
+                    break
             cdt = time.perf_counter() - t0
             L.moshi_hot_free(cm)
             result["cpu_baseline"] = {"value": round(n / cdt, 4), "unit": "frames/s", "cores": cores, "kind": "port",
-                                      "sample": f"{n} frames of the same moshika-7B q4_k sts loop after 2 warm-up frames, "
+                                      "sample": f"{n} frames ({cdt:.1f} s) of the same moshika-7B q4_k sts loop after 1 warm-up frame, "
                                                 "oracle/liboracle.so (scalar ggml-CPU semantics, OpenMP over mat-vec rows)"}
         except Exception as e:  # the baseline is auxiliary; never lose the GPU number over it
             result["cpu_baseline"] = {"value": None, "unit": "frames/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e}"}

@@ -128,6 +128,25 @@ __device__ __forceinline__ double wave_allsum_f64(double v) {
     const double r3 = __hiloint2double(__builtin_amdgcn_readlane(hi, 48), __builtin_amdgcn_readlane(lo, 48));
     return (r0 + r1) + (r2 + r3);
 }
+__device__ __forceinline__ int wave_allmax_i32(int v) {
+    v = max(v, dpp_i32<DPP_QUAD_XOR1>(v));
+    v = max(v, dpp_i32<DPP_QUAD_XOR2>(v));
+    v = max(v, dpp_i32<DPP_HALF_MIRROR>(v));
+    v = max(v, dpp_i32<DPP_ROW_MIRROR>(v));
+    return max(max(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)), max(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
+}
+// sum over each aligned group of `n` lanes (n = 8 or 16 on the DPP path, any power of two otherwise), result in all of them
+__device__ __forceinline__ double group_allsum_f64(double v, int n) {
+    if (n == 16 || n == 8) {
+        v += dpp_f64<DPP_QUAD_XOR1>(v);
+        v += dpp_f64<DPP_QUAD_XOR2>(v);
+        v += dpp_f64<DPP_HALF_MIRROR>(v);
+        if (n == 16) v += dpp_f64<DPP_ROW_MIRROR>(v);
+        return v;
+    }
+    for (int o = n >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
 // sum over each aligned group of 4 lanes, result in all 4
 __device__ __forceinline__ int quad_allsum_i32(int v) { v += dpp_i32<DPP_QUAD_XOR1>(v); v += dpp_i32<DPP_QUAD_XOR2>(v); return v; }
 // sum over each aligned group of 16 lanes (one DPP row), result in all 16

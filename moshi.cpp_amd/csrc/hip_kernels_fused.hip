@@ -362,7 +362,7 @@ __global__ void __launch_bounds__(NW * 64) matvec_q4k_kernel(mv_args a, int rows
         sum = row16_allsum_f32(sum);
         if ((tid & 15) == 0) {
             const int64_t row = row0 + rr;
-            if (a.residual) sum = a.residual[row] + sum;
+            if (a.residual) sum = a.residual[row] + sum;   // (requesting this before the dot products measured slower: 218 vs 226 fps)
             else if (a.res_embed.table) {
                 int64_t r = *a.res_embed.index;
                 if (r < 0 || r >= a.res_embed.n_rows) r = 0;
@@ -773,7 +773,12 @@ void k_matvec(hipStream_t s, const mv_args & a) {
 // ---------------------------------------------------------------------------------------------------
 #define ATTN_THREADS 256
 #define ATTN_MAX_T 4
+#define ATTN_NPRE 4      // ring-slot passes whose K and V rows are requested at kernel entry (4 passes x 4 waves x SPW slots)
 
+// Latency structure: every global load that does not depend on a computed value - the new q/k/v rows, the RoPE table, the mask,
+// and the K and V ring rows of the first ATTN_NPRE passes - is requested at kernel entry, ahead of the first wait, so a short
+// context costs about one memory round trip; longer contexts stream the remaining rows in the pass loops. Ring rows are valid
+// memory for every slot < C, so the speculative rows are simply discarded where the mask says -inf.
 __global__ void __launch_bounds__(ATTN_THREADS) attn_decode_kernel(attn_args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int D = a.D, C = a.C, T = a.T, h = blockIdx.x;
@@ -782,52 +787,98 @@ __global__ void __launch_bounds__(ATTN_THREADS) attn_decode_kernel(attn_args a) 
     float * qf   = sc + C;                  // [T][D] bf16-rounded rotated q
     float * knew = qf + T * D;              // [T][D] bf16-rounded new k rows
     float * vnew = knew + T * D;            // [T][D] bf16-rounded new v rows
-    double * red = (double *) (vnew + T * D);   // [4][D] partial outputs
+    double * red = (double *) (smem + (((size_t) (C + 3 * T * D) * 4 + 7) & ~(size_t) 7));   // [4 waves][SPW slot groups][D] partial outputs
     __shared__ float sh_f[4];
     __shared__ double sh_d[4];
     __shared__ int sh_i[4];
     __shared__ int sh_slot[ATTN_MAX_T];
 
     char * kc = a.kcache + (int64_t) h * a.k_nb2, * vc = a.vcache + (int64_t) h * a.v_nb2;
-    if (tid < T) sh_slot[tid] = a.index[tid];
-
-    // 1. RoPE + cache write for all T new rows (the reference's set_rows precede the attention of every row)
-    const int half = D / 2;
-    for (int e = tid; e < T * D; e += ATTN_THREADS) {
-        const int t = e / D, j = e - t * D;
-        const float * q = a.q + (int64_t) t * a.q_ts + (int64_t) h * a.q_hs;
-        const float * k = a.k + (int64_t) t * a.k_ts + (int64_t) h * a.k_hs;
-        const float * v = a.v + (int64_t) t * a.v_ts + (int64_t) h * a.v_hs;
-        float qo, ko;
-        if (a.rot) {
-            const int p = j < half ? j : j - half;
-            const float c = a.rot[t * D + p], sn = a.rot[t * D + half + p];
-            const float qr = q[2 * p], qi = q[2 * p + 1], kr = k[2 * p], ki = k[2 * p + 1];
-            if (j < half) { qo = qr * c - qi * sn; ko = kr * c - ki * sn; }
-            else          { qo = qr * sn + qi * c; ko = kr * sn + ki * c; }
-        } else { qo = q[j]; ko = k[j]; }
-        const uint16_t kb = f2bf(ko), vb = f2bf(v[j]);
-        qf[e] = bf2f(f2bf(qo));
-        knew[e] = bf2f(kb);
-        vnew[e] = bf2f(vb);
-        const int slot = a.index[t];
-        if (slot >= 0 && slot < C) {
-            ((uint16_t *) (kc + (int64_t) slot * a.k_nb1))[j] = kb;
-            ((uint16_t *) (vc + (int64_t) slot * a.v_nb1))[j] = vb;
-        }
-    }
-    // live range over all query rows: everything at or beyond n_end is masked (-inf) and contributes exactly 0
-    int last_live = -1;
-    for (int e = tid; e < T * C; e += ATTN_THREADS) if (a.mask[e] > -INFINITY) { const int c = e % C; last_live = c > last_live ? c : last_live; }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) last_live = max(last_live, __shfl_xor(last_live, o, 64));
-    if (lane == 0) sh_i[wave] = last_live;
-    __syncthreads();
-    const int n_end = max(max(sh_i[0], sh_i[1]), max(sh_i[2], sh_i[3])) + 1;
-
     const int LPS = D / 8;              // lanes per slot (16 for D=128, 8 for D=64): 8 dims (16 B) per lane
     const int SPW = 64 / LPS;           // slots per wave-instruction
     const int sub = lane / LPS, dl = (lane % LPS) * 8;
+    const int half = D / 2;
+
+    // ---- entry loads -----------------------------------------------------------------------------------------------
+    int slot_t[ATTN_MAX_T];
+#pragma unroll
+    for (int t = 0; t < ATTN_MAX_T; t++) slot_t[t] = a.index[t < T ? t : 0];
+    // new rows: thread e < T*D handles element (t, j); T*D <= 512 -> at most 2 per thread
+    float in_q0[2], in_q1[2], in_k0[2], in_k1[2], in_v[2], in_c[2], in_s[2];
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+        const int e = tid + u * ATTN_THREADS;
+        const int ee = e < T * D ? e : 0;
+        const int t = ee / D, j = ee - t * D;
+        const float * q = a.q + (int64_t) t * a.q_ts + (int64_t) h * a.q_hs;
+        const float * k = a.k + (int64_t) t * a.k_ts + (int64_t) h * a.k_hs;
+        const float * v = a.v + (int64_t) t * a.v_ts + (int64_t) h * a.v_hs;
+        in_v[u] = v[j];
+        if (a.rot) {
+            const int p = j < half ? j : j - half;
+            in_c[u] = a.rot[t * D + p]; in_s[u] = a.rot[t * D + half + p];
+            in_q0[u] = q[2 * p]; in_q1[u] = q[2 * p + 1]; in_k0[u] = k[2 * p]; in_k1[u] = k[2 * p + 1];
+        } else { in_c[u] = 1.f; in_s[u] = 0.f; in_q0[u] = q[j]; in_q1[u] = 0.f; in_k0[u] = k[j]; in_k1[u] = 0.f; }
+    }
+    // speculative ring rows of the first passes
+    uint4 kpre[ATTN_NPRE], vpre[ATTN_NPRE];
+#pragma unroll
+    for (int pi = 0; pi < ATTN_NPRE; pi++) {
+        const int c = wave * SPW + pi * 4 * SPW + sub;
+        const int cc = c < C ? c : C - 1;
+        kpre[pi] = *(const uint4 *) (kc + (int64_t) cc * a.k_nb1 + dl * 2);
+        vpre[pi] = *(const uint4 *) (vc + (int64_t) cc * a.v_nb1 + dl * 2);
+    }
+    // live range over all query rows: everything at or beyond n_end is masked (-inf) and contributes exactly 0
+    int last_live = -1;
+    if ((C & 3) == 0 && (((uintptr_t) a.mask) & 15) == 0) {   // 16-byte rows: four slots per load, three loads in flight
+        const int n4 = T * C / 4;
+        for (int e0 = tid; e0 < n4; e0 += 3 * ATTN_THREADS) {
+            float4 m4[3];
+#pragma unroll
+            for (int u = 0; u < 3; u++) { const int e = e0 + u * ATTN_THREADS; m4[u] = ((const float4 *) a.mask)[e < n4 ? e : n4 - 1]; }
+#pragma unroll
+            for (int u = 0; u < 3; u++) {
+                const int e = e0 + u * ATTN_THREADS;
+                if (e < n4) {
+                    const int c = (e * 4) % C;
+                    const int hi = m4[u].w > -INFINITY ? 3 : m4[u].z > -INFINITY ? 2 : m4[u].y > -INFINITY ? 1 : m4[u].x > -INFINITY ? 0 : -1;
+                    if (hi >= 0) last_live = max(last_live, c + hi);
+                }
+            }
+        }
+    } else {
+        for (int e = tid; e < T * C; e += ATTN_THREADS) if (a.mask[e] > -INFINITY) { const int c = e % C; last_live = c > last_live ? c : last_live; }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- 1. RoPE + cache write for all T new rows (the reference's set_rows precede the attention of every row) ----------------
+    if (tid < T) sh_slot[tid] = a.index[tid];
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+        const int e = tid + u * ATTN_THREADS;
+        if (e < T * D) {
+            const int t = e / D, j = e - t * D;
+            float qo, ko;
+            if (a.rot) {
+                if (j < half) { qo = in_q0[u] * in_c[u] - in_q1[u] * in_s[u]; ko = in_k0[u] * in_c[u] - in_k1[u] * in_s[u]; }
+                else          { qo = in_q0[u] * in_s[u] + in_q1[u] * in_c[u]; ko = in_k0[u] * in_s[u] + in_k1[u] * in_c[u]; }
+            } else { qo = in_q0[u]; ko = in_k0[u]; }
+            const uint16_t kb = f2bf(ko), vb = f2bf(in_v[u]);
+            qf[e] = bf2f(f2bf(qo));
+            knew[e] = bf2f(kb);
+            vnew[e] = bf2f(vb);
+            const int slot = slot_t[t < ATTN_MAX_T ? t : 0];
+            if (slot >= 0 && slot < C) {
+                ((uint16_t *) (kc + (int64_t) slot * a.k_nb1))[j] = kb;
+                ((uint16_t *) (vc + (int64_t) slot * a.v_nb1))[j] = vb;
+            }
+        }
+    }
+    last_live = wave_allmax_i32(last_live);
+    if (lane == 0) sh_i[wave] = last_live;
+    __syncthreads();
+    const int n_end = max(max(sh_i[0], sh_i[1]), max(sh_i[2], sh_i[3])) + 1;
 
     for (int t = 0; t < T; t++) {
         const float * mask = a.mask + (int64_t) t * C;
@@ -836,19 +887,22 @@ __global__ void __launch_bounds__(ATTN_THREADS) attn_decode_kernel(attn_args a) 
 #pragma unroll
         for (int i = 0; i < 8; i++) qv[i] = qf[t * D + dl + i];
         float lmax = -INFINITY;
-        for (int c0 = wave * SPW; c0 < n_end; c0 += 4 * SPW) {
+        int pi = 0;
+        for (int c0 = wave * SPW; c0 < n_end; c0 += 4 * SPW, pi++) {
             const int c = c0 + sub;
             const float m = c < n_end ? mask[c] : -INFINITY;
             const bool live = m > -INFINITY;
             double acc = 0;
+            int fresh = -1;
+            for (int tt = 0; tt < T; tt++) if (sh_slot[tt] == c) fresh = tt;   // last writer wins, like set_rows
+            uint4 kv;
+            if (pi < ATTN_NPRE) kv = pi == 0 ? kpre[0] : pi == 1 ? kpre[1] : pi == 2 ? kpre[2] : kpre[3];
+            else kv = *(const uint4 *) (kc + (int64_t) (c < C ? c : C - 1) * a.k_nb1 + dl * 2);
             if (live) {
-                int fresh = -1;
-                for (int tt = 0; tt < T; tt++) if (sh_slot[tt] == c) fresh = tt;   // last writer wins, like set_rows
                 if (fresh >= 0) {
 #pragma unroll
                     for (int i = 0; i < 8; i++) acc += (double) (knew[fresh * D + dl + i] * qv[i]);
                 } else {
-                    const uint4 kv = *(const uint4 *) (kc + (int64_t) c * a.k_nb1 + dl * 2);
                     const uint32_t kw[4] = { kv.x, kv.y, kv.z, kv.w };
 #pragma unroll
                     for (int i = 0; i < 4; i++) {
@@ -857,14 +911,14 @@ __global__ void __launch_bounds__(ATTN_THREADS) attn_decode_kernel(attn_args a) 
                     }
                 }
             }
-            for (int o = LPS >> 1; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+            acc = group_allsum_f64(acc, LPS);
             if (c < n_end && (lane % LPS) == 0) {
                 const float sv = live ? (float) acc * a.scale + m : -INFINITY;
                 sc[c] = sv;
                 lmax = fmaxf(lmax, sv);
             }
         }
-        lmax = wave_max_f32(lmax);
+        lmax = wave_allmax_f32(lmax);
         if (lane == 0) sh_f[wave] = lmax;
         __syncthreads();
         const float gmax = fmaxf(fmaxf(sh_f[0], sh_f[1]), fmaxf(sh_f[2], sh_f[3]));
@@ -877,28 +931,29 @@ __global__ void __launch_bounds__(ATTN_THREADS) attn_decode_kernel(attn_args a) 
             sc[c] = e;
             lsum += (double) e;
         }
-        lsum = wave_sum_f64(lsum);
+        lsum = wave_allsum_f64(lsum);
         if (lane == 0) sh_d[wave] = lsum;
         __syncthreads();
-        const float inv = (float) (1.0 / (sh_d[0] + sh_d[1] + sh_d[2] + sh_d[3]));
-        for (int c = tid; c < n_end; c += ATTN_THREADS) sc[c] = bf2f(f2bf(sc[c] * inv));
-        __syncthreads();
+        const float inv = (float) (1.0 / (sh_d[0] + sh_d[1] + sh_d[2] + sh_d[3]));   // p = bf16(e * inv), formed where it is used
 
         // 4. out[d] = sum_c V[d, c] * p[c]
         double o8[8];
 #pragma unroll
         for (int i = 0; i < 8; i++) o8[i] = 0;
-        for (int c0 = wave * SPW; c0 < n_end; c0 += 4 * SPW) {
+        pi = 0;
+        for (int c0 = wave * SPW; c0 < n_end; c0 += 4 * SPW, pi++) {
             const int c = c0 + sub;
-            const float p = c < n_end ? sc[c] : 0.f;
+            const float p = c < n_end ? bf2f(f2bf(sc[c] * inv)) : 0.f;
+            int fresh = -1;
+            for (int tt = 0; tt < T; tt++) if (sh_slot[tt] == c) fresh = tt;
+            uint4 vv;
+            if (pi < ATTN_NPRE) vv = pi == 0 ? vpre[0] : pi == 1 ? vpre[1] : pi == 2 ? vpre[2] : vpre[3];
+            else vv = *(const uint4 *) (vc + (int64_t) (c < C ? c : C - 1) * a.v_nb1 + dl * 2);
             if (p != 0.f) {
-                int fresh = -1;
-                for (int tt = 0; tt < T; tt++) if (sh_slot[tt] == c) fresh = tt;
                 if (fresh >= 0) {
 #pragma unroll
                     for (int i = 0; i < 8; i++) o8[i] += (double) (vnew[fresh * D + dl + i] * p);
                 } else {
-                    const uint4 vv = *(const uint4 *) (vc + (int64_t) c * a.v_nb1 + dl * 2);
                     const uint32_t vw[4] = { vv.x, vv.y, vv.z, vv.w };
 #pragma unroll
                     for (int i = 0; i < 4; i++) {
@@ -909,21 +964,21 @@ __global__ void __launch_bounds__(ATTN_THREADS) attn_decode_kernel(attn_args a) 
             }
         }
 #pragma unroll
-        for (int i = 0; i < 8; i++) for (int o = LPS; o < 64; o <<= 1) o8[i] += __shfl_xor(o8[i], o, 64);
-        if (sub == 0) {
-#pragma unroll
-            for (int i = 0; i < 8; i++) red[wave * D + dl + i] = o8[i];
-        }
+        for (int i = 0; i < 8; i++) red[(wave * SPW + sub) * D + dl + i] = o8[i];
         __syncthreads();
-        for (int j = tid; j < D; j += ATTN_THREADS)
-            a.out[(int64_t) t * a.out_ts + (int64_t) h * D + j] = (float) (red[j] + red[D + j] + red[2 * D + j] + red[3 * D + j]);
+        for (int j = tid; j < D; j += ATTN_THREADS) {
+            double tot = 0;
+#pragma unroll 8
+            for (int g = 0; g < 4 * SPW; g++) tot += red[g * D + j];   // fixed order: wave-major, slot group minor
+            a.out[(int64_t) t * a.out_ts + (int64_t) h * D + j] = (float) tot;
+        }
         __syncthreads();
     }
 }
 
 void k_attn_decode(hipStream_t s, const attn_args & a) {
-    GGML_ASSERT(a.D % 8 == 0 && 64 % (a.D / 8) == 0 && a.D <= 512 && a.T >= 1 && a.T <= ATTN_MAX_T);
-    const size_t smem = (size_t) a.C * 4 + (size_t) a.T * a.D * 4 * 3 + (size_t) (ATTN_THREADS / 64) * a.D * 8 + 16;
+    GGML_ASSERT(a.D % 8 == 0 && 64 % (a.D / 8) == 0 && a.D <= 512 && a.T >= 1 && a.T <= ATTN_MAX_T && a.T * a.D <= 2 * ATTN_THREADS);
+    const size_t smem = (size_t) a.C * 4 + (size_t) a.T * a.D * 4 * 3 + (size_t) (ATTN_THREADS / 64) * 64 * 8 * 8 + 16;
     GGML_ASSERT(smem <= 160 * 1024);
     attn_decode_kernel<<<a.H, ATTN_THREADS, smem, s>>>(a);
 }
