@@ -1208,7 +1208,9 @@ static plan_t * build_plan(hip_ctx * c, ggml_cgraph * g) {
     for (auto & ag : attn_groups) {
         if (ag.emit_pos < 0) continue;
         const attn_args a = ag.a;
-        at_pos[ag.emit_pos].insert(at_pos[ag.emit_pos].begin(), [=](hipStream_t s) { k_attn_decode(s, a); });
+        void * ws = nullptr;
+        if (const size_t n = k_attn_decode_ws_size(a)) { ws = em.ws(n); HIP_CHECK(hipMemset(ws, 0, n)); }   // arrival counters start at zero
+        at_pos[ag.emit_pos].insert(at_pos[ag.emit_pos].begin(), [=](hipStream_t s) { k_attn_decode(s, a, ws); });
     }
     const bool dump = getenv("MI355X_DUMP_PLAN") != nullptr;
     for (int i = 0; i < g->n_nodes; i++) {

@@ -126,7 +126,14 @@ struct attn_args {
     float * out;                // element (d, h, t) at out[t*out_ts + h*D + d]
     int64_t out_ts;
 };
-void k_attn_decode(hipStream_t s, const attn_args & a);
+// Long rings (C >= ATTN_SPLIT_MIN_C, T = 1) are split over ceil(C / ATTN_SPLIT_SLOTS) workgroups per head; `ws` (zeroed once,
+// k_attn_decode_ws_size bytes) carries scores, partial outputs and the per-head arrival counters between them. ws may be NULL
+// for short rings.
+#define ATTN_SPLIT_MIN_C 1024
+#define ATTN_SPLIT_SLOTS 128      // ring slots per workgroup once a head is split
+#define ATTN_SINGLE_MAX 256       // up to this many live slots the head's first workgroup does everything alone
+size_t k_attn_decode_ws_size(const attn_args & a);
+void k_attn_decode(hipStream_t s, const attn_args & a, void * ws = nullptr);
 
 // sum of (scaled) embedding rows, left-to-right
 #define EMBED_SUM_MAX 24

@@ -135,6 +135,15 @@ __device__ __forceinline__ int wave_allmax_i32(int v) {
     v = max(v, dpp_i32<DPP_ROW_MIRROR>(v));
     return max(max(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)), max(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
 }
+// ---- cross-workgroup hand-off without cache-wide fences -------------------------------------------------------------
+// An agent-scope release/acquire fence writes back / invalidates the whole 4 MB L2 of the XCD, which costs many microseconds in
+// the middle of a weight stream. Handed-off values are instead written and read with agent-coherent (sc1) accesses, which go
+// past the non-coherent caches; the producer drains them (workgroup-scope release = s_waitcnt vmcnt(0)) before it bumps the
+// counter (MI355X_MICROARCH.md "Correctness boundaries", second form).
+template <typename V> __device__ __forceinline__ void st_agent(V * p, V v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+template <typename V> __device__ __forceinline__ V ld_agent(const V * p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void drain_stores() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); }
+
 // sum over each aligned group of `n` lanes (n = 8 or 16 on the DPP path, any power of two otherwise), result in all of them
 __device__ __forceinline__ double group_allsum_f64(double v, int n) {
     if (n == 16 || n == 8) {

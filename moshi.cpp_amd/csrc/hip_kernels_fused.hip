@@ -370,7 +370,8 @@ __global__ void __launch_bounds__(NW * 64) matvec_q4k_kernel(mv_args a, int rows
                 if (a.res_embed.scale) e = e * *a.res_embed.scale;
                 sum = sum + e;
             }
-            a.y[row] = sum;
+            if (a.ticket) st_agent(a.y + row, sum);   // read back by whichever workgroup finishes last
+            else a.y[row] = sum;
         }
     }
     MV_STAMP(7);
@@ -379,16 +380,18 @@ __global__ void __launch_bounds__(NW * 64) matvec_q4k_kernel(mv_args a, int rows
         __shared__ int s_last;
         __shared__ float am_v[NW];
         __shared__ int am_i[NW];
-        __threadfence();
+        drain_stores();
         __syncthreads();
         if (tid == 0) s_last = atomicAdd(a.ticket, 1u) == gridDim.x - 1;
         __syncthreads();
         if (!s_last) return;
-        __threadfence();
         float best = -INFINITY; int bi = 0x7fffffff;
-        for (int i = tid; i < (int) a.M; i += NW * 64) {
-            const float v = __builtin_nontemporal_load(a.y + i);
-            if (v > best) { best = v; bi = i; }
+        for (int i0 = tid; i0 < (int) a.M; i0 += 8 * NW * 64) {   // coherent loads, eight in flight
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) { const int i = i0 + u * NW * 64; v[u] = ld_agent(a.y + (i < (int) a.M ? i : (int) a.M - 1)); }
+#pragma unroll
+            for (int u = 0; u < 8; u++) { const int i = i0 + u * NW * 64; if (i < (int) a.M && v[u] > best) { best = v[u]; bi = i; } }
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
@@ -779,11 +782,29 @@ void k_matvec(hipStream_t s, const mv_args & a) {
 // and the K and V ring rows of the first ATTN_NPRE passes - is requested at kernel entry, ahead of the first wait, so a short
 // context costs about one memory round trip; longer contexts stream the remaining rows in the pass loops. Ring rows are valid
 // memory for every slot < C, so the speculative rows are simply discarded where the mask says -inf.
-__global__ void __launch_bounds__(ATTN_THREADS) attn_decode_kernel(attn_args a) {
+//
+// SPLIT (long rings, T = 1): workgroup (h, s) owns ring slots [s * ATTN_SPLIT_SLOTS, +ATTN_SPLIT_SLOTS). Up to ATTN_SINGLE_MAX live
+// slots the head's first workgroup does everything alone (P = 1, exactly the single-workgroup path; the others leave after a
+// mask scan). Beyond that the first P = ceil(n_end / ATTN_SPLIT_SLOTS) workgroups take part: scores of the own slots -> global;
+// arrive + bounded wait on the head's counter; every workgroup then redoes the cheap full soft_max from the published scores, so
+// the probabilities are bit-identical to the single-workgroup path; P x V partials -> global; the last workgroup to arrive adds
+// them in slot order. The wait cannot deadlock: workgroups are dispatched in blockIdx order and a head's workgroups are
+// contiguous, so the lowest unfinished head always has all of its workgroups resident (the spin is bounded regardless).
+struct attn_split_ws { float * scores; float * pmax; double * opart; unsigned * arrive; unsigned * done; int S; };
+
+template <bool SPLIT>
+__global__ void __launch_bounds__(ATTN_THREADS) __attribute__((amdgpu_waves_per_eu(2)))   // >= 2 workgroups per CU: the split grid (<= 512) is resident
+attn_decode_kernel(attn_args a, attn_split_ws w) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int D = a.D, C = a.C, T = a.T, h = blockIdx.x;
+    // passes whose ring rows are requested before the first wait: the whole 256-slot range of a split workgroup, or the first
+    // four passes of the single-workgroup kernel (the rest streams in the pass loops)
+    constexpr int NPRE = SPLIT ? ATTN_SPLIT_SLOTS / 16 : ATTN_NPRE;   // (16 slots per pass at D = 128)
+    const int D = a.D, C = a.C, T = a.T;
+    const int S = SPLIT ? w.S : 1;
+    const int h = SPLIT ? (int) blockIdx.x / S : (int) blockIdx.x, s_idx = SPLIT ? (int) blockIdx.x % S : 0;
+    const int c_base = s_idx * ATTN_SPLIT_SLOTS;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    float * sc   = (float *) smem;          // [C] scores -> probabilities of the current query row
+    float * sc   = (float *) smem;          // [C] scores -> exponentials of the current query row
     float * qf   = sc + C;                  // [T][D] bf16-rounded rotated q
     float * knew = qf + T * D;              // [T][D] bf16-rounded new k rows
     float * vnew = knew + T * D;            // [T][D] bf16-rounded new v rows
@@ -792,12 +813,62 @@ __global__ void __launch_bounds__(ATTN_THREADS) attn_decode_kernel(attn_args a) 
     __shared__ double sh_d[4];
     __shared__ int sh_i[4];
     __shared__ int sh_slot[ATTN_MAX_T];
+    __shared__ int s_last;
 
     char * kc = a.kcache + (int64_t) h * a.k_nb2, * vc = a.vcache + (int64_t) h * a.v_nb2;
     const int LPS = D / 8;              // lanes per slot (16 for D=128, 8 for D=64): 8 dims (16 B) per lane
     const int SPW = 64 / LPS;           // slots per wave-instruction
     const int sub = lane / LPS, dl = (lane % LPS) * 8;
     const int half = D / 2;
+
+    // last un-masked slot at or beyond `from`, over all query rows (the live range ends there: everything later is -inf and
+    // contributes exactly 0). Rows are scanned four slots per load when they are 16-byte aligned.
+    auto scan_last_live = [&](int from) {
+        int last = -1;
+        if ((C & 3) == 0 && (from & 3) == 0 && (((uintptr_t) a.mask) & 15) == 0) {
+            const int row4 = C / 4, from4 = from / 4, per_row = row4 - from4, n4 = T * per_row;
+            for (int e0 = tid; e0 < n4; e0 += 3 * ATTN_THREADS) {
+                float4 m4[3];
+                int cs[3];
+#pragma unroll
+                for (int u = 0; u < 3; u++) {
+                    const int e = e0 + u * ATTN_THREADS, ee = e < n4 ? e : n4 - 1;
+                    const int t = ee / per_row, i4 = from4 + (ee - t * per_row);
+                    cs[u] = i4 * 4;
+                    m4[u] = ((const float4 *) a.mask)[t * row4 + i4];
+                }
+#pragma unroll
+                for (int u = 0; u < 3; u++) {
+                    if (e0 + u * ATTN_THREADS < n4) {
+                        const int hi = m4[u].w > -INFINITY ? 3 : m4[u].z > -INFINITY ? 2 : m4[u].y > -INFINITY ? 1 : m4[u].x > -INFINITY ? 0 : -1;
+                        if (hi >= 0) last = max(last, cs[u] + hi);
+                    }
+                }
+            }
+        } else {
+            const int per_row = C - from;
+            for (int e = tid; e < T * per_row; e += ATTN_THREADS) {
+                const int t = e / per_row, c = from + (e - t * per_row);
+                if (a.mask[t * C + c] > -INFINITY) last = max(last, c);
+            }
+        }
+        return last;
+    };
+    auto block_max_i32 = [&](int v) {
+        v = wave_allmax_i32(v);
+        if (lane == 0) sh_i[wave] = v;
+        __syncthreads();
+        return max(max(sh_i[0], sh_i[1]), max(sh_i[2], sh_i[3]));
+    };
+
+    // A split workgroup other than the head's first only has work when something at or beyond its first slot is live; that
+    // same scan yields n_end. It finds out BEFORE touching the ring (at short context 11 of 12 workgroups leave here).
+    int n_end = 0;
+    if (SPLIT && s_idx > 0) {
+        n_end = block_max_i32(scan_last_live(c_base)) + 1;
+        if (n_end <= ATTN_SINGLE_MAX || n_end <= c_base) return;
+        __syncthreads();
+    }
 
     // ---- entry loads -----------------------------------------------------------------------------------------------
     int slot_t[ATTN_MAX_T];
@@ -820,36 +891,17 @@ __global__ void __launch_bounds__(ATTN_THREADS) attn_decode_kernel(attn_args a) 
             in_q0[u] = q[2 * p]; in_q1[u] = q[2 * p + 1]; in_k0[u] = k[2 * p]; in_k1[u] = k[2 * p + 1];
         } else { in_c[u] = 1.f; in_s[u] = 0.f; in_q0[u] = q[j]; in_q1[u] = 0.f; in_k0[u] = k[j]; in_k1[u] = 0.f; }
     }
-    // speculative ring rows of the first passes
-    uint4 kpre[ATTN_NPRE], vpre[ATTN_NPRE];
+    // ring rows of the first passes; valid memory for every slot < C, discarded where the mask says -inf
+    uint4 kpre[NPRE], vpre[NPRE];
 #pragma unroll
-    for (int pi = 0; pi < ATTN_NPRE; pi++) {
-        const int c = wave * SPW + pi * 4 * SPW + sub;
+    for (int pi = 0; pi < NPRE; pi++) {
+        const int c = c_base + wave * SPW + pi * 4 * SPW + sub;
         const int cc = c < C ? c : C - 1;
         kpre[pi] = *(const uint4 *) (kc + (int64_t) cc * a.k_nb1 + dl * 2);
-        vpre[pi] = *(const uint4 *) (vc + (int64_t) cc * a.v_nb1 + dl * 2);
+        if (pi < ATTN_NPRE) vpre[pi] = *(const uint4 *) (vc + (int64_t) cc * a.v_nb1 + dl * 2);   // later V passes: after the scores (registers)
     }
-    // live range over all query rows: everything at or beyond n_end is masked (-inf) and contributes exactly 0
     int last_live = -1;
-    if ((C & 3) == 0 && (((uintptr_t) a.mask) & 15) == 0) {   // 16-byte rows: four slots per load, three loads in flight
-        const int n4 = T * C / 4;
-        for (int e0 = tid; e0 < n4; e0 += 3 * ATTN_THREADS) {
-            float4 m4[3];
-#pragma unroll
-            for (int u = 0; u < 3; u++) { const int e = e0 + u * ATTN_THREADS; m4[u] = ((const float4 *) a.mask)[e < n4 ? e : n4 - 1]; }
-#pragma unroll
-            for (int u = 0; u < 3; u++) {
-                const int e = e0 + u * ATTN_THREADS;
-                if (e < n4) {
-                    const int c = (e * 4) % C;
-                    const int hi = m4[u].w > -INFINITY ? 3 : m4[u].z > -INFINITY ? 2 : m4[u].y > -INFINITY ? 1 : m4[u].x > -INFINITY ? 0 : -1;
-                    if (hi >= 0) last_live = max(last_live, c + hi);
-                }
-            }
-        }
-    } else {
-        for (int e = tid; e < T * C; e += ATTN_THREADS) if (a.mask[e] > -INFINITY) { const int c = e % C; last_live = c > last_live ? c : last_live; }
-    }
+    if (!SPLIT || s_idx == 0) last_live = scan_last_live(0);
     __builtin_amdgcn_sched_barrier(0);
 
     // ---- 1. RoPE + cache write for all T new rows (the reference's set_rows precede the attention of every row) ----------------
@@ -869,16 +921,30 @@ __global__ void __launch_bounds__(ATTN_THREADS) attn_decode_kernel(attn_args a) 
             knew[e] = bf2f(kb);
             vnew[e] = bf2f(vb);
             const int slot = slot_t[t < ATTN_MAX_T ? t : 0];
-            if (slot >= 0 && slot < C) {
+            if (s_idx == 0 && slot >= 0 && slot < C) {
                 ((uint16_t *) (kc + (int64_t) slot * a.k_nb1))[j] = kb;
                 ((uint16_t *) (vc + (int64_t) slot * a.v_nb1))[j] = vb;
             }
         }
     }
-    last_live = wave_allmax_i32(last_live);
-    if (lane == 0) sh_i[wave] = last_live;
-    __syncthreads();
-    const int n_end = max(max(sh_i[0], sh_i[1]), max(sh_i[2], sh_i[3])) + 1;
+    if (!SPLIT || s_idx == 0) n_end = block_max_i32(last_live) + 1;
+    else __syncthreads();
+    const int P = SPLIT && n_end > ATTN_SINGLE_MAX ? (n_end + ATTN_SPLIT_SLOTS - 1) / ATTN_SPLIT_SLOTS : 1;   // participating workgroups of this head
+    const bool multi = SPLIT && P > 1;
+    const int c_lo = multi ? c_base : 0, c_hi = multi ? min(n_end, c_base + ATTN_SPLIT_SLOTS) : n_end;   // slots whose K / V rows this workgroup reads
+    // a prefetched row may be the slot that was just rewritten (last writer wins, like set_rows): take it from LDS instead
+    auto pack_row = [&](const float * src) {
+        uint4 r;
+        r.x = (uint32_t) f2bf(src[0]) | ((uint32_t) f2bf(src[1]) << 16); r.y = (uint32_t) f2bf(src[2]) | ((uint32_t) f2bf(src[3]) << 16);
+        r.z = (uint32_t) f2bf(src[4]) | ((uint32_t) f2bf(src[5]) << 16); r.w = (uint32_t) f2bf(src[6]) | ((uint32_t) f2bf(src[7]) << 16);
+        return r;   // knew / vnew hold bf16-representable floats: the round trip is exact
+    };
+    auto fresh_of = [&](int c) { int f = -1; for (int tt = 0; tt < T; tt++) if (slot_t[tt] == c) f = tt; return f; };
+#pragma unroll
+    for (int pi = 0; pi < NPRE; pi++) {
+        const int f = fresh_of(c_base + wave * SPW + pi * 4 * SPW + sub);
+        if (f >= 0) { kpre[pi] = pack_row(knew + f * D + dl); if (pi < ATTN_NPRE) vpre[pi] = pack_row(vnew + f * D + dl); }
+    }
 
     for (int t = 0; t < T; t++) {
         const float * mask = a.mask + (int64_t) t * C;
@@ -887,41 +953,75 @@ __global__ void __launch_bounds__(ATTN_THREADS) attn_decode_kernel(attn_args a) 
 #pragma unroll
         for (int i = 0; i < 8; i++) qv[i] = qf[t * D + dl + i];
         float lmax = -INFINITY;
-        int pi = 0;
-        for (int c0 = wave * SPW; c0 < n_end; c0 += 4 * SPW, pi++) {
+        auto score_pass = [&](int c0, const uint4 kv) {
             const int c = c0 + sub;
-            const float m = c < n_end ? mask[c] : -INFINITY;
+            const float m = c < c_hi ? mask[c] : -INFINITY;
             const bool live = m > -INFINITY;
+            const uint32_t kw[4] = { kv.x, kv.y, kv.z, kv.w };
             double acc = 0;
-            int fresh = -1;
-            for (int tt = 0; tt < T; tt++) if (sh_slot[tt] == c) fresh = tt;   // last writer wins, like set_rows
-            uint4 kv;
-            if (pi < ATTN_NPRE) kv = pi == 0 ? kpre[0] : pi == 1 ? kpre[1] : pi == 2 ? kpre[2] : kpre[3];
-            else kv = *(const uint4 *) (kc + (int64_t) (c < C ? c : C - 1) * a.k_nb1 + dl * 2);
-            if (live) {
-                if (fresh >= 0) {
 #pragma unroll
-                    for (int i = 0; i < 8; i++) acc += (double) (knew[fresh * D + dl + i] * qv[i]);
-                } else {
-                    const uint32_t kw[4] = { kv.x, kv.y, kv.z, kv.w };
-#pragma unroll
-                    for (int i = 0; i < 4; i++) {
-                        acc += (double) (bf2f((uint16_t) (kw[i] & 0xffff)) * qv[2 * i]);
-                        acc += (double) (bf2f((uint16_t) (kw[i] >> 16)) * qv[2 * i + 1]);
-                    }
-                }
+            for (int i = 0; i < 4; i++) {
+                acc += (double) (bf2f((uint16_t) (kw[i] & 0xffff)) * qv[2 * i]);
+                acc += (double) (bf2f((uint16_t) (kw[i] >> 16)) * qv[2 * i + 1]);
             }
             acc = group_allsum_f64(acc, LPS);
-            if (c < n_end && (lane % LPS) == 0) {
+            if (c < c_hi && (lane % LPS) == 0) {
                 const float sv = live ? (float) acc * a.scale + m : -INFINITY;
                 sc[c] = sv;
+                if (multi) st_agent(w.scores + (int64_t) h * C + c, sv);
                 lmax = fmaxf(lmax, sv);
+            }
+        };
+#pragma unroll
+        for (int pi = 0; pi < NPRE; pi++) {
+            const int c0 = c_lo + wave * SPW + pi * 4 * SPW;
+            if (c0 < c_hi) score_pass(c0, kpre[pi]);
+        }
+        for (int c0 = c_lo + wave * SPW + NPRE * 4 * SPW; c0 < c_hi; c0 += 4 * SPW) {
+            const int c = c0 + sub, f = fresh_of(c);
+            uint4 kv = *(const uint4 *) (kc + (int64_t) (c < C ? c : C - 1) * a.k_nb1 + dl * 2);
+            if (f >= 0) kv = pack_row(knew + f * D + dl);
+            score_pass(c0, kv);
+        }
+        if (NPRE > ATTN_NPRE) {
+            // the remaining V rows of a split workgroup go out now (the K registers are free) and arrive during the head-wide wait
+#pragma unroll
+            for (int pi = ATTN_NPRE; pi < NPRE; pi++) {
+                const int c = c_base + wave * SPW + pi * 4 * SPW + sub;
+                vpre[pi] = *(const uint4 *) (vc + (int64_t) (c < C ? c : C - 1) * a.v_nb1 + dl * 2);
+                const int f = fresh_of(c);
+                if (f >= 0) vpre[pi] = pack_row(vnew + f * D + dl);
             }
         }
         lmax = wave_allmax_f32(lmax);
         if (lane == 0) sh_f[wave] = lmax;
+        if (multi) drain_stores();   // this wave's published scores have left before the barrier below
         __syncthreads();
-        const float gmax = fmaxf(fmaxf(sh_f[0], sh_f[1]), fmaxf(sh_f[2], sh_f[3]));
+        float gmax = fmaxf(fmaxf(sh_f[0], sh_f[1]), fmaxf(sh_f[2], sh_f[3]));
+        if (multi) {
+            // publish, arrive, wait for the other P - 1 workgroups of this head, then pull everybody's scores
+            if (tid == 0) {
+                st_agent(w.pmax + h * S + s_idx, gmax);
+                drain_stores();
+                atomicAdd(w.arrive + h, 1u);
+                int spins = 0;
+                while (ld_agent(w.arrive + h) < (unsigned) P && ++spins < (1 << 22)) __builtin_amdgcn_s_sleep(2);
+            }
+            __syncthreads();
+            // (coherent loads cost a full memory round trip each: request them eight at a time)
+            for (int c0 = tid; c0 < n_end; c0 += 8 * ATTN_THREADS) {
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) { const int c = c0 + u * ATTN_THREADS; v[u] = ld_agent(w.scores + (int64_t) h * C + (c < n_end ? c : n_end - 1)); }
+#pragma unroll
+                for (int u = 0; u < 8; u++) { const int c = c0 + u * ATTN_THREADS; if (c < n_end && (c < c_lo || c >= c_hi)) sc[c] = v[u]; }
+            }
+            {
+                const float pm = ld_agent(w.pmax + h * S + (lane < P ? lane : 0));   // P <= 24 < 64
+                gmax = fmaxf(gmax, wave_allmax_f32(lane < P ? pm : -INFINITY));
+            }
+            __syncthreads();
+        }
 
         // 3. soft_max: exp in float, sum in double, scale by (float)(1/sum), round to BF16 for the V product
         double lsum = 0;
@@ -940,28 +1040,26 @@ __global__ void __launch_bounds__(ATTN_THREADS) attn_decode_kernel(attn_args a) 
         double o8[8];
 #pragma unroll
         for (int i = 0; i < 8; i++) o8[i] = 0;
-        pi = 0;
-        for (int c0 = wave * SPW; c0 < n_end; c0 += 4 * SPW, pi++) {
+        auto pv_pass = [&](int c0, const uint4 vv) {
             const int c = c0 + sub;
-            const float p = c < n_end ? bf2f(f2bf(sc[c] * inv)) : 0.f;
-            int fresh = -1;
-            for (int tt = 0; tt < T; tt++) if (sh_slot[tt] == c) fresh = tt;
-            uint4 vv;
-            if (pi < ATTN_NPRE) vv = pi == 0 ? vpre[0] : pi == 1 ? vpre[1] : pi == 2 ? vpre[2] : vpre[3];
-            else vv = *(const uint4 *) (vc + (int64_t) (c < C ? c : C - 1) * a.v_nb1 + dl * 2);
-            if (p != 0.f) {
-                if (fresh >= 0) {
+            const float p = c < c_hi ? bf2f(f2bf(sc[c] * inv)) : 0.f;   // masked slots: e = 0 -> p = 0 -> contributes exactly 0
+            const uint32_t vw[4] = { vv.x, vv.y, vv.z, vv.w };
 #pragma unroll
-                    for (int i = 0; i < 8; i++) o8[i] += (double) (vnew[fresh * D + dl + i] * p);
-                } else {
-                    const uint32_t vw[4] = { vv.x, vv.y, vv.z, vv.w };
-#pragma unroll
-                    for (int i = 0; i < 4; i++) {
-                        o8[2 * i]     += (double) (bf2f((uint16_t) (vw[i] & 0xffff)) * p);
-                        o8[2 * i + 1] += (double) (bf2f((uint16_t) (vw[i] >> 16)) * p);
-                    }
-                }
+            for (int i = 0; i < 4; i++) {
+                o8[2 * i]     += (double) (bf2f((uint16_t) (vw[i] & 0xffff)) * p);
+                o8[2 * i + 1] += (double) (bf2f((uint16_t) (vw[i] >> 16)) * p);
             }
+        };
+#pragma unroll
+        for (int pi = 0; pi < NPRE; pi++) {
+            const int c0 = c_lo + wave * SPW + pi * 4 * SPW;
+            if (c0 < c_hi) pv_pass(c0, vpre[pi]);
+        }
+        for (int c0 = c_lo + wave * SPW + NPRE * 4 * SPW; c0 < c_hi; c0 += 4 * SPW) {
+            const int c = c0 + sub, f = fresh_of(c);
+            uint4 vv = *(const uint4 *) (vc + (int64_t) (c < C ? c : C - 1) * a.v_nb1 + dl * 2);
+            if (f >= 0) vv = pack_row(vnew + f * D + dl);
+            pv_pass(c0, vv);
         }
 #pragma unroll
         for (int i = 0; i < 8; i++) red[(wave * SPW + sub) * D + dl + i] = o8[i];
@@ -970,17 +1068,58 @@ __global__ void __launch_bounds__(ATTN_THREADS) attn_decode_kernel(attn_args a) 
             double tot = 0;
 #pragma unroll 8
             for (int g = 0; g < 4 * SPW; g++) tot += red[g * D + j];   // fixed order: wave-major, slot group minor
-            a.out[(int64_t) t * a.out_ts + (int64_t) h * D + j] = (float) tot;
+            if (multi) st_agent(w.opart + ((int64_t) h * S + s_idx) * D + j, tot);
+            else a.out[(int64_t) t * a.out_ts + (int64_t) h * D + j] = (float) tot;
+        }
+        if (multi) {
+            // the last of the P workgroups to get here adds the partial outputs in slot order and re-arms the counters
+            drain_stores();
+            __syncthreads();
+            if (tid == 0) s_last = atomicAdd(w.done + h, 1u) == (unsigned) (P - 1);
+            __syncthreads();
+            if (s_last) {
+                for (int j = tid; j < D; j += ATTN_THREADS) {
+                    double tot = 0;
+                    for (int q0 = 0; q0 < P; q0 += 8) {
+                        double v[8];
+#pragma unroll
+                        for (int u = 0; u < 8; u++) v[u] = ld_agent(w.opart + ((int64_t) h * S + (q0 + u < P ? q0 + u : P - 1)) * D + j);
+#pragma unroll
+                        for (int u = 0; u < 8; u++) if (q0 + u < P) tot += v[u];   // slot order
+                    }
+                    a.out[(int64_t) t * a.out_ts + (int64_t) h * D + j] = (float) tot;
+                }
+                if (tid == 0) { st_agent(w.arrive + h, 0u); st_agent(w.done + h, 0u); }
+            }
         }
         __syncthreads();
     }
 }
 
-void k_attn_decode(hipStream_t s, const attn_args & a) {
+static bool attn_use_split(const attn_args & a) { return a.T == 1 && a.D == 128 && a.C >= ATTN_SPLIT_MIN_C; }
+size_t k_attn_decode_ws_size(const attn_args & a) {
+    if (!attn_use_split(a)) return 0;
+    const size_t S = (size_t) (a.C + ATTN_SPLIT_SLOTS - 1) / ATTN_SPLIT_SLOTS;
+    return (size_t) a.H * a.C * 4 + (size_t) a.H * S * 4 + (size_t) a.H * S * a.D * 8 + (size_t) a.H * 8 + 256;
+}
+void k_attn_decode(hipStream_t s, const attn_args & a, void * ws) {
     GGML_ASSERT(a.D % 8 == 0 && 64 % (a.D / 8) == 0 && a.D <= 512 && a.T >= 1 && a.T <= ATTN_MAX_T && a.T * a.D <= 2 * ATTN_THREADS);
     const size_t smem = (size_t) a.C * 4 + (size_t) a.T * a.D * 4 * 3 + (size_t) (ATTN_THREADS / 64) * 64 * 8 * 8 + 16;
     GGML_ASSERT(smem <= 160 * 1024);
-    attn_decode_kernel<<<a.H, ATTN_THREADS, smem, s>>>(a);
+    attn_split_ws w = { nullptr, nullptr, nullptr, nullptr, nullptr, 1 };
+    if (ws && attn_use_split(a)) {
+        const int S = (a.C + ATTN_SPLIT_SLOTS - 1) / ATTN_SPLIT_SLOTS;
+        GGML_ASSERT(a.D == 128 && "split prefetch depth is sized for 16 slots per pass");
+        char * p = (char *) ws;
+        w.arrive = (unsigned *) p; w.done = w.arrive + a.H; p += ((size_t) a.H * 8 + 255) & ~(size_t) 255;
+        w.opart = (double *) p; p += (size_t) a.H * S * a.D * 8;
+        w.scores = (float *) p; p += (size_t) a.H * a.C * 4;
+        w.pmax = (float *) p;
+        w.S = S;
+        attn_decode_kernel<true><<<a.H * S, ATTN_THREADS, smem, s>>>(a, w);
+        return;
+    }
+    attn_decode_kernel<false><<<a.H, ATTN_THREADS, smem, s>>>(a, w);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1047,17 +1186,16 @@ __global__ void __launch_bounds__(256) vq_level_kernel(vq_level_args a) {
     __syncthreads();
     if (tid == 0) {
         for (int w = 1; w < 4; w++) if (sv[w] > best || (sv[w] == best && si[w] < bi)) { best = sv[w]; bi = si[w]; }
-        a.cand_val[blockIdx.x] = best; a.cand_idx[blockIdx.x] = bi;
-        __threadfence();
+        st_agent(a.cand_val + blockIdx.x, best); st_agent(a.cand_idx + blockIdx.x, bi);
+        drain_stores();
         const unsigned ticket = atomicAdd(a.counter, 1u);
         s_last = ticket == gridDim.x - 1;
     }
     __syncthreads();
     if (!s_last) return;
-    __threadfence();
     // merge: candidates are few (<= 256), one per thread
     best = -INFINITY; bi = 0x7fffffff;
-    if (tid < (int) gridDim.x) { best = __builtin_nontemporal_load(a.cand_val + tid); bi = __builtin_nontemporal_load(a.cand_idx + tid); }
+    if (tid < (int) gridDim.x) { best = ld_agent(a.cand_val + tid); bi = ld_agent(a.cand_idx + tid); }
     __shared__ float mv[256];
     __shared__ int mi[256];
     mv[tid] = best; mi[tid] = bi;
