@@ -859,7 +859,8 @@ static bool match_conv(const analysis & an, int pos, step_group & grp) {
     if (!out || out->op != GGML_OP_RESHAPE || out->ne[2] != 1) return false;
     members.push_back(pos_of(an, out));
     const int64_t OL = out->ne[0], Cout = out->ne[1];
-    mm_epilogue epi = { nullptr, nullptr, 0, 0 };
+    mm_epilogue epi;
+    memset(&epi, 0, sizeof(epi));
     const ggml_tensor * nx = sole_consumer(an, out);
     if (nx && nx->op == GGML_OP_ADD && !nx->view_src && nx->src[0] == out && nx->src[1]->op == GGML_OP_NONE && nx->src[1]->type == GGML_TYPE_F32 && nx->src[1]->ne[0] == 1 &&
         nx->src[1]->ne[1] == Cout && ggml_nelements(nx->src[1]) == Cout && ggml_is_contiguous(nx->src[1])) {
@@ -879,7 +880,10 @@ static bool match_conv(const analysis & an, int pos, step_group & grp) {
     float * pv = prev ? (float *) prev->data : nullptr;
     grp.steps.clear();
     grp.steps.push_back([=](hipStream_t s) { k_stream_im2col(s, d_im, pv, TP, d_x, Kw, s0, pre_elu); });
-    if (TP > 0) grp.steps.push_back([=](hipStream_t s) { k_conv_tail(s, pv, TP, d_x, pre_elu); });
+    if (TP > 0) {   // the tail update rides on the product kernel (it must follow the im2col, which reads the old tail)
+        epi.tail_prev = pv; epi.tail_TP = TP; epi.tail_pre_elu = pre_elu; epi.tail_L = (int) xin->ne[0]; epi.tail_C = Cin;
+        epi.tail_x = (const char *) xin->data; epi.tail_nb0 = (int64_t) xin->nb[0]; epi.tail_nb1 = (int64_t) xin->nb[1];
+    }
     grp.steps.push_back([=](hipStream_t s) { k_mul_mat(s, d_out, d_im, d_w, nullptr, &epi); });
     grp.members = members;
     grp.emit_pos = pos_of(an, out);

@@ -54,7 +54,10 @@ void k_timestep_embedding(hipStream_t s, tdesc dst, tdesc ts, int dim, int max_p
 // (q8_K / q8_0 / f16 / bf16) into `ws` (size from k_mul_mat_ws_size), then dotted
 size_t k_mul_mat_ws_size(const struct ggml_tensor * a, const struct ggml_tensor * b);
 // optional fused epilogue of the dense product: dst[m, n] = residual[m, n] + (dot + bias[n])  (ggml order: add(y, bias) then add(u, y))
-struct mm_epilogue { const float * bias; const char * residual; int64_t res_nb0, res_nb1; };
+//   side job of workgroup 0 (streaming conv): prev <- last TP samples of concat(prev, act(x)), which the preceding im2col has
+//   finished reading (moshi_streaming_conv_1d's tail copy, conv.h:60-75)
+struct mm_epilogue { const float * bias; const char * residual; int64_t res_nb0, res_nb1;
+                     float * tail_prev; int tail_TP, tail_pre_elu, tail_L, tail_C; const char * tail_x; int64_t tail_nb0, tail_nb1; };
 void k_mul_mat(hipStream_t s, tdesc dst, tdesc a, tdesc b, void * ws, const mm_epilogue * epi = nullptr);
 // streaming conv1d helpers (moshi_streaming_conv_1d, conv.h:50-96): F16 im2col straight from (carried tail, new samples) with an
 // optional ELU on the new samples, and the tail update

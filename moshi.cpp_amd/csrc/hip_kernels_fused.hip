@@ -146,6 +146,7 @@ __device__ __forceinline__ void attn_small_wave4(const attn_args & a, int h0, in
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    double osum[4][8], ohalf[4];
 #pragma unroll
     for (int hh = 0; hh < 4; hh++) {
         const float * qf = wbuf + hh * 192, * knew = qf + 64, * vnew = qf + 128;
@@ -166,7 +167,7 @@ __device__ __forceinline__ void attn_small_wave4(const attn_args & a, int h0, in
                 }
             }
         }
-        for (int o = LPS >> 1; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+        acc = group_allsum_f64(acc, LPS);
         const float sv = live ? (float) acc * a.scale + m : -INFINITY;
         const float gmax = wave_allmax_f32(sv);
         const float e = sv > -INFINITY ? expf(sv - gmax) : 0.f;
@@ -191,11 +192,30 @@ __device__ __forceinline__ void attn_small_wave4(const attn_args & a, int h0, in
             }
         }
 #pragma unroll
-        for (int i = 0; i < 8; i++) for (int o = LPS; o < 64; o <<= 1) o8[i] += __shfl_xor(o8[i], o, 64);
-        if (sub == 0) {
+        for (int i = 0; i < 8; i++) osum[hh][i] = o8[i];   // summed over the 8 slot groups below, through LDS (48 cross-lane permutes per head otherwise)
+    }
+    // cross-group sums for all four heads at once, through the wave's output buffer region
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    double * ored = (double *) wbuf;   // the q/k/v scratch (768 floats) is dead by now: 4 groups x 64 dims of doubles per round
 #pragma unroll
-            for (int i = 0; i < 8; i++) xa[hh * 64 + dl + i] = (float) o8[i];
+    for (int hh = 0; hh < 4; hh++) {
+        // two rounds of 4 slot groups each (8 x 64 doubles would not fit the scratch); lane j ends up with dim j
+#pragma unroll
+        for (int half_g = 0; half_g < 2; half_g++) {
+            if ((sub >> 2) == half_g) {
+#pragma unroll
+                for (int i = 0; i < 8; i++) ored[(sub & 3) * 64 + dl + i] = osum[hh][i];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const double part = (ored[lane] + ored[64 + lane]) + (ored[128 + lane] + ored[192 + lane]);
+            if (half_g == 0) ohalf[hh] = part; else ohalf[hh] = ohalf[hh] + part;
+            __builtin_amdgcn_wave_barrier();
         }
+        xa[hh * 64 + lane] = (float) ohalf[hh];
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -1129,14 +1149,29 @@ void k_attn_decode(hipStream_t s, const attn_args & a, void * ws) {
 __global__ void embed_sum_kernel(embed_sum_args a) {
     const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= a.K) return;
+    // three dependent round trips in total (indices, rows, done) instead of one per table: the row index and scale of every
+    // term are requested first, then every row element, then the left-to-right sum
+    int64_t r[EMBED_SUM_MAX];
+    float sc[EMBED_SUM_MAX], v[EMBED_SUM_MAX];
+#pragma unroll
+    for (int t = 0; t < EMBED_SUM_MAX; t++) {
+        const embed_src & e = a.src[t < a.n ? t : 0];
+        r[t] = *e.index;
+        sc[t] = e.scale ? *e.scale : 1.f;
+    }
+#pragma unroll
+    for (int t = 0; t < EMBED_SUM_MAX; t++) {
+        const embed_src & e = a.src[t < a.n ? t : 0];
+        if (r[t] < 0 || r[t] >= e.n_rows) r[t] = 0;
+        v[t] = dequant_elem(e.table + r[t] * e.row_bytes, e.type, i);
+    }
     float acc = 0.f;
-    for (int t = 0; t < a.n; t++) {
-        const embed_src & e = a.src[t];
-        int64_t r = *e.index;
-        if (r < 0 || r >= e.n_rows) r = 0;
-        float v = dequant_elem(e.table + r * e.row_bytes, e.type, i);
-        if (e.scale) v = v * *e.scale;
-        acc = t == 0 ? v : acc + v;
+#pragma unroll
+    for (int t = 0; t < EMBED_SUM_MAX; t++) {
+        if (t < a.n) {
+            const float x = a.src[t].scale ? v[t] * sc[t] : v[t];
+            acc = t == 0 ? x : acc + x;
+        }
     }
     a.out[i] = acc;
 }

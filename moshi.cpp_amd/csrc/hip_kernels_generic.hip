@@ -656,7 +656,27 @@ __global__ void convert_rows_kernel(tdesc b, int vt, char * ws, int64_t row_byte
 }
 
 // one wave per output element; lanes stride the K dimension (in blocks for quantised types)
+// streaming-conv tail update folded into the product kernel (workgroup 0 only; reads complete before the writes per channel)
+__device__ __forceinline__ void mm_tail_job(const mm_epilogue & e) {
+    if (e.tail_prev == nullptr || blockIdx.x != 0) return;
+    const int TP = e.tail_TP, L = e.tail_L;
+    for (int ci = threadIdx.x; ci < e.tail_C; ci += blockDim.x) {
+        float v[32];
+#pragma unroll
+        for (int j = 0; j < 32; j++) {
+            if (j < TP) {
+                const int l = L + j;   // index into the concatenation (prev | x)
+                if (l < TP) v[j] = e.tail_prev[l + (int64_t) ci * TP];
+                else { const float t = *(const float *) (e.tail_x + (int64_t) (l - TP) * e.tail_nb0 + (int64_t) ci * e.tail_nb1); v[j] = e.tail_pre_elu ? (t > 0.f ? t : expm1f(t)) : t; }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 32; j++) if (j < TP) e.tail_prev[j + (int64_t) ci * TP] = v[j];
+    }
+}
+
 __global__ void mul_mat_kernel(tdesc dst, tdesc a, tdesc b, const char * ws, int64_t ws_row_bytes, int vt, int64_t total, mm_epilogue epi) {
+    mm_tail_job(epi);
     const int lane = threadIdx.x & 63;
     const int64_t o = (int64_t) blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (o >= total) return;
@@ -719,6 +739,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // four fragment pairs before the first MFMA.
 __global__ void __launch_bounds__(1024) mul_mat_f16_mfma_kernel(tdesc dst, tdesc a, tdesc b, int mt, int nt, int SK, int TPW, mm_epilogue epi) {
     __shared__ f32x4 red[16][64];
+    mm_tail_job(epi);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int slice = wave % SK, tw = wave / SK;
     const int tile = blockIdx.x * TPW + tw;
@@ -765,6 +786,7 @@ __global__ void __launch_bounds__(1024) mul_mat_f16_mfma_kernel(tdesc dst, tdesc
 // few activation rows (M = a.ne1 <= 8) against many weight rows in `b`: one wave per b row, b read once; four 16-byte chunks
 // of the b row are requested before any arithmetic
 __global__ void __launch_bounds__(256) mul_mat_smallm_kernel(tdesc dst, tdesc a, tdesc b, int M, int N, mm_epilogue epi) {
+    mm_tail_job(epi);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int n = blockIdx.x * 4 + wave;
     if (n >= N) return;
@@ -806,9 +828,10 @@ __global__ void __launch_bounds__(256) mul_mat_smallm_kernel(tdesc dst, tdesc a,
 
 // short rows (K <= 64, e.g. the first SEANet conv: 1 input channel x 7 taps): one thread per output element
 __global__ void mul_mat_f16_shortk_kernel(tdesc dst, tdesc a, tdesc b, int K, int M, int64_t total, mm_epilogue epi) {
+    mm_tail_job(epi);
     const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
-    const int m = (int) (i % M), n = (int) (i / M);
+    const uint32_t n = (uint32_t) i / (uint32_t) M, m = (uint32_t) i - n * (uint32_t) M;
     const uint16_t * ap = (const uint16_t *) (a.data + (int64_t) m * a.nb[1]);
     const uint16_t * bp = (const uint16_t *) (b.data + (int64_t) n * b.nb[1]);
     double acc = 0;
@@ -822,10 +845,11 @@ __global__ void mul_mat_f16_shortk_kernel(tdesc dst, tdesc a, tdesc b, int K, in
 void k_mul_mat(hipStream_t s, tdesc dst, tdesc a, tdesc b, void * ws, const mm_epilogue * epi_) {
     const int64_t total = td_nelements(dst);
     if (total == 0) return;
-    mm_epilogue epi = { nullptr, nullptr, 0, 0 };
+    mm_epilogue epi;
+    memset(&epi, 0, sizeof(epi));
     if (epi_) epi = *epi_;
     if (a.type == GGML_TYPE_F16 && b.type == GGML_TYPE_F16 && a.nb[0] == 2 && b.nb[0] == 2 && a.ne[2] * a.ne[3] * b.ne[2] * b.ne[3] == 1 &&
-        a.ne[0] <= 64 && a.ne[1] >= 256) {
+        a.ne[0] < 32 && a.ne[1] >= 256) {
         mul_mat_f16_shortk_kernel<<<nblocks(total), BLOCK, 0, s>>>(dst, a, b, (int) a.ne[0], (int) a.ne[1], total, epi);
         return;
     }
