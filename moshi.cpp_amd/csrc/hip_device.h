@@ -135,6 +135,15 @@ __device__ __forceinline__ int wave_allmax_i32(int v) {
     v = max(v, dpp_i32<DPP_ROW_MIRROR>(v));
     return max(max(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)), max(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
 }
+// Workgroup barrier for data exchanged through LDS only. __syncthreads() also waits for every outstanding global load of the
+// wave (vmcnt(0) on gfx9), which would serialise a prologue behind the weight tile / ring rows it deliberately left in flight;
+// this one waits for LDS traffic only (s_waitcnt lgkmcnt(0); s_barrier).
+__device__ __forceinline__ void lds_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 // ---- cross-workgroup hand-off without cache-wide fences -------------------------------------------------------------
 // An agent-scope release/acquire fence writes back / invalidates the whole 4 MB L2 of the XCD, which costs many microseconds in
 // the middle of a weight stream. Handed-off values are instead written and read with agent-coherent (sc1) accesses, which go
