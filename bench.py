@@ -35,6 +35,8 @@ def reduce_max_time(dist, dt, device="cuda"):
     if dist is None:
         return dt
     import torch
+    if dist.get_backend() == "gloo":
+        device = "cpu"
     tt = torch.tensor([dt], device=device, dtype=torch.float64)
     dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     return float(tt.item())
@@ -71,7 +73,11 @@ def main():
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        try:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))   # RCCL; control plane only (barrier + max)
+        except Exception as e:   # the data path has no collective: a host-side rendezvous is enough to time the replicas
+            print(f"bench.py: RCCL init failed on rank {rank} ({e}); falling back to gloo for the barrier", file=sys.stderr)
+            dist.init_process_group("gloo")
 
     pkg = load_package()
     L = pkg.load()

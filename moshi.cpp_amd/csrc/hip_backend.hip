@@ -61,6 +61,9 @@ struct hip_ctx {
     double prof_seconds = 0; int64_t prof_launches = 0, prof_bytes = 0;
     // cached plans keyed by cgraph pointer
     std::unordered_map<const ggml_cgraph *, plan_t *> plans;
+    // device-visible error word in pinned host memory: kernels with bounded waits raise it instead of hanging
+    volatile unsigned * err_host = nullptr;
+    unsigned * err_dev = nullptr;
     ggml_backend_device dev_obj;
 };
 
@@ -77,6 +80,14 @@ static void ctx_init_lazy(hip_ctx * c) {
         HIP_CHECK(hipHostMalloc((void **) &s.descs, UPLOAD_MAX_DESCS * sizeof(upload_desc), hipHostMallocMapped));
         HIP_CHECK(hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
     }
+    HIP_CHECK(hipHostMalloc((void **) &c->err_host, 64, hipHostMallocMapped));
+    c->err_host[0] = 0u;
+    HIP_CHECK(hipHostGetDevicePointer((void **) &c->err_dev, (void *) c->err_host, 0));
+}
+
+static void check_device_error(hip_ctx * c) {
+    if (c->err_host && c->err_host[0] != 0u)
+        GGML_ABORT("mi355x backend: a kernel gave up a bounded wait (code %u: 1 = split attention head barrier); results are invalid", c->err_host[0]);
 }
 
 // ---- pool -----------------------------------------------------------------------------------------
@@ -159,6 +170,7 @@ static void hip_buf_get(ggml_backend_buffer_t b, const struct ggml_tensor * t, v
     flush_uploads(c);
     HIP_CHECK(hipMemcpyAsync(data, (const char *) t->data + offset, size, hipMemcpyDeviceToHost, c->stream));
     HIP_CHECK(hipStreamSynchronize(c->stream));
+    check_device_error(c);
 }
 static void hip_buf_memset(ggml_backend_buffer_t b, struct ggml_tensor * t, uint8_t v, size_t offset, size_t size) {
     hip_ctx * c = ((hip_buffer_ctx *) b->context)->c;
@@ -1091,6 +1103,67 @@ static bool match_vq_level(const analysis & an, int pos, step_group & grp, emitt
     return true;
 }
 
+// G. a tree of concats / layout nodes over one-element F32 tensors, optionally cast to I32 at the top (the RVQ encoder's code
+//    vector: vq.h:32-45, 97-114): one gather instead of a copy per concat
+static bool vector_like(const ggml_tensor * t) {
+    int big = 0;
+    for (int i = 0; i < 4; i++) if (t->ne[i] > 1) big++;
+    return big <= 1;
+}
+static bool collect_scalar_leaves(const analysis & an, const ggml_tensor * t, bool top, std::vector<const ggml_tensor *> & leaves, std::vector<int> & members) {
+    if (!vector_like(t) || t->type != GGML_TYPE_F32) return false;
+    if (ggml_nelements(t) == 1 && t->op != GGML_OP_CONCAT) {
+        const ggml_tensor * base = t;
+        while ((base->op == GGML_OP_PERMUTE || base->op == GGML_OP_RESHAPE || base->op == GGML_OP_VIEW) && pos_of(an, base) >= 0) {
+            if (uses_of(an, base) != 1) break;
+            members.push_back(pos_of(an, base));
+            base = base->src[0];
+            if (ggml_nelements(base) != 1) return false;
+        }
+        if (!t->data) return false;
+        leaves.push_back(t);
+        return true;
+    }
+    if (!top && uses_of(an, t) != 1) return false;
+    if (pos_of(an, t) < 0) return false;
+    if (t->op == GGML_OP_CONCAT) {
+        if (t->view_src) return false;
+        members.push_back(pos_of(an, t));
+        return collect_scalar_leaves(an, t->src[0], false, leaves, members) && collect_scalar_leaves(an, t->src[1], false, leaves, members);
+    }
+    if (t->op == GGML_OP_PERMUTE || t->op == GGML_OP_RESHAPE) {
+        members.push_back(pos_of(an, t));
+        return collect_scalar_leaves(an, t->src[0], false, leaves, members);
+    }
+    return false;
+}
+static bool match_scalar_gather(const analysis & an, int pos, step_group & grp) {
+    const ggml_tensor * top = an.g->nodes[pos];
+    const ggml_tensor * tree = top;
+    std::vector<int> members;
+    if (top->op == GGML_OP_CPY && top->view_src == NULL && top->type == GGML_TYPE_I32 && top->src[0]->type == GGML_TYPE_F32 && ggml_is_contiguous(top)) {
+        members.push_back(pos);
+        tree = top->src[0];
+        if (uses_of(an, tree) != 1) return false;
+    } else if (top->op != GGML_OP_CONCAT || !ggml_is_contiguous(top)) return false;
+    if (!vector_like(top) || !top->data) return false;
+    std::vector<const ggml_tensor *> leaves;
+    if (!collect_scalar_leaves(an, tree, tree == top, leaves, members)) return false;
+    if ((int64_t) leaves.size() != ggml_nelements(top) || leaves.size() < 3 || leaves.size() > GATHER_MAX) return false;
+    for (int m : members) if (m < 0) return false;
+    gather_args a;
+    memset(&a, 0, sizeof(a));
+    a.n = (int) leaves.size();
+    for (int i = 0; i < a.n; i++) a.src[i] = (const float *) leaves[(size_t) i]->data;
+    a.dst = top->data;
+    a.dst_type = top->type;
+    grp.steps.clear();
+    grp.steps.push_back([=](hipStream_t s) { k_gather_scalars(s, a); });
+    grp.members = members;
+    grp.emit_pos = pos;
+    return true;
+}
+
 // ---- plan construction --------------------------------------------------------------------------------------
 static plan_t * build_plan(hip_ctx * c, ggml_cgraph * g) {
     plan_t * p = new plan_t;
@@ -1133,6 +1206,18 @@ static plan_t * build_plan(hip_ctx * c, ggml_cgraph * g) {
             else if (g->nodes[i]->op == GGML_OP_ARGMAX) { if (!match_vq_level(an, i, grp, em)) continue; }
             else if (g->nodes[i]->op == GGML_OP_CONCAT) { if (!match_dw_convtr(an, i, grp)) continue; }
             else continue;
+            bool clash = false;
+            for (int m : grp.members) if (an.skip[(size_t) m]) clash = true;
+            if (clash) continue;
+            for (int m : grp.members) an.skip[(size_t) m] = 1;
+            for (auto & f : grp.steps) at_pos[grp.emit_pos].push_back(f);
+            p->n_fused += (int) grp.members.size();
+        }
+        // scalar gathers (top-most node first, so it claims the whole tree)
+        for (int i = g->n_nodes - 1; i >= 0; i--) {
+            if (an.skip[(size_t) i] || !(g->nodes[i]->op == GGML_OP_CPY || g->nodes[i]->op == GGML_OP_CONCAT)) continue;
+            step_group grp;
+            if (!match_scalar_gather(an, i, grp)) continue;
             bool clash = false;
             for (int m : grp.members) if (an.skip[(size_t) m]) clash = true;
             if (clash) continue;
@@ -1214,7 +1299,8 @@ static plan_t * build_plan(hip_ctx * c, ggml_cgraph * g) {
         const attn_args a = ag.a;
         void * ws = nullptr;
         if (const size_t n = k_attn_decode_ws_size(a)) { ws = em.ws(n); HIP_CHECK(hipMemset(ws, 0, n)); }   // arrival counters start at zero
-        at_pos[ag.emit_pos].insert(at_pos[ag.emit_pos].begin(), [=](hipStream_t s) { k_attn_decode(s, a, ws); });
+        unsigned * err = c->err_dev;
+        at_pos[ag.emit_pos].insert(at_pos[ag.emit_pos].begin(), [=](hipStream_t s) { k_attn_decode(s, a, ws, err); });
     }
     const bool dump = getenv("MI355X_DUMP_PLAN") != nullptr;
     for (int i = 0; i < g->n_nodes; i++) {

@@ -136,7 +136,7 @@ struct attn_args {
 #define ATTN_SPLIT_SLOTS 128      // ring slots per workgroup once a head is split
 #define ATTN_SINGLE_MAX 256       // up to this many live slots the head's first workgroup does everything alone
 size_t k_attn_decode_ws_size(const attn_args & a);
-void k_attn_decode(hipStream_t s, const attn_args & a, void * ws = nullptr);
+void k_attn_decode(hipStream_t s, const attn_args & a, void * ws = nullptr, unsigned * err = nullptr);   // *err <- 1 if a head-wide wait timed out
 
 // sum of (scaled) embedding rows, left-to-right
 #define EMBED_SUM_MAX 24
@@ -150,5 +150,9 @@ struct vq_level_args {
     float * resid_out; float * idx_f; int32_t * idx_i;        // resid_out may be NULL (last level)
     float * cand_val; int32_t * cand_idx; unsigned * counter; // workspace: one candidate per workgroup + arrival counter (zeroed once)
 };
+// dst[i] = (dst type) *src[i]: a tree of concats of one-element F32 tensors collapsed into one launch (RVQ code vectors)
+#define GATHER_MAX 32
+struct gather_args { const float * src[GATHER_MAX]; int n; void * dst; int dst_type; };
+void k_gather_scalars(hipStream_t s, const gather_args & a);
 #define VQ_LEVEL_WS_BYTES 4096
 void k_vq_level(hipStream_t s, const vq_level_args & a);

@@ -810,7 +810,7 @@ void k_matvec(hipStream_t s, const mv_args & a) {
 // the probabilities are bit-identical to the single-workgroup path; P x V partials -> global; the last workgroup to arrive adds
 // them in slot order. The wait cannot deadlock: workgroups are dispatched in blockIdx order and a head's workgroups are
 // contiguous, so the lowest unfinished head always has all of its workgroups resident (the spin is bounded regardless).
-struct attn_split_ws { float * scores; float * pmax; double * opart; unsigned * arrive; unsigned * done; int S; };
+struct attn_split_ws { float * scores; float * pmax; double * opart; unsigned * arrive; unsigned * done; int S; unsigned * err; };
 
 template <bool SPLIT>
 __global__ void __launch_bounds__(ATTN_THREADS) __attribute__((amdgpu_waves_per_eu(2)))   // >= 2 workgroups per CU: the split grid (<= 512) is resident
@@ -1026,6 +1026,7 @@ attn_decode_kernel(attn_args a, attn_split_ws w) {
                 atomicAdd(w.arrive + h, 1u);
                 int spins = 0;
                 while (ld_agent(w.arrive + h) < (unsigned) P && ++spins < (1 << 22)) __builtin_amdgcn_s_sleep(2);
+                if (spins >= (1 << 22) && w.err) *w.err = 1u;   // host-visible: the backend aborts at the next read-back
             }
             __syncthreads();
             // (coherent loads cost a full memory round trip each: request them eight at a time)
@@ -1122,11 +1123,11 @@ size_t k_attn_decode_ws_size(const attn_args & a) {
     const size_t S = (size_t) (a.C + ATTN_SPLIT_SLOTS - 1) / ATTN_SPLIT_SLOTS;
     return (size_t) a.H * a.C * 4 + (size_t) a.H * S * 4 + (size_t) a.H * S * a.D * 8 + (size_t) a.H * 8 + 256;
 }
-void k_attn_decode(hipStream_t s, const attn_args & a, void * ws) {
+void k_attn_decode(hipStream_t s, const attn_args & a, void * ws, unsigned * err) {
     GGML_ASSERT(a.D % 8 == 0 && 64 % (a.D / 8) == 0 && a.D <= 512 && a.T >= 1 && a.T <= ATTN_MAX_T && a.T * a.D <= 2 * ATTN_THREADS);
     const size_t smem = (size_t) a.C * 4 + (size_t) a.T * a.D * 4 * 3 + (size_t) (ATTN_THREADS / 64) * 64 * 8 * 8 + 16;
     GGML_ASSERT(smem <= 160 * 1024);
-    attn_split_ws w = { nullptr, nullptr, nullptr, nullptr, nullptr, 1 };
+    attn_split_ws w = { nullptr, nullptr, nullptr, nullptr, nullptr, 1, err };
     if (ws && attn_use_split(a)) {
         const int S = (a.C + ATTN_SPLIT_SLOTS - 1) / ATTN_SPLIT_SLOTS;
         GGML_ASSERT(a.D == 128 && "split prefetch depth is sized for 16 slots per pass");
@@ -1256,4 +1257,16 @@ void k_vq_level(hipStream_t s, const vq_level_args & a) {
     const int grid = (a.NC + 4 * VQ_CPW - 1) / (4 * VQ_CPW);
     GGML_ASSERT(grid <= 256);
     vq_level_kernel<<<grid, 256, 0, s>>>(a);
+}
+
+__global__ void gather_scalars_kernel(gather_args a) {
+    const int i = threadIdx.x;
+    if (i >= a.n) return;
+    const float v = *a.src[i];
+    if (a.dst_type == GGML_TYPE_I32) ((int32_t *) a.dst)[i] = (int32_t) v;
+    else ((float *) a.dst)[i] = v;
+}
+void k_gather_scalars(hipStream_t s, const gather_args & a) {
+    GGML_ASSERT(a.n <= GATHER_MAX && (a.dst_type == GGML_TYPE_I32 || a.dst_type == GGML_TYPE_F32));
+    gather_scalars_kernel<<<1, 64, 0, s>>>(a);
 }
