@@ -355,11 +355,13 @@ struct emitter {
     void push(step_fn f) { p->steps.push_back(std::move(f)); }
 };
 
+static bool is_qblock(enum ggml_type t) { return t == GGML_TYPE_Q4_K || t == GGML_TYPE_Q8_0 || t == GGML_TYPE_Q4_0; }
+
 static bool fill_matvec_base(mv_args & a, const ggml_tensor * mm) {
     const ggml_tensor * w = mm->src[0], * b = mm->src[1];
     if (!dense_rows(w) || !k_matvec_supported(w->type, w->ne[0], w->ne[1])) return false;
     if (b->type != GGML_TYPE_F32 || b->ne[2] != 1 || b->ne[3] != 1 || b->ne[1] < 1) return false;
-    if (b->ne[1] > (w->type == GGML_TYPE_Q4_K ? 1 : MV_MAX_COLS)) return false;
+    if (b->ne[1] > (is_qblock(w->type) ? 1 : MV_MAX_COLS)) return false;
     if (b->nb[0] != 4 || mm->nb[0] != 4) return false;
     memset(&a, 0, sizeof(a));
     a.ncols = (int) b->ne[1];
@@ -490,7 +492,7 @@ static bool match_matvec(const analysis & an, int pos, mv_group & grp) {
            ggml_nelements(b->src[0]) == ggml_nelements(b) && ggml_is_contiguous(b->src[0])) b = b->src[0];
 
     // prologue 1: b = alpha * rms_norm(x), private to this mat-vec
-    if (a.ncols == 1 && b->op == GGML_OP_MUL && is_f32_vec(b, K) && uses_of(an, b) == 1 && (mm->src[0]->type != GGML_TYPE_Q4_K || K <= 4096)) {
+    if (a.ncols == 1 && b->op == GGML_OP_MUL && is_f32_vec(b, K) && uses_of(an, b) == 1 && (!is_qblock(mm->src[0]->type) || K <= 4096)) {
         const ggml_tensor * al = b->src[0], * nr = b->src[1];
         if (nr->op != GGML_OP_RMS_NORM) std::swap(al, nr);
         if (nr->op == GGML_OP_RMS_NORM && uses_of(an, nr) == 1 && is_f32_vec(al, K) && is_f32_vec(nr->src[0], K)) {
@@ -503,7 +505,7 @@ static bool match_matvec(const analysis & an, int pos, mv_group & grp) {
         }
     }
     // prologue 1b: b = norm(x) * w (+ bias) (torch_nn_layer_norm, torch.h:49-60), any column count
-    if (!have_x && mm->src[0]->type != GGML_TYPE_Q4_K && uses_of(an, b) == 1 && (b->op == GGML_OP_ADD || b->op == GGML_OP_MUL)) {
+    if (!have_x && !is_qblock(mm->src[0]->type) && uses_of(an, b) == 1 && (b->op == GGML_OP_ADD || b->op == GGML_OP_MUL)) {
         const ggml_tensor * mulw = b, * bias = nullptr;
         if (b->op == GGML_OP_ADD && b->src[0]->op == GGML_OP_MUL && uses_of(an, b->src[0]) == 1) { mulw = b->src[0]; bias = b->src[1]; }
         if (mulw->op == GGML_OP_MUL && mulw->src[0]->op == GGML_OP_NORM && uses_of(an, mulw->src[0]) == 1) {
@@ -523,7 +525,7 @@ static bool match_matvec(const analysis & an, int pos, mv_group & grp) {
         }
     }
     // prologue 1c: b = gelu(h)
-    if (!have_x && mm->src[0]->type != GGML_TYPE_Q4_K && b->op == GGML_OP_UNARY && b->op_params[0] == GGML_UNARY_OP_GELU && uses_of(an, b) == 1 &&
+    if (!have_x && !is_qblock(mm->src[0]->type) && b->op == GGML_OP_UNARY && b->op_params[0] == GGML_UNARY_OP_GELU && uses_of(an, b) == 1 &&
         !an.skip[(size_t) pos_of(an, b)]) {   // (already produced by the previous mat-vec's epilogue otherwise)
         const ggml_tensor * hin = b->src[0];
         if (hin->type == GGML_TYPE_F32 && hin->nb[0] == 4 && ggml_are_same_shape(hin, b) && hin->ne[2] == 1 && hin->ne[3] == 1) {
@@ -557,7 +559,7 @@ static bool match_matvec(const analysis & an, int pos, mv_group & grp) {
     // epilogue 0: gelu(W x) (the activation is evaluated once per output element here, not once per consuming workgroup)
     {
         const ggml_tensor * g = sole_consumer(an, mm);
-        if (g && g->op == GGML_OP_UNARY && g->op_params[0] == GGML_UNARY_OP_GELU && mm->src[0]->type != GGML_TYPE_Q4_K && g->view_src == NULL &&
+        if (g && g->op == GGML_OP_UNARY && g->op_params[0] == GGML_UNARY_OP_GELU && !is_qblock(mm->src[0]->type) && g->view_src == NULL &&
             ggml_are_same_shape(g, mm) && g->nb[0] == 4 && g->type == GGML_TYPE_F32) {
             a.out_act = 1;
             a.y = (float *) g->data;
@@ -570,7 +572,7 @@ static bool match_matvec(const analysis & an, int pos, mv_group & grp) {
     // epilogue: (optional per-row layer_scale, then) the only consumer adds a same-shaped F32 tensor
     const ggml_tensor * cons = sole_consumer(an, mm);
     const ggml_tensor * scaled = nullptr;
-    if (cons && cons->op == GGML_OP_MUL && cons->view_src == NULL && cons->src[0] == mm && mm->src[0]->type != GGML_TYPE_Q4_K &&
+    if (cons && cons->op == GGML_OP_MUL && cons->view_src == NULL && cons->src[0] == mm && !is_qblock(mm->src[0]->type) &&
         is_f32_vec(cons->src[1], a.M) && ggml_are_same_shape(cons, mm) && cons->nb[0] == 4) {
         const ggml_tensor * c2 = sole_consumer(an, cons);
         if (c2 && c2->op == GGML_OP_ADD) { scaled = cons; cons = c2; }
@@ -585,7 +587,7 @@ static bool match_matvec(const analysis & an, int pos, mv_group & grp) {
         embed_src es;
         const ggml_tensor * term = other;
         bool embed = false;
-        if (shapes && !scaled && a.wtype == GGML_TYPE_Q4_K && a.ncols == 1 && uses_of(an, other) == 1) {
+        if (shapes && !scaled && is_qblock((enum ggml_type) a.wtype) && a.ncols == 1 && uses_of(an, other) == 1) {
             if (term->op == GGML_OP_CPY && term->view_src == NULL && term->src[0]->type == GGML_TYPE_F32 && ggml_are_same_shape(term->src[0], term) && uses_of(an, term->src[0]) == 1) {
                 emb_members.push_back(pos_of(an, term));
                 term = term->src[0];
@@ -1248,7 +1250,7 @@ static plan_t * build_plan(hip_ctx * c, ggml_cgraph * g) {
             if (clash) continue;
             for (int m : grp.members) an.skip[(size_t) m] = 1;
             mv_args a = grp.a;
-            if (a.wtype == GGML_TYPE_Q4_K && a.ncols == 1 && !no_argmax_epilogue) {
+            if (is_qblock((enum ggml_type) a.wtype) && a.ncols == 1 && !no_argmax_epilogue) {
                 // greedy sampling (sampling.h:57-63): argmax of the logits, optionally copied into the token buffer
                 const ggml_tensor * ynode = g->nodes[grp.emit_pos];
                 const ggml_tensor * am = nullptr;
@@ -1268,7 +1270,7 @@ static plan_t * build_plan(hip_ctx * c, ggml_cgraph * g) {
                     p->n_fused += 1 + (cp ? 1 : 0);
                 }
             }
-            if (a.prologue == MV_PLAIN && a.wtype == GGML_TYPE_Q4_K && a.ncols == 1 && !no_attn_prologue) {
+            if (a.prologue == MV_PLAIN && is_qblock((enum ggml_type) a.wtype) && a.ncols == 1 && !no_attn_prologue) {
                 // x is the output of a single-token attention over a short ring (Depth transformer): recompute it in every
                 // workgroup of this projection instead of launching it on its own (16 heads x 8 slots is ~nothing)
                 for (auto & ag : attn_groups) {
@@ -1282,11 +1284,12 @@ static plan_t * build_plan(hip_ctx * c, ggml_cgraph * g) {
                     break;
                 }
             }
-            if (a.prologue == MV_GATE_SILU && a.wtype == GGML_TYPE_Q4_K && a.K > 4096) {
+            if (a.prologue == MV_GATE_SILU && is_qblock((enum ggml_type) a.wtype) && a.K > 4096) {
                 // long gated rows: quantise the activation once, not once per workgroup
                 void * blocks = em.ws((size_t) (a.K / 256) * MV_XBLK_BYTES);
                 const float * h = a.x; const int64_t K = a.K;
-                at_pos[grp.emit_pos].push_back([=](hipStream_t s) { k_gate_quant_q8k(s, h, K, blocks); });
+                const int wt = a.wtype;
+                at_pos[grp.emit_pos].push_back([=](hipStream_t s) { k_gate_quant_q8k(s, h, K, blocks, wt); });
                 a.prologue = MV_PREQ8K;
                 a.x = (const float *) blocks;
             }

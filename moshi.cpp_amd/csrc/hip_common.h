@@ -112,7 +112,7 @@ void k_matvec_set_profile(mv_profile * p);
 void k_matvec(hipStream_t s, const mv_args & a);
 // gated-FFN activation silu(h[:K]) * h[K:] quantised to padded Q8_K blocks (K/256 x 304 B) for a following MV_PREQ8K mat-vec
 #define MV_XBLK_BYTES 304
-void k_gate_quant_q8k(hipStream_t s, const float * h, int64_t K, void * out_blocks);
+void k_gate_quant_q8k(hipStream_t s, const float * h, int64_t K, void * out_blocks, int wtype);   // activation format follows the weight type
 
 // streaming self-attention over a ring KV cache (T <= 4 new tokens): RoPE(q,k) -> cache write -> masked
 // softmax(K q) V restricted to un-masked slots; see hip_kernels_fused.hip

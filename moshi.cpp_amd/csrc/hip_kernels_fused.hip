@@ -74,6 +74,85 @@ __device__ unsigned long long g_mv_real[4096][2];
 struct xblk { int8_t q[256]; int16_t bsums[16]; float d; float pad[3]; };
 static_assert(sizeof(xblk) == XBLK_BYTES, "xblk layout");
 
+// Weight formats of the block mat-vec. A lane always owns 256 consecutive weights of one row: one Q4_K super-block, or eight
+// consecutive Q8_0 / Q4_0 blocks (K % 256 == 0 for every linear of the models). Activations are quantised the way ggml's CPU
+// backend does for that weight type: Q8_K (256-wide) for Q4_K, Q8_0 (32-wide, F16 scale) for Q8_0 and Q4_0; both kinds are kept
+// in the same 304-byte LDS record.
+#define MVF_Q4K 0
+#define MVF_Q80 1
+#define MVF_Q40 2
+template <int FMT> struct mvfmt;
+template <> struct mvfmt<MVF_Q4K> { static constexpr int SB = 144, NLOAD = 9; };    // f16 d, f16 dmin, 12 B scales, 128 B nibbles
+template <> struct mvfmt<MVF_Q80> { static constexpr int SB = 272, NLOAD = 17; };   // 8 x (f16 d, 32 int8)
+template <> struct mvfmt<MVF_Q40> { static constexpr int SB = 144, NLOAD = 9; };    // 8 x (f16 d, 16 B nibbles)
+struct xblk80 { int8_t q[256]; float d[8]; int16_t bsums[8]; };   // d = the F16-rounded scale of each 32-wide block, bsums = sum of its q
+static_assert(sizeof(xblk80) == XBLK_BYTES, "xblk80 layout");
+
+// quantise the 256 values held by one wave (4 per lane, contiguous) to eight Q8_0 blocks in LDS (quantize_row_q8_0_ref:
+// d = amax / 127, q = roundf(x / d), d stored as F16)
+__device__ __forceinline__ void quantize_block_q80(xblk80 * dst, const float v[4], int lane) {
+    float amax = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
+    amax = fmaxf(amax, dpp_f32<DPP_QUAD_XOR1>(amax));
+    amax = fmaxf(amax, dpp_f32<DPP_QUAD_XOR2>(amax));
+    amax = fmaxf(amax, dpp_f32<DPP_HALF_MIRROR>(amax));   // the 8 lanes of one 32-wide block
+    const float d = amax / 127.f;
+    const float id = d != 0.f ? 1.0f / d : 0.0f;
+    int q[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) q[k] = (int) roundf(v[k] * id);
+    *(uint32_t *) (dst->q + lane * 4) = (uint32_t) (q[0] & 0xff) | ((uint32_t) (q[1] & 0xff) << 8) | ((uint32_t) (q[2] & 0xff) << 16) | ((uint32_t) (q[3] & 0xff) << 24);
+    int s = q[0] + q[1] + q[2] + q[3];
+    s += dpp_i32<DPP_QUAD_XOR1>(s);
+    s += dpp_i32<DPP_QUAD_XOR2>(s);
+    s += dpp_i32<DPP_HALF_MIRROR>(s);
+    if ((lane & 7) == 0) { dst->d[lane >> 3] = h2f(f2h(d)); dst->bsums[lane >> 3] = (int16_t) s; }
+}
+
+// dword `i` of a byte stream that starts 2 bytes into a 4-byte-aligned image (D = the aligned dwords)
+__device__ __forceinline__ uint32_t dword_at2(const uint32_t * D, int byte_off) {
+    const int i = byte_off >> 2;
+    return (byte_off & 2) ? __builtin_amdgcn_alignbyte(D[i + 1], D[i], 2) : D[i];
+}
+// eight Q8_0 blocks (272 B, 16-byte aligned) against 256 Q8_0-quantised activations: sum_j sumi_j * (d_w * d_x), in block order
+// (vec_dot_q8_0_q8_0)
+__device__ __forceinline__ float q80_q80_sb_dot(const char * wb, const xblk80 * xb) {
+    const uint32_t * D = (const uint32_t *) wb;
+    const int * y = (const int *) xb->q;
+    float sumf = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const int off = 34 * j;
+        const float dw = h2f((uint16_t) (D[off >> 2] >> ((off & 2) * 8)));
+        int sumi = 0;
+#pragma unroll
+        for (int t = 0; t < 8; t++) sumi = dot4_i8((int) dword_at2(D, off + 2 + 4 * t), y[j * 8 + t], sumi);
+        sumf += (float) sumi * (dw * xb->d[j]);
+    }
+    return sumf;
+}
+// eight Q4_0 blocks (144 B) against 256 Q8_0-quantised activations: sum_j (sumi_j * d_w) * d_x with sumi = sum (q - 8) * y
+// (vec_dot_q4_0_q8_0); the -8 offset is applied through the per-block activation sums
+__device__ __forceinline__ float q40_q80_sb_dot(const char * wb, const xblk80 * xb) {
+    const uint32_t * D = (const uint32_t *) wb;
+    const int * y = (const int *) xb->q;
+    float sumf = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const int off = 18 * j;
+        const float dw = h2f((uint16_t) (D[off >> 2] >> ((off & 2) * 8)));
+        int sumi = 0;
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            const uint32_t q = dword_at2(D, off + 2 + 4 * t);
+            sumi = dot4_i8((int) (q & 0x0F0F0F0Fu), y[j * 8 + t], sumi);
+            sumi = dot4_i8((int) ((q >> 4) & 0x0F0F0F0Fu), y[j * 8 + 4 + t], sumi);
+        }
+        sumi -= 8 * (int) xb->bsums[j];
+        sumf += ((float) sumi * dw) * xb->d[j];
+    }
+    return sumf;
+}
+
 // quantise the 256 values held by one wave (4 per lane, contiguous) to a Q8_K block in LDS
 __device__ __forceinline__ void quantize_block_q8k(xblk * dst, const float v[4], int lane) {
     // the signed value of largest magnitude (ggml: iscale = -127 / max); when +a and -a tie the sign is immaterial
@@ -228,22 +307,26 @@ __device__ __forceinline__ void attn_small_wave4(const attn_args & a, int h0, in
 //           16-block batch are issued before any of them is used, so the phase costs ~one L2 round trip
 //  phase 3: tiles stream registers -> LDS image -> one super-block per lane (next tile prefetched first)
 //  phase 4: fixed-order row sums (+ residual)
-template <int PRO, int NW>
+template <int PRO, int NW, int FMT = MVF_Q4K>
 __global__ void __launch_bounds__(NW * 64) matvec_q4k_kernel(mv_args a, int rows_per_wg, attn_args at) {
+    constexpr int SB = mvfmt<FMT>::SB, NLOAD = mvfmt<FMT>::NLOAD, TILE = 64 * SB;   // bytes per lane-chunk / 16-byte loads per lane per tile
+    auto quantize_block = [&](xblk * dst, const float v[4]) {
+        if (FMT == MVF_Q4K) quantize_block_q8k(dst, v, threadIdx.x & 63); else quantize_block_q80((xblk80 *) dst, v, threadIdx.x & 63);
+    };
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ double sh_red[NW];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     constexpr int nwaves = NW;
     const int nb = (int) (a.K / 256);
     xblk * xs = (xblk *) smem;
-    char * stage = smem + nb * XBLK_BYTES + wave * TILE_BYTES;
-    float * part = (float *) (smem + nb * XBLK_BYTES + nwaves * TILE_BYTES);
+    char * stage = smem + nb * XBLK_BYTES + wave * TILE;
+    float * part = (float *) (smem + nb * XBLK_BYTES + nwaves * TILE);
 
     const int64_t row0 = (int64_t) blockIdx.x * rows_per_wg;
     const int rows = (int) (a.M - row0 < rows_per_wg ? a.M - row0 : rows_per_wg);
     const int nblk = rows * nb;
     const int ntiles = (nblk + 63) >> 6;
-    const int nchunks = nblk * 9;
+    const int nchunks = nblk * (SB / 16);
     const u32x4 * wsrc = (const u32x4 *) (a.w + row0 * a.row_bytes);
 
     MV_STAMP(0);
@@ -269,13 +352,13 @@ __global__ void __launch_bounds__(NW * 64) matvec_q4k_kernel(mv_args a, int rows
     if (PRO != MV_PREQ8K && PRO != MV_ATTN) load_batch(0);
     __builtin_amdgcn_sched_barrier(0);   // keep the activation loads ahead of the weight tile in program (= return) order
 
-    u32x4 r[9];
+    u32x4 r[NLOAD];
     int t = wave;
     {   // unconditional, clamped: chunks past the end re-read the last valid chunk and are never consumed
         const int tt = t < ntiles ? t : ntiles - 1;
 #pragma unroll
-        for (int i = 0; i < 9; i++) {
-            const int g = tt * 576 + i * 64 + lane;
+        for (int i = 0; i < NLOAD; i++) {
+            const int g = tt * (NLOAD * 64) + i * 64 + lane;
             r[i] = __builtin_nontemporal_load(wsrc + (g < nchunks ? g : nchunks - 1));
         }
     }
@@ -291,7 +374,7 @@ __global__ void __launch_bounds__(NW * 64) matvec_q4k_kernel(mv_args a, int rows
 #pragma unroll
         for (int k = 0; k < 4; k++) v[k] = xa[lane * 4 + k];
         if (a.x_out != nullptr && blockIdx.x == 0) *(float4 *) (a.x_out + wave * 256 + lane * 4) = make_float4(v[0], v[1], v[2], v[3]);
-        quantize_block_q8k(xs + wave, v, lane);
+        quantize_block(xs + wave, v);
     } else if (PRO == MV_PREQ8K) {
         // activations were quantised by gate_quant_q8k_kernel: copy the padded Q8_K blocks (304 B each) into LDS
         const u32x4 * src = (const u32x4 *) a.x;
@@ -339,7 +422,7 @@ __global__ void __launch_bounds__(NW * 64) matvec_q4k_kernel(mv_args a, int rows
                 if (!ok[j]) continue;   // wave-uniform: a wave always holds one whole block
                 const int b = base / 256 + j * NW + wave;
                 if (a.x_out != nullptr && blockIdx.x == 0) *(float4 *) (a.x_out + base + j * (NW * 256) + tid * 4) = make_float4(v[j][0], v[j][1], v[j][2], v[j][3]);
-                quantize_block_q8k(xs + b, v[j], lane);
+                quantize_block(xs + b, v[j]);
             }
         }
     }
@@ -350,13 +433,13 @@ __global__ void __launch_bounds__(NW * 64) matvec_q4k_kernel(mv_args a, int rows
     // phase 3
     for (; t < ntiles; t += nwaves) {
 #pragma unroll
-        for (int i = 0; i < 9; i++) ((u32x4 *) stage)[i * 64 + lane] = r[i];
+        for (int i = 0; i < NLOAD; i++) ((u32x4 *) stage)[i * 64 + lane] = r[i];
         MV_STAMP(4);
         {
             const int tn = t + nwaves < ntiles ? t + nwaves : ntiles - 1;
 #pragma unroll
-            for (int i = 0; i < 9; i++) {
-                const int g = tn * 576 + i * 64 + lane;
+            for (int i = 0; i < NLOAD; i++) {
+                const int g = tn * (NLOAD * 64) + i * 64 + lane;
                 r[i] = __builtin_nontemporal_load(wsrc + (g < nchunks ? g : nchunks - 1));
             }
         }
@@ -365,9 +448,11 @@ __global__ void __launch_bounds__(NW * 64) matvec_q4k_kernel(mv_args a, int rows
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         const int bi = t * 64 + lane;
         if (bi < nblk) {
-            const block_q4_K * wb = (const block_q4_K *) (stage + lane * 144);
+            const char * wb = stage + lane * SB;
             const xblk * xb = xs + (bi % nb);
-            part[bi] = q4k_q8k_block_dot(wb, xb->q, xb->bsums, xb->d);
+            if (FMT == MVF_Q4K) part[bi] = q4k_q8k_block_dot((const block_q4_K *) wb, xb->q, xb->bsums, xb->d);
+            else if (FMT == MVF_Q80) part[bi] = q80_q80_sb_dot(wb, (const xblk80 *) xb);
+            else part[bi] = q40_q80_sb_dot(wb, (const xblk80 *) xb);
         }
         __builtin_amdgcn_wave_barrier();
     }
@@ -676,7 +761,7 @@ __global__ void __launch_bounds__(256) matvec_f32_reg_kernel(mv_args a) {
 bool k_matvec_supported(int wtype, int64_t K, int64_t M) {
     if (M <= 0) return false;
     switch (wtype) {
-        case GGML_TYPE_Q4_K: return K % 256 == 0 && K <= 16384;
+        case GGML_TYPE_Q4_K: case GGML_TYPE_Q8_0: case GGML_TYPE_Q4_0: return K % 256 == 0 && K <= 16384;
         case GGML_TYPE_F32:  return K % 4 == 0 && K <= 16384;
         case GGML_TYPE_F16: case GGML_TYPE_BF16: return K % 8 == 0 && K <= 16384;
         default: return false;
@@ -685,7 +770,8 @@ bool k_matvec_supported(int wtype, int64_t K, int64_t M) {
 
 // silu(left) * right of the gated FFN, quantised to padded Q8_K blocks in global memory: one wave per 256-element block.
 // Used for long rows (K > 4096), where redoing this in every mat-vec workgroup would dominate the kernel.
-__global__ void __launch_bounds__(64) gate_quant_q8k_kernel(const float * h, int K, xblk * out, float * g_out) {
+template <int FMT>
+__global__ void __launch_bounds__(64) gate_quant_kernel(const float * h, int K, xblk * out, float * g_out) {
     const int b = blockIdx.x, lane = threadIdx.x;
     const int e = b * 256 + lane * 4;
     const float4 l4 = *(const float4 *) (h + e), r4 = *(const float4 *) (h + K + e);
@@ -694,10 +780,11 @@ __global__ void __launch_bounds__(64) gate_quant_q8k_kernel(const float * h, int
 #pragma unroll
     for (int k = 0; k < 4; k++) v[k] = (l[k] / (1.0f + expf(-l[k]))) * r[k];
     if (g_out) *(float4 *) (g_out + e) = make_float4(v[0], v[1], v[2], v[3]);
-    quantize_block_q8k(out + b, v, lane);
+    if (FMT == MVF_Q4K) quantize_block_q8k(out + b, v, lane); else quantize_block_q80((xblk80 *) (out + b), v, lane);
 }
-void k_gate_quant_q8k(hipStream_t s, const float * h, int64_t K, void * out_blocks) {
-    gate_quant_q8k_kernel<<<(int) (K / 256), 64, 0, s>>>(h, (int) K, (xblk *) out_blocks, nullptr);
+void k_gate_quant_q8k(hipStream_t s, const float * h, int64_t K, void * out_blocks, int wtype) {
+    if (wtype == GGML_TYPE_Q4_K) gate_quant_kernel<MVF_Q4K><<<(int) (K / 256), 64, 0, s>>>(h, (int) K, (xblk *) out_blocks, nullptr);
+    else gate_quant_kernel<MVF_Q80><<<(int) (K / 256), 64, 0, s>>>(h, (int) K, (xblk *) out_blocks, nullptr);
 }
 
 static mv_profile * g_mv_profile = nullptr;
@@ -706,8 +793,10 @@ void k_matvec_set_profile(mv_profile * p) { g_mv_profile = p; }
 static int env_int(const char * name, int def) { const char * v = getenv(name); return v ? atoi(v) : def; }
 
 void k_matvec(hipStream_t s, const mv_args & a) {
-    if (a.wtype == GGML_TYPE_Q4_K) {
+    if (a.wtype == GGML_TYPE_Q4_K || a.wtype == GGML_TYPE_Q8_0 || a.wtype == GGML_TYPE_Q4_0) {
         const int nb = (int) (a.K / 256);
+        const int fmt = a.wtype == GGML_TYPE_Q4_K ? MVF_Q4K : a.wtype == GGML_TYPE_Q8_0 ? MVF_Q80 : MVF_Q40;
+        const size_t tile_bytes = fmt == MVF_Q80 ? 64 * 272 : 64 * 144;
         // Workgroup shape. Large matrices (>= ~8 tiles per CU): ONE workgroup of 8 or 12 waves per CU, so the activation
         // prologue (cost ~K, identical in every workgroup) runs once per CU and every wave keeps a 9 KB tile in flight.
         // Small matrices: 4-wave workgroups of >= 1 tile each, as many as there are tiles (latency-bound anyway).
@@ -731,15 +820,22 @@ void k_matvec(hipStream_t s, const mv_args & a) {
             rows = (tpw * 64 + nb - 1) / nb;
             while (rows > 1 && (a.M + rows - 1) / rows < grid_min && (rows / 2) * nb >= 64) rows >>= 1;
         }
+        if (fmt == MVF_Q80 && nw > 4 && a.prologue != MV_ATTN) {   // 17 KB tiles: four waves per workgroup fit the LDS comfortably
+            nw = 4;
+            rows = (int) ((a.M + 511) / 512);
+            while (rows * nb > 4096) rows = (rows + 1) / 2;
+        }
         if (rows < 1) rows = 1;
-        const size_t smem = (size_t) nb * XBLK_BYTES + (size_t) nw * TILE_BYTES + (size_t) rows * nb * 4;
+        const size_t smem = (size_t) nb * XBLK_BYTES + (size_t) nw * tile_bytes + (size_t) rows * nb * 4;
+        GGML_ASSERT(smem <= 160 * 1024);
         const int grid = (int) ((a.M + rows - 1) / rows);
         GGML_ASSERT(a.prologue != MV_RMSNORM || a.K <= nw * 1024);
         GGML_ASSERT(a.ncols == 1 && a.out_scale == nullptr && (a.prologue <= MV_GATE_SILU || a.prologue == MV_PREQ8K || a.prologue == MV_ATTN));
         void (*kern)(mv_args, int, attn_args) = nullptr;
-#define MV_PICK(NWV) (a.prologue == MV_RMSNORM ? matvec_q4k_kernel<MV_RMSNORM, NWV> : a.prologue == MV_GATE_SILU ? matvec_q4k_kernel<MV_GATE_SILU, NWV> \
-                      : a.prologue == MV_ATTN ? matvec_q4k_kernel<MV_ATTN, NWV> \
-                      : a.prologue == MV_PREQ8K ? matvec_q4k_kernel<MV_PREQ8K, NWV> : matvec_q4k_kernel<MV_PLAIN, NWV>)
+#define MV_PICKF(NWV, F) (a.prologue == MV_RMSNORM ? matvec_q4k_kernel<MV_RMSNORM, NWV, F> : a.prologue == MV_GATE_SILU ? matvec_q4k_kernel<MV_GATE_SILU, NWV, F> \
+                      : a.prologue == MV_ATTN ? matvec_q4k_kernel<MV_ATTN, NWV, F> \
+                      : a.prologue == MV_PREQ8K ? matvec_q4k_kernel<MV_PREQ8K, NWV, F> : matvec_q4k_kernel<MV_PLAIN, NWV, F>)
+#define MV_PICK(NWV) (fmt == MVF_Q4K ? MV_PICKF(NWV, MVF_Q4K) : fmt == MVF_Q40 ? MV_PICKF(NWV, MVF_Q40) : MV_PICKF(NWV, MVF_Q80))
         kern = nw == 12 ? MV_PICK(12) : nw == 8 ? MV_PICK(8) : MV_PICK(4);
         if (smem > 64 * 1024) {   // > 64 KB of dynamic LDS needs a one-time opt-in per kernel
             static std::map<const void *, size_t> granted;

@@ -168,7 +168,10 @@ def test_set_rows_bf16_cache():
 
 @pytest.mark.parametrize("wtype,K,M,N", [(F32, 512, 96, 2), (F16, 256, 64, 3), (BF16, 128, 50, 1), (Q8_0, 256, 33, 2),
                                          (Q4_0, 512, 17, 1), (Q4_K, 1024, 40, 2), (Q4_K, 4096, 64, 1), (Q4_K, 2816, 48, 1),
-                                         (F32, 512, 1536, 1), (BF16, 4096, 256, 1), (F16, 1024, 100, 1)])
+                                         (F32, 512, 1536, 1), (BF16, 4096, 256, 1), (F16, 1024, 100, 1),
+                                         # block mat-vec fast path (K % 256 == 0, one activation column) for the other two block formats
+                                         (Q8_0, 256, 33, 1), (Q8_0, 1024, 300, 1), (Q8_0, 4096, 520, 1), (Q8_0, 2816, 64, 1),
+                                         (Q4_0, 512, 17, 1), (Q4_0, 1024, 300, 1), (Q4_0, 4096, 520, 1)])
 def test_mul_mat_types(wtype, K, M, N):
     r = np.random.default_rng(K + M)
     x = r.standard_normal((N, K)).astype(np.float32)
