@@ -62,6 +62,7 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=1)
     ap.add_argument("--cpu-threads", type=int, default=32, help="OpenMP threads of the CPU baseline (capped by the affinity mask)")
+    ap.add_argument("--quant", default="q4_k", choices=["q4_k", "q8_0", "q4_0"], help="linear weight type (the headline metric is q4_k)")
     ap.add_argument("--backend-flags", type=int, default=0, help="ggml_backend_mi355x_set_flags bits (2 = no hipGraph: use under rocprofv3)")
     args = ap.parse_args()
 
@@ -93,6 +94,8 @@ def main():
     if args.backend_flags:
         L.ggml_backend_mi355x_set_flags(be, args.backend_flags)
     cfg = hot.moshika(L)
+    if args.quant != "q4_k":
+        cfg.linear_type = {"q8_0": 8, "q4_0": 2}[args.quant]   # ggml_type ids
     t0 = time.time()
     m = L.moshi_hot_create(be, C.byref(cfg), 0)
     t_load = time.time() - t0
@@ -140,7 +143,7 @@ def main():
     L.ggml_backend_mi355x_get_stats(be, C.byref(st))
 
     result = {
-        "metric": "audio frames/sec (12.5 Hz target) moshika-7B q4_k decode",
+        "metric": "audio frames/sec (12.5 Hz target) moshika-7B %s decode" % args.quant,
         "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "q4_K weights x q8_K activations (int8 dot, f32 accumulate); bf16 KV; f32 elsewhere",

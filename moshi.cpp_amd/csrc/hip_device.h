@@ -251,8 +251,9 @@ __device__ __forceinline__ float q4k_q8k_block_dot(const block_q4_K * xb, const 
         }
         const int s0 = (int) ((sc[j >> 1] >> (16 * (j & 1))) & 0xff), s1 = (int) ((sc[j >> 1] >> (16 * (j & 1) + 8)) & 0xff);
         const int m0 = (int) ((mn[j >> 1] >> (16 * (j & 1))) & 0xff), m1 = (int) ((mn[j >> 1] >> (16 * (j & 1) + 8)) & 0xff);
-        isum += s0 * lo + s1 * hi;
-        msum += m0 * ((int) bsums[4 * j] + (int) bsums[4 * j + 1]) + m1 * ((int) bsums[4 * j + 2] + (int) bsums[4 * j + 3]);
+        // 6-bit scales times sums bounded by 32 * 15 * 127 < 2^23: exact in the full-rate 24-bit multiplier (v_mul_lo_u32 is quarter rate)
+        isum += __mul24(s0, lo) + __mul24(s1, hi);
+        msum += __mul24(m0, (int) bsums[4 * j] + (int) bsums[4 * j + 1]) + __mul24(m1, (int) bsums[4 * j + 2] + (int) bsums[4 * j + 3]);
     }
     const float d = h2f(xb->d) * d8, dmin = h2f(xb->dmin) * d8;
     return d * (float) isum - dmin * (float) msum;
