@@ -50,15 +50,21 @@ def check_lm(ref, got, tol=LOGIT_TOL):
     assert np.median(errs) < 1e-5, f"median logit error {np.median(errs):.2e}: more than summation noise"
 
 
-@pytest.mark.parametrize("lt,et", [(Q4_K, Q4_0), (BF16, BF16), (F32, F32), (Q8_0, Q8_0)])
+# north_star bars: bf16 logits within 1e-3 (measured: bit-identical), quantised within a quantiser step. Observed maxima over 16
+# steps (tests/microbench/parity_report.py): bf16 0, f32 1.2e-7, q8_0 2.0e-7 of max |logit|; q4_k / q4_0 sit at ~5e-7 except on the
+# rare step where one Q8_K / Q8_0 activation value rounds the other way (see the module docstring), hence the looser hard bound.
+TYPE_TOL = {BF16: 1e-6, F32: 1e-5, Q8_0: 1e-5, Q4_K: LOGIT_TOL, Q4_0: LOGIT_TOL}
+
+
+@pytest.mark.parametrize("lt,et", [(Q4_K, Q4_0), (BF16, BF16), (F32, F32), (Q8_0, Q8_0), (Q4_0, Q4_0)])
 def test_lm_steps_match_oracle(lt, et):
     cfg = hu.hot.tiny(hu.L, linear_type=lt, embed_type=et)
     cfg.enable_mimi_encoder = cfg.enable_mimi_decoder = 0
     ref, _ = run_lm("oracle", cfg, 8)
     got, st = run_lm("hip", cfg, 8)
-    check_lm(ref, got)
+    check_lm(ref, got, tol=TYPE_TOL[lt])
     assert st.graph_replays > 0, "cached graphs must replay as hipGraphs"
-    if lt in (Q4_K, BF16, F32):
+    if lt in (Q4_K, BF16, F32, Q8_0, Q4_0):
         assert st.fused_nodes_in_last_plan > 0, "fusion matchers did not fire on the Depth graph"
 
 
