@@ -906,7 +906,7 @@ void k_matvec(hipStream_t s, const mv_args & a) {
 // the probabilities are bit-identical to the single-workgroup path; P x V partials -> global; the last workgroup to arrive adds
 // them in slot order. The wait cannot deadlock: workgroups are dispatched in blockIdx order and a head's workgroups are
 // contiguous, so the lowest unfinished head always has all of its workgroups resident (the spin is bounded regardless).
-struct attn_split_ws { float * scores; float * pmax; double * opart; unsigned * arrive; unsigned * done; int S; unsigned * err; };
+struct attn_split_ws { float * scores; float * pmax; double * opart; unsigned * arrive; unsigned * done; int S; unsigned * err; int slots; };
 
 template <bool SPLIT>
 __global__ void __launch_bounds__(ATTN_THREADS) __attribute__((amdgpu_waves_per_eu(2)))   // >= 2 workgroups per CU: the split grid (<= 512) is resident
@@ -914,11 +914,12 @@ attn_decode_kernel(attn_args a, attn_split_ws w) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // passes whose ring rows are requested before the first wait: the whole 256-slot range of a split workgroup, or the first
     // four passes of the single-workgroup kernel (the rest streams in the pass loops)
-    constexpr int NPRE = SPLIT ? ATTN_SPLIT_SLOTS / 16 : ATTN_NPRE;   // (16 slots per pass at D = 128)
+    constexpr int NPRE = SPLIT ? 8 : ATTN_NPRE;   // (8 x 16 slots at D = 128: half of a split workgroup's range; more would spill registers)
     const int D = a.D, C = a.C, T = a.T;
     const int S = SPLIT ? w.S : 1;
     const int h = SPLIT ? (int) blockIdx.x / S : (int) blockIdx.x, s_idx = SPLIT ? (int) blockIdx.x % S : 0;
-    const int c_base = s_idx * ATTN_SPLIT_SLOTS;
+    const int SLOTS = SPLIT ? w.slots : ATTN_SPLIT_SLOTS;
+    const int c_base = s_idx * SLOTS;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     float * sc   = (float *) smem;          // [C] scores -> exponentials of the current query row
     float * qf   = sc + C;                  // [T][D] bf16-rounded rotated q
@@ -1045,9 +1046,9 @@ attn_decode_kernel(attn_args a, attn_split_ws w) {
     }
     if (!SPLIT || s_idx == 0) n_end = block_max_i32(last_live) + 1;
     else __syncthreads();
-    const int P = SPLIT && n_end > ATTN_SINGLE_MAX ? (n_end + ATTN_SPLIT_SLOTS - 1) / ATTN_SPLIT_SLOTS : 1;   // participating workgroups of this head
+    const int P = SPLIT && n_end > ATTN_SINGLE_MAX ? (n_end + SLOTS - 1) / SLOTS : 1;   // participating workgroups of this head
     const bool multi = SPLIT && P > 1;
-    const int c_lo = multi ? c_base : 0, c_hi = multi ? min(n_end, c_base + ATTN_SPLIT_SLOTS) : n_end;   // slots whose K / V rows this workgroup reads
+    const int c_lo = multi ? c_base : 0, c_hi = multi ? min(n_end, c_base + SLOTS) : n_end;   // slots whose K / V rows this workgroup reads
     // a prefetched row may be the slot that was just rewritten (last writer wins, like set_rows): take it from LDS instead
     auto pack_row = [&](const float * src) {
         uint4 r;
@@ -1093,11 +1094,20 @@ attn_decode_kernel(attn_args a, attn_split_ws w) {
             const int c0 = c_lo + wave * SPW + pi * 4 * SPW;
             if (c0 < c_hi) score_pass(c0, kpre[pi]);
         }
-        for (int c0 = c_lo + wave * SPW + NPRE * 4 * SPW; c0 < c_hi; c0 += 4 * SPW) {
-            const int c = c0 + sub, f = fresh_of(c);
-            uint4 kv = *(const uint4 *) (kc + (int64_t) (c < C ? c : C - 1) * a.k_nb1 + dl * 2);
-            if (f >= 0) kv = pack_row(knew + f * D + dl);
-            score_pass(c0, kv);
+        // further slots: NPRE rows requested together, then consumed (one memory round trip per batch, not per pass)
+        for (int cb = c_lo + NPRE * 4 * SPW; cb < c_hi; cb += NPRE * 4 * SPW) {
+            uint4 kb[NPRE];
+#pragma unroll
+            for (int pi = 0; pi < NPRE; pi++) {
+                const int c = cb + wave * SPW + pi * 4 * SPW + sub, f = fresh_of(c);
+                kb[pi] = *(const uint4 *) (kc + (int64_t) (c < C ? c : C - 1) * a.k_nb1 + dl * 2);
+                if (f >= 0) kb[pi] = pack_row(knew + f * D + dl);
+            }
+#pragma unroll
+            for (int pi = 0; pi < NPRE; pi++) {
+                const int c0 = cb + wave * SPW + pi * 4 * SPW;
+                if (c0 < c_hi) score_pass(c0, kb[pi]);
+            }
         }
         if (NPRE > ATTN_NPRE) {
             // the remaining V rows of a split workgroup go out now (the K registers are free) and arrive during the head-wide wait
@@ -1172,11 +1182,19 @@ attn_decode_kernel(attn_args a, attn_split_ws w) {
             const int c0 = c_lo + wave * SPW + pi * 4 * SPW;
             if (c0 < c_hi) pv_pass(c0, vpre[pi]);
         }
-        for (int c0 = c_lo + wave * SPW + NPRE * 4 * SPW; c0 < c_hi; c0 += 4 * SPW) {
-            const int c = c0 + sub, f = fresh_of(c);
-            uint4 vv = *(const uint4 *) (vc + (int64_t) (c < C ? c : C - 1) * a.v_nb1 + dl * 2);
-            if (f >= 0) vv = pack_row(vnew + f * D + dl);
-            pv_pass(c0, vv);
+        for (int cb = c_lo + NPRE * 4 * SPW; cb < c_hi; cb += NPRE * 4 * SPW) {
+            uint4 vb[NPRE];
+#pragma unroll
+            for (int pi = 0; pi < NPRE; pi++) {
+                const int c = cb + wave * SPW + pi * 4 * SPW + sub, f = fresh_of(c);
+                vb[pi] = *(const uint4 *) (vc + (int64_t) (c < C ? c : C - 1) * a.v_nb1 + dl * 2);
+                if (f >= 0) vb[pi] = pack_row(vnew + f * D + dl);
+            }
+#pragma unroll
+            for (int pi = 0; pi < NPRE; pi++) {
+                const int c0 = cb + wave * SPW + pi * 4 * SPW;
+                if (c0 < c_hi) pv_pass(c0, vb[pi]);
+            }
         }
 #pragma unroll
         for (int i = 0; i < 8; i++) red[(wave * SPW + sub) * D + dl + i] = o8[i];
@@ -1214,18 +1232,20 @@ attn_decode_kernel(attn_args a, attn_split_ws w) {
 }
 
 static bool attn_use_split(const attn_args & a) { return a.T == 1 && a.D == 128 && a.C >= ATTN_SPLIT_MIN_C; }
+static int attn_split_slots() { static const int v = env_int("MI355X_ATTN_SLOTS", ATTN_SPLIT_SLOTS); return v < ATTN_SINGLE_MAX ? ATTN_SINGLE_MAX : v; }
 size_t k_attn_decode_ws_size(const attn_args & a) {
     if (!attn_use_split(a)) return 0;
-    const size_t S = (size_t) (a.C + ATTN_SPLIT_SLOTS - 1) / ATTN_SPLIT_SLOTS;
+    const size_t S = (size_t) (a.C + attn_split_slots() - 1) / attn_split_slots();
     return (size_t) a.H * a.C * 4 + (size_t) a.H * S * 4 + (size_t) a.H * S * a.D * 8 + (size_t) a.H * 8 + 256;
 }
 void k_attn_decode(hipStream_t s, const attn_args & a, void * ws, unsigned * err) {
     GGML_ASSERT(a.D % 8 == 0 && 64 % (a.D / 8) == 0 && a.D <= 512 && a.T >= 1 && a.T <= ATTN_MAX_T && a.T * a.D <= 2 * ATTN_THREADS);
     const size_t smem = (size_t) a.C * 4 + (size_t) a.T * a.D * 4 * 3 + (size_t) (ATTN_THREADS / 64) * 64 * 8 * 8 + 16;
     GGML_ASSERT(smem <= 160 * 1024);
-    attn_split_ws w = { nullptr, nullptr, nullptr, nullptr, nullptr, 1, err };
+    attn_split_ws w = { nullptr, nullptr, nullptr, nullptr, nullptr, 1, err, ATTN_SPLIT_SLOTS };
     if (ws && attn_use_split(a)) {
-        const int S = (a.C + ATTN_SPLIT_SLOTS - 1) / ATTN_SPLIT_SLOTS;
+        const int S = (a.C + attn_split_slots() - 1) / attn_split_slots();
+        w.slots = attn_split_slots();
         GGML_ASSERT(a.D == 128 && "split prefetch depth is sized for 16 slots per pass");
         char * p = (char *) ws;
         w.arrive = (unsigned *) p; w.done = w.arrive + a.H; p += ((size_t) a.H * 8 + 255) & ~(size_t) 255;
