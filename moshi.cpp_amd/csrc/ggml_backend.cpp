@@ -196,10 +196,46 @@ static ggml_backend_buffer_t cpu_alloc_buffer(ggml_backend_t, size_t size) {
 
 static const char * cpu_backend_name(ggml_backend_t) { return "CPU"; }
 static void cpu_backend_free(ggml_backend_t b) { delete (cpu_backend_ctx *) b->context; delete b; }
+// Load-time type conversion on host tensors. The reference quantises safetensors weights with a one-node ggml_cast graph
+// on the CPU backend before copying them to the accelerator (src/loader.h:180-187, src/moshi.cpp:107); that - and nothing
+// else - is what the host device executes by itself: graphs made only of cpy / cont / dup (plus layout nodes) over contiguous
+// tensors. Every other op still fails loudly: the decode hot path has no CPU route.
+static bool cast_only_graph(const struct ggml_cgraph * g) {
+    for (int i = 0; i < g->n_nodes; i++) {
+        const struct ggml_tensor * n = g->nodes[i];
+        switch (n->op) {
+            case GGML_OP_NONE: case GGML_OP_VIEW: case GGML_OP_RESHAPE: case GGML_OP_PERMUTE: case GGML_OP_TRANSPOSE: break;
+            case GGML_OP_CPY: case GGML_OP_CONT: case GGML_OP_DUP:
+                if (!ggml_is_contiguous(n) || !ggml_is_contiguous(n->src[0]) || ggml_nelements(n) != ggml_nelements(n->src[0])) return false;
+                break;
+            default: return false;
+        }
+    }
+    return g->n_nodes > 0;
+}
+static void host_cast(const struct ggml_tensor * src, struct ggml_tensor * dst) {
+    const int64_t K = src->ne[0], rows = ggml_nelements(src) / K;
+    if (src->type == dst->type) { memcpy(dst->data, src->data, ggml_nbytes(src)); return; }
+    GGML_ASSERT(dst->ne[0] == K && "a converting copy keeps the row length");
+    std::vector<float> row((size_t) K);
+    for (int64_t r = 0; r < rows; r++) {
+        const char * sp = (const char *) src->data + (size_t) r * ggml_row_size(src->type, K);
+        char * dp = (char *) dst->data + (size_t) r * ggml_row_size(dst->type, K);
+        if (src->type == GGML_TYPE_F32) ggml_quantize_row(dst->type, (const float *) sp, dp, K);
+        else { ggml_dequantize_row(src->type, sp, row.data(), K); ggml_quantize_row(dst->type, row.data(), dp, K); }
+    }
+}
 static enum ggml_status cpu_graph_compute(ggml_backend_t b, struct ggml_cgraph * g) {
+    if (!g_cpu_compute && cast_only_graph(g)) {
+        for (int i = 0; i < g->n_nodes; i++) {
+            struct ggml_tensor * n = g->nodes[i];
+            if (n->op == GGML_OP_CPY || n->op == GGML_OP_CONT || n->op == GGML_OP_DUP) host_cast(n->src[0], n);
+        }
+        return GGML_STATUS_SUCCESS;
+    }
     if (!g_cpu_compute) {
-        fprintf(stderr, "ggml (mi355x build): the CPU device has no graph executor; the decode hot path runs on the "
-                        "MI355X device only. Attach one with ggml_backend_cpu_set_graph_compute() (tests use oracle/).\n");
+        fprintf(stderr, "ggml (mi355x build): the CPU device has no graph executor (only load-time cpy/cast graphs run on the host); "
+                        "the decode hot path runs on the MI355X device only. Attach one with ggml_backend_cpu_set_graph_compute() (tests use oracle/).\n");
         return GGML_STATUS_FAILED;
     }
     return g_cpu_compute(g, ((cpu_backend_ctx *) b->context)->n_threads);

@@ -62,6 +62,24 @@ def test_cpu_device_has_no_builtin_executor():
     L.ggml_build_forward_expand(g, y)
     buf = L.ggml_backend_alloc_ctx_tensors(ctx, cpu)
     assert L.ggml_backend_graph_compute(cpu, g) == -1   # GGML_STATUS_FAILED
+
+    # ... with one exception: the load-time re-quantisation graph of the reference's weight loader (a lone ggml_cast on host
+    # tensors, src/loader.h:180-187) is converted on the host
+    w = L.ggml_new_tensor_2d(ctx, 0, 512, 3)           # F32 [512, 3]
+    q = L.ggml_cast(ctx, w, 12)                        # -> Q4_K
+    back = L.ggml_cast(ctx, q, 0)                      # -> F32 again
+    g2 = L.ggml_new_graph(ctx)
+    L.ggml_build_forward_expand(g2, back)
+    buf2 = L.ggml_backend_alloc_ctx_tensors(ctx, cpu)
+    assert buf2
+    import numpy as np
+    x = (np.random.default_rng(0).standard_normal((3, 512)) * 0.05).astype(np.float32)
+    L.ggml_backend_tensor_set(w, x.ctypes.data, 0, x.nbytes)
+    assert L.ggml_backend_graph_compute(cpu, g2) == 0
+    y = np.zeros_like(x)
+    L.ggml_backend_tensor_get(back, y.ctypes.data, 0, y.nbytes)
+    assert np.abs(y - x).max() < 0.02 and np.abs(y - x).mean() < 0.004   # 4-bit round trip of N(0, 0.05)
+    L.ggml_backend_buffer_free(buf2)
     L.ggml_backend_buffer_free(buf)
     L.ggml_free(ctx)
     L.ggml_backend_free(cpu)
