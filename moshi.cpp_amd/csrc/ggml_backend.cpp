@@ -196,26 +196,46 @@ static ggml_backend_buffer_t cpu_alloc_buffer(ggml_backend_t, size_t size) {
 
 static const char * cpu_backend_name(ggml_backend_t) { return "CPU"; }
 static void cpu_backend_free(ggml_backend_t b) { delete (cpu_backend_ctx *) b->context; delete b; }
-// Load-time type conversion on host tensors. The reference quantises safetensors weights with a one-node ggml_cast graph
-// on the CPU backend before copying them to the accelerator (src/loader.h:180-187, src/moshi.cpp:107); that - and nothing
-// else - is what the host device executes by itself: graphs made only of cpy / cont / dup (plus layout nodes) over contiguous
-// tensors. Every other op still fails loudly: the decode hot path has no CPU route.
-static bool cast_only_graph(const struct ggml_cgraph * g) {
+// Load-time graphs on host tensors. The reference prepares safetensors weights with tiny graphs on its CPU backend before
+// copying them to the accelerator (scratch_cpu, src/moshi.cpp:107): a lone ggml_cast for re-quantisation (src/loader.h:180-187),
+// row-range views + cast for the per-step projection split (transformer.h:780-848), and clamp / cont(transpose) / div for the
+// codebook centroids (core_vq.h:58-85). Exactly that op set - cpy / cont / dup, clamp, div, layout nodes - is what the host
+// device executes by itself, in plain scalar loops. Every other op still fails loudly: the decode hot path has no CPU route.
+static bool load_time_graph(const struct ggml_cgraph * g) {
     for (int i = 0; i < g->n_nodes; i++) {
         const struct ggml_tensor * n = g->nodes[i];
         switch (n->op) {
             case GGML_OP_NONE: case GGML_OP_VIEW: case GGML_OP_RESHAPE: case GGML_OP_PERMUTE: case GGML_OP_TRANSPOSE: break;
             case GGML_OP_CPY: case GGML_OP_CONT: case GGML_OP_DUP:
-                if (!ggml_is_contiguous(n) || !ggml_is_contiguous(n->src[0]) || ggml_nelements(n) != ggml_nelements(n->src[0])) return false;
+                if (ggml_nelements(n) != ggml_nelements(n->src[0])) return false;
+                if (n->type != n->src[0]->type && !(ggml_is_contiguous(n) && ggml_is_contiguous(n->src[0]))) return false;
+                if (n->type == n->src[0]->type && n->type != GGML_TYPE_F32 && !(ggml_is_contiguous(n) && ggml_is_contiguous(n->src[0]))) return false;
+                break;
+            case GGML_OP_CLAMP:
+                if (n->type != GGML_TYPE_F32) return false;
+                break;
+            case GGML_OP_DIV:
+                if (n->type != GGML_TYPE_F32 || n->src[0]->type != GGML_TYPE_F32 || n->src[1]->type != GGML_TYPE_F32 || !ggml_are_same_shape(n, n->src[0])) return false;
                 break;
             default: return false;
         }
     }
     return g->n_nodes > 0;
 }
+static inline char * elem_ptr(const struct ggml_tensor * t, int64_t i0, int64_t i1, int64_t i2, int64_t i3) {
+    return (char *) t->data + i0 * (int64_t) t->nb[0] + i1 * (int64_t) t->nb[1] + i2 * (int64_t) t->nb[2] + i3 * (int64_t) t->nb[3];
+}
 static void host_cast(const struct ggml_tensor * src, struct ggml_tensor * dst) {
+    if (src->type == dst->type && ggml_is_contiguous(src) && ggml_is_contiguous(dst)) { memcpy(dst->data, src->data, ggml_nbytes(src)); return; }
+    if (src->type == GGML_TYPE_F32 && dst->type == GGML_TYPE_F32) {   // strided copy in logical element order (cont of a transpose, ...)
+        int64_t d[4] = { 0, 0, 0, 0 };
+        for (int64_t i3 = 0; i3 < src->ne[3]; i3++) for (int64_t i2 = 0; i2 < src->ne[2]; i2++) for (int64_t i1 = 0; i1 < src->ne[1]; i1++) for (int64_t i0 = 0; i0 < src->ne[0]; i0++) {
+            *(float *) elem_ptr(dst, d[0], d[1], d[2], d[3]) = *(const float *) elem_ptr(src, i0, i1, i2, i3);
+            if (++d[0] == dst->ne[0]) { d[0] = 0; if (++d[1] == dst->ne[1]) { d[1] = 0; if (++d[2] == dst->ne[2]) { d[2] = 0; ++d[3]; } } }
+        }
+        return;
+    }
     const int64_t K = src->ne[0], rows = ggml_nelements(src) / K;
-    if (src->type == dst->type) { memcpy(dst->data, src->data, ggml_nbytes(src)); return; }
     GGML_ASSERT(dst->ne[0] == K && "a converting copy keeps the row length");
     std::vector<float> row((size_t) K);
     for (int64_t r = 0; r < rows; r++) {
@@ -225,16 +245,33 @@ static void host_cast(const struct ggml_tensor * src, struct ggml_tensor * dst) 
         else { ggml_dequantize_row(src->type, sp, row.data(), K); ggml_quantize_row(dst->type, row.data(), dp, K); }
     }
 }
+static void host_load_time_node(struct ggml_tensor * n) {
+    switch (n->op) {
+        case GGML_OP_CPY: case GGML_OP_CONT: case GGML_OP_DUP: host_cast(n->src[0], n); break;
+        case GGML_OP_CLAMP: {
+            const struct ggml_tensor * a = n->src[0];
+            float lo, hi;
+            memcpy(&lo, (const char *) n->op_params, 4); memcpy(&hi, (const char *) n->op_params + 4, 4);
+            for (int64_t i3 = 0; i3 < n->ne[3]; i3++) for (int64_t i2 = 0; i2 < n->ne[2]; i2++) for (int64_t i1 = 0; i1 < n->ne[1]; i1++) for (int64_t i0 = 0; i0 < n->ne[0]; i0++) {
+                const float v = *(const float *) elem_ptr(a, i0, i1, i2, i3);
+                *(float *) elem_ptr(n, i0, i1, i2, i3) = v < lo ? lo : (v > hi ? hi : v);
+            }
+        } break;
+        case GGML_OP_DIV: {
+            const struct ggml_tensor * a = n->src[0], * b = n->src[1];
+            for (int64_t i3 = 0; i3 < n->ne[3]; i3++) for (int64_t i2 = 0; i2 < n->ne[2]; i2++) for (int64_t i1 = 0; i1 < n->ne[1]; i1++) for (int64_t i0 = 0; i0 < n->ne[0]; i0++)
+                *(float *) elem_ptr(n, i0, i1, i2, i3) = *(const float *) elem_ptr(a, i0, i1, i2, i3) / *(const float *) elem_ptr(b, i0 % b->ne[0], i1 % b->ne[1], i2 % b->ne[2], i3 % b->ne[3]);
+        } break;
+        default: break;
+    }
+}
 static enum ggml_status cpu_graph_compute(ggml_backend_t b, struct ggml_cgraph * g) {
-    if (!g_cpu_compute && cast_only_graph(g)) {
-        for (int i = 0; i < g->n_nodes; i++) {
-            struct ggml_tensor * n = g->nodes[i];
-            if (n->op == GGML_OP_CPY || n->op == GGML_OP_CONT || n->op == GGML_OP_DUP) host_cast(n->src[0], n);
-        }
+    if (!g_cpu_compute && load_time_graph(g)) {
+        for (int i = 0; i < g->n_nodes; i++) host_load_time_node(g->nodes[i]);
         return GGML_STATUS_SUCCESS;
     }
     if (!g_cpu_compute) {
-        fprintf(stderr, "ggml (mi355x build): the CPU device has no graph executor (only load-time cpy/cast graphs run on the host); "
+        fprintf(stderr, "ggml (mi355x build): the CPU device has no graph executor (only load-time cpy/cast/clamp/div graphs run on the host); "
                         "the decode hot path runs on the MI355X device only. Attach one with ggml_backend_cpu_set_graph_compute() (tests use oracle/).\n");
         return GGML_STATUS_FAILED;
     }

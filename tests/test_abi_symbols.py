@@ -80,6 +80,24 @@ def test_cpu_device_has_no_builtin_executor():
     L.ggml_backend_tensor_get(back, y.ctypes.data, 0, y.nbytes)
     assert np.abs(y - x).max() < 0.02 and np.abs(y - x).mean() < 0.004   # 4-bit round trip of N(0, 0.05)
     L.ggml_backend_buffer_free(buf2)
+
+    # ... and the codebook preparation of the Mimi loader (core_vq.h:58-85): embedding_sum / cont(transpose(clamp(cluster_usage)))
+    es = L.ggml_new_tensor_2d(ctx, 0, 8, 5)            # [dim 8, 5 centroids]
+    cu = L.ggml_new_tensor_2d(ctx, 0, 5, 1)            # [5, 1]
+    cl = L.ggml_clamp(ctx, cu, 1e-5, float("inf"))
+    emb = L.ggml_div(ctx, es, L.ggml_cont(ctx, L.ggml_transpose(ctx, cl)))
+    g3 = L.ggml_new_graph(ctx)
+    L.ggml_build_forward_expand(g3, emb)
+    buf3 = L.ggml_backend_alloc_ctx_tensors(ctx, cpu)
+    a = np.arange(40, dtype=np.float32).reshape(5, 8)
+    u = np.array([[2.0, 0.0, 4.0, 1e-9, 0.5]], np.float32)
+    L.ggml_backend_tensor_set(es, a.ctypes.data, 0, a.nbytes)
+    L.ggml_backend_tensor_set(cu, u.ctypes.data, 0, u.nbytes)
+    assert L.ggml_backend_graph_compute(cpu, g3) == 0
+    o = np.zeros_like(a)
+    L.ggml_backend_tensor_get(emb, o.ctypes.data, 0, o.nbytes)
+    np.testing.assert_array_equal(o, a / np.maximum(u.reshape(5, 1), np.float32(1e-5)))
+    L.ggml_backend_buffer_free(buf3)
     L.ggml_backend_buffer_free(buf)
     L.ggml_free(ctx)
     L.ggml_backend_free(cpu)
