@@ -139,6 +139,27 @@ def test_mimi_encoder_codes_exact():
     assert codes["oracle"] == codes["hip"]
 
 
+def test_mimi_fused_equals_unfused():
+    # the codec fusions (streaming conv / conv-transpose groups, RVQ levels and sums, scalar gather, fused transformer layers)
+    # against one generic kernel per node on the same device: same codes, same samples up to summation order
+    cfg = hu.hot.tiny(hu.L)
+    cfg.enable_lm = 0
+    rng = np.random.default_rng(21)
+    frames = [rng.standard_normal(1920).astype(np.float32) * 0.2 for _ in range(6)]
+    res = {}
+    for flags in (0, 1 | 2 | 4):
+        m = hu.Model("hip", cfg, seed=0, flags=flags)
+        codes = [m.mimi_encode(f) for f in frames]
+        pcm = [m.mimi_decode(c) for c in codes]
+        st = m.stats()
+        m.free()
+        res[flags] = (codes, pcm, st)
+    assert res[0][0] == res[7][0], "RVQ codes differ between the fused and the per-node path"
+    errs = [hu.rel_err(a, b) for a, b in zip(res[7][1], res[0][1])]
+    assert max(errs) < 1e-5, f"pcm fused vs unfused rel err {max(errs):.2e}"
+    assert res[0][2].fused_nodes_in_last_plan > 0 and res[7][2].fused_nodes_in_last_plan == 0
+
+
 def test_long_ring_split_attention_teacher_forced():
     # Ring capacity 1280 >= ATTN_SPLIT_MIN_C: the Temporal attention runs split over 5 workgroups per head once more than
     # 256 slots are live (hip_kernels_fused.hip, attn_decode_kernel<true>). 560 teacher-forced steps cross P = 1 -> 2 -> 3
