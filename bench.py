@@ -196,7 +196,7 @@ def main():
                                   "avg_launch_us": round(1e6 * kp.seconds / kp.launches, 3),
                                   "algorithmic_bytes_per_launch": int(kp.bytes // kp.launches)}
 
-    if rank == 0 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
         # the same frame loop on the host cores through the CPU oracle (a port of ggml's CPU semantics; the reference's
         # own ggml CPU backend cannot be built here or on the box). Bounded sample: ~10-30 s of CPU work.
         try:
