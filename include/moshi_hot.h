@@ -65,7 +65,12 @@ GGML_API int moshi_hot_sts_frame(moshi_hot_model_t * m, const float * pcm_in, in
 GGML_API int64_t moshi_hot_offset(moshi_hot_model_t * m);                      // frames stepped so far
 GGML_API void    moshi_hot_last_raw_tokens(moshi_hot_model_t * m, int32_t * text_token, int32_t * audio_tokens);  // sampled this step, before the delay ring
 GGML_API size_t  moshi_hot_weight_bytes(moshi_hot_model_t * m, int part);     // 0 temporal, 1 depth, 2 mimi enc, 3 mimi dec, 4 embeddings
-GGML_API int     moshi_hot_read_last(moshi_hot_model_t * m, const char * what, float * out, int64_t n);  // "text_logits", "transformer_out", "dep_logits"
+GGML_API int     moshi_hot_read_last(moshi_hot_model_t * m, const char * what, float * out, int64_t n);  // "text_logits", "transformer_out", "transformer_in", "stack_out", "dep_logits<k>"
+// a weight tensor by its checkpoint-style name (e.g. "lm.transformer.layers.0.self_attn.in_projs.weight"); tests/ref_link uses it
+// to hand the SAME tensors to the reference's own graph builders
+GGML_API struct ggml_tensor * moshi_hot_weight(moshi_hot_model_t * m, const char * name);
+// the cached graph of a phase once it has run (0 temporal, 1 depth, 2 mimi encoder, 3 mimi decoder), for structural comparison
+GGML_API struct ggml_cgraph * moshi_hot_graph(moshi_hot_model_t * m, int which);
 // per-phase wall clock (synchronises around each phase while on): us_per_call[4] = mimi encode, temporal, depth, mimi decode
 GGML_API void    moshi_hot_set_timing(moshi_hot_model_t * m, int on);
 GGML_API void    moshi_hot_get_timing(moshi_hot_model_t * m, double * us_per_call);

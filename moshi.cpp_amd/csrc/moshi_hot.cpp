@@ -14,6 +14,7 @@
 #include <string.h>
 
 #include <functional>
+#include <map>
 #include <string>
 #include <vector>
 
@@ -114,6 +115,7 @@ struct Weights {
     uint64_t seed;
     struct pending { T t; std::function<void(T, Rng &, std::vector<uint8_t> &)> gen; std::string name; };
     std::vector<pending> todo;
+    std::map<std::string, T> by_name;
     size_t bytes[5] = { 0, 0, 0, 0, 0 };
     int part = 0;
 
@@ -126,6 +128,7 @@ struct Weights {
         T t = ggml_new_tensor_3d(ctx, type, n0, n1, n2);
         ggml_set_name(t, name.size() < GGML_MAX_NAME ? name.c_str() : name.substr(name.size() - GGML_MAX_NAME + 1).c_str());
         todo.push_back({ t, gen, name });
+        by_name[name] = t;   // full checkpoint name (ggml names are cut to GGML_MAX_NAME, which makes encoder/decoder tails collide)
         bytes[part] += ggml_nbytes(t);
         return t;
     }
@@ -549,7 +552,7 @@ struct moshi_hot_model {
     std::vector<T> emb, depformer_in, depformer_emb, linears;
     T depformer_text_emb = nullptr;
     T transformer_out = nullptr;   // state F32[dim] (lm.h:434)
-    Builder * g_temporal = nullptr; std::vector<T> emb_idx, emb_scale; T sampler_out = nullptr, text_logits = nullptr, g_transformer_out = nullptr;
+    Builder * g_temporal = nullptr; std::vector<T> emb_idx, emb_scale; T sampler_out = nullptr, text_logits = nullptr, g_transformer_out = nullptr, g_transformer_in = nullptr, g_stack_out = nullptr;
     Builder * g_depth = nullptr; T dep_text_idx = nullptr, dep_text_scale = nullptr, dep_tokens = nullptr; std::vector<T> dep_logits;
     // delay ring (lm.h:715-743)
     int offset = 0; std::vector<std::vector<int>> cache; std::vector<int> initial; int max_delay = 0;
@@ -663,7 +666,9 @@ void build_temporal_graph(moshi_hot_model * m) {
     };
     T input = embed(m->text_emb);
     for (int k = 0; k < c.n_q; k++) input = ggml_add(g, input, embed(m->emb[(size_t) k]));
+    m->g_transformer_in = input;
     T x = transformer_graph_build(g, m->temporal, input);
+    m->g_stack_out = x;
     x = apply_norm(g, m->out_norm, x);
     m->g_transformer_out = x;
     m->text_logits = linear(g, m->text_linear, x);
@@ -985,10 +990,20 @@ extern "C" int moshi_hot_read_last(moshi_hot_model_t * m, const char * what, flo
     T t = nullptr;
     if (!strcmp(what, "text_logits")) t = m->text_logits;
     else if (!strcmp(what, "transformer_out")) t = m->transformer_out;
+    else if (!strcmp(what, "transformer_in")) t = m->g_transformer_in;     // sum of the 17 embeddings (input of the Temporal stack)
+    else if (!strcmp(what, "stack_out")) t = m->g_stack_out;               // output of the Temporal stack, before out_norm
     else if (!strncmp(what, "dep_logits", 10)) { const int k = atoi(what + 10); if (k >= 0 && k < (int) m->dep_logits.size()) t = m->dep_logits[(size_t) k]; }
     if (!t || ggml_nelements(t) < n) return -1;
     ggml_backend_tensor_get(t, out, 0, (size_t) n * 4);
     return 0;
+}
+extern "C" struct ggml_cgraph * moshi_hot_graph(moshi_hot_model_t * m, int which) {
+    Builder * b = which == 0 ? m->g_temporal : which == 1 ? m->g_depth : which == 2 ? m->g_enc : which == 3 ? m->g_dec : nullptr;
+    return b ? b->gf : nullptr;
+}
+extern "C" struct ggml_tensor * moshi_hot_weight(moshi_hot_model_t * m, const char * name) {
+    auto it = m->W->by_name.find(name);
+    return it == m->W->by_name.end() ? nullptr : it->second;
 }
 extern "C" void moshi_hot_set_timing(moshi_hot_model_t * m, int on) { m->timing = on != 0; for (int i = 0; i < 4; i++) { m->phase_us[i] = 0; m->phase_n[i] = 0; } }
 extern "C" void moshi_hot_get_timing(moshi_hot_model_t * m, double * us_per_call) { for (int i = 0; i < 4; i++) us_per_call[i] = m->phase_n[i] ? m->phase_us[i] / (double) m->phase_n[i] : 0.0; }

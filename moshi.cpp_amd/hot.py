@@ -26,6 +26,8 @@ SIGNATURES = {
     "moshi_hot_offset": (C.c_int64, [P]),
     "moshi_hot_weight_bytes": (C.c_size_t, [P, C.c_int]),
     "moshi_hot_read_last": (C.c_int, [P, C.c_char_p, P, C.c_int64]),
+    "moshi_hot_weight": (P, [P, C.c_char_p]),
+    "moshi_hot_graph": (P, [P, C.c_int]),
     "moshi_hot_set_context_fill": (None, [P, C.c_int64]),
     "moshi_hot_force_last": (None, [P, C.c_int32, P]),
     "moshi_hot_set_timing": (None, [P, C.c_int]),
