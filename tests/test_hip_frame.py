@@ -20,13 +20,16 @@ LOGIT_TOL = 1e-2
 PCM_TOL = 1e-2
 
 
-def run_lm(kind, cfg, steps, seed=3, flags=0, forced=None):
-    """Free-running when forced is None; otherwise after every step the ring is overwritten with forced[i] (teacher forcing)."""
+def run_lm(kind, cfg, steps, seed=3, flags=0, forced=None, srand=None):
+    """Free-running when forced is None; otherwise after every step the ring is overwritten with forced[i] (teacher forcing).
+    srand: re-seed libc rand() before every step (the sampler's exponential noise is drawn from it on the host)."""
     m = hu.Model(kind, cfg, seed=0, flags=flags)
     rng = np.random.default_rng(seed)
     rec = []
     n_in = cfg.n_q - cfg.dep_q
     for i in range(steps):
+        if srand is not None:
+            srand(1000 + i)
         ia = rng.integers(0, cfg.card, n_in).tolist()
         r, txt, aud = m.lm_step(ia)
         raw = m.last_raw()
@@ -66,6 +69,21 @@ def test_lm_steps_match_oracle(lt, et):
     assert st.graph_replays > 0, "cached graphs must replay as hipGraphs"
     if lt in (Q4_K, BF16, F32, Q8_0, Q4_0):
         assert st.fused_nodes_in_last_plan > 0, "fusion matchers did not fire on the Depth graph"
+
+
+def test_sampled_decoding_matches_oracle_with_the_same_host_noise():
+    # temp > 0: softmax(l / T) -> top-k -> argmax(p / Exp(1)) (sampling.h:4-64); the exponential noise comes from libc rand() on the
+    # host and is uploaded per compute (context.h:456-480), so re-seeding libc before every step gives both backends the same draws
+    import ctypes
+    libc = ctypes.CDLL(None)
+    cfg = hu.hot.tiny(hu.L)
+    cfg.enable_mimi_encoder = cfg.enable_mimi_decoder = 0
+    cfg.temp, cfg.temp_text, cfg.top_k, cfg.top_k_text = 0.8, 0.7, 20, 10
+    ref, _ = run_lm("oracle", cfg, 10, srand=libc.srand)
+    got, _ = run_lm("hip", cfg, 10, srand=libc.srand)
+    for i, (a, b) in enumerate(zip(ref, got)):
+        assert a[:3] == b[:3], f"step {i}: sampled tokens differ: oracle {a[:3]} vs hip {b[:3]}"
+    assert len({a[1] for a in ref}) > 1, "sampling produced a constant text token: the test is not exercising the sampler"
 
 
 def test_fused_and_unfused_paths_agree_with_oracle():

@@ -268,3 +268,24 @@ def test_add_inplace_and_negative_view_offsets():
         outs, _, extra = build(g)
         return [extra[0], extra[1], g.cont(extra[2])] + outs
     gu.compare(build3, atol_rel=0, rtol=0)
+
+
+def test_sampler_chain_top_k_with_given_noise():
+    # moshi_sample_token for temp > 0 (sampling.h:4-64) with the exponential noise supplied as an input
+    n, k = 500, 10
+    logits = rnd(1, n) * 3
+    noise = rng.exponential(1.0, (1, k)).astype(np.float32)
+
+    def build(g):
+        lg = g.input(logits)
+        probs = g.soft_max(g.scale(lg, 1.0 / 0.7))
+        indices = g.argsort_top_k(probs, k)
+        rows = g.get_rows(g.cont(g.permute(probs, 1, 0, 2, 3)), indices)
+        p2 = g.permute(rows, 1, 0, 2, 3)
+        in2 = g.reshape_2d(p2, p2.contents.ne[0], p2.contents.ne[1] * p2.contents.ne[2] * p2.contents.ne[3])
+        q = g.div(in2, g.input(noise))
+        nxt = g.argmax(q)
+        nxt4 = g.reshape_4d(nxt, nxt.contents.ne[0], p2.contents.ne[1], p2.contents.ne[2], p2.contents.ne[3])
+        tok = g.get_rows(g.cont(g.permute(indices, 1, 0, 2, 3)), nxt4)
+        return [tok, g.cont(indices), g.cont(q)]
+    gu.compare(build)
