@@ -800,7 +800,7 @@ void k_matvec(hipStream_t s, const mv_args & a) {
         // Workgroup shape. Large matrices (>= ~8 tiles per CU): ONE workgroup of 8 or 12 waves per CU, so the activation
         // prologue (cost ~K, identical in every workgroup) runs once per CU and every wave keeps a 9 KB tile in flight.
         // Small matrices: 4-wave workgroups of >= 1 tile each, as many as there are tiles (latency-bound anyway).
-        static const int force_nw = env_int("MI355X_MV_NW", 0), tpw_min = env_int("MI355X_MV_TPW", 4), grid_min = env_int("MI355X_MV_GRID_MIN", 256);
+        static const int force_nw = env_int("MI355X_MV_NW", 0), tpw_min = env_int("MI355X_MV_TPW", 4), grid_min = env_int("MI355X_MV_GRID_MIN", 128);   // bench sweep (tests/microbench/sweep_bench_mv.sh): Depth 1.27 -> 1.22 ms vs 256
         const int64_t tiles_total = (a.M * nb + 63) / 64;
         int nw = 4, rows;
         if (force_nw ? force_nw > 4 : tiles_total >= 256 * 6) {
