@@ -797,14 +797,15 @@ void k_matvec(hipStream_t s, const mv_args & a) {
         const int nb = (int) (a.K / 256);
         const int fmt = a.wtype == GGML_TYPE_Q4_K ? MVF_Q4K : a.wtype == GGML_TYPE_Q8_0 ? MVF_Q80 : MVF_Q40;
         const size_t tile_bytes = fmt == MVF_Q80 ? 64 * 272 : 64 * 144;
-        // Workgroup shape. Large matrices (>= ~8 tiles per CU): ONE workgroup of 8 or 12 waves per CU, so the activation
+        // Workgroup shape. Large matrices (>= ~6 tiles per CU): ONE workgroup of 8 (optionally 12) waves per CU, so the activation
         // prologue (cost ~K, identical in every workgroup) runs once per CU and every wave keeps a 9 KB tile in flight.
         // Small matrices: 4-wave workgroups of >= 1 tile each, as many as there are tiles (latency-bound anyway).
         static const int force_nw = env_int("MI355X_MV_NW", 0), tpw_min = env_int("MI355X_MV_TPW", 4), grid_min = env_int("MI355X_MV_GRID_MIN", 128);   // bench sweep (tests/microbench/sweep_bench_mv.sh): Depth 1.27 -> 1.22 ms vs 256
         const int64_t tiles_total = (a.M * nb + 63) / 64;
         int nw = 4, rows;
-        if (force_nw ? force_nw > 4 : tiles_total >= 256 * 6) {
-            nw = force_nw ? force_nw : (tiles_total >= 256 * 10 ? 12 : 8);
+        static const int big_tiles = env_int("MI355X_MV_BIG_TILES", 256 * 6), w12_tiles = env_int("MI355X_MV_12W_TILES", 1 << 30);   // bench sweep: 8 waves beat 12 on every moshika shape (Temporal 1.79 -> 1.73 ms)
+        if (force_nw ? force_nw > 4 : tiles_total >= big_tiles) {
+            nw = force_nw ? force_nw : (tiles_total >= w12_tiles ? 12 : 8);
             rows = (int) ((a.M + 255) / 256);
             while (rows * nb > 4096) rows = (rows + 1) / 2;
         } else {
