@@ -860,7 +860,8 @@ void k_matvec(hipStream_t s, const mv_args & a) {
     static const int no_reg = env_int("MI355X_MV_NOREG", 0);
     if (a.wtype == GGML_TYPE_F32 && !no_reg && (a.K == 512 || a.K == 1024 || a.K == 2048) && a.row_bytes % 16 == 0 && ((uintptr_t) a.w % 16) == 0) {
         // one row per wave until every CU has a workgroup, then two
-        const bool two = a.K <= 1024 && a.M >= 4 * 2 * 256;
+        static const int two_min = env_int("MI355X_MVF_TWO_MIN", 4 * 2 * 256);
+        const bool two = a.K <= 1024 && a.M >= two_min;
         const int grid = (int) ((a.M + (two ? 8 : 4) - 1) / (two ? 8 : 4));
         if (a.K == 512)       { if (two) matvec_f32_reg_kernel<2, 2><<<grid, 256, 0, s>>>(a); else matvec_f32_reg_kernel<2, 1><<<grid, 256, 0, s>>>(a); }
         else if (a.K == 1024) { if (two) matvec_f32_reg_kernel<4, 2><<<grid, 256, 0, s>>>(a); else matvec_f32_reg_kernel<4, 1><<<grid, 256, 0, s>>>(a); }

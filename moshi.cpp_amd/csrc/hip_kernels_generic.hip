@@ -480,10 +480,43 @@ __global__ void convtr_finish_kernel(tdesc out, float * prev, const float * bias
         return acc;
     };
     float * pv = prev + (int64_t) oc * OLf;
-    float y = conv_at(t);
-    float y2 = 0.f;
     const bool has2 = t < PT;               // position t + keep lies in the carried tail
-    if (has2) { y = y + pv[keep + t]; y2 = conv_at(t + keep); }
+    float y, y2 = 0.f;
+    if (K <= 2 * s0 && nsplit <= 16) {
+        // at most two taps per output position: request every partial of both positions (2 x 2 taps x 16 splits) before the first
+        // add - the partials were just written by other workgroups, so each dependent batch would cost a memory round trip
+        double v[2][2][16];
+        bool ok[2][2];
+#pragma unroll
+        for (int p = 0; p < 2; p++) {
+            const int tt = p == 0 ? t : t + keep;
+            int l0 = (tt - (K - 1) + s0 - 1) / s0;
+            if (l0 < 0) l0 = 0;
+#pragma unroll
+            for (int q = 0; q < 2; q++) {
+                const int l = l0 + q, k = tt - l * s0;
+                ok[p][q] = (p == 0 || has2) && l < L && k >= 0 && k < K;
+                const int lc = ok[p][q] ? l : 0, kc = ok[p][q] ? k : 0;
+#pragma unroll
+                for (int sp = 0; sp < 16; sp++) v[p][q][sp] = P[((int64_t) (sp < nsplit ? sp : 0) * L + lc) * N + oc * K + kc];
+            }
+        }
+        float r[2] = { 0.f, 0.f };
+#pragma unroll
+        for (int p = 0; p < 2; p++)
+#pragma unroll
+            for (int q = 0; q < 2; q++) {
+                double sum = 0;
+#pragma unroll
+                for (int sp = 0; sp < 16; sp++) if (sp < nsplit) sum += v[p][q][sp];
+                if (ok[p][q]) r[p] += (float) sum;   // taps in ascending l, splits in ascending order: as conv_at
+            }
+        y = r[0]; y2 = r[1];
+        if (has2) y = y + pv[keep + t];
+    } else {
+        y = conv_at(t);
+        if (has2) { y = y + pv[keep + t]; y2 = conv_at(t + keep); }
+    }
     pv[t] = y;
     if (has2) pv[t + keep] = y2;
     *(float *) at(out, t, oc, 0, 0) = bias ? y + bias[oc] : y;
@@ -860,7 +893,8 @@ void k_mul_mat(hipStream_t s, tdesc dst, tdesc a, tdesc b, void * ws, const mm_e
         if (M % 16 == 0 && N % 16 == 0 && a.ne[0] % 32 == 0 && (dst.nb[1] % 16) == 0 && ((uintptr_t) dst.data % 16) == 0) {
             const int mt = M / 16, nt = N / 16, tiles = mt * nt, steps = (int) a.ne[0] / 32;
             int SK = 1;
-            while (SK < 16 && tiles * SK < 512 && steps / (SK * 2) >= 4) SK *= 2;
+            static const int sk_target = getenv("MI355X_MFMA_SK_TARGET") ? atoi(getenv("MI355X_MFMA_SK_TARGET")) : 512;
+            while (SK < 16 && tiles * SK < sk_target && steps / (SK * 2) >= 4) SK *= 2;
             const int TPW = SK >= 4 ? 1 : 4 / SK;
             mul_mat_f16_mfma_kernel<<<(tiles + TPW - 1) / TPW, 64 * SK * TPW, 0, s>>>(dst, a, b, mt, nt, SK, TPW, epi);
             return;
