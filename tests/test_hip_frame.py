@@ -20,10 +20,12 @@ LOGIT_TOL = 1e-2
 PCM_TOL = 1e-2
 
 
-def run_lm(kind, cfg, steps, seed=3, flags=0, forced=None, srand=None):
+def run_lm(kind, cfg, steps, seed=3, flags=0, forced=None, srand=None, context_fill=0):
     """Free-running when forced is None; otherwise after every step the ring is overwritten with forced[i] (teacher forcing).
     srand: re-seed libc rand() before every step (the sampler's exponential noise is drawn from it on the host)."""
     m = hu.Model(kind, cfg, seed=0, flags=flags)
+    if context_fill:
+        hu.L.moshi_hot_set_context_fill(m.m, context_fill)   # Temporal ring position jumps ahead; skipped slots hold their zero init
     rng = np.random.default_rng(seed)
     rec = []
     n_in = cfg.n_q - cfg.dep_q
@@ -193,4 +195,17 @@ def test_long_ring_split_attention_teacher_forced():
     assert errs.max() < 0.2, f"max logit err {errs.max():.2e}"
     assert np.quantile(late, 0.8) < 1e-2, f"80th percentile logit err (split steps) {np.quantile(late, 0.8):.2e}"
     assert np.median(late) < 1e-4, f"median logit err (split steps) {np.median(late):.2e}"
+    assert agree >= 0.9, f"greedy tokens agree on only {agree:.0%} of teacher-forced steps"
+
+
+def test_long_ring_split_attention_across_the_wrap():
+    # the same split path with every slot live and the write position wrapping (offset 1270 .. 1310 over a ring of 1280): five
+    # workgroups per head, the freshly written slot owned by the last and then by the first of them
+    cfg = hu.hot.tiny(hu.L, context=1280, layers=1, dep_q=1, n_q=2)
+    cfg.enable_mimi_encoder = cfg.enable_mimi_decoder = 0
+    ref, _ = run_lm("oracle", cfg, 40, context_fill=1270)
+    got, _ = run_lm("hip", cfg, 40, forced=ref, context_fill=1270)
+    errs = np.array([hu.rel_err(a[3], b[3]) for a, b in zip(ref, got)])
+    agree = np.mean([a[5][0] == b[5][0] for a, b in zip(ref, got)])
+    assert errs.max() < 0.2 and np.quantile(errs, 0.8) < 1e-2 and np.median(errs) < 1e-4, f"logit err max {errs.max():.2e} p80 {np.quantile(errs, 0.8):.2e} median {np.median(errs):.2e}"
     assert agree >= 0.9, f"greedy tokens agree on only {agree:.0%} of teacher-forced steps"
