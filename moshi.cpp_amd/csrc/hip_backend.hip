@@ -32,7 +32,8 @@
 #define UPLOAD_SLOTS       8
 #define UPLOAD_BLOB_BYTES  (64 * 1024)
 #define UPLOAD_MAX_DESCS   1024
-#define UPLOAD_SMALL_MAX   4096
+#define READBACK_PINNED_BYTES (64 * 1024)
+#define UPLOAD_SMALL_MAX   16384   // the 7.7 KB PCM frame rides the batched path too (a pageable hipMemcpy + sync otherwise)
 
 struct plan_t;
 
@@ -64,6 +65,7 @@ struct hip_ctx {
     // device-visible error word in pinned host memory: kernels with bounded waits raise it instead of hanging
     volatile unsigned * err_host = nullptr;
     unsigned * err_dev = nullptr;
+    char * readback = nullptr;   // pinned staging for small device -> host reads
     ggml_backend_device dev_obj;
 };
 
@@ -80,6 +82,7 @@ static void ctx_init_lazy(hip_ctx * c) {
         HIP_CHECK(hipHostMalloc((void **) &s.descs, UPLOAD_MAX_DESCS * sizeof(upload_desc), hipHostMallocMapped));
         HIP_CHECK(hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
     }
+    HIP_CHECK(hipHostMalloc((void **) &c->readback, READBACK_PINNED_BYTES, hipHostMallocDefault));
     HIP_CHECK(hipHostMalloc((void **) &c->err_host, 64, hipHostMallocMapped));
     c->err_host[0] = 0u;
     HIP_CHECK(hipHostGetDevicePointer((void **) &c->err_dev, (void *) c->err_host, 0));
@@ -168,8 +171,16 @@ static void hip_buf_get(ggml_backend_buffer_t b, const struct ggml_tensor * t, v
     hip_ctx * c = ((hip_buffer_ctx *) b->context)->c;
     set_device(c);
     flush_uploads(c);
-    HIP_CHECK(hipMemcpyAsync(data, (const char *) t->data + offset, size, hipMemcpyDeviceToHost, c->stream));
-    HIP_CHECK(hipStreamSynchronize(c->stream));
+    if (size <= READBACK_PINNED_BYTES) {
+        // small read-backs (token ids, one PCM frame) land in a pinned staging buffer: a pageable destination makes the runtime
+        // pin / stage it on every call
+        HIP_CHECK(hipMemcpyAsync(c->readback, (const char *) t->data + offset, size, hipMemcpyDeviceToHost, c->stream));
+        HIP_CHECK(hipStreamSynchronize(c->stream));
+        memcpy(data, c->readback, size);
+    } else {
+        HIP_CHECK(hipMemcpyAsync(data, (const char *) t->data + offset, size, hipMemcpyDeviceToHost, c->stream));
+        HIP_CHECK(hipStreamSynchronize(c->stream));
+    }
     check_device_error(c);
 }
 static void hip_buf_memset(ggml_backend_buffer_t b, struct ggml_tensor * t, uint8_t v, size_t offset, size_t size) {

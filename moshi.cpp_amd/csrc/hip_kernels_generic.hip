@@ -920,13 +920,15 @@ void k_mul_mat(hipStream_t s, tdesc dst, tdesc a, tdesc b, void * ws, const mm_e
 // ---------------------------------------------------------------------------------------------------
 __global__ void scatter_uploads_kernel(const upload_desc * descs, const char * blob) {
     const upload_desc d = descs[blockIdx.x];
-    const char * src = blob + d.offset;
-    if (((uintptr_t) d.dst & 3) == 0 && (d.size & 3) == 0) {
+    const char * src = blob + d.offset;   // 16-byte aligned inside the blob (queue_upload pads)
+    if (((uintptr_t) d.dst & 15) == 0 && (d.size & 15) == 0) {   // e.g. the 7.7 KB PCM frame: two 16-byte rounds of 256 threads
+        for (uint32_t i = threadIdx.x; i < d.size / 16; i += blockDim.x) ((uint4 *) d.dst)[i] = ((const uint4 *) src)[i];
+    } else if (((uintptr_t) d.dst & 3) == 0 && (d.size & 3) == 0) {
         for (uint32_t i = threadIdx.x; i < d.size / 4; i += blockDim.x) ((uint32_t *) d.dst)[i] = ((const uint32_t *) src)[i];
     } else {
         for (uint32_t i = threadIdx.x; i < d.size; i += blockDim.x) d.dst[i] = src[i];
     }
 }
 void k_scatter_uploads(hipStream_t s, const upload_desc * descs, const char * blob, int n) {
-    if (n > 0) scatter_uploads_kernel<<<n, 64, 0, s>>>(descs, blob);
+    if (n > 0) scatter_uploads_kernel<<<n, 256, 0, s>>>(descs, blob);
 }
