@@ -1287,7 +1287,7 @@ static plan_t * build_plan(hip_ctx * c, ggml_cgraph * g) {
                 for (auto & ag : attn_groups) {
                     const attn_args & at = ag.a;
                     if (ag.emit_pos < 0 || (const float *) at.out != a.x || at.T != 1 || at.D != 64 || at.C > 8 || (int64_t) at.H * at.D != a.K) continue;
-                    if (!(a.K == 1024 || a.K == 2048 || a.K == 3072) || ag.emit_pos > grp.emit_pos || uses_of(an, g->nodes[ag.emit_pos]) != 1) continue;
+                    if (a.K != 1024 || at.H != 16 || ag.emit_pos > grp.emit_pos || uses_of(an, g->nodes[ag.emit_pos]) != 1) continue;
                     p->attn_copies.emplace_back(new attn_args(at));   // owned by the plan, passed by value at launch
                     a.prologue = MV_ATTN;
                     a.attn = p->attn_copies.back().get();

@@ -175,11 +175,12 @@ __device__ __forceinline__ void quantize_block_q8k(xblk * dst, const float v[4],
     if (lane == 0) dst->d = d;
 }
 
-// Attention of FOUR consecutive heads by ONE wave, for a single new token over a short ring (C <= 8 slots of D = 64): the Depth
+// Attention of NH (2 or 4) consecutive heads by ONE wave, for a single new token over a short ring (C <= 8 slots of D = 64): the Depth
 // transformer's shape. Same arithmetic, in the same order, as attn_decode_kernel below restricted to the one wave that has work
 // there (lane = (slot, 8-dim chunk)). Every global load of all four heads (q/k/v, ring rows) is requested before the first use, so
 // the whole thing costs about one memory round trip. 256 outputs land in xa (LDS); `wbuf` is >= 768 floats of wave-private LDS.
-__device__ __forceinline__ void attn_small_wave4(const attn_args & a, int h0, int lane, float * wbuf, float * xa, bool write_cache) {
+template <int NH>
+__device__ __forceinline__ void attn_small_wave(const attn_args & a, int h0, int lane, float * wbuf, float * xa, bool write_cache) {
     constexpr int LPS = 8, half = 32;
     const int C = a.C;
     const int sub = lane / LPS, dl = (lane % LPS) * 8;
@@ -190,10 +191,10 @@ __device__ __forceinline__ void attn_small_wave4(const attn_args & a, int h0, in
     const float m = a.mask[cc];
     float rc = 1.f, rs = 0.f;
     if (a.rot) { rc = a.rot[p]; rs = a.rot[half + p]; }
-    float qr[4], qi[4], kr[4], ki[4], vv[4];
-    uint4 kq[4], vq[4];
+    float qr[NH], qi[NH], kr[NH], ki[NH], vv[NH];
+    uint4 kq[NH], vq[NH];
 #pragma unroll
-    for (int hh = 0; hh < 4; hh++) {
+    for (int hh = 0; hh < NH; hh++) {
         const int h = h0 + hh;
         const float * q = a.q + (int64_t) h * a.q_hs, * k = a.k + (int64_t) h * a.k_hs, * v = a.v + (int64_t) h * a.v_hs;
         if (a.rot) { qr[hh] = q[2 * p]; qi[hh] = q[2 * p + 1]; kr[hh] = k[2 * p]; ki[hh] = k[2 * p + 1]; }
@@ -207,7 +208,7 @@ __device__ __forceinline__ void attn_small_wave4(const attn_args & a, int h0, in
     const bool fresh = slot == c;
     // ---- RoPE, BF16 rounding, ring write
 #pragma unroll
-    for (int hh = 0; hh < 4; hh++) {
+    for (int hh = 0; hh < NH; hh++) {
         float qo, ko;
         if (a.rot) {
             if (j < half) { qo = qr[hh] * rc - qi[hh] * rs; ko = kr[hh] * rc - ki[hh] * rs; }
@@ -225,9 +226,9 @@ __device__ __forceinline__ void attn_small_wave4(const attn_args & a, int h0, in
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    double osum[4][8], ohalf[4];
+    double osum[NH][8], ohalf[NH];
 #pragma unroll
-    for (int hh = 0; hh < 4; hh++) {
+    for (int hh = 0; hh < NH; hh++) {
         const float * qf = wbuf + hh * 192, * knew = qf + 64, * vnew = qf + 128;
         float qv[8];
 #pragma unroll
@@ -279,7 +280,7 @@ __device__ __forceinline__ void attn_small_wave4(const attn_args & a, int h0, in
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     double * ored = (double *) wbuf;   // the q/k/v scratch (768 floats) is dead by now: 4 groups x 64 dims of doubles per round
 #pragma unroll
-    for (int hh = 0; hh < 4; hh++) {
+    for (int hh = 0; hh < NH; hh++) {
         // two rounds of 4 slot groups each (8 x 64 doubles would not fit the scratch); lane j ends up with dim j
 #pragma unroll
         for (int half_g = 0; half_g < 2; half_g++) {
@@ -368,13 +369,21 @@ __global__ void __launch_bounds__(NW * 64) matvec_q4k_kernel(mv_args a, int rows
     if (PRO == MV_ATTN) {
         // x = attention output (H heads of 64, K = NW * 256): wave w computes heads 4w..4w+3 = its own Q8_K block, entirely in
         // its (still unused) tile-staging LDS; workgroup 0 also performs the ring write the attention node implies
-        float * wbuf = (float *) stage, * xa = wbuf + 768;
-        attn_small_wave4(at, wave * 4, lane, wbuf, xa, blockIdx.x == 0);
-        float v[4];
+        // heads are spread over all NW waves (H / NW = 2 or 4 each: the serial arithmetic of one head is ~0.5 us), the outputs meet
+        // in a buffer carved from wave 0's staging area, then the first K / 256 waves quantise one block each
+        float * wbuf = (float *) stage;
+        float * xa_all = (float *) (smem + nb * XBLK_BYTES + 4096);   // bytes 4096 .. 4096 + 4 K of wave 0's 9 KB (its own scratch uses < 4 KB)
+        const int hpw = at.H / NW;
+        if (hpw == 4) attn_small_wave<4>(at, wave * 4, lane, wbuf, xa_all + wave * 256, blockIdx.x == 0);
+        else          attn_small_wave<2>(at, wave * 2, lane, wbuf, xa_all + wave * 128, blockIdx.x == 0);
+        lds_barrier();
+        if (wave < nb) {
+            float v[4];
 #pragma unroll
-        for (int k = 0; k < 4; k++) v[k] = xa[lane * 4 + k];
-        if (a.x_out != nullptr && blockIdx.x == 0) *(float4 *) (a.x_out + wave * 256 + lane * 4) = make_float4(v[0], v[1], v[2], v[3]);
-        quantize_block(xs + wave, v);
+            for (int k = 0; k < 4; k++) v[k] = xa_all[wave * 256 + lane * 4 + k];
+            if (a.x_out != nullptr && blockIdx.x == 0) *(float4 *) (a.x_out + wave * 256 + lane * 4) = make_float4(v[0], v[1], v[2], v[3]);
+            quantize_block(xs + wave, v);
+        }
     } else if (PRO == MV_PREQ8K) {
         // activations were quantised by gate_quant_q8k_kernel: copy the padded Q8_K blocks (304 B each) into LDS
         const u32x4 * src = (const u32x4 *) a.x;
@@ -814,9 +823,11 @@ void k_matvec(hipStream_t s, const mv_args & a) {
             if (rows * nb > 4096) rows = 4096 / nb;
             while (rows > 1 && (a.M + rows - 1) / rows < grid_min && (rows / 2) * nb >= 64) rows >>= 1;
         }
-        if (a.prologue == MV_ATTN) {   // one Q8_K block (4 heads of 64) per wave
-            GGML_ASSERT(a.K == 1024 || a.K == 2048 || a.K == 3072);
-            nw = (int) (a.K / 256);
+        if (a.prologue == MV_ATTN) {   // heads of 64 over all waves, 2 or 4 per wave; K <= 1024 keeps the gathered vector inside wave 0's staging area
+            static const int attn_nw = env_int("MI355X_ATTN_PROLOGUE_NW", 8);
+            const int H = a.attn->H;
+            GGML_ASSERT(a.K == 1024 && H == 16);
+            nw = attn_nw == 4 ? 4 : 8;
             int tpw = 4;
             rows = (tpw * 64 + nb - 1) / nb;
             while (rows > 1 && (a.M + rows - 1) / rows < grid_min && (rows / 2) * nb >= 64) rows >>= 1;
