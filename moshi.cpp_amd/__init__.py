@@ -11,7 +11,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libggml-mi355x.so")
+LIB_PATH = os.environ.get("MI355X_LIB") or os.path.join(_HERE, "libggml-mi355x.so")   # MI355X_LIB: A/B another build (tests/microbench/ab_bench.sh)
 
 GGML_MAX_DIMS, GGML_MAX_SRC, GGML_MAX_NAME = 4, 10, 64
 

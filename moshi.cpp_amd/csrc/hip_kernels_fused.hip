@@ -355,12 +355,13 @@ __global__ void __launch_bounds__(NW * 64) matvec_q4k_kernel(mv_args a, int rows
 
     u32x4 r[NLOAD];
     int t = wave;
-    {   // unconditional, clamped: chunks past the end re-read the last valid chunk and are never consumed
-        const int tt = t < ntiles ? t : ntiles - 1;
+    {   // unconditional (no branch around a load, see above): chunks past the end re-read the last valid chunk, and a wave without
+        // a tile reads chunk 0 in every lane - one 16-byte request instead of a 9 KB tile in the CU's load queue; neither is consumed
+        const bool has_tile = t < ntiles;
 #pragma unroll
         for (int i = 0; i < NLOAD; i++) {
-            const int g = tt * (NLOAD * 64) + i * 64 + lane;
-            r[i] = __builtin_nontemporal_load(wsrc + (g < nchunks ? g : nchunks - 1));
+            const int g = t * (NLOAD * 64) + i * 64 + lane;
+            r[i] = __builtin_nontemporal_load(wsrc + (has_tile ? (g < nchunks ? g : nchunks - 1) : 0));
         }
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -828,9 +829,10 @@ void k_matvec(hipStream_t s, const mv_args & a) {
             const int H = a.attn->H;
             GGML_ASSERT(a.K == 1024 && H == 16);
             nw = attn_nw == 4 ? 4 : 8;
+            static const int attn_grid_min = env_int("MI355X_ATTN_GRID_MIN", 128);
             int tpw = 4;
             rows = (tpw * 64 + nb - 1) / nb;
-            while (rows > 1 && (a.M + rows - 1) / rows < grid_min && (rows / 2) * nb >= 64) rows >>= 1;
+            while (rows > 1 && (a.M + rows - 1) / rows < attn_grid_min && (rows / 2) * nb >= 32) rows >>= 1;
         }
         if (fmt == MVF_Q80 && nw > 4 && a.prologue != MV_ATTN) {   // 17 KB tiles: four waves per workgroup fit the LDS comfortably
             nw = 4;
