@@ -927,9 +927,8 @@ template <bool SPLIT>
 __global__ void __launch_bounds__(ATTN_THREADS) __attribute__((amdgpu_waves_per_eu(2)))   // >= 2 workgroups per CU: the split grid (<= 512) is resident
 attn_decode_kernel(attn_args a, attn_split_ws w) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    // passes whose ring rows are requested before the first wait: the whole 256-slot range of a split workgroup, or the first
-    // four passes of the single-workgroup kernel (the rest streams in the pass loops)
-    constexpr int NPRE = SPLIT ? 8 : ATTN_NPRE;   // (8 x 16 slots at D = 128: half of a split workgroup's range; more would spill registers)
+    // passes whose ring rows are requested before the first wait (the rest streams in batches of the same size in the pass loops)
+    constexpr int NPRE = ATTN_NPRE;   // A/B at bench level: 4 beats 2 and 8 for the split kernel at empty, 600-slot and full context (registers vs round trips)
     const int D = a.D, C = a.C, T = a.T;
     const int S = SPLIT ? w.S : 1;
     const int h = SPLIT ? (int) blockIdx.x / S : (int) blockIdx.x, s_idx = SPLIT ? (int) blockIdx.x % S : 0;
