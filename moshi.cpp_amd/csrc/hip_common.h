@@ -133,8 +133,9 @@ struct attn_args {
 // k_attn_decode_ws_size bytes) carries scores, partial outputs and the per-head arrival counters between them. ws may be NULL
 // for short rings.
 #define ATTN_SPLIT_MIN_C 1024
-#define ATTN_SPLIT_SLOTS 256      // ring slots per workgroup once a head is split
-#define ATTN_SINGLE_MAX 256       // up to this many live slots the head's first workgroup does everything alone
+#define ATTN_SPLIT_SLOTS 128      // ring slots per workgroup once a head is split ...
+#define ATTN_SPLIT_BIG_MIN 1024   // ... doubled when more than this many slots are live (bench sweeps at 230 / 600 / 2900 live slots)
+#define ATTN_SINGLE_MAX 160       // up to this many live slots the head's first workgroup does everything alone
 size_t k_attn_decode_ws_size(const attn_args & a);
 void k_attn_decode(hipStream_t s, const attn_args & a, void * ws = nullptr, unsigned * err = nullptr);   // *err <- 1 if a head-wide wait timed out
 

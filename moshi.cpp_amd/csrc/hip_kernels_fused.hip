@@ -921,7 +921,7 @@ void k_matvec(hipStream_t s, const mv_args & a) {
 // the probabilities are bit-identical to the single-workgroup path; P x V partials -> global; the last workgroup to arrive adds
 // them in slot order. The wait cannot deadlock: workgroups are dispatched in blockIdx order and a head's workgroups are
 // contiguous, so the lowest unfinished head always has all of its workgroups resident (the spin is bounded regardless).
-struct attn_split_ws { float * scores; float * pmax; double * opart; unsigned * arrive; unsigned * done; int S; unsigned * err; int slots; };
+struct attn_split_ws { float * scores; float * pmax; double * opart; unsigned * arrive; unsigned * done; int S; unsigned * err; int slots; int single_max; int big_min; };
 
 template <bool SPLIT>
 __global__ void __launch_bounds__(ATTN_THREADS) __attribute__((amdgpu_waves_per_eu(2)))   // >= 2 workgroups per CU: the split grid (<= 512) is resident
@@ -932,8 +932,11 @@ attn_decode_kernel(attn_args a, attn_split_ws w) {
     const int D = a.D, C = a.C, T = a.T;
     const int S = SPLIT ? w.S : 1;
     const int h = SPLIT ? (int) blockIdx.x / S : (int) blockIdx.x, s_idx = SPLIT ? (int) blockIdx.x % S : 0;
-    const int SLOTS = SPLIT ? w.slots : ATTN_SPLIT_SLOTS;
-    const int c_base = s_idx * SLOTS;
+    // the range a workgroup owns adapts to the live length: w.slots (small) up to w.big_min live slots, twice that beyond - short
+    // ranges cut the per-workgroup round trips at a few hundred slots, long ones the number of participants at a few thousand.
+    // The grid is sized for the small range; with the big one the upper half of a head's workgroups simply leaves after the scan.
+    int SLOTS = SPLIT ? w.slots : ATTN_SPLIT_SLOTS;
+    int c_base = s_idx * SLOTS;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     float * sc   = (float *) smem;          // [C] scores -> exponentials of the current query row
     float * qf   = sc + C;                  // [T][D] bf16-rounded rotated q
@@ -996,8 +999,9 @@ attn_decode_kernel(attn_args a, attn_split_ws w) {
     // same scan yields n_end. It finds out BEFORE touching the ring (at short context 11 of 12 workgroups leave here).
     int n_end = 0;
     if (SPLIT && s_idx > 0) {
-        n_end = block_max_i32(scan_last_live(c_base)) + 1;
-        if (n_end <= ATTN_SINGLE_MAX || n_end <= c_base) return;
+        n_end = block_max_i32(scan_last_live(c_base)) + 1;      // exact whenever it exceeds c_base, which is all that matters below
+        if (n_end > w.big_min) { SLOTS *= 2; c_base = s_idx * SLOTS; }
+        if (n_end <= w.single_max || n_end <= c_base) return;
         __syncthreads();
     }
 
@@ -1058,9 +1062,9 @@ attn_decode_kernel(attn_args a, attn_split_ws w) {
             }
         }
     }
-    if (!SPLIT || s_idx == 0) n_end = block_max_i32(last_live) + 1;
+    if (!SPLIT || s_idx == 0) { n_end = block_max_i32(last_live) + 1; if (SPLIT && n_end > w.big_min) SLOTS *= 2; }
     else __syncthreads();
-    const int P = SPLIT && n_end > ATTN_SINGLE_MAX ? (n_end + SLOTS - 1) / SLOTS : 1;   // participating workgroups of this head
+    const int P = SPLIT && n_end > w.single_max ? (n_end + SLOTS - 1) / SLOTS : 1;   // participating workgroups of this head
     const bool multi = SPLIT && P > 1;
     const int c_lo = multi ? c_base : 0, c_hi = multi ? min(n_end, c_base + SLOTS) : n_end;   // slots whose K / V rows this workgroup reads
     // a prefetched row may be the slot that was just rewritten (last writer wins, like set_rows): take it from LDS instead
@@ -1158,7 +1162,7 @@ attn_decode_kernel(attn_args a, attn_split_ws w) {
                 for (int u = 0; u < 8; u++) { const int c = c0 + u * ATTN_THREADS; if (c < n_end && (c < c_lo || c >= c_hi)) sc[c] = v[u]; }
             }
             {
-                const float pm = ld_agent(w.pmax + h * S + (lane < P ? lane : 0));   // P <= 24 < 64
+                const float pm = ld_agent(w.pmax + h * S + (lane < P ? lane : 0));   // P <= C / 128 = 24 < 64
                 gmax = fmaxf(gmax, wave_allmax_f32(lane < P ? pm : -INFINITY));
             }
             __syncthreads();
@@ -1246,7 +1250,7 @@ attn_decode_kernel(attn_args a, attn_split_ws w) {
 }
 
 static bool attn_use_split(const attn_args & a) { return a.T == 1 && a.D == 128 && a.C >= ATTN_SPLIT_MIN_C; }
-static int attn_split_slots() { static const int v = env_int("MI355X_ATTN_SLOTS", ATTN_SPLIT_SLOTS); return v < ATTN_SINGLE_MAX ? ATTN_SINGLE_MAX : v; }
+static int attn_split_slots() { static const int v = env_int("MI355X_ATTN_SLOTS", ATTN_SPLIT_SLOTS); return v < 64 ? 64 : v; }
 size_t k_attn_decode_ws_size(const attn_args & a) {
     if (!attn_use_split(a)) return 0;
     const size_t S = (size_t) (a.C + attn_split_slots() - 1) / attn_split_slots();
@@ -1256,7 +1260,8 @@ void k_attn_decode(hipStream_t s, const attn_args & a, void * ws, unsigned * err
     GGML_ASSERT(a.D % 8 == 0 && 64 % (a.D / 8) == 0 && a.D <= 512 && a.T >= 1 && a.T <= ATTN_MAX_T && a.T * a.D <= 2 * ATTN_THREADS);
     const size_t smem = (size_t) a.C * 4 + (size_t) a.T * a.D * 4 * 3 + (size_t) (ATTN_THREADS / 64) * 64 * 8 * 8 + 16;
     GGML_ASSERT(smem <= 160 * 1024);
-    attn_split_ws w = { nullptr, nullptr, nullptr, nullptr, nullptr, 1, err, ATTN_SPLIT_SLOTS };
+    static const int single_max = env_int("MI355X_ATTN_SINGLE_MAX", ATTN_SINGLE_MAX), big_min = env_int("MI355X_ATTN_BIG_MIN", ATTN_SPLIT_BIG_MIN);
+    attn_split_ws w = { nullptr, nullptr, nullptr, nullptr, nullptr, 1, err, ATTN_SPLIT_SLOTS, single_max, big_min };
     if (ws && attn_use_split(a)) {
         const int S = (a.C + attn_split_slots() - 1) / attn_split_slots();
         w.slots = attn_split_slots();
