@@ -834,10 +834,15 @@ void k_matvec(hipStream_t s, const mv_args & a) {
             rows = (tpw * 64 + nb - 1) / nb;
             while (rows > 1 && (a.M + rows - 1) / rows < attn_grid_min && (rows / 2) * nb >= 32) rows >>= 1;
         }
-        if (fmt == MVF_Q80 && nw > 4 && a.prologue != MV_ATTN) {   // 17 KB tiles: four waves per workgroup fit the LDS comfortably
-            nw = 4;
-            rows = (int) ((a.M + 511) / 512);
-            while (rows * nb > 4096) rows = (rows + 1) / 2;
+        static const int q80_nw = env_int("MI355X_Q80_NW", 8);   // A/B: Temporal 2.31 -> 2.21 ms at q8_0
+        if (fmt == MVF_Q80 && nw > 4 && a.prologue != MV_ATTN) {   // 17 KB tiles: 8 waves only where xs + 8 tiles + partials fit 160 KB
+            const size_t need8 = (size_t) nb * XBLK_BYTES + 8 * tile_bytes + (size_t) rows * nb * 4;
+            if (q80_nw == 8 && need8 <= 158 * 1024) nw = 8;
+            else {
+                nw = 4;
+                rows = (int) ((a.M + 511) / 512);
+                while (rows * nb > 4096) rows = (rows + 1) / 2;
+            }
         }
         if (rows < 1) rows = 1;
         const size_t smem = (size_t) nb * XBLK_BYTES + (size_t) nw * tile_bytes + (size_t) rows * nb * 4;
