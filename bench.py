@@ -63,6 +63,8 @@ def main():
     ap.add_argument("--cpu-frames", type=int, default=1)
     ap.add_argument("--cpu-threads", type=int, default=32, help="OpenMP threads of the CPU baseline (capped by the affinity mask)")
     ap.add_argument("--quant", default="q4_k", choices=["q4_k", "q8_0", "q4_0"], help="linear weight type (the headline metric is q4_k)")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"], help="control-plane backend for N > 1 (nccl = RCCL; gloo for single-GPU dry runs)")
+    ap.add_argument("--device", type=int, default=None, help="override the device index (default LOCAL_RANK); only for dry runs of the N > 1 path on one GPU")
     ap.add_argument("--backend-flags", type=int, default=0, help="ggml_backend_mi355x_set_flags bits (2 = no hipGraph: use under rocprofv3)")
     args = ap.parse_args()
 
@@ -73,21 +75,29 @@ def main():
     if world > 1:
         import torch
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        try:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))   # RCCL; control plane only (barrier + max)
-        except Exception as e:   # the data path has no collective: a host-side rendezvous is enough to time the replicas
-            print(f"bench.py: RCCL init failed on rank {rank} ({e}); falling back to gloo for the barrier", file=sys.stderr)
+        dev_index = local_rank if args.device is None else args.device
+        torch.cuda.set_device(dev_index)
+        if args.dist_backend == "gloo":
             dist.init_process_group("gloo")
+        else:
+            try:
+                dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))   # RCCL; control plane only (barrier + max)
+                dist.barrier()                                                                  # forces communicator creation now
+            except Exception as e:   # the data path has no collective: a host-side rendezvous is enough to time the replicas
+                print(f"bench.py: RCCL init failed on rank {rank} ({e}); falling back to gloo for the barrier", file=sys.stderr)
+                if dist.is_initialized():
+                    dist.destroy_process_group()
+                dist.init_process_group("gloo")
 
     pkg = load_package()
     L = pkg.load()
     from moshi_cpp_amd import hot
 
     L.ggml_backend_load_all()
-    be = L.ggml_backend_init_by_name(f"ROCm{local_rank}".encode(), None)
+    dev_index = local_rank if args.device is None else args.device
+    be = L.ggml_backend_init_by_name(f"ROCm{dev_index}".encode(), None)
     if not be:
-        raise SystemExit("bench.py: no MI355X device 'ROCm%d' (the hot path has no CPU fallback)" % local_rank)
+        raise SystemExit("bench.py: no MI355X device 'ROCm%d' (the hot path has no CPU fallback)" % dev_index)
     dev = L.ggml_backend_get_device(be)
     dev_desc = L.ggml_backend_dev_description(dev).decode()
 
