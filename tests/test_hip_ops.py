@@ -289,3 +289,56 @@ def test_sampler_chain_top_k_with_given_noise():
         tok = g.get_rows(g.cont(g.permute(indices, 1, 0, 2, 3)), nxt4)
         return [tok, g.cont(indices), g.cont(q)]
     gu.compare(build)
+
+
+# ---- the large-matrix launch shape of the block mat-vec (one workgroup of 8 waves per CU, >= 1536 tiles) and the prologue /
+# ---- epilogue variants that only occur at moshika's real widths
+@pytest.mark.parametrize("wtype", [Q4_K, Q8_0, Q4_0])
+def test_big_matvec_rmsnorm_prologue_residual_epilogue(wtype):
+    K, M = 4096, 6144            # 1536 tiles of 64 super-blocks
+    r = np.random.default_rng(K + M + wtype)
+    x = r.standard_normal((1, K)).astype(np.float32)
+    alpha = (1.0 + 0.1 * r.standard_normal((1, K))).astype(np.float32)
+    res = r.standard_normal((1, M)).astype(np.float32)
+    wraw = {Q4_K: gu.random_q4_K, Q8_0: gu.random_q8_0, Q4_0: gu.random_q4_0}[wtype](r, M, K)
+
+    def build(g):
+        w = g.input_raw(wraw, wtype, K, M)
+        xn = g.mul(g.input(alpha), g.rms_norm(g.input(x), 1e-8))
+        return [g.add(g.input(res), g.mul_mat(w, xn))]
+    gu.compare(build, atol_rel=2e-6)
+
+
+def test_big_matvec_gated_ffn_prequantised_activation():
+    # linear_out of the Temporal FFN: silu(h[:K]) * h[K:] with K = 11264 > 4096 is quantised once by its own kernel, the
+    # mat-vec (2816 tiles -> large shape) copies the Q8_K blocks; + residual
+    K, M = 11264, 4096
+    r = np.random.default_rng(11264)
+    h = r.standard_normal((1, 2 * K)).astype(np.float32)
+    res = r.standard_normal((1, M)).astype(np.float32)
+    wraw = gu.random_q4_K(r, M, K)
+
+    def build(g):
+        w = g.input_raw(wraw, Q4_K, K, M)
+        hh = g.input(h)
+        t = hh.contents
+        left = g.view_4d(hh, t.ne[0] // 2, 1, t.ne[1], t.ne[2], t.nb[1] // 2, t.nb[1], t.nb[2], 0)      # gating.h:16-29
+        right = g.view_4d(hh, t.ne[0] // 2, 1, t.ne[1], t.ne[2], t.nb[1] // 2, t.nb[1], t.nb[2], t.nb[1] // 2)
+        gate = g.mul(g.silu(left), right)
+        return [g.add(g.input(res), g.mul_mat(w, gate))]
+    gu.compare(build, atol_rel=2e-6)
+
+
+def test_big_matvec_argmax_epilogue_text_head():
+    # text_linear: 4096 -> 32000 rows (large shape, 125 rows per workgroup) followed by the greedy argmax (fused through the
+    # arrival ticket: the last workgroup scans all 32000 logits)
+    K, M = 4096, 32000
+    r = np.random.default_rng(32000)
+    x = r.standard_normal((1, K)).astype(np.float32)
+    wraw = gu.random_q4_K(r, M, K)
+
+    def build(g):
+        w = g.input_raw(wraw, Q4_K, K, M)
+        logits = g.mul_mat(w, g.input(x))
+        return [g.argmax(logits)], [logits]
+    gu.compare(build, atol_rel=2e-6)
