@@ -309,17 +309,18 @@ def test_big_matvec_rmsnorm_prologue_residual_epilogue(wtype):
     gu.compare(build, atol_rel=2e-6)
 
 
-def test_big_matvec_gated_ffn_prequantised_activation():
+@pytest.mark.parametrize("wtype", [Q4_K, Q8_0, Q4_0])
+def test_big_matvec_gated_ffn_prequantised_activation(wtype):
     # linear_out of the Temporal FFN: silu(h[:K]) * h[K:] with K = 11264 > 4096 is quantised once by its own kernel, the
     # mat-vec (2816 tiles -> large shape) copies the Q8_K blocks; + residual
     K, M = 11264, 4096
     r = np.random.default_rng(11264)
     h = r.standard_normal((1, 2 * K)).astype(np.float32)
     res = r.standard_normal((1, M)).astype(np.float32)
-    wraw = gu.random_q4_K(r, M, K)
+    wraw = {Q4_K: gu.random_q4_K, Q8_0: gu.random_q8_0, Q4_0: gu.random_q4_0}[wtype](r, M, K)
 
     def build(g):
-        w = g.input_raw(wraw, Q4_K, K, M)
+        w = g.input_raw(wraw, wtype, K, M)
         hh = g.input(h)
         t = hh.contents
         left = g.view_4d(hh, t.ne[0] // 2, 1, t.ne[1], t.ne[2], t.nb[1] // 2, t.nb[1], t.nb[2], 0)      # gating.h:16-29
