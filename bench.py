@@ -63,6 +63,9 @@ def main():
     ap.add_argument("--cpu-frames", type=int, default=1)
     ap.add_argument("--cpu-threads", type=int, default=32, help="OpenMP threads of the CPU baseline (capped by the affinity mask)")
     ap.add_argument("--quant", default="q4_k", choices=["q4_k", "q8_0", "q4_0"], help="linear weight type (the headline metric is q4_k)")
+    ap.add_argument("--model", default="moshika", choices=["moshika", "personaplex"],
+                    help="moshika = BASELINE.json's metric config (default); personaplex = configs[4]: 16 chained Depth steps, run with --context 2000")
+    ap.add_argument("--context", type=int, default=0, help="Temporal ring capacity (-c of the tools); 0 = the config's 3000")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"], help="control-plane backend for N > 1 (nccl = RCCL; gloo for single-GPU dry runs)")
     ap.add_argument("--device", type=int, default=None, help="override the device index (default LOCAL_RANK); only for dry runs of the N > 1 path on one GPU")
     ap.add_argument("--backend-flags", type=int, default=0, help="ggml_backend_mi355x_set_flags bits (2 = no hipGraph: use under rocprofv3)")
@@ -103,7 +106,9 @@ def main():
 
     if args.backend_flags:
         L.ggml_backend_mi355x_set_flags(be, args.backend_flags)
-    cfg = hot.moshika(L)
+    cfg = hot.moshika(L) if args.model == "moshika" else hot.personaplex(L)
+    if args.context:
+        cfg.context = args.context
     if args.quant != "q4_k":
         cfg.linear_type = {"q8_0": 8, "q4_0": 2}[args.quant]   # ggml_type ids
     t0 = time.time()
@@ -153,13 +158,13 @@ def main():
     L.ggml_backend_mi355x_get_stats(be, C.byref(st))
 
     result = {
-        "metric": "audio frames/sec (12.5 Hz target) moshika-7B %s decode" % args.quant,
+        "metric": "audio frames/sec (12.5 Hz target) %s-7B %s decode" % (args.model, args.quant),
         "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "q4_K weights x q8_K activations (int8 dot, f32 accumulate); bf16 KV; f32 elsewhere",
         "data": "synthetic",
-        "config": {"workload": "moshi-sts --bench loop: mimi encode + Temporal step + 8 Depth steps + mimi decode, "
-                               "moshika-7B q4_k, 1 stream per GPU, greedy, ctx capacity 3000",
+        "config": {"workload": "moshi-sts --bench loop: mimi encode + Temporal step + %d Depth steps + mimi decode, "
+                               "%s-7B %s, 1 stream per GPU, greedy, ctx capacity %d" % (cfg.dep_q, args.model, args.quant, cfg.context),
                    "context_fill_start": args.context_fill, "parallelism": "independent stream replica per GPU" if world > 1 else "1 GPU",
                    "device": dev_desc},
         "realtime_factor": round(fps / world / 12.5, 1),

@@ -38,12 +38,18 @@ struct moshi_hot_config {
     // sampling: temp <= 0 -> greedy argmax (the parity mode, sampling.h:57-63)
     float   temp, temp_text;
     int32_t top_k, top_k_text;
+    // model variants (all zero = moshika)
+    int32_t personaplex;             // "model_type": "personaplex" (lm_default.h:223): the Depth graph chains dep_q (16) steps, the frame
+                                     // protocol exposes 8 of them and takes the other speaker's 8 (lm.h:803-805); delay ring one row deeper (lm.h:728)
+    int32_t extra_heads, extra_heads_dim;   // stt: linear heads on transformer_out; extra_heads[2] is the VAD head (lm.h:966-976)
 };
 
 typedef struct moshi_hot_model moshi_hot_model_t;
 
 // fills cfg with tools/moshi-config.json (moshika-7B) under `-q q4_k`: Q4_K linears, Q4_0 embeddings
 GGML_API void moshi_hot_config_moshika(struct moshi_hot_config * cfg);
+// tools/personaplex-config.json under `-q q4_k` (BASELINE.json configs[4]; run with context 2000 there)
+GGML_API void moshi_hot_config_personaplex(struct moshi_hot_config * cfg);
 
 // allocates weights (synthetic, deterministic in `seed`), persistent state (KV rings, conv tails) and
 // the scratch contexts on `backend` (moshi_alloc / mimi_alloc / moshi_lm_load / moshi_lm_start,
@@ -58,6 +64,17 @@ GGML_API void moshi_hot_mimi_decode(moshi_hot_model_t * m, const int32_t * codes
 // moshi_lm_send2 + moshi_lm_receive (src/moshi.cpp:904-926) = one moshi_lmgen_step (lm.h:778-979):
 // in_audio = the (n_q - dep_q) codes of the other speaker; returns 1 when text/out_audio are valid
 GGML_API int moshi_hot_lm_step(moshi_hot_model_t * m, const int32_t * in_audio, int32_t * text_token, int32_t * out_audio);
+// moshi_lmgen_step in full (lm.h:778-979). n_tokens == n_q + 1: "provided" mode — every codebook of this frame is given (text first),
+// the model still steps but its samples are not written to the delay ring: PersonaPlex prompt frames (lm.h:1063-1075, 1088-1097).
+// Otherwise tokens = the other speaker's (n_q - dep_q) codes as in moshi_hot_lm_step. vad (may be NULL): softmax(extra_heads[2]·transformer_out)[0].
+GGML_API int moshi_hot_lm_step_n(moshi_hot_model_t * m, const int32_t * tokens, int n_tokens, int32_t * text_token, int32_t * out_audio, float * vad);
+// one voice-prompt frame from a precomputed input embedding F32[dim] (moshi_lmgen_step_voice_prompt, lm.h:1004-1037): the Temporal
+// stack runs on the scratch context (moshi_lmmodel_forward_embedding, lm.h:694-709), text is forced to 3, the Depth graph steps
+GGML_API void moshi_hot_lm_step_embedding(moshi_hot_model_t * m, const float * embedding);
+// PROMPT_TOKENS (lm.h:983-987): 17 ids, text first
+GGML_API const int32_t * moshi_hot_personaplex_prompt_tokens(void);
+// moshi_lmgen_step_system_prompts without a voice (lm.h:1118-1134): 6 silence frames, the text prompt, 6 silence frames
+GGML_API void moshi_hot_personaplex_system_prompts(moshi_hot_model_t * m, const int32_t * text_prompt, int n_text);
 // one iteration of the moshi-sts --bench loop (tools/moshi-sts.cpp:770-808); returns 1 when a frame was produced
 GGML_API int moshi_hot_sts_frame(moshi_hot_model_t * m, const float * pcm_in, int32_t * text_token, int32_t * audio_tokens, float * pcm_out);
 

@@ -52,6 +52,8 @@ struct Builder {
     struct noise { T t; float lambd; };
     std::vector<noise> exponentials;
     std::vector<float> noise_tmp;
+    struct download { T t; void * dst; size_t n; };
+    std::vector<download> readbacks;   // ScratchContext::build_forward_expand(tensor, dst): read back after compute, before the buffer is freed (src/context.h:588-606)
 
     Builder(ggml_backend_t be_, size_t mb) : be(be_) { ctx = ggml_init({ mb * 1024 * 1024, NULL, true }); }
     ~Builder() { if (buf) ggml_backend_buffer_free(buf); ggml_free(ctx); }
@@ -93,9 +95,12 @@ struct Builder {
     }
     void compute() { upload_noise(); if (gf) ggml_backend_graph_compute(be, gf); }
     // scratch protocol: alloc -> upload -> compute -> free -> reset (src/context.h:628-653)
+    void expand_read(T t, void * dst) { expand(t); readbacks.push_back({ t, dst, ggml_nbytes(t) }); }
     void compute_scratch() {
         alloc();
         compute();
+        for (auto & r : readbacks) ggml_backend_tensor_get(r.t, r.dst, 0, r.n);
+        readbacks.clear();
         consts.clear();
         exponentials.clear();
         ggml_backend_buffer_free(buf);
@@ -551,6 +556,7 @@ struct moshi_hot_model {
     T text_emb = nullptr, text_linear = nullptr;
     std::vector<T> emb, depformer_in, depformer_emb, linears;
     T depformer_text_emb = nullptr;
+    std::vector<T> extra_heads;
     T transformer_out = nullptr;   // state F32[dim] (lm.h:434)
     Builder * g_temporal = nullptr; std::vector<T> emb_idx, emb_scale; T sampler_out = nullptr, text_logits = nullptr, g_transformer_out = nullptr, g_transformer_in = nullptr, g_stack_out = nullptr;
     Builder * g_depth = nullptr; T dep_text_idx = nullptr, dep_text_scale = nullptr, dep_tokens = nullptr; std::vector<T> dep_logits;
@@ -789,6 +795,12 @@ extern "C" void moshi_hot_config_moshika(struct moshi_hot_config * c) {
     c->temp = 0.f; c->temp_text = 0.f; c->top_k = 250; c->top_k_text = 25;
 }
 
+extern "C" void moshi_hot_config_personaplex(struct moshi_hot_config * c) {
+    moshi_hot_config_moshika(c);     // same widths; dep_q 16 chained Depth steps over a ring of 8 (tools/personaplex-config.json)
+    c->dep_q = 16;
+    c->personaplex = 1;
+}
+
 extern "C" moshi_hot_model_t * moshi_hot_create(ggml_backend_t backend, const struct moshi_hot_config * cfg, uint64_t seed) {
     moshi_hot_model * m = new moshi_hot_model;
     m->cfg = *cfg;
@@ -811,6 +823,8 @@ extern "C" moshi_hot_model_t * moshi_hot_create(ggml_backend_t backend, const st
         m->out_norm = { true, 1e-8f, W.add("lm.out_norm.alpha", GGML_TYPE_F32, c.dim, 1, 1, ones), nullptr };
         m->text_linear = W.add("lm.text_linear.weight", lt, c.dim, c.text_card, 1, qgen(1.f / sqrtf((float) c.dim)));
         m->transformer_out = state(m, GGML_TYPE_F32, c.dim);
+        for (int k = 0; k < c.extra_heads; k++)
+            m->extra_heads.push_back(W.add("lm.extra_heads." + std::to_string(k) + ".weight", lt, c.dim, c.extra_heads_dim, 1, qgen(1.f / sqrtf((float) c.dim))));
         if (c.dep_q > 0) {
             W.part = 1;
             for (int k = 0; k < c.dep_q; k++) {
@@ -828,7 +842,7 @@ extern "C" moshi_hot_model_t * moshi_hot_create(ggml_backend_t backend, const st
         // moshi_lmgen_state (lm.h:722-743)
         const int ncb = c.n_q + 1;
         for (int i = 0; i < ncb; i++) if (c.delays[i] > m->max_delay) m->max_delay = c.delays[i];
-        m->cache.assign((size_t) (m->max_delay + 2), std::vector<int>((size_t) ncb, -2));
+        m->cache.assign((size_t) (m->max_delay + 2 + (c.personaplex ? 1 : 0)), std::vector<int>((size_t) ncb, -2));
         m->initial.assign((size_t) ncb, c.card);
         m->initial[0] = c.text_card;
     }
@@ -868,7 +882,7 @@ extern "C" moshi_hot_model_t * moshi_hot_create(ggml_backend_t backend, const st
     GGML_ASSERT(m->st_buf);
     for (auto & s : m->st_init) ggml_backend_tensor_set(s.first, s.second.data(), 0, s.second.size());
     m->st_init.clear();
-    m->tokens_tmp.resize((size_t) (c.n_q + 1));
+    m->tokens_tmp.resize((size_t) (c.n_q + 1 + 32));
     return m;
 }
 
@@ -913,21 +927,39 @@ extern "C" void moshi_hot_mimi_encode(moshi_hot_model_t * m, const float * pcm, 
 }
 
 // moshi_lmgen_step (lm.h:778-979) for the plain moshi model: no state machine, no prefixes
-extern "C" int moshi_hot_lm_step(moshi_hot_model_t * m, const int32_t * in_audio, int32_t * text_token_out, int32_t * out_audio) {
+namespace {
+void depth_step(moshi_hot_model * m, int32_t text_token, std::vector<int32_t> & audio) {   // moshi_lmmodel_depformer_step (lm.h:532-552)
+    PhaseTimer pt(m, 2);
+    if (!m->g_depth) build_depth_graph(m);
+    int32_t id = text_token; const float sc = id == -1 ? 0.f : 1.f;
+    if (id < 0) id = 0;
+    ggml_backend_tensor_set(m->dep_text_idx, &id, 0, 4);
+    ggml_backend_tensor_set(m->dep_text_scale, &sc, 0, 4);
+    m->g_depth->compute();
+    ggml_backend_tensor_get(m->dep_tokens, audio.data(), 0, audio.size() * 4);
+}
+}
+
+extern "C" int moshi_hot_lm_step_n(moshi_hot_model_t * m, const int32_t * tokens, int n_tokens, int32_t * text_token_out, int32_t * out_audio, float * vad) {
     const moshi_hot_config & c = m->cfg;
     const int ncb = c.n_q + 1, CT = (int) m->cache.size();
-    const int dep_q = c.dep_q, dep_q_1 = dep_q + 1;
+    const int dep_q = c.personaplex ? 8 : c.dep_q, dep_q_1 = dep_q + 1;   // lm.h:802-805
     const int needed = ncb - dep_q - 1;
-    for (int i = 0; i < needed; i++) {   // other speaker's codes enter the delay ring (lm.h:819-824)
-        const int wp = (m->offset + c.delays[dep_q_1 + i]) % CT;
-        m->cache[(size_t) wp][(size_t) (dep_q_1 + i)] = in_audio[i];
+    bool provided = false;
+    if (needed > 0) {
+        if (n_tokens == ncb) {           // every codebook given: prompt frames (lm.h:812-817)
+            for (int i = 0; i < ncb; i++) m->cache[(size_t) ((m->offset + c.delays[i]) % CT)][(size_t) i] = tokens[i];
+            provided = true;
+        } else {                         // other speaker's codes enter the delay ring (lm.h:819-824)
+            GGML_ASSERT(n_tokens >= needed);
+            for (int i = 0; i < needed; i++) m->cache[(size_t) ((m->offset + c.delays[dep_q_1 + i]) % CT)][(size_t) (dep_q_1 + i)] = tokens[i];
+        }
     }
     const int pos = m->offset % CT;
     std::vector<int> input((size_t) ncb);
     for (int i = 0; i < ncb; i++) input[(size_t) i] = m->offset <= c.delays[i] ? m->initial[(size_t) i] : m->cache[(size_t) pos][(size_t) i];
 
     if (!m->g_temporal) build_temporal_graph(m);
-    if (dep_q > 0 && !m->g_depth) build_depth_graph(m);
     int32_t text_token = 0;
     {
     PhaseTimer pt(m, 1);
@@ -945,30 +977,75 @@ extern "C" int moshi_hot_lm_step(moshi_hot_model_t * m, const int32_t * in_audio
     ggml_backend_tensor_get(m->sampler_out, &text_token, 0, 4);
     }
 
-    std::vector<int32_t> audio((size_t) dep_q, 0);
-    if (dep_q > 0) {   // moshi_lmmodel_depformer_step (lm.h:532-552)
-        PhaseTimer pt(m, 2);
-        int32_t id = text_token; const float sc = id == -1 ? 0.f : 1.f;
-        if (id < 0) id = 0;
-        ggml_backend_tensor_set(m->dep_text_idx, &id, 0, 4);
-        ggml_backend_tensor_set(m->dep_text_scale, &sc, 0, 4);
-        m->g_depth->compute();
-        ggml_backend_tensor_get(m->dep_tokens, audio.data(), 0, (size_t) dep_q * 4);
-    }
+    std::vector<int32_t> audio((size_t) c.dep_q, 0);   // int_audio_tokens.resize(lm->dep_q) (lm.h:902)
+    if (c.dep_q > 0) depth_step(m, text_token, audio);
     m->last_text = text_token; m->last_audio = audio;
     m->offset++;
-    const int wpos = m->offset % CT;   // lm.h:935-943
-    m->cache[(size_t) wpos][0] = text_token;
-    for (int q = 0; q < dep_q; q++) m->cache[(size_t) wpos][(size_t) (q + 1)] = audio[(size_t) q];
+    if (!provided) {                      // lm.h:935-943
+        const int wpos = m->offset % CT;
+        m->cache[(size_t) wpos][0] = text_token;
+        for (int q = 0; q < c.dep_q; q++) m->cache[(size_t) wpos][(size_t) (q + 1)] = audio[(size_t) q];
+    }
     if (m->offset <= m->max_delay) return 0;
     int idx = (m->offset - m->max_delay + c.delays[0]) % CT;   // lm.h:954-959
     *text_token_out = m->cache[(size_t) idx][0];
     for (int i = 1; i < dep_q_1; i++) {
         idx = (m->offset - m->max_delay + c.delays[i]) % CT;
-        out_audio[i - 1] = m->cache[(size_t) idx][(size_t) i];
+        audio[(size_t) (i - 1)] = m->cache[(size_t) idx][(size_t) i];
     }
-    for (int i = 0; i < dep_q; i++) if (out_audio[i] == -1) return 0;
+    for (int i = 0; i < dep_q; i++) out_audio[i] = audio[(size_t) i];
+    for (int32_t x : audio) if (x == -1) return 0;             // all lm->dep_q entries, the tail holding this frame's raw samples (lm.h:961-964)
+    if (vad) {                                                 // lm.h:966-976
+        if (m->extra_heads.size() > 2) {
+            Builder & s = *m->scratch;
+            T sm = ggml_soft_max(s, linear(s, m->extra_heads[2], m->transformer_out));
+            s.expand_read(ggml_view_1d(s, sm, 1, 0), vad);
+            s.compute_scratch();
+        } else *vad = 0.f;
+    }
     return 1;
+}
+
+extern "C" int moshi_hot_lm_step(moshi_hot_model_t * m, const int32_t * in_audio, int32_t * text_token_out, int32_t * out_audio) {
+    const int io_dep_q = m->cfg.personaplex ? 8 : m->cfg.dep_q;
+    return moshi_hot_lm_step_n(m, in_audio, m->cfg.n_q - io_dep_q, text_token_out, out_audio, nullptr);
+}
+
+extern "C" void moshi_hot_lm_step_embedding(moshi_hot_model_t * m, const float * embedding) {
+    const moshi_hot_config & c = m->cfg;
+    Builder & s = *m->scratch;
+    int32_t sampled = 0;
+    {
+    PhaseTimer pt(m, 1);
+    T input = s.constant(s.tensor(GGML_TYPE_F32, c.dim, 1, 1), embedding);
+    input = ggml_cast(s, input, GGML_TYPE_F32);                       // lm.h:1022
+    T x = transformer_inline(s, m->temporal, input);                  // moshi_lmmodel_forward_embedding (lm.h:694-709)
+    x = apply_norm(s, m->out_norm, x);
+    T logits = linear(s, m->text_linear, x);
+    s.expand(ggml_cpy(s, x, m->transformer_out));
+    s.expand_read(sample_token(s, logits, c.temp_text, c.top_k_text), &sampled);   // moshi_sample_token_int: computed, then discarded
+    s.compute_scratch();
+    }
+    std::vector<int32_t> audio((size_t) c.dep_q, 0);
+    if (c.dep_q > 0) depth_step(m, 3, audio);                         // text_token = 3 (lm.h:1035)
+    m->last_text = sampled; m->last_audio = audio;
+    m->offset++;
+}
+
+static const int32_t PERSONAPLEX_PROMPT_TOKENS[17] = { 3, 948, 243, 1178, 546, 1736, 1030, 1978, 2008, 430, 1268, 381, 1611, 1095, 1495, 56, 472 };
+extern "C" const int32_t * moshi_hot_personaplex_prompt_tokens(void) { return PERSONAPLEX_PROMPT_TOKENS; }
+
+extern "C" void moshi_hot_personaplex_system_prompts(moshi_hot_model_t * m, const int32_t * text_prompt, int n_text) {
+    GGML_ASSERT(m->cfg.n_q + 1 == 17);
+    int32_t tokens[17], text, audio[MOSHI_HOT_MAX_CODEBOOKS];
+    auto frame = [&](int32_t text_id) {
+        memcpy(tokens, PERSONAPLEX_PROMPT_TOKENS, sizeof(tokens));
+        tokens[0] = text_id;
+        moshi_hot_lm_step_n(m, tokens, 17, &text, audio, nullptr);
+    };
+    for (int i = 0; i < 6; i++) frame(PERSONAPLEX_PROMPT_TOKENS[0]);      // moshi_lmgen_step_audio_silence, audio_silence_frame_cnt = 6
+    for (int i = 0; i < n_text; i++) frame(text_prompt[i]);               // moshi_lmgen_step_text_prompt
+    for (int i = 0; i < 6; i++) frame(PERSONAPLEX_PROMPT_TOKENS[0]);
 }
 
 // one iteration of the moshi-sts --bench loop (tools/moshi-sts.cpp:770-808)

@@ -11,12 +11,23 @@ class Config(C.Structure):
                [(n, C.c_int32) for n in ("dep_dim", "dep_heads", "dep_layers", "dep_ffn_hidden", "dep_context",
                                          "linear_type", "embed_type", "mimi_n_q", "mimi_codebook_size",
                                          "enable_lm", "enable_mimi_encoder", "enable_mimi_decoder")] + \
-               [("temp", C.c_float), ("temp_text", C.c_float), ("top_k", C.c_int32), ("top_k_text", C.c_int32)]
+               [("temp", C.c_float), ("temp_text", C.c_float), ("top_k", C.c_int32), ("top_k_text", C.c_int32)] + \
+               [(n, C.c_int32) for n in ("personaplex", "extra_heads", "extra_heads_dim")]
+
+    @property
+    def io_dep_q(self):
+        """codebooks the frame protocol generates per step (lm.h:802-805)"""
+        return 8 if self.personaplex else self.dep_q
 
 
 P = C.c_void_p
 SIGNATURES = {
     "moshi_hot_config_moshika": (None, [C.POINTER(Config)]),
+    "moshi_hot_config_personaplex": (None, [C.POINTER(Config)]),
+    "moshi_hot_lm_step_n": (C.c_int, [P, P, C.c_int, P, P, P]),
+    "moshi_hot_lm_step_embedding": (None, [P, P]),
+    "moshi_hot_personaplex_prompt_tokens": (C.POINTER(C.c_int32), []),
+    "moshi_hot_personaplex_system_prompts": (None, [P, P, C.c_int]),
     "moshi_hot_create": (P, [P, C.POINTER(Config), C.c_uint64]),
     "moshi_hot_free": (None, [P]),
     "moshi_hot_mimi_encode": (None, [P, P, P]),
@@ -48,6 +59,12 @@ def moshika(lib):
     return cfg
 
 
+def personaplex(lib):
+    cfg = Config()
+    lib.moshi_hot_config_personaplex(C.byref(cfg))
+    return cfg
+
+
 def tiny(lib, linear_type=12, embed_type=2, layers=2, dep_q=3, n_q=6, context=24):
     """A small model with the same structure as moshika (for parity tests that the oracle finishes in seconds)."""
     cfg = moshika(lib)
@@ -55,10 +72,20 @@ def tiny(lib, linear_type=12, embed_type=2, layers=2, dep_q=3, n_q=6, context=24
     cfg.text_card, cfg.card, cfg.n_q, cfg.dep_q = 500, 64, n_q, dep_q
     for i in range(MAX_CB):
         cfg.delays[i] = 0
-    d = [0, 0] + [1] * (dep_q - 1) + [0] + [1] * (n_q - dep_q - 1)
+    d = [0, 0] + [1] * (dep_q - 1) + [0] + [1] * (n_q - dep_q - 1) if dep_q > 0 else [0] + [0] * n_q
     for i, v in enumerate(d[:n_q + 1]):
         cfg.delays[i] = v
     cfg.dep_dim, cfg.dep_heads, cfg.dep_layers, cfg.dep_ffn_hidden, cfg.dep_context = 256, 4, 2, 512, dep_q
     cfg.linear_type, cfg.embed_type = linear_type, embed_type
     cfg.mimi_n_q, cfg.mimi_codebook_size = n_q - dep_q, 64
+    return cfg
+
+
+def tiny_personaplex(lib, linear_type=12, embed_type=2, layers=2):
+    """PersonaPlex's structure (17 codebooks, 16 chained Depth steps over a ring of 8, tools/personaplex-config.json) at test widths."""
+    cfg = personaplex(lib)
+    cfg.dim, cfg.num_heads, cfg.num_layers, cfg.ffn_hidden, cfg.context = 512, 4, layers, 768, 24
+    cfg.text_card = 2100          # PROMPT_TOKENS reach id 2008
+    cfg.dep_dim, cfg.dep_heads, cfg.dep_layers, cfg.dep_ffn_hidden = 256, 4, 2, 512
+    cfg.linear_type, cfg.embed_type = linear_type, embed_type
     return cfg

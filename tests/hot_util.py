@@ -46,7 +46,26 @@ class Model:
         txt = C.c_int32(-7)
         aud = (C.c_int32 * 32)()
         r = L.moshi_hot_lm_step(self.m, ia, C.byref(txt), aud)
-        return r, txt.value, list(aud)[:self.cfg.dep_q]
+        return r, txt.value, list(aud)[:self.cfg.io_dep_q]
+
+    def lm_step_n(self, tokens, vad=False):
+        """moshi_lmgen_step in full: len(tokens) == n_q + 1 is a "provided" (prompt) frame; vad=True also returns the VAD head's probability."""
+        ia = (C.c_int32 * 64)(*tokens)
+        txt = C.c_int32(-7)
+        aud = (C.c_int32 * 64)()
+        v = C.c_float(-1.0)
+        r = L.moshi_hot_lm_step_n(self.m, ia, len(tokens), C.byref(txt), aud, C.byref(v) if vad else None)
+        out = (r, txt.value, list(aud)[:self.cfg.io_dep_q])
+        return out + (v.value,) if vad else out
+
+    def lm_step_embedding(self, emb):
+        emb = np.ascontiguousarray(emb, np.float32)
+        assert emb.size == self.cfg.dim
+        L.moshi_hot_lm_step_embedding(self.m, emb.ctypes.data)
+
+    def system_prompts(self, text_prompt):
+        tp = (C.c_int32 * max(1, len(text_prompt)))(*text_prompt)
+        L.moshi_hot_personaplex_system_prompts(self.m, tp, len(text_prompt))
 
     def last_raw(self):
         txt = C.c_int32()
