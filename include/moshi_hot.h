@@ -42,6 +42,14 @@ struct moshi_hot_config {
     int32_t personaplex;             // "model_type": "personaplex" (lm_default.h:223): the Depth graph chains dep_q (16) steps, the frame
                                      // protocol exposes 8 of them and takes the other speaker's 8 (lm.h:803-805); delay ring one row deeper (lm.h:728)
     int32_t extra_heads, extra_heads_dim;   // stt: linear heads on transformer_out; extra_heads[2] is the VAD head (lm.h:966-976)
+    // tts (BASELINE.json configs[1])
+    int32_t demux_second_stream;     // text embeddings E[id % (text_card+1)]·out1 + s·E[id / (text_card+1) - 1]·out2 (lm_utils.h:48-85)
+    int32_t depformer_low_rank;      // width of the Depth embedding tables, followed by a low_rank linear to dep_dim (lm_utils.h:157-217); 0 = none
+    int32_t delay_steps;             // Depth skipped while offset < delay_steps; tokens -1 until delays[q+1] + delay_steps (src/moshi.cpp:905, lm.h:915-921)
+    int32_t cross_attention, cross_len;   // per-layer cross-attention over condition_cross F32[dim, cross_len] (transformer.h:343-396, 714-762)
+    int32_t condition_sum;           // sum_condition F32[dim] added to the embedding sum (lm.h:579-581)
+    int32_t dep_schedule_len;        // depformer_weights_per_step_schedule (lm_default.h:71-81); also the Depth ring capacity when dep_context == 0
+    int32_t dep_schedule[MOSHI_HOT_MAX_CODEBOOKS];
 };
 
 typedef struct moshi_hot_model moshi_hot_model_t;
@@ -68,6 +76,12 @@ GGML_API int moshi_hot_lm_step(moshi_hot_model_t * m, const int32_t * in_audio, 
 // the model still steps but its samples are not written to the delay ring: PersonaPlex prompt frames (lm.h:1063-1075, 1088-1097).
 // Otherwise tokens = the other speaker's (n_q - dep_q) codes as in moshi_hot_lm_step. vad (may be NULL): softmax(extra_heads[2]·transformer_out)[0].
 GGML_API int moshi_hot_lm_step_n(moshi_hot_model_t * m, const int32_t * tokens, int n_tokens, int32_t * text_token, int32_t * out_audio, float * vad);
+// tts conditions: sum F32[dim] (may be NULL) and cross F32[dim * cross_len] (may be NULL); the cross-attention K/V of every layer are
+// computed once here (init(), transformer.h:343-396). Call before the first step.
+GGML_API void moshi_hot_set_conditions(moshi_hot_model_t * m, const float * sum, const float * cross);
+// on_text_hook (lm.h:880-900): replaces the sampled text token (the TTS state machine lives above this boundary)
+typedef int32_t (*moshi_hot_text_hook_t)(void * user, int64_t offset, int32_t sampled);
+GGML_API void moshi_hot_set_text_hook(moshi_hot_model_t * m, moshi_hot_text_hook_t hook, void * user);
 // one voice-prompt frame from a precomputed input embedding F32[dim] (moshi_lmgen_step_voice_prompt, lm.h:1004-1037): the Temporal
 // stack runs on the scratch context (moshi_lmmodel_forward_embedding, lm.h:694-709), text is forced to 3, the Depth graph steps
 GGML_API void moshi_hot_lm_step_embedding(moshi_hot_model_t * m, const float * embedding);

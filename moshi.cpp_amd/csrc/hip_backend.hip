@@ -140,6 +140,12 @@ static void flush_uploads(hip_ctx * c) {
 static void queue_upload(hip_ctx * c, void * dst, const void * src, size_t size) {
     const size_t padded = GGML_PAD(size, 16);
     if (c->n_pending >= UPLOAD_MAX_DESCS || c->pending_bytes + padded > UPLOAD_BLOB_BYTES) flush_uploads(c);
+    // the scatter kernel copies all descriptors of a batch concurrently: a second write to bytes already pending (a state's zero fill
+    // followed by its first value, say) must not share a batch with the first, or the older data may land last
+    for (int i = 0; i < c->n_pending; i++) {
+        const upload_desc & d = c->slots[c->cur_slot].descs[i];
+        if ((char *) dst < d.dst + d.size && d.dst < (char *) dst + size) { flush_uploads(c); break; }
+    }
     upload_slot & s = c->slots[c->cur_slot];
     memcpy(s.blob + c->pending_bytes, src, size);
     s.descs[c->n_pending] = { (char *) dst, (uint32_t) c->pending_bytes, (uint32_t) size };

@@ -264,11 +264,14 @@ struct Layer {
     T linear1 = nullptr, linear2 = nullptr;    // plain FFN (gelu)
     T layer_scale_1 = nullptr, layer_scale_2 = nullptr;
     T kcache = nullptr, vcache = nullptr;      // state: BF16 [D, C, H]
+    // cross-attention (tts): LayerNorm eps 0, in_proj [dim, 3 dim] used through row views, cached F32 K/V [D, Tc, H]
+    Norm norm_cross; T cross_in = nullptr, cross_out = nullptr, k_cross = nullptr, v_cross = nullptr;
 };
 
 struct Transformer {
     int dim = 0, heads = 0, capacity = 0, max_period = 0;
     std::vector<Layer> layers;
+    std::vector<int> schedule;                 // weights_per_step_schedule (transformer.h:80-83); empty = step k uses weight set k
     // bias-mask lookup table (torch.h:162-223)
     struct ggml_context * pat_ctx = nullptr; ggml_backend_buffer_t pat_buf = nullptr; T pattern = nullptr; int pat_T = 0;
     // cached-graph inputs (transformer.h:1101-1109)
@@ -348,12 +351,52 @@ T gating(Builder & c, T w_in, T w_out, T x) {
     return linear(c, w_out, x);
 }
 
+// torch_nn_linear_view (torch.h:103-118): rows [offset, offset + width) of a (quantised) weight
+T linear_view(Builder & c, T w, int offset, int width, T x) {
+    return ggml_mul_mat(c, ggml_view_2d(c, w, w->ne[0], width, w->nb[1], w->nb[1] * (size_t) offset), x);
+}
+
+// moshi_streaming_multihead_cross_attention (transformer.h:714-762): q = first third of in_proj, K/V cached, no mask
+T cross_attention(Builder & c, const Transformer & tr, Layer & L, T query) {
+    const int H = tr.heads, dim = (int) L.cross_in->ne[1] / 3;
+    T q = linear_view(c, L.cross_in, 0, dim, query);
+    q = ggml_reshape_4d(c, q, q->ne[0] / H, H, q->ne[1], q->ne[2]);
+    q = ggml_permute(c, q, 0, 2, 1, 3);
+    const float scale = 1.f / sqrtf((float) q->ne[0]);
+    T w = ggml_mul_mat(c, L.k_cross, q);
+    w = ggml_soft_max_ext(c, w, nullptr, scale, 0.0f);
+    T v = ggml_cont(c, ggml_transpose(c, L.v_cross));
+    T o = ggml_mul_mat(c, v, w);
+    T o2 = ggml_cont(c, ggml_permute(c, o, 0, 2, 1, 3));
+    o = ggml_reshape_3d(c, o2, o2->ne[0] * o2->ne[1], o2->ne[2], o2->ne[3]);
+    return linear(c, L.cross_out, o);
+}
+
+// init() of the cross-attention state (transformer.h:343-396): K/V = last two thirds of in_proj applied to condition_cross
+void init_cross(Builder & s, const Transformer & tr, Layer & L, T condition_cross) {
+    const int H = tr.heads, dim = (int) L.cross_in->ne[1] / 3;
+    T kv = linear_view(s, L.cross_in, dim, 2 * dim, condition_cross);
+    auto half = [&](size_t off) {
+        T t = ggml_view_3d(s, kv, kv->ne[0] / 2, kv->ne[1], kv->ne[2], kv->nb[1], kv->nb[2], off);
+        t = ggml_cont(s, t);
+        t = ggml_reshape_4d(s, t, t->ne[0] / H, H, t->ne[1], t->ne[2]);
+        return ggml_permute(s, t, 0, 2, 1, 3);
+    };
+    s.expand(ggml_cpy(s, half(0), L.k_cross));
+    s.expand(ggml_cpy(s, half(kv->nb[1] / 2), L.v_cross));
+    s.compute_scratch();
+}
+
 // moshi_streaming_transformer_layer (transformer.h:910-1039)
 T transformer_layer(Builder & c, const Transformer & tr, Layer & L, int wi, T indices, T x, T attn_bias, const Rot * rot, bool per_step_views) {
     T nx = apply_norm(c, L.norm1, x);
     T update = attention(c, tr, L, wi, indices, nx, attn_bias, rot, per_step_views);
     if (L.layer_scale_1) update = ggml_mul(c, update, L.layer_scale_1);
     x = ggml_add(c, x, update);
+    if (L.cross_in) {   // transformer.h:936-944
+        nx = apply_norm(c, L.norm_cross, x);
+        x = ggml_add(c, x, cross_attention(c, tr, L, nx));
+    }
     nx = apply_norm(c, L.norm2, x);
     if (L.gate_in.empty()) {
         T h = linear(c, L.linear1, nx);
@@ -408,7 +451,8 @@ T transformer_inline(Builder & g, Transformer & tr, T x) {
     for (int i = 0; i < Tn; i++) idx[(size_t) i] = (offset + i) % tr.capacity;
     T indices = g.i32s(idx);
     const bool multi = tr.layers[0].in_proj.size() > 1;
-    for (auto & L : tr.layers) x = transformer_layer(g, tr, L, multi ? offset : 0, indices, x, attn_bias, tr.max_period ? &rot : nullptr, multi);
+    const int wi = !multi ? 0 : tr.schedule.empty() ? offset : tr.schedule[(size_t) offset];
+    for (auto & L : tr.layers) x = transformer_layer(g, tr, L, wi, indices, x, attn_bias, tr.max_period ? &rot : nullptr, multi);
     tr.offset += Tn;
     return x;
 }
@@ -557,6 +601,12 @@ struct moshi_hot_model {
     std::vector<T> emb, depformer_in, depformer_emb, linears;
     T depformer_text_emb = nullptr;
     std::vector<T> extra_heads;
+    // tts variants
+    T text_out1 = nullptr, text_out2 = nullptr, dep_text_out1 = nullptr, dep_text_out2 = nullptr;   // demux (lm_utils.h:48-85)
+    T dep_text_low_rank = nullptr; std::vector<T> depformer_emb_low_rank;                          // low-rank embeddings (lm_utils.h:157-217)
+    T cond_sum = nullptr, cond_cross = nullptr;
+    T emb_right_idx = nullptr, emb_right_scale = nullptr, dep_right_idx = nullptr, dep_right_scale = nullptr;
+    moshi_hot_text_hook_t text_hook = nullptr; void * text_hook_user = nullptr;
     T transformer_out = nullptr;   // state F32[dim] (lm.h:434)
     Builder * g_temporal = nullptr; std::vector<T> emb_idx, emb_scale; T sampler_out = nullptr, text_logits = nullptr, g_transformer_out = nullptr, g_transformer_in = nullptr, g_stack_out = nullptr;
     Builder * g_depth = nullptr; T dep_text_idx = nullptr, dep_text_scale = nullptr, dep_tokens = nullptr; std::vector<T> dep_logits;
@@ -587,7 +637,7 @@ T state(moshi_hot_model * m, enum ggml_type type, int64_t n0, int64_t n1 = 1, in
 }
 
 void make_transformer(moshi_hot_model * m, Transformer & tr, const std::string & name, int dim, int heads, int n_layers, int ffn_hidden,
-                      int capacity, int max_period, int n_weight_sets, bool mimi_style, enum ggml_type wtype) {
+                      int capacity, int max_period, int n_weight_sets, bool mimi_style, enum ggml_type wtype, int cross_len = 0) {
     Weights & W = *m->W;
     tr.dim = dim; tr.heads = heads; tr.capacity = capacity; tr.max_period = max_period;
     tr.layers.resize((size_t) n_layers);
@@ -620,6 +670,14 @@ void make_transformer(moshi_hot_model * m, Transformer & tr, const std::string &
         }
         L.kcache = state(m, GGML_TYPE_BF16, dim / heads, capacity, heads);
         L.vcache = state(m, GGML_TYPE_BF16, dim / heads, capacity, heads);
+        if (cross_len > 0) {   // lm_default.h:20-35; states filled by init() (transformer.h:335-339)
+            L.norm_cross = { false, 0.0f, W.add(p + "norm_cross.weight", GGML_TYPE_F32, dim, 1, 1, ones),
+                             W.add(p + "norm_cross.bias", GGML_TYPE_F32, dim, 1, 1, [](T t, Rng & r, std::vector<uint8_t> & o) { gen_normal(t, r, o, 0.02f); }) };
+            L.cross_in = W.add(p + "cross_attention.in_projs.0.weight", wtype, dim, 3 * dim, 1, qgen(s_in));
+            L.cross_out = W.add(p + "cross_attention.out_projs.0.weight", wtype, dim, dim, 1, qgen(s_in));
+            L.k_cross = state(m, GGML_TYPE_F32, dim / heads, cross_len, heads);
+            L.v_cross = state(m, GGML_TYPE_F32, dim / heads, cross_len, heads);
+        }
     }
 }
 
@@ -670,8 +728,17 @@ void build_temporal_graph(moshi_hot_model * m) {
         m->emb_idx.push_back(idx); m->emb_scale.push_back(scale);
         return ggml_mul(g, ggml_get_rows(g, table, idx), scale);
     };
-    T input = embed(m->text_emb);
+    T input;
+    if (c.demux_second_stream) {   // moshi_scaled_embedding_demux_build (lm_utils.h:48-66)
+        T left = g.tensor(GGML_TYPE_I32, 1);
+        m->emb_idx.push_back(left); m->emb_scale.push_back(nullptr);
+        m->emb_right_idx = g.tensor(GGML_TYPE_I32, 1); m->emb_right_scale = g.tensor(GGML_TYPE_F32, 1);
+        T l = ggml_get_rows(g, m->text_emb, left), r = ggml_get_rows(g, m->text_emb, m->emb_right_idx);
+        T ry = linear(g, m->text_out2, r), ly = linear(g, m->text_out1, l);
+        input = ggml_add(g, ly, ggml_mul(g, ry, m->emb_right_scale));
+    } else input = embed(m->text_emb);
     for (int k = 0; k < c.n_q; k++) input = ggml_add(g, input, embed(m->emb[(size_t) k]));
+    if (c.condition_sum) input = ggml_add(g, m->cond_sum, input);   // lm.h:579-581
     m->g_transformer_in = input;
     T x = transformer_graph_build(g, m->temporal, input);
     m->g_stack_out = x;
@@ -690,14 +757,27 @@ void build_depth_graph(moshi_hot_model * m) {
     m->g_depth = new Builder(m->be, 256);
     Builder & g = *m->g_depth;
     m->dep_text_idx = g.tensor(GGML_TYPE_I32, 1);
-    m->dep_text_scale = g.tensor(GGML_TYPE_F32, 1);
-    T last = ggml_mul(g, ggml_get_rows(g, m->depformer_text_emb, m->dep_text_idx), m->dep_text_scale);
+    T last;
+    if (c.demux_second_stream) {
+        m->dep_right_idx = g.tensor(GGML_TYPE_I32, 1); m->dep_right_scale = g.tensor(GGML_TYPE_F32, 1);
+        T l = ggml_get_rows(g, m->depformer_text_emb, m->dep_text_idx), r = ggml_get_rows(g, m->depformer_text_emb, m->dep_right_idx);
+        T ry = linear(g, m->dep_text_out2, r), ly = linear(g, m->dep_text_out1, l);
+        last = ggml_add(g, ly, ggml_mul(g, ry, m->dep_right_scale));
+    } else {
+        m->dep_text_scale = g.tensor(GGML_TYPE_F32, 1);
+        last = ggml_mul(g, ggml_get_rows(g, m->depformer_text_emb, m->dep_text_idx), m->dep_text_scale);
+        if (m->dep_text_low_rank) last = linear(g, m->dep_text_low_rank, last);
+    }
     T tokens = g.tensor(GGML_TYPE_I32, c.dep_q);
     T view = nullptr, next = nullptr;
     for (int k = 0; k < c.dep_q; k++) {
-        if (k > 0) last = ggml_get_rows(g, m->depformer_emb[(size_t) (k - 1)], next);   // moshi_scaled_embedding_chained
+        if (k > 0) {   // moshi_scaled_embedding_chained (lm_utils.h:208-217)
+            last = ggml_get_rows(g, m->depformer_emb[(size_t) (k - 1)], next);
+            if (!m->depformer_emb_low_rank.empty()) last = linear(g, m->depformer_emb_low_rank[(size_t) (k - 1)], last);
+        }
         // moshi_lmmodel_forward_depformer_transform (lm.h:446-475)
-        T din = linear(g, m->depformer_in[(size_t) k], m->transformer_out);
+        const int in_index = c.dep_schedule_len ? c.dep_schedule[k] : k;
+        T din = linear(g, m->depformer_in[(size_t) in_index], m->transformer_out);
         last = ggml_cast(g, last, GGML_TYPE_F32);
         din = ggml_add(g, din, last);
         T dout = transformer_inline(g, m->depth, din);
@@ -816,28 +896,57 @@ extern "C" moshi_hot_model_t * moshi_hot_create(ggml_backend_t backend, const st
 
     if (c.enable_lm) {
         W.part = 4;
+        // WeightLoader type fall-back (loader.h:162-173): Q4_K needs ne0 % 256 == 0, else Q4_0 (ne0 % 32), else the source type
+        auto fit = [](enum ggml_type t, int64_t ne0) {
+            if (t == GGML_TYPE_Q4_K && ne0 % 256 != 0) t = GGML_TYPE_Q4_0;
+            if ((t == GGML_TYPE_Q4_0 || t == GGML_TYPE_Q8_0) && ne0 % 32 != 0) t = GGML_TYPE_F32;
+            return t;
+        };
         m->text_emb = W.add("lm.text_emb.weight", et, c.dim, c.text_card + 1, 1, qgen(1.f));
+        if (c.demux_second_stream) {
+            m->text_out1 = W.add("lm.text_emb.out1.weight", lt, c.dim, c.dim, 1, qgen(1.f / sqrtf((float) c.dim)));
+            m->text_out2 = W.add("lm.text_emb.out2.weight", lt, c.dim, c.dim, 1, qgen(1.f / sqrtf((float) c.dim)));
+        }
         for (int k = 0; k < c.n_q; k++) m->emb.push_back(W.add("lm.emb." + std::to_string(k) + ".weight", et, c.dim, c.card + 1, 1, qgen(1.f)));
         W.part = 0;
-        make_transformer(m, m->temporal, "lm.transformer", c.dim, c.num_heads, c.num_layers, c.ffn_hidden, c.context, c.max_period, 1, false, lt);
+        make_transformer(m, m->temporal, "lm.transformer", c.dim, c.num_heads, c.num_layers, c.ffn_hidden, c.context, c.max_period, 1, false, lt,
+                         c.cross_attention ? c.cross_len : 0);
         m->out_norm = { true, 1e-8f, W.add("lm.out_norm.alpha", GGML_TYPE_F32, c.dim, 1, 1, ones), nullptr };
         m->text_linear = W.add("lm.text_linear.weight", lt, c.dim, c.text_card, 1, qgen(1.f / sqrtf((float) c.dim)));
         m->transformer_out = state(m, GGML_TYPE_F32, c.dim);
+        if (c.condition_sum) m->cond_sum = state(m, GGML_TYPE_F32, c.dim);
+        if (c.cross_attention) m->cond_cross = state(m, GGML_TYPE_F32, c.dim, c.cross_len);
         for (int k = 0; k < c.extra_heads; k++)
             m->extra_heads.push_back(W.add("lm.extra_heads." + std::to_string(k) + ".weight", lt, c.dim, c.extra_heads_dim, 1, qgen(1.f / sqrtf((float) c.dim))));
         if (c.dep_q > 0) {
+            // depformer_num_weights (lm_default.h:71-81): one set per step, or max(schedule) + 1
+            int n_sets = c.dep_q;
+            if (c.dep_schedule_len) { n_sets = 0; for (int i = 0; i < c.dep_schedule_len; i++) if (c.dep_schedule[i] + 1 > n_sets) n_sets = c.dep_schedule[i] + 1; }
+            const int E = c.depformer_low_rank ? c.depformer_low_rank : c.dep_dim;   // embedding table width
             W.part = 1;
-            for (int k = 0; k < c.dep_q; k++) {
+            for (int k = 0; k < n_sets; k++)
                 m->depformer_in.push_back(W.add("lm.depformer_in." + std::to_string(k) + ".weight", lt, c.dim, c.dep_dim, 1, qgen(1.f / sqrtf((float) c.dim))));
+            for (int k = 0; k < c.dep_q; k++) {
                 m->linears.push_back(W.add("lm.linears." + std::to_string(k) + ".weight", lt, c.dep_dim, c.card, 1, qgen(1.f / sqrtf((float) c.dep_dim))));
-                W.part = 4;
-                if (k > 0) m->depformer_emb.push_back(W.add("lm.depformer_emb." + std::to_string(k - 1) + ".weight", et, c.dep_dim, c.card + 1, 1, qgen(1.f)));
-                W.part = 1;
+                if (k > 0) {
+                    W.part = 4;
+                    m->depformer_emb.push_back(W.add("lm.depformer_emb." + std::to_string(k - 1) + ".weight", fit(et, E), E, c.card + 1, 1, qgen(1.f)));
+                    W.part = 1;
+                    if (c.depformer_low_rank)
+                        m->depformer_emb_low_rank.push_back(W.add("lm.depformer_emb." + std::to_string(k - 1) + ".low_rank.weight", fit(lt, E), E, c.dep_dim, 1, qgen(1.f / sqrtf((float) E))));
+                }
             }
             W.part = 4;
-            m->depformer_text_emb = W.add("lm.depformer_text_emb.weight", et, c.dep_dim, c.text_card + 1, 1, qgen(1.f));
+            m->depformer_text_emb = W.add("lm.depformer_text_emb.weight", fit(et, E), E, c.text_card + 1, 1, qgen(1.f));
             W.part = 1;
-            make_transformer(m, m->depth, "lm.depformer", c.dep_dim, c.dep_heads, c.dep_layers, c.dep_ffn_hidden, c.dep_context, 0, c.dep_q, false, lt);
+            if (c.demux_second_stream) {
+                m->dep_text_out1 = W.add("lm.depformer_text_emb.out1.weight", fit(lt, E), E, c.dep_dim, 1, qgen(1.f / sqrtf((float) E)));
+                m->dep_text_out2 = W.add("lm.depformer_text_emb.out2.weight", fit(lt, E), E, c.dep_dim, 1, qgen(1.f / sqrtf((float) E)));
+            } else if (c.depformer_low_rank)
+                m->dep_text_low_rank = W.add("lm.depformer_text_emb.low_rank.weight", fit(lt, E), E, c.dep_dim, 1, qgen(1.f / sqrtf((float) E)));
+            // capacity = context ? context : weights_per_step (lm_default.h:86-90)
+            make_transformer(m, m->depth, "lm.depformer", c.dep_dim, c.dep_heads, c.dep_layers, c.dep_ffn_hidden, c.dep_context ? c.dep_context : c.dep_schedule_len, 0, n_sets, false, lt);
+            for (int i = 0; i < c.dep_schedule_len; i++) m->depth.schedule.push_back(c.dep_schedule[i]);
         }
         // moshi_lmgen_state (lm.h:722-743)
         const int ncb = c.n_q + 1;
@@ -928,13 +1037,27 @@ extern "C" void moshi_hot_mimi_encode(moshi_hot_model_t * m, const float * pcm, 
 
 // moshi_lmgen_step (lm.h:778-979) for the plain moshi model: no state machine, no prefixes
 namespace {
+// moshi_scaled_embedding_demux_step (lm_utils.h:68-85)
+void demux_set(const moshi_hot_config & c, int32_t input, T left, T right, T right_scale) {
+    if (input < 0) input = 0;
+    const int32_t n = c.text_card + 1;
+    int32_t l = input % n, r = input / n - 1;
+    const float sc = r < 0 ? 0.f : 1.f;
+    if (r < 0) r = 0;
+    ggml_backend_tensor_set(left, &l, 0, 4);
+    ggml_backend_tensor_set(right, &r, 0, 4);
+    ggml_backend_tensor_set(right_scale, &sc, 0, 4);
+}
 void depth_step(moshi_hot_model * m, int32_t text_token, std::vector<int32_t> & audio) {   // moshi_lmmodel_depformer_step (lm.h:532-552)
     PhaseTimer pt(m, 2);
     if (!m->g_depth) build_depth_graph(m);
-    int32_t id = text_token; const float sc = id == -1 ? 0.f : 1.f;
-    if (id < 0) id = 0;
-    ggml_backend_tensor_set(m->dep_text_idx, &id, 0, 4);
-    ggml_backend_tensor_set(m->dep_text_scale, &sc, 0, 4);
+    if (m->cfg.demux_second_stream) demux_set(m->cfg, text_token, m->dep_text_idx, m->dep_right_idx, m->dep_right_scale);
+    else {
+        int32_t id = text_token; const float sc = id == -1 ? 0.f : 1.f;
+        if (id < 0) id = 0;
+        ggml_backend_tensor_set(m->dep_text_idx, &id, 0, 4);
+        ggml_backend_tensor_set(m->dep_text_scale, &sc, 0, 4);
+    }
     m->g_depth->compute();
     ggml_backend_tensor_get(m->dep_tokens, audio.data(), 0, audio.size() * 4);
 }
@@ -966,6 +1089,7 @@ extern "C" int moshi_hot_lm_step_n(moshi_hot_model_t * m, const int32_t * tokens
     // moshi_lmmodel_text_token_embed_step (lm.h:586-607): -1 -> scale 0, negative ids -> row 0
     for (int i = 0; i < ncb; i++) {
         int32_t id = input[(size_t) i];
+        if (i == 0 && c.demux_second_stream) { demux_set(c, id, m->emb_idx[0], m->emb_right_idx, m->emb_right_scale); continue; }
         const float sc = id == -1 ? 0.f : 1.f;
         if (id < 0) id = 0;
         ggml_backend_tensor_set(m->emb_idx[(size_t) i], &id, 0, 4);
@@ -976,9 +1100,16 @@ extern "C" int moshi_hot_lm_step_n(moshi_hot_model_t * m, const int32_t * tokens
     m->g_temporal->compute();
     ggml_backend_tensor_get(m->sampler_out, &text_token, 0, 4);
     }
+    if (m->text_hook) text_token = m->text_hook(m->text_hook_user, m->offset, text_token);   // on_text_hook (lm.h:880-900)
 
     std::vector<int32_t> audio((size_t) c.dep_q, 0);   // int_audio_tokens.resize(lm->dep_q) (lm.h:902)
-    if (c.dep_q > 0) depth_step(m, text_token, audio);
+    const bool replace = m->offset < c.delay_steps;    // depformer_replace_tokens (src/moshi.cpp:905)
+    if (c.dep_q > 0) {
+        if (!replace) depth_step(m, text_token, audio);
+        else for (auto & a : audio) a = -1;            // lm.h:910-913
+        if (c.delay_steps)                             // on_audio_hook (lm.h:915-921)
+            for (int q = 0; q < c.dep_q; q++) if (m->offset < c.delays[q + 1] + c.delay_steps) audio[(size_t) q] = -1;
+    }
     m->last_text = text_token; m->last_audio = audio;
     m->offset++;
     if (!provided) {                      // lm.h:935-943
@@ -986,7 +1117,7 @@ extern "C" int moshi_hot_lm_step_n(moshi_hot_model_t * m, const int32_t * tokens
         m->cache[(size_t) wpos][0] = text_token;
         for (int q = 0; q < c.dep_q; q++) m->cache[(size_t) wpos][(size_t) (q + 1)] = audio[(size_t) q];
     }
-    if (m->offset <= m->max_delay) return 0;
+    if (m->offset <= m->max_delay || replace) return 0;       // lm.h:950
     int idx = (m->offset - m->max_delay + c.delays[0]) % CT;   // lm.h:954-959
     *text_token_out = m->cache[(size_t) idx][0];
     for (int i = 1; i < dep_q_1; i++) {
@@ -1031,6 +1162,17 @@ extern "C" void moshi_hot_lm_step_embedding(moshi_hot_model_t * m, const float *
     m->last_text = sampled; m->last_audio = audio;
     m->offset++;
 }
+
+extern "C" void moshi_hot_set_conditions(moshi_hot_model_t * m, const float * sum, const float * cross) {
+    const moshi_hot_config & c = m->cfg;
+    if (sum) { GGML_ASSERT(m->cond_sum); ggml_backend_tensor_set(m->cond_sum, sum, 0, (size_t) c.dim * 4); }
+    if (cross) {
+        GGML_ASSERT(m->cond_cross);
+        ggml_backend_tensor_set(m->cond_cross, cross, 0, (size_t) c.dim * (size_t) c.cross_len * 4);
+        for (auto & L : m->temporal.layers) init_cross(*m->scratch, m->temporal, L, m->cond_cross);
+    }
+}
+extern "C" void moshi_hot_set_text_hook(moshi_hot_model_t * m, moshi_hot_text_hook_t hook, void * user) { m->text_hook = hook; m->text_hook_user = user; }
 
 static const int32_t PERSONAPLEX_PROMPT_TOKENS[17] = { 3, 948, 243, 1178, 546, 1736, 1030, 1978, 2008, 430, 1268, 381, 1611, 1095, 1495, 56, 472 };
 extern "C" const int32_t * moshi_hot_personaplex_prompt_tokens(void) { return PERSONAPLEX_PROMPT_TOKENS; }

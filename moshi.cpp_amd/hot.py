@@ -12,7 +12,10 @@ class Config(C.Structure):
                                          "linear_type", "embed_type", "mimi_n_q", "mimi_codebook_size",
                                          "enable_lm", "enable_mimi_encoder", "enable_mimi_decoder")] + \
                [("temp", C.c_float), ("temp_text", C.c_float), ("top_k", C.c_int32), ("top_k_text", C.c_int32)] + \
-               [(n, C.c_int32) for n in ("personaplex", "extra_heads", "extra_heads_dim")]
+               [(n, C.c_int32) for n in ("personaplex", "extra_heads", "extra_heads_dim",
+                                         "demux_second_stream", "depformer_low_rank", "delay_steps", "cross_attention", "cross_len",
+                                         "condition_sum", "dep_schedule_len")] + \
+               [("dep_schedule", C.c_int32 * MAX_CB)]
 
     @property
     def io_dep_q(self):
@@ -26,6 +29,8 @@ SIGNATURES = {
     "moshi_hot_config_personaplex": (None, [C.POINTER(Config)]),
     "moshi_hot_lm_step_n": (C.c_int, [P, P, C.c_int, P, P, P]),
     "moshi_hot_lm_step_embedding": (None, [P, P]),
+    "moshi_hot_set_conditions": (None, [P, P, P]),
+    "moshi_hot_set_text_hook": (None, [P, P, P]),
     "moshi_hot_personaplex_prompt_tokens": (C.POINTER(C.c_int32), []),
     "moshi_hot_personaplex_system_prompts": (None, [P, P, C.c_int]),
     "moshi_hot_create": (P, [P, C.POINTER(Config), C.c_uint64]),
@@ -88,4 +93,27 @@ def tiny_personaplex(lib, linear_type=12, embed_type=2, layers=2):
     cfg.text_card = 2100          # PROMPT_TOKENS reach id 2008
     cfg.dep_dim, cfg.dep_heads, cfg.dep_layers, cfg.dep_ffn_hidden = 256, 4, 2, 512
     cfg.linear_type, cfg.embed_type = linear_type, embed_type
+    return cfg
+
+
+TEXT_HOOK = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_int64, C.c_int32)
+
+
+def tiny_tts(lib, linear_type=12, embed_type=2, layers=2, dep_q=8, cross_len=5):
+    """The tts branches at test widths: cross-attention in every layer, demuxed text embeddings, low-rank
+    Depth embeddings, a per-step weight schedule sharing weight sets, delay_steps, condition_sum; n_q == dep_q (no input streams)."""
+    cfg = tiny(lib, linear_type=linear_type, embed_type=embed_type, layers=layers, dep_q=dep_q, n_q=dep_q)
+    for i in range(MAX_CB):
+        cfg.delays[i] = 0
+    for i in range(2, dep_q + 1):
+        cfg.delays[i] = 1 + (i % 2)
+    cfg.card = 64
+    cfg.demux_second_stream, cfg.depformer_low_rank, cfg.delay_steps = 1, 128, 2
+    cfg.cross_attention, cfg.cross_len, cfg.condition_sum = 1, cross_len, 1
+    sched = [0, 1, 2, 3, 3, 3, 4, 4][:dep_q]
+    cfg.dep_schedule_len = len(sched)
+    for i, v in enumerate(sched):
+        cfg.dep_schedule[i] = v
+    cfg.dep_context = 0            # ring capacity = len(schedule) (lm_default.h:86-90)
+    cfg.mimi_n_q = dep_q
     return cfg

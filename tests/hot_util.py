@@ -106,3 +106,18 @@ class Model:
 def rel_err(ref, got):
     scale = max(float(np.max(np.abs(ref))), 1e-30)
     return float(np.max(np.abs(ref - got))) / scale
+
+
+def set_conditions(m, cfg, seed=4):
+    """tts conditions: deterministic sum F32[dim] and cross F32[dim, cross_len]; returns them"""
+    rng = np.random.default_rng(seed)
+    s = (rng.standard_normal(cfg.dim) * 0.1).astype(np.float32) if cfg.condition_sum else None
+    x = rng.standard_normal((cfg.cross_len, cfg.dim)).astype(np.float32) if cfg.cross_attention else None
+    L.moshi_hot_set_conditions(m.m, s.ctypes.data if s is not None else None, x.ctypes.data if x is not None else None)
+    return s, x
+
+
+def set_text_hook(m, fn):
+    """fn(offset, sampled) -> text token; keeps the ctypes thunk alive on the model"""
+    m._hook = hot.TEXT_HOOK(lambda user, offset, sampled: fn(offset, sampled))
+    L.moshi_hot_set_text_hook(m.m, C.cast(m._hook, C.c_void_p), None)

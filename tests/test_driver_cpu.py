@@ -101,6 +101,10 @@ class RingModel:
         self.cache = [[-2] * self.ncb for _ in range(self.CT)]
         self.initial = [cfg.text_card] + [cfg.card] * (self.ncb - 1)
         self.offset = 0
+        self.delay_steps = cfg.delay_steps
+
+    def replace(self):
+        return self.offset < self.delay_steps          # depformer_replace_tokens (src/moshi.cpp:905)
 
     def inputs(self, tokens):
         needed = self.ncb - self.dep_q - 1
@@ -119,13 +123,18 @@ class RingModel:
 
     def outputs(self, text, audio):
         audio = list(audio)
+        replaced = self.replace()
+        if replaced:
+            audio = [-1] * self.lm_dep_q                # lm.h:910-913
+        if self.delay_steps:                            # lm.h:915-921
+            audio = [-1 if self.offset < self.delays[q + 1] + self.delay_steps else a for q, a in enumerate(audio)]
         self.offset += 1
         if not self.provided:
             pos = self.offset % self.CT
             self.cache[pos][0] = text
             for q in range(self.lm_dep_q):
                 self.cache[pos][q + 1] = audio[q]
-        if self.offset <= self.max_delay:
+        if self.offset <= self.max_delay or replaced:
             return 0, None, None
         t = self.cache[(self.offset - self.max_delay + self.delays[0]) % self.CT][0]
         for i in range(1, self.dep_q + 1):
@@ -239,3 +248,93 @@ def test_vad_head_is_softmax_of_extra_head_2():
     m.lm_step_n([1] * n_in)
     assert m.lm_step_n([1] * n_in, vad=True)[3] == 0.0                   # no heads: *vad = 0 (lm.h:973-975)
     m.free()
+
+
+# ---- tts branches (BASELINE.json configs[1]) ----------------------------------------------------------------
+def demux_token(cfg, first, second):
+    return (second + 1) * (cfg.text_card + 1) + first      # lm.h:176-191
+
+
+def weight_f32(m, name, shape):
+    w = np.zeros(shape, np.float32)
+    t = C.cast(hu.L.moshi_hot_weight(m.m, name.encode()), hu.pkg.TP)
+    assert t, name
+    hu.L.ggml_backend_tensor_get(t, w.ctypes.data, 0, w.nbytes)
+    return w
+
+
+def test_tts_frame_protocol_delay_steps_and_text_hook():
+    cfg = hu.hot.tiny_tts(hu.L, layers=1, linear_type=F32, embed_type=F32)
+    cfg.enable_mimi_encoder = cfg.enable_mimi_decoder = 0
+    m = hu.Model("oracle", cfg)
+    hu.set_conditions(m, cfg)
+    forced = [demux_token(cfg, 7 + i, i - 1) for i in range(12)]           # second = -1 on the first frame: right half scaled by 0
+    seen = []
+    hu.set_text_hook(m, lambda offset, sampled: (seen.append((offset, sampled)), forced[offset])[1])
+    ring = RingModel(cfg)
+    produced = []
+    for step in range(12):
+        want_in = ring.inputs([])
+        r, txt, aud = m.lm_step_n([])
+        raw_t, raw_a = m.last_raw()
+        assert raw_t == forced[step]                                       # the hook's token is what goes on (lm.h:880-900)
+        if step < cfg.delay_steps:
+            assert raw_a == [-1] * cfg.dep_q                               # Depth skipped (src/moshi.cpp:905, lm.h:910-913)
+        wr, wt, wa = ring.outputs(raw_t, raw_a)
+        assert r == wr, f"step {step}"
+        if r:
+            assert (txt, aud) == (wt, wa)
+        produced.append(r)
+        # what the model was fed: text id split into (left, right) by the demux step
+        g = hu.L.moshi_hot_graph(m.m, 0)
+        ids = []
+        for i in range(hu.L.ggml_graph_n_nodes(g)):
+            t = hu.L.ggml_graph_node(g, i)
+            if hu.L.ggml_op_name(t.contents.op) == b"GET_ROWS" and len(ids) < 2:
+                idx = np.zeros(1, np.int32)
+                hu.L.ggml_backend_tensor_get(t.contents.src[1], idx.ctypes.data, 0, 4)
+                ids.append(int(idx[0]))
+        tok = max(want_in[0], 0)
+        n = cfg.text_card + 1
+        assert ids == [tok % n, max(tok // n - 1, 0)], f"step {step}: demux ids {ids} for token {tok}"
+    assert [o for o, _ in seen] == list(range(12))
+    # nothing comes out until every stream is past delays[q + 1] + delay_steps and the delay ring has turned over
+    first = produced.index(1)
+    assert first >= cfg.delay_steps + max(cfg.delays[i] for i in range(cfg.n_q + 1)) and all(produced[first:])
+    m.free()
+
+
+def test_tts_embedding_sum_is_demux_plus_audio_rows_plus_condition():
+    cfg = hu.hot.tiny_tts(hu.L, layers=1, linear_type=F32, embed_type=F32)
+    cfg.enable_mimi_encoder = cfg.enable_mimi_decoder = 0
+    m = hu.Model("oracle", cfg)
+    cond_sum, _ = hu.set_conditions(m, cfg)
+    first, second = 11, 5
+    toks = [demux_token(cfg, first, second), demux_token(cfg, 3, -1)]
+    hu.set_text_hook(m, lambda offset, sampled: toks[offset])
+    m.lm_step_n([])
+    m.lm_step_n([])          # frame 1 reads frame 0's text token from the ring (delay 0); audio streams still at their initial / -1 tokens
+    E = weight_f32(m, "lm.text_emb.weight", (cfg.text_card + 1, cfg.dim)).astype(np.float64)
+    o1 = weight_f32(m, "lm.text_emb.out1.weight", (cfg.dim, cfg.dim)).astype(np.float64)
+    o2 = weight_f32(m, "lm.text_emb.out2.weight", (cfg.dim, cfg.dim)).astype(np.float64)
+    want = o1 @ E[first] + o2 @ E[second] + cond_sum
+    for k in range(cfg.n_q):           # offset 1: streams with delay >= 1 feed their initial token (row `card`), delay 0 the ring (-1 -> scale 0)
+        if 1 <= cfg.delays[k + 1]:
+            want += weight_f32(m, f"lm.emb.{k}.weight", (cfg.card + 1, cfg.dim))[cfg.card]
+    got = m.read("transformer_in", cfg.dim)
+    assert np.max(np.abs(got - want)) < 1e-4 * np.max(np.abs(want))
+    m.free()
+
+
+def test_tts_cross_attention_reads_the_condition():
+    cfg = hu.hot.tiny_tts(hu.L, layers=1, linear_type=F32, embed_type=F32)
+    cfg.enable_mimi_encoder = cfg.enable_mimi_decoder = 0
+    outs = []
+    for seed in (4, 4, 5):
+        m = hu.Model("oracle", cfg)
+        hu.set_conditions(m, cfg, seed=seed)
+        hu.set_text_hook(m, lambda offset, sampled: 9)
+        m.lm_step_n([])
+        outs.append(m.read("transformer_out", cfg.dim).copy())
+        m.free()
+    assert np.array_equal(outs[0], outs[1]) and not np.allclose(outs[0], outs[2])

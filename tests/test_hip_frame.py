@@ -399,3 +399,48 @@ def test_stt_shape_no_depth_graph_and_vad_head():
         assert abs(a[3] - b[3]) < 1e-4, f"step {i}: vad {a[3]} vs {b[3]}"
         assert hu.rel_err(a[4], b[4]) < LOGIT_TOL
     assert any(a[0] == 1 and 0.0 < a[3] < 1.0 for a in rec["oracle"])
+
+
+def run_tts(kind, cfg, steps, flags=0, forced=None):
+    m = hu.Model(kind, cfg, seed=0, flags=flags)
+    hu.set_conditions(m, cfg)
+    n = cfg.text_card + 1
+    hu.set_text_hook(m, lambda offset, sampled: ((offset * 7) % 5) * n + (offset * 13) % cfg.text_card)   # demuxed (second + 1, first) pairs
+    rec = []
+    for i in range(steps):
+        out = m.lm_step_n([])
+        rec.append((out, m.last_raw(), m.read("text_logits", cfg.text_card).copy(), m.read("transformer_out", cfg.dim).copy(),
+                    [m.read(f"dep_logits{k}", cfg.card).copy() for k in range(cfg.dep_q)] if i >= cfg.delay_steps else None))
+        if forced is not None:
+            m.force_last(*forced[i][1])
+    st = m.stats() if kind == "hip" else None
+    m.free()
+    return rec, st
+
+
+@pytest.mark.parametrize("lt", [F32, Q8_0, Q4_K], ids=["f32", "q8_0", "q4_k"])
+def test_tts_branches_match_oracle(lt):
+    # configs[1] (moshi-tts): cross-attention over a cached F32 K/V in every layer (q through a row view of the quantised in_proj, LayerNorm
+    # eps 0), demuxed text embeddings, condition_sum, low-rank Depth embeddings (Q4_K falls back to Q4_0 at width 128), a weight schedule
+    # sharing weight sets between steps, delay_steps; the text token comes from the hook (the state machine is above the boundary)
+    cfg = hu.hot.tiny_tts(hu.L, linear_type=lt)
+    cfg.enable_mimi_encoder = cfg.enable_mimi_decoder = 0
+    steps = 8
+    ref, _ = run_tts("oracle", cfg, steps)
+    # F32 weights: summation noise only. Quantised: one Q8_0 / Q8_K activation flip (module docstring) perturbs a cache row and then stays
+    # in every later frame of this 8-frame run, so the bar is the flip level — and the two device plans, which see bit-identical
+    # activations, must agree with each other far more closely than that.
+    text_tol, dep_tol = (1e-5, 1e-4) if lt == F32 else (5e-2, 0.2)
+    runs = {}
+    for name, flags in (("fused", 0), ("per-node", 1 | 2 | 4)):
+        got, st = run_tts("hip", cfg, steps, flags=flags, forced=ref)
+        runs[name] = got
+        for i, (a, b) in enumerate(zip(ref, got)):
+            assert a[0][0] == b[0][0], f"{name} step {i}: produced flag"
+            assert hu.rel_err(a[3], b[3]) < text_tol, f"{name} step {i}: transformer_out rel err {hu.rel_err(a[3], b[3]):.2e}"
+            if a[4] is not None:
+                compare_frame(cfg, (a[1], a[2], a[4]), (b[1], b[2], b[4]), text_tol, dep_tol, f"{name} step {i}")
+            else:
+                assert a[1] == b[1]                              # Depth skipped: all -1
+    dd = [max(hu.rel_err(a[2], b[2]), hu.rel_err(a[3], b[3])) for a, b in zip(runs["per-node"], runs["fused"])]
+    assert np.median(dd) < 1e-5 and max(dd) < 1e-2, f"fused vs per-node: {dd}"

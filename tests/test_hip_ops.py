@@ -343,3 +343,24 @@ def test_big_matvec_argmax_epilogue_text_head():
         logits = g.mul_mat(w, g.input(x))
         return [g.argmax(logits)], [logits]
     gu.compare(build, atol_rel=2e-6)
+
+
+def test_small_uploads_to_the_same_bytes_keep_their_order():
+    # ggml_backend_tensor_set of small tensors is batched and scattered by one kernel before the next compute; a zero fill followed by
+    # the first value of the same state tensor (StateContext init then a condition upload) must not race inside one batch
+    g = gu.Graph("hip")
+    try:
+        ts = [g.new(F32, 512) for _ in range(24)]
+        g.build([g.add(ts[0], ts[1])])
+        g.alloc()
+        want = []
+        for rep in range(20):
+            for i, t in enumerate(ts):
+                g.set(t, np.zeros(512, np.float32))
+            for i, t in enumerate(ts):
+                g.set(t, np.full(512, rep * 100.0 + i, np.float32))
+                g.set(t, np.full(512, rep * 100.0 + i + 0.5, np.float32))
+            got = [g.get(t)[0, 0, 0, 0] for t in (ts[0], ts[7], ts[23])]
+            assert got == [rep * 100.0 + 0.5, rep * 100.0 + 7.5, rep * 100.0 + 23.5], (rep, got)
+    finally:
+        g.free()
