@@ -338,3 +338,52 @@ def test_tts_cross_attention_reads_the_condition():
         outs.append(m.read("transformer_out", cfg.dim).copy())
         m.free()
     assert np.array_equal(outs[0], outs[1]) and not np.allclose(outs[0], outs[2])
+
+
+def test_tts_cross_attention_update_matches_numpy_restatement():
+    # moshi_streaming_multihead_cross_attention + init() (transformer.h:343-396, 714-762) restated in numpy from the module's definition:
+    # q = W[:dim]·LN(x); (k | v) = W[dim:]·cond, "b t (p h d) -> p b h t d"; softmax(q·k/sqrt(D)) over the Tc condition rows; out_proj
+    cfg = hu.hot.tiny_tts(hu.L, layers=1, linear_type=F32, embed_type=F32)
+    cfg.enable_mimi_encoder = cfg.enable_mimi_decoder = 0
+    m = hu.Model("oracle", cfg)
+    _, cond = hu.set_conditions(m, cfg)
+    hu.set_text_hook(m, lambda offset, sampled: 9)
+    m.lm_step_n([])
+    dim, H = cfg.dim, cfg.num_heads
+    D = dim // H
+    W = weight_f32(m, "lm.transformer.layers.0.cross_attention.in_projs.0.weight", (3 * dim, dim)).astype(np.float64)
+    Wo = weight_f32(m, "lm.transformer.layers.0.cross_attention.out_projs.0.weight", (dim, dim)).astype(np.float64)
+    lw = weight_f32(m, "lm.transformer.layers.0.norm_cross.weight", (dim,)).astype(np.float64)
+    lb = weight_f32(m, "lm.transformer.layers.0.norm_cross.bias", (dim,)).astype(np.float64)
+    wo_ptr = hu.L.moshi_hot_weight(m.m, b"lm.transformer.layers.0.cross_attention.out_projs.0.weight")
+    g = hu.L.moshi_hot_graph(m.m, 0)
+
+    def value(t):
+        a = np.zeros(hu.L.ggml_nelements(t), np.float32)
+        hu.L.ggml_backend_tensor_get(t, a.ctypes.data, 0, a.nbytes)
+        return a.astype(np.float64)
+
+    out_node = norm_node = None
+    for i in range(hu.L.ggml_graph_n_nodes(g)):
+        t = hu.L.ggml_graph_node(g, i)
+        if hu.L.ggml_op_name(t.contents.op) == b"NORM":
+            norm_node = t
+        if hu.L.ggml_op_name(t.contents.op) == b"MUL_MAT" and C.cast(t.contents.src[0], C.c_void_p).value == wo_ptr:
+            out_node = t
+    assert out_node and norm_node
+    x = value(norm_node.contents.src[0])                      # the residual stream entering the cross-attention block
+    mu, var = x.mean(), x.var()
+    n = (x - mu) / np.sqrt(var + 0.0) * lw + lb               # LayerNorm, eps 0.0 (lm_default.h:34)
+    q = (W[:dim] @ n).reshape(H, D)
+    kv = cond.astype(np.float64) @ W[dim:].T                  # [Tc, 2 dim]
+    k = kv[:, :dim].reshape(-1, H, D)
+    v = kv[:, dim:].reshape(-1, H, D)
+    o = np.zeros((H, D))
+    for h in range(H):
+        s = k[:, h] @ q[h] / np.sqrt(D)
+        p = np.exp(s - s.max()); p /= p.sum()
+        o[h] = p @ v[:, h]
+    want = Wo @ o.reshape(dim)
+    got = value(out_node)
+    assert np.max(np.abs(got - want)) < 1e-4 * np.max(np.abs(want)), np.max(np.abs(got - want)) / np.max(np.abs(want))
+    m.free()
