@@ -85,6 +85,10 @@ GGML_API void moshi_hot_set_text_hook(moshi_hot_model_t * m, moshi_hot_text_hook
 // one voice-prompt frame from a precomputed input embedding F32[dim] (moshi_lmgen_step_voice_prompt, lm.h:1004-1037): the Temporal
 // stack runs on the scratch context (moshi_lmmodel_forward_embedding, lm.h:694-709), text is forced to 3, the Depth graph steps
 GGML_API void moshi_hot_lm_step_embedding(moshi_hot_model_t * m, const float * embedding);
+// n_frames provided frames (tokens: n_frames x (n_q + 1), text first) as batched [dim, T] passes of at most `chunk` frames (0 = 32):
+// leaves the delay ring, the offsets and the Temporal KV ring as n_frames calls of moshi_hot_lm_step_n(.., n_q + 1, ..) would,
+// without running the Depth graph or the text head
+GGML_API void moshi_hot_prefill(moshi_hot_model_t * m, const int32_t * tokens, int n_frames, int chunk);
 // PROMPT_TOKENS (lm.h:983-987): 17 ids, text first
 GGML_API const int32_t * moshi_hot_personaplex_prompt_tokens(void);
 // moshi_lmgen_step_system_prompts without a voice (lm.h:1118-1134): 6 silence frames, the text prompt, 6 silence frames

@@ -474,6 +474,19 @@ static void emit_generic(emitter & em, ggml_tensor * n) {
                 em.push([=](hipStream_t s) { k_matvec(s, mv); });
                 return;
             }
+            {   // several activation rows against Q4_K weights (batched prompt prefill): int8 MFMA tiles
+                const ggml_tensor * w0 = n->src[0], * x1 = n->src[1];
+                const int64_t Tn = ggml_nelements(x1) / x1->ne[0];
+                static const bool no_batched = getenv("MI355X_NO_BATCHED_MM") != nullptr;
+                if (!no_batched && x1->type == GGML_TYPE_F32 && ggml_is_contiguous(x1) && ggml_is_contiguous(n) && ggml_is_contiguous(w0) && w0->ne[2] == 1 && w0->ne[3] == 1 &&
+                    k_mm_q4k_batched_supported(w0->type, w0->ne[0], w0->ne[1], Tn)) {
+                    const char * wp = (const char *) w0->data; const int64_t rb = (int64_t) w0->nb[1], K = w0->ne[0], M = w0->ne[1];
+                    const float * xp = (const float *) x1->data; float * yp = (float *) n->data;
+                    void * ws = em.ws(k_mm_q4k_batched_ws_size(K, Tn));
+                    em.push([=](hipStream_t s) { k_mm_q4k_batched(s, wp, rb, K, M, Tn, xp, K, ws, yp, M, nullptr, 0); });
+                    return;
+                }
+            }
             const tdesc a = make_tdesc(n->src[0]), b = make_tdesc(n->src[1]);
             void * w = em.ws(k_mul_mat_ws_size(n->src[0], n->src[1]));
             em.push([=](hipStream_t s) { k_mul_mat(s, d, a, b, w); });
@@ -691,7 +704,7 @@ static bool match_attention(const analysis & an, int pos, attn_group & grp) {
     if (!x2 || x2->op != GGML_OP_CONT) return false;
 
     const int64_t D = kc->ne[0], C = kc->ne[1], H = kc->ne[2], Tn = qo->ne[1];
-    if (qo->ne[0] != D || Tn < 1 || Tn > 4 || qo->ne[2] != H || qo->ne[3] != 1) return false;   // B == 1
+    if (qo->ne[0] != D || Tn < 1 || Tn > 64 || qo->ne[2] != H || qo->ne[3] != 1) return false;   // B == 1; blocks longer than 4 rows (prompt prefill) run as consecutive launches of 4
     if (vc->ne[0] != D || vc->ne[1] != C || vc->ne[2] != H) return false;
     if (mask->type != GGML_TYPE_F32 || mask->ne[0] != C || mask->ne[1] != Tn || !ggml_is_contiguous(mask)) return false;
     if (D % 8 != 0 || 64 % (D / 8) != 0 || D > 256) return false;
@@ -1317,9 +1330,20 @@ static plan_t * build_plan(hip_ctx * c, ggml_cgraph * g) {
     for (auto & ag : attn_groups) {
         if (ag.emit_pos < 0) continue;
         const attn_args a = ag.a;
+        unsigned * err = c->err_dev;
+        if (a.T > 4) {
+            // a block of T > 4 new rows (batched prompt prefill): one workgroup per head and group of 4 rows; first every row's K / V
+            // goes into the ring, then all groups attend at once (causality is in the mask rows)
+            at_pos[ag.emit_pos].insert(at_pos[ag.emit_pos].begin(), [=](hipStream_t s) {
+                attn_args b = a;
+                b.n_groups = (a.T + 3) / 4;
+                b.write_only = 1; k_attn_decode(s, b, nullptr, err);
+                b.write_only = 0; k_attn_decode(s, b, nullptr, err);
+            });
+            continue;
+        }
         void * ws = nullptr;
         if (const size_t n = k_attn_decode_ws_size(a)) { ws = em.ws(n); HIP_CHECK(hipMemset(ws, 0, n)); }   // arrival counters start at zero
-        unsigned * err = c->err_dev;
         at_pos[ag.emit_pos].insert(at_pos[ag.emit_pos].begin(), [=](hipStream_t s) { k_attn_decode(s, a, ws, err); });
     }
     const bool dump = getenv("MI355X_DUMP_PLAN") != nullptr;

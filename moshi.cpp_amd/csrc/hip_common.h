@@ -113,6 +113,11 @@ void k_matvec(hipStream_t s, const mv_args & a);
 // gated-FFN activation silu(h[:K]) * h[K:] quantised to padded Q8_K blocks (K/256 x 304 B) for a following MV_PREQ8K mat-vec
 #define MV_XBLK_BYTES 304
 void k_gate_quant_q8k(hipStream_t s, const float * h, int64_t K, void * out_blocks, int wtype);   // activation format follows the weight type
+// batched Q4_K mat-mul for prompt prefill (T = 2..64 activation rows): rows quantised to Q8_K into `ws`, then 16x16x32 int8 MFMA tiles
+size_t k_mm_q4k_batched_ws_size(int64_t K, int64_t T);
+bool k_mm_q4k_batched_supported(int wtype, int64_t K, int64_t M, int64_t T);
+void k_mm_q4k_batched(hipStream_t s, const char * w, int64_t row_bytes, int64_t K, int64_t M, int64_t T, const float * x, int64_t x_cs,
+                      void * ws, float * y, int64_t y_cs, const float * residual, int64_t r_cs);
 
 // streaming self-attention over a ring KV cache (T <= 4 new tokens): RoPE(q,k) -> cache write -> masked
 // softmax(K q) V restricted to un-masked slots; see hip_kernels_fused.hip
@@ -128,6 +133,10 @@ struct attn_args {
     float scale;
     float * out;                // element (d, h, t) at out[t*out_ts + h*D + d]
     int64_t out_ts;
+    // blocks of T > 4 new rows (batched prompt prefill): n_groups = ceil(T / 4) workgroups per head (blockIdx.y), each taking rows
+    // 4 g .. 4 g + 3. Launched twice: write_only = 1 puts every row's K / V into the ring, then all groups attend concurrently
+    // (their own rows come from registers, earlier groups' rows from the ring, later rows are masked).
+    int n_groups, write_only;
 };
 // Long rings (C >= ATTN_SPLIT_MIN_C, T = 1) are split over ceil(C / ATTN_SPLIT_SLOTS) workgroups per head; `ws` (zeroed once,
 // k_attn_decode_ws_size bytes) carries scores, partial outputs and the per-head arrival counters between them. ws may be NULL

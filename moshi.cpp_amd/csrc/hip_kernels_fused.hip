@@ -797,6 +797,160 @@ void k_gate_quant_q8k(hipStream_t s, const float * h, int64_t K, void * out_bloc
     else gate_quant_kernel<MVF_Q80><<<(int) (K / 256), 64, 0, s>>>(h, (int) K, (xblk *) out_blocks, nullptr);
 }
 
+// ---------------------------------------------------------------------------------------------------
+// batched quantised mat-mul (prompt prefill: T = 2..64 activation rows against Q4_K weights)
+// ---------------------------------------------------------------------------------------------------
+// Each activation row is quantised to Q8_K exactly as for T = 1 (ggml quantises src1 row by row), then the 4-bit x 8-bit dot products
+// of one 32-wide sub-block for 16 weight rows x 16 activation rows are ONE v_mfma_i32_16x16x32_i8: integer, hence exact. Operand maps
+// (checked with integer data, tests/microbench/mfma_i8_layout.hip): lane l supplies A[row l&15][k = 8(l>>4)+j] and
+// B[k = 8(l>>4)+j][col l&15], j = byte 0..7; it receives C[row 4(l>>4)+q][col l&15] in register q. A Q4_K 32-byte group holds sub-block 2j
+// in its low nibbles and 2j+1 in its high nibbles, so the 8 bytes at 32j + 8(l>>4) of a row ARE this lane's A fragment of both sub-blocks.
+// The 6-bit sub-block scale multiplies the int32 tile (24-bit multiplier, exact), mins meet the Q8_K block sums on the VALU, and the float
+// combination per super-block is the T = 1 kernel's: d_w d_x isum - dmin_w d_x msum, summed over super-blocks in order.
+typedef int i32x4_t __attribute__((ext_vector_type(4)));
+
+__global__ void __launch_bounds__(64) quant_rows_q8k_kernel(const float * x, int64_t x_cs, int nb, xblk * out) {
+    const int b = blockIdx.x % nb, t = blockIdx.x / nb, lane = threadIdx.x;
+    const float4 v4 = *(const float4 *) (x + (int64_t) t * x_cs + b * 256 + lane * 4);
+    const float v[4] = { v4.x, v4.y, v4.z, v4.w };
+    quantize_block_q8k(out + (int64_t) t * nb + b, v, lane);
+}
+
+#define MMQ_NW 4   // waves per workgroup: the super-blocks of the 16 rows are dealt round-robin to the waves (split K), partial sums meet in LDS
+template <int NT>
+__global__ void __launch_bounds__(64 * MMQ_NW) mm_q4k_mfma_kernel(const char * w, int64_t row_bytes, int nb, int M, int T, const xblk * xq,
+                                                                   float * y, int64_t y_cs, const float * residual, int64_t r_cs) {
+    __shared__ float red[MMQ_NW - 1][NT * 4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 15, g = lane >> 4;
+    const int row0 = blockIdx.x * 16;
+    const int arow = row0 + r < M ? row0 + r : M - 1;
+    const block_q4_K * wa = (const block_q4_K *) (w + (int64_t) arow * row_bytes);
+    const block_q4_K * wo[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) { const int rr = row0 + 4 * g + q < M ? row0 + 4 * g + q : M - 1; wo[q] = (const block_q4_K *) (w + (int64_t) rr * row_bytes); }
+    const xblk * xc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; nt++) { const int col = nt * 16 + r < T ? nt * 16 + r : T - 1; xc[nt] = xq + (int64_t) col * nb; }
+    float acc[NT][4];
+#pragma unroll
+    for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+        for (int q = 0; q < 4; q++) acc[nt][q] = 0.f;
+    // weights of the next super-block are requested before the current one is consumed (two HBM round trips in flight per wave)
+    uint4 hdr_n[4]; uint2 qs_n[4];
+    {
+        const int b = wave < nb ? wave : nb - 1;
+#pragma unroll
+        for (int q = 0; q < 4; q++) hdr_n[q] = *(const uint4 *) &wo[q][b];
+#pragma unroll
+        for (int j = 0; j < 4; j++) qs_n[j] = ((const uint2 *) wa[b].qs)[4 * j + g];
+    }
+    for (int b = wave; b < nb; b += MMQ_NW) {
+        uint4 hdr[4]; uint2 qsr[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) hdr[q] = hdr_n[q];
+#pragma unroll
+        for (int j = 0; j < 4; j++) qsr[j] = qs_n[j];
+        {
+            const int bn = b + MMQ_NW < nb ? b + MMQ_NW : b;
+#pragma unroll
+            for (int q = 0; q < 4; q++) hdr_n[q] = *(const uint4 *) &wo[q][bn];
+#pragma unroll
+            for (int j = 0; j < 4; j++) qs_n[j] = ((const uint2 *) wa[bn].qs)[4 * j + g];
+        }
+        uint32_t sc[4][2], mn[4][2];
+        float dw[4], dm[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const uint32_t scl[3] = { hdr[q].y, hdr[q].z, hdr[q].w };   // d, dmin (f16 x 2) + 12 scale bytes
+            q4k_unpack_scales((const uint8_t *) scl, sc[q], mn[q]);
+            dw[q] = h2f((uint16_t) (hdr[q].x & 0xffff)); dm[q] = h2f((uint16_t) (hdr[q].x >> 16));
+        }
+        int isum[NT][4];
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+            for (int q = 0; q < 4; q++) isum[nt][q] = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const uint2 q8 = qsr[j];
+            const uint64_t lo = (uint64_t) (q8.x & 0x0F0F0F0Fu) | ((uint64_t) (q8.y & 0x0F0F0F0Fu) << 32);
+            const uint64_t hi = (uint64_t) ((q8.x >> 4) & 0x0F0F0F0Fu) | ((uint64_t) ((q8.y >> 4) & 0x0F0F0F0Fu) << 32);
+#pragma unroll
+            for (int nt = 0; nt < NT; nt++) {
+                const int8_t * xqp = xc[nt][b].q + 64 * j + 8 * g;
+                const long x_lo = *(const long *) xqp, x_hi = *(const long *) (xqp + 32);
+                const i32x4_t z = { 0, 0, 0, 0 };
+                const i32x4_t p0 = __builtin_amdgcn_mfma_i32_16x16x32_i8((long) lo, x_lo, z, 0, 0, 0);
+                const i32x4_t p1 = __builtin_amdgcn_mfma_i32_16x16x32_i8((long) hi, x_hi, z, 0, 0, 0);
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const int s0 = (int) ((sc[q][j >> 1] >> (16 * (j & 1))) & 0xff), s1 = (int) ((sc[q][j >> 1] >> (16 * (j & 1) + 8)) & 0xff);
+                    isum[nt][q] += __mul24(s0, p0[q]) + __mul24(s1, p1[q]);
+                }
+            }
+        }
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++) {
+            const xblk * xb = &xc[nt][b];
+            const uint4 b0 = *(const uint4 *) xb->bsums, b1 = *(const uint4 *) (xb->bsums + 8);
+            const uint32_t bw[8] = { b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w };
+            int bs[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) bs[k] = (int) (int16_t) (bw[k] & 0xffff) + (int) (int16_t) (bw[k] >> 16);
+            const float d8 = xb->d;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                int msum = 0;
+#pragma unroll
+                for (int k = 0; k < 8; k++) msum += __mul24((int) ((mn[q][k >> 2] >> (8 * (k & 3))) & 0xff), bs[k]);
+                const float d = dw[q] * d8, dmin = dm[q] * d8;
+                acc[nt][q] += d * (float) isum[nt][q] - dmin * (float) msum;
+            }
+        }
+    }
+    if (wave > 0) {
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+            for (int q = 0; q < 4; q++) red[wave - 1][nt * 4 + q][lane] = acc[nt][q];
+    }
+    __syncthreads();
+    if (wave > 0) return;
+#pragma unroll
+    for (int nt = 0; nt < NT; nt++) {
+        const int col = nt * 16 + r;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            float v = acc[nt][q];
+#pragma unroll
+            for (int ww = 0; ww < MMQ_NW - 1; ww++) v += red[ww][nt * 4 + q][lane];
+            const int row = row0 + 4 * g + q;
+            if (col >= T || row >= M) continue;
+            if (residual) v = residual[(int64_t) col * r_cs + row] + v;
+            y[(int64_t) col * y_cs + row] = v;
+        }
+    }
+}
+
+size_t k_mm_q4k_batched_ws_size(int64_t K, int64_t T) { return (size_t) (K / 256) * (size_t) T * XBLK_BYTES; }
+bool k_mm_q4k_batched_supported(int wtype, int64_t K, int64_t M, int64_t T) { return wtype == GGML_TYPE_Q4_K && K % 256 == 0 && T >= 2 && T <= 64 && M >= 16; }
+void k_mm_q4k_batched(hipStream_t s, const char * w, int64_t row_bytes, int64_t K, int64_t M, int64_t T, const float * x, int64_t x_cs,
+                      void * ws, float * y, int64_t y_cs, const float * residual, int64_t r_cs) {
+    const int nb = (int) (K / 256);
+    quant_rows_q8k_kernel<<<(int) (T * nb), 64, 0, s>>>(x, x_cs, nb, (xblk *) ws);
+    const int grid = (int) ((M + 15) / 16);
+    const int thr = 64 * MMQ_NW;
+    for (int64_t c0 = 0; c0 < T; c0 += 32) {   // 32 columns per pass (two MFMA column tiles; four would leave one wave per SIMD)
+        const int Tc = (int) (T - c0 < 32 ? T - c0 : 32);
+        const xblk * xq = (const xblk *) ws + c0 * nb;
+        float * yc = y + c0 * y_cs;
+        const float * rc = residual ? residual + c0 * r_cs : nullptr;
+        if (Tc <= 16) mm_q4k_mfma_kernel<1><<<grid, thr, 0, s>>>(w, row_bytes, nb, (int) M, Tc, xq, yc, y_cs, rc, r_cs);
+        else mm_q4k_mfma_kernel<2><<<grid, thr, 0, s>>>(w, row_bytes, nb, (int) M, Tc, xq, yc, y_cs, rc, r_cs);
+    }
+}
+
 static mv_profile * g_mv_profile = nullptr;
 void k_matvec_set_profile(mv_profile * p) { g_mv_profile = p; }
 
@@ -930,8 +1084,18 @@ struct attn_split_ws { float * scores; float * pmax; double * opart; unsigned * 
 
 template <bool SPLIT>
 __global__ void __launch_bounds__(ATTN_THREADS) __attribute__((amdgpu_waves_per_eu(2)))   // >= 2 workgroups per CU: the split grid (<= 512) is resident
-attn_decode_kernel(attn_args a, attn_split_ws w) {
+attn_decode_kernel(attn_args a_in, attn_split_ws w) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    attn_args a = a_in;
+    if (!SPLIT && a.n_groups > 1) {   // rows 4 g .. 4 g + 3 of a longer block
+        const int t0 = 4 * (int) blockIdx.y;
+        a.T = a.T - t0 < 4 ? a.T - t0 : 4;
+        a.q += (int64_t) t0 * a.q_ts; a.k += (int64_t) t0 * a.k_ts; a.v += (int64_t) t0 * a.v_ts;
+        if (a.rot) a.rot += (int64_t) t0 * a.D;
+        a.mask += (int64_t) t0 * a.C;
+        a.index += t0;
+        a.out += (int64_t) t0 * a.out_ts;
+    }
     // passes whose ring rows are requested before the first wait (the rest streams in batches of the same size in the pass loops)
     constexpr int NPRE = ATTN_NPRE;   // A/B at bench level: 4 beats 2 and 8 for the split kernel at empty, 600-slot and full context (registers vs round trips)
     const int D = a.D, C = a.C, T = a.T;
@@ -1067,6 +1231,7 @@ attn_decode_kernel(attn_args a, attn_split_ws w) {
             }
         }
     }
+    if (!SPLIT && a.write_only) return;
     if (!SPLIT || s_idx == 0) { n_end = block_max_i32(last_live) + 1; if (SPLIT && n_end > w.big_min) SLOTS *= 2; }
     else __syncthreads();
     const int P = SPLIT && n_end > w.single_max ? (n_end + SLOTS - 1) / SLOTS : 1;   // participating workgroups of this head
@@ -1254,7 +1419,7 @@ attn_decode_kernel(attn_args a, attn_split_ws w) {
     }
 }
 
-static bool attn_use_split(const attn_args & a) { return a.T == 1 && a.D == 128 && a.C >= ATTN_SPLIT_MIN_C; }
+static bool attn_use_split(const attn_args & a) { return a.T == 1 && a.n_groups <= 1 && a.D == 128 && a.C >= ATTN_SPLIT_MIN_C; }
 static int attn_split_slots() { static const int v = env_int("MI355X_ATTN_SLOTS", ATTN_SPLIT_SLOTS); return v < 64 ? 64 : v; }
 size_t k_attn_decode_ws_size(const attn_args & a) {
     if (!attn_use_split(a)) return 0;
@@ -1262,8 +1427,10 @@ size_t k_attn_decode_ws_size(const attn_args & a) {
     return (size_t) a.H * a.C * 4 + (size_t) a.H * S * 4 + (size_t) a.H * S * a.D * 8 + (size_t) a.H * 8 + 256;
 }
 void k_attn_decode(hipStream_t s, const attn_args & a, void * ws, unsigned * err) {
-    GGML_ASSERT(a.D % 8 == 0 && 64 % (a.D / 8) == 0 && a.D <= 512 && a.T >= 1 && a.T <= ATTN_MAX_T && a.T * a.D <= 2 * ATTN_THREADS);
-    const size_t smem = (size_t) a.C * 4 + (size_t) a.T * a.D * 4 * 3 + (size_t) (ATTN_THREADS / 64) * 64 * 8 * 8 + 16;
+    const int Tg = a.n_groups > 1 ? ATTN_MAX_T : a.T;   // rows per workgroup
+    GGML_ASSERT(a.D % 8 == 0 && 64 % (a.D / 8) == 0 && a.D <= 512 && a.T >= 1 && Tg <= ATTN_MAX_T && Tg * a.D <= 2 * ATTN_THREADS);
+    GGML_ASSERT(a.n_groups <= 1 || a.n_groups == (a.T + 3) / 4);
+    const size_t smem = (size_t) a.C * 4 + (size_t) Tg * a.D * 4 * 3 + (size_t) (ATTN_THREADS / 64) * 64 * 8 * 8 + 16;
     GGML_ASSERT(smem <= 160 * 1024);
     static const int single_max = env_int("MI355X_ATTN_SINGLE_MAX", ATTN_SINGLE_MAX), big_min = env_int("MI355X_ATTN_BIG_MIN", ATTN_SPLIT_BIG_MIN);
     attn_split_ws w = { nullptr, nullptr, nullptr, nullptr, nullptr, 1, err, ATTN_SPLIT_SLOTS, single_max, big_min };
@@ -1280,7 +1447,7 @@ void k_attn_decode(hipStream_t s, const attn_args & a, void * ws, unsigned * err
         attn_decode_kernel<true><<<a.H * S, ATTN_THREADS, smem, s>>>(a, w);
         return;
     }
-    attn_decode_kernel<false><<<a.H, ATTN_THREADS, smem, s>>>(a, w);
+    attn_decode_kernel<false><<<dim3((unsigned) a.H, (unsigned) (a.n_groups > 1 ? a.n_groups : 1)), ATTN_THREADS, smem, s>>>(a, w);
 }
 
 // ---------------------------------------------------------------------------------------------------

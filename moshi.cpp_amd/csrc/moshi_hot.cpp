@@ -209,7 +209,11 @@ struct Norm { bool rms; float eps; T w = nullptr, b = nullptr; };
 
 // moshi_rms_norm (moshi/modules/transformer.h:15-23) / torch_nn_layer_norm (torch.h:49-60)
 T apply_norm(Builder & c, const Norm & n, T x) {
-    if (n.rms) return ggml_mul(c, n.w, ggml_rms_norm(c, x, n.eps));
+    if (n.rms) {   // moshi_rms_norm (transformer.h:16-23) multiplies alpha * y, which ggml only broadcasts for one column; the batched
+                   // prefill (T > 1, not a reference path) swaps the operands — same products
+        T y = ggml_rms_norm(c, x, n.eps);
+        return x->ne[1] > 1 ? ggml_mul(c, y, n.w) : ggml_mul(c, n.w, y);
+    }
     x = ggml_norm(c, x, n.eps);
     x = ggml_mul(c, x, n.w);
     if (n.b) x = ggml_add(c, x, n.b);
@@ -273,21 +277,24 @@ struct Transformer {
     std::vector<Layer> layers;
     std::vector<int> schedule;                 // weights_per_step_schedule (transformer.h:80-83); empty = step k uses weight set k
     // bias-mask lookup table (torch.h:162-223)
-    struct ggml_context * pat_ctx = nullptr; ggml_backend_buffer_t pat_buf = nullptr; T pattern = nullptr; int pat_T = 0;
+    struct Pat { struct ggml_context * ctx; ggml_backend_buffer_t buf; T pattern; };
+    std::map<int, Pat> pats;                   // one table per block length T (frame steps use one T; batched prefill adds its own)
     // cached-graph inputs (transformer.h:1101-1109)
     T g_bias = nullptr, g_offset = nullptr, g_indices = nullptr;
     int offset = 0;
-    ~Transformer() { if (pat_buf) ggml_backend_buffer_free(pat_buf); if (pat_ctx) ggml_free(pat_ctx); }
+    ~Transformer() { for (auto & p : pats) { ggml_backend_buffer_free(p.second.buf); ggml_free(p.second.ctx); } }
 };
 
 // create_bias_pattern(capacity, t, hi = 0, lo = -inf) (torch.h:170-203)
-void create_bias_pattern(ggml_backend_t be, Transformer & tr, int Tn) {
-    if (tr.pattern) { GGML_ASSERT(tr.pat_T == Tn); return; }
+T create_bias_pattern(ggml_backend_t be, Transformer & tr, int Tn) {
+    auto it = tr.pats.find(Tn);
+    if (it != tr.pats.end()) return it->second.pattern;
     const int C = tr.capacity, start = C * 2 - Tn, width = start + C;
-    tr.pat_ctx = ggml_init({ ggml_tensor_overhead(), NULL, true });
-    tr.pattern = ggml_new_tensor_2d(tr.pat_ctx, GGML_TYPE_F32, width, Tn);
-    tr.pat_buf = ggml_backend_alloc_ctx_tensors(tr.pat_ctx, be);
-    tr.pat_T = Tn;
+    Transformer::Pat pt;
+    pt.ctx = ggml_init({ ggml_tensor_overhead(), NULL, true });
+    pt.pattern = ggml_new_tensor_2d(pt.ctx, GGML_TYPE_F32, width, Tn);
+    pt.buf = ggml_backend_alloc_ctx_tensors(pt.ctx, be);
+    tr.pats[Tn] = pt;
     std::vector<float> v((size_t) width * (size_t) Tn);
     for (int j = 0; j < Tn; j++) {
         float * row = v.data() + (size_t) j * (size_t) width;
@@ -295,14 +302,16 @@ void create_bias_pattern(ggml_backend_t be, Transformer & tr, int Tn) {
         for (int i = 0; i < width; i++) row[i] = i < right ? 0.0f : -INFINITY;
         for (int i = 0; i < Tn - j - 1; i++) row[C - 1 - i] = -INFINITY;
     }
-    ggml_backend_tensor_set(tr.pattern, v.data(), 0, v.size() * 4);
+    ggml_backend_tensor_set(pt.pattern, v.data(), 0, v.size() * 4);
+    return pt.pattern;
 }
 
 // bias_pattern_index (torch.h:205-223)
-T bias_pattern_index(Builder & c, Transformer & tr, int offset) {
-    const int C = tr.capacity, start = C * 2 - tr.pat_T;
+T bias_pattern_index(Builder & c, Transformer & tr, int Tn, int offset) {
+    T pattern = create_bias_pattern(c.be, tr, Tn);
+    const int C = tr.capacity, start = C * 2 - Tn;
     const int col = offset <= C ? start - offset : C - (offset % C);
-    T view = ggml_view_2d(c, tr.pattern, C, tr.pat_T, tr.pattern->nb[1], (size_t) col * tr.pattern->nb[0]);
+    T view = ggml_view_2d(c, pattern, C, Tn, pattern->nb[1], (size_t) col * pattern->nb[0]);
     return ggml_cont(c, view);
 }
 
@@ -406,6 +415,8 @@ T transformer_layer(Builder & c, const Transformer & tr, Layer & L, int wi, T in
         T gx = nx;
         if (per_step_views) gx = ggml_view_3d(c, nx, nx->ne[0], 1, nx->ne[2], nx->nb[1], nx->nb[2], 0);   // transformer.h:132-138
         update = gating(c, L.gate_in[(size_t) wi], L.gate_out[(size_t) wi], gx);
+        // moshi_activation_gating returns [dim, 1, T]: addable to x only for T = 1, the reference's only LM shape; the batched prefill folds it back
+        if (x->ne[1] > 1) update = ggml_reshape_3d(c, update, update->ne[0], x->ne[1], x->ne[2]);
     }
     if (L.layer_scale_2) update = ggml_mul(c, update, L.layer_scale_2);
     return ggml_add(c, x, update);
@@ -430,7 +441,7 @@ T transformer_graph_build(Builder & g, Transformer & tr, T x) {
 void transformer_graph_step(Builder & scratch, Transformer & tr, int Tn) {
     const int offset = tr.offset;
     tr.offset += Tn;
-    T bias = bias_pattern_index(scratch, tr, offset);
+    T bias = bias_pattern_index(scratch, tr, Tn, offset);
     scratch.expand(ggml_cpy(scratch, bias, tr.g_bias));
     if (tr.g_offset) { const float f = (float) offset; ggml_backend_tensor_set(tr.g_offset, &f, 0, 4); }
     std::vector<int32_t> idx((size_t) Tn);
@@ -444,7 +455,7 @@ T transformer_inline(Builder & g, Transformer & tr, T x) {
     const int Tn = (int) x->ne[1];
     const int offset = tr.offset;
     create_bias_pattern(g.be, tr, Tn);
-    T attn_bias = bias_pattern_index(g, tr, offset);
+    T attn_bias = bias_pattern_index(g, tr, Tn, offset);
     Rot rot;
     if (tr.max_period) rot = timestep_embedding(g, Tn, tr.dim / tr.heads, g.f32((float) offset), tr.max_period);
     std::vector<int32_t> idx((size_t) Tn);
@@ -1173,6 +1184,59 @@ extern "C" void moshi_hot_set_conditions(moshi_hot_model_t * m, const float * su
     }
 }
 extern "C" void moshi_hot_set_text_hook(moshi_hot_model_t * m, moshi_hot_text_hook_t hook, void * user) { m->text_hook = hook; m->text_hook_user = user; }
+
+// Batched prompt prefill: n_frames "provided" frames (every codebook given, lm.h:812-817) pushed through the Temporal stack as ONE
+// [dim, T] pass per chunk instead of T single-frame steps. The reference steps prompts frame by frame (lm.h:1063-1134) and discards
+// what the model samples on them; what survives a provided frame is the delay ring, the offsets and the Temporal KV rows — exactly
+// what this leaves behind. The Depth graph is not run: every slot of its ring is rewritten by the next
+// frame before it is read. Falls back to single provided frames where a chunk would wrap the ring (the T > 1 mask table is only
+// causal before the wrap, torch.h:170-223).
+extern "C" void moshi_hot_prefill(moshi_hot_model_t * m, const int32_t * tokens, int n_frames, int chunk) {
+    const moshi_hot_config & c = m->cfg;
+    const int ncb = c.n_q + 1, CT = (int) m->cache.size();
+    GGML_ASSERT(ncb - (c.personaplex ? 8 : c.dep_q) - 1 > 0 && !c.demux_second_stream && !c.cross_attention);
+    if (chunk < 1) chunk = 32;
+    int done = 0;
+    while (done < n_frames) {
+        int Tn = n_frames - done < chunk ? n_frames - done : chunk;
+        if (Tn == 1 || m->temporal.offset + Tn > m->temporal.capacity) {
+            int32_t text, audio[MOSHI_HOT_MAX_CODEBOOKS];
+            moshi_hot_lm_step_n(m, tokens + (size_t) done * ncb, ncb, &text, audio, nullptr);
+            done++;
+            continue;
+        }
+        // host side of Tn provided frames (lm.h:812-817, 826-834, 933): ring writes, model inputs, offset
+        std::vector<std::vector<int32_t>> ids((size_t) ncb, std::vector<int32_t>((size_t) Tn));
+        std::vector<std::vector<float>> scales((size_t) ncb, std::vector<float>((size_t) Tn));
+        for (int t = 0; t < Tn; t++) {
+            const int32_t * tk = tokens + (size_t) (done + t) * ncb;
+            for (int i = 0; i < ncb; i++) m->cache[(size_t) ((m->offset + c.delays[i]) % CT)][(size_t) i] = tk[i];
+            const int pos = m->offset % CT;
+            for (int i = 0; i < ncb; i++) {
+                int32_t id = m->offset <= c.delays[i] ? m->initial[(size_t) i] : m->cache[(size_t) pos][(size_t) i];
+                scales[(size_t) i][(size_t) t] = id == -1 ? 0.f : 1.f;
+                ids[(size_t) i][(size_t) t] = id < 0 ? 0 : id;
+            }
+            m->offset++;
+        }
+        PhaseTimer pt(m, 1);
+        Builder & s = *m->scratch;
+        T input = nullptr;
+        for (int i = 0; i < ncb; i++) {   // moshi_lmmodel_text_token_embed over Tn columns
+            T idx = s.i32s(ids[(size_t) i]);
+            T sc = s.constant(s.tensor(GGML_TYPE_F32, 1, Tn), scales[(size_t) i].data());
+            T e = ggml_mul(s, ggml_get_rows(s, i == 0 ? m->text_emb : m->emb[(size_t) (i - 1)], idx), sc);
+            input = input ? ggml_add(s, input, e) : e;
+        }
+        if (c.condition_sum) input = ggml_add(s, m->cond_sum, input);
+        T x = transformer_inline(s, m->temporal, input);
+        // transformer_out as the last of these frames would have left it (lm.h:434, 847-849)
+        T last = ggml_view_2d(s, x, x->ne[0], 1, x->nb[1], (size_t) (Tn - 1) * x->nb[1]);
+        s.expand(ggml_cpy(s, apply_norm(s, m->out_norm, last), m->transformer_out));
+        s.compute_scratch();
+        done += Tn;
+    }
+}
 
 static const int32_t PERSONAPLEX_PROMPT_TOKENS[17] = { 3, 948, 243, 1178, 546, 1736, 1030, 1978, 2008, 430, 1268, 381, 1611, 1095, 1495, 56, 472 };
 extern "C" const int32_t * moshi_hot_personaplex_prompt_tokens(void) { return PERSONAPLEX_PROMPT_TOKENS; }

@@ -30,6 +30,7 @@ SIGNATURES = {
     "moshi_hot_lm_step_n": (C.c_int, [P, P, C.c_int, P, P, P]),
     "moshi_hot_lm_step_embedding": (None, [P, P]),
     "moshi_hot_set_conditions": (None, [P, P, P]),
+    "moshi_hot_prefill": (None, [P, P, C.c_int, C.c_int]),
     "moshi_hot_set_text_hook": (None, [P, P, P]),
     "moshi_hot_personaplex_prompt_tokens": (C.POINTER(C.c_int32), []),
     "moshi_hot_personaplex_system_prompts": (None, [P, P, C.c_int]),

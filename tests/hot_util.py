@@ -63,6 +63,11 @@ class Model:
         assert emb.size == self.cfg.dim
         L.moshi_hot_lm_step_embedding(self.m, emb.ctypes.data)
 
+    def prefill(self, frames, chunk=0):
+        """frames: list of (n_q + 1)-token lists (text first)"""
+        flat = np.ascontiguousarray(np.array(frames, np.int32).reshape(-1))
+        L.moshi_hot_prefill(self.m, flat.ctypes.data, len(frames), chunk)
+
     def system_prompts(self, text_prompt):
         tp = (C.c_int32 * max(1, len(text_prompt)))(*text_prompt)
         L.moshi_hot_personaplex_system_prompts(self.m, tp, len(text_prompt))

@@ -387,3 +387,43 @@ def test_tts_cross_attention_update_matches_numpy_restatement():
     got = value(out_node)
     assert np.max(np.abs(got - want)) < 1e-4 * np.max(np.abs(want)), np.max(np.abs(got - want)) / np.max(np.abs(want))
     m.free()
+
+
+# ---- batched prompt prefill -----------------------------------------------------------------------------------
+@pytest.mark.parametrize("variant,chunk", [("moshika", 0), ("moshika", 3), ("personaplex", 4)])
+def test_batched_prefill_leaves_the_state_of_frame_by_frame_provided_steps(variant, chunk):
+    cfg = hu.hot.tiny(hu.L, layers=2) if variant == "moshika" else hu.hot.tiny_personaplex(hu.L, layers=2)
+    cfg.enable_mimi_encoder = cfg.enable_mimi_decoder = 0
+    rng = np.random.default_rng(21)
+    n = 10
+    frames = [[int(rng.integers(0, cfg.text_card))] + rng.integers(0, cfg.card, cfg.n_q).tolist() for _ in range(n)]
+    after = [rng.integers(0, cfg.card, cfg.n_q - cfg.io_dep_q).tolist() for _ in range(4)]
+    a, b = hu.Model("oracle", cfg), hu.Model("oracle", cfg)
+    a.lm_step(after[0]); b.lm_step(after[0])                    # not from a cold start: one ordinary frame first
+    for f in frames:
+        a.lm_step_n(f)                                          # frame by frame, as the reference steps its prompts (lm.h:1063-1134)
+    b.prefill(frames, chunk)
+    assert hu.L.moshi_hot_offset(a.m) == hu.L.moshi_hot_offset(b.m) == n + 1
+    assert np.array_equal(a.read("transformer_out", cfg.dim), b.read("transformer_out", cfg.dim))
+    for ia in after:                                            # everything the model does afterwards is identical, bit for bit
+        ra, rb = a.lm_step(ia), b.lm_step(ia)
+        assert ra == rb and a.last_raw() == b.last_raw()
+        assert np.array_equal(a.read("text_logits", cfg.text_card), b.read("text_logits", cfg.text_card))
+        assert np.array_equal(a.read(f"dep_logits{cfg.dep_q - 1}", cfg.card), b.read(f"dep_logits{cfg.dep_q - 1}", cfg.card))
+    a.free(); b.free()
+
+
+def test_batched_prefill_falls_back_to_single_frames_at_the_ring_wrap():
+    cfg = hu.hot.tiny(hu.L, layers=1, context=12)
+    cfg.enable_mimi_encoder = cfg.enable_mimi_decoder = 0
+    rng = np.random.default_rng(22)
+    frames = [[int(rng.integers(0, cfg.text_card))] + rng.integers(0, cfg.card, cfg.n_q).tolist() for _ in range(20)]   # crosses capacity 12
+    a, b = hu.Model("oracle", cfg), hu.Model("oracle", cfg)
+    for f in frames:
+        a.lm_step_n(f)
+    b.prefill(frames, 8)
+    ia = list(range(cfg.n_q - cfg.dep_q))
+    for _ in range(3):
+        assert a.lm_step(ia) == b.lm_step(ia)
+        assert np.array_equal(a.read("text_logits", cfg.text_card), b.read("text_logits", cfg.text_card))
+    a.free(); b.free()

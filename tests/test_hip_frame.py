@@ -444,3 +444,42 @@ def test_tts_branches_match_oracle(lt):
                 assert a[1] == b[1]                              # Depth skipped: all -1
     dd = [max(hu.rel_err(a[2], b[2]), hu.rel_err(a[3], b[3])) for a, b in zip(runs["per-node"], runs["fused"])]
     assert np.median(dd) < 1e-5 and max(dd) < 1e-2, f"fused vs per-node: {dd}"
+
+
+# ---- batched prompt prefill --------------------------------------------------------------------------------------
+@pytest.mark.parametrize("lt", [F32, Q8_0, Q4_K], ids=["f32", "q8_0", "q4_k"])
+def test_batched_prefill_on_the_device_matches_frame_by_frame_oracle(lt):
+    # 20 prompt frames as [dim, T] passes of 8 on the device; reference = the oracle stepping them one by one (as lm.h:1063-1134 does).
+    # Afterwards both continue with ordinary frames (teacher-forced): same tokens, logits within the type's bar.
+    cfg = hu.hot.tiny_personaplex(hu.L, linear_type=lt)
+    cfg.enable_mimi_encoder = cfg.enable_mimi_decoder = 0
+    rng = np.random.default_rng(31)
+    frames = [[int(rng.integers(0, cfg.text_card))] + rng.integers(0, cfg.card, cfg.n_q).tolist() for _ in range(20)]
+    after = [rng.integers(0, cfg.card, cfg.n_q - cfg.io_dep_q).tolist() for _ in range(4)]
+    rec = {}
+    for kind in ("oracle", "hip", "hip-frames"):
+        m = hu.Model("hip" if kind != "oracle" else "oracle", cfg, seed=0)
+        if kind == "hip":
+            m.prefill(frames, 8)
+        else:
+            for f in frames:
+                m.lm_step_n(f)
+        r = [(None, None, None, m.read("transformer_out", cfg.dim).copy())]
+        for i, ia in enumerate(after):
+            m.lm_step(ia)
+            r.append(snapshot(m, cfg) + (m.read("transformer_out", cfg.dim).copy(),))
+            if kind != "oracle":
+                m.force_last(*rec["oracle"][i + 1][0])
+        rec[kind] = r
+        m.free()
+    text_tol, dep_tol = (1e-5, 1e-4) if lt == F32 else (5e-2, 0.2)
+    for kind in ("hip", "hip-frames"):
+        for i, (a, b) in enumerate(zip(rec["oracle"], rec[kind])):
+            assert hu.rel_err(a[3], b[3]) < text_tol, f"{kind} stage {i}: transformer_out rel err {hu.rel_err(a[3], b[3]):.2e}"
+            if i:
+                compare_frame(cfg, a[:3], b[:3], text_tol, dep_tol, f"{kind} stage {i}")
+    # batched and frame-by-frame on the device: same integer dot products row by row, so they agree far below the quantiser-flip level
+    # batched and frame-by-frame on the device: same integer dot products row by row; the float sums over super-blocks associate
+    # differently, so quantised types may still part by a flip
+    dd = [hu.rel_err(a[3], b[3]) for a, b in zip(rec["hip-frames"], rec["hip"])]
+    assert np.median(dd) < (1e-5 if lt == F32 else 1e-2), f"device prefill vs device frame-by-frame: {dd}"

@@ -364,3 +364,20 @@ def test_small_uploads_to_the_same_bytes_keep_their_order():
             assert got == [rep * 100.0 + 0.5, rep * 100.0 + 7.5, rep * 100.0 + 23.5], (rep, got)
     finally:
         g.free()
+
+
+@pytest.mark.parametrize("K,M,T", [(256, 16, 2), (512, 40, 5), (1024, 250, 16), (4096, 512, 17), (2048, 96, 32), (512, 64, 33), (4096, 128, 64), (11264, 64, 24)])
+def test_batched_q4k_matmul_int8_mfma(K, M, T):
+    # prompt prefill: T activation rows against Q4_K weights. Rows are quantised to Q8_K one by one (as ggml does for any T), the
+    # sub-block dot products run on v_mfma_i32_16x16x32_i8; ragged M (not a multiple of 16) and T (not a multiple of 16) included
+    r = np.random.default_rng(K + M + T)
+    x = (r.standard_normal((T, K)) * r.uniform(0.2, 3.0, (T, 1))).astype(np.float32)
+    wraw = gu.random_q4_K(r, M, K)
+
+    def build(g):
+        return [g.mul_mat(g.input_raw(wraw, Q4_K, K, M), g.input(x))]
+    gu.compare(build, atol_rel=2e-6)
+
+    def build3(g):     # the gated FFN hands its activation over as [K, 1, T] (gating.h:16-37)
+        return [g.mul_mat(g.input_raw(wraw, Q4_K, K, M), g.input(x.reshape(T, 1, K)))]
+    gu.compare(build3, atol_rel=2e-6)
