@@ -1418,20 +1418,30 @@ static enum ggml_status hip_graph_compute(ggml_backend_t backend, struct ggml_cg
         if (it->second->hash == h) p = it->second;
         else { HIP_CHECK(hipStreamSynchronize(c->stream)); plan_free(c, it->second); c->plans.erase(it); }
     }
+    static const bool time_plan = getenv("MI355X_TIME_PLAN") != nullptr;
+    const int64_t tp0 = time_plan ? ggml_time_us() : 0;
+    bool fresh = false;
     if (!p) {
         p = build_plan(c, g);
         p->hash = h;
         c->plans[g] = p;
-        if (!(c->flags & 2)) {
-            // capture the launch sequence once; replays cost one hipGraphLaunch
-            HIP_CHECK(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
-            run_steps(c, p);
-            HIP_CHECK(hipStreamEndCapture(c->stream, &p->graph));
-            HIP_CHECK(hipGraphInstantiate(&p->exec, p->graph, nullptr, nullptr, 0));
-        }
+        fresh = true;
     }
+    const int64_t tp1 = time_plan ? ggml_time_us() : 0;
+    if (!fresh && !p->exec && !(c->flags & 2)) {
+        // second compute of the same graph: it is a cached graph (the per-frame ones), so capture the launch sequence now; replays cost one
+        // hipGraphLaunch. One-shot graphs (scratch contexts, prompt prefill chunks) never pay for a capture.
+        HIP_CHECK(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+        run_steps(c, p);
+        HIP_CHECK(hipStreamEndCapture(c->stream, &p->graph));
+        HIP_CHECK(hipGraphInstantiate(&p->exec, p->graph, nullptr, nullptr, 0));
+    }
+    const int64_t tp2 = time_plan ? ggml_time_us() : 0;
     if (p->exec) { HIP_CHECK(hipGraphLaunch(p->exec, c->stream)); c->stats.graph_replays++; }
     else run_steps(c, p);
+    if (time_plan && g->n_nodes > 500)
+        fprintf(stderr, "graph %p nodes %d: plan %s %.2f ms, capture %.2f ms, launch %.2f ms (%zu kernels)\n", (void *) g, g->n_nodes, fresh ? "built" : "reused",
+                (tp1 - tp0) / 1e3, (tp2 - tp1) / 1e3, (ggml_time_us() - tp2) / 1e3, p->steps.size());
     c->stats.kernels_in_last_plan = (int64_t) p->steps.size();
     c->stats.nodes_in_last_plan = p->n_nodes;
     c->stats.fused_nodes_in_last_plan = p->n_fused;

@@ -72,7 +72,7 @@ __device__ unsigned long long g_mv_real[4096][2];
 #endif
 
 struct xblk { int8_t q[256]; int16_t bsums[16]; float d; float pad[3]; };
-static_assert(sizeof(xblk) == XBLK_BYTES, "xblk layout");
+static_assert(sizeof(xblk) == XBLK_BYTES && offsetof(xblk, bsums) == 256 && offsetof(xblk, d) == 288, "xblk layout");
 
 // Weight formats of the block mat-vec. A lane always owns 256 consecutive weights of one row: one Q4_K super-block, or eight
 // consecutive Q8_0 / Q4_0 blocks (K % 256 == 0 for every linear of the models). Activations are quantised the way ggml's CPU
@@ -808,106 +808,140 @@ void k_gate_quant_q8k(hipStream_t s, const float * h, int64_t K, void * out_bloc
 // The 6-bit sub-block scale multiplies the int32 tile (24-bit multiplier, exact), mins meet the Q8_K block sums on the VALU, and the float
 // combination per super-block is the T = 1 kernel's: d_w d_x isum - dmin_w d_x msum, summed over super-blocks in order.
 typedef int i32x4_t __attribute__((ext_vector_type(4)));
+typedef unsigned short u16x2_t __attribute__((ext_vector_type(2)));
 
-__global__ void __launch_bounds__(64) quant_rows_q8k_kernel(const float * x, int64_t x_cs, int nb, xblk * out) {
+// activation record of the batched path: the Q8_K block (same rounding as quantize_block_q8k), its eight 32-wide sums split as
+// 64 * hi + lo (hi in [-64, 63], lo in [0, 63]: both int8, so the mins product runs on the MFMA too), the block scale
+struct xblkb { int8_t q[256]; int8_t bs_hi[8]; int8_t bs_lo[8]; float d; float pad[3]; };
+static_assert(sizeof(xblkb) == 288, "xblkb layout");
+
+__global__ void __launch_bounds__(64) quant_rows_q8k_kernel(const float * x, int64_t x_cs, int nb, xblkb * out) {
+    __shared__ xblk tmp;
     const int b = blockIdx.x % nb, t = blockIdx.x / nb, lane = threadIdx.x;
     const float4 v4 = *(const float4 *) (x + (int64_t) t * x_cs + b * 256 + lane * 4);
     const float v[4] = { v4.x, v4.y, v4.z, v4.w };
-    quantize_block_q8k(out + (int64_t) t * nb + b, v, lane);
+    quantize_block_q8k(&tmp, v, lane);
+    __syncthreads();
+    xblkb * o = out + (int64_t) t * nb + b;
+    ((uint32_t *) o->q)[lane] = ((const uint32_t *) tmp.q)[lane];
+    if (lane < 8) {
+        const int bs = (int) tmp.bsums[2 * lane] + (int) tmp.bsums[2 * lane + 1];
+        o->bs_hi[lane] = (int8_t) (bs >> 6);
+        o->bs_lo[lane] = (int8_t) (bs & 63);
+    }
+    if (lane == 0) o->d = tmp.d;
 }
 
-#define MMQ_NW 4   // waves per workgroup: the super-blocks of the 16 rows are dealt round-robin to the waves (split K), partial sums meet in LDS
+#define MMQ_NW 4          // waves per workgroup; tiles of 4 consecutive super-blocks are dealt round-robin to the waves (split K)
+#define MMQ_TSB 4         // super-blocks per tile: 16 rows x 4 x 144 B = 9216 B = 9 coalesced 16-byte loads per lane
+#define MMQ_ROW 608       // LDS bytes per staged row (576 used): 152 dwords = 24 mod 64, so the 16 rows of one ds_read_b64 spread over all banks
+// The activation rows take the MFMA's M side and the weight rows its N side: lane l holds C[t = 4(l>>4)+q][row l&15], ONE weight row per
+// lane. Its 6-bit sub-block scale s = 8 sh + sl is folded into the 4-bit weights before the MFMA (q * sh and q * sl stay below 128, a
+// packed dword times a small integer never carries between bytes), so the eight sub-blocks of a super-block ACCUMULATE in the matrix
+// core: isum = 8 * sum(x . q sh) + sum(x . q sl), no per-tile scaling on the VALU. The mins meet the split block sums the same way.
 template <int NT>
-__global__ void __launch_bounds__(64 * MMQ_NW) mm_q4k_mfma_kernel(const char * w, int64_t row_bytes, int nb, int M, int T, const xblk * xq,
+__global__ void __launch_bounds__(64 * MMQ_NW) mm_q4k_mfma_kernel(const char * w, int64_t row_bytes, int nb, int M, int T, const xblkb * xq,
                                                                    float * y, int64_t y_cs, const float * residual, int64_t r_cs) {
+    __shared__ __attribute__((aligned(16))) char stage_all[MMQ_NW][16 * MMQ_ROW];
     __shared__ float red[MMQ_NW - 1][NT * 4][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 15, g = lane >> 4;
     const int row0 = blockIdx.x * 16;
-    const int arow = row0 + r < M ? row0 + r : M - 1;
-    const block_q4_K * wa = (const block_q4_K *) (w + (int64_t) arow * row_bytes);
-    const block_q4_K * wo[4];
+    char * stage = stage_all[wave];
+    const char * xa[NT]; const char * xo[NT][4];   // A operand: activation row nt*16 + r; results: activation rows nt*16 + 4g + q
 #pragma unroll
-    for (int q = 0; q < 4; q++) { const int rr = row0 + 4 * g + q < M ? row0 + 4 * g + q : M - 1; wo[q] = (const block_q4_K *) (w + (int64_t) rr * row_bytes); }
-    const xblk * xc[NT];
+    for (int nt = 0; nt < NT; nt++) {
+        const int col = nt * 16 + r < T ? nt * 16 + r : T - 1;
+        xa[nt] = (const char *) (xq + (int64_t) col * nb);
 #pragma unroll
-    for (int nt = 0; nt < NT; nt++) { const int col = nt * 16 + r < T ? nt * 16 + r : T - 1; xc[nt] = xq + (int64_t) col * nb; }
+        for (int q = 0; q < 4; q++) { const int co = nt * 16 + 4 * g + q < T ? nt * 16 + 4 * g + q : T - 1; xo[nt][q] = (const char *) (xq + (int64_t) co * nb); }
+    }
     float acc[NT][4];
 #pragma unroll
     for (int nt = 0; nt < NT; nt++)
 #pragma unroll
         for (int q = 0; q < 4; q++) acc[nt][q] = 0.f;
-    // weights of the next super-block are requested before the current one is consumed (two HBM round trips in flight per wave)
-    uint4 hdr_n[4]; uint2 qs_n[4];
-    {
-        const int b = wave < nb ? wave : nb - 1;
+    const int ntiles = (nb + MMQ_TSB - 1) / MMQ_TSB;
+    // the tile of 16 rows x 4 super-blocks as 576 chunks of 16 B: chunk c -> row c / 36, byte (c % 36) * 16 of that row's 576 B
+    int grow[9], goff[9], loff[9];
 #pragma unroll
-        for (int q = 0; q < 4; q++) hdr_n[q] = *(const uint4 *) &wo[q][b];
-#pragma unroll
-        for (int j = 0; j < 4; j++) qs_n[j] = ((const uint2 *) wa[b].qs)[4 * j + g];
+    for (int i = 0; i < 9; i++) {
+        const int c = i * 64 + lane, rr = c / 36, o = (c - rr * 36) * 16;
+        grow[i] = row0 + rr < M ? row0 + rr : M - 1;
+        goff[i] = o;
+        loff[i] = rr * MMQ_ROW + o;
     }
-    for (int b = wave; b < nb; b += MMQ_NW) {
-        uint4 hdr[4]; uint2 qsr[4];
+    auto load_tile = [&](int tile, u32x4 * dst) {
 #pragma unroll
-        for (int q = 0; q < 4; q++) hdr[q] = hdr_n[q];
-#pragma unroll
-        for (int j = 0; j < 4; j++) qsr[j] = qs_n[j];
-        {
-            const int bn = b + MMQ_NW < nb ? b + MMQ_NW : b;
-#pragma unroll
-            for (int q = 0; q < 4; q++) hdr_n[q] = *(const uint4 *) &wo[q][bn];
-#pragma unroll
-            for (int j = 0; j < 4; j++) qs_n[j] = ((const uint2 *) wa[bn].qs)[4 * j + g];
+        for (int i = 0; i < 9; i++) {
+            int64_t off = (int64_t) tile * (MMQ_TSB * 144) + goff[i];
+            if (off > row_bytes - 16) off = row_bytes - 16;   // ragged last tile: stay inside the row
+            dst[i] = __builtin_nontemporal_load((const u32x4 *) (w + (int64_t) grow[i] * row_bytes + off));
         }
-        uint32_t sc[4][2], mn[4][2];
-        float dw[4], dm[4];
+    };
+    u32x4 rn[9];
+    if (wave < ntiles) load_tile(wave, rn);
+    for (int tile = wave; tile < ntiles; tile += MMQ_NW) {
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const uint32_t scl[3] = { hdr[q].y, hdr[q].z, hdr[q].w };   // d, dmin (f16 x 2) + 12 scale bytes
-            q4k_unpack_scales((const uint8_t *) scl, sc[q], mn[q]);
-            dw[q] = h2f((uint16_t) (hdr[q].x & 0xffff)); dm[q] = h2f((uint16_t) (hdr[q].x >> 16));
-        }
-        int isum[NT][4];
+        for (int i = 0; i < 9; i++) *(u32x4 *) (stage + loff[i]) = rn[i];
+        if (tile + MMQ_NW < ntiles) load_tile(tile + MMQ_NW, rn);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const int nsb = nb - tile * MMQ_TSB < MMQ_TSB ? nb - tile * MMQ_TSB : MMQ_TSB;
+        for (int sb = 0; sb < nsb; sb++) {
+            const int64_t xoff = (int64_t) (tile * MMQ_TSB + sb) * (int64_t) sizeof(xblkb);
+            const char * wrow = stage + r * MMQ_ROW + sb * 144;
+            const uint4 hdr = *(const uint4 *) wrow;   // d, dmin (f16 x 2) + 12 scale bytes of this lane's weight row
+            uint32_t sc[2], mn[2];
+            const uint32_t scl[3] = { hdr.y, hdr.z, hdr.w };
+            q4k_unpack_scales((const uint8_t *) scl, sc, mn);
+            const float dw = h2f((uint16_t) (hdr.x & 0xffff)), dm = h2f((uint16_t) (hdr.x >> 16));
+            const uint32_t shi[2] = { (sc[0] >> 3) & 0x07070707u, (sc[1] >> 3) & 0x07070707u }, slo[2] = { sc[0] & 0x07070707u, sc[1] & 0x07070707u };
+            i32x4_t ihi[NT], ilo[NT];
 #pragma unroll
-        for (int nt = 0; nt < NT; nt++)
+            for (int nt = 0; nt < NT; nt++) { ihi[nt] = i32x4_t{ 0, 0, 0, 0 }; ilo[nt] = i32x4_t{ 0, 0, 0, 0 }; }
 #pragma unroll
-            for (int q = 0; q < 4; q++) isum[nt][q] = 0;
+            for (int j = 0; j < 4; j++) {
+                const uint2 q8 = *(const uint2 *) (wrow + 16 + 32 * j + 8 * g);
+                const uint32_t l0 = q8.x & 0x0F0F0F0Fu, l1 = q8.y & 0x0F0F0F0Fu, h0 = (q8.x >> 4) & 0x0F0F0F0Fu, h1 = (q8.y >> 4) & 0x0F0F0F0Fu;
+                const uint32_t sh0 = (shi[j >> 1] >> (16 * (j & 1))) & 0xff, sh1 = (shi[j >> 1] >> (16 * (j & 1) + 8)) & 0xff;
+                const uint32_t sl0 = (slo[j >> 1] >> (16 * (j & 1))) & 0xff, sl1 = (slo[j >> 1] >> (16 * (j & 1) + 8)) & 0xff;
+                // packed bytes (<= 15) times a scale half (<= 7): <= 105 per byte, so a packed 16-bit multiply (two bytes per half-word,
+                // <= 0x6969) never carries; v_pk_mul_lo_u16 is full rate, a 32-bit v_mul_lo_u32 a quarter
+                auto pkmul = [](uint32_t v, uint32_t k) { const u16x2_t a = __builtin_bit_cast(u16x2_t, v), b = { (unsigned short) k, (unsigned short) k }; return __builtin_bit_cast(uint32_t, (u16x2_t) (a * b)); };
+                const long w_h0 = (long) ((uint64_t) pkmul(l0, sh0) | ((uint64_t) pkmul(l1, sh0) << 32));
+                const long w_l0 = (long) ((uint64_t) pkmul(l0, sl0) | ((uint64_t) pkmul(l1, sl0) << 32));
+                const long w_h1 = (long) ((uint64_t) pkmul(h0, sh1) | ((uint64_t) pkmul(h1, sh1) << 32));
+                const long w_l1 = (long) ((uint64_t) pkmul(h0, sl1) | ((uint64_t) pkmul(h1, sl1) << 32));
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const uint2 q8 = qsr[j];
-            const uint64_t lo = (uint64_t) (q8.x & 0x0F0F0F0Fu) | ((uint64_t) (q8.y & 0x0F0F0F0Fu) << 32);
-            const uint64_t hi = (uint64_t) ((q8.x >> 4) & 0x0F0F0F0Fu) | ((uint64_t) ((q8.y >> 4) & 0x0F0F0F0Fu) << 32);
+                for (int nt = 0; nt < NT; nt++) {
+                    const char * xqp = xa[nt] + xoff + 64 * j + 8 * g;
+                    const long x_lo = *(const long *) xqp, x_hi = *(const long *) (xqp + 32);
+                    ihi[nt] = __builtin_amdgcn_mfma_i32_16x16x32_i8(x_lo, w_h0, ihi[nt], 0, 0, 0);
+                    ilo[nt] = __builtin_amdgcn_mfma_i32_16x16x32_i8(x_lo, w_l0, ilo[nt], 0, 0, 0);
+                    ihi[nt] = __builtin_amdgcn_mfma_i32_16x16x32_i8(x_hi, w_h1, ihi[nt], 0, 0, 0);
+                    ilo[nt] = __builtin_amdgcn_mfma_i32_16x16x32_i8(x_hi, w_l1, ilo[nt], 0, 0, 0);
+                }
+            }
+            // mins x block sums: K = 8 of the 32 (lanes of group 0 carry them, the rest zeros)
+            const long mins_b = g == 0 ? (long) ((uint64_t) mn[0] | ((uint64_t) mn[1] << 32)) : 0L;
 #pragma unroll
             for (int nt = 0; nt < NT; nt++) {
-                const int8_t * xqp = xc[nt][b].q + 64 * j + 8 * g;
-                const long x_lo = *(const long *) xqp, x_hi = *(const long *) (xqp + 32);
+                long a_hi = 0, a_lo = 0;
+                if (g == 0) { a_hi = *(const long *) (xa[nt] + xoff + 256); a_lo = *(const long *) (xa[nt] + xoff + 264); }
                 const i32x4_t z = { 0, 0, 0, 0 };
-                const i32x4_t p0 = __builtin_amdgcn_mfma_i32_16x16x32_i8((long) lo, x_lo, z, 0, 0, 0);
-                const i32x4_t p1 = __builtin_amdgcn_mfma_i32_16x16x32_i8((long) hi, x_hi, z, 0, 0, 0);
+                const i32x4_t mh = __builtin_amdgcn_mfma_i32_16x16x32_i8(a_hi, mins_b, z, 0, 0, 0);
+                const i32x4_t ml = __builtin_amdgcn_mfma_i32_16x16x32_i8(a_lo, mins_b, z, 0, 0, 0);
 #pragma unroll
                 for (int q = 0; q < 4; q++) {
-                    const int s0 = (int) ((sc[q][j >> 1] >> (16 * (j & 1))) & 0xff), s1 = (int) ((sc[q][j >> 1] >> (16 * (j & 1) + 8)) & 0xff);
-                    isum[nt][q] += __mul24(s0, p0[q]) + __mul24(s1, p1[q]);
+                    const int isum = 8 * ihi[nt][q] + ilo[nt][q], msum = 64 * mh[q] + ml[q];
+                    const float d8 = *(const float *) (xo[nt][q] + xoff + 272);
+                    const float d = dw * d8, dmin = dm * d8;
+                    acc[nt][q] += d * (float) isum - dmin * (float) msum;
                 }
             }
         }
-#pragma unroll
-        for (int nt = 0; nt < NT; nt++) {
-            const xblk * xb = &xc[nt][b];
-            const uint4 b0 = *(const uint4 *) xb->bsums, b1 = *(const uint4 *) (xb->bsums + 8);
-            const uint32_t bw[8] = { b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w };
-            int bs[8];
-#pragma unroll
-            for (int k = 0; k < 8; k++) bs[k] = (int) (int16_t) (bw[k] & 0xffff) + (int) (int16_t) (bw[k] >> 16);
-            const float d8 = xb->d;
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                int msum = 0;
-#pragma unroll
-                for (int k = 0; k < 8; k++) msum += __mul24((int) ((mn[q][k >> 2] >> (8 * (k & 3))) & 0xff), bs[k]);
-                const float d = dw[q] * d8, dmin = dm[q] * d8;
-                acc[nt][q] += d * (float) isum[nt][q] - dmin * (float) msum;
-            }
-        }
+        __builtin_amdgcn_wave_barrier();   // every lane is done with the staged tile before it is overwritten
     }
     if (wave > 0) {
 #pragma unroll
@@ -917,33 +951,32 @@ __global__ void __launch_bounds__(64 * MMQ_NW) mm_q4k_mfma_kernel(const char * w
     }
     __syncthreads();
     if (wave > 0) return;
+    const int row = row0 + r;
 #pragma unroll
-    for (int nt = 0; nt < NT; nt++) {
-        const int col = nt * 16 + r;
+    for (int nt = 0; nt < NT; nt++)
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             float v = acc[nt][q];
 #pragma unroll
             for (int ww = 0; ww < MMQ_NW - 1; ww++) v += red[ww][nt * 4 + q][lane];
-            const int row = row0 + 4 * g + q;
+            const int col = nt * 16 + 4 * g + q;
             if (col >= T || row >= M) continue;
             if (residual) v = residual[(int64_t) col * r_cs + row] + v;
             y[(int64_t) col * y_cs + row] = v;
         }
-    }
 }
 
-size_t k_mm_q4k_batched_ws_size(int64_t K, int64_t T) { return (size_t) (K / 256) * (size_t) T * XBLK_BYTES; }
+size_t k_mm_q4k_batched_ws_size(int64_t K, int64_t T) { return (size_t) (K / 256) * (size_t) T * sizeof(xblkb); }
 bool k_mm_q4k_batched_supported(int wtype, int64_t K, int64_t M, int64_t T) { return wtype == GGML_TYPE_Q4_K && K % 256 == 0 && T >= 2 && T <= 64 && M >= 16; }
 void k_mm_q4k_batched(hipStream_t s, const char * w, int64_t row_bytes, int64_t K, int64_t M, int64_t T, const float * x, int64_t x_cs,
                       void * ws, float * y, int64_t y_cs, const float * residual, int64_t r_cs) {
     const int nb = (int) (K / 256);
-    quant_rows_q8k_kernel<<<(int) (T * nb), 64, 0, s>>>(x, x_cs, nb, (xblk *) ws);
+    quant_rows_q8k_kernel<<<(int) (T * nb), 64, 0, s>>>(x, x_cs, nb, (xblkb *) ws);
     const int grid = (int) ((M + 15) / 16);
     const int thr = 64 * MMQ_NW;
     for (int64_t c0 = 0; c0 < T; c0 += 32) {   // 32 columns per pass (two MFMA column tiles; four would leave one wave per SIMD)
         const int Tc = (int) (T - c0 < 32 ? T - c0 : 32);
-        const xblk * xq = (const xblk *) ws + c0 * nb;
+        const xblkb * xq = (const xblkb *) ws + c0 * nb;
         float * yc = y + c0 * y_cs;
         const float * rc = residual ? residual + c0 * r_cs : nullptr;
         if (Tc <= 16) mm_q4k_mfma_kernel<1><<<grid, thr, 0, s>>>(w, row_bytes, nb, (int) M, Tc, xq, yc, y_cs, rc, r_cs);
