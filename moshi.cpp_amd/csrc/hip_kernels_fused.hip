@@ -966,6 +966,134 @@ __global__ void __launch_bounds__(64 * MMQ_NW) mm_q4k_mfma_kernel(const char * w
         }
 }
 
+// Large-M variant: the four waves of a workgroup take four 16-row tiles (64 rows) and walk K TOGETHER, so the activation tile of
+// the current 4 super-blocks (T x 4 x 288 B) is fetched from L2 once per workgroup into LDS instead of once per wave through L1
+// (with K split over the waves the activation traffic was ~4x the weight bytes). Weights: per-wave tile as above. Both tiles of the
+// next step are requested into registers before the current one is multiplied.
+#define MMQ_XCOL 1184     // LDS bytes per activation column (4 x 288 used): 296 dwords = 40 mod 64 -> 16 columns of a ds_read_b64 spread over the banks
+template <int NT>
+__global__ void __launch_bounds__(256) mm_q4k_mfma_rows_kernel(const char * w, int64_t row_bytes, int nb, int M, int T, const xblkb * xq,
+                                                               float * y, int64_t y_cs, const float * residual, int64_t r_cs) {
+    __shared__ __attribute__((aligned(16))) char stage_all[4][16 * MMQ_ROW];
+    __shared__ __attribute__((aligned(16))) char xs[NT * 16 * MMQ_XCOL];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, g = lane >> 4;
+    const int row0 = blockIdx.x * 64 + wave * 16;
+    char * stage = stage_all[wave];
+    float acc[NT][4];
+#pragma unroll
+    for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+        for (int q = 0; q < 4; q++) acc[nt][q] = 0.f;
+    const int ntiles = (nb + MMQ_TSB - 1) / MMQ_TSB;
+    int grow[9], goff[9], loff[9];
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        const int c = i * 64 + lane, rr = c / 36, o = (c - rr * 36) * 16;
+        grow[i] = row0 + rr < M ? row0 + rr : M - 1;
+        goff[i] = o;
+        loff[i] = rr * MMQ_ROW + o;
+    }
+    auto load_tile = [&](int tile, u32x4 * dst) {
+#pragma unroll
+        for (int i = 0; i < 9; i++) {
+            int64_t off = (int64_t) tile * (MMQ_TSB * 144) + goff[i];
+            if (off > row_bytes - 16) off = row_bytes - 16;
+            dst[i] = __builtin_nontemporal_load((const u32x4 *) (w + (int64_t) grow[i] * row_bytes + off));
+        }
+    };
+    // activation tile: NT*16 columns x 1152 B = NT*16*72 chunks of 16 B over 256 threads
+    constexpr int XCH = NT * 16 * 72 / 256;      // 4.5 for NT = 1 -> handled with a guard below
+    constexpr int XN = (NT * 16 * 72 + 255) / 256;
+    auto load_x = [&](int tile, u32x4 * dst) {
+#pragma unroll
+        for (int i = 0; i < XN; i++) {
+            const int c = i * 256 + tid, col = c / 72, o = (c - col * 72) * 16;
+            const int cc = col < T ? col : T - 1;
+            int64_t sbo = (int64_t) tile * (MMQ_TSB * 288) + o;
+            if (sbo > (int64_t) nb * 288 - 16) sbo = (int64_t) nb * 288 - 16;
+            if (c < NT * 16 * 72) dst[i] = *(const u32x4 *) ((const char *) xq + (int64_t) cc * nb * 288 + sbo);
+        }
+    };
+    (void) XCH;
+    u32x4 rn[9], xn[XN];
+    load_tile(0, rn);
+    load_x(0, xn);
+    for (int tile = 0; tile < ntiles; tile++) {
+        __syncthreads();                          // everyone is done with the previous activation tile
+#pragma unroll
+        for (int i = 0; i < 9; i++) *(u32x4 *) (stage + loff[i]) = rn[i];
+#pragma unroll
+        for (int i = 0; i < XN; i++) {
+            const int c = i * 256 + tid, col = c / 72, o = (c - col * 72) * 16;
+            if (c < NT * 16 * 72) *(u32x4 *) (xs + col * MMQ_XCOL + o) = xn[i];
+        }
+        if (tile + 1 < ntiles) { load_tile(tile + 1, rn); load_x(tile + 1, xn); }
+        __syncthreads();
+        const int nsb = nb - tile * MMQ_TSB < MMQ_TSB ? nb - tile * MMQ_TSB : MMQ_TSB;
+        for (int sb = 0; sb < nsb; sb++) {
+            const char * wrow = stage + r * MMQ_ROW + sb * 144;
+            const uint4 hdr = *(const uint4 *) wrow;
+            uint32_t sc[2], mn[2];
+            const uint32_t scl[3] = { hdr.y, hdr.z, hdr.w };
+            q4k_unpack_scales((const uint8_t *) scl, sc, mn);
+            const float dw = h2f((uint16_t) (hdr.x & 0xffff)), dm = h2f((uint16_t) (hdr.x >> 16));
+            const uint32_t shi[2] = { (sc[0] >> 3) & 0x07070707u, (sc[1] >> 3) & 0x07070707u }, slo[2] = { sc[0] & 0x07070707u, sc[1] & 0x07070707u };
+            i32x4_t ihi[NT], ilo[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; nt++) { ihi[nt] = i32x4_t{ 0, 0, 0, 0 }; ilo[nt] = i32x4_t{ 0, 0, 0, 0 }; }
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const uint2 q8 = *(const uint2 *) (wrow + 16 + 32 * j + 8 * g);
+                const uint32_t l0 = q8.x & 0x0F0F0F0Fu, l1 = q8.y & 0x0F0F0F0Fu, h0 = (q8.x >> 4) & 0x0F0F0F0Fu, h1 = (q8.y >> 4) & 0x0F0F0F0Fu;
+                const uint32_t sh0 = (shi[j >> 1] >> (16 * (j & 1))) & 0xff, sh1 = (shi[j >> 1] >> (16 * (j & 1) + 8)) & 0xff;
+                const uint32_t sl0 = (slo[j >> 1] >> (16 * (j & 1))) & 0xff, sl1 = (slo[j >> 1] >> (16 * (j & 1) + 8)) & 0xff;
+                auto pkmul = [](uint32_t v, uint32_t k) { const u16x2_t a = __builtin_bit_cast(u16x2_t, v), b = { (unsigned short) k, (unsigned short) k }; return __builtin_bit_cast(uint32_t, (u16x2_t) (a * b)); };
+                const long w_h0 = (long) ((uint64_t) pkmul(l0, sh0) | ((uint64_t) pkmul(l1, sh0) << 32));
+                const long w_l0 = (long) ((uint64_t) pkmul(l0, sl0) | ((uint64_t) pkmul(l1, sl0) << 32));
+                const long w_h1 = (long) ((uint64_t) pkmul(h0, sh1) | ((uint64_t) pkmul(h1, sh1) << 32));
+                const long w_l1 = (long) ((uint64_t) pkmul(h0, sl1) | ((uint64_t) pkmul(h1, sl1) << 32));
+#pragma unroll
+                for (int nt = 0; nt < NT; nt++) {
+                    const char * xqp = xs + (nt * 16 + r) * MMQ_XCOL + sb * 288 + 64 * j + 8 * g;
+                    const long x_lo = *(const long *) xqp, x_hi = *(const long *) (xqp + 32);
+                    ihi[nt] = __builtin_amdgcn_mfma_i32_16x16x32_i8(x_lo, w_h0, ihi[nt], 0, 0, 0);
+                    ilo[nt] = __builtin_amdgcn_mfma_i32_16x16x32_i8(x_lo, w_l0, ilo[nt], 0, 0, 0);
+                    ihi[nt] = __builtin_amdgcn_mfma_i32_16x16x32_i8(x_hi, w_h1, ihi[nt], 0, 0, 0);
+                    ilo[nt] = __builtin_amdgcn_mfma_i32_16x16x32_i8(x_hi, w_l1, ilo[nt], 0, 0, 0);
+                }
+            }
+            const long mins_b = g == 0 ? (long) ((uint64_t) mn[0] | ((uint64_t) mn[1] << 32)) : 0L;
+#pragma unroll
+            for (int nt = 0; nt < NT; nt++) {
+                const char * xb = xs + (nt * 16 + r) * MMQ_XCOL + sb * 288;
+                const long a_hi = g == 0 ? *(const long *) (xb + 256) : 0L, a_lo = g == 0 ? *(const long *) (xb + 264) : 0L;
+                const i32x4_t z = { 0, 0, 0, 0 };
+                const i32x4_t mh = __builtin_amdgcn_mfma_i32_16x16x32_i8(a_hi, mins_b, z, 0, 0, 0);
+                const i32x4_t ml = __builtin_amdgcn_mfma_i32_16x16x32_i8(a_lo, mins_b, z, 0, 0, 0);
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const int isum = 8 * ihi[nt][q] + ilo[nt][q], msum = 64 * mh[q] + ml[q];
+                    const float d8 = *(const float *) (xs + (nt * 16 + 4 * g + q) * MMQ_XCOL + sb * 288 + 272);
+                    const float d = dw * d8, dmin = dm * d8;
+                    acc[nt][q] += d * (float) isum - dmin * (float) msum;
+                }
+            }
+        }
+    }
+    const int row = row0 + r;
+#pragma unroll
+    for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int col = nt * 16 + 4 * g + q;
+            if (col >= T || row >= M) continue;
+            float v = acc[nt][q];
+            if (residual) v = residual[(int64_t) col * r_cs + row] + v;
+            y[(int64_t) col * y_cs + row] = v;
+        }
+}
+
+static int env_int(const char * name, int def);
 size_t k_mm_q4k_batched_ws_size(int64_t K, int64_t T) { return (size_t) (K / 256) * (size_t) T * sizeof(xblkb); }
 bool k_mm_q4k_batched_supported(int wtype, int64_t K, int64_t M, int64_t T) { return wtype == GGML_TYPE_Q4_K && K % 256 == 0 && T >= 2 && T <= 64 && M >= 16; }
 void k_mm_q4k_batched(hipStream_t s, const char * w, int64_t row_bytes, int64_t K, int64_t M, int64_t T, const float * x, int64_t x_cs,
@@ -979,7 +1107,12 @@ void k_mm_q4k_batched(hipStream_t s, const char * w, int64_t row_bytes, int64_t 
         const xblkb * xq = (const xblkb *) ws + c0 * nb;
         float * yc = y + c0 * y_cs;
         const float * rc = residual ? residual + c0 * r_cs : nullptr;
-        if (Tc <= 16) mm_q4k_mfma_kernel<1><<<grid, thr, 0, s>>>(w, row_bytes, nb, (int) M, Tc, xq, yc, y_cs, rc, r_cs);
+        static const int rows_min = env_int("MI355X_MMQ_ROWS_MIN_M", 8192);   // >= 128 workgroups of 64 rows
+        if (M >= rows_min) {
+            const int grid64 = (int) ((M + 63) / 64);
+            if (Tc <= 16) mm_q4k_mfma_rows_kernel<1><<<grid64, 256, 0, s>>>(w, row_bytes, nb, (int) M, Tc, xq, yc, y_cs, rc, r_cs);
+            else mm_q4k_mfma_rows_kernel<2><<<grid64, 256, 0, s>>>(w, row_bytes, nb, (int) M, Tc, xq, yc, y_cs, rc, r_cs);
+        } else if (Tc <= 16) mm_q4k_mfma_kernel<1><<<grid, thr, 0, s>>>(w, row_bytes, nb, (int) M, Tc, xq, yc, y_cs, rc, r_cs);
         else mm_q4k_mfma_kernel<2><<<grid, thr, 0, s>>>(w, row_bytes, nb, (int) M, Tc, xq, yc, y_cs, rc, r_cs);
     }
 }

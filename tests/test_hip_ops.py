@@ -366,7 +366,9 @@ def test_small_uploads_to_the_same_bytes_keep_their_order():
         g.free()
 
 
-@pytest.mark.parametrize("K,M,T", [(256, 16, 2), (512, 40, 5), (1024, 250, 16), (4096, 512, 17), (2048, 96, 32), (512, 64, 33), (4096, 128, 64), (11264, 64, 24)])
+@pytest.mark.parametrize("K,M,T", [(256, 16, 2), (512, 40, 5), (1024, 250, 16), (4096, 512, 17), (2048, 96, 32), (512, 64, 33), (4096, 128, 64), (11264, 64, 24),
+                                   (2560, 72, 9),                                   # ragged last tile (10 super-blocks)
+                                   (512, 8232, 20), (2560, 8200, 32), (1024, 12288, 7), (256, 9000, 40)])   # >= 8192 rows: shared activation tile variant
 def test_batched_q4k_matmul_int8_mfma(K, M, T):
     # prompt prefill: T activation rows against Q4_K weights. Rows are quantised to Q8_K one by one (as ggml does for any T), the
     # sub-block dot products run on v_mfma_i32_16x16x32_i8; ragged M (not a multiple of 16) and T (not a multiple of 16) included
