@@ -796,6 +796,72 @@ static bool match_attention(const analysis & an, int pos, attn_group & grp) {
     return true;
 }
 
+// A'. several activation rows against Q4_K weights (batched prompt prefill): the int8-MFMA mat-mul with the activation producer
+//     (alpha * rms_norm(x), or silu(h[:n]) * h[n:]) folded into its row quantiser and the residual add into its epilogue
+struct bmm_group { int emit_pos; std::vector<int> members; std::function<void(hipStream_t)> run; };
+static bool match_batched_mm(const analysis & an, int pos, emitter & em, bmm_group & grp) {
+    const ggml_tensor * mm = an.g->nodes[pos];
+    if (mm->op != GGML_OP_MUL_MAT) return false;
+    const ggml_tensor * w0 = mm->src[0], * x1 = mm->src[1];
+    if (w0->type != GGML_TYPE_Q4_K || !ggml_is_contiguous(w0) || w0->ne[2] != 1 || w0->ne[3] != 1) return false;
+    if (x1->type != GGML_TYPE_F32 || !ggml_is_contiguous(x1) || mm->type != GGML_TYPE_F32 || !ggml_is_contiguous(mm) || mm->view_src) return false;
+    const int64_t K = w0->ne[0], M = w0->ne[1], Tn = ggml_nelements(x1) / K;
+    if (!k_mm_q4k_batched_supported(w0->type, K, M, Tn)) return false;
+    grp.members.assign(1, pos);
+    grp.emit_pos = pos;
+    int prologue = MV_PLAIN;
+    const float * xp = (const float *) x1->data, * alpha = nullptr;
+    int64_t x_cs = K;
+    float eps = 0.f;
+    const ggml_tensor * b = x1;
+    while ((b->op == GGML_OP_VIEW || b->op == GGML_OP_RESHAPE) && uses_of(an, b) == 1 && b->src[0]->data == b->data &&
+           ggml_nelements(b->src[0]) == ggml_nelements(b) && ggml_is_contiguous(b->src[0])) b = b->src[0];
+    if (b->op == GGML_OP_MUL && uses_of(an, b) == 1 && b->view_src == NULL) {
+        const ggml_tensor * s0 = b->src[0], * s1 = b->src[1];
+        const ggml_tensor * nr = s0->op == GGML_OP_RMS_NORM ? s0 : s1->op == GGML_OP_RMS_NORM ? s1 : nullptr;
+        const ggml_tensor * al = nr == s0 ? s1 : s0;
+        if (nr && uses_of(an, nr) == 1 && is_f32_vec(al, K) && is_f32_vec(nr->src[0], K * Tn) && nr->src[0]->ne[0] == K) {
+            prologue = MV_RMSNORM;
+            xp = (const float *) nr->src[0]->data;
+            alpha = (const float *) al->data;
+            eps = ggml_get_op_params_f32(nr, 0);
+            grp.members.push_back(pos_of(an, b)); grp.members.push_back(pos_of(an, nr));
+        } else if (s0->op == GGML_OP_UNARY && s0->op_params[0] == GGML_UNARY_OP_SILU && uses_of(an, s0) == 1 && s0->src[0]->op == GGML_OP_VIEW &&
+                   s1->op == GGML_OP_VIEW && uses_of(an, s0->src[0]) == 1 && uses_of(an, s1) == 1) {
+            const ggml_tensor * l = s0->src[0], * r = s1, * h = l->src[0];
+            if (r->src[0] == h && is_f32_vec(h, 2 * K * Tn) && h->ne[0] == 2 * K && l->data == h->data && (const char *) r->data == (const char *) h->data + K * 4 &&
+                l->ne[0] == K && r->ne[0] == K && ggml_nelements(l) == K * Tn && ggml_nelements(r) == K * Tn &&
+                l->ne[1] == 1 && r->ne[1] == 1 && l->nb[2] == h->nb[1] && r->nb[2] == h->nb[1] && l->ne[2] == Tn && r->ne[2] == Tn) {
+                prologue = MV_GATE_SILU;
+                xp = (const float *) h->data;
+                x_cs = 2 * K;
+                grp.members.push_back(pos_of(an, b)); grp.members.push_back(pos_of(an, s0));
+            }
+        }
+    }
+    float * yp = (float *) mm->data;
+    const float * res = nullptr;
+    {   // residual add, possibly behind the gating's shape fold
+        const ggml_tensor * cur = mm, * c = sole_consumer(an, mm);
+        while (c && (c->op == GGML_OP_RESHAPE || c->op == GGML_OP_VIEW) && c->data == cur->data && ggml_is_contiguous(c) && ggml_nelements(c) == ggml_nelements(cur)) { cur = c; c = sole_consumer(an, c); }
+        if (c && c->op == GGML_OP_ADD && c->type == GGML_TYPE_F32 && ggml_is_contiguous(c) && c->view_src == NULL && ggml_nelements(c) == M * Tn && (c->src[0] == cur || c->src[1] == cur)) {
+            const ggml_tensor * other = c->src[0] == cur ? c->src[1] : c->src[0];
+            if (other != cur && is_f32_vec(other, M * Tn)) {
+                res = (const float *) other->data;
+                yp = (float *) c->data;
+                grp.members.push_back(pos_of(an, c));
+                grp.emit_pos = pos_of(an, c);
+            }
+        }
+    }
+    for (int m : grp.members) if (m < 0) return false;
+    const char * wp = (const char *) w0->data;
+    const int64_t rb = (int64_t) w0->nb[1];
+    void * ws = em.ws(k_mm_q4k_batched_ws_size(K, Tn));
+    grp.run = [=](hipStream_t s) { k_mm_q4k_batched(s, wp, rb, K, M, Tn, xp, x_cs, ws, yp, M, res, M, prologue, alpha, eps); };
+    return true;
+}
+
 // C. left-deep sum of (scaled) embedding rows ending at node `pos`
 struct embed_group { embed_sum_args a; std::vector<int> members; };
 
@@ -1271,10 +1337,23 @@ static plan_t * build_plan(hip_ctx * c, ggml_cgraph * g) {
             p->n_fused += (int) grp.members.size();
         }
         // mat-vecs with prologue / epilogue
+        static const bool no_batched_fusion = getenv("MI355X_NO_BATCHED_MM") != nullptr || getenv("MI355X_NO_BATCHED_FUSION") != nullptr;
         for (int i = 0; i < g->n_nodes; i++) {
             if (an.skip[(size_t) i] || g->nodes[i]->op != GGML_OP_MUL_MAT) continue;
             mv_group grp;
-            if (!match_matvec(an, i, grp)) continue;
+            if (!match_matvec(an, i, grp)) {
+                bmm_group bg;
+                if (!no_batched_fusion && match_batched_mm(an, i, em, bg)) {
+                    bool bclash = false;
+                    for (int m : bg.members) if (m != i && an.skip[(size_t) m]) bclash = true;
+                    if (!bclash) {
+                        for (int m : bg.members) an.skip[(size_t) m] = 1;
+                        at_pos[bg.emit_pos].push_back(bg.run);
+                        p->n_fused += (int) bg.members.size();
+                    }
+                }
+                continue;
+            }
             bool clash = false;
             for (int m : grp.members) if (m < 0 || (m != i && an.skip[(size_t) m])) clash = true;
             if (clash) continue;

@@ -832,6 +832,55 @@ __global__ void __launch_bounds__(64) quant_rows_q8k_kernel(const float * x, int
     if (lane == 0) o->d = tmp.d;
 }
 
+__device__ __forceinline__ void store_xblkb(xblkb * o, const xblk * tmp, int lane) {
+    ((uint32_t *) o->q)[lane] = ((const uint32_t *) tmp->q)[lane];
+    if (lane < 8) {
+        const int bs = (int) tmp->bsums[2 * lane] + (int) tmp->bsums[2 * lane + 1];
+        o->bs_hi[lane] = (int8_t) (bs >> 6);
+        o->bs_lo[lane] = (int8_t) (bs & 63);
+    }
+    if (lane == 0) o->d = tmp->d;
+}
+
+// alpha * rms_norm(x) of one activation row, quantised (norm_kernel's arithmetic: float squares summed in double, 1 / sqrtf(mean + eps))
+__global__ void __launch_bounds__(256) rms_quant_rows_q8k_kernel(const float * x, int64_t x_cs, const float * alpha, float eps, int K, int nb, xblkb * out) {
+    __shared__ double sh[4];
+    __shared__ xblk tmp[4];
+    const int t = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float * row = x + (int64_t) t * x_cs;
+    double acc = 0;
+    for (int i = tid; i < K; i += 256) { const float v = row[i]; acc += (double) (v * v); }
+    acc = wave_allsum_f64(acc);
+    if (lane == 0) sh[wave] = acc;
+    __syncthreads();
+    const float var = (float) ((sh[0] + sh[1] + sh[2] + sh[3]) / (double) K);
+    const float scale = 1.0f / sqrtf(var + eps);
+    for (int b = wave; b < nb; b += 4) {
+        const int e = b * 256 + lane * 4;
+        const float4 x4 = *(const float4 *) (row + e), a4 = *(const float4 *) (alpha + e);
+        const float v[4] = { (x4.x * scale) * a4.x, (x4.y * scale) * a4.y, (x4.z * scale) * a4.z, (x4.w * scale) * a4.w };
+        quantize_block_q8k(&tmp[wave], v, lane);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        store_xblkb(out + (int64_t) t * nb + b, &tmp[wave], lane);
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// silu(h[:n]) * h[n:] of one activation row, quantised (gate_quant_kernel's arithmetic)
+__global__ void __launch_bounds__(64) gate_quant_rows_q8k_kernel(const float * h, int64_t h_cs, int n, int nb, xblkb * out) {
+    __shared__ xblk tmp;
+    const int b = blockIdx.x % nb, t = blockIdx.x / nb, lane = threadIdx.x;
+    const int e = b * 256 + lane * 4;
+    const float4 l4 = *(const float4 *) (h + (int64_t) t * h_cs + e), r4 = *(const float4 *) (h + (int64_t) t * h_cs + n + e);
+    const float l[4] = { l4.x, l4.y, l4.z, l4.w }, r[4] = { r4.x, r4.y, r4.z, r4.w };
+    float v[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) v[k] = (l[k] / (1.0f + expf(-l[k]))) * r[k];
+    quantize_block_q8k(&tmp, v, lane);
+    __syncthreads();
+    store_xblkb(out + (int64_t) t * nb + b, &tmp, lane);
+}
+
 #define MMQ_NW 4          // waves per workgroup; tiles of 4 consecutive super-blocks are dealt round-robin to the waves (split K)
 #define MMQ_TSB 4         // super-blocks per tile: 16 rows x 4 x 144 B = 9216 B = 9 coalesced 16-byte loads per lane
 #define MMQ_ROW 608       // LDS bytes per staged row (576 used): 152 dwords = 24 mod 64, so the 16 rows of one ds_read_b64 spread over all banks
@@ -1097,9 +1146,11 @@ static int env_int(const char * name, int def);
 size_t k_mm_q4k_batched_ws_size(int64_t K, int64_t T) { return (size_t) (K / 256) * (size_t) T * sizeof(xblkb); }
 bool k_mm_q4k_batched_supported(int wtype, int64_t K, int64_t M, int64_t T) { return wtype == GGML_TYPE_Q4_K && K % 256 == 0 && T >= 2 && T <= 64 && M >= 16; }
 void k_mm_q4k_batched(hipStream_t s, const char * w, int64_t row_bytes, int64_t K, int64_t M, int64_t T, const float * x, int64_t x_cs,
-                      void * ws, float * y, int64_t y_cs, const float * residual, int64_t r_cs) {
+                      void * ws, float * y, int64_t y_cs, const float * residual, int64_t r_cs, int prologue, const float * alpha, float eps) {
     const int nb = (int) (K / 256);
-    quant_rows_q8k_kernel<<<(int) (T * nb), 64, 0, s>>>(x, x_cs, nb, (xblkb *) ws);
+    if (prologue == MV_RMSNORM) rms_quant_rows_q8k_kernel<<<(int) T, 256, 0, s>>>(x, x_cs, alpha, eps, (int) K, nb, (xblkb *) ws);
+    else if (prologue == MV_GATE_SILU) gate_quant_rows_q8k_kernel<<<(int) (T * nb), 64, 0, s>>>(x, x_cs, (int) K, nb, (xblkb *) ws);
+    else quant_rows_q8k_kernel<<<(int) (T * nb), 64, 0, s>>>(x, x_cs, nb, (xblkb *) ws);
     const int grid = (int) ((M + 15) / 16);
     const int thr = 64 * MMQ_NW;
     for (int64_t c0 = 0; c0 < T; c0 += 32) {   // 32 columns per pass (two MFMA column tiles; four would leave one wave per SIMD)

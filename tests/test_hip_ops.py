@@ -383,3 +383,40 @@ def test_batched_q4k_matmul_int8_mfma(K, M, T):
     def build3(g):     # the gated FFN hands its activation over as [K, 1, T] (gating.h:16-37)
         return [g.mul_mat(g.input_raw(wraw, Q4_K, K, M), g.input(x.reshape(T, 1, K)))]
     gu.compare(build3, atol_rel=2e-6)
+
+
+@pytest.mark.parametrize("K,M,T", [(512, 96, 5), (4096, 8192, 32), (1024, 72, 17)])
+def test_batched_q4k_matmul_rmsnorm_rows_and_residual(K, M, T):
+    # the batched prefill layer shape: y = res + W (rms_norm(x) * alpha) for T rows: the norm runs inside the row quantiser, the add in the epilogue
+    r = np.random.default_rng(K + M + T + 1)
+    x = (r.standard_normal((T, K)) * r.uniform(0.2, 3.0, (T, 1))).astype(np.float32)
+    alpha = (1.0 + 0.1 * r.standard_normal((1, K))).astype(np.float32)
+    res = r.standard_normal((T, M)).astype(np.float32)
+    wraw = gu.random_q4_K(r, M, K)
+
+    def build(g):
+        xn = g.mul(g.rms_norm(g.input(x), 1e-8), g.input(alpha))
+        return [g.add(g.input(res), g.mul_mat(g.input_raw(wraw, Q4_K, K, M), xn))]
+    gu.compare(build, atol_rel=2e-6)
+    _, st = gu.run_graph("hip", build)
+    assert st.kernels_in_last_plan == 1, st.kernels_in_last_plan      # one fused step: row quantiser + mat-mul, nothing else
+
+
+@pytest.mark.parametrize("n,M,T", [(512, 80, 6), (11264, 64, 20)])
+def test_batched_q4k_matmul_gated_rows_and_residual(n, M, T):
+    # linear_out of the gated FFN for T rows (gating.h:16-37): silu(h[:n]) * h[n:] handed over as [n, 1, T], folded back to [M, T] and added
+    r = np.random.default_rng(n + M + T)
+    h = r.standard_normal((T, 2 * n)).astype(np.float32)
+    res = r.standard_normal((T, M)).astype(np.float32)
+    wraw = gu.random_q4_K(r, M, n)
+
+    def build(g):
+        hh = g.input(h)
+        t = hh.contents
+        left = g.view_4d(hh, t.ne[0] // 2, 1, t.ne[1], t.ne[2], t.nb[1] // 2, t.nb[1], t.nb[2], 0)
+        right = g.view_4d(hh, t.ne[0] // 2, 1, t.ne[1], t.ne[2], t.nb[1] // 2, t.nb[1], t.nb[2], t.nb[1] // 2)
+        y = g.mul_mat(g.input_raw(wraw, Q4_K, n, M), g.mul(g.silu(left), right))
+        return [g.add(g.input(res), g.reshape_3d(y, M, T, 1))]
+    gu.compare(build, atol_rel=2e-6)
+    _, st = gu.run_graph("hip", build)
+    assert st.kernels_in_last_plan == 1, st.kernels_in_last_plan
