@@ -63,8 +63,9 @@ def main():
     ap.add_argument("--cpu-frames", type=int, default=1)
     ap.add_argument("--cpu-threads", type=int, default=32, help="OpenMP threads of the CPU baseline (capped by the affinity mask)")
     ap.add_argument("--quant", default="q4_k", choices=["q4_k", "q8_0", "q4_0"], help="linear weight type (the headline metric is q4_k)")
-    ap.add_argument("--model", default="moshika", choices=["moshika", "personaplex"],
-                    help="moshika = BASELINE.json's metric config (default); personaplex = configs[4]: 16 chained Depth steps, run with --context 2000")
+    ap.add_argument("--model", default="moshika", choices=["moshika", "personaplex", "tts_like", "stt_like"],
+                    help="moshika = BASELINE.json's metric config (default); personaplex = configs[4]: 16 chained Depth steps, run with --context 2000; "
+                         "tts_like / stt_like = the shapes of configs[1] / configs[2] (hot.py), extra lines only")
     ap.add_argument("--context", type=int, default=0, help="Temporal ring capacity (-c of the tools); 0 = the config's 3000")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"], help="control-plane backend for N > 1 (nccl = RCCL; gloo for single-GPU dry runs)")
     ap.add_argument("--device", type=int, default=None, help="override the device index (default LOCAL_RANK); only for dry runs of the N > 1 path on one GPU")
@@ -106,10 +107,12 @@ def main():
 
     if args.backend_flags:
         L.ggml_backend_mi355x_set_flags(be, args.backend_flags)
-    cfg = hot.moshika(L) if args.model == "moshika" else hot.personaplex(L)
+    cfg = {"moshika": hot.moshika, "personaplex": hot.personaplex, "tts_like": hot.tts_like, "stt_like": hot.stt_like}[args.model](L)
     if args.context:
         cfg.context = args.context
-    if args.quant != "q4_k":
+    if args.model == "tts_like":
+        args.quant = "q8_0"
+    elif args.quant != "q4_k":
         cfg.linear_type = {"q8_0": 8, "q4_0": 2}[args.quant]   # ggml_type ids
     t0 = time.time()
     m = L.moshi_hot_create(be, C.byref(cfg), 0)
@@ -122,8 +125,31 @@ def main():
     txt = C.c_int32()
     aud = (C.c_int32 * 32)()
 
-    def frame():
-        return L.moshi_hot_sts_frame(m, pcm.ctypes.data, C.byref(txt), aud, out.ctypes.data)
+    if args.model == "tts_like":      # moshi-tts loop (tools/moshi-tts.cpp:757-820): LM step (text from the state machine: here a fixed hook) + Mimi decode
+        rng = np.random.default_rng(1)
+        cond_sum = (rng.standard_normal(cfg.dim) * 0.1).astype(np.float32)
+        cond_cross = rng.standard_normal((cfg.cross_len, cfg.dim)).astype(np.float32)
+        L.moshi_hot_set_conditions(m, cond_sum.ctypes.data, cond_cross.ctypes.data)
+        hook = hot.TEXT_HOOK(lambda user, offset, sampled: int((offset * 13) % cfg.text_card))
+        L.moshi_hot_set_text_hook(m, C.cast(hook, C.c_void_p), None)
+        aud64 = (C.c_int32 * 64)()
+        none_in = (C.c_int32 * 1)()
+
+        def frame():
+            if L.moshi_hot_lm_step_n(m, none_in, 0, C.byref(txt), aud64, None):
+                L.moshi_hot_mimi_decode(m, aud64, out.ctypes.data)
+            return 1
+    elif args.model == "stt_like":    # moshi-stt loop (tools/moshi-stt.cpp:552-719): Mimi encode (32 levels) + LM step with the VAD head
+        codes = (C.c_int32 * 64)()
+        aud64 = (C.c_int32 * 64)()
+        vad = C.c_float()
+
+        def frame():
+            L.moshi_hot_mimi_encode(m, pcm.ctypes.data, codes)
+            return L.moshi_hot_lm_step_n(m, codes, cfg.n_q, C.byref(txt), aud64, C.byref(vad))
+    else:
+        def frame():
+            return L.moshi_hot_sts_frame(m, pcm.ctypes.data, C.byref(txt), aud, out.ctypes.data)
 
     def barrier():
         L.ggml_backend_synchronize(be)
@@ -158,13 +184,16 @@ def main():
     L.ggml_backend_mi355x_get_stats(be, C.byref(st))
 
     result = {
-        "metric": "audio frames/sec (12.5 Hz target) %s-7B %s decode" % (args.model, args.quant),
+        "metric": "audio frames/sec (12.5 Hz target) %s %s decode" % ({"moshika": "moshika-7B", "personaplex": "personaplex-7B", "tts_like": "tts-1.6b-shaped",
+                                                                        "stt_like": "stt-1b-shaped"}[args.model], args.quant),
         "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "q4_K weights x q8_K activations (int8 dot, f32 accumulate); bf16 KV; f32 elsewhere",
         "data": "synthetic",
-        "config": {"workload": "moshi-sts --bench loop: mimi encode + Temporal step + %d Depth steps + mimi decode, "
-                               "%s-7B %s, 1 stream per GPU, greedy, ctx capacity %d" % (cfg.dep_q, args.model, args.quant, cfg.context),
+        "config": {"workload": ({"tts_like": "moshi-tts loop: Temporal step (cross-attention, demux) + %d Depth steps + mimi decode (32 levels), ",
+                                 "stt_like": "moshi-stt loop: mimi encode (32 levels) + Temporal step + VAD head (%d Depth steps), "}
+                                .get(args.model, "moshi-sts --bench loop: mimi encode + Temporal step + %d Depth steps + mimi decode, ") % cfg.dep_q) +
+                               "%s %s, 1 stream per GPU, greedy, ctx capacity %d" % (args.model, args.quant, cfg.context),
                    "context_fill_start": args.context_fill, "parallelism": "independent stream replica per GPU" if world > 1 else "1 GPU",
                    "device": dev_desc},
         "realtime_factor": round(fps / world / 12.5, 1),

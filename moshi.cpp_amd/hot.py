@@ -118,3 +118,42 @@ def tiny_tts(lib, linear_type=12, embed_type=2, layers=2, dep_q=8, cross_len=5):
     cfg.dep_context = 0            # ring capacity = len(schedule) (lm_default.h:86-90)
     cfg.mimi_n_q = dep_q
     return cfg
+
+
+def tts_like(lib):
+    """BASELINE.json configs[1] (moshi-tts tts-1.6b q8_0) at full size. The model's config.json is downloaded, not in the reference repo; widths follow
+    the comments of include/moshi/moshi.h:111-139 (dim 2048, 16 heads, 16 layers, n_q = dep_q = 32, card 2048, text_card 8000, context 500, depformer
+    1024 / 16 heads / 4 layers / feed-forward 3072, low-rank 128, demux, cross-attention); delays, schedule and condition length are placeholders of
+    the right shape. Q8_0 linears and embeddings."""
+    cfg = moshika(lib)
+    cfg.dim, cfg.num_heads, cfg.num_layers, cfg.ffn_hidden, cfg.context = 2048, 16, 16, 5632, 500
+    cfg.text_card, cfg.card, cfg.n_q, cfg.dep_q = 8000, 2048, 32, 32
+    for i in range(MAX_CB):
+        cfg.delays[i] = 0
+    for i in range(2, 33):
+        cfg.delays[i] = 2
+    cfg.dep_dim, cfg.dep_heads, cfg.dep_layers, cfg.dep_ffn_hidden, cfg.dep_context = 1024, 16, 4, 2048, 0
+    cfg.linear_type, cfg.embed_type = 8, 8
+    cfg.demux_second_stream, cfg.depformer_low_rank, cfg.delay_steps = 1, 128, 16
+    cfg.cross_attention, cfg.cross_len, cfg.condition_sum = 1, 64, 1
+    sched = list(range(8)) + [8] * 24
+    cfg.dep_schedule_len = 32
+    for i, v in enumerate(sched):
+        cfg.dep_schedule[i] = v
+    cfg.mimi_n_q = 32
+    cfg.enable_mimi_encoder = 0
+    return cfg
+
+
+def stt_like(lib):
+    """BASELINE.json configs[2] (moshi-stt stt-1b q4_k) at full size, same caveat as tts_like: dim 2048, 16 layers, n_q 32 input codebooks, no Depth
+    transformer, 3 extra heads of width 6 (the third is the VAD head), Mimi encoder with 32 RVQ levels."""
+    cfg = moshika(lib)
+    cfg.dim, cfg.num_heads, cfg.num_layers, cfg.ffn_hidden, cfg.context = 2048, 16, 16, 5632, 750
+    cfg.text_card, cfg.card, cfg.n_q, cfg.dep_q = 8000, 2048, 32, 0
+    for i in range(MAX_CB):
+        cfg.delays[i] = 0
+    cfg.extra_heads, cfg.extra_heads_dim = 3, 6
+    cfg.mimi_n_q = 32
+    cfg.enable_mimi_decoder = 0
+    return cfg
