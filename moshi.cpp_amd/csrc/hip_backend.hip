@@ -862,6 +862,42 @@ static bool match_batched_mm(const analysis & an, int pos, emitter & em, bmm_gro
     return true;
 }
 
+// B'. cross-attention over a cached condition, ending at x2 = cont(permute(mul_mat(cont(transpose(V)), soft_max(mul_mat(K, q)))))
+struct xattn_group { xattn_args a; int emit_pos; std::vector<int> members; };
+static bool match_cross_attention(const analysis & an, int pos, xattn_group & grp) {
+    const ggml_tensor * x2 = an.g->nodes[pos];
+    if (x2->op != GGML_OP_CONT || x2->type != GGML_TYPE_F32 || x2->src[0]->op != GGML_OP_PERMUTE || uses_of(an, x2->src[0]) != 1) return false;
+    const ggml_tensor * x1 = x2->src[0], * pv = x1->src[0];
+    if (pv->op != GGML_OP_MUL_MAT || uses_of(an, pv) != 1) return false;
+    const ggml_tensor * vt = pv->src[0], * sm = pv->src[1];
+    if (vt->op != GGML_OP_CONT || uses_of(an, vt) != 1 || vt->src[0]->op != GGML_OP_TRANSPOSE || uses_of(an, vt->src[0]) != 1) return false;
+    const ggml_tensor * vx = vt->src[0]->src[0];
+    if (sm->op != GGML_OP_SOFT_MAX || uses_of(an, sm) != 1 || sm->src[1] != NULL || ggml_get_op_params_f32(sm, 1) != 0.0f) return false;
+    const ggml_tensor * kq = sm->src[0];
+    if (kq->op != GGML_OP_MUL_MAT || uses_of(an, kq) != 1) return false;
+    const ggml_tensor * kx = kq->src[0], * qp = kq->src[1];
+    if (kx->type != GGML_TYPE_F32 || vx->type != GGML_TYPE_F32 || !kx->data || !vx->data || pos_of(an, kx) >= 0 || pos_of(an, vx) >= 0) return false;   // cached state, not graph values
+    const int64_t D = kx->ne[0], Tc = kx->ne[1], H = kx->ne[2];
+    if (vx->ne[0] != D || vx->ne[1] != Tc || vx->ne[2] != H || kx->ne[3] != 1 || kx->nb[0] != 4 || vx->nb[0] != 4) return false;
+    // q: [D, 1, H] permuted view of a dense [D * H] vector
+    if (qp->ne[0] != D || qp->ne[1] != 1 || qp->ne[2] != H || qp->ne[3] != 1 || qp->type != GGML_TYPE_F32 || qp->nb[0] != 4 || (int64_t) qp->nb[2] != D * 4) return false;
+    const ggml_tensor * qsrc = qp;
+    while (is_view_op(qsrc->op) && qsrc->op != GGML_OP_NONE && qsrc->src[0]) { if (uses_of(an, qsrc) != 1) return false; qsrc = qsrc->src[0]; }
+    if (!is_f32_vec(qsrc, D * H) || qsrc->data != qp->data) return false;
+    if (x2->ne[0] != D || x2->ne[1] != H || ggml_nelements(x2) != D * H || !ggml_is_contiguous(x2)) return false;
+    xattn_args & a = grp.a;
+    a.q = (const float *) qp->data;
+    a.k = (const char *) kx->data; a.v = (const char *) vx->data;
+    a.k_nb1 = (int64_t) kx->nb[1]; a.k_nb2 = (int64_t) kx->nb[2]; a.v_nb1 = (int64_t) vx->nb[1]; a.v_nb2 = (int64_t) vx->nb[2];
+    a.H = (int) H; a.D = (int) D; a.Tc = (int) Tc;
+    a.scale = ggml_get_op_params_f32(sm, 0);
+    a.out = (float *) x2->data;
+    grp.members = { pos, pos_of(an, pv), pos_of(an, vt), pos_of(an, sm), pos_of(an, kq) };
+    for (int m : grp.members) if (m < 0) return false;
+    grp.emit_pos = pos;
+    return true;
+}
+
 // C. left-deep sum of (scaled) embedding rows ending at node `pos`
 struct embed_group { embed_sum_args a; std::vector<int> members; };
 
@@ -1322,6 +1358,20 @@ static plan_t * build_plan(hip_ctx * c, ggml_cgraph * g) {
             for (int m : grp.members) an.skip[(size_t) m] = 1;
             for (auto & f : grp.steps) at_pos[grp.emit_pos].push_back(f);
             p->n_fused += (int) grp.members.size();
+        }
+        // cross-attention over cached conditions (tts)
+        static const bool no_xattn = getenv("MI355X_NO_CROSS_ATTN_FUSION") != nullptr;
+        for (int i = 0; i < g->n_nodes && !no_xattn; i++) {
+            if (an.skip[(size_t) i] || g->nodes[i]->op != GGML_OP_CONT) continue;
+            xattn_group xg;
+            if (!match_cross_attention(an, i, xg)) continue;
+            bool clash = false;
+            for (int m : xg.members) if (an.skip[(size_t) m]) clash = true;
+            if (clash) continue;
+            for (int m : xg.members) an.skip[(size_t) m] = 1;
+            const xattn_args xa = xg.a;
+            at_pos[xg.emit_pos].push_back([=](hipStream_t s) { k_cross_attn(s, xa); });
+            p->n_fused += (int) xg.members.size();
         }
         // embedding sums
         for (int i = g->n_nodes - 1; i >= 0; i--) {

@@ -149,6 +149,11 @@ struct attn_args {
 size_t k_attn_decode_ws_size(const attn_args & a);
 void k_attn_decode(hipStream_t s, const attn_args & a, void * ws = nullptr, unsigned * err = nullptr);   // *err <- 1 if a head-wide wait timed out
 
+// single-token cross-attention over cached F32 K / V [D, Tc, H] without a mask (moshi_streaming_multihead_cross_attention,
+// transformer.h:714-762): scores = K q (float products, double sums), soft_max(scale * s), out = sum_t p_t V_t; one workgroup per head
+struct xattn_args { const float * q; const char * k; const char * v; int64_t k_nb1, k_nb2, v_nb1, v_nb2; int H, D, Tc; float scale; float * out; };
+void k_cross_attn(hipStream_t s, const xattn_args & a);
+
 // sum of (scaled) embedding rows, left-to-right
 #define EMBED_SUM_MAX 24
 struct embed_sum_args { embed_src src[EMBED_SUM_MAX]; int n; int64_t K; float * out; };

@@ -1668,6 +1668,55 @@ void k_attn_decode(hipStream_t s, const attn_args & a, void * ws, unsigned * err
 }
 
 // ---------------------------------------------------------------------------------------------------
+// cross-attention over the cached condition (tts): the node sequence mul_mat(K, q) -> soft_max_ext(scale, no mask) ->
+// mul_mat(cont(transpose(V)), p) -> cont(permute) with the per-op kernels' arithmetic (float products summed in double, expf of
+// scale * s - max, probabilities scaled by float(1 / sum)), without materialising the transposed V every frame
+// ---------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) cross_attn_kernel(xattn_args a) {
+    extern __shared__ float xsm[];          // [D] q | [Tc] scores -> probabilities
+    __shared__ float sh_f[4];
+    __shared__ double sh_d[4];
+    const int h = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int D = a.D, Tc = a.Tc;
+    float * qs = xsm, * sc = xsm + D;
+    for (int d = tid; d < D; d += 256) qs[d] = a.q[(int64_t) h * D + d];
+    __syncthreads();
+    const char * kh = a.k + (int64_t) h * a.k_nb2, * vh = a.v + (int64_t) h * a.v_nb2;
+    for (int t = wave; t < Tc; t += 4) {
+        const float * kr = (const float *) (kh + (int64_t) t * a.k_nb1);
+        double acc = 0;
+        for (int d = lane; d < D; d += 64) acc += (double) (kr[d] * qs[d]);
+        acc = wave_allsum_f64(acc);
+        if (lane == 0) sc[t] = (float) acc;
+    }
+    __syncthreads();
+    float mx = -INFINITY;
+    for (int t = tid; t < Tc; t += 256) mx = fmaxf(mx, sc[t] * a.scale);
+    mx = wave_allmax_f32(mx);
+    if (lane == 0) sh_f[wave] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(sh_f[0], sh_f[1]), fmaxf(sh_f[2], sh_f[3]));
+    double sum = 0;
+    for (int t = tid; t < Tc; t += 256) { const float e = expf(sc[t] * a.scale - mx); sc[t] = e; sum += (double) e; }
+    sum = wave_allsum_f64(sum);
+    if (lane == 0) sh_d[wave] = sum;
+    __syncthreads();
+    const float inv = (float) (1.0 / (sh_d[0] + sh_d[1] + sh_d[2] + sh_d[3]));
+    for (int t = tid; t < Tc; t += 256) sc[t] *= inv;
+    __syncthreads();
+    for (int d = tid; d < D; d += 256) {
+        double acc = 0;
+        for (int t = 0; t < Tc; t++) acc += (double) (*(const float *) (vh + (int64_t) t * a.v_nb1 + (int64_t) d * 4) * sc[t]);
+        a.out[(int64_t) h * D + d] = (float) acc;
+    }
+}
+void k_cross_attn(hipStream_t s, const xattn_args & a) {
+    const size_t smem = (size_t) (a.D + a.Tc) * 4;
+    GGML_ASSERT(smem <= 64 * 1024);
+    cross_attn_kernel<<<a.H, 256, smem, s>>>(a);
+}
+
+// ---------------------------------------------------------------------------------------------------
 // embedding sum: out = (((e_0 + e_1) + e_2) + ...), e_i = dequant(table_i[row idx_i]) * scale_i
 // (src/moshi/models/lm.h:555-584, lm_utils.h:157-170); same left-to-right float order as the graph
 // ---------------------------------------------------------------------------------------------------
