@@ -93,6 +93,8 @@ GGML_API void moshi_hot_prefill(moshi_hot_model_t * m, const int32_t * tokens, i
 GGML_API const int32_t * moshi_hot_personaplex_prompt_tokens(void);
 // moshi_lmgen_step_system_prompts without a voice (lm.h:1118-1134): 6 silence frames, the text prompt, 6 silence frames
 GGML_API void moshi_hot_personaplex_system_prompts(moshi_hot_model_t * m, const int32_t * text_prompt, int n_text);
+// the same 12 + n_text prompt frames as batched passes (moshi_hot_prefill): same state afterwards
+GGML_API void moshi_hot_personaplex_system_prompts_batched(moshi_hot_model_t * m, const int32_t * text_prompt, int n_text, int chunk);
 // one iteration of the moshi-sts --bench loop (tools/moshi-sts.cpp:770-808); returns 1 when a frame was produced
 GGML_API int moshi_hot_sts_frame(moshi_hot_model_t * m, const float * pcm_in, int32_t * text_token, int32_t * audio_tokens, float * pcm_out);
 

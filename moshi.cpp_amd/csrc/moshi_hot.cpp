@@ -1241,6 +1241,17 @@ extern "C" void moshi_hot_prefill(moshi_hot_model_t * m, const int32_t * tokens,
 static const int32_t PERSONAPLEX_PROMPT_TOKENS[17] = { 3, 948, 243, 1178, 546, 1736, 1030, 1978, 2008, 430, 1268, 381, 1611, 1095, 1495, 56, 472 };
 extern "C" const int32_t * moshi_hot_personaplex_prompt_tokens(void) { return PERSONAPLEX_PROMPT_TOKENS; }
 
+// the same prompt frames through moshi_hot_prefill: identical state afterwards, a fraction of the time
+extern "C" void moshi_hot_personaplex_system_prompts_batched(moshi_hot_model_t * m, const int32_t * text_prompt, int n_text, int chunk) {
+    GGML_ASSERT(m->cfg.n_q + 1 == 17);
+    std::vector<int32_t> frames((size_t) (12 + n_text) * 17);
+    for (int f = 0; f < 12 + n_text; f++) {
+        memcpy(&frames[(size_t) f * 17], PERSONAPLEX_PROMPT_TOKENS, sizeof(PERSONAPLEX_PROMPT_TOKENS));
+        if (f >= 6 && f < 6 + n_text) frames[(size_t) f * 17] = text_prompt[f - 6];
+    }
+    moshi_hot_prefill(m, frames.data(), 12 + n_text, chunk);
+}
+
 extern "C" void moshi_hot_personaplex_system_prompts(moshi_hot_model_t * m, const int32_t * text_prompt, int n_text) {
     GGML_ASSERT(m->cfg.n_q + 1 == 17);
     int32_t tokens[17], text, audio[MOSHI_HOT_MAX_CODEBOOKS];

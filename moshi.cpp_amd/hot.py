@@ -34,6 +34,7 @@ SIGNATURES = {
     "moshi_hot_set_text_hook": (None, [P, P, P]),
     "moshi_hot_personaplex_prompt_tokens": (C.POINTER(C.c_int32), []),
     "moshi_hot_personaplex_system_prompts": (None, [P, P, C.c_int]),
+    "moshi_hot_personaplex_system_prompts_batched": (None, [P, P, C.c_int, C.c_int]),
     "moshi_hot_create": (P, [P, C.POINTER(Config), C.c_uint64]),
     "moshi_hot_free": (None, [P]),
     "moshi_hot_mimi_encode": (None, [P, P, P]),

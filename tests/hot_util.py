@@ -68,9 +68,12 @@ class Model:
         flat = np.ascontiguousarray(np.array(frames, np.int32).reshape(-1))
         L.moshi_hot_prefill(self.m, flat.ctypes.data, len(frames), chunk)
 
-    def system_prompts(self, text_prompt):
+    def system_prompts(self, text_prompt, batched=False, chunk=0):
         tp = (C.c_int32 * max(1, len(text_prompt)))(*text_prompt)
-        L.moshi_hot_personaplex_system_prompts(self.m, tp, len(text_prompt))
+        if batched:
+            L.moshi_hot_personaplex_system_prompts_batched(self.m, tp, len(text_prompt), chunk)
+        else:
+            L.moshi_hot_personaplex_system_prompts(self.m, tp, len(text_prompt))
 
     def last_raw(self):
         txt = C.c_int32()

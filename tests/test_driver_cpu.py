@@ -427,3 +427,17 @@ def test_batched_prefill_falls_back_to_single_frames_at_the_ring_wrap():
         assert a.lm_step(ia) == b.lm_step(ia)
         assert np.array_equal(a.read("text_logits", cfg.text_card), b.read("text_logits", cfg.text_card))
     a.free(); b.free()
+
+
+def test_personaplex_system_prompts_batched_equals_frame_by_frame():
+    cfg = hu.hot.tiny_personaplex(hu.L, layers=2)
+    cfg.enable_mimi_encoder = cfg.enable_mimi_decoder = 0
+    a, b = hu.Model("oracle", cfg), hu.Model("oracle", cfg)
+    a.system_prompts([21, 22, 23, 24, 25])
+    b.system_prompts([21, 22, 23, 24, 25], batched=True, chunk=8)
+    assert hu.L.moshi_hot_offset(a.m) == hu.L.moshi_hot_offset(b.m) == 17
+    for i in range(3):
+        ia = list(range(i, i + 8))
+        assert a.lm_step(ia) == b.lm_step(ia) and a.last_raw() == b.last_raw()
+        assert np.array_equal(a.read("text_logits", cfg.text_card), b.read("text_logits", cfg.text_card))
+    a.free(); b.free()
