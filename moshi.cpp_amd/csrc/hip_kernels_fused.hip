@@ -1682,12 +1682,21 @@ __global__ void __launch_bounds__(256) cross_attn_kernel(xattn_args a) {
     for (int d = tid; d < D; d += 256) qs[d] = a.q[(int64_t) h * D + d];
     __syncthreads();
     const char * kh = a.k + (int64_t) h * a.k_nb2, * vh = a.v + (int64_t) h * a.v_nb2;
-    for (int t = wave; t < Tc; t += 4) {
-        const float * kr = (const float *) (kh + (int64_t) t * a.k_nb1);
-        double acc = 0;
-        for (int d = lane; d < D; d += 64) acc += (double) (kr[d] * qs[d]);
-        acc = wave_allsum_f64(acc);
-        if (lane == 0) sc[t] = (float) acc;
+    // scores: a wave takes four condition rows at a time so that their loads travel together (one round trip per four rows, not per row)
+    for (int t0 = wave * 4; t0 < Tc; t0 += 16) {
+        double acc[4] = { 0, 0, 0, 0 };
+        for (int d = lane; d < D; d += 64) {
+            float kv[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) kv[u] = *(const float *) (kh + (int64_t) (t0 + u < Tc ? t0 + u : Tc - 1) * a.k_nb1 + (int64_t) d * 4);
+#pragma unroll
+            for (int u = 0; u < 4; u++) acc[u] += (double) (kv[u] * qs[d]);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const double r = wave_allsum_f64(acc[u]);
+            if (lane == 0 && t0 + u < Tc) sc[t0 + u] = (float) r;
+        }
     }
     __syncthreads();
     float mx = -INFINITY;
@@ -1704,14 +1713,33 @@ __global__ void __launch_bounds__(256) cross_attn_kernel(xattn_args a) {
     const float inv = (float) (1.0 / (sh_d[0] + sh_d[1] + sh_d[2] + sh_d[3]));
     for (int t = tid; t < Tc; t += 256) sc[t] *= inv;
     __syncthreads();
-    for (int d = tid; d < D; d += 256) {
+    // out[d] = sum_t p_t V[d, t] in t order; the Tc rows are split over the 256 / D thread groups (partials through LDS), eight loads in flight
+    {
+        const int G = 256 / D > 0 ? 256 / D : 1, grp = tid / D, d = tid - grp * D;
         double acc = 0;
-        for (int t = 0; t < Tc; t++) acc += (double) (*(const float *) (vh + (int64_t) t * a.v_nb1 + (int64_t) d * 4) * sc[t]);
-        a.out[(int64_t) h * D + d] = (float) acc;
+        if (grp < G) {
+            const int per = (Tc + G - 1) / G, tb = grp * per, te = tb + per < Tc ? tb + per : Tc;
+            for (int t = tb; t < te; t += 8) {
+                float vv[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) vv[u] = *(const float *) (vh + (int64_t) (t + u < te ? t + u : te - 1) * a.v_nb1 + (int64_t) d * 4);
+#pragma unroll
+                for (int u = 0; u < 8; u++) if (t + u < te) acc += (double) (vv[u] * sc[t + u]);
+            }
+        }
+        double * part = (double *) (xsm + ((D + Tc + 1) & ~1));   // [G][D]
+        if (grp < G) part[grp * D + d] = acc;
+        __syncthreads();
+        if (tid < D) {
+            double tot = 0;
+            for (int gi = 0; gi < G; gi++) tot += part[gi * D + tid];
+            a.out[(int64_t) h * D + tid] = (float) tot;
+        }
     }
 }
 void k_cross_attn(hipStream_t s, const xattn_args & a) {
-    const size_t smem = (size_t) (a.D + a.Tc) * 4;
+    GGML_ASSERT(a.D <= 256);
+    const size_t smem = (size_t) ((a.D + a.Tc + 1) & ~1) * 4 + (size_t) (256 / a.D > 0 ? 256 / a.D : 1) * a.D * 8;
     GGML_ASSERT(smem <= 64 * 1024);
     cross_attn_kernel<<<a.H, 256, smem, s>>>(a);
 }
