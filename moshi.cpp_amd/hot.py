@@ -112,7 +112,7 @@ def tiny_tts(lib, linear_type=12, embed_type=2, layers=2, dep_q=8, cross_len=5):
     cfg.card = 64
     cfg.demux_second_stream, cfg.depformer_low_rank, cfg.delay_steps = 1, 128, 2
     cfg.cross_attention, cfg.cross_len, cfg.condition_sum = 1, cross_len, 1
-    sched = [0, 1, 2, 3, 3, 3, 4, 4][:dep_q]
+    sched = ([0, 1, 2, 3, 3, 3, 4, 4] + [5] * MAX_CB)[:dep_q]
     cfg.dep_schedule_len = len(sched)
     for i, v in enumerate(sched):
         cfg.dep_schedule[i] = v

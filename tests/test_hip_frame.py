@@ -483,3 +483,25 @@ def test_batched_prefill_on_the_device_matches_frame_by_frame_oracle(lt):
     # differently, so quantised types may still part by a flip
     dd = [hu.rel_err(a[3], b[3]) for a, b in zip(rec["hip-frames"], rec["hip"])]
     assert np.median(dd) < (1e-5 if lt == F32 else 1e-2), f"device prefill vs device frame-by-frame: {dd}"
+
+
+def test_tts_depth_at_real_width_ring_of_32():
+    # the tts Depth transformer: 1024 wide (16 heads x 64), 32 chained steps over a ring of 32 = len(schedule) (lm_default.h:86-90); rings
+    # longer than 8 slots keep the stand-alone attention kernel (recomputing 32 slots in every out_proj workgroup measured no faster)
+    cfg = hu.hot.tiny_tts(hu.L, linear_type=F32, dep_q=32)
+    cfg.dep_dim, cfg.dep_heads, cfg.dep_layers, cfg.dep_ffn_hidden = 1024, 16, 2, 2816
+    cfg.linear_type = Q8_0
+    cfg.enable_mimi_encoder = cfg.enable_mimi_decoder = 0
+    steps = 6
+    ref, _ = run_tts("oracle", cfg, steps)
+    runs = {}
+    for name, flags in (("fused", 0), ("per-node", 1 | 2 | 4)):
+        got, st = run_tts("hip", cfg, steps, flags=flags, forced=ref)
+        runs[name] = got
+        for i, (a, b) in enumerate(zip(ref, got)):
+            if a[4] is not None:
+                compare_frame(cfg, (a[1], a[2], a[4]), (b[1], b[2], b[4]), 5e-2, 0.2, f"{name} step {i}")
+    # the two device plans against each other, with the same rule: equal picks, or near-ties, along the 32-step chain
+    for i, (a, b) in enumerate(zip(runs["per-node"], runs["fused"])):
+        if a[4] is not None:
+            compare_frame(cfg, (a[1], a[2], a[4]), (b[1], b[2], b[4]), 5e-2, 0.2, f"fused vs per-node step {i}")
