@@ -129,3 +129,39 @@ def set_text_hook(m, fn):
     """fn(offset, sampled) -> text token; keeps the ctypes thunk alive on the model"""
     m._hook = hot.TEXT_HOOK(lambda user, offset, sampled: fn(offset, sampled))
     L.moshi_hot_set_text_hook(m.m, C.cast(m._hook, C.c_void_p), None)
+
+
+# ---- the .mimi container of tools/mimi-encode.cpp:171-195 / mimi-decode.cpp:139-187: "MIMI", int32 n_q, then frames of n_q int16 codes ----
+def write_mimi(path, frames):
+    import struct
+    n_q = len(frames[0])
+    with open(path, "wb") as f:
+        f.write(b"MIMI")
+        f.write(struct.pack("<i", n_q))
+        for fr in frames:
+            assert len(fr) == n_q
+            f.write(np.asarray(fr, np.int16).tobytes())
+
+
+def read_mimi(path):
+    import struct
+    with open(path, "rb") as f:
+        if f.read(4) != b"MIMI":
+            raise ValueError("invalid mimi input file")
+        (n_q,) = struct.unpack("<i", f.read(4))
+        if n_q < 1 or n_q > 32:
+            raise ValueError("n_q in mimi file out of range %d" % n_q)
+        data = f.read()
+        raw = np.frombuffer(data[:len(data) // 2 * 2], np.int16)
+    n = raw.size // n_q                      # a trailing partial frame is dropped, as fread(..., n_q*2, 1, f) == 1 does
+    return n_q, raw[:n * n_q].reshape(n, n_q).astype(np.int32)
+
+
+def decode_mimi_file(kind, path, cfg_fn):
+    """the main loop of tools/mimi-decode.cpp:186-196: one mimi_decode per frame of codes"""
+    n_q, frames = read_mimi(path)
+    cfg = cfg_fn(n_q)
+    m = Model(kind, cfg)
+    pcm = [m.mimi_decode(fr.tolist()) for fr in frames]
+    m.free()
+    return n_q, np.concatenate(pcm) if pcm else np.zeros(0, np.float32)

@@ -441,3 +441,37 @@ def test_personaplex_system_prompts_batched_equals_frame_by_frame():
         assert a.lm_step(ia) == b.lm_step(ia) and a.last_raw() == b.last_raw()
         assert np.array_equal(a.read("text_logits", cfg.text_card), b.read("text_logits", cfg.text_card))
     a.free(); b.free()
+
+
+# ---- BASELINE.json configs[0]: mimi-decode on a 1-second .mimi file (12.5 frames of codes), CPU -------------------------------------------
+def mimi_decoder_cfg(n_q):
+    cfg = hu.hot.moshika(hu.L)                     # the real codec: 2048-entry codebooks, SEANet + 8-layer transformer
+    cfg.enable_lm = cfg.enable_mimi_encoder = 0
+    cfg.mimi_n_q = n_q                             # mimi_alloc(..., n_q) sizes rvq_rest to n_q - 1 levels (lm_default.h:229-241)
+    return cfg
+
+
+@pytest.mark.parametrize("n_q", [1, 8, 32])
+def test_mimi_file_one_second_decodes_on_the_cpu_device(tmp_path, n_q):
+    rng = np.random.default_rng(n_q)
+    frames = rng.integers(0, 2048, (13, n_q)).tolist()
+    path = str(tmp_path / "one_second.mimi")
+    hu.write_mimi(path, frames)
+    with open(path, "ab") as f:
+        f.write(b"\x01")                           # a ragged tail (less than one frame) is ignored, like the tool's fread loop
+    got_q, codes = hu.read_mimi(path)
+    assert got_q == n_q and codes.tolist() == frames
+    _, pcm = hu.decode_mimi_file("oracle", path, mimi_decoder_cfg)
+    assert pcm.size == 13 * 1920 and np.isfinite(pcm).all() and np.abs(pcm).max() > 0      # 13 frames x 80 ms at 24 kHz
+    _, again = hu.decode_mimi_file("oracle", path, mimi_decoder_cfg)
+    assert np.array_equal(pcm, again)
+
+
+def test_mimi_file_rejects_bad_headers(tmp_path):
+    p = str(tmp_path / "bad.mimi")
+    open(p, "wb").write(b"MIMO" + b"\x08\x00\x00\x00")
+    with pytest.raises(ValueError):
+        hu.read_mimi(p)
+    open(p, "wb").write(b"MIMI" + b"\x21\x00\x00\x00")     # n_q = 33 > 32 (tools/mimi-decode.cpp:146-149)
+    with pytest.raises(ValueError):
+        hu.read_mimi(p)

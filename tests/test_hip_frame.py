@@ -505,3 +505,17 @@ def test_tts_depth_at_real_width_ring_of_32():
     for i, (a, b) in enumerate(zip(runs["per-node"], runs["fused"])):
         if a[4] is not None:
             compare_frame(cfg, (a[1], a[2], a[4]), (b[1], b[2], b[4]), 5e-2, 0.2, f"fused vs per-node step {i}")
+
+
+@pytest.mark.parametrize("n_q", [8, 32])
+def test_mimi_file_decode_matches_oracle(tmp_path, n_q):
+    # BASELINE.json configs[0] on the device: a 1-second .mimi file (13 frames of n_q codes) through the real codec, against the CPU device
+    import test_driver_cpu as tdc
+    rng = np.random.default_rng(n_q)
+    path = str(tmp_path / "one_second.mimi")
+    hu.write_mimi(path, rng.integers(0, 2048, (13, n_q)).tolist())
+    _, ref = hu.decode_mimi_file("oracle", path, tdc.mimi_decoder_cfg)
+    _, got = hu.decode_mimi_file("hip", path, tdc.mimi_decoder_cfg)
+    for i in range(13):
+        a, b = ref[i * 1920:(i + 1) * 1920], got[i * 1920:(i + 1) * 1920]
+        assert hu.rel_err(a, b) < PCM_TOL, f"frame {i}: pcm rel err {hu.rel_err(a, b):.2e}"
