@@ -475,3 +475,24 @@ def test_mimi_file_rejects_bad_headers(tmp_path):
     open(p, "wb").write(b"MIMI" + b"\x21\x00\x00\x00")     # n_q = 33 > 32 (tools/mimi-decode.cpp:146-149)
     with pytest.raises(ValueError):
         hu.read_mimi(p)
+
+
+def test_batched_prefill_edge_cases_zero_one_and_chunk_one():
+    cfg = hu.hot.tiny(hu.L, layers=1)
+    cfg.enable_mimi_encoder = cfg.enable_mimi_decoder = 0
+    rng = np.random.default_rng(5)
+    frames = [[int(rng.integers(0, cfg.text_card))] + rng.integers(0, cfg.card, cfg.n_q).tolist() for _ in range(5)]
+    ref = hu.Model("oracle", cfg)
+    for f in frames:
+        ref.lm_step_n(f)
+    want = ref.lm_step([1] * (cfg.n_q - cfg.dep_q))
+    for split in ([0, 5], [1, 4], [5, 0], [2, 1, 2]):          # empty calls, single frames (stepped one by one), mixed
+        m = hu.Model("oracle", cfg)
+        at = 0
+        for n in split:
+            m.prefill(frames[at:at + n], 1 if n == 1 else 0) if n else hu.L.moshi_hot_prefill(m.m, None, 0, 0)
+            at += n
+        assert hu.L.moshi_hot_offset(m.m) == 5
+        assert m.lm_step([1] * (cfg.n_q - cfg.dep_q)) == want, split
+        m.free()
+    ref.free()
