@@ -18,6 +18,9 @@ extern "C" {
 GGML_API ggml_backend_t ggml_backend_cpu_init(void);
 GGML_API bool ggml_backend_is_cpu(ggml_backend_t backend);
 GGML_API void ggml_backend_cpu_set_n_threads(ggml_backend_t backend_cpu, int n_threads);
+// graph evaluation in host memory without a backend (tensors of a no_alloc = false context): only the replay tool uses it
+// (src/replay.h:321, 375). Runs the host device's executor: load-time graphs, or whatever ggml_backend_cpu_set_graph_compute attached.
+GGML_API enum ggml_status ggml_graph_compute_with_ctx(struct ggml_context * ctx, struct ggml_cgraph * cgraph, int n_threads);
 GGML_API ggml_backend_reg_t ggml_backend_cpu_reg(void);
 
 // Attach / detach an external CPU graph executor (NULL detaches). Without one,

@@ -227,6 +227,10 @@ GGML_API enum ggml_unary_op ggml_get_unary_op(const struct ggml_tensor * tensor)
 GGML_API struct ggml_tensor * ggml_dup (struct ggml_context * ctx, struct ggml_tensor * a);
 GGML_API struct ggml_tensor * ggml_add (struct ggml_context * ctx, struct ggml_tensor * a, struct ggml_tensor * b);          // transformer.h:934
 GGML_API struct ggml_tensor * ggml_add_inplace(struct ggml_context * ctx, struct ggml_tensor * a, struct ggml_tensor * b);   // conv.h:290
+// in-place variants the reference only reaches through its capture / replay tooling (src/replay_ops.h:293-308, CLASS_OP_INPLACE)
+GGML_API struct ggml_tensor * ggml_sub_inplace(struct ggml_context * ctx, struct ggml_tensor * a, struct ggml_tensor * b);
+GGML_API struct ggml_tensor * ggml_mul_inplace(struct ggml_context * ctx, struct ggml_tensor * a, struct ggml_tensor * b);
+GGML_API struct ggml_tensor * ggml_div_inplace(struct ggml_context * ctx, struct ggml_tensor * a, struct ggml_tensor * b);
 GGML_API struct ggml_tensor * ggml_sub (struct ggml_context * ctx, struct ggml_tensor * a, struct ggml_tensor * b);          // rope.h:104
 GGML_API struct ggml_tensor * ggml_mul (struct ggml_context * ctx, struct ggml_tensor * a, struct ggml_tensor * b);          // transformer.h:22
 GGML_API struct ggml_tensor * ggml_div (struct ggml_context * ctx, struct ggml_tensor * a, struct ggml_tensor * b);          // sampling.h:13

@@ -91,6 +91,7 @@ SIGNATURES = {
     "ggml_set_input": (None, [TP]), "ggml_set_output": (None, [TP]), "ggml_get_unary_op": (I, [TP]),
     # op builders
     "ggml_dup": (TP, [P, TP]), "ggml_add": (TP, [P, TP, TP]), "ggml_add_inplace": (TP, [P, TP, TP]), "ggml_sub": (TP, [P, TP, TP]),
+    "ggml_sub_inplace": (TP, [P, TP, TP]), "ggml_mul_inplace": (TP, [P, TP, TP]), "ggml_div_inplace": (TP, [P, TP, TP]),
     "ggml_mul": (TP, [P, TP, TP]), "ggml_div": (TP, [P, TP, TP]), "ggml_neg": (TP, [P, TP]),
     "ggml_scale": (TP, [P, TP, F]), "ggml_scale_inplace": (TP, [P, TP, F]), "ggml_clamp": (TP, [P, TP, F, F]),
     "ggml_sum": (TP, [P, TP]), "ggml_sum_rows": (TP, [P, TP]), "ggml_argmax": (TP, [P, TP]),
@@ -136,6 +137,7 @@ SIGNATURES = {
     "ggml_backend_mi355x_get_kernel_profile": (None, [P, C.POINTER(KernelProfile)]),
     # ggml-cpu.h
     "ggml_backend_cpu_init": (P, []), "ggml_backend_is_cpu": (B, [P]), "ggml_backend_cpu_set_n_threads": (None, [P, I]),
+    "ggml_graph_compute_with_ctx": (I, [P, P, I]),
     "ggml_backend_cpu_reg": (P, []), "ggml_backend_cpu_set_graph_compute": (None, [P]),
     # gguf.h
     "gguf_init_empty": (P, []), "gguf_init_from_file": (P, [S, GGUFInitParams]), "gguf_free": (None, [P]),

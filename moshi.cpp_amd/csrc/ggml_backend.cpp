@@ -278,6 +278,12 @@ static enum ggml_status cpu_graph_compute(ggml_backend_t b, struct ggml_cgraph *
     return g_cpu_compute(g, ((cpu_backend_ctx *) b->context)->n_threads);
 }
 static bool cpu_supports_op(ggml_backend_t, const struct ggml_tensor *) { return g_cpu_compute != NULL; }
+extern "C" enum ggml_status ggml_graph_compute_with_ctx(struct ggml_context *, struct ggml_cgraph * g, int n_threads) {
+    if (g_cpu_compute) return g_cpu_compute(g, n_threads);
+    if (load_time_graph(g)) { for (int i = 0; i < g->n_nodes; i++) host_load_time_node(g->nodes[i]); return GGML_STATUS_SUCCESS; }
+    fprintf(stderr, "ggml (mi355x build): ggml_graph_compute_with_ctx needs a host executor (ggml_backend_cpu_set_graph_compute); the decode hot path runs on the MI355X device only.\n");
+    return GGML_STATUS_FAILED;
+}
 
 static const char * cpu_dev_name(ggml_backend_dev_t) { return "CPU"; }
 static const char * cpu_dev_desc(ggml_backend_dev_t) { return "host memory device"; }

@@ -416,6 +416,9 @@ static T binary_impl(CTX, enum ggml_op op, T a, T b, bool inplace) {
 extern "C" T ggml_add(CTX, T a, T b) { return binary_impl(ctx, GGML_OP_ADD, a, b, false); }
 extern "C" T ggml_add_inplace(CTX, T a, T b) { return binary_impl(ctx, GGML_OP_ADD, a, b, true); }
 extern "C" T ggml_sub(CTX, T a, T b) { return binary_impl(ctx, GGML_OP_SUB, a, b, false); }
+extern "C" T ggml_sub_inplace(CTX, T a, T b) { return binary_impl(ctx, GGML_OP_SUB, a, b, true); }
+extern "C" T ggml_mul_inplace(CTX, T a, T b) { return binary_impl(ctx, GGML_OP_MUL, a, b, true); }
+extern "C" T ggml_div_inplace(CTX, T a, T b) { return binary_impl(ctx, GGML_OP_DIV, a, b, true); }
 extern "C" T ggml_mul(CTX, T a, T b) { return binary_impl(ctx, GGML_OP_MUL, a, b, false); }
 extern "C" T ggml_div(CTX, T a, T b) { return binary_impl(ctx, GGML_OP_DIV, a, b, false); }
 
