@@ -1423,7 +1423,7 @@ static plan_t * build_plan(hip_ctx * c, ggml_cgraph * g) {
                     for (int j = pos_of(an, am) + 1; j < g->n_nodes; j++)
                         if (g->nodes[j]->op == GGML_OP_CPY && g->nodes[j]->src[0] == am && g->nodes[j]->type == GGML_TYPE_I32 && ggml_nelements(g->nodes[j]) == 1) { cp = g->nodes[j]; break; }
                     if (cp && !an.skip[(size_t) pos_of(an, cp)]) { a.argmax_out[1] = (int32_t *) cp->data; an.skip[(size_t) pos_of(an, cp)] = 1; }
-                    unsigned * tk = (unsigned *) em.ws(256);
+                    unsigned * tk = (unsigned *) em.ws(256 + 2 * 4 * 8192);   // arrival counter | per-workgroup argmax candidates (value, index)
                     HIP_CHECK(hipMemset(tk, 0, 256));
                     a.ticket = tk;
                     p->n_fused += 1 + (cp ? 1 : 0);

@@ -147,11 +147,20 @@ __device__ __forceinline__ void lds_barrier() {
 // ---- cross-workgroup hand-off without cache-wide fences -------------------------------------------------------------
 // An agent-scope release/acquire fence writes back / invalidates the whole 4 MB L2 of the XCD, which costs many microseconds in
 // the middle of a weight stream. Handed-off values are instead written and read with agent-coherent (sc1) accesses, which go
-// past the non-coherent caches; the producer drains them (workgroup-scope release = s_waitcnt vmcnt(0)) before it bumps the
-// counter (MI355X_MICROARCH.md "Correctness boundaries", second form).
+// past the non-coherent caches (MI355X_MICROARCH.md "Correctness boundaries", second form). The data itself is published with
+// xchg_agent_wait below, not st_agent: see the note there.
 template <typename V> __device__ __forceinline__ void st_agent(V * p, V v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 template <typename V> __device__ __forceinline__ V ld_agent(const V * p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void drain_stores() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); }
+// Cross-workgroup hand-offs publish their data with RETURNING agent-scope exchanges: such an exchange is complete at the device's coherence
+// point when its old value is back, and consuming that value (the empty asm) makes the compiler emit the returning form and wait for it.
+// A plain agent-scope store followed by drain_stores() and the counter increment is NOT enough: the store is acknowledged by this XCD's L2,
+// and about once per 1e5 hand-offs a consumer on another XCD saw the counter before the data (tests/microbench/soak.py: two runs of the same
+// 3300 frames diverged). An agent-scope release fence by the incrementing thread also fixes it, but its L2 write-back request costs ~10 % of
+// the frame at long context; the exchanges cost one round trip.
+__device__ __forceinline__ void xchg_agent_wait(float * p, float v) { const float o = __hip_atomic_exchange(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); asm volatile("" :: "v"(o)); }
+__device__ __forceinline__ void xchg_agent_wait(int * p, int v) { const int o = __hip_atomic_exchange(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); asm volatile("" :: "v"(o)); }
+__device__ __forceinline__ void xchg_agent_wait(double * p, double v) { const double o = __hip_atomic_exchange(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); asm volatile("" :: "v"(o)); }
 
 // sum over each aligned group of `n` lanes (n = 8 or 16 on the DPP path, any power of two otherwise), result in all of them
 __device__ __forceinline__ double group_allsum_f64(double v, int n) {

@@ -471,6 +471,7 @@ __global__ void __launch_bounds__(NW * 64) matvec_q4k_kernel(mv_args a, int rows
     MV_STAMP(6);
 
     // phase 4: row sums (+ residual): 16 lanes per row, strided partials then a 4-step butterfly
+    float best = -INFINITY; int bi = 0x7fffffff;   // fused greedy sampling: this thread's first maximum among its rows
     for (int rr = tid >> 4; rr < rows; rr += NW * 4) {
         float sum = 0.f;
         for (int j = tid & 15; j < nb; j += 16) sum += part[rr * nb + j];
@@ -485,34 +486,46 @@ __global__ void __launch_bounds__(NW * 64) matvec_q4k_kernel(mv_args a, int rows
                 if (a.res_embed.scale) e = e * *a.res_embed.scale;
                 sum = sum + e;
             }
-            if (a.ticket) st_agent(a.y + row, sum);   // read back by whichever workgroup finishes last
-            else a.y[row] = sum;
+            a.y[row] = sum;
+            if (row < a.M && sum > best) { best = sum; bi = (int) row; }   // rows ascend per thread: '>' keeps the first maximum
         }
     }
     MV_STAMP(7);
     if (a.ticket) {
-        // greedy sampling fused in: the last workgroup to finish scans y for its first maximum (ggml argmax semantics)
+        // greedy sampling fused in (ggml argmax: the FIRST maximum): every workgroup reduces its own rows to one candidate and publishes it
+        // with returning agent-scope exchanges (complete at the coherence point once the old value is back - a plain store followed by the
+        // counter increment was observed to lose that race once per ~1e5 hand-offs); the last workgroup to arrive merges the candidates
         __shared__ int s_last;
         __shared__ float am_v[NW];
         __shared__ int am_i[NW];
-        drain_stores();
+        float * cand_v = (float *) (a.ticket + 64);          // workspace: counter | 256 B | values[grid] | indices[grid]
+        int * cand_i = (int *) (cand_v + gridDim.x);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(best, o, 64); const int oi = __shfl_xor(bi, o, 64);
+            if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+        }
+        if (lane == 0) { am_v[wave] = best; am_i[wave] = bi; }
         __syncthreads();
-        if (tid == 0) s_last = atomicAdd(a.ticket, 1u) == gridDim.x - 1;
+        if (tid == 0) {
+            for (int w = 1; w < NW; w++) if (am_v[w] > best || (am_v[w] == best && am_i[w] < bi)) { best = am_v[w]; bi = am_i[w]; }
+            xchg_agent_wait(cand_v + blockIdx.x, best);
+            xchg_agent_wait(cand_i + blockIdx.x, bi);
+            s_last = atomicAdd(a.ticket, 1u) == gridDim.x - 1;
+        }
         __syncthreads();
         if (!s_last) return;
-        float best = -INFINITY; int bi = 0x7fffffff;
-        for (int i0 = tid; i0 < (int) a.M; i0 += 8 * NW * 64) {   // coherent loads, eight in flight
-            float v[8];
-#pragma unroll
-            for (int u = 0; u < 8; u++) { const int i = i0 + u * NW * 64; v[u] = ld_agent(a.y + (i < (int) a.M ? i : (int) a.M - 1)); }
-#pragma unroll
-            for (int u = 0; u < 8; u++) { const int i = i0 + u * NW * 64; if (i < (int) a.M && v[u] > best) { best = v[u]; bi = i; } }
+        best = -INFINITY; bi = 0x7fffffff;
+        for (int i = tid; i < (int) gridDim.x; i += NW * 64) {
+            const float v = ld_agent(cand_v + i); const int ci = ld_agent(cand_i + i);
+            if (v > best || (v == best && ci < bi)) { best = v; bi = ci; }
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
             const float ov = __shfl_xor(best, o, 64); const int oi = __shfl_xor(bi, o, 64);
             if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
         }
+        __syncthreads();
         if (lane == 0) { am_v[wave] = best; am_i[wave] = bi; }
         __syncthreads();
         if (tid == 0) {
@@ -1490,7 +1503,6 @@ attn_decode_kernel(attn_args a_in, attn_split_ws w) {
             if (c < c_hi && (lane % LPS) == 0) {
                 const float sv = live ? (float) acc * a.scale + m : -INFINITY;
                 sc[c] = sv;
-                if (multi) st_agent(w.scores + (int64_t) h * C + c, sv);
                 lmax = fmaxf(lmax, sv);
             }
         };
@@ -1530,10 +1542,15 @@ attn_decode_kernel(attn_args a_in, attn_split_ws w) {
         __syncthreads();
         float gmax = fmaxf(fmaxf(sh_f[0], sh_f[1]), fmaxf(sh_f[2], sh_f[3]));
         if (multi) {
-            // publish, arrive, wait for the other P - 1 workgroups of this head, then pull everybody's scores
+            // publish (this workgroup's scores, at most one per thread: SLOTS <= 256 = ATTN_THREADS), arrive, wait for the other P - 1
+            // workgroups of this head, then pull everybody's scores
+            {
+                const int c = c_lo + tid;
+                if (c < c_hi) xchg_agent_wait(w.scores + (int64_t) h * C + c, sc[c]);
+            }
+            __syncthreads();
             if (tid == 0) {
-                st_agent(w.pmax + h * S + s_idx, gmax);
-                drain_stores();
+                xchg_agent_wait(w.pmax + h * S + s_idx, gmax);
                 atomicAdd(w.arrive + h, 1u);
                 int spins = 0;
                 while (ld_agent(w.arrive + h) < (unsigned) P && ++spins < (1 << 22)) __builtin_amdgcn_s_sleep(2);
@@ -1608,7 +1625,7 @@ attn_decode_kernel(attn_args a_in, attn_split_ws w) {
             double tot = 0;
 #pragma unroll 8
             for (int g = 0; g < 4 * SPW; g++) tot += red[g * D + j];   // fixed order: wave-major, slot group minor
-            if (multi) st_agent(w.opart + ((int64_t) h * S + s_idx) * D + j, tot);
+            if (multi) xchg_agent_wait(w.opart + ((int64_t) h * S + s_idx) * D + j, tot);
             else a.out[(int64_t) t * a.out_ts + (int64_t) h * D + j] = (float) tot;
         }
         if (multi) {
@@ -1823,8 +1840,7 @@ __global__ void __launch_bounds__(256) vq_level_kernel(vq_level_args a) {
     __syncthreads();
     if (tid == 0) {
         for (int w = 1; w < 4; w++) if (sv[w] > best || (sv[w] == best && si[w] < bi)) { best = sv[w]; bi = si[w]; }
-        st_agent(a.cand_val + blockIdx.x, best); st_agent(a.cand_idx + blockIdx.x, bi);
-        drain_stores();
+        xchg_agent_wait(a.cand_val + blockIdx.x, best); xchg_agent_wait(a.cand_idx + blockIdx.x, bi);   // complete before the counter moves
         const unsigned ticket = atomicAdd(a.counter, 1u);
         s_last = ticket == gridDim.x - 1;
     }

@@ -12,15 +12,20 @@ for rep in range(2):
     m = hu.Model("hip", cfg, seed=0)
     hu.L.moshi_hot_set_context_fill(m.m, fill)
     rng = np.random.default_rng(3)
-    toks, crc = [], 0
+    toks, crc, crcs = [], 0, []
     t0 = time.perf_counter()
     for i in range(n):
         r, txt, aud, pcm = m.sts_frame((rng.standard_normal(1920) * 0.05).astype(np.float32))
         toks.append((r, txt, tuple(aud)))
         crc = zlib.crc32(pcm.tobytes(), crc)
+        crcs.append(zlib.crc32(pcm.tobytes()))
     dt = time.perf_counter() - t0
-    runs.append((toks, crc))
+    runs.append((toks, crc, crcs))
     print(f"run {rep}: {n} frames from ring offset {fill} (capacity {cfg.context}) in {dt:.2f} s = {n / dt:.1f} frames/s incl. host-side noise generation; pcm crc {crc:08x}", flush=True)
     m.free()
+if runs[0] != runs[1]:
+    ft = next((i for i, (a, b) in enumerate(zip(runs[0][0], runs[1][0])) if a != b), None)
+    fp = next((i for i, (a, b) in enumerate(zip(runs[0][2], runs[1][2])) if a != b), None)
+    print(f"first differing tokens at frame {ft}: {runs[0][0][ft] if ft is not None else None} vs {runs[1][0][ft] if ft is not None else None}; first differing pcm at frame {fp}")
 assert runs[0] == runs[1], "two identical runs differ"
 print("identical token streams and PCM; no device error raised")

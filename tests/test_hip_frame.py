@@ -519,3 +519,25 @@ def test_mimi_file_decode_matches_oracle(tmp_path, n_q):
     for i in range(13):
         a, b = ref[i * 1920:(i + 1) * 1920], got[i * 1920:(i + 1) * 1920]
         assert hu.rel_err(a, b) < PCM_TOL, f"frame {i}: pcm rel err {hu.rel_err(a, b):.2e}"
+
+
+def test_long_context_decode_is_deterministic():
+    # 1300 sts frames from 1000 filled ring slots (the split-attention regime, across the 1024-slot range doubling) at the full moshika
+    # configuration, twice from fresh models: identical tokens and PCM. The cross-workgroup hand-offs (split attention, fused argmax, VQ merge)
+    # once lost a store-vs-counter race about every 1e5 hand-offs, which no oracle comparison of a few frames can see - this can.
+    import zlib
+    cfg = hu.hot.moshika(hu.L)
+    runs = []
+    for rep in range(2):
+        m = hu.Model("hip", cfg, seed=0)
+        hu.L.moshi_hot_set_context_fill(m.m, 1000)
+        rng = np.random.default_rng(3)
+        toks, crc = [], 0
+        for i in range(1300):
+            r, txt, aud, pcm = m.sts_frame((rng.standard_normal(1920) * 0.05).astype(np.float32))
+            toks.append((r, txt, tuple(aud)))
+            crc = zlib.crc32(pcm.tobytes(), crc)
+        runs.append((toks, crc))
+        m.free()
+    first = next((i for i, (a, b) in enumerate(zip(runs[0][0], runs[1][0])) if a != b), None)
+    assert runs[0] == runs[1], f"two identical runs differ, first at frame {first}"
