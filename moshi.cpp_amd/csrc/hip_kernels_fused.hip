@@ -1538,7 +1538,6 @@ attn_decode_kernel(attn_args a_in, attn_split_ws w) {
         }
         lmax = wave_allmax_f32(lmax);
         if (lane == 0) sh_f[wave] = lmax;
-        if (multi) drain_stores();   // this wave's published scores have left before the barrier below
         __syncthreads();
         float gmax = fmaxf(fmaxf(sh_f[0], sh_f[1]), fmaxf(sh_f[2], sh_f[3]));
         if (multi) {
@@ -1630,8 +1629,7 @@ attn_decode_kernel(attn_args a_in, attn_split_ws w) {
         }
         if (multi) {
             // the last of the P workgroups to get here adds the partial outputs in slot order and re-arms the counters
-            drain_stores();
-            __syncthreads();
+            __syncthreads();   // every thread's partial-output exchange has completed (xchg_agent_wait)
             if (tid == 0) s_last = atomicAdd(w.done + h, 1u) == (unsigned) (P - 1);
             __syncthreads();
             if (s_last) {
