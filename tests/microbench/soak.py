@@ -7,6 +7,8 @@ import hot_util as hu
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 600
 fill = int(sys.argv[2]) if len(sys.argv) > 2 else 2800
 cfg = hu.hot.personaplex(hu.L) if len(sys.argv) > 3 and sys.argv[3] == "personaplex" else hu.hot.moshika(hu.L)
+if len(sys.argv) > 4:
+    cfg.linear_type = {"q8_0": 8, "q4_0": 2, "q4_k": 12}[sys.argv[4]]
 runs = []
 for rep in range(2):
     m = hu.Model("hip", cfg, seed=0)
