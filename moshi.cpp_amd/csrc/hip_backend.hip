@@ -100,18 +100,25 @@ static size_t size_class(size_t n) {
     while (c < n) c <<= 1;
     return c;
 }
+// MI355X_POISON=1 (diagnosis): every buffer and workspace handed out is first filled with 0xFF bytes (NaN as F32 / BF16 / F16, -1 as I32), so
+// that a kernel reading memory nobody wrote shows up as NaNs or wild indices in the parity tests instead of passing on leftover zeros
+static void * pool_poison(hip_ctx * c, void * p, size_t n) {
+    static const bool poison = getenv("MI355X_POISON") != nullptr;
+    if (poison && p) { HIP_CHECK(hipMemsetAsync(p, 0xFF, n, c->stream)); HIP_CHECK(hipStreamSynchronize(c->stream)); }
+    return p;
+}
 static void * pool_alloc(hip_ctx * c, size_t n, size_t * actual) {
     set_device(c);
     const size_t cls = size_class(n ? n : 1);
     if (cls) {
         auto & fl = c->pool[cls];
         *actual = cls;
-        if (!fl.empty()) { void * p = fl.back(); fl.pop_back(); return p; }
+        if (!fl.empty()) { void * p = fl.back(); fl.pop_back(); return pool_poison(c, p, *actual); }
     } else *actual = n;
     void * p = nullptr;
     hipError_t e = hipMalloc(&p, *actual);
     if (e != hipSuccess) { fprintf(stderr, "mi355x: hipMalloc(%zu) failed: %s\n", *actual, hipGetErrorString(e)); return nullptr; }
-    return p;
+    return pool_poison(c, p, *actual);
 }
 static void pool_free(hip_ctx * c, void * p, size_t actual) {
     if (!p) return;
