@@ -107,26 +107,44 @@ static void * pool_poison(hip_ctx * c, void * p, size_t n) {
     if (poison && p) { HIP_CHECK(hipMemsetAsync(p, 0xFF, n, c->stream)); HIP_CHECK(hipStreamSynchronize(c->stream)); }
     return p;
 }
+// MI355X_GUARD=1 (diagnosis): every allocation sits between two 4 KB zones filled with 0xA5; they are checked when the allocation is
+// returned - a kernel writing just outside its buffer aborts the process with the offending size instead of corrupting a neighbour
+#define GUARD_BYTES 4096
+static bool guard_mode() { static const bool g = getenv("MI355X_GUARD") != nullptr; return g; }
+static void guard_fill(hip_ctx * c, char * user, size_t actual) {
+    HIP_CHECK(hipMemsetAsync(user - GUARD_BYTES, 0xA5, GUARD_BYTES, c->stream));
+    HIP_CHECK(hipMemsetAsync(user + actual, 0xA5, GUARD_BYTES, c->stream));
+}
+static void guard_check(hip_ctx * c, char * user, size_t actual) {
+    static std::vector<unsigned char> h(2 * GUARD_BYTES);
+    HIP_CHECK(hipStreamSynchronize(c->stream));
+    HIP_CHECK(hipMemcpy(h.data(), user - GUARD_BYTES, GUARD_BYTES, hipMemcpyDeviceToHost));
+    HIP_CHECK(hipMemcpy(h.data() + GUARD_BYTES, user + actual, GUARD_BYTES, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < 2 * GUARD_BYTES; i++)
+        if (h[i] != 0xA5) GGML_ABORT("mi355x: guard zone %s a %zu-byte allocation was overwritten (offset %zu)", i < GUARD_BYTES ? "before" : "after", actual, i % GUARD_BYTES);
+}
 static void * pool_alloc(hip_ctx * c, size_t n, size_t * actual) {
     set_device(c);
     const size_t cls = size_class(n ? n : 1);
     if (cls) {
         auto & fl = c->pool[cls];
         *actual = cls;
-        if (!fl.empty()) { void * p = fl.back(); fl.pop_back(); return pool_poison(c, p, *actual); }
+        if (!fl.empty()) { void * p = fl.back(); fl.pop_back(); if (guard_mode()) guard_fill(c, (char *) p, *actual); return pool_poison(c, p, *actual); }
     } else *actual = n;
     void * p = nullptr;
-    hipError_t e = hipMalloc(&p, *actual);
+    hipError_t e = hipMalloc(&p, *actual + (guard_mode() ? 2 * GUARD_BYTES : 0));
     if (e != hipSuccess) { fprintf(stderr, "mi355x: hipMalloc(%zu) failed: %s\n", *actual, hipGetErrorString(e)); return nullptr; }
+    if (guard_mode()) { p = (char *) p + GUARD_BYTES; guard_fill(c, (char *) p, *actual); }
     return pool_poison(c, p, *actual);
 }
 static void pool_free(hip_ctx * c, void * p, size_t actual) {
     if (!p) return;
+    if (guard_mode()) guard_check(c, (char *) p, actual);
     const size_t cls = size_class(actual);
     if (cls && cls == actual) { c->pool[cls].push_back(p); return; }
     set_device(c);
     HIP_CHECK(hipStreamSynchronize(c->stream));
-    HIP_CHECK(hipFree(p));
+    HIP_CHECK(hipFree(guard_mode() ? (char *) p - GUARD_BYTES : (char *) p));
 }
 
 // ---- batched uploads -------------------------------------------------------------------------------
