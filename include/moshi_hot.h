@@ -85,7 +85,7 @@ GGML_API void moshi_hot_set_text_hook(moshi_hot_model_t * m, moshi_hot_text_hook
 // one voice-prompt frame from a precomputed input embedding F32[dim] (moshi_lmgen_step_voice_prompt, lm.h:1004-1037): the Temporal
 // stack runs on the scratch context (moshi_lmmodel_forward_embedding, lm.h:694-709), text is forced to 3, the Depth graph steps
 GGML_API void moshi_hot_lm_step_embedding(moshi_hot_model_t * m, const float * embedding);
-// n_frames provided frames (tokens: n_frames x (n_q + 1), text first) as batched [dim, T] passes of at most `chunk` frames (0 = 32):
+// n_frames provided frames (tokens: n_frames x (n_q + 1), text first) as batched [dim, T] passes of at most `chunk` frames (0 = 64, the largest the batched kernels take):
 // leaves the delay ring, the offsets and the Temporal KV ring as n_frames calls of moshi_hot_lm_step_n(.., n_q + 1, ..) would,
 // without running the Depth graph or the text head
 GGML_API void moshi_hot_prefill(moshi_hot_model_t * m, const int32_t * tokens, int n_frames, int chunk);

@@ -1195,7 +1195,7 @@ extern "C" void moshi_hot_prefill(moshi_hot_model_t * m, const int32_t * tokens,
     const moshi_hot_config & c = m->cfg;
     const int ncb = c.n_q + 1, CT = (int) m->cache.size();
     GGML_ASSERT(ncb - (c.personaplex ? 8 : c.dep_q) - 1 > 0 && !c.demux_second_stream && !c.cross_attention);
-    if (chunk < 1) chunk = 32;
+    if (chunk < 1) chunk = 64;
     if (chunk > 64) chunk = 64;   // the device's batched kernels take up to 64 rows per pass
     int done = 0;
     while (done < n_frames) {
