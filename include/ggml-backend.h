@@ -117,6 +117,9 @@ GGML_API void ggml_backend_mi355x_get_kernel_profile(ggml_backend_t backend, str
 // bit flags, default 0: 1 = disable fusion (one kernel per node), 2 = disable hipGraph capture, 4 = disable upload batching,
 // 8 = profile mode (eager launches, per-dispatch HIP events on matvec_q4k_kernel)
 GGML_API void ggml_backend_mi355x_set_flags(ggml_backend_t backend, int flags);
+// hipGraph capture of repeated graphs on / off without touching cached plans (off: a repeated graph still reuses its plan, launched eagerly -
+// for sequences of same-shaped one-off graphs such as prompt-prefill chunks, where a capture costs more than it saves). No-op on other backends.
+GGML_API void ggml_backend_mi355x_set_capture(ggml_backend_t backend, int enabled);
 // HIP stream the backend launches on (void* = hipStream_t) so callers can bracket it with HIP events
 GGML_API void * ggml_backend_mi355x_get_stream(ggml_backend_t backend);
 

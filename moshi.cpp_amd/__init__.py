@@ -132,7 +132,7 @@ SIGNATURES = {
     "ggml_backend_tensor_set": (None, [TP, P, Z, Z]), "ggml_backend_tensor_get": (None, [TP, P, Z, Z]),
     "ggml_backend_tensor_memset": (None, [TP, C.c_uint8, Z, Z]), "ggml_backend_tensor_copy": (None, [TP, TP]),
     "ggml_backend_graph_compute": (I, [P, P]), "ggml_backend_supports_op": (B, [P, TP]),
-    "ggml_backend_mi355x_get_stats": (None, [P, C.POINTER(Stats)]), "ggml_backend_mi355x_set_flags": (None, [P, I]),
+    "ggml_backend_mi355x_get_stats": (None, [P, C.POINTER(Stats)]), "ggml_backend_mi355x_set_flags": (None, [P, I]), "ggml_backend_mi355x_set_capture": (None, [P, I]),
     "ggml_backend_mi355x_get_stream": (P, [P]),
     "ggml_backend_mi355x_get_kernel_profile": (None, [P, C.POINTER(KernelProfile)]),
     # ggml-cpu.h

@@ -49,6 +49,7 @@ struct hip_ctx {
     std::string name, description;
     hipStream_t stream = nullptr;
     int flags = 0;
+    bool no_capture = false;     // ggml_backend_mi355x_set_capture(.., 0): plans of repeated graphs are reused but not captured into hipGraphs
     ggml_mi355x_stats stats = {};
     // pooled allocations: size class -> free pointers
     std::map<size_t, std::vector<void *>> pool;
@@ -1582,7 +1583,7 @@ static enum ggml_status hip_graph_compute(ggml_backend_t backend, struct ggml_cg
         fresh = true;
     }
     const int64_t tp1 = time_plan ? ggml_time_us() : 0;
-    if (!fresh && !p->exec && !(c->flags & 2)) {
+    if (!fresh && !p->exec && !(c->flags & 2) && !c->no_capture) {
         // second compute of the same graph: it is a cached graph (the per-frame ones), so capture the launch sequence now; replays cost one
         // hipGraphLaunch. One-shot graphs (scratch contexts, prompt prefill chunks) never pay for a capture.
         HIP_CHECK(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
@@ -1688,6 +1689,9 @@ static hip_ctx * ctx_of(ggml_backend_t b) {
     return (hip_ctx *) b->context;
 }
 extern "C" void ggml_backend_mi355x_get_stats(ggml_backend_t b, struct ggml_mi355x_stats * stats) { *stats = ctx_of(b)->stats; }
+extern "C" void ggml_backend_mi355x_set_capture(ggml_backend_t b, int enabled) {
+    if (b && b->iface.get_name == hip_backend_name) ((hip_ctx *) b->context)->no_capture = !enabled;   // any other backend: nothing to do
+}
 extern "C" void ggml_backend_mi355x_set_flags(ggml_backend_t b, int flags) {
     hip_ctx * c = ctx_of(b);
     if (c->stream) { flush_uploads(c); HIP_CHECK(hipStreamSynchronize(c->stream)); }

@@ -451,11 +451,10 @@ void transformer_graph_step(Builder & scratch, Transformer & tr, int Tn) {
 
 // moshi_streaming_transformer, non-graph overload with offsets baked at build time (transformer.h:1182-1215);
 // this is how the Depth steps sit inside one cached graph (lm.h:469-470)
-T transformer_inline(Builder & g, Transformer & tr, T x) {
+T transformer_inline(Builder & g, Transformer & tr, T x, T mask_override = nullptr) {
     const int Tn = (int) x->ne[1];
     const int offset = tr.offset;
-    create_bias_pattern(g.be, tr, Tn);
-    T attn_bias = bias_pattern_index(g, tr, Tn, offset);
+    T attn_bias = mask_override ? mask_override : bias_pattern_index(g, tr, Tn, offset);
     Rot rot;
     if (tr.max_period) rot = timestep_embedding(g, Tn, tr.dim / tr.heads, g.f32((float) offset), tr.max_period);
     std::vector<int32_t> idx((size_t) Tn);
@@ -1197,6 +1196,7 @@ extern "C" void moshi_hot_prefill(moshi_hot_model_t * m, const int32_t * tokens,
     GGML_ASSERT(ncb - (c.personaplex ? 8 : c.dep_q) - 1 > 0 && !c.demux_second_stream && !c.cross_attention);
     if (chunk < 1) chunk = 64;
     if (chunk > 64) chunk = 64;   // the device's batched kernels take up to 64 rows per pass
+    ggml_backend_mi355x_set_capture(m->be, 0);   // same-shaped chunk graphs: reuse the plan, do not pay a hipGraph capture for a handful of replays
     int done = 0;
     while (done < n_frames) {
         int Tn = n_frames - done < chunk ? n_frames - done : chunk;
@@ -1230,13 +1230,23 @@ extern "C" void moshi_hot_prefill(moshi_hot_model_t * m, const int32_t * tokens,
             input = input ? ggml_add(s, input, e) : e;
         }
         if (c.condition_sum) input = ggml_add(s, m->cond_sum, input);
-        T x = transformer_inline(s, m->temporal, input);
+        // the [C, Tn] block of the bias table as an uploaded constant (before the wrap it is plainly causal: slot cc is open to row t iff
+        // cc <= offset + t, torch.h:170-223): the chunk graphs of one prefill are then structurally identical and the backend reuses one plan
+        T mask = s.tensor(GGML_TYPE_F32, m->temporal.capacity, Tn);
+        {
+            std::vector<float> mv((size_t) m->temporal.capacity * (size_t) Tn);
+            for (int t = 0; t < Tn; t++)
+                for (int cc = 0; cc < m->temporal.capacity; cc++) mv[(size_t) t * (size_t) m->temporal.capacity + (size_t) cc] = cc <= m->temporal.offset + t ? 0.0f : -INFINITY;
+            s.constant(mask, mv.data());
+        }
+        T x = transformer_inline(s, m->temporal, input, mask);
         // transformer_out as the last of these frames would have left it (lm.h:434, 847-849)
         T last = ggml_view_2d(s, x, x->ne[0], 1, x->nb[1], (size_t) (Tn - 1) * x->nb[1]);
         s.expand(ggml_cpy(s, apply_norm(s, m->out_norm, last), m->transformer_out));
         s.compute_scratch();
         done += Tn;
     }
+    ggml_backend_mi355x_set_capture(m->be, 1);
 }
 
 static const int32_t PERSONAPLEX_PROMPT_TOKENS[17] = { 3, 948, 243, 1178, 546, 1736, 1030, 1978, 2008, 430, 1268, 381, 1611, 1095, 1495, 56, 472 };
