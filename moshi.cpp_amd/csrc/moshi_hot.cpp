@@ -1160,7 +1160,16 @@ extern "C" void moshi_hot_lm_step_embedding(moshi_hot_model_t * m, const float *
     PhaseTimer pt(m, 1);
     T input = s.constant(s.tensor(GGML_TYPE_F32, c.dim, 1, 1), embedding);
     input = ggml_cast(s, input, GGML_TYPE_F32);                       // lm.h:1022
-    T x = transformer_inline(s, m->temporal, input);                  // moshi_lmmodel_forward_embedding (lm.h:694-709)
+    // the mask row as an uploaded constant instead of a view into the bias table (same values: slot cc is open iff the ring has wrapped or
+    // cc <= offset, torch.h:205-223 for T = 1): consecutive voice-prompt frames then rebuild a structurally identical graph in place and the
+    // backend reuses (and from the second frame on replays) one plan instead of planning ~4 000 nodes per frame
+    T mask = s.tensor(GGML_TYPE_F32, m->temporal.capacity, 1);
+    {
+        std::vector<float> mv((size_t) m->temporal.capacity);
+        for (int cc = 0; cc < m->temporal.capacity; cc++) mv[(size_t) cc] = (m->temporal.offset >= m->temporal.capacity || cc <= m->temporal.offset) ? 0.0f : -INFINITY;
+        s.constant(mask, mv.data());
+    }
+    T x = transformer_inline(s, m->temporal, input, mask);            // moshi_lmmodel_forward_embedding (lm.h:694-709)
     x = apply_norm(s, m->out_norm, x);
     T logits = linear(s, m->text_linear, x);
     s.expand(ggml_cpy(s, x, m->transformer_out));
