@@ -1,4 +1,4 @@
-"""moshi.cpp_amd — ctypes binding of the MI355X ggml drop-in (libggml-mi355x.so).
+"""moshi.cpp_amd — ctypes binding of the MI355X ggml drop-in (libggml-mi355x.so) and of the frame-driver harness (libmoshi-hot.so).
 
 The product is the C-ABI library declared in include/{ggml,ggml-backend,ggml-cpu,gguf}.h and
 include/moshi_hot.h; this module only loads it and attaches signatures so that tests and bench.py can
@@ -12,6 +12,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MI355X_LIB") or os.path.join(_HERE, "libggml-mi355x.so")   # MI355X_LIB: A/B another build (tests/microbench/ab_bench.sh)
+HOT_LIB_PATH = os.environ.get("MI355X_HOT_LIB") or os.path.join(os.path.dirname(LIB_PATH), "libmoshi-hot.so")   # harness: include/moshi_hot.h
 
 GGML_MAX_DIMS, GGML_MAX_SRC, GGML_MAX_NAME = 4, 10, 64
 
@@ -152,14 +153,32 @@ SIGNATURES = {
 _lib = None
 
 
+class _Libs:
+    """The boundary library plus the harness library behind one attribute namespace (a symbol lives in exactly one of them)."""
+
+    def __init__(self, ggml, hot):
+        self.ggml, self.hot = ggml, hot
+
+    def __getattr__(self, name):
+        for lib in (self.__dict__["ggml"], self.__dict__["hot"]):
+            try:
+                fn = getattr(lib, name)
+            except AttributeError:
+                continue
+            setattr(self, name, fn)
+            return fn
+        raise AttributeError(name)
+
+
 def load():
-    """Load libggml-mi355x.so and attach signatures. Raises if the library or a declared symbol is missing."""
+    """Load libggml-mi355x.so (+ libmoshi-hot.so) and attach signatures. Raises if a library or a declared symbol is missing."""
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
-        raise RuntimeError(f"{LIB_PATH} not found: build it with moshi.cpp_amd/build.sh (hipcc --offload-arch=gfx950); "
-                           "there is no CPU or Python fallback for the decode hot path")
+    for path in (LIB_PATH, HOT_LIB_PATH):
+        if not os.path.exists(path):
+            raise RuntimeError(f"{path} not found: build it with moshi.cpp_amd/build.sh (hipcc --offload-arch=gfx950); "
+                               "there is no CPU or Python fallback for the decode hot path")
     lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
     missing = []
     for name, (res, args) in SIGNATURES.items():
@@ -171,10 +190,14 @@ def load():
         fn.restype, fn.argtypes = res, args
     if missing:
         raise RuntimeError(f"libggml-mi355x.so lacks symbols declared in include/*.h: {missing}")
+    stray = [n for n in ("moshi_hot_create", "moshi_hot_sts_frame") if hasattr(lib, n)]
+    if stray:
+        raise RuntimeError(f"the boundary library must not carry the harness: {stray}")
+    hot_lib = C.CDLL(HOT_LIB_PATH, mode=C.RTLD_GLOBAL)
     from . import hot as _hot  # host-side hot-path driver bindings (include/moshi_hot.h)
-    _hot.attach(lib)
-    _lib = lib
-    return lib
+    _hot.attach(hot_lib)
+    _lib = _Libs(lib, hot_lib)
+    return _lib
 
 
 def declared_symbols():

@@ -1,5 +1,7 @@
 #!/bin/bash
-# Builds the MI355X ggml drop-in (libggml-mi355x.so) for gfx950. hipcc cross-compiles without a GPU.
+# Builds the MI355X ggml drop-in (libggml-mi355x.so: the boundary library, nothing but the ggml C API) and, next to it, the test / bench
+# harness (libmoshi-hot.so: synthetic weights + the frame driver of include/moshi_hot.h, linked AGAINST the drop-in through its public
+# surface only) for gfx950. hipcc cross-compiles without a GPU.
 set -e
 cd "$(dirname "$0")"
 SRC=csrc
@@ -21,5 +23,6 @@ for f in hip_backend hip_kernels_generic hip_kernels_fused; do
   fi
 done
 for p in "${pids[@]}"; do wait $p; done
-hipcc --offload-arch=$ARCH -shared -fPIC -o $OUT/libggml-mi355x.so build/*.o -Wl,-soname,libggml-mi355x.so
-echo "built $OUT/libggml-mi355x.so"
+hipcc --offload-arch=$ARCH -shared -fPIC -o $OUT/libggml-mi355x.so build/ggml_core.o build/ggml_backend.o build/gguf.o build/hip_backend.o build/hip_kernels_generic.o build/hip_kernels_fused.o -Wl,-soname,libggml-mi355x.so
+g++ -shared -fPIC -o $OUT/libmoshi-hot.so build/moshi_hot.o -L$OUT -lggml-mi355x -Wl,-soname,libmoshi-hot.so -Wl,-rpath,'$ORIGIN'
+echo "built $OUT/libggml-mi355x.so $OUT/libmoshi-hot.so"

@@ -19,6 +19,7 @@
 
 #include <string.h>
 
+#include <algorithm>
 #include <functional>
 #include <map>
 #include <memory>
@@ -63,6 +64,7 @@ struct hip_ctx {
     double prof_seconds = 0; int64_t prof_launches = 0, prof_bytes = 0;
     // cached plans keyed by cgraph pointer
     std::unordered_map<const ggml_cgraph *, plan_t *> plans;
+    uint64_t orphan_clock = 0;
     // device-visible error word in pinned host memory: kernels with bounded waits raise it instead of hanging
     volatile unsigned * err_host = nullptr;
     unsigned * err_dev = nullptr;
@@ -184,9 +186,12 @@ static void queue_upload(hip_ctx * c, void * dst, const void * src, size_t size)
 // ---------------------------------------------------------------------------------------------------
 struct hip_buffer_ctx { hip_ctx * c; size_t actual; };
 
+static void evict_plans_of_buffer(hip_ctx * c, const ggml_backend_buffer * b);
+
 static void hip_buf_free(ggml_backend_buffer_t b) {
     hip_buffer_ctx * bc = (hip_buffer_ctx *) b->context;
     flush_uploads(bc->c);
+    evict_plans_of_buffer(bc->c, b);   // plans (captured hipGraphs with baked pointers, pool workspaces) must not silently outlive the memory they address
     pool_free(bc->c, b->base, bc->actual);
     delete bc;
     delete b;
@@ -253,6 +258,8 @@ struct plan_t {
     std::vector<step_fn> steps;
     std::vector<std::pair<void *, size_t>> workspaces;
     std::vector<std::unique_ptr<attn_args>> attn_copies;
+    std::vector<const ggml_backend_buffer *> buffers;   // every buffer a node / leaf of the planned graph lives in: freeing one orphans the plan
+    uint64_t orphan_seq = 0;                            // != 0: a buffer of the planned graph has been freed since (see evict_plans_of_buffer)
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
     uint64_t hash = 0;
@@ -266,18 +273,62 @@ static void plan_free(hip_ctx * c, plan_t * p) {
     delete p;
 }
 
-static uint64_t graph_hash(const ggml_cgraph * g) {
-    uint64_t h = 0xcbf29ce484222325ull ^ (uint64_t) g->n_nodes;
-    for (int i = 0; i < g->n_nodes; i++) {
-        const ggml_tensor * n = g->nodes[i];
-        h = (h ^ (uint64_t) (uintptr_t) n) * 0x100000001b3ull;
-        h = (h ^ (uint64_t) (uintptr_t) n->data) * 0x100000001b3ull;
-        h = (h ^ (uint64_t) n->op) * 0x100000001b3ull;
-        h = (h ^ (uint64_t) (uint32_t) n->op_params[0] ^ ((uint64_t) (uint32_t) n->op_params[1] << 32)) * 0x100000001b3ull;
-        h = (h ^ (uint64_t) n->ne[0] ^ ((uint64_t) n->ne[1] << 24) ^ ((uint64_t) n->nb[1] << 40)) * 0x100000001b3ull;
-        for (int s = 0; s < 3; s++) if (n->src[s]) h = (h ^ (uint64_t) (uintptr_t) n->src[s]->data) * 0x100000001b3ull;
+// A plan bakes device addresses into its launch arguments. When a buffer it touches is freed (moshi_hot_free, a scratch context going away) the
+// plan becomes an ORPHAN: it is only ever used again if a graph with the same full hash - same tensor descriptors at the same host addresses with
+// the same device addresses - is submitted under the same cgraph pointer (the scratch protocol of src/context.h:628-653 rebuilds structurally
+// identical graphs in place: one plan then serves every chunk of a prompt prefill). Anything else at that address replaces it, and at most
+// MAX_ORPHANS are kept (oldest first out), so plans of freed models do not pile up with their pool workspaces.
+#define MAX_ORPHANS 8
+static void collect_plan_buffers(plan_t * p, const ggml_cgraph * g) {
+    p->buffers.clear();
+    auto note = [&](const ggml_tensor * t) {
+        const ggml_backend_buffer * b = t->buffer ? t->buffer : (t->view_src ? t->view_src->buffer : nullptr);
+        if (b && std::find(p->buffers.begin(), p->buffers.end(), b) == p->buffers.end()) p->buffers.push_back(b);
+    };
+    for (int i = 0; i < g->n_nodes; i++) note(g->nodes[i]);
+    for (int i = 0; i < g->n_leafs; i++) note(g->leafs[i]);
+}
+static void evict_plans_of_buffer(hip_ctx * c, const ggml_backend_buffer * b) {
+    for (auto & kv : c->plans) {
+        plan_t * p = kv.second;
+        if (p->orphan_seq || std::find(p->buffers.begin(), p->buffers.end(), b) == p->buffers.end()) continue;
+        p->orphan_seq = ++c->orphan_clock;
+        p->buffers.clear();
     }
-    return h;
+    for (;;) {   // bound the orphans
+        int n = 0; auto oldest = c->plans.end();
+        for (auto it = c->plans.begin(); it != c->plans.end(); ++it)
+            if (it->second->orphan_seq) { n++; if (oldest == c->plans.end() || it->second->orphan_seq < oldest->second->orphan_seq) oldest = it; }
+        if (n <= MAX_ORPHANS) break;
+        if (c->stream) { set_device(c); HIP_CHECK(hipStreamSynchronize(c->stream)); }
+        plan_free(c, oldest->second);
+        c->plans.erase(oldest);
+    }
+}
+
+// Everything the planner reads goes into the hash: for every node AND leaf the tensor's address and its whole descriptor up to (not including)
+// the name - type, ne, nb, op, op_params, flags, the src pointers, view_src / view_offs, data (tensors are zero-filled on creation, so the
+// padding bytes are defined). A source is either a node or a leaf of the same graph, so its shape / type / strides / data are covered too.
+// Four interleaved multiply-xor lanes keep this at ~15 us for the 1.3 k-node Temporal graph.
+static uint64_t graph_hash(const ggml_cgraph * g) {
+    constexpr size_t NW = offsetof(ggml_tensor, name) / 8;
+    static_assert(offsetof(ggml_tensor, name) % 32 == 0, "tensor descriptor is hashed in 4 lanes of 8-byte words");
+    uint64_t h[4] = { 0xcbf29ce484222325ull ^ (uint64_t) g->n_nodes, 0x9e3779b97f4a7c15ull ^ (uint64_t) g->n_leafs, 0xc2b2ae3d27d4eb4full, 0x165667b19e3779f9ull };
+    auto mix = [&](const ggml_tensor * t) {
+        uint64_t w[NW];
+        memcpy(w, t, NW * 8);
+        w[offsetof(ggml_tensor, buffer) / 8] = 0;   // the buffer OBJECT is not read by the planner (data addresses are): a re-allocated scratch buffer keeps the hash
+        h[0] = (h[0] ^ (uint64_t) (uintptr_t) t) * 0x100000001b3ull;
+        for (size_t i = 0; i < NW; i += 4) {
+            h[0] = (h[0] ^ w[i]) * 0x100000001b3ull; h[1] = (h[1] ^ w[i + 1]) * 0x100000001b3ull;
+            h[2] = (h[2] ^ w[i + 2]) * 0x100000001b3ull; h[3] = (h[3] ^ w[i + 3]) * 0x100000001b3ull;
+        }
+    };
+    for (int i = 0; i < g->n_nodes; i++) mix(g->nodes[i]);
+    for (int i = 0; i < g->n_leafs; i++) mix(g->leafs[i]);
+    uint64_t r = h[0];
+    for (int k = 1; k < 4; k++) r = (r ^ (h[k] >> 29) ^ h[k]) * 0x100000001b3ull;
+    return r;
 }
 
 // ---- graph analysis helpers --------------------------------------------------------------------------
@@ -1249,7 +1300,7 @@ static bool match_vq_level(const analysis & an, int pos, step_group & grp, emitt
     last = pos_of(an, cs);
     if (last < pos) return false;
     char * ws = (char *) em.ws(VQ_LEVEL_WS_BYTES);
-    HIP_CHECK(hipMemset(ws, 0, VQ_LEVEL_WS_BYTES));
+    HIP_CHECK(hipMemsetAsync(ws, 0, VQ_LEVEL_WS_BYTES, em.c->stream));   // stream-ordered behind the block's previous user (plans are built outside capture)
     vq_level_args a;
     a.emb = (const char *) emb->data; a.emb_row_bytes = (int64_t) emb->nb[1]; a.D = (int) D; a.NC = (int) NC;
     a.resid = (const char *) resid->data; a.resid_stride = (int64_t) resid->nb[1];
@@ -1331,6 +1382,7 @@ static plan_t * build_plan(hip_ctx * c, ggml_cgraph * g) {
     emitter em = { c, p };
     analysis an;
     analyse(an, g);
+    collect_plan_buffers(p, g);
     const bool fuse = !(c->flags & 1);
 
     // fused groups, keyed by the position at which they are emitted
@@ -1450,7 +1502,7 @@ static plan_t * build_plan(hip_ctx * c, ggml_cgraph * g) {
                         if (g->nodes[j]->op == GGML_OP_CPY && g->nodes[j]->src[0] == am && g->nodes[j]->type == GGML_TYPE_I32 && ggml_nelements(g->nodes[j]) == 1) { cp = g->nodes[j]; break; }
                     if (cp && !an.skip[(size_t) pos_of(an, cp)]) { a.argmax_out[1] = (int32_t *) cp->data; an.skip[(size_t) pos_of(an, cp)] = 1; }
                     unsigned * tk = (unsigned *) em.ws(256 + 2 * 4 * 8192);   // arrival counter | per-workgroup argmax candidates (value, index)
-                    HIP_CHECK(hipMemset(tk, 0, 256));
+                    HIP_CHECK(hipMemsetAsync(tk, 0, 256, em.c->stream));
                     a.ticket = tk;
                     p->n_fused += 1 + (cp ? 1 : 0);
                 }
@@ -1498,7 +1550,7 @@ static plan_t * build_plan(hip_ctx * c, ggml_cgraph * g) {
             continue;
         }
         void * ws = nullptr;
-        if (const size_t n = k_attn_decode_ws_size(a)) { ws = em.ws(n); HIP_CHECK(hipMemset(ws, 0, n)); }   // arrival counters start at zero
+        if (const size_t n = k_attn_decode_ws_size(a)) { ws = em.ws(n); HIP_CHECK(hipMemsetAsync(ws, 0, n, c->stream)); }   // arrival counters start at zero
         at_pos[ag.emit_pos].insert(at_pos[ag.emit_pos].begin(), [=](hipStream_t s) { k_attn_decode(s, a, ws, err); });
     }
     const bool dump = getenv("MI355X_DUMP_PLAN") != nullptr;
@@ -1570,7 +1622,7 @@ static enum ggml_status hip_graph_compute(ggml_backend_t backend, struct ggml_cg
     plan_t * p = nullptr;
     auto it = c->plans.find(g);
     if (it != c->plans.end()) {
-        if (it->second->hash == h) p = it->second;
+        if (it->second->hash == h) { p = it->second; if (p->orphan_seq) { p->orphan_seq = 0; collect_plan_buffers(p, g); } }
         else { HIP_CHECK(hipStreamSynchronize(c->stream)); plan_free(c, it->second); c->plans.erase(it); }
     }
     static const bool time_plan = getenv("MI355X_TIME_PLAN") != nullptr;

@@ -97,7 +97,7 @@ struct mv_args {
     float *     y;              // [M, ncols]
     float *     x_out;          // optional: prologue result written by block 0 (keeps the ggml node materialised)
     embed_src   res_embed;      // optional (table != NULL, instead of `residual`): y = W x + one embedding row (Q4_K path)
-    int32_t *   argmax_out[2];  // optional (Q4_K path): index of the first maximum of y, written by the last workgroup to finish
+    int32_t *   argmax_out[2];  // optional (Q4_K path): index of the last maximum of y (ggml_vec_argmax_f32), written by the last workgroup to finish
     unsigned *  ticket;         //   ... arrival counter for that (zero between launches)
     const attn_args * attn;     // MV_ATTN: (host pointer) the attention whose output is x; short ring, recomputed per workgroup
 };

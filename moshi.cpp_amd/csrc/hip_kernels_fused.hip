@@ -471,7 +471,7 @@ __global__ void __launch_bounds__(NW * 64) matvec_q4k_kernel(mv_args a, int rows
     MV_STAMP(6);
 
     // phase 4: row sums (+ residual): 16 lanes per row, strided partials then a 4-step butterfly
-    float best = -INFINITY; int bi = 0x7fffffff;   // fused greedy sampling: this thread's first maximum among its rows
+    float best = -INFINITY; int bi = -1;   // fused greedy sampling: this thread's LAST maximum among its rows (ggml_vec_argmax_f32 keeps the last)
     for (int rr = tid >> 4; rr < rows; rr += NW * 4) {
         float sum = 0.f;
         for (int j = tid & 15; j < nb; j += 16) sum += part[rr * nb + j];
@@ -487,12 +487,12 @@ __global__ void __launch_bounds__(NW * 64) matvec_q4k_kernel(mv_args a, int rows
                 sum = sum + e;
             }
             a.y[row] = sum;
-            if (row < a.M && sum > best) { best = sum; bi = (int) row; }   // rows ascend per thread: '>' keeps the first maximum
+            if (row < a.M && sum >= best) { best = sum; bi = (int) row; }   // rows ascend per thread: '>=' keeps the last maximum
         }
     }
     MV_STAMP(7);
     if (a.ticket) {
-        // greedy sampling fused in (ggml argmax: the FIRST maximum): every workgroup reduces its own rows to one candidate and publishes it
+        // greedy sampling fused in (ggml's CPU argmax: the LAST maximum): every workgroup reduces its own rows to one candidate and publishes it
         // with returning agent-scope exchanges (complete at the coherence point once the old value is back - a plain store followed by the
         // counter increment was observed to lose that race once per ~1e5 hand-offs); the last workgroup to arrive merges the candidates
         __shared__ int s_last;
@@ -503,34 +503,34 @@ __global__ void __launch_bounds__(NW * 64) matvec_q4k_kernel(mv_args a, int rows
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
             const float ov = __shfl_xor(best, o, 64); const int oi = __shfl_xor(bi, o, 64);
-            if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+            if (ov > best || (ov == best && oi > bi)) { best = ov; bi = oi; }
         }
         if (lane == 0) { am_v[wave] = best; am_i[wave] = bi; }
         __syncthreads();
         if (tid == 0) {
-            for (int w = 1; w < NW; w++) if (am_v[w] > best || (am_v[w] == best && am_i[w] < bi)) { best = am_v[w]; bi = am_i[w]; }
+            for (int w = 1; w < NW; w++) if (am_v[w] > best || (am_v[w] == best && am_i[w] > bi)) { best = am_v[w]; bi = am_i[w]; }
             xchg_agent_wait(cand_v + blockIdx.x, best);
             xchg_agent_wait(cand_i + blockIdx.x, bi);
             s_last = atomicAdd(a.ticket, 1u) == gridDim.x - 1;
         }
         __syncthreads();
         if (!s_last) return;
-        best = -INFINITY; bi = 0x7fffffff;
+        best = -INFINITY; bi = -1;
         for (int i = tid; i < (int) gridDim.x; i += NW * 64) {
             const float v = ld_agent(cand_v + i); const int ci = ld_agent(cand_i + i);
-            if (v > best || (v == best && ci < bi)) { best = v; bi = ci; }
+            if (v > best || (v == best && ci > bi)) { best = v; bi = ci; }
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
             const float ov = __shfl_xor(best, o, 64); const int oi = __shfl_xor(bi, o, 64);
-            if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+            if (ov > best || (ov == best && oi > bi)) { best = ov; bi = oi; }
         }
         __syncthreads();
         if (lane == 0) { am_v[wave] = best; am_i[wave] = bi; }
         __syncthreads();
         if (tid == 0) {
-            for (int w = 1; w < NW; w++) if (am_v[w] > best || (am_v[w] == best && am_i[w] < bi)) { best = am_v[w]; bi = am_i[w]; }
-            const int code = bi == 0x7fffffff ? 0 : bi;
+            for (int w = 1; w < NW; w++) if (am_v[w] > best || (am_v[w] == best && am_i[w] > bi)) { best = am_v[w]; bi = am_i[w]; }
+            const int code = bi < 0 ? 0 : bi;
             if (a.argmax_out[0]) *a.argmax_out[0] = code;
             if (a.argmax_out[1]) *a.argmax_out[1] = code;
             *a.ticket = 0u;
@@ -1800,7 +1800,7 @@ void k_embed_sum(hipStream_t s, const embed_sum_args & a) {
 // residual-VQ encode level: argmax_c 1 / (||e_c - x||^2 + 1), then x <- x - e_best
 // ---------------------------------------------------------------------------------------------------
 // The reference materialises (e - x) for all 2048 centroids, squares, sum_rows (double accumulate), adds 1, takes the
-// reciprocal and argmaxes (first maximum wins). Here every wave scores VQ_CPW centroids (row loads requested up front), the
+// reciprocal and argmaxes (ggml's CPU argmax: the last maximum wins). Here every wave scores VQ_CPW centroids (row loads requested up front), the
 // workgroup keeps its best candidate, and the last workgroup to arrive (device-scope counter) merges the candidates, writes
 // the code and updates the residual - one launch per level instead of fifteen.
 #define VQ_CPW 4
@@ -1821,7 +1821,7 @@ __global__ void __launch_bounds__(256) vq_level_kernel(vq_level_args a) {
 #pragma unroll
     for (int j = 0; j < 4; j++) x[j] = *(const float *) (a.resid + (int64_t) (lane * 4 + j) * a.resid_stride);
     const float addc = a.add_c[0];
-    float best = -INFINITY; int bi = 0x7fffffff;
+    float best = -INFINITY; int bi = -1;
 #pragma unroll
     for (int u = 0; u < VQ_CPW; u++) {
         double acc = 0;
@@ -1831,13 +1831,13 @@ __global__ void __launch_bounds__(256) vq_level_kernel(vq_level_args a) {
         const int c = c0 + u;
         if (c < a.NC) {
             const float v = a.num[c] / ((float) acc + addc);
-            if (v > best) { best = v; bi = c; }
+            if (v >= best) { best = v; bi = c; }   // centroids ascend: '>=' keeps the last maximum (ggml_vec_argmax_f32)
         }
     }
     if (lane == 0) { sv[wave] = best; si[wave] = bi; }
     __syncthreads();
     if (tid == 0) {
-        for (int w = 1; w < 4; w++) if (sv[w] > best || (sv[w] == best && si[w] < bi)) { best = sv[w]; bi = si[w]; }
+        for (int w = 1; w < 4; w++) if (sv[w] > best || (sv[w] == best && si[w] > bi)) { best = sv[w]; bi = si[w]; }
         xchg_agent_wait(a.cand_val + blockIdx.x, best); xchg_agent_wait(a.cand_idx + blockIdx.x, bi);   // complete before the counter moves
         const unsigned ticket = atomicAdd(a.counter, 1u);
         s_last = ticket == gridDim.x - 1;
@@ -1845,7 +1845,7 @@ __global__ void __launch_bounds__(256) vq_level_kernel(vq_level_args a) {
     __syncthreads();
     if (!s_last) return;
     // merge: candidates are few (<= 256), one per thread
-    best = -INFINITY; bi = 0x7fffffff;
+    best = -INFINITY; bi = -1;
     if (tid < (int) gridDim.x) { best = ld_agent(a.cand_val + tid); bi = ld_agent(a.cand_idx + tid); }
     __shared__ float mv[256];
     __shared__ int mi[256];
@@ -1854,11 +1854,11 @@ __global__ void __launch_bounds__(256) vq_level_kernel(vq_level_args a) {
     for (int st = 128; st > 0; st >>= 1) {
         if (tid < st) {
             const float v = mv[tid + st]; const int j = mi[tid + st];
-            if (v > mv[tid] || (v == mv[tid] && j < mi[tid])) { mv[tid] = v; mi[tid] = j; }
+            if (v > mv[tid] || (v == mv[tid] && j > mi[tid])) { mv[tid] = v; mi[tid] = j; }
         }
         __syncthreads();
     }
-    const int code = mi[0] == 0x7fffffff ? 0 : mi[0];
+    const int code = mi[0] < 0 ? 0 : mi[0];
     if (tid == 0) { *a.idx_i = code; *a.idx_f = (float) code; *a.counter = 0u; }
     if (a.resid_out) {
         for (int j = tid; j < D; j += 256) {

@@ -203,25 +203,27 @@ __global__ void sum_all_kernel(tdesc dst, tdesc a, int64_t n) {
 }
 void k_sum_all(hipStream_t s, tdesc dst, tdesc a) { sum_all_kernel<<<1, BLOCK, 0, s>>>(dst, a, td_nelements(a)); }
 
+// ggml's CPU argmax keeps overwriting the index while the running maximum equals the element (ggml_vec_argmax_f32), so the LAST
+// maximum of a row wins; an all -inf row yields ne0 - 1
 __global__ void argmax_kernel(tdesc dst, tdesc a) {
     __shared__ float shv[BLOCK];
     __shared__ int shi[BLOCK];
     const int64_t i1 = blockIdx.x;
-    float best = -INFINITY; int bi = 0x7fffffff;
+    float best = -INFINITY; int bi = -1;
     for (int64_t i0 = threadIdx.x; i0 < a.ne[0]; i0 += blockDim.x) {
         const float v = *(const float *) at(a, i0, i1, 0, 0);
-        if (v > best) { best = v; bi = (int) i0; }
+        if (v >= best) { best = v; bi = (int) i0; }
     }
     shv[threadIdx.x] = best; shi[threadIdx.x] = bi;
     __syncthreads();
     for (int st = BLOCK / 2; st > 0; st >>= 1) {
         if ((int) threadIdx.x < st) {
             const float v = shv[threadIdx.x + st]; const int j = shi[threadIdx.x + st];
-            if (v > shv[threadIdx.x] || (v == shv[threadIdx.x] && j < shi[threadIdx.x])) { shv[threadIdx.x] = v; shi[threadIdx.x] = j; }
+            if (v > shv[threadIdx.x] || (v == shv[threadIdx.x] && j > shi[threadIdx.x])) { shv[threadIdx.x] = v; shi[threadIdx.x] = j; }
         }
         __syncthreads();
     }
-    if (threadIdx.x == 0) ((int32_t *) dst.data)[i1] = shi[0] == 0x7fffffff ? 0 : shi[0];
+    if (threadIdx.x == 0) ((int32_t *) dst.data)[i1] = shi[0] < 0 ? 0 : shi[0];
 }
 void k_argmax(hipStream_t s, tdesc dst, tdesc a) { if (a.ne[1]) argmax_kernel<<<(int) a.ne[1], BLOCK, 0, s>>>(dst, a); }
 

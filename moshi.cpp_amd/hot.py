@@ -1,4 +1,5 @@
-"""ctypes binding of include/moshi_hot.h (the host-side hot-path driver inside libggml-mi355x.so)."""
+"""ctypes binding of include/moshi_hot.h (the host-side frame driver + synthetic weights: libmoshi-hot.so, a harness library that calls
+libggml-mi355x.so through the public ggml C API only)."""
 import ctypes as C
 
 MAX_CB = 33

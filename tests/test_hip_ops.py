@@ -66,7 +66,8 @@ def test_scale_clamp_inplace():
 def test_sum_sumrows_argmax():
     a = rnd(3, 4, 1000)
     m = rnd(5, 2048)
-    m[2, 7] = m[2, 900] = 50.0      # tie: first index wins
+    m[2, 7] = m[2, 900] = 50.0      # tie: ggml_vec_argmax_f32 keeps overwriting while max == x[i], so the LAST index wins
+    m[4, :] = -np.inf                # all -inf: ne0 - 1
 
     def build(g):
         x = g.input(a)

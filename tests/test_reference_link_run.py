@@ -30,7 +30,7 @@ def build_and_run(src, args):
     with tempfile.TemporaryDirectory() as d:
         exe = os.path.join(d, "prog")
         cc = subprocess.run(["g++", "-std=c++20", "-O1", "-w", "-I" + os.path.join(gu.ROOT, "include"), "-I" + os.path.join(REF, "include"), "-I" + REF,
-                             os.path.join(HERE, "ref_link", src), "-o", exe, "-L" + lib_dir, "-lggml-mi355x", "-ldl", "-Wl,-rpath," + lib_dir],
+                             os.path.join(HERE, "ref_link", src), "-o", exe, "-L" + lib_dir, "-lmoshi-hot", "-lggml-mi355x", "-ldl", "-Wl,-rpath," + lib_dir],
                             capture_output=True, text=True)
         assert cc.returncode == 0, cc.stderr[-3000:]
         run = subprocess.run([exe, oracle] + [str(a) for a in args], capture_output=True, text=True, timeout=900)
