@@ -30,15 +30,15 @@ from __graft_entry__ import load_oracle, load_package  # noqa: E402
 HBM_PEAK_GBPS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 
 
-def reduce_max_time(dist, dt, device="cuda"):
+def reduce_max_time(dist, dt, device="cuda", group=None):
     """MAX over ranks of the timed-region duration (every rank must have finished its K steps)."""
     if dist is None:
         return dt
     import torch
-    if dist.get_backend() == "gloo":
+    if dist.get_backend(group) == "gloo":
         device = "cpu"
     tt = torch.tensor([dt], device=device, dtype=torch.float64)
-    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX, group=group)
     return float(tt.item())
 
 
@@ -72,26 +72,49 @@ def main():
     ap.add_argument("--backend-flags", type=int, default=0, help="ggml_backend_mi355x_set_flags bits (2 = no hipGraph: use under rocprofv3)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` on its own: start the documented launcher as a CHILD (this process has not touched the GPU and never
+        # will) and leave with its exit code; the workers re-enter main() with RANK / LOCAL_RANK / WORLD_SIZE set
+        import subprocess
+        port = os.environ.get("MASTER_PORT", "29533")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+               "--master-port", port, os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.run(cmd).returncode)
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus}")
     dist = None
     if world > 1:
         import torch
         import torch.distributed as dist
         dev_index = local_rank if args.device is None else args.device
         torch.cuda.set_device(dev_index)
-        if args.dist_backend == "gloo":
-            dist.init_process_group("gloo")
-        else:
+        # One backend for the whole job, decided collectively: every rank first joins a host-side gloo group; RCCL is then tried by
+        # all ranks and the outcome is agreed on over gloo (MIN of the success flags), so no rank is ever left alone in an RCCL barrier.
+        dist.init_process_group("gloo")
+        ctl = dist.group.WORLD
+        if args.dist_backend == "nccl":
+            ok = 1
             try:
-                dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))   # RCCL; control plane only (barrier + max)
-                dist.barrier()                                                                  # forces communicator creation now
-            except Exception as e:   # the data path has no collective: a host-side rendezvous is enough to time the replicas
-                print(f"bench.py: RCCL init failed on rank {rank} ({e}); falling back to gloo for the barrier", file=sys.stderr)
-                if dist.is_initialized():
-                    dist.destroy_process_group()
-                dist.init_process_group("gloo")
+                ctl = dist.new_group(backend="nccl", device_id=torch.device("cuda", dev_index))   # RCCL over xGMI
+                probe = torch.ones(1, device=f"cuda:{dev_index}")
+                dist.all_reduce(probe, group=ctl)                                                    # forces communicator creation now
+                torch.cuda.synchronize()
+                ok = int(probe.item() == world)
+            except Exception as e:
+                print(f"bench.py: RCCL init failed on rank {rank}: {e}", file=sys.stderr)
+                ok = 0
+            flag = torch.tensor([ok])
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)                                              # over gloo
+            if int(flag.item()) == 0:
+                raise SystemExit("bench.py: RCCL could not be initialised on every rank (see above); refusing to time a job on a mixed control plane. "
+                                 "Use --dist-backend gloo for a host-side dry run.")
+        dist_group = ctl
+    else:
+        dist_group = None
 
     pkg = load_package()
     L = pkg.load()
@@ -157,7 +180,7 @@ def main():
         if dist is not None:
             import torch
             torch.cuda.synchronize()
-            dist.barrier()
+            dist.barrier(group=dist_group)
 
     for _ in range(args.warmup):
         frame()
@@ -169,7 +192,7 @@ def main():
         tokens.append(txt.value)
     barrier()
     dt = time.perf_counter() - t0
-    dt = reduce_max_time(dist, dt)
+    dt = reduce_max_time(dist, dt, group=dist_group)
     fps = whole_job_rate(world, args.steps, dt)
     offset_end = L.moshi_hot_offset(m)
 

@@ -50,6 +50,11 @@ struct moshi_hot_config {
     int32_t condition_sum;           // sum_condition F32[dim] added to the embedding sum (lm.h:579-581)
     int32_t dep_schedule_len;        // depformer_weights_per_step_schedule (lm_default.h:71-81); also the Depth ring capacity when dep_context == 0
     int32_t dep_schedule[MOSHI_HOT_MAX_CODEBOOKS];
+    // synthetic weights only: standard deviation of the residual-update projections (out_proj, gating linear_out) relative to the
+    // default 1/sqrt(fan_in); 0 = 1. Values < 1 give a CONTRACTIVE stack (every layer's update is small against the residual stream), on
+    // which ggml's discontinuous roundings no longer compound chaotically: the parity tests then assert bit-exact greedy tokens and 1e-3
+    // logits over many free-running frames at the full benchmark widths (same shapes, types and bytes moved).
+    float   update_scale;
 };
 
 typedef struct moshi_hot_model moshi_hot_model_t;
@@ -114,6 +119,15 @@ GGML_API void    moshi_hot_get_timing(moshi_hot_model_t * m, double * us_per_cal
 // teacher forcing for parity runs: overwrite the tokens the last moshi_hot_lm_step wrote into the delay ring
 GGML_API void    moshi_hot_force_last(moshi_hot_model_t * m, int32_t text_token, const int32_t * audio_tokens);
 GGML_API void    moshi_hot_set_context_fill(moshi_hot_model_t * m, int64_t offset); // jump the Temporal ring to a given fill level (bench only)
+// Parity probe: ONE transformer layer (moshi_streaming_transformer_layer, transformer.h:910-1039) of the Temporal (which = 0) or Depth
+// (which = 1, with weight set `weight_set`) stack on the scratch context, fed x_in F32[dim] at stream position `offset` (mask row, RoPE
+// phase and ring slot as transformer.h:1182-1215 computes them), over the model's own weights and KV ring of that layer (the new K / V
+// rows are written at slot offset % capacity). Every tensor of the graph buffer is poisoned with 0xFF bytes before the compute, so a node
+// a backend never materialised (fused away) reads back as NaN. After the compute `visit` is called for every node in execution order while
+// the buffer is still alive (read values with ggml_backend_tensor_get); x_out (may be NULL) receives the layer output. Returns the node count.
+typedef void (*moshi_hot_node_visitor_t)(void * user, int index, struct ggml_tensor * node);
+GGML_API int     moshi_hot_layer_probe(moshi_hot_model_t * m, int which, int layer, int weight_set, const float * x_in, int offset, float * x_out,
+                                       moshi_hot_node_visitor_t visit, void * user);
 
 #ifdef __cplusplus
 }

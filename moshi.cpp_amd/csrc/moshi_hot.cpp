@@ -93,6 +93,20 @@ struct Builder {
             ggml_backend_tensor_set(e.t, noise_tmp.data(), 0, (size_t) n * 4);
         }
     }
+    // parity probes: every byte of the graph buffer reads 0xFF (NaN as F32 / BF16 / F16) until a kernel or an upload writes it
+    void alloc_poisoned() {
+        buf = ggml_backend_alloc_ctx_tensors(ctx, be);
+        GGML_ASSERT(buf);
+        ggml_backend_buffer_clear(buf, 0xFF);
+        for (auto & c : consts) ggml_backend_tensor_set(c.t, c.data.data(), 0, c.data.size());
+    }
+    void release_scratch() {
+        readbacks.clear(); consts.clear(); exponentials.clear();
+        ggml_backend_buffer_free(buf);
+        buf = nullptr;
+        ggml_reset(ctx);
+        gf = nullptr;
+    }
     void compute() { upload_noise(); if (gf) ggml_backend_graph_compute(be, gf); }
     // scratch protocol: alloc -> upload -> compute -> free -> reset (src/context.h:628-653)
     void expand_read(T t, void * dst) { expand(t); readbacks.push_back({ t, dst, ggml_nbytes(t) }); }
@@ -652,6 +666,7 @@ void make_transformer(moshi_hot_model * m, Transformer & tr, const std::string &
     tr.dim = dim; tr.heads = heads; tr.capacity = capacity; tr.max_period = max_period;
     tr.layers.resize((size_t) n_layers);
     const float s_in = 1.f / sqrtf((float) dim);
+    const float upd = m->cfg.update_scale > 0.f ? m->cfg.update_scale : 1.f;   // contractive variant for tight full-width parity runs (moshi_hot.h)
     auto qgen = [](float sd) { return [sd](T t, Rng & r, std::vector<uint8_t> & o) { gen_quant(t, r, o, sd); }; };
     auto ones = [](T t, Rng &, std::vector<uint8_t> & o) { gen_const(t, 1.f, o); };
     auto zeros = [](T t, Rng &, std::vector<uint8_t> & o) { gen_const(t, 0.f, o); };
@@ -672,10 +687,10 @@ void make_transformer(moshi_hot_model * m, Transformer & tr, const std::string &
         for (int w = 0; w < n_weight_sets; w++) {
             const std::string ws = n_weight_sets > 1 ? "." + std::to_string(w) : "";
             L.in_proj.push_back(W.add(p + "self_attn.in_projs" + ws + ".weight", wtype, dim, 3 * dim, 1, qgen(s_in)));
-            L.out_proj.push_back(W.add(p + "self_attn.out_projs" + ws + ".weight", wtype, dim, dim, 1, qgen(s_in)));
+            L.out_proj.push_back(W.add(p + "self_attn.out_projs" + ws + ".weight", wtype, dim, dim, 1, qgen(s_in * upd)));
             if (!mimi_style) {
                 L.gate_in.push_back(W.add(p + "gating" + ws + ".linear_in.weight", wtype, dim, 2 * ffn_hidden, 1, qgen(s_in)));
-                L.gate_out.push_back(W.add(p + "gating" + ws + ".linear_out.weight", wtype, ffn_hidden, dim, 1, qgen(1.f / sqrtf((float) ffn_hidden))));
+                L.gate_out.push_back(W.add(p + "gating" + ws + ".linear_out.weight", wtype, ffn_hidden, dim, 1, qgen(upd / sqrtf((float) ffn_hidden))));
             }
         }
         L.kcache = state(m, GGML_TYPE_BF16, dim / heads, capacity, heads);
@@ -1327,3 +1342,28 @@ extern "C" void moshi_hot_force_last(moshi_hot_model_t * m, int32_t text_token, 
     for (int q = 0; q < m->cfg.dep_q; q++) m->cache[(size_t) wpos][(size_t) (q + 1)] = audio_tokens[q];
 }
 extern "C" void moshi_hot_set_context_fill(moshi_hot_model_t * m, int64_t offset) { m->temporal.offset = (int) offset; }
+
+extern "C" int moshi_hot_layer_probe(moshi_hot_model_t * m, int which, int layer, int weight_set, const float * x_in, int offset, float * x_out,
+                                     moshi_hot_node_visitor_t visit, void * user) {
+    Transformer & tr = which == 0 ? m->temporal : m->depth;
+    GGML_ASSERT(layer >= 0 && layer < (int) tr.layers.size());
+    Layer & L = tr.layers[(size_t) layer];
+    const bool multi = L.in_proj.size() > 1;
+    GGML_ASSERT(weight_set >= 0 && weight_set < (int) L.in_proj.size());
+    Builder & s = *m->scratch;
+    T x = s.constant(s.tensor(GGML_TYPE_F32, tr.dim, 1, 1), x_in);
+    // the same three inputs transformer_inline derives from the offset (transformer.h:1182-1215), mask row read from the bias table
+    T attn_bias = bias_pattern_index(s, tr, 1, offset);
+    Rot rot;
+    if (tr.max_period) rot = timestep_embedding(s, 1, tr.dim / tr.heads, s.f32((float) offset), tr.max_period);
+    T indices = s.i32s({ offset % tr.capacity });
+    T y = transformer_layer(s, tr, L, weight_set, indices, x, attn_bias, tr.max_period ? &rot : nullptr, multi);
+    s.expand(y);
+    s.alloc_poisoned();
+    s.compute();
+    if (x_out) ggml_backend_tensor_get(y, x_out, 0, (size_t) tr.dim * 4);
+    const int n = ggml_graph_n_nodes(s.gf);
+    if (visit) for (int i = 0; i < n; i++) visit(user, i, ggml_graph_node(s.gf, i));
+    s.release_scratch();
+    return n;
+}

@@ -16,7 +16,7 @@ class Config(C.Structure):
                [(n, C.c_int32) for n in ("personaplex", "extra_heads", "extra_heads_dim",
                                          "demux_second_stream", "depformer_low_rank", "delay_steps", "cross_attention", "cross_len",
                                          "condition_sum", "dep_schedule_len")] + \
-               [("dep_schedule", C.c_int32 * MAX_CB)]
+               [("dep_schedule", C.c_int32 * MAX_CB), ("update_scale", C.c_float)]
 
     @property
     def io_dep_q(self):
@@ -52,7 +52,9 @@ SIGNATURES = {
     "moshi_hot_set_timing": (None, [P, C.c_int]),
     "moshi_hot_get_timing": (None, [P, P]),
     "moshi_hot_last_raw_tokens": (None, [P, P, P]),
+    "moshi_hot_layer_probe": (C.c_int, [P, C.c_int, C.c_int, C.c_int, P, C.c_int, P, P, P]),
 }
+NODE_VISITOR = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_void_p)
 
 
 def attach(lib):

@@ -421,3 +421,19 @@ def test_batched_q4k_matmul_gated_rows_and_residual(n, M, T):
     gu.compare(build, atol_rel=2e-6)
     _, st = gu.run_graph("hip", build)
     assert st.kernels_in_last_plan == 1, st.kernels_in_last_plan
+
+
+@pytest.mark.parametrize("kind", ["q4_K", "q8_0", "q4_0"])
+def test_quantised_matvec_against_the_numpy_golden_vectors(kind):
+    # the device against tests/golden/quant.npz directly (independent numpy block arithmetic, tests/golden/make_golden.py), not via the oracle
+    import os
+    Q = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "quant.npz"))
+    w = Q[kind + "_w"]
+    gt = {"q4_K": gu.Q4_K, "q8_0": gu.Q8_0, "q4_0": gu.Q4_0}[kind]
+
+    def build(g):
+        return [g.mul_mat(g.input_raw(w, gt, Q["x"].size, w.shape[0]), g.input(Q["x"]))]
+    for flags in (0, 1):
+        y = gu.run_graph("hip", build, flags=flags)[0][0].reshape(-1)
+        ref = Q[kind + "_y"]
+        assert np.abs(y - ref).max() <= 2e-6 * np.abs(ref).max(), (kind, flags, np.abs(y - ref).max())

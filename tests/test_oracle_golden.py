@@ -125,3 +125,50 @@ def test_rvq_nearest_centroid():
         c = g.div(g.input(np.ones((1, ne1, n), np.float32)), c)
         return [g.argmax(c)]
     assert np.array_equal(oracle(build)[0].reshape(-1), G["vq_idx"])
+
+
+# ---- block-quantised mat-vec against tests/golden/quant.npz: an independent numpy restatement of ggml's block layouts and of its
+# ---- quantise-the-activation-then-integer-dot arithmetic (generator: tests/golden/make_golden.py, second half) --------------------
+Q = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "quant.npz"))
+QTYPES = {"q4_K": gu.Q4_K, "q8_0": gu.Q8_0, "q4_0": gu.Q4_0}
+
+
+def quant_matvec_build(kind):
+    w = Q[kind + "_w"]
+    K = Q["x"].size
+
+    def build(g):
+        wt = g.input_raw(w, QTYPES[kind], K, w.shape[0])
+        return [g.mul_mat(wt, g.input(Q["x"]))]
+    return build
+
+
+@pytest.mark.parametrize("kind", ["q4_K", "q8_0", "q4_0"])
+def test_quantised_matvec_matches_the_numpy_block_arithmetic(kind):
+    y = oracle(quant_matvec_build(kind))[0]
+    close(y, Q[kind + "_y"], 1e-6)      # same integers, same per-block float products; only the order of the final block sum differs
+
+
+@pytest.mark.parametrize("kind", ["q4_K", "q4_0"])
+def test_dequantise_rows_exact(kind):
+    got = gu.dequantize(Q[kind + "_w"], QTYPES[kind], Q["x"].size)
+    assert np.array_equal(got, Q[kind + "_deq"])
+
+
+def test_activation_quantisers_exact():
+    from __graft_entry__ import load_oracle
+    olib = load_oracle().load()
+    x = np.ascontiguousarray(Q["x"])
+    nb = x.size // 256
+    out = np.zeros(nb * 292, np.uint8)      # block_q8_K {f32 d; i8 q[256]; i16 bsums[16]}
+    olib.oracle_quantize_row(15, x.ctypes.data, out.ctypes.data, x.size)
+    blk = out.reshape(nb, 292)
+    assert np.array_equal(blk[:, 4:260].view(np.int8).reshape(-1), Q["x_q8k_q"].reshape(-1))
+    assert np.array_equal(blk[:, 0:4].view(np.float32).reshape(-1), Q["x_q8k_d"])
+    bs = blk[:, 260:292].view(np.int16).reshape(nb, 16)
+    assert np.array_equal(bs, Q["x_q8k_q"].reshape(nb, 16, 16).astype(np.int32).sum(-1))
+    out = np.zeros(x.size // 32 * 34, np.uint8)
+    olib.oracle_quantize_row(8, x.ctypes.data, out.ctypes.data, x.size)
+    blk = out.reshape(-1, 34)
+    assert np.array_equal(blk[:, 2:].view(np.int8).reshape(-1), Q["x_q80_q"].reshape(-1))
+    assert np.array_equal(blk[:, 0:2].view(np.float16).astype(np.float32).reshape(-1), Q["x_q80_d"])
