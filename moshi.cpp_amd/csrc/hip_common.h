@@ -113,6 +113,8 @@ void k_matvec(hipStream_t s, const mv_args & a);
 // gated-FFN activation silu(h[:K]) * h[K:] quantised to padded Q8_K blocks (K/256 x 304 B) for a following MV_PREQ8K mat-vec
 #define MV_XBLK_BYTES 304
 void k_gate_quant_q8k(hipStream_t s, const float * h, int64_t K, void * out_blocks, int wtype);   // activation format follows the weight type
+// alpha * rms_norm(x) quantised once to the same padded blocks (K <= 4096); n_out (optional) receives the normed floats
+void k_norm_quant_q8k(hipStream_t s, const float * x, const float * alpha, float eps, int64_t K, void * out_blocks, int wtype, float * n_out);
 // batched Q4_K mat-mul for prompt prefill (T = 2..64 activation rows): rows quantised to Q8_K into `ws`, then 16x16x32 int8 MFMA tiles
 size_t k_mm_q4k_batched_ws_size(int64_t K, int64_t T);
 bool k_mm_q4k_batched_supported(int wtype, int64_t K, int64_t M, int64_t T);

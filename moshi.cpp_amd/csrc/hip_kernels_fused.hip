@@ -351,6 +351,18 @@ __global__ void __launch_bounds__(NW * 64) matvec_q4k_kernel(mv_args a, int rows
         }
     };
     if (PRO != MV_PREQ8K && PRO != MV_ATTN) load_batch(0);
+    // MV_PREQ8K: the activation arrives quantised (norm_quant / gate_quant kernels): nb padded Q8_K blocks of 304 B = nb * 19 chunks of 16 B,
+    // at most 3 per thread (K <= 16384 at 256 threads); requested ahead of the weight tile for the same reason
+    constexpr int PQ_MAX = 4;
+    u32x4 pq[PQ_MAX];
+    if (PRO == MV_PREQ8K) {
+        const int nchunk = nb * (XBLK_BYTES / 16);
+#pragma unroll
+        for (int j = 0; j < PQ_MAX; j++) {
+            const int i = tid + j * NW * 64;
+            pq[j] = ((const u32x4 *) a.x)[i < nchunk ? i : nchunk - 1];
+        }
+    }
     __builtin_amdgcn_sched_barrier(0);   // keep the activation loads ahead of the weight tile in program (= return) order
 
     u32x4 r[NLOAD];
@@ -386,9 +398,13 @@ __global__ void __launch_bounds__(NW * 64) matvec_q4k_kernel(mv_args a, int rows
             quantize_block(xs + wave, v);
         }
     } else if (PRO == MV_PREQ8K) {
-        // activations were quantised by gate_quant_q8k_kernel: copy the padded Q8_K blocks (304 B each) into LDS
-        const u32x4 * src = (const u32x4 *) a.x;
-        for (int i = tid; i < nb * (XBLK_BYTES / 16); i += NW * 64) ((u32x4 *) xs)[i] = src[i];
+        // activations were quantised once by norm_quant / gate_quant: the padded Q8_K blocks (304 B each) go to LDS as they are
+        const int nchunk = nb * (XBLK_BYTES / 16);
+#pragma unroll
+        for (int j = 0; j < PQ_MAX; j++) {
+            const int i = tid + j * NW * 64;
+            if (i < nchunk) ((u32x4 *) xs)[i] = pq[j];
+        }
     } else {
         for (int base = 0; base < K; base += NW * 1024) {
             if (base > 0) load_batch(base);
@@ -805,6 +821,36 @@ __global__ void __launch_bounds__(64) gate_quant_kernel(const float * h, int K, 
     if (g_out) *(float4 *) (g_out + e) = make_float4(v[0], v[1], v[2], v[3]);
     if (FMT == MVF_Q4K) quantize_block_q8k(out + b, v, lane); else quantize_block_q80((xblk80 *) (out + b), v, lane);
 }
+// alpha * rms_norm(x) quantised ONCE to padded Q8_K / Q8_0 blocks (K <= 4096: one workgroup of K / 4 threads, wave w owns block w; the
+// whole vector lives in registers between the statistics and the quantiser). The mat-vecs that consume it (MV_PREQ8K) then start with a
+// 4.8 KB copy instead of re-reading 32 KB and redoing the norm in each of their 256 workgroups.
+template <int FMT>
+__global__ void __launch_bounds__(1024) norm_quant_kernel(const float * x, const float * alpha, float eps, int K, xblk * out, float * n_out) {
+    __shared__ double sh[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
+    const float4 x4 = *(const float4 *) (x + tid * 4), a4 = *(const float4 *) (alpha + tid * 4);
+    float v[4] = { x4.x, x4.y, x4.z, x4.w };
+    const float al[4] = { a4.x, a4.y, a4.z, a4.w };
+    double acc = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) acc += (double) (v[k] * v[k]);
+    acc = wave_allsum_f64(acc);
+    if (lane == 0) sh[wave] = acc;
+    __syncthreads();
+    double tot = 0;
+    for (int w = 0; w < nw; w++) tot += sh[w];
+    const float scale = 1.0f / sqrtf((float) (tot / (double) K) + eps);
+#pragma unroll
+    for (int k = 0; k < 4; k++) v[k] = al[k] * (v[k] * scale);
+    if (n_out) *(float4 *) (n_out + tid * 4) = make_float4(v[0], v[1], v[2], v[3]);
+    if (FMT == MVF_Q4K) quantize_block_q8k(out + wave, v, lane); else quantize_block_q80((xblk80 *) (out + wave), v, lane);
+}
+void k_norm_quant_q8k(hipStream_t s, const float * x, const float * alpha, float eps, int64_t K, void * out_blocks, int wtype, float * n_out) {
+    GGML_ASSERT(K % 256 == 0 && K <= 4096);
+    if (wtype == GGML_TYPE_Q4_K) norm_quant_kernel<MVF_Q4K><<<1, (int) (K / 4), 0, s>>>(x, alpha, eps, (int) K, (xblk *) out_blocks, n_out);
+    else norm_quant_kernel<MVF_Q80><<<1, (int) (K / 4), 0, s>>>(x, alpha, eps, (int) K, (xblk *) out_blocks, n_out);
+}
+
 void k_gate_quant_q8k(hipStream_t s, const float * h, int64_t K, void * out_blocks, int wtype) {
     if (wtype == GGML_TYPE_Q4_K) gate_quant_kernel<MVF_Q4K><<<(int) (K / 256), 64, 0, s>>>(h, (int) K, (xblk *) out_blocks, nullptr);
     else gate_quant_kernel<MVF_Q80><<<(int) (K / 256), 64, 0, s>>>(h, (int) K, (xblk *) out_blocks, nullptr);

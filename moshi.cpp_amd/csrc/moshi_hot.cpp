@@ -590,8 +590,9 @@ T codebook_encode(Builder & g, Codebook & cb, T x) {
     return ggml_argmax(g, d);
 }
 // moshi_rvq_encode + moshi_residual_vq_encode (vq.h:32-45, core_vq.h:171-194)
-T rvq_encode(Builder & g, Rvq & rvq, T x) {
+T rvq_encode(Builder & g, Rvq & rvq, T x, T * latent = nullptr) {
     x = ggml_conv_1d(g, rvq.input_proj, x, 1, 0, 1);
+    if (latent) *latent = x;
     T residual = x, out = nullptr;
     for (int i = 0; i < rvq.n_q; i++) {
         T xp = ggml_permute(g, residual, 1, 0, 2, 3);
@@ -645,6 +646,7 @@ struct moshi_hot_model {
     std::vector<Conv> enc_convs; std::vector<ResBlock> enc_res;
     Builder * g_dec = nullptr; T dec_codes = nullptr, dec_frame = nullptr; int dec_T = 0;
     Builder * g_enc = nullptr; T enc_frame = nullptr, enc_codes = nullptr; int enc_T = 0;
+    T enc_latent[2] = { nullptr, nullptr };   // the projected latents the two RVQ stacks quantise (inputs of their first levels), for tie analysis in tests
 
     std::vector<int32_t> tokens_tmp;
     int32_t last_text = 0; std::vector<int32_t> last_audio;   // raw (un-delayed) tokens of the last step
@@ -874,8 +876,8 @@ void build_encode_graph(moshi_hot_model * m) {
     x = ggml_transpose(g, x);
     x = streaming_conv(g, m->downsample, x);
     // moshi_split_rvq_encode (vq.h:97-114)
-    T codes = rvq_encode(g, m->rvq_first, x);
-    if (c.mimi_n_q > 1) codes = ggml_concat(g, codes, rvq_encode(g, m->rvq_rest, x), 1);
+    T codes = rvq_encode(g, m->rvq_first, x, &m->enc_latent[0]);
+    if (c.mimi_n_q > 1) codes = ggml_concat(g, codes, rvq_encode(g, m->rvq_rest, x, &m->enc_latent[1]), 1);
     codes = ggml_cast(g, codes, GGML_TYPE_I32);
     m->enc_codes = codes;
     g.expand(codes);
@@ -1321,6 +1323,8 @@ extern "C" int moshi_hot_read_last(moshi_hot_model_t * m, const char * what, flo
     else if (!strcmp(what, "transformer_out")) t = m->transformer_out;
     else if (!strcmp(what, "transformer_in")) t = m->g_transformer_in;     // sum of the 17 embeddings (input of the Temporal stack)
     else if (!strcmp(what, "stack_out")) t = m->g_stack_out;               // output of the Temporal stack, before out_norm
+    else if (!strcmp(what, "enc_latent_first")) t = m->enc_latent[0];
+    else if (!strcmp(what, "enc_latent_rest")) t = m->enc_latent[1];
     else if (!strncmp(what, "dep_logits", 10)) { const int k = atoi(what + 10); if (k >= 0 && k < (int) m->dep_logits.size()) t = m->dep_logits[(size_t) k]; }
     if (!t || ggml_nelements(t) < n) return -1;
     ggml_backend_tensor_get(t, out, 0, (size_t) n * 4);

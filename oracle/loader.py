@@ -16,8 +16,9 @@ def load():
     global _lib
     if _lib is None:
         path = os.path.join(_HERE, "liboracle.so")
-        if not os.path.exists(path):
-            build()
+        import shutil
+        if not os.path.exists(path) or (shutil.which("make") and shutil.which("g++") and os.path.getmtime(path) < os.path.getmtime(os.path.join(_HERE, "oracle.cpp"))):
+            build()   # never check against a stale build of the checker
         lib = C.CDLL(path)
         lib.oracle_graph_compute.restype = C.c_int
         lib.oracle_graph_compute.argtypes = [C.c_void_p, C.c_int]
