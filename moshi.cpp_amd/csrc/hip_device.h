@@ -210,6 +210,15 @@ __device__ __forceinline__ void q4k_unpack_scales(const uint8_t * scales, uint32
     mn[1] = ((u2 >> 4) & kmask2) | (((u1 >> 6) & kmask3) << 4);
 }
 
+// the same from the three scale words held in registers
+__device__ __forceinline__ void q4k_unpack_scales_w(uint32_t u0, uint32_t u1, uint32_t u2, uint32_t sc[2], uint32_t mn[2]) {
+    const uint32_t kmask1 = 0x3f3f3f3fu, kmask2 = 0x0f0f0f0fu, kmask3 = 0x03030303u;
+    sc[0] = u0 & kmask1;
+    sc[1] = (u2 & kmask2) | (((u0 >> 6) & kmask3) << 4);
+    mn[0] = u1 & kmask1;
+    mn[1] = ((u2 >> 4) & kmask2) | (((u1 >> 6) & kmask3) << 4);
+}
+
 __device__ __forceinline__ float dequant_elem(const char * row, int type, int64_t i) {
     switch (type) {
         case GGML_TYPE_F32:  return ((const float *) row)[i];

@@ -61,8 +61,24 @@ __device__ float block_rms_scale(const float * x, int64_t K, float eps, double *
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-// diagnostic build only (-DMV_STAMPS, tests/microbench/mv_bench.hip): per-phase s_memtime stamps of wave 0 of each workgroup
-#ifdef MV_STAMPS
+// diagnostic builds only. -DMV_STAMPS (tests/microbench/mv_bench.hip): per-phase s_memtime stamps of wave 0 of each workgroup.
+// -DMV_LOG (tests/microbench/frame_stamps.py): one record per LAUNCH, taken by workgroup 0 / wave 0 - phase stamps, start / end in
+// s_memrealtime ticks (10 ns), shape - so that a graph-replayed frame shows every mat-vec's in-kernel phases and the gaps between kernels.
+#if defined(MV_LOG)
+__device__ unsigned long long g_mv_log[8192][24];
+__device__ unsigned g_mv_launch;
+#define MV_STAMP(i) do { if (blockIdx.x == 0 && tid == 0) { if ((i) == 0) mv_log_id = atomicAdd(&g_mv_launch, 1u) & 8191u; unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); g_mv_log[mv_log_id][i] = t_; \
+    if ((i) == 0 || (i) == 7) { unsigned long long r_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(r_) :: "memory"); g_mv_log[mv_log_id][16 + ((i) == 7)] = r_; } \
+    if ((i) == 0) { g_mv_log[mv_log_id][18] = (unsigned long long) a.K | ((unsigned long long) a.M << 32); g_mv_log[mv_log_id][19] = (unsigned long long) PRO | ((unsigned long long) WS << 8) | ((unsigned long long) gridDim.x << 32); } } } while (0)
+extern "C" __attribute__((visibility("default"))) int mi355x_mv_log_read(unsigned long long * out, int max_records) {
+    unsigned n = 0;
+    if (hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_mv_launch), 4) != hipSuccess) return -1;
+    const int m = (int) (n < 8192u ? n : 8192u) < max_records ? (int) (n < 8192u ? n : 8192u) : max_records;
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_mv_log), (size_t) m * 24 * 8) != hipSuccess) return -1;
+    const unsigned z = 0; (void) hipMemcpyToSymbol(HIP_SYMBOL(g_mv_launch), &z, 4);
+    return (int) n;
+}
+#elif defined(MV_STAMPS)
 __device__ unsigned long long g_mv_stamps[4096][8];
 __device__ unsigned long long g_mv_real[4096][2];
 #define MV_STAMP(i) do { if (lane == 0 && wave == 0 && blockIdx.x < 4096) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); g_mv_stamps[blockIdx.x][i] = t_; \
@@ -178,7 +194,7 @@ __device__ __forceinline__ void quantize_block_q8k(xblk * dst, const float v[4],
 // Attention of NH (2 or 4) consecutive heads by ONE wave, for a single new token over a short ring (C <= 8 slots of D = 64): the Depth
 // transformer's shape. Same arithmetic, in the same order, as attn_decode_kernel below restricted to the one wave that has work
 // there (lane = (slot, 8-dim chunk)). Every global load of all four heads (q/k/v, ring rows) is requested before the first use, so
-// the whole thing costs about one memory round trip. 256 outputs land in xa (LDS); `wbuf` is >= 768 floats of wave-private LDS.
+// the whole thing costs about one memory round trip. NH x 64 outputs land in xa (LDS); `wbuf` is >= 1792 floats (7 KB) of wave-private LDS.
 template <int NH>
 __device__ __forceinline__ void attn_small_wave(const attn_args & a, int h0, int lane, float * wbuf, float * xa, bool write_cache) {
     constexpr int LPS = 8, half = 32;
@@ -226,80 +242,75 @@ __device__ __forceinline__ void attn_small_wave(const attn_args & a, int h0, int
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    double osum[NH][8], ohalf[NH];
+    // P x V: every lane forms the 8 products of its (slot, 8-dim chunk) - exact in float, both factors being BF16 values - and parks them in
+    // LDS as [slot][dim]; lane j then adds the 8 slots of dim j in double, in slot order: the oracle's accumulation order, one LDS round trip
+    // per pair of heads (the previous form tree-summed 8 doubles per lane through LDS in two rounds per head).
+    float * prod = wbuf + 768;   // 2 heads x 8 slots x 64 dims floats = 4 KB behind the q / k / v scratch
 #pragma unroll
-    for (int hh = 0; hh < NH; hh++) {
-        const float * qf = wbuf + hh * 192, * knew = qf + 64, * vnew = qf + 128;
-        float qv[8];
+    for (int hp = 0; hp < NH; hp += 2) {
 #pragma unroll
-        for (int i = 0; i < 8; i++) qv[i] = qf[dl + i];
-        double acc = 0;
-        if (live) {
-            if (fresh) {
+        for (int hq = 0; hq < 2; hq++) {
+            const int hh = hp + hq;
+            const float * qf = wbuf + hh * 192, * knew = qf + 64, * vnew = qf + 128;
+            float qv[8];
 #pragma unroll
-                for (int i = 0; i < 8; i++) acc += (double) (knew[dl + i] * qv[i]);
-            } else {
-                const uint32_t kw[4] = { kq[hh].x, kq[hh].y, kq[hh].z, kq[hh].w };
+            for (int i = 0; i < 8; i++) qv[i] = qf[dl + i];
+            double acc = 0;
+            if (live) {
+                if (fresh) {
 #pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    acc += (double) (bf2f((uint16_t) (kw[i] & 0xffff)) * qv[2 * i]);
-                    acc += (double) (bf2f((uint16_t) (kw[i] >> 16)) * qv[2 * i + 1]);
+                    for (int i = 0; i < 8; i++) acc += (double) (knew[dl + i] * qv[i]);
+                } else {
+                    const uint32_t kw[4] = { kq[hh].x, kq[hh].y, kq[hh].z, kq[hh].w };
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        acc += (double) (bf2f((uint16_t) (kw[i] & 0xffff)) * qv[2 * i]);
+                        acc += (double) (bf2f((uint16_t) (kw[i] >> 16)) * qv[2 * i + 1]);
+                    }
                 }
             }
-        }
-        acc = group_allsum_f64(acc, LPS);
-        const float sv = live ? (float) acc * a.scale + m : -INFINITY;
-        const float gmax = wave_allmax_f32(sv);
-        const float e = sv > -INFINITY ? expf(sv - gmax) : 0.f;
-        double lsum = (lane % LPS) == 0 ? (double) e : 0.0;   // one representative per slot
-        lsum = wave_allsum_f64(lsum);
-        const float inv = (float) (1.0 / lsum);
-        const float pr = bf2f(f2bf(e * inv));
-        double o8[8];
+            acc = group_allsum_f64(acc, LPS);
+            const float sv = live ? (float) acc * a.scale + m : -INFINITY;
+            const float gmax = wave_allmax_f32(sv);
+            const float e = sv > -INFINITY ? expf(sv - gmax) : 0.f;
+            double lsum = (lane % LPS) == 0 ? (double) e : 0.0;   // one representative per slot
+            lsum = wave_allsum_f64(lsum);
+            const float inv = (float) (1.0 / lsum);
+            const float pr = bf2f(f2bf(e * inv));
+            float pf[8];
 #pragma unroll
-        for (int i = 0; i < 8; i++) o8[i] = 0;
-        if (pr != 0.f) {
-            if (fresh) {
+            for (int i = 0; i < 8; i++) pf[i] = 0.f;
+            if (pr != 0.f) {
+                if (fresh) {
 #pragma unroll
-                for (int i = 0; i < 8; i++) o8[i] += (double) (vnew[dl + i] * pr);
-            } else {
-                const uint32_t vw[4] = { vq[hh].x, vq[hh].y, vq[hh].z, vq[hh].w };
+                    for (int i = 0; i < 8; i++) pf[i] = vnew[dl + i] * pr;
+                } else {
+                    const uint32_t vw[4] = { vq[hh].x, vq[hh].y, vq[hh].z, vq[hh].w };
 #pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    o8[2 * i]     += (double) (bf2f((uint16_t) (vw[i] & 0xffff)) * pr);
-                    o8[2 * i + 1] += (double) (bf2f((uint16_t) (vw[i] >> 16)) * pr);
+                    for (int i = 0; i < 4; i++) {
+                        pf[2 * i]     = bf2f((uint16_t) (vw[i] & 0xffff)) * pr;
+                        pf[2 * i + 1] = bf2f((uint16_t) (vw[i] >> 16)) * pr;
+                    }
                 }
             }
+            float * dst = prod + hq * 512 + sub * 64 + dl;
+            *(float4 *) dst = make_float4(pf[0], pf[1], pf[2], pf[3]);
+            *(float4 *) (dst + 4) = make_float4(pf[4], pf[5], pf[6], pf[7]);
         }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
-        for (int i = 0; i < 8; i++) osum[hh][i] = o8[i];   // summed over the 8 slot groups below, through LDS (48 cross-lane permutes per head otherwise)
-    }
-    // cross-group sums for all four heads at once, through the wave's output buffer region
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    double * ored = (double *) wbuf;   // the q/k/v scratch (768 floats) is dead by now: 4 groups x 64 dims of doubles per round
+        for (int hq = 0; hq < 2; hq++) {
+            double tot = 0;
 #pragma unroll
-    for (int hh = 0; hh < NH; hh++) {
-        // two rounds of 4 slot groups each (8 x 64 doubles would not fit the scratch); lane j ends up with dim j
-#pragma unroll
-        for (int half_g = 0; half_g < 2; half_g++) {
-            if ((sub >> 2) == half_g) {
-#pragma unroll
-                for (int i = 0; i < 8; i++) ored[(sub & 3) * 64 + dl + i] = osum[hh][i];
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            const double part = (ored[lane] + ored[64 + lane]) + (ored[128 + lane] + ored[192 + lane]);
-            if (half_g == 0) ohalf[hh] = part; else ohalf[hh] = ohalf[hh] + part;
-            __builtin_amdgcn_wave_barrier();
+            for (int c2 = 0; c2 < 8; c2++) tot += (double) prod[hq * 512 + c2 * 64 + lane];
+            xa[(hp + hq) * 64 + lane] = (float) tot;
         }
-        xa[hh * 64 + lane] = (float) ohalf[hh];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
 // One workgroup = 4 waves = `rows_per_wg` output rows.
@@ -308,20 +319,31 @@ __device__ __forceinline__ void attn_small_wave(const attn_args & a, int h0, int
 //           16-block batch are issued before any of them is used, so the phase costs ~one L2 round trip
 //  phase 3: tiles stream registers -> LDS image -> one super-block per lane (next tile prefetched first)
 //  phase 4: fixed-order row sums (+ residual)
-template <int PRO, int NW, int FMT = MVF_Q4K>
+//
+// WS = 1 (small matrices, Q4_K): no LDS tiles. Eight lanes share a super-block - every lane requests the 16-byte header (d, dmin, 6-bit scales;
+// one fetch for the group) and ONE 16-byte nibble chunk, all passes up front - so a wave covers 8 super-blocks per pass with 1/8 of the integer
+// work per lane. The Depth mat-vecs are a few tiles in all: with a super-block per lane 192 waves did ~2 000 cycles of serial dot4 / unpack each
+// while 3/4 of the chip's SIMDs idled; this way the dot phase is ~300 cycles. Same integers, same per-super-block float expression.
+#define MVD_PMAX 4   // passes (super-blocks per lane group) a workgroup can hold in registers: rows * nb <= MVD_PMAX * NW * 8
+template <int PRO, int NW, int FMT = MVF_Q4K, int WS = 0>
 __global__ void __launch_bounds__(NW * 64) matvec_q4k_kernel(mv_args a, int rows_per_wg, attn_args at) {
     constexpr int SB = mvfmt<FMT>::SB, NLOAD = mvfmt<FMT>::NLOAD, TILE = 64 * SB;   // bytes per lane-chunk / 16-byte loads per lane per tile
+    static_assert(WS == 0 || FMT == MVF_Q4K, "the direct layout is written for Q4_K super-blocks");
     auto quantize_block = [&](xblk * dst, const float v[4]) {
         if (FMT == MVF_Q4K) quantize_block_q8k(dst, v, threadIdx.x & 63); else quantize_block_q80((xblk80 *) dst, v, threadIdx.x & 63);
     };
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ double sh_red[NW];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#if defined(MV_LOG)
+    unsigned mv_log_id = 0;
+#endif
     constexpr int nwaves = NW;
     const int nb = (int) (a.K / 256);
+    constexpr int STAGE = (WS == 0 || PRO == MV_ATTN) ? TILE : 0;   // wave-private staging area (weight tiles; scratch of the attention prologue)
     xblk * xs = (xblk *) smem;
-    char * stage = smem + nb * XBLK_BYTES + wave * TILE;
-    float * part = (float *) (smem + nb * XBLK_BYTES + nwaves * TILE);
+    char * stage = smem + nb * XBLK_BYTES + wave * STAGE;
+    float * part = (float *) (smem + nb * XBLK_BYTES + nwaves * STAGE);
 
     const int64_t row0 = (int64_t) blockIdx.x * rows_per_wg;
     const int rows = (int) (a.M - row0 < rows_per_wg ? a.M - row0 : rows_per_wg);
@@ -365,15 +387,34 @@ __global__ void __launch_bounds__(NW * 64) matvec_q4k_kernel(mv_args a, int rows
     }
     __builtin_amdgcn_sched_barrier(0);   // keep the activation loads ahead of the weight tile in program (= return) order
 
-    u32x4 r[NLOAD];
+    u32x4 r[WS == 0 ? NLOAD : 1];
+    u32x4 dh[WS == 1 ? MVD_PMAX : 1], dq[WS == 1 ? MVD_PMAX : 1];   // WS = 1: header / nibble chunk of this lane group's super-block, per pass
     int t = wave;
-    {   // unconditional (no branch around a load, see above): chunks past the end re-read the last valid chunk, and a wave without
+    if (WS == 0) {   // unconditional (no branch around a load, see above): chunks past the end re-read the last valid chunk, and a wave without
         // a tile reads chunk 0 in every lane - one 16-byte request instead of a 9 KB tile in the CU's load queue; neither is consumed
         const bool has_tile = t < ntiles;
 #pragma unroll
         for (int i = 0; i < NLOAD; i++) {
             const int g = t * (NLOAD * 64) + i * 64 + lane;
             r[i] = __builtin_nontemporal_load(wsrc + (has_tile ? (g < nchunks ? g : nchunks - 1) : 0));
+        }
+    } else {
+#pragma unroll
+        for (int p = 0; p < MVD_PMAX; p++) {
+            const int sb = p * (NW * 8) + wave * 8 + (lane >> 3);
+            const u32x4 * src = wsrc + (sb < nblk ? sb : nblk - 1) * 9;
+            dh[p] = __builtin_nontemporal_load(src);
+            dq[p] = __builtin_nontemporal_load(src + 1 + (lane & 7));
+        }
+    }
+    // the residual of this thread's rows (phase 4) rides behind the first weight loads: its round trip used to sit, exposed, at the very end
+    float res_pre[4];
+    {
+        const float * rp = a.residual ? a.residual : a.y;   // (no branch around a load) y is valid memory of the same extent
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int rr = (tid >> 4) + k * (NW * 4);
+            res_pre[k] = rp[row0 + (rr < rows ? rr : 0)];
         }
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -385,7 +426,7 @@ __global__ void __launch_bounds__(NW * 64) matvec_q4k_kernel(mv_args a, int rows
         // heads are spread over all NW waves (H / NW = 2 or 4 each: the serial arithmetic of one head is ~0.5 us), the outputs meet
         // in a buffer carved from wave 0's staging area, then the first K / 256 waves quantise one block each
         float * wbuf = (float *) stage;
-        float * xa_all = (float *) (smem + nb * XBLK_BYTES + 4096);   // bytes 4096 .. 4096 + 4 K of wave 0's 9 KB (its own scratch uses < 4 KB)
+        float * xa_all = part + rows_per_wg * nb;   // 4 KB behind the partial sums (the waves' own scratch fills 7 of their 9 KB)
         const int hpw = at.H / NW;
         if (hpw == 4) attn_small_wave<4>(at, wave * 4, lane, wbuf, xa_all + wave * 256, blockIdx.x == 0);
         else          attn_small_wave<2>(at, wave * 2, lane, wbuf, xa_all + wave * 128, blockIdx.x == 0);
@@ -457,7 +498,41 @@ __global__ void __launch_bounds__(NW * 64) matvec_q4k_kernel(mv_args a, int rows
     MV_STAMP(3);
 
     // phase 3
-    for (; t < ntiles; t += nwaves) {
+    if (WS == 1) {
+#pragma unroll
+        for (int p = 0; p < MVD_PMAX; p++) {
+            const int sb = p * (NW * 8) + wave * 8 + (lane >> 3);
+            if (p * (NW * 8) >= nblk) break;
+            const int j8 = lane & 7, g32 = j8 >> 1, hf = j8 & 1;
+            const xblk * xb = xs + ((sb < nblk ? sb : nblk - 1) % nb);
+            const uint32_t hw[4] = { dh[p].x, dh[p].y, dh[p].z, dh[p].w };
+            uint32_t sc[2], mn[2];
+            q4k_unpack_scales_w(hw[1], hw[2], hw[3], sc, mn);
+            const u32x4 ylo = *(const u32x4 *) (xb->q + 64 * g32 + 16 * hf), yhi = *(const u32x4 *) (xb->q + 64 * g32 + 32 + 16 * hf);
+            const uint32_t qw[4] = { dq[p].x, dq[p].y, dq[p].z, dq[p].w }, yl[4] = { ylo.x, ylo.y, ylo.z, ylo.w }, yh[4] = { yhi.x, yhi.y, yhi.z, yhi.w };
+            int lo = 0, hi = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                lo = dot4_i8((int) (qw[k] & 0x0F0F0F0Fu), (int) yl[k], lo);
+                hi = dot4_i8((int) ((qw[k] >> 4) & 0x0F0F0F0Fu), (int) yh[k], hi);
+            }
+            const int i0 = 2 * g32, i1 = 2 * g32 + 1;
+            const int s0 = (int) ((sc[i0 >> 2] >> (8 * (i0 & 3))) & 0xff), s1 = (int) ((sc[i1 >> 2] >> (8 * (i1 & 3))) & 0xff);
+            int isum = __mul24(s0, lo) + __mul24(s1, hi);
+            // mins: lane j8 takes sub-block j8
+            const uint32_t bs2 = *(const uint32_t *) (xb->bsums + 2 * j8);
+            const int bs = (int) (int16_t) (bs2 & 0xffff) + (int) (int16_t) (bs2 >> 16);
+            int msum = __mul24((int) ((mn[j8 >> 2] >> (8 * (j8 & 3))) & 0xff), bs);
+            isum += dpp_i32<DPP_QUAD_XOR1>(isum); msum += dpp_i32<DPP_QUAD_XOR1>(msum);
+            isum += dpp_i32<DPP_QUAD_XOR2>(isum); msum += dpp_i32<DPP_QUAD_XOR2>(msum);
+            isum += dpp_i32<DPP_HALF_MIRROR>(isum); msum += dpp_i32<DPP_HALF_MIRROR>(msum);
+            if (j8 == 0 && sb < nblk) {
+                const float d = h2f((uint16_t) (hw[0] & 0xffff)) * xb->d, dmin = h2f((uint16_t) (hw[0] >> 16)) * xb->d;
+                part[sb] = d * (float) isum - dmin * (float) msum;
+            }
+        }
+    }
+    for (; WS == 0 && t < ntiles; t += nwaves) {
 #pragma unroll
         for (int i = 0; i < NLOAD; i++) ((u32x4 *) stage)[i * 64 + lane] = r[i];
         MV_STAMP(4);
@@ -488,13 +563,14 @@ __global__ void __launch_bounds__(NW * 64) matvec_q4k_kernel(mv_args a, int rows
 
     // phase 4: row sums (+ residual): 16 lanes per row, strided partials then a 4-step butterfly
     float best = -INFINITY; int bi = -1;   // fused greedy sampling: this thread's LAST maximum among its rows (ggml_vec_argmax_f32 keeps the last)
-    for (int rr = tid >> 4; rr < rows; rr += NW * 4) {
+    int kq = 0;
+    for (int rr = tid >> 4; rr < rows; rr += NW * 4, kq++) {
         float sum = 0.f;
         for (int j = tid & 15; j < nb; j += 16) sum += part[rr * nb + j];
         sum = row16_allsum_f32(sum);
         if ((tid & 15) == 0) {
             const int64_t row = row0 + rr;
-            if (a.residual) sum = a.residual[row] + sum;   // (requesting this before the dot products measured slower: 218 vs 226 fps)
+            if (a.residual) sum = (kq == 0 ? res_pre[0] : kq == 1 ? res_pre[1] : kq == 2 ? res_pre[2] : kq == 3 ? res_pre[3] : a.residual[row]) + sum;
             else if (a.res_embed.table) {
                 int64_t r = *a.res_embed.index;
                 if (r < 0 || r >= a.res_embed.n_rows) r = 0;
@@ -1275,7 +1351,19 @@ void k_matvec(hipStream_t s, const mv_args & a) {
             }
         }
         if (rows < 1) rows = 1;
-        const size_t smem = (size_t) nb * XBLK_BYTES + (size_t) nw * tile_bytes + (size_t) rows * nb * 4;
+        // small Q4_K matrices (the Depth transformer, the codebook heads): 8 lanes per super-block, no LDS tiles (WS = 1)
+        static const int direct_on = env_int("MI355X_MV_DIRECT", 1), direct_passes = env_int("MI355X_MVD_PASSES", 3), direct_max_tiles = env_int("MI355X_MVD_MAX_TILES", 512);
+        const bool direct = direct_on && fmt == MVF_Q4K && (nw == 4 || (nw == 8 && a.prologue == MV_ATTN)) && tiles_total <= direct_max_tiles && nb <= nw * 8 * MVD_PMAX;
+        if (direct) {
+            int passes = direct_passes < 1 ? 1 : direct_passes > MVD_PMAX ? MVD_PMAX : direct_passes;
+            if (nw == 8 && passes > 1) passes = 1;                                         // 8 waves: 64 super-blocks per pass already
+            rows = passes * nw * 8 / nb;
+            if (rows < 1) { rows = 1; }
+            while (rows > 1 && (a.M + rows - 1) / rows < 96) rows = (rows + 1) / 2;   // keep >= ~100 workgroups in flight
+            GGML_ASSERT(rows * nb <= MVD_PMAX * nw * 8);
+        }
+        const size_t stage_bytes = (!direct || a.prologue == MV_ATTN) ? (size_t) nw * tile_bytes : 0;
+        const size_t smem = (size_t) nb * XBLK_BYTES + stage_bytes + (size_t) rows * nb * 4 + (a.prologue == MV_ATTN ? 4096 : 0);
         GGML_ASSERT(smem <= 160 * 1024);
         const int grid = (int) ((a.M + rows - 1) / rows);
         GGML_ASSERT(a.prologue != MV_RMSNORM || a.K <= nw * 1024);
@@ -1285,7 +1373,10 @@ void k_matvec(hipStream_t s, const mv_args & a) {
                       : a.prologue == MV_ATTN ? matvec_q4k_kernel<MV_ATTN, NWV, F> \
                       : a.prologue == MV_PREQ8K ? matvec_q4k_kernel<MV_PREQ8K, NWV, F> : matvec_q4k_kernel<MV_PLAIN, NWV, F>)
 #define MV_PICK(NWV) (fmt == MVF_Q4K ? MV_PICKF(NWV, MVF_Q4K) : fmt == MVF_Q40 ? MV_PICKF(NWV, MVF_Q40) : MV_PICKF(NWV, MVF_Q80))
-        kern = nw == 12 ? MV_PICK(12) : nw == 8 ? MV_PICK(8) : MV_PICK(4);
+#define MV_PICKD (a.prologue == MV_RMSNORM ? matvec_q4k_kernel<MV_RMSNORM, 4, MVF_Q4K, 1> : a.prologue == MV_GATE_SILU ? matvec_q4k_kernel<MV_GATE_SILU, 4, MVF_Q4K, 1> \
+                  : a.prologue == MV_ATTN ? (nw == 8 ? matvec_q4k_kernel<MV_ATTN, 8, MVF_Q4K, 1> : matvec_q4k_kernel<MV_ATTN, 4, MVF_Q4K, 1>) \
+                  : a.prologue == MV_PREQ8K ? matvec_q4k_kernel<MV_PREQ8K, 4, MVF_Q4K, 1> : matvec_q4k_kernel<MV_PLAIN, 4, MVF_Q4K, 1>)
+        kern = direct ? MV_PICKD : nw == 12 ? MV_PICK(12) : nw == 8 ? MV_PICK(8) : MV_PICK(4);
         if (smem > 64 * 1024) {   // > 64 KB of dynamic LDS needs a one-time opt-in per kernel
             static std::map<const void *, size_t> granted;
             size_t & g = granted[(const void *) kern];
@@ -1358,10 +1449,21 @@ void k_matvec(hipStream_t s, const mv_args & a) {
 // contiguous, so the lowest unfinished head always has all of its workgroups resident (the spin is bounded regardless).
 struct attn_split_ws { float * scores; float * pmax; double * opart; unsigned * arrive; unsigned * done; int S; unsigned * err; int slots; int single_max; int big_min; };
 
+#if defined(MV_LOG)
+#define AT_STAMP(i) do { if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { if ((i) == 0) at_log_id = atomicAdd(&g_mv_launch, 1u) & 8191u; unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); g_mv_log[at_log_id][i] = t_; \
+    if ((i) == 0 || (i) == 7) { unsigned long long r_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(r_) :: "memory"); g_mv_log[at_log_id][16 + ((i) == 7)] = r_; } \
+    if ((i) == 0) { g_mv_log[at_log_id][18] = (unsigned long long) a_in.D | ((unsigned long long) a_in.C << 32); g_mv_log[at_log_id][19] = 0xA7ull | ((unsigned long long) gridDim.x << 32); } } } while (0)
+#else
+#define AT_STAMP(i) do {} while (0)
+#endif
 template <bool SPLIT>
 __global__ void __launch_bounds__(ATTN_THREADS) __attribute__((amdgpu_waves_per_eu(2)))   // >= 2 workgroups per CU: the split grid (<= 512) is resident
 attn_decode_kernel(attn_args a_in, attn_split_ws w) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+#if defined(MV_LOG)
+    unsigned at_log_id = 0;
+#endif
+    AT_STAMP(0);
     attn_args a = a_in;
     if (!SPLIT && a.n_groups > 1) {   // rows 4 g .. 4 g + 3 of a longer block
         const int t0 = 4 * (int) blockIdx.y;
@@ -1387,7 +1489,8 @@ attn_decode_kernel(attn_args a_in, attn_split_ws w) {
     float * qf   = sc + C;                  // [T][D] bf16-rounded rotated q
     float * knew = qf + T * D;              // [T][D] bf16-rounded new k rows
     float * vnew = knew + T * D;            // [T][D] bf16-rounded new v rows
-    double * red = (double *) (smem + (((size_t) (C + 3 * T * D) * 4 + 7) & ~(size_t) 7));   // [4 waves][SPW slot groups][D] partial outputs
+    double * red = (double *) (smem + (((size_t) (C + 3 * T * D) * 4 + 15) & ~(size_t) 15));   // [4 waves][SPW slot groups][D] partial outputs
+    float * msk = (float *) (red + 4 * (64 / (D / 8)) * D);   // [T][C] the mask rows, staged by the live-range scan (a global load per score pass otherwise)
     __shared__ float sh_f[4];
     __shared__ double sh_d[4];
     __shared__ int sh_i[4];
@@ -1415,6 +1518,7 @@ attn_decode_kernel(attn_args a_in, attn_split_ws w) {
                     const int t = ee / per_row, i4 = from4 + (ee - t * per_row);
                     cs[u] = i4 * 4;
                     m4[u] = ((const float4 *) a.mask)[t * row4 + i4];
+                    if (e < n4) ((float4 *) msk)[t * row4 + i4] = m4[u];
                 }
 #pragma unroll
                 for (int u = 0; u < 3; u++) {
@@ -1428,7 +1532,9 @@ attn_decode_kernel(attn_args a_in, attn_split_ws w) {
             const int per_row = C - from;
             for (int e = tid; e < T * per_row; e += ATTN_THREADS) {
                 const int t = e / per_row, c = from + (e - t * per_row);
-                if (a.mask[t * C + c] > -INFINITY) last = max(last, c);
+                const float mv = a.mask[t * C + c];
+                msk[t * C + c] = mv;
+                if (mv > -INFINITY) last = max(last, c);
             }
         }
         return last;
@@ -1483,6 +1589,7 @@ attn_decode_kernel(attn_args a_in, attn_split_ws w) {
     int last_live = -1;
     if (!SPLIT || s_idx == 0) last_live = scan_last_live(0);
     __builtin_amdgcn_sched_barrier(0);
+    AT_STAMP(1);
 
     // ---- 1. RoPE + cache write for all T new rows (the reference's set_rows precede the attention of every row) ----------------
     if (tid < T) sh_slot[tid] = a.index[tid];
@@ -1510,6 +1617,7 @@ attn_decode_kernel(attn_args a_in, attn_split_ws w) {
     if (!SPLIT && a.write_only) return;
     if (!SPLIT || s_idx == 0) { n_end = block_max_i32(last_live) + 1; if (SPLIT && n_end > w.big_min) SLOTS *= 2; }
     else __syncthreads();
+    AT_STAMP(2);
     const int P = SPLIT && n_end > w.single_max ? (n_end + SLOTS - 1) / SLOTS : 1;   // participating workgroups of this head
     const bool multi = SPLIT && P > 1;
     const int c_lo = multi ? c_base : 0, c_hi = multi ? min(n_end, c_base + SLOTS) : n_end;   // slots whose K / V rows this workgroup reads
@@ -1526,13 +1634,15 @@ attn_decode_kernel(attn_args a_in, attn_split_ws w) {
         const int f = fresh_of(c_base + wave * SPW + pi * 4 * SPW + sub);
         if (f >= 0) { kpre[pi] = pack_row(knew + f * D + dl); if (pi < ATTN_NPRE) vpre[pi] = pack_row(vnew + f * D + dl); }
     }
+    AT_STAMP(8);
 
     for (int t = 0; t < T; t++) {
-        const float * mask = a.mask + (int64_t) t * C;
+        const float * mask = msk + t * C;
         // 2. scores
         float qv[8];
 #pragma unroll
         for (int i = 0; i < 8; i++) qv[i] = qf[t * D + dl + i];
+        AT_STAMP(9);
         float lmax = -INFINITY;
         auto score_pass = [&](int c0, const uint4 kv) {
             const int c = c0 + sub;
@@ -1582,9 +1692,12 @@ attn_decode_kernel(attn_args a_in, attn_split_ws w) {
                 if (f >= 0) vpre[pi] = pack_row(vnew + f * D + dl);
             }
         }
+        AT_STAMP(10);
         lmax = wave_allmax_f32(lmax);
         if (lane == 0) sh_f[wave] = lmax;
+        AT_STAMP(11);
         __syncthreads();
+        AT_STAMP(3);
         float gmax = fmaxf(fmaxf(sh_f[0], sh_f[1]), fmaxf(sh_f[2], sh_f[3]));
         if (multi) {
             // publish (this workgroup's scores, at most one per thread: SLOTS <= 256 = ATTN_THREADS), arrive, wait for the other P - 1
@@ -1629,6 +1742,7 @@ attn_decode_kernel(attn_args a_in, attn_split_ws w) {
         if (lane == 0) sh_d[wave] = lsum;
         __syncthreads();
         const float inv = (float) (1.0 / (sh_d[0] + sh_d[1] + sh_d[2] + sh_d[3]));   // p = bf16(e * inv), formed where it is used
+        AT_STAMP(4);
 
         // 4. out[d] = sum_c V[d, c] * p[c]
         double o8[8];
@@ -1663,9 +1777,11 @@ attn_decode_kernel(attn_args a_in, attn_split_ws w) {
                 if (c0 < c_hi) pv_pass(c0, vb[pi]);
             }
         }
+        AT_STAMP(5);
 #pragma unroll
         for (int i = 0; i < 8; i++) red[(wave * SPW + sub) * D + dl + i] = o8[i];
         __syncthreads();
+        AT_STAMP(6);
         for (int j = tid; j < D; j += ATTN_THREADS) {
             double tot = 0;
 #pragma unroll 8
@@ -1695,6 +1811,7 @@ attn_decode_kernel(attn_args a_in, attn_split_ws w) {
         }
         __syncthreads();
     }
+    AT_STAMP(7);
 }
 
 static bool attn_use_split(const attn_args & a) { return a.T == 1 && a.n_groups <= 1 && a.D == 128 && a.C >= ATTN_SPLIT_MIN_C; }
@@ -1708,8 +1825,16 @@ void k_attn_decode(hipStream_t s, const attn_args & a, void * ws, unsigned * err
     const int Tg = a.n_groups > 1 ? ATTN_MAX_T : a.T;   // rows per workgroup
     GGML_ASSERT(a.D % 8 == 0 && 64 % (a.D / 8) == 0 && a.D <= 512 && a.T >= 1 && Tg <= ATTN_MAX_T && Tg * a.D <= 2 * ATTN_THREADS);
     GGML_ASSERT(a.n_groups <= 1 || a.n_groups == (a.T + 3) / 4);
-    const size_t smem = (size_t) a.C * 4 + (size_t) Tg * a.D * 4 * 3 + (size_t) (ATTN_THREADS / 64) * 64 * 8 * 8 + 16;
+    const size_t smem = (size_t) a.C * 4 + (size_t) Tg * a.D * 4 * 3 + (size_t) (ATTN_THREADS / 64) * 64 * 8 * 8 + 16 + (size_t) Tg * a.C * 4;
     GGML_ASSERT(smem <= 160 * 1024);
+    if (smem > 64 * 1024) {   // > 64 KB of dynamic LDS needs a one-time opt-in per kernel
+        static size_t granted[2] = { 0, 0 };
+        const int which = ws && attn_use_split(a) ? 1 : 0;
+        if (granted[which] < smem) {
+            HIP_CHECK(hipFuncSetAttribute(which ? (const void *) attn_decode_kernel<true> : (const void *) attn_decode_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) smem));
+            granted[which] = smem;
+        }
+    }
     static const int single_max = env_int("MI355X_ATTN_SINGLE_MAX", ATTN_SINGLE_MAX), big_min = env_int("MI355X_ATTN_BIG_MIN", ATTN_SPLIT_BIG_MIN);
     attn_split_ws w = { nullptr, nullptr, nullptr, nullptr, nullptr, 1, err, ATTN_SPLIT_SLOTS, single_max, big_min };
     if (ws && attn_use_split(a)) {
