@@ -47,6 +47,20 @@ def whole_job_rate(world, steps, seconds):
     return world * steps / seconds
 
 
+def shard_hop_latency(shard, dist, group, L, be, n=200):
+    """average time of one step-message broadcast (stream-ordered, synchronised once at the end), owners rotating as in a frame; collective: every rank calls it"""
+    if shard.world == 1:
+        return 0.0
+    for k in range(8):
+        shard._bcast(shard.msg, k % shard.world)
+    L.ggml_backend_synchronize(be)
+    t0 = time.perf_counter()
+    for k in range(n):
+        shard._bcast(shard.msg, k % shard.world)
+    L.ggml_backend_synchronize(be)
+    return round(1e6 * (time.perf_counter() - t0) / n, 2)
+
+
 def device_sync():
     hip = C.CDLL("libamdhip64.so")
     hip.hipDeviceSynchronize()
@@ -70,6 +84,9 @@ def main():
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"], help="control-plane backend for N > 1 (nccl = RCCL; gloo for single-GPU dry runs)")
     ap.add_argument("--device", type=int, default=None, help="override the device index (default LOCAL_RANK); only for dry runs of the N > 1 path on one GPU")
     ap.add_argument("--backend-flags", type=int, default=0, help="ggml_backend_mi355x_set_flags bits (2 = no hipGraph: use under rocprofv3)")
+    ap.add_argument("--shard", default="none", choices=["none", "depth"],
+                    help="depth: ONE stream, the Depth transformer's per-codebook weight sets sharded over the ranks (SURVEY.md 8e: step k on rank k %% N, "
+                         "K/V rows + token broadcast per step over RCCL); strong scaling. Default: independent stream replicas (weak scaling)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -137,9 +154,23 @@ def main():
         args.quant = "q8_0"
     elif args.quant != "q4_k":
         cfg.linear_type = {"q8_0": 8, "q4_0": 2}[args.quant]   # ggml_type ids
+    shard = None
+    if args.shard == "depth":
+        if args.model not in ("moshika", "personaplex"):
+            raise SystemExit("--shard depth: moshika / personaplex only")
+        cfg.dep_shard_world, cfg.dep_shard_rank, cfg.depth_only = world, rank, int(rank != 0)
+        if rank != 0:
+            cfg.enable_mimi_encoder = cfg.enable_mimi_decoder = 0
     t0 = time.time()
     m = L.moshi_hot_create(be, C.byref(cfg), 0)
     t_load = time.time() - t0
+    if args.shard == "depth":
+        from moshi_cpp_amd import shard as shard_mod
+        import torch
+        shard = shard_mod.DepthShard(L, m, cfg, rank, world, dist, group=dist_group, device=torch.device("cuda", dev_index),
+                                     stream_ptr=L.ggml_backend_mi355x_get_stream(be))
+        if rank == 0:
+            shard.install()
     if args.context_fill:
         L.moshi_hot_set_context_fill(m, args.context_fill)
 
@@ -182,18 +213,34 @@ def main():
             torch.cuda.synchronize()
             dist.barrier(group=dist_group)
 
+    if shard is not None and rank != 0:
+        # a Depth-only rank: serve the owner's frames (warm-up, timed region, phase pass) until it says stop; the owner's clock is the job's
+        shard.serve()
+        hop_us = shard_hop_latency(shard, dist, dist_group, L, be)
+        reduce_max_time(dist, 0.0, group=dist_group)
+        L.moshi_hot_free(m)
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     for _ in range(args.warmup):
         frame()
     tokens = []
-    barrier()
+    if shard is None:
+        barrier()
+    else:
+        L.ggml_backend_synchronize(be); device_sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         frame()
         tokens.append(txt.value)
-    barrier()
+    if shard is None:
+        barrier()
+    else:
+        L.ggml_backend_synchronize(be); device_sync()      # every step message of the last frame has been received here: the chain is complete
     dt = time.perf_counter() - t0
-    dt = reduce_max_time(dist, dt, group=dist_group)
-    fps = whole_job_rate(world, args.steps, dt)
+    if shard is None:
+        dt = reduce_max_time(dist, dt, group=dist_group)
+    fps = whole_job_rate(world, args.steps, dt) if shard is None else args.steps / dt   # shard: ONE stream over all ranks (strong scaling)
     offset_end = L.moshi_hot_offset(m)
 
     # algorithmic HBM bytes per frame: every weight byte once + the filled KV slots
@@ -210,19 +257,21 @@ def main():
         "metric": "audio frames/sec (12.5 Hz target) %s %s decode" % ({"moshika": "moshika-7B", "personaplex": "personaplex-7B", "tts_like": "tts-1.6b-shaped",
                                                                         "stt_like": "stt-1b-shaped"}[args.model], args.quant),
         "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True, "scaling": "weak",
+        "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True, "scaling": "weak" if shard is None else "strong",
         "vs_baseline": None, "dtype": "q4_K weights x q8_K activations (int8 dot, f32 accumulate); bf16 KV; f32 elsewhere",
         "data": "synthetic",
         "config": {"workload": ({"tts_like": "moshi-tts loop: Temporal step (cross-attention, demux) + %d Depth steps + mimi decode (32 levels), ",
                                  "stt_like": "moshi-stt loop: mimi encode (32 levels) + Temporal step + VAD head (%d Depth steps), "}
                                 .get(args.model, "moshi-sts --bench loop: mimi encode + Temporal step + %d Depth steps + mimi decode, ") % cfg.dep_q) +
                                "%s %s, 1 stream per GPU, greedy, ctx capacity %d" % (args.model, args.quant, cfg.context),
-                   "context_fill_start": args.context_fill, "parallelism": "independent stream replica per GPU" if world > 1 else "1 GPU",
+                   "context_fill_start": args.context_fill,
+                   "parallelism": ("Depth codebook shard: step k on rank k %% %d, replicated 8-slot ring, 1 + dep_q broadcasts per frame" % world) if shard is not None
+                                  else "independent stream replica per GPU" if world > 1 else "1 GPU",
                    "device": dev_desc},
-        "realtime_factor": round(fps / world / 12.5, 1),
+        "realtime_factor": round(fps / (world if shard is None else 1) / 12.5, 1),
         "frame_bytes": int(frame_bytes),
-        "hbm_gbps_whole_frame": round(frame_bytes * fps / world / 1e9, 1),
-        "hbm_frac_whole_frame": round(frame_bytes * fps / world / 1e9 / HBM_PEAK_GBPS, 4),
+        "hbm_gbps_whole_frame": round(frame_bytes * fps / (world if shard is None else 1) / 1e9, 1),
+        "hbm_frac_whole_frame": round(frame_bytes * fps / (world if shard is None else 1) / 1e9 / HBM_PEAK_GBPS, 4),
         "load_seconds": round(t_load, 1),
         "graph_replays": int(st.graph_replays), "uploads_batched": int(st.uploads_batched),
     }
@@ -236,6 +285,16 @@ def main():
         L.moshi_hot_get_timing(m, ph)
         L.moshi_hot_set_timing(m, 0)
         result["phase_us"] = {"mimi_encode": round(ph[0], 1), "temporal": round(ph[1], 1), "depth": round(ph[2], 1), "mimi_decode": round(ph[3], 1)}
+
+    if shard is not None:
+        shard.stop_workers()
+        hop_us = shard_hop_latency(shard, dist, dist_group, L, be)
+        reduce_max_time(dist, dt, group=dist_group)
+        result["shard"] = {"kind": "depth codebook shard (SURVEY.md 8e)", "ranks": world, "messages_per_frame": 1 + cfg.dep_q,
+                           "message_bytes": int(shard.msg_floats.value * 4), "broadcast_us": hop_us,
+                           "depth_weight_bytes_this_rank": int(L.moshi_hot_weight_bytes(m, 1))}
+        args.no_roofline = True          # flag 8 re-plans graphs eagerly; the roofline line belongs to the default (unsharded) run
+        args.no_cpu_baseline = True
 
     if rank == 0 and not args.no_roofline:
         # dominant kernel = matvec_q4k_kernel (3.77 of 4.4 GB per frame). Its launches are timed in situ with HIP

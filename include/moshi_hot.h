@@ -55,6 +55,11 @@ struct moshi_hot_config {
     // which ggml's discontinuous roundings no longer compound chaotically: the parity tests then assert bit-exact greedy tokens and 1e-3
     // logits over many free-running frames at the full benchmark widths (same shapes, types and bytes moved).
     float   update_scale;
+    // Depth-transformer codebook shard (lm.h:505-527, lm_default.h:136-146,187-216). dep_shard_world > 1: this model holds
+    // the per-step Depth weight sets (depformer_in[k], in_projs[k], out_projs[k], gating[k], linears[k], depformer_emb[k-1]) of the steps
+    // k with k % dep_shard_world == dep_shard_rank only - 1/world of the 375 MB - and runs the Depth chain as per-step graphs behind the
+    // moshi_hot_depth_shard_* calls. depth_only: no Temporal stack, embeddings or codec at all (the ranks other than the Temporal owner).
+    int32_t dep_shard_rank, dep_shard_world, depth_only;
 };
 
 typedef struct moshi_hot_model moshi_hot_model_t;
@@ -128,6 +133,22 @@ GGML_API void    moshi_hot_set_context_fill(moshi_hot_model_t * m, int64_t offse
 typedef void (*moshi_hot_node_visitor_t)(void * user, int index, struct ggml_tensor * node);
 GGML_API int     moshi_hot_layer_probe(moshi_hot_model_t * m, int which, int layer, int weight_set, const float * x_in, int offset, float * x_out,
                                        moshi_hot_node_visitor_t visit, void * user);
+
+// ---- Depth codebook shard: one frame = begin, then for k = 0 .. dep_q-1 the owner runs `step` and everybody else `import` ---------------
+// The 8-slot Depth ring is REPLICATED on every rank; what an owner hands on per step is one message F32[2 * dep_layers * dep_dim + 8]:
+// its new K and V ring rows of all layers (BF16 values widened exactly) and the sampled token (+ the frame's stop flag in word 1 of the tail).
+// The transport between ranks is the caller's (torch.distributed over RCCL / xGMI in bench.py, gloo in the CPU test): the message lives in
+// one tensor whose storage pointer is returned here - a device pointer on the MI355X backend - so it can be handed to a collective as is.
+GGML_API void *  moshi_hot_depth_shard_msg(moshi_hot_model_t * m, int64_t * n_floats);        // step message (rows + token)
+GGML_API void *  moshi_hot_depth_shard_tout(moshi_hot_model_t * m, int64_t * n_floats);       // frame message: transformer_out F32[dim] + 8 (word dim = 1 while frames follow)
+GGML_API void    moshi_hot_depth_shard_begin_export(moshi_hot_model_t * m, int32_t text_token, int more);   // Temporal owner: pack the frame message; text token feeds step 0
+GGML_API int     moshi_hot_depth_shard_begin_import(moshi_hot_model_t * m);                   // others: unpack it; returns the "more frames" flag
+GGML_API void    moshi_hot_depth_shard_step(moshi_hot_model_t * m, int k);                    // owner of step k: one Depth step (lm.h:505-527 body) + pack the message
+GGML_API void    moshi_hot_depth_shard_import(moshi_hot_model_t * m, int k);                  // non-owner: rows -> ring slot k % capacity, token -> token vector
+GGML_API void    moshi_hot_depth_shard_tokens(moshi_hot_model_t * m, int32_t * out, int n);   // the frame's sampled tokens so far
+// replaces the local chained Depth graph inside moshi_hot_lm_step_n: fn(user, text_token, audio[dep_q]) must fill all dep_q tokens
+typedef void (*moshi_hot_depth_hook_t)(void * user, int32_t text_token, int32_t * audio);
+GGML_API void    moshi_hot_set_depth_hook(moshi_hot_model_t * m, moshi_hot_depth_hook_t fn, void * user);
 
 #ifdef __cplusplus
 }

@@ -635,6 +635,11 @@ struct moshi_hot_model {
     T transformer_out = nullptr;   // state F32[dim] (lm.h:434)
     Builder * g_temporal = nullptr; std::vector<T> emb_idx, emb_scale; T sampler_out = nullptr, text_logits = nullptr, g_transformer_out = nullptr, g_transformer_in = nullptr, g_stack_out = nullptr;
     Builder * g_depth = nullptr; T dep_text_idx = nullptr, dep_text_scale = nullptr, dep_tokens = nullptr; std::vector<T> dep_logits;
+    // Depth codebook shard (moshi_hot.h): per-step graphs, import graphs, the two messages, the device-side token vector
+    std::vector<Builder *> g_shard_step, g_shard_import; Builder * g_shard_begin = nullptr;
+    T shard_msg = nullptr, shard_tout = nullptr, shard_tokens = nullptr;
+    std::vector<T> shard_text_idx, shard_text_scale;
+    moshi_hot_depth_hook_t depth_hook = nullptr; void * depth_hook_user = nullptr;
     // delay ring (lm.h:715-743)
     int offset = 0; std::vector<std::vector<int>> cache; std::vector<int> initial; int max_delay = 0;
 
@@ -662,6 +667,9 @@ T state(moshi_hot_model * m, enum ggml_type type, int64_t n0, int64_t n1 = 1, in
     return t;
 }
 
+// Depth codebook shard: does this model hold the weight set of Depth step k?
+bool owns_step(const moshi_hot_config & c, int k) { return c.dep_shard_world <= 1 || k % c.dep_shard_world == c.dep_shard_rank; }
+
 void make_transformer(moshi_hot_model * m, Transformer & tr, const std::string & name, int dim, int heads, int n_layers, int ffn_hidden,
                       int capacity, int max_period, int n_weight_sets, bool mimi_style, enum ggml_type wtype, int cross_len = 0) {
     Weights & W = *m->W;
@@ -688,6 +696,11 @@ void make_transformer(moshi_hot_model * m, Transformer & tr, const std::string &
         }
         for (int w = 0; w < n_weight_sets; w++) {
             const std::string ws = n_weight_sets > 1 ? "." + std::to_string(w) : "";
+            if (n_weight_sets > 1 && !owns_step(m->cfg, w)) {   // another rank's step: no weights here
+                L.in_proj.push_back(nullptr); L.out_proj.push_back(nullptr);
+                if (!mimi_style) { L.gate_in.push_back(nullptr); L.gate_out.push_back(nullptr); }
+                continue;
+            }
             L.in_proj.push_back(W.add(p + "self_attn.in_projs" + ws + ".weight", wtype, dim, 3 * dim, 1, qgen(s_in)));
             L.out_proj.push_back(W.add(p + "self_attn.out_projs" + ws + ".weight", wtype, dim, dim, 1, qgen(s_in * upd)));
             if (!mimi_style) {
@@ -929,6 +942,7 @@ extern "C" moshi_hot_model_t * moshi_hot_create(ggml_backend_t backend, const st
             if ((t == GGML_TYPE_Q4_0 || t == GGML_TYPE_Q8_0) && ne0 % 32 != 0) t = GGML_TYPE_F32;
             return t;
         };
+        if (!c.depth_only) {   // (a Depth-only shard rank holds neither the embeddings nor the Temporal stack)
         m->text_emb = W.add("lm.text_emb.weight", et, c.dim, c.text_card + 1, 1, qgen(1.f));
         if (c.demux_second_stream) {
             m->text_out1 = W.add("lm.text_emb.out1.weight", lt, c.dim, c.dim, 1, qgen(1.f / sqrtf((float) c.dim)));
@@ -940,6 +954,7 @@ extern "C" moshi_hot_model_t * moshi_hot_create(ggml_backend_t backend, const st
                          c.cross_attention ? c.cross_len : 0);
         m->out_norm = { true, 1e-8f, W.add("lm.out_norm.alpha", GGML_TYPE_F32, c.dim, 1, 1, ones), nullptr };
         m->text_linear = W.add("lm.text_linear.weight", lt, c.dim, c.text_card, 1, qgen(1.f / sqrtf((float) c.dim)));
+        }
         m->transformer_out = state(m, GGML_TYPE_F32, c.dim);
         if (c.condition_sum) m->cond_sum = state(m, GGML_TYPE_F32, c.dim);
         if (c.cross_attention) m->cond_cross = state(m, GGML_TYPE_F32, c.dim, c.cross_len);
@@ -951,20 +966,21 @@ extern "C" moshi_hot_model_t * moshi_hot_create(ggml_backend_t backend, const st
             if (c.dep_schedule_len) { n_sets = 0; for (int i = 0; i < c.dep_schedule_len; i++) if (c.dep_schedule[i] + 1 > n_sets) n_sets = c.dep_schedule[i] + 1; }
             const int E = c.depformer_low_rank ? c.depformer_low_rank : c.dep_dim;   // embedding table width
             W.part = 1;
+            GGML_ASSERT(c.dep_shard_world <= 1 || c.dep_schedule_len == 0);   // the shard is by step = by weight set
             for (int k = 0; k < n_sets; k++)
-                m->depformer_in.push_back(W.add("lm.depformer_in." + std::to_string(k) + ".weight", lt, c.dim, c.dep_dim, 1, qgen(1.f / sqrtf((float) c.dim))));
+                m->depformer_in.push_back(!owns_step(c, k) ? nullptr : W.add("lm.depformer_in." + std::to_string(k) + ".weight", lt, c.dim, c.dep_dim, 1, qgen(1.f / sqrtf((float) c.dim))));
             for (int k = 0; k < c.dep_q; k++) {
-                m->linears.push_back(W.add("lm.linears." + std::to_string(k) + ".weight", lt, c.dep_dim, c.card, 1, qgen(1.f / sqrtf((float) c.dep_dim))));
+                m->linears.push_back(!owns_step(c, k) ? nullptr : W.add("lm.linears." + std::to_string(k) + ".weight", lt, c.dep_dim, c.card, 1, qgen(1.f / sqrtf((float) c.dep_dim))));
                 if (k > 0) {
                     W.part = 4;
-                    m->depformer_emb.push_back(W.add("lm.depformer_emb." + std::to_string(k - 1) + ".weight", fit(et, E), E, c.card + 1, 1, qgen(1.f)));
+                    m->depformer_emb.push_back(!owns_step(c, k) ? nullptr : W.add("lm.depformer_emb." + std::to_string(k - 1) + ".weight", fit(et, E), E, c.card + 1, 1, qgen(1.f)));
                     W.part = 1;
                     if (c.depformer_low_rank)
                         m->depformer_emb_low_rank.push_back(W.add("lm.depformer_emb." + std::to_string(k - 1) + ".low_rank.weight", fit(lt, E), E, c.dep_dim, 1, qgen(1.f / sqrtf((float) E))));
                 }
             }
             W.part = 4;
-            m->depformer_text_emb = W.add("lm.depformer_text_emb.weight", fit(et, E), E, c.text_card + 1, 1, qgen(1.f));
+            if (owns_step(c, 0)) m->depformer_text_emb = W.add("lm.depformer_text_emb.weight", fit(et, E), E, c.text_card + 1, 1, qgen(1.f));
             W.part = 1;
             if (c.demux_second_stream) {
                 m->dep_text_out1 = W.add("lm.depformer_text_emb.out1.weight", fit(lt, E), E, c.dep_dim, 1, qgen(1.f / sqrtf((float) E)));
@@ -974,6 +990,11 @@ extern "C" moshi_hot_model_t * moshi_hot_create(ggml_backend_t backend, const st
             // capacity = context ? context : weights_per_step (lm_default.h:86-90)
             make_transformer(m, m->depth, "lm.depformer", c.dep_dim, c.dep_heads, c.dep_layers, c.dep_ffn_hidden, c.dep_context ? c.dep_context : c.dep_schedule_len, 0, n_sets, false, lt);
             for (int i = 0; i < c.dep_schedule_len; i++) m->depth.schedule.push_back(c.dep_schedule[i]);
+            if (c.dep_shard_world >= 1) {   // shard messages + the device-side token vector (zero-filled states)
+                m->shard_msg = state(m, GGML_TYPE_F32, 2 * (int64_t) c.dep_layers * c.dep_dim + 8);
+                m->shard_tout = state(m, GGML_TYPE_F32, (int64_t) c.dim + 8);
+                m->shard_tokens = state(m, GGML_TYPE_I32, c.dep_q);
+            }
         }
         // moshi_lmgen_state (lm.h:722-743)
         const int ncb = c.n_q + 1;
@@ -1024,7 +1045,9 @@ extern "C" moshi_hot_model_t * moshi_hot_create(ggml_backend_t backend, const st
 
 extern "C" void moshi_hot_free(moshi_hot_model_t * m) {
     if (!m) return;
-    delete m->g_temporal; delete m->g_depth; delete m->g_dec; delete m->g_enc; delete m->scratch;
+    delete m->g_temporal; delete m->g_depth; delete m->g_dec; delete m->g_enc; delete m->scratch; delete m->g_shard_begin;
+    for (auto * b : m->g_shard_step) delete b;
+    for (auto * b : m->g_shard_import) delete b;
     if (m->st_buf) ggml_backend_buffer_free(m->st_buf);
     ggml_free(m->st_ctx);
     delete m->W;
@@ -1090,6 +1113,110 @@ void depth_step(moshi_hot_model * m, int32_t text_token, std::vector<int32_t> & 
 }
 }
 
+// ---- Depth codebook shard ---------------------------------------------------------------------------------------
+namespace {
+// ring rows of slot `slot` of one cache tensor [D, C, H] <-> a dense [D, 1, H] F32 window of the step message
+T ring_rows(Builder & g, T cache, int slot) { return ggml_view_3d(g, cache, cache->ne[0], 1, cache->ne[2], cache->nb[1], cache->nb[2], (size_t) slot * cache->nb[1]); }
+T msg_rows(Builder & g, T msg, T like, int64_t index) {
+    const int64_t n = like->ne[0] * like->ne[2];
+    return ggml_view_3d(g, msg, like->ne[0], 1, like->ne[2], (size_t) like->ne[0] * 4, (size_t) like->ne[0] * 4, (size_t) (index * n) * 4);
+}
+// one Depth step as its own cached graph: the body of the chained loop (lm.h:505-527) for step k, the previous token read from the token
+// vector, plus the packing of this step's message
+void build_shard_step(moshi_hot_model * m, int k) {
+    const moshi_hot_config & c = m->cfg;
+    GGML_ASSERT(owns_step(c, k) && !c.demux_second_stream && !c.depformer_low_rank && c.dep_schedule_len == 0);
+    Builder * b = new Builder(m->be, 64);
+    Builder & g = *b;
+    T last;
+    if (k == 0) {
+        T idx = g.tensor(GGML_TYPE_I32, 1), sc = g.tensor(GGML_TYPE_F32, 1);
+        m->shard_text_idx.push_back(idx); m->shard_text_scale.push_back(sc);
+        last = ggml_mul(g, ggml_get_rows(g, m->depformer_text_emb, idx), sc);
+    } else last = ggml_get_rows(g, m->depformer_emb[(size_t) (k - 1)], ggml_view_1d(g, m->shard_tokens, 1, (size_t) (k - 1) * 4));
+    T din = linear(g, m->depformer_in[(size_t) k], m->transformer_out);
+    last = ggml_cast(g, last, GGML_TYPE_F32);
+    din = ggml_add(g, din, last);
+    m->depth.offset = k;
+    T dout = transformer_inline(g, m->depth, din);
+    T logits = linear(g, m->linears[(size_t) k], dout);
+    T next = sample_token(g, logits, c.temp, c.top_k);
+    g.expand(ggml_cpy(g, next, ggml_view_1d(g, m->shard_tokens, 1, (size_t) k * 4)));
+    // the message: this step's new K / V rows of every layer, then the token
+    const int slot = k % m->depth.capacity;
+    int64_t w = 0;
+    for (auto & L : m->depth.layers) for (T cache : { L.kcache, L.vcache }) {
+        T rows = ring_rows(g, cache, slot);
+        g.expand(ggml_cpy(g, rows, msg_rows(g, m->shard_msg, rows, w++)));
+    }
+    g.expand(ggml_cpy(g, next, ggml_view_1d(g, m->shard_msg, 1, (size_t) (2 * c.dep_layers * c.dep_dim) * 4)));
+    g.alloc();
+    if ((int) m->g_shard_step.size() <= k) m->g_shard_step.resize((size_t) k + 1, nullptr);
+    m->g_shard_step[(size_t) k] = b;
+}
+void build_shard_import(moshi_hot_model * m, int k) {
+    const moshi_hot_config & c = m->cfg;
+    Builder * b = new Builder(m->be, 16);
+    Builder & g = *b;
+    const int slot = k % m->depth.capacity;
+    int64_t w = 0;
+    for (auto & L : m->depth.layers) for (T cache : { L.kcache, L.vcache }) {
+        T rows = ring_rows(g, cache, slot);
+        g.expand(ggml_cpy(g, msg_rows(g, m->shard_msg, rows, w++), rows));   // F32 -> BF16 of BF16-valued floats: exact
+    }
+    g.expand(ggml_cpy(g, ggml_view_1d(g, m->shard_msg, 1, (size_t) (2 * c.dep_layers * c.dep_dim) * 4), ggml_view_1d(g, m->shard_tokens, 1, (size_t) k * 4)));
+    g.alloc();
+    if ((int) m->g_shard_import.size() <= k) m->g_shard_import.resize((size_t) k + 1, nullptr);
+    m->g_shard_import[(size_t) k] = b;
+}
+}  // namespace
+
+extern "C" void * moshi_hot_depth_shard_msg(moshi_hot_model_t * m, int64_t * n) { GGML_ASSERT(m->shard_msg); if (n) *n = ggml_nelements(m->shard_msg); return m->shard_msg->data; }
+extern "C" void * moshi_hot_depth_shard_tout(moshi_hot_model_t * m, int64_t * n) { GGML_ASSERT(m->shard_tout); if (n) *n = ggml_nelements(m->shard_tout); return m->shard_tout->data; }
+extern "C" void moshi_hot_depth_shard_begin_export(moshi_hot_model_t * m, int32_t text_token, int more) {
+    const moshi_hot_config & c = m->cfg;
+    if (!m->g_shard_begin) {
+        m->g_shard_begin = new Builder(m->be, 4);
+        Builder & g = *m->g_shard_begin;
+        g.expand(ggml_cpy(g, m->transformer_out, ggml_view_1d(g, m->shard_tout, c.dim, 0)));
+        g.alloc();
+    }
+    const float flag = more ? 1.f : 0.f;
+    ggml_backend_tensor_set(m->shard_tout, &flag, (size_t) c.dim * 4, 4);
+    m->g_shard_begin->compute();
+    if (owns_step(c, 0)) {
+        if (m->g_shard_step.empty() || !m->g_shard_step[0]) build_shard_step(m, 0);
+        int32_t id = text_token; const float sc = id == -1 ? 0.f : 1.f;   // moshi_lmmodel_depformer_step's text embedding (lm.h:532-552)
+        if (id < 0) id = 0;
+        ggml_backend_tensor_set(m->shard_text_idx[0], &id, 0, 4);
+        ggml_backend_tensor_set(m->shard_text_scale[0], &sc, 0, 4);
+    }
+}
+extern "C" int moshi_hot_depth_shard_begin_import(moshi_hot_model_t * m) {
+    const moshi_hot_config & c = m->cfg;
+    if (!m->g_shard_begin) {
+        m->g_shard_begin = new Builder(m->be, 4);
+        Builder & g = *m->g_shard_begin;
+        g.expand(ggml_cpy(g, ggml_view_1d(g, m->shard_tout, c.dim, 0), m->transformer_out));
+        g.alloc();
+    }
+    float flag = 0.f;
+    ggml_backend_tensor_get(m->shard_tout, &flag, (size_t) c.dim * 4, 4);
+    if (flag != 0.f) m->g_shard_begin->compute();
+    return flag != 0.f;
+}
+extern "C" void moshi_hot_depth_shard_step(moshi_hot_model_t * m, int k) {
+    PhaseTimer pt(m, 2);
+    if ((int) m->g_shard_step.size() <= k || !m->g_shard_step[(size_t) k]) build_shard_step(m, k);
+    m->g_shard_step[(size_t) k]->compute();
+}
+extern "C" void moshi_hot_depth_shard_import(moshi_hot_model_t * m, int k) {
+    if ((int) m->g_shard_import.size() <= k || !m->g_shard_import[(size_t) k]) build_shard_import(m, k);
+    m->g_shard_import[(size_t) k]->compute();
+}
+extern "C" void moshi_hot_depth_shard_tokens(moshi_hot_model_t * m, int32_t * out, int n) { ggml_backend_tensor_get(m->shard_tokens, out, 0, (size_t) n * 4); }
+extern "C" void moshi_hot_set_depth_hook(moshi_hot_model_t * m, moshi_hot_depth_hook_t fn, void * user) { m->depth_hook = fn; m->depth_hook_user = user; }
+
 extern "C" int moshi_hot_lm_step_n(moshi_hot_model_t * m, const int32_t * tokens, int n_tokens, int32_t * text_token_out, int32_t * out_audio, float * vad) {
     const moshi_hot_config & c = m->cfg;
     const int ncb = c.n_q + 1, CT = (int) m->cache.size();
@@ -1132,7 +1259,7 @@ extern "C" int moshi_hot_lm_step_n(moshi_hot_model_t * m, const int32_t * tokens
     std::vector<int32_t> audio((size_t) c.dep_q, 0);   // int_audio_tokens.resize(lm->dep_q) (lm.h:902)
     const bool replace = m->offset < c.delay_steps;    // depformer_replace_tokens (src/moshi.cpp:905)
     if (c.dep_q > 0) {
-        if (!replace) depth_step(m, text_token, audio);
+        if (!replace) { if (m->depth_hook) m->depth_hook(m->depth_hook_user, text_token, audio.data()); else depth_step(m, text_token, audio); }
         else for (auto & a : audio) a = -1;            // lm.h:910-913
         if (c.delay_steps)                             // on_audio_hook (lm.h:915-921)
             for (int q = 0; q < c.dep_q; q++) if (m->offset < c.delays[q + 1] + c.delay_steps) audio[(size_t) q] = -1;

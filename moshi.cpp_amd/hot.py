@@ -16,7 +16,8 @@ class Config(C.Structure):
                [(n, C.c_int32) for n in ("personaplex", "extra_heads", "extra_heads_dim",
                                          "demux_second_stream", "depformer_low_rank", "delay_steps", "cross_attention", "cross_len",
                                          "condition_sum", "dep_schedule_len")] + \
-               [("dep_schedule", C.c_int32 * MAX_CB), ("update_scale", C.c_float)]
+               [("dep_schedule", C.c_int32 * MAX_CB), ("update_scale", C.c_float),
+                ("dep_shard_rank", C.c_int32), ("dep_shard_world", C.c_int32), ("depth_only", C.c_int32)]
 
     @property
     def io_dep_q(self):
@@ -53,7 +54,16 @@ SIGNATURES = {
     "moshi_hot_get_timing": (None, [P, P]),
     "moshi_hot_last_raw_tokens": (None, [P, P, P]),
     "moshi_hot_layer_probe": (C.c_int, [P, C.c_int, C.c_int, C.c_int, P, C.c_int, P, P, P]),
+    "moshi_hot_depth_shard_msg": (P, [P, C.POINTER(C.c_int64)]),
+    "moshi_hot_depth_shard_tout": (P, [P, C.POINTER(C.c_int64)]),
+    "moshi_hot_depth_shard_begin_export": (None, [P, C.c_int32, C.c_int]),
+    "moshi_hot_depth_shard_begin_import": (C.c_int, [P]),
+    "moshi_hot_depth_shard_step": (None, [P, C.c_int]),
+    "moshi_hot_depth_shard_import": (None, [P, C.c_int]),
+    "moshi_hot_depth_shard_tokens": (None, [P, P, C.c_int]),
+    "moshi_hot_set_depth_hook": (None, [P, P, P]),
 }
+DEPTH_HOOK = C.CFUNCTYPE(None, C.c_void_p, C.c_int32, C.POINTER(C.c_int32))
 NODE_VISITOR = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_void_p)
 
 

@@ -541,3 +541,23 @@ def test_long_context_decode_is_deterministic():
         m.free()
     first = next((i for i, (a, b) in enumerate(zip(runs[0][0], runs[1][0])) if a != b), None)
     assert runs[0] == runs[1], f"two identical runs differ, first at frame {first}"
+
+
+def test_depth_shard_step_graphs_match_the_chained_graph_on_the_device():
+    # SURVEY.md 8e plumbing on the MI355X backend, one rank (no transport): per-step Depth graphs + K/V-row messages vs the chained graph, and vs
+    # the oracle's chained graph; the two-rank transport itself is covered on CPU (tests/test_depth_shard_cpu.py, gloo)
+    from moshi_cpp_amd import shard
+    cfg = hu.hot.tiny(hu.L, linear_type=F32, embed_type=F32)
+    cfg.enable_mimi_encoder = cfg.enable_mimi_decoder = 0
+    ref, _ = run_lm("oracle", cfg, 8)
+    chained, _ = run_lm("hip", cfg, 8)
+    cfg.dep_shard_world, cfg.dep_shard_rank = 1, 0
+    m = hu.Model("hip", cfg, seed=0)
+    sh = shard.DepthShard(hu.L, m.m, cfg, 0, 1, None)
+    sh.install()
+    rng = np.random.default_rng(3)
+    for i in range(8):
+        r, txt, aud = m.lm_step(rng.integers(0, cfg.card, cfg.n_q - cfg.io_dep_q).tolist())
+        assert (r, txt, aud) == ref[i][:3] == chained[i][:3], f"step {i}"
+        assert m.last_raw() == ref[i][5]
+    m.free()
