@@ -84,6 +84,8 @@ def main():
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"], help="control-plane backend for N > 1 (nccl = RCCL; gloo for single-GPU dry runs)")
     ap.add_argument("--device", type=int, default=None, help="override the device index (default LOCAL_RANK); only for dry runs of the N > 1 path on one GPU")
     ap.add_argument("--backend-flags", type=int, default=0, help="ggml_backend_mi355x_set_flags bits (2 = no hipGraph: use under rocprofv3)")
+    ap.add_argument("--sampled", action="store_true", help="the reference's own --bench sampling mode (tools/moshi-sts.cpp:106-107: Depth temperature 0.8, "
+                    "text temperature 0.7, top-k 250 / 25) instead of greedy; host rand() noise uploaded per compute as src/context.h:456-480 does")
     ap.add_argument("--shard", default="none", choices=["none", "depth"],
                     help="depth: ONE stream, the Depth transformer's per-codebook weight sets sharded over the ranks (SURVEY.md 8e: step k on rank k %% N, "
                          "K/V rows + token broadcast per step over RCCL); strong scaling. Default: independent stream replicas (weak scaling)")
@@ -154,6 +156,8 @@ def main():
         args.quant = "q8_0"
     elif args.quant != "q4_k":
         cfg.linear_type = {"q8_0": 8, "q4_0": 2}[args.quant]   # ggml_type ids
+    if args.sampled:
+        cfg.temp, cfg.temp_text = 0.8, 0.7
     shard = None
     if args.shard == "depth":
         if args.model not in ("moshika", "personaplex"):
@@ -263,7 +267,7 @@ def main():
         "config": {"workload": ({"tts_like": "moshi-tts loop: Temporal step (cross-attention, demux) + %d Depth steps + mimi decode (32 levels), ",
                                  "stt_like": "moshi-stt loop: mimi encode (32 levels) + Temporal step + VAD head (%d Depth steps), "}
                                 .get(args.model, "moshi-sts --bench loop: mimi encode + Temporal step + %d Depth steps + mimi decode, ") % cfg.dep_q) +
-                               "%s %s, 1 stream per GPU, greedy, ctx capacity %d" % (args.model, args.quant, cfg.context),
+                               "%s %s, 1 stream per GPU, %s, ctx capacity %d" % (args.model, args.quant, "sampled (temp 0.8 / 0.7, top-k 250 / 25)" if args.sampled else "greedy", cfg.context),
                    "context_fill_start": args.context_fill,
                    "parallelism": ("Depth codebook shard: step k on rank k %% %d, replicated 8-slot ring, 1 + dep_q broadcasts per frame" % world) if shard is not None
                                   else "independent stream replica per GPU" if world > 1 else "1 GPU",

@@ -1375,6 +1375,55 @@ static bool match_scalar_gather(const analysis & an, int pos, step_group & grp) 
     return true;
 }
 
+// H. the top-k sampler (moshi_sample_token with temp > 0, sampling.h:4-64), matched at its last node:
+//    out = get_rows(cont(permute(idx)), reshape(argmax(div(reshape(permute(get_rows(cont(permute(p)), idx))), noise))))
+//    with idx = view(argsort_desc(p), k), p = soft_max(scale(logits, 1 / temp))
+static bool match_sampler(const analysis & an, int pos, step_group & grp) {
+    const ggml_tensor * out = an.g->nodes[pos];
+    if (out->op != GGML_OP_GET_ROWS || out->type != GGML_TYPE_I32 || ggml_nelements(out) != 1) return false;
+    auto is = [&](const ggml_tensor * t, enum ggml_op op, int uses) { return t && t->op == op && pos_of(an, t) >= 0 && uses_of(an, t) == uses; };
+    const ggml_tensor * cont2 = out->src[0], * nx = out->src[1];
+    if (!is(cont2, GGML_OP_CONT, 1) || !is(cont2->src[0], GGML_OP_PERMUTE, 1)) return false;
+    const ggml_tensor * irows = cont2->src[0], * idx = irows->src[0];
+    if (!is(idx, GGML_OP_VIEW, 2) || !is(idx->src[0], GGML_OP_ARGSORT, 1) || idx->type != GGML_TYPE_I32 || idx->data != idx->src[0]->data) return false;
+    const ggml_tensor * srt = idx->src[0], * pr = srt->src[0];
+    if (srt->op_params[0] != GGML_SORT_ORDER_DESC || !is(pr, GGML_OP_SOFT_MAX, 2) || pr->src[1] != NULL) return false;
+    if (ggml_get_op_params_f32(pr, 0) != 1.0f || ggml_get_op_params_f32(pr, 1) != 0.0f) return false;
+    const ggml_tensor * sc = pr->src[0];
+    if (!is(sc, GGML_OP_SCALE, 1) || ggml_get_op_params_f32(sc, 1) != 0.0f) return false;
+    const ggml_tensor * logits = sc->src[0];
+    const int64_t n = pr->ne[0], k = idx->ne[0];
+    if (logits->type != GGML_TYPE_F32 || !ggml_is_contiguous(logits) || ggml_nelements(logits) != n || ggml_nelements(pr) != n || !logits->data) return false;
+    if (n > SAMPLE_MAX_N || k > SAMPLE_MAX_K || k < 1 || ggml_nelements(idx) != k) return false;
+    // the argmax side
+    while (nx && (nx->op == GGML_OP_RESHAPE || nx->op == GGML_OP_VIEW) && pos_of(an, nx) >= 0 && uses_of(an, nx) == 1) nx = nx->src[0];
+    std::vector<int> members = { pos, pos_of(an, cont2), pos_of(an, irows), pos_of(an, idx), pos_of(an, srt), pos_of(an, pr), pos_of(an, sc) };
+    for (const ggml_tensor * t = out->src[1]; t != nx; t = t->src[0]) members.push_back(pos_of(an, t));
+    const ggml_tensor * am = nx;
+    if (!is(am, GGML_OP_ARGMAX, 1)) return false;
+    const ggml_tensor * q = am->src[0];
+    if (!is(q, GGML_OP_DIV, 1) || q->view_src) return false;
+    const ggml_tensor * noise = q->src[1], * in2 = q->src[0];
+    if (noise->type != GGML_TYPE_F32 || ggml_nelements(noise) != k || !ggml_is_contiguous(noise) || !noise->data || pos_of(an, noise) >= 0) return false;
+    members.push_back(pos_of(an, am)); members.push_back(pos_of(an, q));
+    const ggml_tensor * t = in2;
+    while (t && (t->op == GGML_OP_RESHAPE || t->op == GGML_OP_PERMUTE || t->op == GGML_OP_VIEW) && pos_of(an, t) >= 0 && uses_of(an, t) == 1) { members.push_back(pos_of(an, t)); t = t->src[0]; }
+    if (!is(t, GGML_OP_GET_ROWS, 1) || t->src[1] != idx) return false;
+    members.push_back(pos_of(an, t));
+    const ggml_tensor * c1 = t->src[0];
+    if (!is(c1, GGML_OP_CONT, 1) || !is(c1->src[0], GGML_OP_PERMUTE, 1) || c1->src[0]->src[0] != pr) return false;
+    members.push_back(pos_of(an, c1)); members.push_back(pos_of(an, c1->src[0]));
+    for (int m : members) if (m < 0) return false;
+    sample_args a;
+    a.logits = (const float *) logits->data; a.n = (int) n; a.scale = ggml_get_op_params_f32(sc, 0); a.k = (int) k;
+    a.noise = (const float *) noise->data; a.out = (int32_t *) out->data;
+    grp.steps.clear();
+    grp.steps.push_back([=](hipStream_t s) { k_sample_topk(s, a); });
+    grp.members = members;
+    grp.emit_pos = pos;
+    return true;
+}
+
 // ---- plan construction --------------------------------------------------------------------------------------
 static plan_t * build_plan(hip_ctx * c, ggml_cgraph * g) {
     plan_t * p = new plan_t;
@@ -1430,6 +1479,19 @@ static plan_t * build_plan(hip_ctx * c, ggml_cgraph * g) {
             if (an.skip[(size_t) i] || !(g->nodes[i]->op == GGML_OP_CPY || g->nodes[i]->op == GGML_OP_CONCAT)) continue;
             step_group grp;
             if (!match_scalar_gather(an, i, grp)) continue;
+            bool clash = false;
+            for (int m : grp.members) if (an.skip[(size_t) m]) clash = true;
+            if (clash) continue;
+            for (int m : grp.members) an.skip[(size_t) m] = 1;
+            for (auto & f : grp.steps) at_pos[grp.emit_pos].push_back(f);
+            p->n_fused += (int) grp.members.size();
+        }
+        // top-k samplers (temp > 0)
+        static const bool no_sampler = getenv("MI355X_NO_SAMPLER_FUSION") != nullptr;
+        for (int i = g->n_nodes - 1; i >= 0 && !no_sampler; i--) {
+            if (an.skip[(size_t) i] || g->nodes[i]->op != GGML_OP_GET_ROWS || g->nodes[i]->type != GGML_TYPE_I32) continue;
+            step_group grp;
+            if (!match_sampler(an, i, grp)) continue;
             bool clash = false;
             for (int m : grp.members) if (an.skip[(size_t) m]) clash = true;
             if (clash) continue;

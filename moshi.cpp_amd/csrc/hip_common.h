@@ -172,5 +172,11 @@ struct vq_level_args {
 #define GATHER_MAX 32
 struct gather_args { const float * src[GATHER_MAX]; int n; void * dst; int dst_type; };
 void k_gather_scalars(hipStream_t s, const gather_args & a);
+// moshi_sample_token with temp > 0 (sampling.h:4-64): soft_max(logits / temp) -> top-k (descending, ties by lower index) -> p / Exp(1) noise ->
+// argmax -> the chosen index, as one launch (the node chain costs ~12 launches and a full argsort of up to 32 000 values)
+#define SAMPLE_MAX_N 32768
+#define SAMPLE_MAX_K 256
+struct sample_args { const float * logits; int n; float scale; int k; const float * noise; int32_t * out; };
+void k_sample_topk(hipStream_t s, const sample_args & a);
 #define VQ_LEVEL_WS_BYTES 4096
 void k_vq_level(hipStream_t s, const vq_level_args & a);

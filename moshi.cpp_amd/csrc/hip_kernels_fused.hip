@@ -2045,6 +2045,150 @@ void k_vq_level(hipStream_t s, const vq_level_args & a) {
     vq_level_kernel<<<grid, 256, 0, s>>>(a);
 }
 
+// ---------------------------------------------------------------------------------------------------
+// fused sampler (moshi_sample_token, temp > 0; src/moshi/utils/sampling.h:4-64)
+//   p = soft_max(logits * (1 / temp))  [ggml: expf(x - max) summed in double, scaled by float(1 / sum)]
+//   top-k of p, descending, ties by lower index (the argsort convention of this library)
+//   q_j = p_(j) / noise_j  (Exp(1) noise drawn on the host per compute, src/context.h:456-480);  token = index of the LAST maximum of q
+// One workgroup; every thread keeps n / 1024 probabilities in registers. The k-th largest value is found by a 4-pass radix select on the
+// float bits (p >= 0, so the bit patterns order like the values), the k survivors are rank-sorted in LDS.
+// ---------------------------------------------------------------------------------------------------
+#define SMP_THREADS 1024
+#define SMP_NPT (SAMPLE_MAX_N / SMP_THREADS)
+__global__ void __launch_bounds__(SMP_THREADS) sample_topk_kernel(sample_args a) {
+    __shared__ float shf[SMP_THREADS / 64];
+    __shared__ double shd[SMP_THREADS / 64];
+    __shared__ int shi[SMP_THREADS / 64];
+    __shared__ unsigned hist[256];
+    __shared__ unsigned s_bin, s_remaining, s_ncand, s_eq, s_base;
+    __shared__ float cand_p[SAMPLE_MAX_K], sort_p[SAMPLE_MAX_K];
+    __shared__ int cand_i[SAMPLE_MAX_K], sort_i[SAMPLE_MAX_K];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = a.n, k = a.k;
+    constexpr int NW = SMP_THREADS / 64;
+    float p[SMP_NPT];
+    // ---- soft_max
+    float mx = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < SMP_NPT; j++) {
+        const int i = tid + j * SMP_THREADS;
+        p[j] = i < n ? a.logits[i] * a.scale : -INFINITY;
+        mx = fmaxf(mx, p[j]);
+    }
+    mx = wave_allmax_f32(mx);
+    if (lane == 0) shf[wave] = mx;
+    if (tid == 0) { s_ncand = 0u; }
+    __syncthreads();
+    mx = shf[0];
+#pragma unroll
+    for (int w = 1; w < NW; w++) mx = fmaxf(mx, shf[w]);
+    double sum = 0;
+#pragma unroll
+    for (int j = 0; j < SMP_NPT; j++) {
+        const int i = tid + j * SMP_THREADS;
+        const float e = i < n ? expf(p[j] - mx) : 0.f;
+        p[j] = e;
+        sum += (double) e;
+    }
+    sum = wave_allsum_f64(sum);
+    if (lane == 0) shd[wave] = sum;
+    __syncthreads();
+    sum = 0;
+#pragma unroll
+    for (int w = 0; w < NW; w++) sum += shd[w];
+    const float inv = (float) (1.0 / sum);
+#pragma unroll
+    for (int j = 0; j < SMP_NPT; j++) p[j] *= inv;
+    // ---- k-th largest by radix select over the bit patterns
+    unsigned prefix = 0u, mask = 0u, remaining = (unsigned) k;
+    for (int shift = 24; shift >= 0; shift -= 8) {
+        if (tid < 256) hist[tid] = 0u;
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < SMP_NPT; j++) {
+            const int i = tid + j * SMP_THREADS;
+            const unsigned key = __float_as_uint(p[j]);
+            if (i < n && (key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1u);
+        }
+        __syncthreads();
+        if (wave == 0) {
+            // lane l owns bins 255 - 4 l .. 252 - 4 l (descending); inclusive prefix over lanes, first lane reaching `remaining` resolves its bin
+            unsigned h[4], tot = 0;
+#pragma unroll
+            for (int t = 0; t < 4; t++) { h[t] = hist[255 - (4 * lane + t)]; tot += h[t]; }
+            unsigned inc = tot;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const unsigned up = __shfl_up(inc, o, 64); if (lane >= o) inc += up; }
+            const unsigned long long hit = __ballot(inc >= remaining);
+            const int first = __ffsll((long long) hit) - 1;
+            if (lane == first) {
+                unsigned before = inc - tot;
+                int t = 0;
+                while (t < 3 && before + h[t] < remaining) { before += h[t]; t++; }
+                s_bin = 255u - (unsigned) (4 * lane + t);
+                s_remaining = remaining - before;
+                s_eq = h[t];
+            }
+        }
+        __syncthreads();
+        prefix |= s_bin << shift;
+        mask |= 255u << shift;
+        remaining = s_remaining;
+    }
+    const unsigned T = prefix, need_eq = remaining, have_eq = s_eq;   // key of the k-th largest; how many of its ties belong to the top k
+    // ---- collect: everything above T, then the `need_eq` lowest-indexed ties
+#pragma unroll
+    for (int j = 0; j < SMP_NPT; j++) {
+        const int i = tid + j * SMP_THREADS;
+        const unsigned key = __float_as_uint(p[j]);
+        if (i < n && (key > T || (key == T && have_eq == need_eq))) { const unsigned c = atomicAdd(&s_ncand, 1u); if (c < SAMPLE_MAX_K) { cand_p[c] = p[j]; cand_i[c] = i; } }
+    }
+    if (have_eq != need_eq) {   // more ties than places (rare: exact float ties at the cut): take them in index order, j-major / thread-minor
+        if (tid == 0) s_base = 0u;
+        __syncthreads();
+        for (int j = 0; j < SMP_NPT; j++) {
+            const int i = tid + j * SMP_THREADS;
+            const bool f = i < n && __float_as_uint(p[j]) == T;
+            const unsigned long long b = __ballot(f);
+            if (lane == 0) shi[wave] = __popcll(b);
+            __syncthreads();
+            unsigned off = s_base;
+            for (int w = 0; w < wave; w++) off += (unsigned) shi[w];
+            off += (unsigned) __popcll(b & ((1ull << lane) - 1ull));
+            if (f && off < need_eq) { const unsigned c = atomicAdd(&s_ncand, 1u); if (c < SAMPLE_MAX_K) { cand_p[c] = p[j]; cand_i[c] = i; } }
+            __syncthreads();
+            if (tid == 0) { unsigned tot = 0; for (int w = 0; w < NW; w++) tot += (unsigned) shi[w]; s_base += tot; }
+            __syncthreads();
+        }
+    }
+    __syncthreads();
+    // ---- rank sort of the k survivors: value descending, index ascending
+    if (tid < k) {
+        const float pc = cand_p[tid]; const int ic = cand_i[tid];
+        int rank = 0;
+        for (int d = 0; d < k; d++) { const float pd = cand_p[d]; rank += (pd > pc || (pd == pc && cand_i[d] < ic)) ? 1 : 0; }
+        sort_p[rank] = pc; sort_i[rank] = ic;
+    }
+    __syncthreads();
+    // ---- q = p / noise, LAST maximum (ggml_vec_argmax_f32)
+    float best = -INFINITY; int bj = -1;
+    if (tid < k) { best = sort_p[tid] / a.noise[tid]; bj = tid; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(best, o, 64); const int oj = __shfl_xor(bj, o, 64);
+        if (ov > best || (ov == best && oj > bj)) { best = ov; bj = oj; }
+    }
+    if (lane == 0) { shf[wave] = best; shi[wave] = bj; }
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < NW; w++) if (shf[w] > best || (shf[w] == best && shi[w] > bj)) { best = shf[w]; bj = shi[w]; }
+        *a.out = sort_i[bj < 0 ? 0 : bj];
+    }
+}
+void k_sample_topk(hipStream_t s, const sample_args & a) {
+    GGML_ASSERT(a.n >= 1 && a.n <= SAMPLE_MAX_N && a.k >= 1 && a.k <= SAMPLE_MAX_K && a.k <= a.n);
+    sample_topk_kernel<<<1, SMP_THREADS, 0, s>>>(a);
+}
+
 __global__ void gather_scalars_kernel(gather_args a) {
     const int i = threadIdx.x;
     if (i >= a.n) return;

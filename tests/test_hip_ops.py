@@ -437,3 +437,35 @@ def test_quantised_matvec_against_the_numpy_golden_vectors(kind):
         y = gu.run_graph("hip", build, flags=flags)[0][0].reshape(-1)
         ref = Q[kind + "_y"]
         assert np.abs(y - ref).max() <= 2e-6 * np.abs(ref).max(), (kind, flags, np.abs(y - ref).max())
+
+
+@pytest.mark.parametrize("n,k,case", [(32000, 25, "random"), (2048, 250, "random"), (2048, 250, "ties"), (32000, 25, "peaked"), (2049, 250, "zeros"), (300, 250, "random")])
+def test_fused_sampler_matches_the_node_chain(n, k, case):
+    # the one-launch sampler (k_sample_topk) at the real shapes of moshi_sample_token (text: 32000 logits, top 25; audio: 2048, top 250), incl.
+    # exact ties inside and at the top-k cut, a distribution so peaked that most probabilities underflow to 0 (ties at zero: lower index first),
+    # against the oracle's node-by-node chain; several noise draws each
+    r = np.random.default_rng(n + k)
+    logits = (r.standard_normal((1, n)) * 3).astype(np.float32)
+    if case == "ties":
+        logits[0, r.integers(0, n, 600)] = np.float32(1.25)          # hundreds of equal values straddling the cut
+        logits[0, 5] = logits[0, 1900] = logits[0].max()              # and an exact tie for first place
+    elif case == "peaked":
+        logits *= 40
+    elif case == "zeros":
+        logits[0, 200:] = -1e4                                        # expf underflows: exact zeros from index 200 on, k = 250 reaches into them
+    for draw in range(3):
+        noise = r.exponential(1.0, (1, k)).astype(np.float32)
+
+        def build(g):
+            probs = g.soft_max(g.scale(g.input(logits), 1.0 / 0.8))
+            indices = g.argsort_top_k(probs, k)
+            rows = g.get_rows(g.cont(g.permute(probs, 1, 0, 2, 3)), indices)
+            p2 = g.permute(rows, 1, 0, 2, 3)
+            in2 = g.reshape_2d(p2, p2.contents.ne[0], p2.contents.ne[1] * p2.contents.ne[2] * p2.contents.ne[3])
+            nxt = g.argmax(g.div(in2, g.input(noise)))
+            nxt4 = g.reshape_4d(nxt, nxt.contents.ne[0], p2.contents.ne[1], p2.contents.ne[2], p2.contents.ne[3])
+            return [g.get_rows(g.cont(g.permute(indices, 1, 0, 2, 3)), nxt4)]
+        ref, got, st = gu.compare(build)
+        assert st.fused_nodes_in_last_plan >= 12, "the sampler chain was not fused"
+        plain, _ = gu.run_graph("hip", build, flags=1)
+        assert np.array_equal(plain[0], ref[0])
