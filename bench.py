@@ -61,6 +61,18 @@ def shard_hop_latency(shard, dist, group, L, be, n=200):
     return round(1e6 * (time.perf_counter() - t0) / n, 2)
 
 
+def source_sha():
+    """hash of the kernel / backend sources the library was built from: profile files under profiles/ carry it, and a counter file taken from
+    other sources is refused (its numbers would describe another kernel)"""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "moshi.cpp_amd", "csrc", "*"))):
+        with open(f, "rb") as fh:
+            h.update(os.path.basename(f).encode() + b"\0" + fh.read())
+    return h.hexdigest()[:16]
+
+
 def device_sync():
     hip = C.CDLL("libamdhip64.so")
     hip.hipDeviceSynchronize()
@@ -84,6 +96,7 @@ def main():
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"], help="control-plane backend for N > 1 (nccl = RCCL; gloo for single-GPU dry runs)")
     ap.add_argument("--device", type=int, default=None, help="override the device index (default LOCAL_RANK); only for dry runs of the N > 1 path on one GPU")
     ap.add_argument("--backend-flags", type=int, default=0, help="ggml_backend_mi355x_set_flags bits (2 = no hipGraph: use under rocprofv3)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the extra lines (sampled mode, long context, PersonaPlex) that ride in the JSON's `extras` object")
     ap.add_argument("--sampled", action="store_true", help="the reference's own --bench sampling mode (tools/moshi-sts.cpp:106-107: Depth temperature 0.8, "
                     "text temperature 0.7, top-k 250 / 25) instead of greedy; host rand() noise uploaded per compute as src/context.h:456-480 does")
     ap.add_argument("--shard", default="none", choices=["none", "depth"],
@@ -289,6 +302,11 @@ def main():
         L.moshi_hot_get_timing(m, ph)
         L.moshi_hot_set_timing(m, 0)
         result["phase_us"] = {"mimi_encode": round(ph[0], 1), "temporal": round(ph[1], 1), "depth": round(ph[2], 1), "mimi_decode": round(ph[3], 1)}
+        # algorithmic bytes of each phase (every weight byte once + the live KV rows) over its synchronised wall time
+        pb = {"temporal": wb[0] + kv_bytes + (cfg.n_q + 1) * cfg.dim * 18 / 32, "depth": wb[1] + cfg.dep_q * cfg.dep_dim * 18 / 32, "mimi_encode": wb[2], "mimi_decode": wb[3]}
+        result["phase_roofline"] = {k: {"bytes": int(pb[k]), "GB/s": round(pb[k] / (result["phase_us"][k] * 1e-6) / 1e9, 1) if result["phase_us"][k] else None,
+                                        "frac": round(pb[k] / (result["phase_us"][k] * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4) if result["phase_us"][k] else None} for k in pb}
+        result["source_sha"] = source_sha()
 
     if shard is not None:
         shard.stop_workers()
@@ -312,16 +330,20 @@ def main():
         L.ggml_backend_mi355x_set_flags(be, args.backend_flags)
         # HBM bytes per launch from the PMC pass committed under profiles/ (rocprofv3 --pmc FETCH_SIZE on this same command,
         # corrected as MI355X_MICROARCH.md prescribes); counters cannot be read from inside the timed process
-        traffic = None
+        traffic, traffic_note = None, "no counter file for these sources"
         try:
-            with open(os.path.join(ROOT, "profiles", "r01_pmc_fetch_size.json")) as f:
-                traffic = json.load(f)["matvec_q4k_kernel"]["fetch_bytes_per_launch"]
+            with open(os.path.join(ROOT, "profiles", "r02_pmc_fetch_size.json")) as f:
+                pmc = json.load(f)
+            if pmc.get("source_sha") == source_sha():
+                traffic, traffic_note = pmc["matvec_q4k_kernel"]["fetch_bytes_per_launch"], "profiles/r02_pmc_fetch_size.json (rocprofv3 --pmc FETCH_SIZE, x2 gfx950 correction)"
+            else:
+                traffic_note = "profiles/r02_pmc_fetch_size.json was taken from other sources (%s, now %s): refused" % (pmc.get("source_sha"), source_sha())
         except Exception:
             pass
         if kp.launches:
             gbps = kp.bytes / kp.seconds / 1e9
             result["roofline"] = {"bound": "hbm", "achieved": round(gbps, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                                  "frac": round(gbps / HBM_PEAK_GBPS, 4), "traffic": traffic,
+                                  "frac": round(gbps / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": traffic_note,
                                   "kernel": "matvec_q4k_kernel", "launches_per_frame": int(kp.launches // 3),
                                   "avg_launch_us": round(1e6 * kp.seconds / kp.launches, 3),
                                   "algorithmic_bytes_per_launch": int(kp.bytes // kp.launches)}
@@ -359,7 +381,43 @@ def main():
         except Exception as e:  # the baseline is auxiliary; never lose the GPU number over it
             result["cpu_baseline"] = {"value": None, "unit": "frames/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e}"}
 
-    L.moshi_hot_free(m)
+    if rank == 0 and world == 1 and shard is None and not args.no_extras and args.model == "moshika" and args.quant == "q4_k" and not args.sampled and not args.context_fill:
+        # not the headline: the same loop (a) with the reference's --bench sampling defaults, (b) from a nearly full ring, (c) at BASELINE configs[4]
+        def quick(make_cfg, fill=0, steps=40):
+            c2 = make_cfg()
+            mm = L.moshi_hot_create(be, C.byref(c2), 0)
+            if fill:
+                L.moshi_hot_set_context_fill(mm, fill)
+            for _ in range(6):
+                L.moshi_hot_sts_frame(mm, pcm.ctypes.data, C.byref(txt), aud, out.ctypes.data)
+            L.ggml_backend_synchronize(be)
+            t1 = time.perf_counter()
+            for _ in range(steps):
+                L.moshi_hot_sts_frame(mm, pcm.ctypes.data, C.byref(txt), aud, out.ctypes.data)
+            L.ggml_backend_synchronize(be)
+            r = steps / (time.perf_counter() - t1)
+            L.moshi_hot_free(mm)
+            return round(r, 2)
+
+        def sampled_cfg():
+            c2 = hot.moshika(L); c2.temp, c2.temp_text = 0.8, 0.7
+            return c2
+
+        def pp_cfg():
+            c2 = hot.personaplex(L); c2.context = 2000
+            return c2
+        L.moshi_hot_free(m)
+        m = None
+        try:
+            result["extras"] = {
+                "sampled_temp_0.8_0.7_frames_per_s": quick(sampled_cfg),
+                "context_fill_2800_of_3000_frames_per_s": quick(lambda: hot.moshika(L), fill=2800),
+                "personaplex_ctx2000_fill_1900_frames_per_s": quick(pp_cfg, fill=1900),
+            }
+        except Exception as e:
+            result["extras"] = {"error": str(e)}
+    if m is not None:
+        L.moshi_hot_free(m)
     if rank == 0:
         print(json.dumps(result), flush=True)
     if dist is not None:

@@ -2061,8 +2061,10 @@ __global__ void __launch_bounds__(SMP_THREADS) sample_topk_kernel(sample_args a)
     __shared__ int shi[SMP_THREADS / 64];
     __shared__ unsigned hist[256];
     __shared__ unsigned s_bin, s_remaining, s_ncand, s_eq, s_base;
-    __shared__ float cand_p[SAMPLE_MAX_K], sort_p[SAMPLE_MAX_K];
-    __shared__ int cand_i[SAMPLE_MAX_K], sort_i[SAMPLE_MAX_K];
+    __shared__ __attribute__((aligned(16))) float cand_p[SAMPLE_MAX_K + 8];
+    __shared__ __attribute__((aligned(16))) int cand_i[SAMPLE_MAX_K + 8];
+    __shared__ float sort_p[SAMPLE_MAX_K];
+    __shared__ int sort_i[SAMPLE_MAX_K];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = a.n, k = a.k;
     constexpr int NW = SMP_THREADS / 64;
     float p[SMP_NPT];
@@ -2084,6 +2086,7 @@ __global__ void __launch_bounds__(SMP_THREADS) sample_topk_kernel(sample_args a)
     double sum = 0;
 #pragma unroll
     for (int j = 0; j < SMP_NPT; j++) {
+        if (j * SMP_THREADS >= n) { p[j] = 0.f; continue; }
         const int i = tid + j * SMP_THREADS;
         const float e = i < n ? expf(p[j] - mx) : 0.f;
         p[j] = e;
@@ -2098,6 +2101,7 @@ __global__ void __launch_bounds__(SMP_THREADS) sample_topk_kernel(sample_args a)
     const float inv = (float) (1.0 / sum);
 #pragma unroll
     for (int j = 0; j < SMP_NPT; j++) p[j] *= inv;
+    {
     // ---- k-th largest by radix select over the bit patterns
     unsigned prefix = 0u, mask = 0u, remaining = (unsigned) k;
     for (int shift = 24; shift >= 0; shift -= 8) {
@@ -2105,9 +2109,26 @@ __global__ void __launch_bounds__(SMP_THREADS) sample_topk_kernel(sample_args a)
         __syncthreads();
 #pragma unroll
         for (int j = 0; j < SMP_NPT; j++) {
+            if (j * SMP_THREADS >= n) break;
             const int i = tid + j * SMP_THREADS;
             const unsigned key = __float_as_uint(p[j]);
-            if (i < n && (key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1u);
+            // probabilities crowd into a handful of exponent bins: lanes that hit the same bin add ONCE (one LDS atomic per distinct bin and
+            // wave-instruction; 2 048 same-address atomics per pass cost ~18 us otherwise)
+            bool todo = i < n && (key & mask) == prefix;
+            const unsigned bin = (key >> shift) & 255u;
+            if (shift != 24) {   // lower digits are spread over the bins: plain atomics do not collide (and the loop below would run once per distinct bin)
+                if (todo) atomicAdd(&hist[bin], 1u);
+                continue;
+            }
+            unsigned long long left = __ballot(todo);
+            while (left) {
+                const int leader = __ffsll((long long) left) - 1;
+                const unsigned lb = (unsigned) __shfl((int) bin, leader, 64);
+                const unsigned long long same = __ballot(todo && bin == lb);
+                if (lane == leader) atomicAdd(&hist[lb], (unsigned) __popcll(same));
+                if (bin == lb) todo = false;
+                left &= ~same;
+            }
         }
         __syncthreads();
         if (wave == 0) {
@@ -2138,14 +2159,23 @@ __global__ void __launch_bounds__(SMP_THREADS) sample_topk_kernel(sample_args a)
     // ---- collect: everything above T, then the `need_eq` lowest-indexed ties
 #pragma unroll
     for (int j = 0; j < SMP_NPT; j++) {
+        if (j * SMP_THREADS >= n) break;
         const int i = tid + j * SMP_THREADS;
         const unsigned key = __float_as_uint(p[j]);
-        if (i < n && (key > T || (key == T && have_eq == need_eq))) { const unsigned c = atomicAdd(&s_ncand, 1u); if (c < SAMPLE_MAX_K) { cand_p[c] = p[j]; cand_i[c] = i; } }
+        const bool take = i < n && (key > T || (key == T && have_eq == need_eq));
+        const unsigned long long tb = __ballot(take);   // one LDS atomic per wave-instruction, not per survivor
+        if (tb) {
+            unsigned base = 0;
+            if (lane == __ffsll((long long) tb) - 1) base = atomicAdd(&s_ncand, (unsigned) __popcll(tb));
+            base = (unsigned) __shfl((int) base, __ffsll((long long) tb) - 1, 64);
+            const unsigned c = base + (unsigned) __popcll(tb & ((1ull << lane) - 1ull));
+            if (take && c < SAMPLE_MAX_K) { cand_p[c] = p[j]; cand_i[c] = i; }
+        }
     }
     if (have_eq != need_eq) {   // more ties than places (rare: exact float ties at the cut): take them in index order, j-major / thread-minor
         if (tid == 0) s_base = 0u;
         __syncthreads();
-        for (int j = 0; j < SMP_NPT; j++) {
+        for (int j = 0; j < SMP_NPT && j * SMP_THREADS < n; j++) {
             const int i = tid + j * SMP_THREADS;
             const bool f = i < n && __float_as_uint(p[j]) == T;
             const unsigned long long b = __ballot(f);
@@ -2160,15 +2190,24 @@ __global__ void __launch_bounds__(SMP_THREADS) sample_topk_kernel(sample_args a)
             __syncthreads();
         }
     }
+    if (tid < 8) { cand_p[k + tid] = -1.f; cand_i[k + tid] = 0x7fffffff; }   // sentinels (p >= 0): the sort below reads eight candidates at a time
     __syncthreads();
     // ---- rank sort of the k survivors: value descending, index ascending
     if (tid < k) {
         const float pc = cand_p[tid]; const int ic = cand_i[tid];
         int rank = 0;
-        for (int d = 0; d < k; d++) { const float pd = cand_p[d]; rank += (pd > pc || (pd == pc && cand_i[d] < ic)) ? 1 : 0; }
+        for (int d0 = 0; d0 < k; d0 += 8) {
+            const float4 pa = *(const float4 *) (cand_p + d0), pb = *(const float4 *) (cand_p + d0 + 4);
+            const int4 ia = *(const int4 *) (cand_i + d0), ib = *(const int4 *) (cand_i + d0 + 4);
+            const float pd[8] = { pa.x, pa.y, pa.z, pa.w, pb.x, pb.y, pb.z, pb.w };
+            const int id[8] = { ia.x, ia.y, ia.z, ia.w, ib.x, ib.y, ib.z, ib.w };
+#pragma unroll
+            for (int u = 0; u < 8; u++) rank += (pd[u] > pc || (pd[u] == pc && id[u] < ic)) ? 1 : 0;
+        }
         sort_p[rank] = pc; sort_i[rank] = ic;
     }
     __syncthreads();
+    }
     // ---- q = p / noise, LAST maximum (ggml_vec_argmax_f32)
     float best = -INFINITY; int bj = -1;
     if (tid < k) { best = sort_p[tid] / a.noise[tid]; bj = tid; }

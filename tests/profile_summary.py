@@ -29,7 +29,10 @@ def pmc(src, dst):
         k = r["Kernel_Name"].split("(")[0]
         agg[k][0] += 1
         agg[k][1] += float(r["Counter_Value"])
-    out = {"unit": "bytes per launch = 2 * 1024 * FETCH_SIZE[KB] (gfx950 wide-read correction)", "kernels": {}}
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    out = {"unit": "bytes per launch = 2 * 1024 * FETCH_SIZE[KB] (gfx950 wide-read correction)", "source_sha": bench.source_sha(), "kernels": {}}
     mv = [0, 0.0]
     for k, (n, kb) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
         out["kernels"][k] = {"launches": n, "fetch_bytes_per_launch": round(2 * 1024 * kb / n)}
