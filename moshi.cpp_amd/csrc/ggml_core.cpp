@@ -897,16 +897,61 @@ static void get_scale_min_k4(int j, const uint8_t * q, uint8_t * d, uint8_t * m)
     else { *d = (q[j + 4] & 0xF) | ((q[j - 4] >> 6) << 4); *m = (q[j + 4] >> 4) | ((q[j] >> 6) << 4); }
 }
 
+// make_qkx2_quants [ggml-upstream, ggml-quants.c]: affine quantisation x ~ scale * l + min of n values to l in [0, nmax] that minimises the weighted squared
+// error, searched over nstep + 1 candidate scales around nmax / (max - min) with a closed-form (scale, min) refit for each; returns scale, *the_min = -min
+static float make_qkx2_quants(int n, int nmax, const float * x, const float * weights, uint8_t * L, float * the_min, uint8_t * Laux,
+                              float rmin, float rdelta, int nstep) {
+    float min = x[0], max = x[0], sum_w = weights[0], sum_x = sum_w * x[0];
+    for (int i = 1; i < n; ++i) {
+        if (x[i] < min) min = x[i];
+        if (x[i] > max) max = x[i];
+        const float w = weights[i];
+        sum_w += w; sum_x += w * x[i];
+    }
+    if (min > 0) min = 0;
+    if (max == min) { for (int i = 0; i < n; ++i) L[i] = 0; *the_min = -min; return 0.f; }
+    float iscale = nmax / (max - min), scale = 1 / iscale, best_mad = 0;
+    for (int i = 0; i < n; ++i) {
+        int l = nearest_int(iscale * (x[i] - min));
+        L[i] = (uint8_t) (l < 0 ? 0 : l > nmax ? nmax : l);
+        float diff = scale * L[i] + min - x[i];
+        diff = diff * diff;
+        best_mad += weights[i] * diff;
+    }
+    for (int is = 0; is <= nstep; ++is) {
+        iscale = (rmin + rdelta * is + nmax) / (max - min);
+        float sum_l = 0, sum_l2 = 0, sum_xl = 0;
+        for (int i = 0; i < n; ++i) {
+            int l = nearest_int(iscale * (x[i] - min));
+            l = l < 0 ? 0 : l > nmax ? nmax : l;
+            Laux[i] = (uint8_t) l;
+            const float w = weights[i];
+            sum_l += w * l; sum_l2 += w * l * l; sum_xl += w * l * x[i];
+        }
+        const float D = sum_w * sum_l2 - sum_l * sum_l;
+        if (D > 0) {
+            float this_scale = (sum_w * sum_xl - sum_x * sum_l) / D, this_min = (sum_l2 * sum_x - sum_l * sum_xl) / D;
+            if (this_min > 0) { this_min = 0; this_scale = sum_xl / sum_l2; }
+            float mad = 0;
+            for (int i = 0; i < n; ++i) { float diff = this_scale * Laux[i] + this_min - x[i]; diff = diff * diff; mad += weights[i] * diff; }
+            if (mad < best_mad) { for (int i = 0; i < n; ++i) L[i] = Laux[i]; best_mad = mad; scale = this_scale; min = this_min; }
+        }
+    }
+    *the_min = -min;
+    return scale;
+}
+
+// quantize_row_q4_K_ref [ggml-upstream], one super-block: w = d * sc * q - dmin * m with 6-bit (sc, m) per 32-weight sub-block
 static void quantize_q4_K_block(const float * x, block_q4_K * y) {
-    // per 32-weight sub-block: affine 4-bit quantisation w = d*sc*q - dmin*m with 6-bit (sc, m)
-    float scales[8], mins[8];
+    uint8_t L[256], Laux[32];
+    float weights[32], mins[8], scales[8];
     float max_scale = 0, max_min = 0;
     for (int j = 0; j < 8; j++) {
-        float mn = x[32 * j], mx = x[32 * j];
-        for (int l = 1; l < 32; l++) { float v = x[32 * j + l]; if (v < mn) mn = v; if (v > mx) mx = v; }
-        if (mn > 0) mn = 0;
-        scales[j] = (mx - mn) / 15.f;
-        mins[j] = -mn;
+        float sum_x2 = 0;
+        for (int l = 0; l < 32; ++l) sum_x2 += x[32 * j + l] * x[32 * j + l];
+        const float av_x = sqrtf(sum_x2 / 32);
+        for (int l = 0; l < 32; ++l) weights[l] = av_x + fabsf(x[32 * j + l]);
+        scales[j] = make_qkx2_quants(32, 15, x + 32 * j, weights, L + 32 * j, &mins[j], Laux, -1.f, 0.1f, 20);
         if (scales[j] > max_scale) max_scale = scales[j];
         if (mins[j] > max_min) max_min = mins[j];
     }
@@ -927,14 +972,14 @@ static void quantize_q4_K_block(const float * x, block_q4_K * y) {
     }
     y->d    = ggml_fp32_to_fp16(max_scale / 63.f);
     y->dmin = ggml_fp32_to_fp16(max_min / 63.f);
-    uint8_t L[256];
     for (int j = 0; j < 8; j++) {
         uint8_t sc, m;
         get_scale_min_k4(j, y->scales, &sc, &m);
         const float d = ggml_fp16_to_fp32(y->d) * sc;
+        if (!d) continue;                                   // (the search's own L stays)
         const float dm = ggml_fp16_to_fp32(y->dmin) * m;
         for (int l = 0; l < 32; l++) {
-            int q = d ? nearest_int((x[32 * j + l] + dm) / d) : 0;
+            int q = nearest_int((x[32 * j + l] + dm) / d);
             L[32 * j + l] = (uint8_t) (q < 0 ? 0 : q > 15 ? 15 : q);
         }
     }

@@ -1741,7 +1741,13 @@ static void hip_backend_sync(ggml_backend_t b) {
 static bool hip_supports_op(ggml_backend_t, const struct ggml_tensor * op) {
     switch (op->op) {
         case GGML_OP_CPY: case GGML_OP_CONT: case GGML_OP_DUP:
-            if (ggml_is_quantized(op->type) || ggml_is_quantized(op->src[0]->type)) return op->type == op->src[0]->type;
+            if (ggml_is_quantized(op->type) || ggml_is_quantized(op->src[0]->type)) {
+                if (op->type == op->src[0]->type) return true;
+                // load-time (re)quantisation of float rows (src/loader.h:160-187): F32 / F16 / BF16 -> Q8_0 / Q4_0 / Q4_K
+                const enum ggml_type st = op->src[0]->type;
+                return (st == GGML_TYPE_F32 || st == GGML_TYPE_F16 || st == GGML_TYPE_BF16) &&
+                       (op->type == GGML_TYPE_Q8_0 || op->type == GGML_TYPE_Q4_0 || op->type == GGML_TYPE_Q4_K) && op->src[0]->ne[0] % ggml_blck_size(op->type) == 0;
+            }
             return true;
         case GGML_OP_MUL_MAT:
             switch (op->src[0]->type) { case GGML_TYPE_F32: case GGML_TYPE_F16: case GGML_TYPE_BF16: case GGML_TYPE_Q4_0: case GGML_TYPE_Q8_0: case GGML_TYPE_Q4_K: return true; default: return false; }

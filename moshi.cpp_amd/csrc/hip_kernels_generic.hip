@@ -89,14 +89,179 @@ __global__ void cpy_kernel(tdesc dst, tdesc src, int64_t n) {
         st_from_f32(dp, dst.type, ld_as_f32(sp, src.type));
     }
 }
+// ---- weight (re)quantisation on the device: ggml_cast / cpy of F32 / F16 / BF16 rows to Q8_0 / Q4_0 / Q4_K (WeightLoader's load-time cast,
+// ---- src/loader.h:160-187), the same float operations in the same order as the host quantisers of ggml_core.cpp, hence the same bytes ------
+// element (i0, row r) of the source rows as F32; rows are the flattened dims 1..3
+struct qsrc { const char * base; int64_t nb0, nb1, nb2, nb3, ne1, ne2; int type; };
+__device__ __forceinline__ float qsrc_at(const qsrc & q, int64_t i0, int64_t r) {
+    const int64_t i1 = r % q.ne1, i2 = (r / q.ne1) % q.ne2, i3 = r / (q.ne1 * q.ne2);
+    return ld_as_f32(q.base + i0 * q.nb0 + i1 * q.nb1 + i2 * q.nb2 + i3 * q.nb3, q.type);
+}
+// one thread per 32-wide block
+template <int DST>
+__global__ void quantize32_kernel(qsrc q, char * out, int64_t nb_row, int64_t nblocks_total) {
+    const int64_t b = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nblocks_total) return;
+    const int64_t r = b / nb_row, i0 = (b % nb_row) * 32;
+    float x[32];
+#pragma unroll
+    for (int j = 0; j < 32; j++) x[j] = qsrc_at(q, i0 + j, r);
+    if (DST == GGML_TYPE_Q8_0) {
+        block_q8_0 * y = (block_q8_0 *) out + b;
+        float amax = 0;
+#pragma unroll
+        for (int j = 0; j < 32; j++) { const float v = fabsf(x[j]); if (v > amax) amax = v; }
+        const float d = amax / 127.f, id = d ? 1.f / d : 0.f;
+        y->d = f2h(d);
+#pragma unroll
+        for (int j = 0; j < 32; j++) y->qs[j] = (int8_t) roundf(x[j] * id);
+    } else {
+        block_q4_0 * y = (block_q4_0 *) out + b;
+        float amax = 0, mx = 0;
+#pragma unroll
+        for (int j = 0; j < 32; j++) { const float v = x[j]; if (amax < fabsf(v)) { amax = fabsf(v); mx = v; } }
+        const float d = mx / -8.f, id = d ? 1.f / d : 0.f;
+        y->d = mx == 0.f ? (uint16_t) 0x8000 : f2h(d);   // an all-zero block: 0 / -8 = -0.0 on the host, sign included
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            const float x0 = x[j] * id, x1 = x[16 + j] * id;
+            const int a = (int) (x0 + 8.5f), c = (int) (x1 + 8.5f);
+            y->qs[j] = (uint8_t) ((a > 15 ? 15 : a) | ((c > 15 ? 15 : c) << 4));
+        }
+    }
+}
+// Q4_K (quantize_row_q4_K_ref + make_qkx2_quants, as restated in ggml_core.cpp): eight lanes per super-block, one per 32-weight sub-block; the
+// 21-step scale search runs per lane in the reference's order, the super-block maxima meet over the 8 lanes, the nibbles are packed through LDS
+__global__ void __launch_bounds__(256) quantize_q4k_kernel(qsrc q, block_q4_K * out, int64_t nb_row, int64_t nsb_total) {
+    __shared__ uint8_t Ls[32][256];
+    const int tid = threadIdx.x, j = tid & 7, sbl = tid >> 3;                       // sub-block, super-block within the workgroup
+    const int64_t sb = (int64_t) blockIdx.x * 32 + sbl;
+    const bool valid = sb < nsb_total;
+    const int64_t sbc = valid ? sb : nsb_total - 1;
+    const int64_t r = sbc / nb_row, i0 = (sbc % nb_row) * 256 + 32 * j;
+    float x[32], w[32];
+    uint8_t L[32], Laux[32];
+#pragma unroll
+    for (int l = 0; l < 32; l++) x[l] = qsrc_at(q, i0 + l, r);
+    float sum_x2 = 0;
+#pragma unroll
+    for (int l = 0; l < 32; l++) sum_x2 += x[l] * x[l];
+    const float av_x = sqrtf(sum_x2 / 32);
+#pragma unroll
+    for (int l = 0; l < 32; l++) w[l] = av_x + fabsf(x[l]);
+    // make_qkx2_quants(32, 15, x, w, L, &the_min, Laux, -1, 0.1, 20, false)
+    float scale, the_min;
+    {
+        const int nmax = 15;
+        float mn = x[0], mx = x[0], sum_w = w[0], sum_x = sum_w * x[0];
+#pragma unroll
+        for (int i = 1; i < 32; ++i) { if (x[i] < mn) mn = x[i]; if (x[i] > mx) mx = x[i]; sum_w += w[i]; sum_x += w[i] * x[i]; }
+        if (mn > 0) mn = 0;
+        if (mx == mn) {
+#pragma unroll
+            for (int i = 0; i < 32; ++i) L[i] = 0;
+            scale = 0.f; the_min = -mn;
+        } else {
+            float iscale = nmax / (mx - mn);
+            scale = 1 / iscale;
+            float best_mad = 0;
+#pragma unroll
+            for (int i = 0; i < 32; ++i) {
+                int l = nearest_int_dev(iscale * (x[i] - mn));
+                L[i] = (uint8_t) (l < 0 ? 0 : l > nmax ? nmax : l);
+                float diff = scale * L[i] + mn - x[i];
+                diff = diff * diff;
+                best_mad += w[i] * diff;
+            }
+            for (int is = 0; is <= 20; ++is) {
+                iscale = (-1.f + 0.1f * is + nmax) / (mx - mn);
+                float sum_l = 0, sum_l2 = 0, sum_xl = 0;
+#pragma unroll
+                for (int i = 0; i < 32; ++i) {
+                    int l = nearest_int_dev(iscale * (x[i] - mn));
+                    l = l < 0 ? 0 : l > nmax ? nmax : l;
+                    Laux[i] = (uint8_t) l;
+                    sum_l += w[i] * l; sum_l2 += w[i] * l * l; sum_xl += w[i] * l * x[i];
+                }
+                const float D = sum_w * sum_l2 - sum_l * sum_l;
+                if (D > 0) {
+                    float this_scale = (sum_w * sum_xl - sum_x * sum_l) / D, this_min = (sum_l2 * sum_x - sum_l * sum_xl) / D;
+                    if (this_min > 0) { this_min = 0; this_scale = sum_xl / sum_l2; }
+                    float mad = 0;
+#pragma unroll
+                    for (int i = 0; i < 32; ++i) { float diff = this_scale * Laux[i] + this_min - x[i]; diff = diff * diff; mad += w[i] * diff; }
+                    if (mad < best_mad) {
+#pragma unroll
+                        for (int i = 0; i < 32; ++i) L[i] = Laux[i];
+                        best_mad = mad; scale = this_scale; mn = this_min;
+                    }
+                }
+            }
+            the_min = -mn;
+        }
+    }
+    // super-block maxima over the 8 lanes (max is order-free)
+    float max_scale = scale > 0 ? scale : 0.f, max_min = the_min > 0 ? the_min : 0.f;
+    max_scale = fmaxf(max_scale, dpp_f32<DPP_QUAD_XOR1>(max_scale)); max_min = fmaxf(max_min, dpp_f32<DPP_QUAD_XOR1>(max_min));
+    max_scale = fmaxf(max_scale, dpp_f32<DPP_QUAD_XOR2>(max_scale)); max_min = fmaxf(max_min, dpp_f32<DPP_QUAD_XOR2>(max_min));
+    max_scale = fmaxf(max_scale, dpp_f32<DPP_HALF_MIRROR>(max_scale)); max_min = fmaxf(max_min, dpp_f32<DPP_HALF_MIRROR>(max_min));
+    const float inv_scale = max_scale > 0 ? 63.f / max_scale : 0.f, inv_min = max_min > 0 ? 63.f / max_min : 0.f;
+    int ls = nearest_int_dev(inv_scale * scale) & 0xff, lm = nearest_int_dev(inv_min * the_min) & 0xff;   // (uint8_t) nearest_int(.)
+    if (ls > 63) ls = 63;
+    if (lm > 63) lm = 63;
+    const uint16_t dh = f2h(max_scale / 63.f), dmh = f2h(max_min / 63.f);
+    const float d = h2f(dh) * ls;
+    if (d) {
+        const float dm = h2f(dmh) * lm;
+#pragma unroll
+        for (int l = 0; l < 32; l++) { int v = nearest_int_dev((x[l] + dm) / d); L[l] = (uint8_t) (v < 0 ? 0 : v > 15 ? 15 : v); }
+    }
+#pragma unroll
+    for (int l = 0; l < 32; l++) Ls[sbl][32 * j + l] = L[l];
+    __shared__ uint8_t sls[32][8], slm[32][8];
+    sls[sbl][j] = (uint8_t) ls; slm[sbl][j] = (uint8_t) lm;
+    __syncthreads();
+    if (!valid) return;
+    block_q4_K * y = out + sb;
+    // lane j packs 16 bytes of qs: group g = j / 2 (sub-blocks 2g | 2g + 1), half h = j % 2
+    {
+        const int g = j >> 1, h = j & 1;
+#pragma unroll
+        for (int l = 0; l < 16; l++) y->qs[32 * g + 16 * h + l] = (uint8_t) (Ls[sbl][64 * g + 16 * h + l] | (Ls[sbl][64 * g + 32 + 16 * h + l] << 4));
+    }
+    if (j < 4) {
+        y->scales[j]     = (uint8_t) (sls[sbl][j] | ((sls[sbl][j + 4] >> 4) << 6));
+        y->scales[j + 4] = (uint8_t) (slm[sbl][j] | ((slm[sbl][j + 4] >> 4) << 6));
+        y->scales[j + 8] = (uint8_t) ((sls[sbl][j + 4] & 0xF) | ((slm[sbl][j + 4] & 0xF) << 4));
+    }
+    if (j == 0) { y->d = dh; y->dmin = dmh; }
+}
+static bool k_quantize_rows(hipStream_t s, tdesc dst, tdesc src) {
+    if (!(src.type == GGML_TYPE_F32 || src.type == GGML_TYPE_F16 || src.type == GGML_TYPE_BF16)) return false;
+    if (!(dst.type == GGML_TYPE_Q8_0 || dst.type == GGML_TYPE_Q4_0 || dst.type == GGML_TYPE_Q4_K)) return false;
+    const int64_t K = src.ne[0], rows = src.ne[1] * src.ne[2] * src.ne[3], blk = ggml_blck_size((enum ggml_type) dst.type);
+    if (K % blk != 0 || dst.ne[0] != K || td_nelements(dst) != td_nelements(src)) return false;
+    // the destination must be dense rows (it is a freshly allocated weight tensor)
+    const int64_t rb = (int64_t) ggml_row_size((enum ggml_type) dst.type, K);
+    if (dst.nb[1] != rb || (dst.ne[2] > 1 && dst.nb[2] != rb * dst.ne[1]) || (dst.ne[3] > 1 && dst.nb[3] != rb * dst.ne[1] * dst.ne[2])) return false;
+    if (dst.ne[1] != src.ne[1] || dst.ne[2] != src.ne[2] || dst.ne[3] != src.ne[3]) return false;
+    qsrc q = { src.data, src.nb[0], src.nb[1], src.nb[2], src.nb[3], src.ne[1], src.ne[2], src.type };
+    const int64_t nb_row = K / blk, total = nb_row * rows;
+    if (dst.type == GGML_TYPE_Q4_K) quantize_q4k_kernel<<<(unsigned) ((total + 31) / 32), 256, 0, s>>>(q, (block_q4_K *) dst.data, nb_row, total);
+    else if (dst.type == GGML_TYPE_Q8_0) quantize32_kernel<GGML_TYPE_Q8_0><<<nblocks(total), BLOCK, 0, s>>>(q, dst.data, nb_row, total);
+    else quantize32_kernel<GGML_TYPE_Q4_0><<<nblocks(total), BLOCK, 0, s>>>(q, dst.data, nb_row, total);
+    return true;
+}
+
 void k_cpy(hipStream_t s, tdesc dst, tdesc src) {
     const int64_t n = td_nelements(src);
     if (n == 0) return;
     GGML_ASSERT(n == td_nelements(dst));
     const bool q = ggml_is_quantized((enum ggml_type) src.type) || ggml_is_quantized((enum ggml_type) dst.type);
     if (q) {
-        // only the byte-identical contiguous case is needed on-device (weights are quantised at load time)
-        GGML_ASSERT(src.type == dst.type && "on-device (re)quantisation is not implemented; quantise on the host");
+        if (src.type != dst.type && k_quantize_rows(s, dst, src)) return;
+        // otherwise only the byte-identical contiguous case is handled on the device
+        GGML_ASSERT(src.type == dst.type && "this (re)quantising copy is not implemented on the device; cast on the host device");
         const size_t bytes = ggml_row_size((enum ggml_type) src.type, src.ne[0]) * (size_t) (src.ne[1] * src.ne[2] * src.ne[3]);
         HIP_CHECK(hipMemcpyAsync(dst.data, src.data, bytes, hipMemcpyDeviceToDevice, s));
         return;

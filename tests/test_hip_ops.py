@@ -469,3 +469,68 @@ def test_fused_sampler_matches_the_node_chain(n, k, case):
         assert st.fused_nodes_in_last_plan >= 12, "the sampler chain was not fused"
         plain, _ = gu.run_graph("hip", build, flags=1)
         assert np.array_equal(plain[0], ref[0])
+
+
+@pytest.mark.parametrize("dst", [Q8_0, Q4_0, Q4_K])
+@pytest.mark.parametrize("src", [F32, BF16, F16])
+def test_requantising_cast_on_the_device_is_bit_exact(src, dst):
+    # WeightLoader's load-time cast (src/loader.h:160-187: ggml_cast of a float checkpoint tensor to the -q type) run on the MI355X backend:
+    # the bytes must equal the host quantiser's (ggml_quantize_row, what the host device runs for the same graph) and the oracle's cpy
+    import ctypes as C
+    r = np.random.default_rng(src * 100 + dst)
+    K, M = 1024, 24
+    x = (r.standard_normal((M, K)) * np.exp(r.standard_normal((M, K)))).astype(np.float32)
+    x[1, 256:512] = 0.0; x[2, :256] = 2.5; x[3, 32:64] = 0.0; x[4] *= 1e-6; x[5, 256:288] = -1.0
+    x[6, ::7] = 0.0
+    results = {}
+    for kind in ("oracle", "hip"):
+        g = gu.Graph(kind)
+        t = g.cast(g.input(x, src), dst)
+        g.build([t])
+        g.alloc()
+        g.compute()
+        n = g.L.ggml_nbytes(t)
+        raw = C.create_string_buffer(n)
+        g.L.ggml_backend_tensor_get(t, raw, 0, n)
+        results[kind] = np.frombuffer(raw.raw, np.uint8).copy()
+        g.free()
+    # host quantiser on the values the source type can hold
+    xs = gu.decode(gu.encode(x, src), src, x.shape)
+    L = gu.lib()
+    host = np.zeros(results["hip"].size, np.uint8)
+    rb = host.size // M
+    for i in range(M):
+        row = np.ascontiguousarray(xs[i], np.float32)
+        L.ggml_quantize_row(dst, row.ctypes.data, host[i * rb:(i + 1) * rb].ctypes.data, K)
+    assert np.array_equal(results["hip"], host), f"device vs host quantiser: {np.count_nonzero(results['hip'] != host)} bytes differ"
+    assert np.array_equal(results["oracle"], host), "oracle vs host quantiser"
+
+
+def test_per_step_projection_split_requantised_on_the_device():
+    # the Depth transformer's per-step in_proj split (transformer.h:780-848): row ranges of one float weight, each cast to the -q type
+    import ctypes as C
+    r = np.random.default_rng(99)
+    K, M, steps = 512, 3 * 64, 3
+    w = r.standard_normal((M, K)).astype(np.float32)
+    outs = {}
+    for kind in ("oracle", "hip"):
+        g = gu.Graph(kind)
+        wt = g.input(w, BF16)
+        parts = []
+        for k in range(steps):
+            rows = g.view_2d(wt, K, M // steps, wt.contents.nb[1], wt.contents.nb[1] * (M // steps) * k)
+            parts.append(g.cast(rows, Q4_K))
+        g.build(parts)
+        g.alloc()
+        g.compute()
+        got = []
+        for t in parts:
+            n = g.L.ggml_nbytes(t)
+            raw = C.create_string_buffer(n)
+            g.L.ggml_backend_tensor_get(t, raw, 0, n)
+            got.append(np.frombuffer(raw.raw, np.uint8).copy())
+        outs[kind] = got
+        g.free()
+    for a, b in zip(outs["oracle"], outs["hip"]):
+        assert np.array_equal(a, b)
+    assert not np.array_equal(outs["hip"][0], outs["hip"][1])
