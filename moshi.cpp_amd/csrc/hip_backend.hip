@@ -1527,6 +1527,10 @@ static plan_t * build_plan(hip_ctx * c, ggml_cgraph * g) {
             p->n_fused += (int) grp.members.size();
         }
         // mat-vecs with prologue / epilogue
+        std::unordered_map<const void *, float *> paired_gate;   // storage of a linear_in output h (never materialised) -> g = silu(h_l) * h_r
+        // opt-in (MI355X_PAIRED_GATE=1): measured neutral on moshika - the gate kernel it removes (-2.3 us per layer) is paid back by linear_out quantising
+        // its 44 activation blocks in every workgroup (+1.8 us), profiles/r02_frame_stamps_paired_gate.txt
+        static const bool no_pair = getenv("MI355X_PAIRED_GATE") == nullptr;
         static const bool no_batched_fusion = getenv("MI355X_NO_BATCHED_MM") != nullptr || getenv("MI355X_NO_BATCHED_FUSION") != nullptr;
         for (int i = 0; i < g->n_nodes; i++) {
             if (an.skip[(size_t) i] || g->nodes[i]->op != GGML_OP_MUL_MAT) continue;
@@ -1582,6 +1586,41 @@ static plan_t * build_plan(hip_ctx * c, ggml_cgraph * g) {
                     ag.emit_pos = -1;
                     break;
                 }
+            }
+            if (!no_pair && a.prologue != MV_GATE_SILU && a.ncols == 1 && a.residual == nullptr && a.res_embed.table == nullptr && a.ticket == nullptr &&
+                a.M % 2 == 0 && k_matvec_pair_ok(a.wtype, a.K, a.M / 2) && grp.emit_pos == i) {
+                // linear_in of a gated FFN whose only readers are the silu(left) * right pair feeding a long linear_out: let every workgroup take
+                // matching rows of both halves and write g itself (the [2 F] intermediate and the gate kernel disappear)
+                const ggml_tensor * h = g->nodes[i];
+                const int64_t F = a.M / 2;
+                const ggml_tensor * l = nullptr, * r = nullptr;
+                int nv = 0;
+                for (int j = i + 1; j < g->n_nodes && j < i + 12; j++) {
+                    const ggml_tensor * v = g->nodes[j];
+                    if (v->op == GGML_OP_VIEW && v->src[0] == h) { nv++; if (v->data == h->data) l = v; else if ((const char *) v->data == (const char *) h->data + F * 4) r = v; }
+                }
+                if (uses_of(an, h) == 2 && nv == 2 && l && r && ggml_nelements(l) == F && ggml_nelements(r) == F && ggml_is_contiguous(l) && ggml_is_contiguous(r) &&
+                    uses_of(an, l) == 1 && uses_of(an, r) == 1) {
+                    const ggml_tensor * sl = sole_consumer(an, l), * ml = sole_consumer(an, r);
+                    if (sl && sl->op == GGML_OP_UNARY && sl->op_params[0] == GGML_UNARY_OP_SILU && uses_of(an, sl) == 1 && ml && ml->op == GGML_OP_MUL &&
+                        ml->src[0] == sl && ml->src[1] == r && uses_of(an, ml) == 1) {
+                        const ggml_tensor * mo = sole_consumer(an, ml);
+                        if (mo && mo->op == GGML_OP_MUL_MAT && mo->src[1] == ml && is_qblock(mo->src[0]->type) && mo->src[0]->ne[0] == F && F > 4096 &&
+                            !an.skip[(size_t) pos_of(an, mo)]) {
+                            float * gbuf = (float *) em.ws((size_t) F * 4);
+                            a.pair_F = F;
+                            a.y = gbuf;
+                            paired_gate[h->data] = gbuf;
+                        }
+                    }
+                }
+            }
+            if (a.prologue == MV_GATE_SILU && is_qblock((enum ggml_type) a.wtype) && a.K > 4096 && paired_gate.count((const void *) a.x)) {
+                // the producer already wrote g = silu(left) * right: plain activation, quantised in this kernel's prologue
+                const float * gbuf = paired_gate[(const void *) a.x];
+                a.prologue = MV_PLAIN;
+                a.x = gbuf;
+                a.x_cs = a.K;
             }
             if (a.prologue == MV_GATE_SILU && is_qblock((enum ggml_type) a.wtype) && a.K > 4096) {
                 // long gated rows: quantise the activation once, not once per workgroup

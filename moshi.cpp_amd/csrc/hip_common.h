@@ -100,8 +100,13 @@ struct mv_args {
     int32_t *   argmax_out[2];  // optional (Q4_K path): index of the last maximum of y (ggml_vec_argmax_f32), written by the last workgroup to finish
     unsigned *  ticket;         //   ... arrival counter for that (zero between launches)
     const attn_args * attn;     // MV_ATTN: (host pointer) the attention whose output is x; short ring, recomputed per workgroup
+    // gated FFN, "paired" form (moshi_activation_gating, gating.h:11-37): W is linear_in [K, 2 F]; a workgroup takes rows_per_wg / 2 rows of the
+    // left half AND the same rows of the right half, so it can finish g = silu(W_l x) * (W_r x) itself: y receives g[F] (M stays 2 F). The [2 F]
+    // intermediate and the separate gate kernel disappear.
+    int64_t     pair_F;         // 0 = off
 };
 bool k_matvec_supported(int wtype, int64_t K, int64_t M);
+bool k_matvec_pair_ok(int wtype, int64_t K, int64_t F);
 // optional per-launch timing of the dominant kernel (matvec_q4k_kernel) with HIP start/stop events that are
 // attached to the dispatch itself (hipExtLaunchKernelGGL), i.e. kernel begin -> kernel end like a profiler
 struct mv_profile {

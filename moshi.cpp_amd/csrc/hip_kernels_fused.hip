@@ -345,12 +345,18 @@ __global__ void __launch_bounds__(NW * 64) matvec_q4k_kernel(mv_args a, int rows
     char * stage = smem + nb * XBLK_BYTES + wave * STAGE;
     float * part = (float *) (smem + nb * XBLK_BYTES + nwaves * STAGE);
 
-    const int64_t row0 = (int64_t) blockIdx.x * rows_per_wg;
-    const int rows = (int) (a.M - row0 < rows_per_wg ? a.M - row0 : rows_per_wg);
+    // paired gate (a.pair_F): rows_per_wg = 2 h rows, the first h from W_l at [blockIdx * h, +h), the second h from W_r at F + the same range
+    const bool paired = WS == 0 && a.pair_F > 0;
+    const int half_rows = rows_per_wg >> 1;
+    const int64_t row0 = paired ? (int64_t) blockIdx.x * half_rows : (int64_t) blockIdx.x * rows_per_wg;
+    const int rows = paired ? rows_per_wg : (int) (a.M - row0 < rows_per_wg ? a.M - row0 : rows_per_wg);
     const int nblk = rows * nb;
     const int ntiles = (nblk + 63) >> 6;
     const int nchunks = nblk * (SB / 16);
     const u32x4 * wsrc = (const u32x4 *) (a.w + row0 * a.row_bytes);
+    // (paired: tiles of the second half start half_rows * nb / 64 tiles in - whole tiles, checked on the host - and come from the W_r rows)
+    const int tiles_half = paired ? (half_rows * nb) >> 6 : 0x7fffffff;
+    const u32x4 * wsrc_r = paired ? (const u32x4 *) (a.w + (a.pair_F + row0) * a.row_bytes) - (int64_t) tiles_half * (NLOAD * 64) : wsrc;
 
     MV_STAMP(0);
     const int K = (int) a.K;
@@ -396,7 +402,7 @@ __global__ void __launch_bounds__(NW * 64) matvec_q4k_kernel(mv_args a, int rows
 #pragma unroll
         for (int i = 0; i < NLOAD; i++) {
             const int g = t * (NLOAD * 64) + i * 64 + lane;
-            r[i] = __builtin_nontemporal_load(wsrc + (has_tile ? (g < nchunks ? g : nchunks - 1) : 0));
+            r[i] = __builtin_nontemporal_load((t >= tiles_half ? wsrc_r : wsrc) + (has_tile ? (g < nchunks ? g : nchunks - 1) : 0));
         }
     } else {
 #pragma unroll
@@ -414,7 +420,7 @@ __global__ void __launch_bounds__(NW * 64) matvec_q4k_kernel(mv_args a, int rows
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             const int rr = (tid >> 4) + k * (NW * 4);
-            res_pre[k] = rp[row0 + (rr < rows ? rr : 0)];
+            res_pre[k] = rp[row0 + (rr < (paired ? half_rows : rows) ? rr : 0)];
         }
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -541,7 +547,7 @@ __global__ void __launch_bounds__(NW * 64) matvec_q4k_kernel(mv_args a, int rows
 #pragma unroll
             for (int i = 0; i < NLOAD; i++) {
                 const int g = tn * (NLOAD * 64) + i * 64 + lane;
-                r[i] = __builtin_nontemporal_load(wsrc + (g < nchunks ? g : nchunks - 1));
+                r[i] = __builtin_nontemporal_load((tn >= tiles_half ? wsrc_r : wsrc) + (g < nchunks ? g : nchunks - 1));
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -563,6 +569,17 @@ __global__ void __launch_bounds__(NW * 64) matvec_q4k_kernel(mv_args a, int rows
 
     // phase 4: row sums (+ residual): 16 lanes per row, strided partials then a 4-step butterfly
     float best = -INFINITY; int bi = -1;   // fused greedy sampling: this thread's LAST maximum among its rows (ggml_vec_argmax_f32 keeps the last)
+    if (paired) {
+        // g[row] = silu(l) * r from the two row sums this workgroup holds (same 16-lane fixed-order sums as below)
+        for (int rr = tid >> 4; rr < half_rows; rr += NW * 4) {
+            float sl = 0.f, sr = 0.f;
+            for (int j = tid & 15; j < nb; j += 16) { sl += part[rr * nb + j]; sr += part[(half_rows + rr) * nb + j]; }
+            sl = row16_allsum_f32(sl); sr = row16_allsum_f32(sr);
+            if ((tid & 15) == 0) a.y[row0 + rr] = (sl / (1.0f + expf(-sl))) * sr;
+        }
+        MV_STAMP(7);
+        return;
+    }
     int kq = 0;
     for (int rr = tid >> 4; rr < rows; rr += NW * 4, kq++) {
         float sum = 0.f;
@@ -873,6 +890,14 @@ __global__ void __launch_bounds__(256) matvec_f32_reg_kernel(mv_args a) {
     }
 }
 
+// can linear_in [K, 2 F] run in the paired-gate form? (whole 64-super-block tiles per half and workgroup, one workgroup per CU)
+bool k_matvec_pair_ok(int wtype, int64_t K, int64_t F) {
+    if (!(wtype == GGML_TYPE_Q4_K || wtype == GGML_TYPE_Q4_0) || K % 256 != 0 || F < 2048) return false;
+    const int nb = (int) (K / 256);
+    int h = (int) ((F + 255) / 256);
+    while ((h * nb) % 64 != 0) h++;
+    return F % h == 0 && 2 * h * nb <= 4096 && F / h >= 128;
+}
 bool k_matvec_supported(int wtype, int64_t K, int64_t M) {
     if (M <= 0) return false;
     switch (wtype) {
@@ -1350,10 +1375,17 @@ void k_matvec(hipStream_t s, const mv_args & a) {
                 while (rows * nb > 4096) rows = (rows + 1) / 2;
             }
         }
+        if (a.pair_F > 0) {   // paired gate: h rows of each half per workgroup, whole tiles per half, 8 waves; the planner only asks when this fits
+            GGML_ASSERT(a.M == 2 * a.pair_F && fmt != MVF_Q80);
+            int h = (int) ((a.pair_F + 255) / 256);
+            while ((h * nb) % 64 != 0) h++;
+            GGML_ASSERT(a.pair_F % h == 0 && 2 * h * nb <= 4096);
+            nw = 8; rows = 2 * h;
+        }
         if (rows < 1) rows = 1;
         // small Q4_K matrices (the Depth transformer, the codebook heads): 8 lanes per super-block, no LDS tiles (WS = 1)
         static const int direct_on = env_int("MI355X_MV_DIRECT", 1), direct_passes = env_int("MI355X_MVD_PASSES", 3), direct_max_tiles = env_int("MI355X_MVD_MAX_TILES", 512);
-        const bool direct = direct_on && fmt == MVF_Q4K && (nw == 4 || (nw == 8 && a.prologue == MV_ATTN)) && tiles_total <= direct_max_tiles && nb <= nw * 8 * MVD_PMAX;
+        const bool direct = direct_on && a.pair_F == 0 && fmt == MVF_Q4K && (nw == 4 || (nw == 8 && a.prologue == MV_ATTN)) && tiles_total <= direct_max_tiles && nb <= nw * 8 * MVD_PMAX;
         if (direct) {
             int passes = direct_passes < 1 ? 1 : direct_passes > MVD_PMAX ? MVD_PMAX : direct_passes;
             if (nw == 8 && passes > 1) passes = 1;                                         // 8 waves: 64 super-blocks per pass already
@@ -1365,7 +1397,7 @@ void k_matvec(hipStream_t s, const mv_args & a) {
         const size_t stage_bytes = (!direct || a.prologue == MV_ATTN) ? (size_t) nw * tile_bytes : 0;
         const size_t smem = (size_t) nb * XBLK_BYTES + stage_bytes + (size_t) rows * nb * 4 + (a.prologue == MV_ATTN ? 4096 : 0);
         GGML_ASSERT(smem <= 160 * 1024);
-        const int grid = (int) ((a.M + rows - 1) / rows);
+        const int grid = a.pair_F > 0 ? (int) (a.pair_F / (rows / 2)) : (int) ((a.M + rows - 1) / rows);
         GGML_ASSERT(a.prologue != MV_RMSNORM || a.K <= nw * 1024);
         GGML_ASSERT(a.ncols == 1 && a.out_scale == nullptr && (a.prologue <= MV_GATE_SILU || a.prologue == MV_PREQ8K || a.prologue == MV_ATTN));
         void (*kern)(mv_args, int, attn_args) = nullptr;

@@ -534,3 +534,42 @@ def test_per_step_projection_split_requantised_on_the_device():
     for a, b in zip(outs["oracle"], outs["hip"]):
         assert np.array_equal(a, b)
     assert not np.array_equal(outs["hip"][0], outs["hip"][1])
+
+
+def test_paired_gate_ffn_opt_in_matches_oracle():
+    # MI355X_PAIRED_GATE=1: linear_in's workgroups take matching rows of both halves and write silu(l) * r themselves (no [2 F] intermediate, no gate
+    # kernel); opt-in because it measured neutral (hip_backend.hip). Checked at the Temporal FFN shape in a fresh process.
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import numpy as np, ggml_util as gu
+from ggml_util import Q4_K
+K, F = 4096, 11264
+r = np.random.default_rng(5)
+x = r.standard_normal((1, K)).astype(np.float32)
+alpha = (1.0 + 0.1 * r.standard_normal((1, K))).astype(np.float32)
+res = r.standard_normal((1, K)).astype(np.float32)
+w_in = gu.random_q4_K(r, 2 * F, K); w_out = gu.random_q4_K(r, K, F)
+def build(g):
+    xn = g.mul(g.input(alpha), g.rms_norm(g.input(x), 1e-8))
+    h = g.mul_mat(g.input_raw(w_in, Q4_K, K, 2 * F), xn)
+    hh = h.contents
+    l = g.view_4d(h, hh.ne[0] // 2, 1, hh.ne[1], hh.ne[2], hh.nb[1] // 2, hh.nb[1], hh.nb[2], 0)
+    rr = g.view_4d(h, hh.ne[0] // 2, 1, hh.ne[1], hh.ne[2], hh.nb[1] // 2, hh.nb[1], hh.nb[2], hh.nb[1] // 2)
+    y = g.mul_mat(g.input_raw(w_out, Q4_K, F, K), g.mul(g.silu(l), rr))
+    return [g.add(g.input(res), y)]
+ref, got, st = gu.compare(build, atol_rel=3e-5)
+assert st.fused_nodes_in_last_plan >= 6
+print("OK", st.kernels_in_last_plan)
+'''
+    out = {}
+    for flag in ("1", None):
+        env = dict(os.environ, PYTHONPATH=os.path.dirname(os.path.abspath(__file__)))
+        env.pop("MI355X_PAIRED_GATE", None)
+        if flag:
+            env["MI355X_PAIRED_GATE"] = flag
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
+        assert r.returncode == 0 and "OK" in r.stdout, (r.stdout + r.stderr)[-2000:]
+        out[flag] = int(r.stdout.split()[-1])
+    assert out["1"] == out[None] - 1, f"paired form should save exactly the gate kernel: {out}"
