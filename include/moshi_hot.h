@@ -60,6 +60,12 @@ struct moshi_hot_config {
     // k with k % dep_shard_world == dep_shard_rank only - 1/world of the 375 MB - and runs the Depth chain as per-step graphs behind the
     // moshi_hot_depth_shard_* calls. depth_only: no Temporal stack, embeddings or codec at all (the ranks other than the Temporal owner).
     int32_t dep_shard_rank, dep_shard_world, depth_only;
+    // Tensor-parallel Temporal stack (moshi_streaming_transformer_layer, transformer.h:910-1039). tp_world > 1: this model holds
+    // rank tp_rank's SLICES of every Temporal layer - in_proj rows of its heads (q | k | v), the matching 1/N column block of out_proj, linear_in rows
+    // [r F/N, (r+1) F/N) of both gate halves, the matching column block of linear_out - and its heads' KV rings; the stack runs as 2 L + 1 segment
+    // graphs with a sum over ranks of one F32[dim] partial between them (moshi_hot_tp_* below). Column blocks fall on 256-value boundaries, so
+    // the Q8_K activation blocks and every integer block dot are those of the unsplit layer; only the final float sums split.
+    int32_t tp_rank, tp_world;
 };
 
 typedef struct moshi_hot_model moshi_hot_model_t;
@@ -146,6 +152,14 @@ GGML_API int     moshi_hot_depth_shard_begin_import(moshi_hot_model_t * m);     
 GGML_API void    moshi_hot_depth_shard_step(moshi_hot_model_t * m, int k);                    // owner of step k: one Depth step (lm.h:505-527 body) + pack the message
 GGML_API void    moshi_hot_depth_shard_import(moshi_hot_model_t * m, int k);                  // non-owner: rows -> ring slot k % capacity, token -> token vector
 GGML_API void    moshi_hot_depth_shard_tokens(moshi_hot_model_t * m, int32_t * out, int n);   // the frame's sampled tokens so far
+// ---- tensor-parallel Temporal stack: begin(x) ; for i in 0 .. 2 L: { segment(i) ; [i < 2 L: all-reduce(sum) of the message over the ranks] } ; end(out) ----
+// segment 2 l   : x += message (l > 0) ; message = out_proj_r(attention_r(in_proj_r(norm1(x))))      (this rank's heads, its KV ring shard)
+// segment 2 l+1 : x += message         ; message = linear_out_r(silu * mul of linear_in_r(norm2(x)))  (this rank's F / N hidden units)
+// segment 2 L   : x += message         (the stack output)
+GGML_API void *  moshi_hot_tp_msg(moshi_hot_model_t * m, int64_t * n_floats);          // the partial F32[dim] (device / host pointer: hand it to the collective)
+GGML_API void    moshi_hot_tp_begin(moshi_hot_model_t * m, const float * x);            // stack input F32[dim]; advances the stream position (mask row, RoPE phase, ring slot)
+GGML_API void    moshi_hot_tp_segment(moshi_hot_model_t * m, int i);
+GGML_API void    moshi_hot_tp_end(moshi_hot_model_t * m, float * out);                  // stack output F32[dim]
 // replaces the local chained Depth graph inside moshi_hot_lm_step_n: fn(user, text_token, audio[dep_q]) must fill all dep_q tokens
 typedef void (*moshi_hot_depth_hook_t)(void * user, int32_t text_token, int32_t * audio);
 GGML_API void    moshi_hot_set_depth_hook(moshi_hot_model_t * m, moshi_hot_depth_hook_t fn, void * user);

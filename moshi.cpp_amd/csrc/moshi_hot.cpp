@@ -151,10 +151,38 @@ struct Weights {
         bytes[part] += ggml_nbytes(t);
         return t;
     }
+    // a SLICE of a synthetic matrix [K, M]: output row j is rows[j] of the full matrix, restricted to the K-range [k0, k0 + Ks) (whole blocks).
+    // The full matrix is generated exactly as add() would (same name, same seed), so N slices sum up to the unsplit layer (tensor parallelism).
+    struct slice { T t; std::function<void(T, Rng &, std::vector<uint8_t> &)> gen; std::string name; int64_t K, M; std::vector<int64_t> rows; int64_t k0; };
+    std::vector<slice> sliced;
+    T add_slice(const std::string & name, enum ggml_type type, int64_t K, int64_t M, std::function<void(T, Rng &, std::vector<uint8_t> &)> gen,
+                const std::vector<int64_t> & rows, int64_t k0, int64_t Ks) {
+        GGML_ASSERT(k0 % ggml_blck_size(type) == 0 && Ks % ggml_blck_size(type) == 0 && k0 + Ks <= K);
+        T t = ggml_new_tensor_2d(ctx, type, Ks, (int64_t) rows.size());
+        const std::string nm = name + ".slice";
+        ggml_set_name(t, nm.size() < GGML_MAX_NAME ? nm.c_str() : nm.substr(nm.size() - GGML_MAX_NAME + 1).c_str());
+        sliced.push_back({ t, gen, name, K, M, rows, k0 });
+        by_name[nm] = t;
+        bytes[part] += ggml_nbytes(t);
+        return t;
+    }
     void load() {
         buf = ggml_backend_alloc_ctx_tensors(ctx, be);
         GGML_ASSERT(buf);
         std::vector<uint8_t> tmp;
+        for (auto & sl : sliced) {
+            struct ggml_context * fc = ggml_init({ ggml_tensor_overhead() * 2, NULL, true });
+            T full = ggml_new_tensor_2d(fc, sl.t->type, sl.K, sl.M);
+            Rng r(name_seed(seed, sl.name));
+            tmp.resize(ggml_nbytes(full));
+            sl.gen(full, r, tmp);
+            const size_t rb_full = ggml_row_size(sl.t->type, sl.K), rb = ggml_row_size(sl.t->type, sl.t->ne[0]), off = ggml_row_size(sl.t->type, sl.k0);
+            std::vector<uint8_t> out(ggml_nbytes(sl.t));
+            for (size_t j = 0; j < sl.rows.size(); j++) memcpy(out.data() + j * rb, tmp.data() + (size_t) sl.rows[j] * rb_full + off, rb);
+            ggml_backend_tensor_set(sl.t, out.data(), 0, out.size());
+            ggml_free(fc);
+        }
+        sliced.clear();
         for (auto & p : todo) {
             Rng r(name_seed(seed, p.name));
             tmp.resize(ggml_nbytes(p.t));
@@ -640,6 +668,8 @@ struct moshi_hot_model {
     T shard_msg = nullptr, shard_tout = nullptr, shard_tokens = nullptr;
     std::vector<T> shard_text_idx, shard_text_scale;
     moshi_hot_depth_hook_t depth_hook = nullptr; void * depth_hook_user = nullptr;
+    // tensor-parallel Temporal stack (moshi_hot.h): this rank's sliced layers, the replicated stream x, the partial message, one graph per segment
+    Transformer temporal_tp; T tp_x = nullptr, tp_msg = nullptr; std::vector<Builder *> g_tp;
     // delay ring (lm.h:715-743)
     int offset = 0; std::vector<std::vector<int>> cache; std::vector<int> initial; int max_delay = 0;
 
@@ -671,7 +701,7 @@ T state(moshi_hot_model * m, enum ggml_type type, int64_t n0, int64_t n1 = 1, in
 bool owns_step(const moshi_hot_config & c, int k) { return c.dep_shard_world <= 1 || k % c.dep_shard_world == c.dep_shard_rank; }
 
 void make_transformer(moshi_hot_model * m, Transformer & tr, const std::string & name, int dim, int heads, int n_layers, int ffn_hidden,
-                      int capacity, int max_period, int n_weight_sets, bool mimi_style, enum ggml_type wtype, int cross_len = 0) {
+                      int capacity, int max_period, int n_weight_sets, bool mimi_style, enum ggml_type wtype, int cross_len = 0, bool norms_only = false) {
     Weights & W = *m->W;
     tr.dim = dim; tr.heads = heads; tr.capacity = capacity; tr.max_period = max_period;
     tr.layers.resize((size_t) n_layers);
@@ -694,6 +724,7 @@ void make_transformer(moshi_hot_model * m, Transformer & tr, const std::string &
             L.norm1 = { true, 1e-8f, W.add(p + "norm1.alpha", GGML_TYPE_F32, dim, 1, 1, ones), nullptr };
             L.norm2 = { true, 1e-8f, W.add(p + "norm2.alpha", GGML_TYPE_F32, dim, 1, 1, ones), nullptr };
         }
+        if (norms_only) continue;   // a tensor-parallel rank (tp_world > 1) holds slices of the matrices and its own ring shard instead (moshi_hot_create)
         for (int w = 0; w < n_weight_sets; w++) {
             const std::string ws = n_weight_sets > 1 ? "." + std::to_string(w) : "";
             if (n_weight_sets > 1 && !owns_step(m->cfg, w)) {   // another rank's step: no weights here
@@ -951,7 +982,40 @@ extern "C" moshi_hot_model_t * moshi_hot_create(ggml_backend_t backend, const st
         for (int k = 0; k < c.n_q; k++) m->emb.push_back(W.add("lm.emb." + std::to_string(k) + ".weight", et, c.dim, c.card + 1, 1, qgen(1.f)));
         W.part = 0;
         make_transformer(m, m->temporal, "lm.transformer", c.dim, c.num_heads, c.num_layers, c.ffn_hidden, c.context, c.max_period, 1, false, lt,
-                         c.cross_attention ? c.cross_len : 0);
+                         c.cross_attention ? c.cross_len : 0, c.tp_world > 1);
+        if (c.tp_world > 1 || c.tp_world == 1) {
+            // this rank's slices of every Temporal layer, cut from the very matrices the unsplit stack above is made of
+            const int N = c.tp_world, r = c.tp_rank, H = c.num_heads, D = c.dim / H, Hr = H / N, F = c.ffn_hidden, Fr = F / N;
+            GGML_ASSERT(H % N == 0 && F % N == 0 && (c.dim / N) % 256 == 0 && Fr % 256 == 0 && !c.cross_attention);
+            Transformer & tp = m->temporal_tp;
+            tp.dim = c.dim / N; tp.heads = Hr; tp.capacity = c.context; tp.max_period = c.max_period;
+            tp.layers.resize((size_t) c.num_layers);
+            const float s_in = 1.f / sqrtf((float) c.dim);
+            const float upd = c.update_scale > 0.f ? c.update_scale : 1.f;
+            for (int l = 0; l < c.num_layers; l++) {
+                Layer & L = tp.layers[(size_t) l];
+                const Layer & full = m->temporal.layers[(size_t) l];
+                const std::string p = "lm.transformer.layers." + std::to_string(l) + ".";
+                L.norm1 = full.norm1; L.norm2 = full.norm2;
+                std::vector<int64_t> rows;
+                for (int part = 0; part < 3; part++) for (int j = 0; j < Hr * D; j++) rows.push_back((int64_t) part * c.dim + (int64_t) r * Hr * D + j);
+                L.in_proj.push_back(W.add_slice(p + "self_attn.in_projs.weight", lt, c.dim, 3 * c.dim, qgen(s_in), rows, 0, c.dim));
+                rows.clear(); for (int j = 0; j < c.dim; j++) rows.push_back(j);
+                L.out_proj.push_back(W.add_slice(p + "self_attn.out_projs.weight", lt, c.dim, c.dim, qgen(s_in * upd), rows, (int64_t) r * Hr * D, (int64_t) Hr * D));
+                rows.clear(); for (int half = 0; half < 2; half++) for (int j = 0; j < Fr; j++) rows.push_back((int64_t) half * F + (int64_t) r * Fr + j);
+                L.gate_in.push_back(W.add_slice(p + "gating.linear_in.weight", lt, c.dim, 2 * F, qgen(s_in), rows, 0, c.dim));
+                rows.clear(); for (int j = 0; j < c.dim; j++) rows.push_back(j);
+                L.gate_out.push_back(W.add_slice(p + "gating.linear_out.weight", lt, F, c.dim, qgen(upd / sqrtf((float) F)), rows, (int64_t) r * Fr, Fr));
+                L.kcache = state(m, GGML_TYPE_BF16, D, c.context, Hr);
+                L.vcache = state(m, GGML_TYPE_BF16, D, c.context, Hr);
+            }
+            m->tp_x = state(m, GGML_TYPE_F32, c.dim);
+            m->tp_msg = state(m, GGML_TYPE_F32, c.dim);
+            // the position inputs of transformer_graph_step are shared by all segment graphs: persistent tensors instead of per-graph inputs
+            tp.g_bias = state(m, GGML_TYPE_F32, c.context);
+            if (c.max_period) tp.g_offset = state(m, GGML_TYPE_F32, 1);
+            tp.g_indices = state(m, GGML_TYPE_I32, 1);
+        }
         m->out_norm = { true, 1e-8f, W.add("lm.out_norm.alpha", GGML_TYPE_F32, c.dim, 1, 1, ones), nullptr };
         m->text_linear = W.add("lm.text_linear.weight", lt, c.dim, c.text_card, 1, qgen(1.f / sqrtf((float) c.dim)));
         }
@@ -1048,6 +1112,7 @@ extern "C" void moshi_hot_free(moshi_hot_model_t * m) {
     delete m->g_temporal; delete m->g_depth; delete m->g_dec; delete m->g_enc; delete m->scratch; delete m->g_shard_begin;
     for (auto * b : m->g_shard_step) delete b;
     for (auto * b : m->g_shard_import) delete b;
+    for (auto * b : m->g_tp) delete b;
     if (m->st_buf) ggml_backend_buffer_free(m->st_buf);
     ggml_free(m->st_ctx);
     delete m->W;
@@ -1112,6 +1177,50 @@ void depth_step(moshi_hot_model * m, int32_t text_token, std::vector<int32_t> & 
     ggml_backend_tensor_get(m->dep_tokens, audio.data(), 0, audio.size() * 4);
 }
 }
+
+// ---- tensor-parallel Temporal stack ---------------------------------------------------------------------------
+namespace {
+void build_tp_segment(moshi_hot_model * m, int i) {
+    const moshi_hot_config & c = m->cfg;
+    Transformer & tp = m->temporal_tp;
+    const int Lc = c.num_layers;
+    Builder * b = new Builder(m->be, 32);
+    Builder & g = *b;
+    T x = m->tp_x;
+    if (i > 0) { x = ggml_add(g, m->tp_x, m->tp_msg); g.expand(ggml_cpy(g, x, m->tp_x)); }   // the residual add of the previous half layer, on the summed partial
+    if (i < 2 * Lc) {
+        Layer & L = tp.layers[(size_t) (i / 2)];
+        T part;
+        if ((i & 1) == 0) {
+            T nx = apply_norm(g, L.norm1, x);
+            Rot rot;
+            if (tp.max_period) rot = timestep_embedding(g, 1, tp.dim / tp.heads, tp.g_offset, tp.max_period);
+            part = attention(g, tp, L, 0, tp.g_indices, nx, tp.g_bias, tp.max_period ? &rot : nullptr, false);
+        } else {
+            T nx = apply_norm(g, L.norm2, x);
+            part = gating(g, L.gate_in[0], L.gate_out[0], nx);
+        }
+        g.expand(ggml_cpy(g, part, m->tp_msg));
+    }
+    g.alloc();
+    if ((int) m->g_tp.size() <= i) m->g_tp.resize((size_t) i + 1, nullptr);
+    m->g_tp[(size_t) i] = b;
+}
+}  // namespace
+
+extern "C" void * moshi_hot_tp_msg(moshi_hot_model_t * m, int64_t * n) { GGML_ASSERT(m->tp_msg); if (n) *n = ggml_nelements(m->tp_msg); return m->tp_msg->data; }
+extern "C" void moshi_hot_tp_begin(moshi_hot_model_t * m, const float * x) {
+    GGML_ASSERT(m->tp_x);
+    ggml_backend_tensor_set(m->tp_x, x, 0, (size_t) m->cfg.dim * 4);
+    transformer_graph_step(*m->scratch, m->temporal_tp, 1);   // mask row -> g_bias (scratch cpy), RoPE phase, ring slot (transformer.h:1259-1289)
+    m->scratch->compute_scratch();
+}
+extern "C" void moshi_hot_tp_segment(moshi_hot_model_t * m, int i) {
+    GGML_ASSERT(i >= 0 && i <= 2 * m->cfg.num_layers);
+    if ((int) m->g_tp.size() <= i || !m->g_tp[(size_t) i]) build_tp_segment(m, i);
+    m->g_tp[(size_t) i]->compute();
+}
+extern "C" void moshi_hot_tp_end(moshi_hot_model_t * m, float * out) { ggml_backend_tensor_get(m->tp_x, out, 0, (size_t) m->cfg.dim * 4); }
 
 // ---- Depth codebook shard ---------------------------------------------------------------------------------------
 namespace {

@@ -17,7 +17,8 @@ class Config(C.Structure):
                                          "demux_second_stream", "depformer_low_rank", "delay_steps", "cross_attention", "cross_len",
                                          "condition_sum", "dep_schedule_len")] + \
                [("dep_schedule", C.c_int32 * MAX_CB), ("update_scale", C.c_float),
-                ("dep_shard_rank", C.c_int32), ("dep_shard_world", C.c_int32), ("depth_only", C.c_int32)]
+                ("dep_shard_rank", C.c_int32), ("dep_shard_world", C.c_int32), ("depth_only", C.c_int32),
+                ("tp_rank", C.c_int32), ("tp_world", C.c_int32)]
 
     @property
     def io_dep_q(self):
@@ -62,6 +63,10 @@ SIGNATURES = {
     "moshi_hot_depth_shard_import": (None, [P, C.c_int]),
     "moshi_hot_depth_shard_tokens": (None, [P, P, C.c_int]),
     "moshi_hot_set_depth_hook": (None, [P, P, P]),
+    "moshi_hot_tp_msg": (P, [P, C.POINTER(C.c_int64)]),
+    "moshi_hot_tp_begin": (None, [P, P]),
+    "moshi_hot_tp_segment": (None, [P, C.c_int]),
+    "moshi_hot_tp_end": (None, [P, P]),
 }
 DEPTH_HOOK = C.CFUNCTYPE(None, C.c_void_p, C.c_int32, C.POINTER(C.c_int32))
 NODE_VISITOR = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_void_p)

@@ -92,3 +92,40 @@ class DepthShard:
                 return frames
             self._chain()
             frames += 1
+
+
+class TemporalTP:
+    """Tensor-parallel Temporal stack (include/moshi_hot.h "tensor-parallel Temporal stack"): every rank holds its slices of each
+    layer and runs the 2 L + 1 segment graphs; between segments the F32[dim] partial is summed over the ranks in place (`all_reduce` on a tensor
+    aliasing the C side's message: RCCL over xGMI on devices, gloo on the host). Two all-reduces of 16 KB per layer."""
+
+    def __init__(self, L, model, cfg, rank, world, dist, group=None, device=None, stream_ptr=None):
+        self.L, self.m, self.cfg, self.rank, self.world, self.dist, self.group = L, model, cfg, rank, world, dist, group
+        self.msg = self.stream = self.torch = None
+        n = C.c_int64()
+        ptr = L.moshi_hot_tp_msg(model, C.byref(n))
+        if world > 1:
+            import torch
+            self.torch = torch
+            self.msg = _alias(torch, ptr, n.value, device)
+            self.stream = torch.cuda.ExternalStream(stream_ptr, device=device) if (device is not None and stream_ptr) else None
+        self.reductions = 0
+
+    def stack(self, x):
+        import numpy as np
+        x = np.ascontiguousarray(x, np.float32)
+        L, m = self.L, self.m
+        L.moshi_hot_tp_begin(m, x.ctypes.data)
+        last = 2 * self.cfg.num_layers
+        for i in range(last + 1):
+            L.moshi_hot_tp_segment(m, i)
+            if i < last and self.world > 1:
+                if self.stream is not None:
+                    with self.torch.cuda.stream(self.stream):
+                        self.dist.all_reduce(self.msg, group=self.group)
+                else:
+                    self.dist.all_reduce(self.msg, group=self.group)
+                self.reductions += 1
+        out = np.zeros(self.cfg.dim, np.float32)
+        L.moshi_hot_tp_end(m, out.ctypes.data)
+        return out

@@ -561,3 +561,22 @@ def test_depth_shard_step_graphs_match_the_chained_graph_on_the_device():
         assert (r, txt, aud) == ref[i][:3] == chained[i][:3], f"step {i}"
         assert m.last_raw() == ref[i][5]
     m.free()
+
+
+def test_tensor_parallel_segments_on_the_device_match_the_oracle():
+    # SURVEY.md 8f.2 plumbing on the MI355X backend, one rank (the two-rank sum is covered on CPU, tests/test_temporal_tp_cpu.py): the 2 L + 1 segment
+    # graphs over sliced weights vs the oracle running the same segments, several stream positions
+    from moshi_cpp_amd import shard
+    cfg = hu.hot.tiny(hu.L, linear_type=F32, embed_type=F32)
+    cfg.ffn_hidden = 1024
+    cfg.enable_mimi_encoder = cfg.enable_mimi_decoder = 0
+    cfg.tp_world, cfg.tp_rank = 1, 0
+    outs = {}
+    for kind in ("oracle", "hip"):
+        m = hu.Model(kind, cfg, seed=0)
+        tp = shard.TemporalTP(hu.L, m.m, cfg, 0, 1, None)
+        rng = np.random.default_rng(4)
+        outs[kind] = [tp.stack((rng.standard_normal(cfg.dim) * 3).astype(np.float32)) for _ in range(6)]
+        m.free()
+    for i, (a, b) in enumerate(zip(outs["oracle"], outs["hip"])):
+        assert hu.rel_err(a, b) < 1e-5, f"position {i}: {hu.rel_err(a, b):.2e}"
