@@ -9,6 +9,8 @@ import hot_util as hu
 L = hu.L
 cfg = hu.hot.moshika(L)
 m = hu.Model("hip", cfg, seed=0)
+if os.environ.get("FILL"):
+    L.moshi_hot_set_context_fill(m.m, int(os.environ["FILL"]))     # start from a ring that is already this full
 pcm = np.zeros(1920, np.float32)
 for _ in range(12):
     m.sts_frame(pcm)
