@@ -1416,7 +1416,14 @@ static bool match_sampler(const analysis & an, int pos, step_group & grp) {
     for (int m : members) if (m < 0) return false;
     sample_args a;
     a.logits = (const float *) logits->data; a.n = (int) n; a.scale = ggml_get_op_params_f32(sc, 0); a.k = (int) k;
-    a.noise = (const float *) noise->data; a.out = (int32_t *) out->data;
+    a.noise = (const float *) noise->data; a.out = (int32_t *) out->data; a.out2 = nullptr;
+    // a copy of the token into an I32 slot (the chained Depth graph's token vector, lm.h:527): written by the same launch
+    for (int j = pos + 1; j < an.g->n_nodes; j++) {
+        const ggml_tensor * cp = an.g->nodes[j];
+        if (cp->op == GGML_OP_CPY && cp->src[0] == out && cp->type == GGML_TYPE_I32 && ggml_nelements(cp) == 1 && cp->data && !an.skip[(size_t) j]) {
+            a.out2 = (int32_t *) cp->data; members.push_back(j); break;
+        }
+    }
     grp.steps.clear();
     grp.steps.push_back([=](hipStream_t s) { k_sample_topk(s, a); });
     grp.members = members;

@@ -181,7 +181,7 @@ void k_gather_scalars(hipStream_t s, const gather_args & a);
 // argmax -> the chosen index, as one launch (the node chain costs ~12 launches and a full argsort of up to 32 000 values)
 #define SAMPLE_MAX_N 32768
 #define SAMPLE_MAX_K 256
-struct sample_args { const float * logits; int n; float scale; int k; const float * noise; int32_t * out; };
+struct sample_args { const float * logits; int n; float scale; int k; const float * noise; int32_t * out; int32_t * out2; };   // out2: optional copy (the token vector slot)
 void k_sample_topk(hipStream_t s, const sample_args & a);
 #define VQ_LEVEL_WS_BYTES 4096
 void k_vq_level(hipStream_t s, const vq_level_args & a);

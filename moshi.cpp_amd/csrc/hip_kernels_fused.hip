@@ -2092,6 +2092,7 @@ __global__ void __launch_bounds__(SMP_THREADS) sample_topk_kernel(sample_args a)
     __shared__ double shd[SMP_THREADS / 64];
     __shared__ int shi[SMP_THREADS / 64];
     __shared__ unsigned hist[256];
+    __shared__ unsigned whist[SMP_THREADS / 64][256];
     __shared__ unsigned s_bin, s_remaining, s_ncand, s_eq, s_base;
     __shared__ __attribute__((aligned(16))) float cand_p[SAMPLE_MAX_K + 8];
     __shared__ __attribute__((aligned(16))) int cand_i[SAMPLE_MAX_K + 8];
@@ -2137,31 +2138,19 @@ __global__ void __launch_bounds__(SMP_THREADS) sample_topk_kernel(sample_args a)
     // ---- k-th largest by radix select over the bit patterns
     unsigned prefix = 0u, mask = 0u, remaining = (unsigned) k;
     for (int shift = 24; shift >= 0; shift -= 8) {
-        if (tid < 256) hist[tid] = 0u;
+        // one private histogram per wave (same-bin lanes of a wave-instruction are serialised by the LDS unit itself, a few cycles each; a shared
+        // histogram costs ~18 us per pass in same-address atomics, a software match loop ~25 us on the text vocabulary's many exponent bins)
+        for (int i = tid; i < NW * 256; i += SMP_THREADS) (&whist[0][0])[i] = 0u;
         __syncthreads();
 #pragma unroll
         for (int j = 0; j < SMP_NPT; j++) {
             if (j * SMP_THREADS >= n) break;
             const int i = tid + j * SMP_THREADS;
             const unsigned key = __float_as_uint(p[j]);
-            // probabilities crowd into a handful of exponent bins: lanes that hit the same bin add ONCE (one LDS atomic per distinct bin and
-            // wave-instruction; 2 048 same-address atomics per pass cost ~18 us otherwise)
-            bool todo = i < n && (key & mask) == prefix;
-            const unsigned bin = (key >> shift) & 255u;
-            if (shift != 24) {   // lower digits are spread over the bins: plain atomics do not collide (and the loop below would run once per distinct bin)
-                if (todo) atomicAdd(&hist[bin], 1u);
-                continue;
-            }
-            unsigned long long left = __ballot(todo);
-            while (left) {
-                const int leader = __ffsll((long long) left) - 1;
-                const unsigned lb = (unsigned) __shfl((int) bin, leader, 64);
-                const unsigned long long same = __ballot(todo && bin == lb);
-                if (lane == leader) atomicAdd(&hist[lb], (unsigned) __popcll(same));
-                if (bin == lb) todo = false;
-                left &= ~same;
-            }
+            if (i < n && (key & mask) == prefix) atomicAdd(&whist[wave][(key >> shift) & 255u], 1u);
         }
+        __syncthreads();
+        if (tid < 256) { unsigned t = 0; for (int w2 = 0; w2 < NW; w2++) t += whist[w2][tid]; hist[tid] = t; }
         __syncthreads();
         if (wave == 0) {
             // lane l owns bins 255 - 4 l .. 252 - 4 l (descending); inclusive prefix over lanes, first lane reaching `remaining` resolves its bin
@@ -2252,7 +2241,9 @@ __global__ void __launch_bounds__(SMP_THREADS) sample_topk_kernel(sample_args a)
     __syncthreads();
     if (tid == 0) {
         for (int w = 1; w < NW; w++) if (shf[w] > best || (shf[w] == best && shi[w] > bj)) { best = shf[w]; bj = shi[w]; }
-        *a.out = sort_i[bj < 0 ? 0 : bj];
+        const int tok = sort_i[bj < 0 ? 0 : bj];
+        *a.out = tok;
+        if (a.out2) *a.out2 = tok;
     }
 }
 void k_sample_topk(hipStream_t s, const sample_args & a) {
