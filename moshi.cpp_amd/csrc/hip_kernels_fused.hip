@@ -1463,7 +1463,10 @@ void k_matvec(hipStream_t s, const mv_args & a) {
 // Masked slots (mask = -inf) contribute exactly 0, so only un-masked slots are read from HBM; the
 // result equals the reference's full-capacity soft_max (README.md:55-57).
 // ---------------------------------------------------------------------------------------------------
-#define ATTN_THREADS 256
+// waves per workgroup (NWA): 4 for D = 128 (Temporal / Depth: A/B at fills 0 / 100 / 600 / 2 800, 8 waves cost +50 ... +770 us per frame), 8 for the codec
+// transformers' 250-slot rings of D = 64 (8 x NPRE x 8 = 256 slots, the whole ring, are in flight from kernel entry: Mimi -30 us each way)
+#define ATTN_NW_BASE 4
+#define ATTN_NW_WIDE 8
 #define ATTN_MAX_T 4
 #define ATTN_NPRE 4      // ring-slot passes whose K and V rows are requested at kernel entry (4 passes x 4 waves x SPW slots)
 
@@ -1488,9 +1491,10 @@ struct attn_split_ws { float * scores; float * pmax; double * opart; unsigned * 
 #else
 #define AT_STAMP(i) do {} while (0)
 #endif
-template <bool SPLIT>
-__global__ void __launch_bounds__(ATTN_THREADS) __attribute__((amdgpu_waves_per_eu(2)))   // >= 2 workgroups per CU: the split grid (<= 512) is resident
+template <bool SPLIT, int NWA>
+__global__ void __launch_bounds__(NWA * 64) __attribute__((amdgpu_waves_per_eu(2)))   // >= 2 workgroups per CU: the split grid (<= 512) is resident
 attn_decode_kernel(attn_args a_in, attn_split_ws w) {
+    constexpr int ATTN_NW = NWA, ATTN_THREADS = NWA * 64;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 #if defined(MV_LOG)
     unsigned at_log_id = 0;
@@ -1522,10 +1526,10 @@ attn_decode_kernel(attn_args a_in, attn_split_ws w) {
     float * knew = qf + T * D;              // [T][D] bf16-rounded new k rows
     float * vnew = knew + T * D;            // [T][D] bf16-rounded new v rows
     double * red = (double *) (smem + (((size_t) (C + 3 * T * D) * 4 + 15) & ~(size_t) 15));   // [4 waves][SPW slot groups][D] partial outputs
-    float * msk = (float *) (red + 4 * (64 / (D / 8)) * D);   // [T][C] the mask rows, staged by the live-range scan (a global load per score pass otherwise)
-    __shared__ float sh_f[4];
-    __shared__ double sh_d[4];
-    __shared__ int sh_i[4];
+    float * msk = (float *) (red + ATTN_NW * (64 / (D / 8)) * D);   // [T][C] the mask rows, staged by the live-range scan (a global load per score pass otherwise)
+    __shared__ float sh_f[ATTN_NW];
+    __shared__ double sh_d[ATTN_NW];
+    __shared__ int sh_i[ATTN_NW];
     __shared__ int sh_slot[ATTN_MAX_T];
     __shared__ int s_last;
 
@@ -1575,7 +1579,10 @@ attn_decode_kernel(attn_args a_in, attn_split_ws w) {
         v = wave_allmax_i32(v);
         if (lane == 0) sh_i[wave] = v;
         __syncthreads();
-        return max(max(sh_i[0], sh_i[1]), max(sh_i[2], sh_i[3]));
+        int r_ = sh_i[0];
+#pragma unroll
+        for (int w_ = 1; w_ < ATTN_NW; w_++) r_ = max(r_, sh_i[w_]);
+        return r_;
     };
 
     // A split workgroup other than the head's first only has work when something at or beyond its first slot is live; that
@@ -1613,7 +1620,7 @@ attn_decode_kernel(attn_args a_in, attn_split_ws w) {
     uint4 kpre[NPRE], vpre[NPRE];
 #pragma unroll
     for (int pi = 0; pi < NPRE; pi++) {
-        const int c = c_base + wave * SPW + pi * 4 * SPW + sub;
+        const int c = c_base + wave * SPW + pi * ATTN_NW * SPW + sub;
         const int cc = c < C ? c : C - 1;
         kpre[pi] = *(const uint4 *) (kc + (int64_t) cc * a.k_nb1 + dl * 2);
         if (pi < ATTN_NPRE) vpre[pi] = *(const uint4 *) (vc + (int64_t) cc * a.v_nb1 + dl * 2);   // later V passes: after the scores (registers)
@@ -1663,7 +1670,7 @@ attn_decode_kernel(attn_args a_in, attn_split_ws w) {
     auto fresh_of = [&](int c) { int f = -1; for (int tt = 0; tt < T; tt++) if (slot_t[tt] == c) f = tt; return f; };
 #pragma unroll
     for (int pi = 0; pi < NPRE; pi++) {
-        const int f = fresh_of(c_base + wave * SPW + pi * 4 * SPW + sub);
+        const int f = fresh_of(c_base + wave * SPW + pi * ATTN_NW * SPW + sub);
         if (f >= 0) { kpre[pi] = pack_row(knew + f * D + dl); if (pi < ATTN_NPRE) vpre[pi] = pack_row(vnew + f * D + dl); }
     }
     AT_STAMP(8);
@@ -1696,21 +1703,21 @@ attn_decode_kernel(attn_args a_in, attn_split_ws w) {
         };
 #pragma unroll
         for (int pi = 0; pi < NPRE; pi++) {
-            const int c0 = c_lo + wave * SPW + pi * 4 * SPW;
+            const int c0 = c_lo + wave * SPW + pi * ATTN_NW * SPW;
             if (c0 < c_hi) score_pass(c0, kpre[pi]);
         }
         // further slots: NPRE rows requested together, then consumed (one memory round trip per batch, not per pass)
-        for (int cb = c_lo + NPRE * 4 * SPW; cb < c_hi; cb += NPRE * 4 * SPW) {
+        for (int cb = c_lo + NPRE * ATTN_NW * SPW; cb < c_hi; cb += NPRE * ATTN_NW * SPW) {
             uint4 kb[NPRE];
 #pragma unroll
             for (int pi = 0; pi < NPRE; pi++) {
-                const int c = cb + wave * SPW + pi * 4 * SPW + sub, f = fresh_of(c);
+                const int c = cb + wave * SPW + pi * ATTN_NW * SPW + sub, f = fresh_of(c);
                 kb[pi] = *(const uint4 *) (kc + (int64_t) (c < C ? c : C - 1) * a.k_nb1 + dl * 2);
                 if (f >= 0) kb[pi] = pack_row(knew + f * D + dl);
             }
 #pragma unroll
             for (int pi = 0; pi < NPRE; pi++) {
-                const int c0 = cb + wave * SPW + pi * 4 * SPW;
+                const int c0 = cb + wave * SPW + pi * ATTN_NW * SPW;
                 if (c0 < c_hi) score_pass(c0, kb[pi]);
             }
         }
@@ -1718,7 +1725,7 @@ attn_decode_kernel(attn_args a_in, attn_split_ws w) {
             // the remaining V rows of a split workgroup go out now (the K registers are free) and arrive during the head-wide wait
 #pragma unroll
             for (int pi = ATTN_NPRE; pi < NPRE; pi++) {
-                const int c = c_base + wave * SPW + pi * 4 * SPW + sub;
+                const int c = c_base + wave * SPW + pi * ATTN_NW * SPW + sub;
                 vpre[pi] = *(const uint4 *) (vc + (int64_t) (c < C ? c : C - 1) * a.v_nb1 + dl * 2);
                 const int f = fresh_of(c);
                 if (f >= 0) vpre[pi] = pack_row(vnew + f * D + dl);
@@ -1730,7 +1737,9 @@ attn_decode_kernel(attn_args a_in, attn_split_ws w) {
         AT_STAMP(11);
         __syncthreads();
         AT_STAMP(3);
-        float gmax = fmaxf(fmaxf(sh_f[0], sh_f[1]), fmaxf(sh_f[2], sh_f[3]));
+        float gmax = sh_f[0];
+#pragma unroll
+        for (int w_ = 1; w_ < ATTN_NW; w_++) gmax = fmaxf(gmax, sh_f[w_]);
         if (multi) {
             // publish (this workgroup's scores, at most one per thread: SLOTS <= 256 = ATTN_THREADS), arrive, wait for the other P - 1
             // workgroups of this head, then pull everybody's scores
@@ -1773,7 +1782,10 @@ attn_decode_kernel(attn_args a_in, attn_split_ws w) {
         lsum = wave_allsum_f64(lsum);
         if (lane == 0) sh_d[wave] = lsum;
         __syncthreads();
-        const float inv = (float) (1.0 / (sh_d[0] + sh_d[1] + sh_d[2] + sh_d[3]));   // p = bf16(e * inv), formed where it is used
+        double lall = sh_d[0];
+#pragma unroll
+        for (int w_ = 1; w_ < ATTN_NW; w_++) lall += sh_d[w_];
+        const float inv = (float) (1.0 / lall);   // p = bf16(e * inv), formed where it is used
         AT_STAMP(4);
 
         // 4. out[d] = sum_c V[d, c] * p[c]
@@ -1792,20 +1804,20 @@ attn_decode_kernel(attn_args a_in, attn_split_ws w) {
         };
 #pragma unroll
         for (int pi = 0; pi < NPRE; pi++) {
-            const int c0 = c_lo + wave * SPW + pi * 4 * SPW;
+            const int c0 = c_lo + wave * SPW + pi * ATTN_NW * SPW;
             if (c0 < c_hi) pv_pass(c0, vpre[pi]);
         }
-        for (int cb = c_lo + NPRE * 4 * SPW; cb < c_hi; cb += NPRE * 4 * SPW) {
+        for (int cb = c_lo + NPRE * ATTN_NW * SPW; cb < c_hi; cb += NPRE * ATTN_NW * SPW) {
             uint4 vb[NPRE];
 #pragma unroll
             for (int pi = 0; pi < NPRE; pi++) {
-                const int c = cb + wave * SPW + pi * 4 * SPW + sub, f = fresh_of(c);
+                const int c = cb + wave * SPW + pi * ATTN_NW * SPW + sub, f = fresh_of(c);
                 vb[pi] = *(const uint4 *) (vc + (int64_t) (c < C ? c : C - 1) * a.v_nb1 + dl * 2);
                 if (f >= 0) vb[pi] = pack_row(vnew + f * D + dl);
             }
 #pragma unroll
             for (int pi = 0; pi < NPRE; pi++) {
-                const int c0 = cb + wave * SPW + pi * 4 * SPW;
+                const int c0 = cb + wave * SPW + pi * ATTN_NW * SPW;
                 if (c0 < c_hi) pv_pass(c0, vb[pi]);
             }
         }
@@ -1817,7 +1829,7 @@ attn_decode_kernel(attn_args a_in, attn_split_ws w) {
         for (int j = tid; j < D; j += ATTN_THREADS) {
             double tot = 0;
 #pragma unroll 8
-            for (int g = 0; g < 4 * SPW; g++) tot += red[g * D + j];   // fixed order: wave-major, slot group minor
+            for (int g = 0; g < ATTN_NW * SPW; g++) tot += red[g * D + j];   // fixed order: wave-major, slot group minor
             if (multi) xchg_agent_wait(w.opart + ((int64_t) h * S + s_idx) * D + j, tot);
             else a.out[(int64_t) t * a.out_ts + (int64_t) h * D + j] = (float) tot;
         }
@@ -1855,15 +1867,18 @@ size_t k_attn_decode_ws_size(const attn_args & a) {
 }
 void k_attn_decode(hipStream_t s, const attn_args & a, void * ws, unsigned * err) {
     const int Tg = a.n_groups > 1 ? ATTN_MAX_T : a.T;   // rows per workgroup
-    GGML_ASSERT(a.D % 8 == 0 && 64 % (a.D / 8) == 0 && a.D <= 512 && a.T >= 1 && Tg <= ATTN_MAX_T && Tg * a.D <= 2 * ATTN_THREADS);
+    GGML_ASSERT(a.D % 8 == 0 && 64 % (a.D / 8) == 0 && a.D <= 512 && a.T >= 1 && Tg <= ATTN_MAX_T && Tg * a.D <= 2 * ATTN_NW_BASE * 64);
     GGML_ASSERT(a.n_groups <= 1 || a.n_groups == (a.T + 3) / 4);
-    const size_t smem = (size_t) a.C * 4 + (size_t) Tg * a.D * 4 * 3 + (size_t) (ATTN_THREADS / 64) * 64 * 8 * 8 + 16 + (size_t) Tg * a.C * 4;
+    static const int wide_on = env_int("MI355X_ATTN_WIDE", 1);
+    const bool wide = wide_on && a.D <= 64 && a.C >= 128;
+    const size_t smem = (size_t) a.C * 4 + (size_t) Tg * a.D * 4 * 3 + (size_t) (wide ? ATTN_NW_WIDE : ATTN_NW_BASE) * 64 * 8 * 8 + 16 + (size_t) Tg * a.C * 4 + (size_t) env_int("MI355X_ATTN_LDS_PAD", 0);
     GGML_ASSERT(smem <= 160 * 1024);
     if (smem > 64 * 1024) {   // > 64 KB of dynamic LDS needs a one-time opt-in per kernel
-        static size_t granted[2] = { 0, 0 };
-        const int which = ws && attn_use_split(a) ? 1 : 0;
+        static size_t granted[3] = { 0, 0, 0 };
+        const int which = ws && attn_use_split(a) ? 1 : wide ? 2 : 0;
         if (granted[which] < smem) {
-            HIP_CHECK(hipFuncSetAttribute(which ? (const void *) attn_decode_kernel<true> : (const void *) attn_decode_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) smem));
+            HIP_CHECK(hipFuncSetAttribute(which == 1 ? (const void *) attn_decode_kernel<true, ATTN_NW_BASE> : which == 2 ? (const void *) attn_decode_kernel<false, ATTN_NW_WIDE> : (const void *) attn_decode_kernel<false, ATTN_NW_BASE>,
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int) smem));
             granted[which] = smem;
         }
     }
@@ -1879,10 +1894,12 @@ void k_attn_decode(hipStream_t s, const attn_args & a, void * ws, unsigned * err
         w.scores = (float *) p; p += (size_t) a.H * a.C * 4;
         w.pmax = (float *) p;
         w.S = S;
-        attn_decode_kernel<true><<<a.H * S, ATTN_THREADS, smem, s>>>(a, w);
+        attn_decode_kernel<true, ATTN_NW_BASE><<<a.H * S, ATTN_NW_BASE * 64, smem, s>>>(a, w);
         return;
     }
-    attn_decode_kernel<false><<<dim3((unsigned) a.H, (unsigned) (a.n_groups > 1 ? a.n_groups : 1)), ATTN_THREADS, smem, s>>>(a, w);
+    const dim3 grid((unsigned) a.H, (unsigned) (a.n_groups > 1 ? a.n_groups : 1));
+    if (wide) attn_decode_kernel<false, ATTN_NW_WIDE><<<grid, ATTN_NW_WIDE * 64, smem, s>>>(a, w);
+    else      attn_decode_kernel<false, ATTN_NW_BASE><<<grid, ATTN_NW_BASE * 64, smem, s>>>(a, w);
 }
 
 // ---------------------------------------------------------------------------------------------------
