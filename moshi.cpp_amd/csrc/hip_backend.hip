@@ -560,7 +560,8 @@ static void emit_generic(emitter & em, ggml_tensor * n) {
                     const char * wp = (const char *) w0->data; const int64_t rb = (int64_t) w0->nb[1], K = w0->ne[0], M = w0->ne[1];
                     const float * xp = (const float *) x1->data; float * yp = (float *) n->data;
                     void * ws = em.ws(k_mm_q4k_batched_ws_size(K, Tn));
-                    em.push([=](hipStream_t s) { k_mm_q4k_batched(s, wp, rb, K, M, Tn, xp, K, ws, yp, M, nullptr, 0); });
+                    const int wt = (int) w0->type;
+                    em.push([=](hipStream_t s) { k_mm_q4k_batched(s, wt, wp, rb, K, M, Tn, xp, K, ws, yp, M, nullptr, 0); });
                     return;
                 }
             }
@@ -880,7 +881,7 @@ static bool match_batched_mm(const analysis & an, int pos, emitter & em, bmm_gro
     const ggml_tensor * mm = an.g->nodes[pos];
     if (mm->op != GGML_OP_MUL_MAT) return false;
     const ggml_tensor * w0 = mm->src[0], * x1 = mm->src[1];
-    if (w0->type != GGML_TYPE_Q4_K || !ggml_is_contiguous(w0) || w0->ne[2] != 1 || w0->ne[3] != 1) return false;
+    if (!is_qblock(w0->type) || !ggml_is_contiguous(w0) || w0->ne[2] != 1 || w0->ne[3] != 1) return false;
     if (x1->type != GGML_TYPE_F32 || !ggml_is_contiguous(x1) || mm->type != GGML_TYPE_F32 || !ggml_is_contiguous(mm) || mm->view_src) return false;
     const int64_t K = w0->ne[0], M = w0->ne[1], Tn = ggml_nelements(x1) / K;
     if (!k_mm_q4k_batched_supported(w0->type, K, M, Tn)) return false;
@@ -935,7 +936,8 @@ static bool match_batched_mm(const analysis & an, int pos, emitter & em, bmm_gro
     const char * wp = (const char *) w0->data;
     const int64_t rb = (int64_t) w0->nb[1];
     void * ws = em.ws(k_mm_q4k_batched_ws_size(K, Tn));
-    grp.run = [=](hipStream_t s) { k_mm_q4k_batched(s, wp, rb, K, M, Tn, xp, x_cs, ws, yp, M, res, M, prologue, alpha, eps); };
+    const int wt = (int) w0->type;
+    grp.run = [=](hipStream_t s) { k_mm_q4k_batched(s, wt, wp, rb, K, M, Tn, xp, x_cs, ws, yp, M, res, M, prologue, alpha, eps); };
     return true;
 }
 

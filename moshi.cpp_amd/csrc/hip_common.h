@@ -120,11 +120,11 @@ void k_matvec(hipStream_t s, const mv_args & a);
 void k_gate_quant_q8k(hipStream_t s, const float * h, int64_t K, void * out_blocks, int wtype);   // activation format follows the weight type
 // alpha * rms_norm(x) quantised once to the same padded blocks (K <= 4096); n_out (optional) receives the normed floats
 void k_norm_quant_q8k(hipStream_t s, const float * x, const float * alpha, float eps, int64_t K, void * out_blocks, int wtype, float * n_out);
-// batched Q4_K mat-mul for prompt prefill (T = 2..64 activation rows): rows quantised to Q8_K into `ws`, then 16x16x32 int8 MFMA tiles
+// batched Q4_K / Q8_0 / Q4_0 mat-mul for prompt prefill (T = 2..64 activation rows): rows quantised to Q8_K (Q4_K weights) or Q8_0 into `ws`, then 16x16x32 int8 MFMA tiles
 size_t k_mm_q4k_batched_ws_size(int64_t K, int64_t T);
 bool k_mm_q4k_batched_supported(int wtype, int64_t K, int64_t M, int64_t T);
 // prologue: MV_PLAIN (x[K, T] as is), MV_RMSNORM (alpha * rms_norm(x), eps) or MV_GATE_SILU (x = h[2K, T]: silu(h[:K]) * h[K:]); residual optional
-void k_mm_q4k_batched(hipStream_t s, const char * w, int64_t row_bytes, int64_t K, int64_t M, int64_t T, const float * x, int64_t x_cs,
+void k_mm_q4k_batched(hipStream_t s, int wtype, const char * w, int64_t row_bytes, int64_t K, int64_t M, int64_t T, const float * x, int64_t x_cs,
                       void * ws, float * y, int64_t y_cs, const float * residual, int64_t r_cs, int prologue = 0, const float * alpha = nullptr, float eps = 0.f);
 
 // streaming self-attention over a ring KV cache (T <= 4 new tokens): RoPE(q,k) -> cache write -> masked

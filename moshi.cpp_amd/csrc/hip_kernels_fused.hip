@@ -1302,12 +1302,203 @@ __global__ void __launch_bounds__(256) mm_q4k_mfma_rows_kernel(const char * w, i
         }
 }
 
+// ---- the same batched mat-mul for Q8_0 / Q4_0 weights (tts / stt checkpoints: `-q q8_0`, the loader's Q4_K -> Q4_0 fall-back) ---------------
+// Activation rows are quantised to Q8_0 (32-wide blocks, F16 scale - what ggml's CPU backend does for these weight types); a 32-wide
+// block is exactly the K = 32 of one v_mfma_i32_16x16x32_i8, so every block is ONE matrix instruction per 16 x 16 tile whose int32 sums
+// are scaled by d_w[row] * d_x[t] on the way into the float accumulators (vec_dot_q8_0_q8_0 / vec_dot_q4_0_q8_0 per block).
+struct xblk80b { int8_t q[256]; float d[8]; };   // eight consecutive blocks of one activation row; same 288 B as xblkb
+static_assert(sizeof(xblk80b) == sizeof(xblkb), "the two batched activation records share the workspace sizing");
+
+__device__ __forceinline__ void store_xblk80b(xblk80b * o, const xblk80 * tmp, int lane) {
+    ((uint32_t *) o->q)[lane] = ((const uint32_t *) tmp->q)[lane];
+    if (lane < 8) o->d[lane] = tmp->d[lane];
+}
+__global__ void __launch_bounds__(64) quant_rows_q80_kernel(const float * x, int64_t x_cs, int nb, xblk80b * out) {
+    __shared__ xblk80 tmp;
+    const int b = blockIdx.x % nb, t = blockIdx.x / nb, lane = threadIdx.x;
+    const float4 v4 = *(const float4 *) (x + (int64_t) t * x_cs + b * 256 + lane * 4);
+    const float v[4] = { v4.x, v4.y, v4.z, v4.w };
+    quantize_block_q80(&tmp, v, lane);
+    __syncthreads();
+    store_xblk80b(out + (int64_t) t * nb + b, &tmp, lane);
+}
+__global__ void __launch_bounds__(256) rms_quant_rows_q80_kernel(const float * x, int64_t x_cs, const float * alpha, float eps, int K, int nb, xblk80b * out) {
+    __shared__ double sh[4];
+    __shared__ xblk80 tmp[4];
+    const int t = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float * row = x + (int64_t) t * x_cs;
+    double acc = 0;
+    for (int i = tid; i < K; i += 256) { const float v = row[i]; acc += (double) (v * v); }
+    acc = wave_allsum_f64(acc);
+    if (lane == 0) sh[wave] = acc;
+    __syncthreads();
+    const float var = (float) ((sh[0] + sh[1] + sh[2] + sh[3]) / (double) K);
+    const float scale = 1.0f / sqrtf(var + eps);
+    for (int b = wave; b < nb; b += 4) {
+        const int e = b * 256 + lane * 4;
+        const float4 x4 = *(const float4 *) (row + e), a4 = *(const float4 *) (alpha + e);
+        const float v[4] = { (x4.x * scale) * a4.x, (x4.y * scale) * a4.y, (x4.z * scale) * a4.z, (x4.w * scale) * a4.w };
+        quantize_block_q80(&tmp[wave], v, lane);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        store_xblk80b(out + (int64_t) t * nb + b, &tmp[wave], lane);
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+__global__ void __launch_bounds__(64) gate_quant_rows_q80_kernel(const float * h, int64_t h_cs, int n, int nb, xblk80b * out) {
+    __shared__ xblk80 tmp;
+    const int b = blockIdx.x % nb, t = blockIdx.x / nb, lane = threadIdx.x;
+    const int e = b * 256 + lane * 4;
+    const float4 l4 = *(const float4 *) (h + (int64_t) t * h_cs + e), r4 = *(const float4 *) (h + (int64_t) t * h_cs + n + e);
+    const float l[4] = { l4.x, l4.y, l4.z, l4.w }, r[4] = { r4.x, r4.y, r4.z, r4.w };
+    float v[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) v[k] = (l[k] / (1.0f + expf(-l[k]))) * r[k];
+    quantize_block_q80(&tmp, v, lane);
+    __syncthreads();
+    store_xblk80b(out + (int64_t) t * nb + b, &tmp, lane);
+}
+
+// Tile = 16 weight rows x TSB groups of eight blocks (Q8_0: 2 x 272 B, Q4_0: 4 x 144 B per row; <= 576 B, staged at the MMQ_ROW stride),
+// dealt round-robin to the four waves (split K) exactly as in mm_q4k_mfma_kernel. The activation rows take the MFMA's M side, the
+// weight rows its N side: lane l = (r = l & 15, g = l >> 4) feeds weights 8 g .. 8 g + 7 of block j of row r and receives
+// C[t = 4 g + q][row r]. Q4_0: weights 0..15 of a block are the low nibbles of its 16 bytes, 16..31 the high ones, so g picks the
+// byte half (g & 1) and the nibble (g >> 1); (nibble - 8) as int8 without a per-byte borrow: ((nibble ^ 8) + 0x78) ^ 0x78.
+template <int NT, int FMT>
+__global__ void __launch_bounds__(64 * MMQ_NW) mm_q80_mfma_kernel(const char * w, int64_t row_bytes, int nb, int M, int T, const xblk80b * xq,
+                                                                   float * y, int64_t y_cs, const float * residual, int64_t r_cs) {
+    constexpr int SBB = FMT == MVF_Q80 ? 272 : 144, BLK = FMT == MVF_Q80 ? 34 : 18, TSB = FMT == MVF_Q80 ? 2 : 4;
+    constexpr int RB = TSB * SBB, CPR = RB / 16, NCH = 16 * CPR, NL = (NCH + 63) / 64;   // bytes / 16-byte chunks per staged row, chunks per tile, loads per lane
+    static_assert(RB <= MMQ_ROW && RB % 16 == 0, "staged row");
+    __shared__ __attribute__((aligned(16))) char stage_all[MMQ_NW][16 * MMQ_ROW];
+    __shared__ float red[MMQ_NW - 1][NT * 4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 15, g = lane >> 4;
+    const int row0 = blockIdx.x * 16;
+    char * stage = stage_all[wave];
+    const char * xa[NT]; const char * xo[NT][4];
+#pragma unroll
+    for (int nt = 0; nt < NT; nt++) {
+        const int col = nt * 16 + r < T ? nt * 16 + r : T - 1;
+        xa[nt] = (const char *) (xq + (int64_t) col * nb);
+#pragma unroll
+        for (int q = 0; q < 4; q++) { const int co = nt * 16 + 4 * g + q < T ? nt * 16 + 4 * g + q : T - 1; xo[nt][q] = (const char *) (xq + (int64_t) co * nb); }
+    }
+    float acc[NT][4];
+#pragma unroll
+    for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+        for (int q = 0; q < 4; q++) acc[nt][q] = 0.f;
+    const int ntiles = (nb + TSB - 1) / TSB;
+    int grow[NL], goff[NL], loff[NL];
+#pragma unroll
+    for (int i = 0; i < NL; i++) {
+        const int c0 = i * 64 + lane, c = c0 < NCH ? c0 : NCH - 1, rr = c / CPR, o = (c - rr * CPR) * 16;
+        grow[i] = row0 + rr < M ? row0 + rr : M - 1;
+        goff[i] = o;
+        loff[i] = rr * MMQ_ROW + o;
+    }
+    auto load_tile = [&](int tile, u32x4 * dst) {
+#pragma unroll
+        for (int i = 0; i < NL; i++) {
+            int64_t off = (int64_t) tile * RB + goff[i];
+            if (off > row_bytes - 16) off = row_bytes - 16;   // ragged last tile: stay inside the row
+            dst[i] = __builtin_nontemporal_load((const u32x4 *) (w + (int64_t) grow[i] * row_bytes + off));
+        }
+    };
+    u32x4 rn[NL];
+    if (wave < ntiles) load_tile(wave, rn);
+    for (int tile = wave; tile < ntiles; tile += MMQ_NW) {
+#pragma unroll
+        for (int i = 0; i < NL; i++) if (i * 64 + lane < NCH) *(u32x4 *) (stage + loff[i]) = rn[i];
+        if (tile + MMQ_NW < ntiles) load_tile(tile + MMQ_NW, rn);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const int nsb = nb - tile * TSB < TSB ? nb - tile * TSB : TSB;
+        for (int sb = 0; sb < nsb; sb++) {
+            const int64_t xoff = (int64_t) (tile * TSB + sb) * (int64_t) sizeof(xblk80b);
+            const uint32_t * D = (const uint32_t *) (stage + r * MMQ_ROW + sb * SBB);   // this lane's weight row: eight blocks
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const int off = BLK * j;
+                const float dw = h2f((uint16_t) (D[off >> 2] >> ((off & 2) * 8)));
+                long wq;
+                if (FMT == MVF_Q80) {
+                    const uint32_t w0 = dword_at2(D, off + 2 + 8 * g), w1 = dword_at2(D, off + 6 + 8 * g);
+                    wq = (long) ((uint64_t) w0 | ((uint64_t) w1 << 32));
+                } else {
+                    const int sh = 4 * (g >> 1);
+                    const uint32_t n0 = (dword_at2(D, off + 2 + 8 * (g & 1)) >> sh) & 0x0F0F0F0Fu, n1 = (dword_at2(D, off + 6 + 8 * (g & 1)) >> sh) & 0x0F0F0F0Fu;
+                    const uint32_t w0 = ((n0 ^ 0x08080808u) + 0x78787878u) ^ 0x78787878u, w1 = ((n1 ^ 0x08080808u) + 0x78787878u) ^ 0x78787878u;
+                    wq = (long) ((uint64_t) w0 | ((uint64_t) w1 << 32));
+                }
+#pragma unroll
+                for (int nt = 0; nt < NT; nt++) {
+                    const long xv = *(const long *) (xa[nt] + xoff + 32 * j + 8 * g);
+                    const i32x4_t z = { 0, 0, 0, 0 };
+                    const i32x4_t c = __builtin_amdgcn_mfma_i32_16x16x32_i8(xv, wq, z, 0, 0, 0);
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        const float dx = *(const float *) (xo[nt][q] + xoff + 256 + 4 * j);
+                        if (FMT == MVF_Q80) acc[nt][q] += (float) c[q] * (dw * dx);
+                        else acc[nt][q] += ((float) c[q] * dw) * dx;
+                    }
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();   // every lane is done with the staged tile before it is overwritten
+    }
+    if (wave > 0) {
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+            for (int q = 0; q < 4; q++) red[wave - 1][nt * 4 + q][lane] = acc[nt][q];
+    }
+    __syncthreads();
+    if (wave > 0) return;
+    const int row = row0 + r;
+#pragma unroll
+    for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            float v = acc[nt][q];
+#pragma unroll
+            for (int ww = 0; ww < MMQ_NW - 1; ww++) v += red[ww][nt * 4 + q][lane];
+            const int col = nt * 16 + 4 * g + q;
+            if (col >= T || row >= M) continue;
+            if (residual) v = residual[(int64_t) col * r_cs + row] + v;
+            y[(int64_t) col * y_cs + row] = v;
+        }
+}
+
 static int env_int(const char * name, int def);
 size_t k_mm_q4k_batched_ws_size(int64_t K, int64_t T) { return (size_t) (K / 256) * (size_t) T * sizeof(xblkb); }
-bool k_mm_q4k_batched_supported(int wtype, int64_t K, int64_t M, int64_t T) { return wtype == GGML_TYPE_Q4_K && K % 256 == 0 && T >= 2 && T <= 64 && M >= 16; }
-void k_mm_q4k_batched(hipStream_t s, const char * w, int64_t row_bytes, int64_t K, int64_t M, int64_t T, const float * x, int64_t x_cs,
+bool k_mm_q4k_batched_supported(int wtype, int64_t K, int64_t M, int64_t T) {
+    return (wtype == GGML_TYPE_Q4_K || wtype == GGML_TYPE_Q8_0 || wtype == GGML_TYPE_Q4_0) && K % 256 == 0 && T >= 2 && T <= 64 && M >= 16;
+}
+void k_mm_q4k_batched(hipStream_t s, int wtype, const char * w, int64_t row_bytes, int64_t K, int64_t M, int64_t T, const float * x, int64_t x_cs,
                       void * ws, float * y, int64_t y_cs, const float * residual, int64_t r_cs, int prologue, const float * alpha, float eps) {
     const int nb = (int) (K / 256);
+    if (wtype != GGML_TYPE_Q4_K) {   // Q8_0 / Q4_0 weights: Q8_0 activation rows
+        xblk80b * xq0 = (xblk80b *) ws;
+        if (prologue == MV_RMSNORM) rms_quant_rows_q80_kernel<<<(int) T, 256, 0, s>>>(x, x_cs, alpha, eps, (int) K, nb, xq0);
+        else if (prologue == MV_GATE_SILU) gate_quant_rows_q80_kernel<<<(int) (T * nb), 64, 0, s>>>(x, x_cs, (int) K, nb, xq0);
+        else quant_rows_q80_kernel<<<(int) (T * nb), 64, 0, s>>>(x, x_cs, nb, xq0);
+        const int grid = (int) ((M + 15) / 16), thr = 64 * MMQ_NW;
+        for (int64_t c0 = 0; c0 < T; c0 += 32) {
+            const int Tc = (int) (T - c0 < 32 ? T - c0 : 32);
+            const xblk80b * xq = xq0 + c0 * nb;
+            float * yc = y + c0 * y_cs;
+            const float * rc = residual ? residual + c0 * r_cs : nullptr;
+            if (wtype == GGML_TYPE_Q8_0) {
+                if (Tc <= 16) mm_q80_mfma_kernel<1, MVF_Q80><<<grid, thr, 0, s>>>(w, row_bytes, nb, (int) M, Tc, xq, yc, y_cs, rc, r_cs);
+                else mm_q80_mfma_kernel<2, MVF_Q80><<<grid, thr, 0, s>>>(w, row_bytes, nb, (int) M, Tc, xq, yc, y_cs, rc, r_cs);
+            } else {
+                if (Tc <= 16) mm_q80_mfma_kernel<1, MVF_Q40><<<grid, thr, 0, s>>>(w, row_bytes, nb, (int) M, Tc, xq, yc, y_cs, rc, r_cs);
+                else mm_q80_mfma_kernel<2, MVF_Q40><<<grid, thr, 0, s>>>(w, row_bytes, nb, (int) M, Tc, xq, yc, y_cs, rc, r_cs);
+            }
+        }
+        return;
+    }
     if (prologue == MV_RMSNORM) rms_quant_rows_q8k_kernel<<<(int) T, 256, 0, s>>>(x, x_cs, alpha, eps, (int) K, nb, (xblkb *) ws);
     else if (prologue == MV_GATE_SILU) gate_quant_rows_q8k_kernel<<<(int) (T * nb), 64, 0, s>>>(x, x_cs, (int) K, nb, (xblkb *) ws);
     else quant_rows_q8k_kernel<<<(int) (T * nb), 64, 0, s>>>(x, x_cs, nb, (xblkb *) ws);

@@ -9,6 +9,10 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 chunks = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else [8, 16, 32]
 cfg = hu.hot.personaplex(L)
 cfg.context = 2000
+if os.environ.get("PREFILL_QUANT"):          # q8_0 / q4_0 linears at the same widths (the int8-MFMA mat-mul of those weight types)
+    cfg.linear_type = {"q8_0": 8, "q4_0": 2, "q4_k": 12}[os.environ["PREFILL_QUANT"]]
+if os.environ.get("PREFILL_DIM"):            # e.g. 2048: the tts / stt width (16 layers, feed-forward 5632)
+    cfg.dim, cfg.num_heads, cfg.num_layers, cfg.ffn_hidden = int(os.environ["PREFILL_DIM"]), 16, 16, 5632
 cfg.enable_mimi_encoder = cfg.enable_mimi_decoder = 0
 rng = np.random.default_rng(1)
 frames = [[int(rng.integers(0, cfg.text_card))] + rng.integers(0, cfg.card, cfg.n_q).tolist() for _ in range(n)]

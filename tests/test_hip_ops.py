@@ -386,6 +386,61 @@ def test_batched_q4k_matmul_int8_mfma(K, M, T):
     gu.compare(build3, atol_rel=2e-6)
 
 
+@pytest.mark.parametrize("wt", ["q8_0", "q4_0"])
+@pytest.mark.parametrize("K,M,T", [(256, 16, 2), (512, 40, 5), (2048, 250, 16), (2048, 6144, 17), (2048, 96, 32), (512, 64, 33), (8448, 128, 64), (768, 72, 9),
+                                   (1024, 8200, 20)])
+def test_batched_q80_q40_matmul_int8_mfma(wt, K, M, T):
+    # prompt prefill of the `-q q8_0` checkpoints (tts / stt) and of the loader's Q4_K -> Q4_0 fall-back: T activation rows, each quantised
+    # to Q8_0 as ggml does, one v_mfma_i32_16x16x32_i8 per 32-wide block and 16 x 16 tile; ragged M, T and tile counts (K = 768: three
+    # groups of eight blocks against tiles of two / four)
+    r = np.random.default_rng(K + M + T + len(wt))
+    x = (r.standard_normal((T, K)) * r.uniform(0.2, 3.0, (T, 1))).astype(np.float32)
+    gt = Q8_0 if wt == "q8_0" else Q4_0
+    wraw = (gu.random_q8_0 if wt == "q8_0" else gu.random_q4_0)(r, M, K)
+
+    def build(g):
+        return [g.mul_mat(g.input_raw(wraw, gt, K, M), g.input(x))]
+    gu.compare(build, atol_rel=2e-6)
+    _, st = gu.run_graph("hip", build)
+    assert st.kernels_in_last_plan == 1, st.kernels_in_last_plan      # row quantiser + MFMA mat-mul are one plan step; the generic mul_mat is not used
+
+
+@pytest.mark.parametrize("wt", ["q8_0", "q4_0"])
+def test_batched_q80_q40_matmul_fused_rows(wt):
+    # the prefill layer shapes at the 2048-wide tts / stt widths: y = res + W (alpha * rms_norm(x)) and y = res + W (silu(h[:n]) * h[n:])
+    r = np.random.default_rng(17 + len(wt))
+    gt = Q8_0 if wt == "q8_0" else Q4_0
+    gen = gu.random_q8_0 if wt == "q8_0" else gu.random_q4_0
+    K, M, T = 2048, 6144, 24
+    x = (r.standard_normal((T, K)) * r.uniform(0.2, 3.0, (T, 1))).astype(np.float32)
+    alpha = (1.0 + 0.1 * r.standard_normal((1, K))).astype(np.float32)
+    res = r.standard_normal((T, M)).astype(np.float32)
+    wraw = gen(r, M, K)
+
+    def build(g):
+        xn = g.mul(g.rms_norm(g.input(x), 1e-8), g.input(alpha))
+        return [g.add(g.input(res), g.mul_mat(g.input_raw(wraw, gt, K, M), xn))]
+    gu.compare(build, atol_rel=2e-6)
+    _, st = gu.run_graph("hip", build)
+    assert st.kernels_in_last_plan == 1, st.kernels_in_last_plan
+
+    n, M2 = 5632, 2048
+    h = r.standard_normal((T, 2 * n)).astype(np.float32)
+    res2 = r.standard_normal((T, M2)).astype(np.float32)
+    wraw2 = gen(r, M2, n)
+
+    def build2(g):
+        hh = g.input(h)
+        t = hh.contents
+        left = g.view_4d(hh, t.ne[0] // 2, 1, t.ne[1], t.ne[2], t.nb[1] // 2, t.nb[1], t.nb[2], 0)
+        right = g.view_4d(hh, t.ne[0] // 2, 1, t.ne[1], t.ne[2], t.nb[1] // 2, t.nb[1], t.nb[2], t.nb[1] // 2)
+        y = g.mul_mat(g.input_raw(wraw2, gt, n, M2), g.mul(g.silu(left), right))
+        return [g.add(g.input(res2), g.reshape_3d(y, M2, T, 1))]
+    gu.compare(build2, atol_rel=2e-6)
+    _, st = gu.run_graph("hip", build2)
+    assert st.kernels_in_last_plan == 1, st.kernels_in_last_plan
+
+
 @pytest.mark.parametrize("K,M,T", [(512, 96, 5), (4096, 8192, 32), (1024, 72, 17)])
 def test_batched_q4k_matmul_rmsnorm_rows_and_residual(K, M, T):
     # the batched prefill layer shape: y = res + W (rms_norm(x) * alpha) for T rows: the norm runs inside the row quantiser, the add in the epilogue
