@@ -386,6 +386,42 @@ def test_batched_q4k_matmul_int8_mfma(K, M, T):
     gu.compare(build3, atol_rel=2e-6)
 
 
+@pytest.mark.parametrize("wt", ["f32", "q8_0"])
+def test_voice_condition_graph(wt):
+    # the one-shot conditioning graph of moshi-tts (src/moshi.cpp:296-366): two (embedding row -> output projection) terms summed into
+    # `condition_sum`; the speaker latents [n, 512] transposed, projected to the model width (T = n activation rows: the batched mat-mul),
+    # written over the first n rows of five repeats of the learnt padding through a cpy into a view, plus sinusoidal position embeddings ->
+    # `condition_cross`; both results copied into separately allocated tensors (ScratchContext::build_forward_expand(src, dst))
+    dim, cdim, sdim, n = 2048, 256, 512, 25
+
+    def build(g):
+        r = np.random.default_rng(5)                                   # the same weights on both executors
+
+        def weight(rows, k):
+            if wt == "f32":
+                return g.input((r.standard_normal((rows, k)) / np.sqrt(k)).astype(np.float32))
+            return g.input_raw(gu.random_q8_0(r, rows, k), Q8_0, k, rows)
+        cfg_proj, control_proj, speaker_proj = weight(dim, cdim), weight(dim, cdim), weight(dim, sdim)
+        cfg_embed = g.input(r.standard_normal((7, cdim)).astype(np.float32))
+        control_embed = g.input(r.standard_normal((1, cdim)).astype(np.float32))
+        padding = g.input(r.standard_normal((1, dim)).astype(np.float32))
+        speaker_wavs = g.input(r.standard_normal((sdim, n)).astype(np.float32))      # ne = [n, 512]
+        cfg_cond = g.mul_mat(cfg_proj, g.get_rows(cfg_embed, g.input(np.array([2], np.int32), I32)))
+        control_cond = g.mul_mat(control_proj, g.get_rows(control_embed, g.input(np.array([0], np.int32), I32)))
+        condition_sum = g.add(cfg_cond, control_cond)
+        wavs_b = g.mul_mat(speaker_proj, g.cont(g.transpose(speaker_wavs)))          # [dim, n]
+        cond = g.repeat_4d(padding, dim, n * 5, 1, 1)
+        nb1 = cond.contents.nb[1]
+        speaker_0 = g.cpy(wavs_b, g.view_2d(cond, dim, n, nb1, 0))
+        cond = g.view_2d(speaker_0, dim, n * 5, nb1, 0)
+        positions = g.input(np.arange(n * 5, dtype=np.float32))
+        condition_cross = g.add(cond, g.scale(g.timestep_embedding(positions, dim, 10000), 1.0))
+        out_sum, out_cross = g.new(F32, dim, 1), g.new(F32, dim, n * 5)
+        return [g.cpy(condition_sum, out_sum), g.cpy(condition_cross, out_cross)]
+    ref, got, _ = gu.compare(build, atol_rel=2e-6)
+    assert ref[1].shape[-2:] == (n * 5, dim) and np.abs(ref[1][..., n:, :]).max() > 0     # padding rows + positions, speaker rows in front
+
+
 @pytest.mark.parametrize("wt", ["q8_0", "q4_0"])
 @pytest.mark.parametrize("K,M,T", [(256, 16, 2), (512, 40, 5), (2048, 250, 16), (2048, 6144, 17), (2048, 96, 32), (512, 64, 33), (8448, 128, 64), (768, 72, 9),
                                    (1024, 8200, 20)])
