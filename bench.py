@@ -99,6 +99,8 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the extra lines (sampled mode, long context, PersonaPlex) that ride in the JSON's `extras` object")
     ap.add_argument("--sampled", action="store_true", help="the reference's own --bench sampling mode (tools/moshi-sts.cpp:106-107: Depth temperature 0.8, "
                     "text temperature 0.7, top-k 250 / 25) instead of greedy; host rand() noise uploaded per compute as src/context.h:456-480 does")
+    ap.add_argument("--serial", action="store_true", help="the frame loop on ONE command stream (encode -> LM -> decode of the same frame, each waited for). Default: the same "
+                    "graphs software-pipelined over two HIP streams (LM of frame k beside decode of k - 1 and encode of k + 1; identical tokens and PCM)")
     ap.add_argument("--shard", default="none", choices=["none", "depth"],
                     help="depth: ONE stream, the Depth transformer's per-codebook weight sets sharded over the ranks (SURVEY.md 8e: step k on rank k %% N, "
                          "K/V rows + token broadcast per step over RCCL); strong scaling. Default: independent stream replicas (weak scaling)")
@@ -171,6 +173,8 @@ def main():
         cfg.linear_type = {"q8_0": 8, "q4_0": 2}[args.quant]   # ggml_type ids
     if args.sampled:
         cfg.temp, cfg.temp_text = 0.8, 0.7
+    pipelined = not args.serial and args.shard == "none" and args.model in ("moshika", "personaplex")
+    cfg.codec_stream = int(pipelined)
     shard = None
     if args.shard == "depth":
         if args.model not in ("moshika", "personaplex"):
@@ -219,8 +223,16 @@ def main():
             L.moshi_hot_mimi_encode(m, pcm.ctypes.data, codes)
             return L.moshi_hot_lm_step_n(m, codes, cfg.n_q, C.byref(txt), aud64, C.byref(vad))
     else:
-        def frame():
+        def frame_serial():
             return L.moshi_hot_sts_frame(m, pcm.ctypes.data, C.byref(txt), aud, out.ctypes.data)
+        frame = frame_serial
+        if pipelined:
+            # call k: LM step of frame k on the backend's stream; decode of frame k - 1 and encode of frame k + 1 on the codec stream
+            # (include/moshi_hot.h "software-pipelined"). One encode, one LM step and one decode per call; results read back before it returns.
+            L.moshi_hot_sts_pipeline_begin(m, pcm.ctypes.data)
+
+            def frame():
+                return L.moshi_hot_sts_pipeline_frame(m, pcm.ctypes.data, C.byref(txt), aud, out.ctypes.data)
 
     def barrier():
         L.ggml_backend_synchronize(be)
@@ -280,8 +292,10 @@ def main():
         "config": {"workload": ({"tts_like": "moshi-tts loop: Temporal step (cross-attention, demux) + %d Depth steps + mimi decode (32 levels), ",
                                  "stt_like": "moshi-stt loop: mimi encode (32 levels) + Temporal step + VAD head (%d Depth steps), "}
                                 .get(args.model, "moshi-sts --bench loop: mimi encode + Temporal step + %d Depth steps + mimi decode, ") % cfg.dep_q) +
-                               "%s %s, 1 stream per GPU, %s, ctx capacity %d" % (args.model, args.quant, "sampled (temp 0.8 / 0.7, top-k 250 / 25)" if args.sampled else "greedy", cfg.context),
+                               "%s %s, 1 audio stream per GPU, %s, ctx capacity %d" % (args.model, args.quant, "sampled (temp 0.8 / 0.7, top-k 250 / 25)" if args.sampled else "greedy", cfg.context),
                    "context_fill_start": args.context_fill,
+                   "frame_loop": "software-pipelined over 2 HIP streams: LM step of frame k beside mimi decode of frame k-1 and mimi encode of frame k+1; same graphs, "
+                                 "inputs, states and outputs as the serial loop (--serial), one of each per step" if pipelined else "serial: encode -> LM -> decode of one frame per step",
                    "parallelism": ("Depth codebook shard: step k on rank k %% %d, replicated 8-slot ring, 1 + dep_q broadcasts per frame" % world) if shard is not None
                                   else "independent stream replica per GPU" if world > 1 else "1 GPU",
                    "device": dev_desc},
@@ -297,7 +311,7 @@ def main():
         # where the frame goes (separate pass, synchronising around each phase; not part of the timed region)
         L.moshi_hot_set_timing(m, 1)
         for _ in range(10):
-            frame()
+            (frame_serial if pipelined else frame)()
         ph = (C.c_double * 4)()
         L.moshi_hot_get_timing(m, ph)
         L.moshi_hot_set_timing(m, 0)
@@ -307,6 +321,15 @@ def main():
         result["phase_roofline"] = {k: {"bytes": int(pb[k]), "GB/s": round(pb[k] / (result["phase_us"][k] * 1e-6) / 1e9, 1) if result["phase_us"][k] else None,
                                         "frac": round(pb[k] / (result["phase_us"][k] * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4) if result["phase_us"][k] else None} for k in pb}
         result["source_sha"] = source_sha()
+        if pipelined:
+            # the same model stepped serially (one frame's encode -> LM -> decode, each waited for): what the pipelining buys
+            ns = min(args.steps, 60)
+            barrier()
+            t1 = time.perf_counter()
+            for _ in range(ns):
+                frame_serial()
+            barrier()
+            result["serial_loop"] = {"value": round(ns / (time.perf_counter() - t1), 2), "unit": "frames/s", "steps": ns}
 
     if shard is not None:
         shard.stop_workers()
@@ -323,7 +346,7 @@ def main():
         # start/stop events attached to each dispatch (flag 8: same plan, launched eagerly on the backend stream).
         L.ggml_backend_mi355x_set_flags(be, 8)
         for _ in range(3):
-            frame()
+            (frame_serial if pipelined else frame)()
         L.ggml_backend_synchronize(be)
         kp = pkg.KernelProfile()
         L.ggml_backend_mi355x_get_kernel_profile(be, C.byref(kp))
@@ -385,15 +408,21 @@ def main():
         # not the headline: the same loop (a) with the reference's --bench sampling defaults, (b) from a nearly full ring, (c) at BASELINE configs[4]
         def quick(make_cfg, fill=0, steps=40):
             c2 = make_cfg()
+            c2.codec_stream = int(pipelined)
             mm = L.moshi_hot_create(be, C.byref(c2), 0)
             if fill:
                 L.moshi_hot_set_context_fill(mm, fill)
+            if pipelined:
+                L.moshi_hot_sts_pipeline_begin(mm, pcm.ctypes.data)
+                step = lambda: L.moshi_hot_sts_pipeline_frame(mm, pcm.ctypes.data, C.byref(txt), aud, out.ctypes.data)
+            else:
+                step = lambda: L.moshi_hot_sts_frame(mm, pcm.ctypes.data, C.byref(txt), aud, out.ctypes.data)
             for _ in range(6):
-                L.moshi_hot_sts_frame(mm, pcm.ctypes.data, C.byref(txt), aud, out.ctypes.data)
+                step()
             L.ggml_backend_synchronize(be)
             t1 = time.perf_counter()
             for _ in range(steps):
-                L.moshi_hot_sts_frame(mm, pcm.ctypes.data, C.byref(txt), aud, out.ctypes.data)
+                step()
             L.ggml_backend_synchronize(be)
             r = steps / (time.perf_counter() - t1)
             L.moshi_hot_free(mm)

@@ -122,6 +122,11 @@ GGML_API void ggml_backend_mi355x_set_flags(ggml_backend_t backend, int flags);
 GGML_API void ggml_backend_mi355x_set_capture(ggml_backend_t backend, int enabled);
 // HIP stream the backend launches on (void* = hipStream_t) so callers can bracket it with HIP events
 GGML_API void * ggml_backend_mi355x_get_stream(ggml_backend_t backend);
+// A second command stream on the same GPU: a backend handle with its own HIP stream, upload queue and plan cache. Graphs submitted through it run
+// concurrently with those of `base` (the codec of neighbouring frames beside the LM step, moshi_hot.h "software-pipelined frame loop"); buffers
+// allocated through either handle are ordinary device memory usable by both - ordering between the two streams is the caller's (host round trips
+// through ggml_backend_tensor_get / ggml_backend_synchronize). Returns NULL when `base` is not an MI355X backend. Free with ggml_backend_free.
+GGML_API ggml_backend_t ggml_backend_mi355x_init_stream(ggml_backend_t base);
 
 #ifdef __cplusplus
 }

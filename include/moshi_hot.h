@@ -66,6 +66,10 @@ struct moshi_hot_config {
     // graphs with a sum over ranks of one F32[dim] partial between them (moshi_hot_tp_* below). Column blocks fall on 256-value boundaries, so
     // the Q8_K activation blocks and every integer block dot are those of the unsplit layer; only the final float sums split.
     int32_t tp_rank, tp_world;
+    // 1: the Mimi encode / decode graphs (and their scratch graphs) are built on a second command stream of the same GPU
+    // (ggml_backend_mi355x_init_stream), so that moshi_hot_sts_pipeline_frame overlaps the codec of neighbouring frames with the LM step.
+    // Ignored (one stream) on any other backend. Results are the same either way.
+    int32_t codec_stream;
 };
 
 typedef struct moshi_hot_model moshi_hot_model_t;
@@ -113,6 +117,15 @@ GGML_API void moshi_hot_personaplex_system_prompts(moshi_hot_model_t * m, const 
 GGML_API void moshi_hot_personaplex_system_prompts_batched(moshi_hot_model_t * m, const int32_t * text_prompt, int n_text, int chunk);
 // one iteration of the moshi-sts --bench loop (tools/moshi-sts.cpp:770-808); returns 1 when a frame was produced
 GGML_API int moshi_hot_sts_frame(moshi_hot_model_t * m, const float * pcm_in, int32_t * text_token, int32_t * audio_tokens, float * pcm_out);
+
+// The moshi-sts --bench loop software-pipelined (tools/moshi-sts.cpp:770-808 feeds every frame without waiting for playback): the LM step of
+// frame k runs on the backend's stream while the codec stream (config.codec_stream) decodes frame k - 1 and encodes frame k + 1. begin: encodes
+// frame 0. frame: pcm_next = input of frame k + 1 (NULL: none follows); returns bit 0 = text_token / audio_tokens of frame k are valid, bit 1 =
+// pcm_prev holds the output of frame k - 1. end: decodes the last frame (returns 1 if there was one). Tokens and PCM are bit-identical to
+// moshi_hot_sts_frame's: every graph consumes the same inputs and states in the same order, only on two streams.
+GGML_API void moshi_hot_sts_pipeline_begin(moshi_hot_model_t * m, const float * pcm0);
+GGML_API int  moshi_hot_sts_pipeline_frame(moshi_hot_model_t * m, const float * pcm_next, int32_t * text_token, int32_t * audio_tokens, float * pcm_prev);
+GGML_API int  moshi_hot_sts_pipeline_end(moshi_hot_model_t * m, float * pcm_last);
 
 // introspection for tests / bench
 GGML_API int64_t moshi_hot_offset(moshi_hot_model_t * m);                      // frames stepped so far

@@ -69,10 +69,14 @@ struct hip_ctx {
     volatile unsigned * err_host = nullptr;
     unsigned * err_dev = nullptr;
     char * readback = nullptr;   // pinned staging for small device -> host reads
+    bool in_use = false;         // stream contexts only: handed out by ggml_backend_mi355x_init_stream, returned by ggml_backend_free
     ggml_backend_device dev_obj;
 };
 
 static std::vector<hip_ctx *> & contexts() { static std::vector<hip_ctx *> v; return v; }
+// additional command streams on a device (ggml_backend_mi355x_init_stream): a full context of its own - stream, upload slots, pool, plan cache -
+// on the same GPU, so graphs submitted through it overlap with the device's first stream. Not listed by the registry.
+static std::vector<hip_ctx *> & stream_contexts() { static std::vector<hip_ctx *> v; return v; }
 
 static void set_device(hip_ctx * c) { HIP_CHECK(hipSetDevice(c->device)); }
 
@@ -191,7 +195,10 @@ static void evict_plans_of_buffer(hip_ctx * c, const ggml_backend_buffer * b);
 static void hip_buf_free(ggml_backend_buffer_t b) {
     hip_buffer_ctx * bc = (hip_buffer_ctx *) b->context;
     flush_uploads(bc->c);
-    evict_plans_of_buffer(bc->c, b);   // plans (captured hipGraphs with baked pointers, pool workspaces) must not silently outlive the memory they address
+    // plans (captured hipGraphs with baked pointers, pool workspaces) must not silently outlive the memory they address - on any stream of the device
+    evict_plans_of_buffer(bc->c, b);
+    for (hip_ctx * o : contexts()) if (o != bc->c && o->device == bc->c->device) evict_plans_of_buffer(o, b);
+    for (hip_ctx * o : stream_contexts()) if (o != bc->c && o->device == bc->c->device) evict_plans_of_buffer(o, b);
     pool_free(bc->c, b->base, bc->actual);
     delete bc;
     delete b;
@@ -1777,6 +1784,7 @@ static void hip_backend_free(ggml_backend_t b) {
         for (auto & kv : c->plans) plan_free(c, kv.second);
         c->plans.clear();
     }
+    c->in_use = false;
     delete b;
 }
 static void hip_backend_sync(ggml_backend_t b) {
@@ -1872,3 +1880,22 @@ extern "C" void ggml_backend_mi355x_get_kernel_profile(ggml_backend_t b, struct 
     out->seconds = c->prof_seconds; out->launches = c->prof_launches; out->bytes = c->prof_bytes;
 }
 extern "C" void * ggml_backend_mi355x_get_stream(ggml_backend_t b) { hip_ctx * c = ctx_of(b); ctx_init_lazy(c); return (void *) c->stream; }
+extern "C" ggml_backend_t ggml_backend_mi355x_init_stream(ggml_backend_t base) {
+    if (!base || base->iface.get_name != hip_backend_name) return NULL;   // any other backend: the caller keeps using `base`
+    hip_ctx * b0 = (hip_ctx *) base->context;
+    hip_ctx * c = nullptr;
+    int n_same = 0;
+    for (hip_ctx * o : stream_contexts()) if (o->device == b0->device) { n_same++; if (!o->in_use && !c) c = o; }
+    if (!c) {
+        c = new hip_ctx;
+        c->device = b0->device;
+        c->name = b0->name + "/s" + std::to_string(n_same + 1);
+        c->description = b0->description + ", additional stream";
+        c->dev_obj.iface = b0->dev_obj.iface;
+        c->dev_obj.reg = b0->dev_obj.reg;
+        c->dev_obj.context = c;
+        stream_contexts().push_back(c);
+    }
+    c->in_use = true;
+    return c->dev_obj.iface.init_backend(&c->dev_obj, NULL);
+}

@@ -641,11 +641,12 @@ T rvq_encode(Builder & g, Rvq & rvq, T x, T * latent = nullptr) {
 struct moshi_hot_model {
     moshi_hot_config cfg;
     ggml_backend_t be;
+    ggml_backend_t be_codec = nullptr; bool own_codec_be = false;   // codec_stream: the Mimi graphs run on a second command stream of the same GPU
     Weights * W = nullptr;
     // persistent state (StateContext, src/context.h:656-780)
     struct ggml_context * st_ctx = nullptr; ggml_backend_buffer_t st_buf = nullptr;
     std::vector<std::pair<T, std::vector<uint8_t>>> st_init;
-    Builder * scratch = nullptr;
+    Builder * scratch = nullptr, * scratch_codec = nullptr;
 
     // LM
     Transformer temporal, depth;
@@ -684,6 +685,9 @@ struct moshi_hot_model {
     T enc_latent[2] = { nullptr, nullptr };   // the projected latents the two RVQ stacks quantise (inputs of their first levels), for tie analysis in tests
 
     std::vector<int32_t> tokens_tmp;
+    // software-pipelined frame loop (moshi_hot_sts_pipeline_*): codes of the frame the next LM step consumes, tokens of the frame still to be decoded
+    std::vector<int32_t> pipe_codes, pipe_tokens; bool pipe_have_codes = false, pipe_have_tokens = false;
+    std::function<void()> after_temporal_launch;   // runs once the Temporal graph is queued, before its text token is waited for
     int32_t last_text = 0; std::vector<int32_t> last_audio;   // raw (un-delayed) tokens of the last step
     // optional per-phase wall-clock (moshi_hot_set_timing): 0 mimi encode, 1 temporal, 2 depth, 3 mimi decode
     bool timing = false; double phase_us[4] = { 0, 0, 0, 0 }; int64_t phase_n[4] = { 0, 0, 0, 0 };
@@ -866,7 +870,7 @@ void build_depth_graph(moshi_hot_model * m) {
 // mimi_decode, graph part (compression.h:156-187)
 void build_decode_graph(moshi_hot_model * m) {
     const moshi_hot_config & c = m->cfg;
-    m->g_dec = new Builder(m->be, 256);
+    m->g_dec = new Builder(m->be_codec, 256);
     Builder & g = *m->g_dec;
     T codes = ggml_new_tensor_2d(g, GGML_TYPE_I32, 1, c.mimi_n_q);
     m->dec_codes = codes;
@@ -901,7 +905,7 @@ void build_decode_graph(moshi_hot_model * m) {
 // mimi_encode, graph part (compression.h:284-308)
 void build_encode_graph(moshi_hot_model * m) {
     const moshi_hot_config & c = m->cfg;
-    m->g_enc = new Builder(m->be, 256);
+    m->g_enc = new Builder(m->be_codec, 256);
     Builder & g = *m->g_enc;
     T x = ggml_new_tensor_1d(g, GGML_TYPE_F32, 1920);
     m->enc_frame = x;
@@ -960,6 +964,12 @@ extern "C" moshi_hot_model_t * moshi_hot_create(ggml_backend_t backend, const st
     m->W = new Weights(backend, seed, 4096);
     m->st_ctx = ggml_init({ ggml_tensor_overhead() * 1024, NULL, true });
     m->scratch = new Builder(backend, 16);
+    m->be_codec = backend;
+    if (c.codec_stream) {
+        ggml_backend_t b2 = ggml_backend_mi355x_init_stream(backend);   // NULL on any other backend: one stream, same results
+        if (b2) { m->be_codec = b2; m->own_codec_be = true; }
+    }
+    m->scratch_codec = m->own_codec_be ? new Builder(m->be_codec, 16) : m->scratch;
     Weights & W = *m->W;
     const enum ggml_type lt = (enum ggml_type) c.linear_type, et = (enum ggml_type) c.embed_type;
     auto qgen = [](float sd) { return [sd](T t, Rng & r, std::vector<uint8_t> & o) { gen_quant(t, r, o, sd); }; };
@@ -1104,50 +1114,67 @@ extern "C" moshi_hot_model_t * moshi_hot_create(ggml_backend_t backend, const st
     for (auto & s : m->st_init) ggml_backend_tensor_set(s.first, s.second.data(), 0, s.second.size());
     m->st_init.clear();
     m->tokens_tmp.resize((size_t) (c.n_q + 1 + 32));
+    m->pipe_codes.resize((size_t) (c.n_q + 1 + 32)); m->pipe_tokens.resize((size_t) (c.n_q + 1 + 32));
+    ggml_backend_synchronize(backend);   // weights and zeroed states are in place before any other stream touches them
     return m;
 }
 
 extern "C" void moshi_hot_free(moshi_hot_model_t * m) {
     if (!m) return;
-    delete m->g_temporal; delete m->g_depth; delete m->g_dec; delete m->g_enc; delete m->scratch; delete m->g_shard_begin;
+    if (m->own_codec_be) ggml_backend_synchronize(m->be_codec);
+    delete m->g_temporal; delete m->g_depth; delete m->g_dec; delete m->g_enc; if (m->scratch_codec != m->scratch) delete m->scratch_codec; delete m->scratch; delete m->g_shard_begin;
     for (auto * b : m->g_shard_step) delete b;
     for (auto * b : m->g_shard_import) delete b;
     for (auto * b : m->g_tp) delete b;
     if (m->st_buf) ggml_backend_buffer_free(m->st_buf);
     ggml_free(m->st_ctx);
     delete m->W;
+    if (m->own_codec_be) ggml_backend_free(m->be_codec);
     delete m;
 }
 
 namespace {
 struct PhaseTimer {
     moshi_hot_model * m; int phase; int64_t t0;
-    PhaseTimer(moshi_hot_model * m_, int p) : m(m_), phase(p), t0(0) { if (m->timing) { ggml_backend_synchronize(m->be); t0 = ggml_time_us(); } }
-    ~PhaseTimer() { if (m->timing) { ggml_backend_synchronize(m->be); m->phase_us[phase] += (double) (ggml_time_us() - t0); m->phase_n[phase]++; } }
+    ggml_backend_t be() const { return phase == 0 || phase == 3 ? m->be_codec : m->be; }
+    PhaseTimer(moshi_hot_model * m_, int p) : m(m_), phase(p), t0(0) { if (m->timing) { ggml_backend_synchronize(be()); t0 = ggml_time_us(); } }
+    ~PhaseTimer() { if (m->timing) { ggml_backend_synchronize(be()); m->phase_us[phase] += (double) (ggml_time_us() - t0); m->phase_n[phase]++; } }
 };
 }
 
-// mimi_decode, per-frame part (compression.h:189-203)
-extern "C" void moshi_hot_mimi_decode(moshi_hot_model_t * m, const int32_t * codes, float * pcm) {
+// mimi_decode, per-frame part (compression.h:189-203), as launch (uploads + graphs queued on the codec stream, nothing waited for) and finish (read-back)
+namespace {
+void mimi_decode_launch(moshi_hot_model * m, const int32_t * codes) {
     if (!m->g_dec) build_decode_graph(m);
-    PhaseTimer pt(m, 3);
     ggml_backend_tensor_set(m->dec_codes, codes, 0, ggml_nbytes(m->dec_codes));
-    transformer_graph_step(*m->scratch, m->dec_tr, m->dec_T);
-    m->scratch->compute_scratch();
+    transformer_graph_step(*m->scratch_codec, m->dec_tr, m->dec_T);
+    m->scratch_codec->compute_scratch();
     m->g_dec->compute();
+}
+void mimi_decode_finish(moshi_hot_model * m, float * pcm) {
     if (pcm) ggml_backend_tensor_get(m->dec_frame, pcm, 0, ggml_nbytes(m->dec_frame));
     else { float tmp; ggml_backend_tensor_get(m->dec_frame, &tmp, 0, 4); }
 }
-
 // mimi_encode, per-frame part (compression.h:310-324)
-extern "C" void moshi_hot_mimi_encode(moshi_hot_model_t * m, const float * pcm, int32_t * codes) {
+void mimi_encode_launch(moshi_hot_model * m, const float * pcm) {
     if (!m->g_enc) build_encode_graph(m);
-    PhaseTimer pt(m, 0);
     ggml_backend_tensor_set(m->enc_frame, pcm, 0, ggml_nbytes(m->enc_frame));
-    transformer_graph_step(*m->scratch, m->enc_tr, m->enc_T);
-    m->scratch->compute_scratch();
+    transformer_graph_step(*m->scratch_codec, m->enc_tr, m->enc_T);
+    m->scratch_codec->compute_scratch();
     m->g_enc->compute();
-    ggml_backend_tensor_get(m->enc_codes, codes, 0, ggml_nbytes(m->enc_codes));
+}
+void mimi_encode_finish(moshi_hot_model * m, int32_t * codes) { ggml_backend_tensor_get(m->enc_codes, codes, 0, ggml_nbytes(m->enc_codes)); }
+}  // namespace
+
+extern "C" void moshi_hot_mimi_decode(moshi_hot_model_t * m, const int32_t * codes, float * pcm) {
+    PhaseTimer pt(m, 3);
+    mimi_decode_launch(m, codes);
+    mimi_decode_finish(m, pcm);
+}
+extern "C" void moshi_hot_mimi_encode(moshi_hot_model_t * m, const float * pcm, int32_t * codes) {
+    PhaseTimer pt(m, 0);
+    mimi_encode_launch(m, pcm);
+    mimi_encode_finish(m, codes);
 }
 
 // moshi_lmgen_step (lm.h:778-979) for the plain moshi model: no state machine, no prefixes
@@ -1361,6 +1388,7 @@ extern "C" int moshi_hot_lm_step_n(moshi_hot_model_t * m, const int32_t * tokens
     transformer_graph_step(*m->scratch, m->temporal, 1);
     m->scratch->compute_scratch();
     m->g_temporal->compute();
+    if (m->after_temporal_launch) { m->after_temporal_launch(); m->after_temporal_launch = nullptr; }
     ggml_backend_tensor_get(m->sampler_out, &text_token, 0, 4);
     }
     if (m->text_hook) text_token = m->text_hook(m->text_hook_user, m->offset, text_token);   // on_text_hook (lm.h:880-900)
@@ -1544,6 +1572,38 @@ extern "C" int moshi_hot_sts_frame(moshi_hot_model_t * m, const float * pcm_in, 
     moshi_hot_mimi_encode(m, pcm_in, codes);
     if (!moshi_hot_lm_step(m, codes, text_token, audio_tokens)) return 0;
     moshi_hot_mimi_decode(m, audio_tokens, pcm_out);
+    return 1;
+}
+
+// The same loop software-pipelined over the two command streams (codec_stream): call k runs the LM step of frame k while the codec stream decodes
+// frame k - 1 and encodes frame k + 1. Each graph sees exactly the inputs and states it sees in moshi_hot_sts_frame, in the same per-graph order
+// (encode 0, 1, 2 ...; decode 0, 1, 2 ...; LM 0, 1, 2 ...), so tokens and PCM are bit-identical; the hand-offs are host round trips (codes and
+// tokens are a few integers). Without a second stream the calls degenerate to the serial order.
+extern "C" void moshi_hot_sts_pipeline_begin(moshi_hot_model_t * m, const float * pcm0) {
+    moshi_hot_mimi_encode(m, pcm0, m->pipe_codes.data());
+    m->pipe_have_codes = true;
+    m->pipe_have_tokens = false;
+}
+extern "C" int moshi_hot_sts_pipeline_frame(moshi_hot_model_t * m, const float * pcm_next, int32_t * text_token, int32_t * audio_tokens, float * pcm_prev) {
+    GGML_ASSERT(m->pipe_have_codes && "moshi_hot_sts_pipeline_begin first");
+    const bool dec = m->pipe_have_tokens;
+    // the LM stream is the critical path: its Temporal graph is queued first, the codec launches follow while it runs
+    m->after_temporal_launch = [m, dec, pcm_next]() {
+        if (dec) mimi_decode_launch(m, m->pipe_tokens.data());          // frame k - 1
+        if (pcm_next) mimi_encode_launch(m, pcm_next);                  // frame k + 1
+    };
+    const int ok = moshi_hot_lm_step(m, m->pipe_codes.data(), text_token, audio_tokens);   // frame k (blocks on the LM stream only)
+    if (dec) mimi_decode_finish(m, pcm_prev);
+    if (pcm_next) mimi_encode_finish(m, m->pipe_codes.data());
+    m->pipe_have_codes = pcm_next != nullptr;
+    m->pipe_have_tokens = ok != 0;
+    if (ok) memcpy(m->pipe_tokens.data(), audio_tokens, (size_t) (m->cfg.personaplex ? 8 : m->cfg.dep_q) * sizeof(int32_t));
+    return (ok ? 1 : 0) | (dec ? 2 : 0);
+}
+extern "C" int moshi_hot_sts_pipeline_end(moshi_hot_model_t * m, float * pcm_last) {
+    if (!m->pipe_have_tokens) return 0;
+    moshi_hot_mimi_decode(m, m->pipe_tokens.data(), pcm_last);
+    m->pipe_have_tokens = false;
     return 1;
 }
 

@@ -18,7 +18,7 @@ class Config(C.Structure):
                                          "condition_sum", "dep_schedule_len")] + \
                [("dep_schedule", C.c_int32 * MAX_CB), ("update_scale", C.c_float),
                 ("dep_shard_rank", C.c_int32), ("dep_shard_world", C.c_int32), ("depth_only", C.c_int32),
-                ("tp_rank", C.c_int32), ("tp_world", C.c_int32)]
+                ("tp_rank", C.c_int32), ("tp_world", C.c_int32), ("codec_stream", C.c_int32)]
 
     @property
     def io_dep_q(self):
@@ -44,6 +44,9 @@ SIGNATURES = {
     "moshi_hot_mimi_decode": (None, [P, P, P]),
     "moshi_hot_lm_step": (C.c_int, [P, P, P, P]),
     "moshi_hot_sts_frame": (C.c_int, [P, P, P, P, P]),
+    "moshi_hot_sts_pipeline_begin": (None, [P, P]),
+    "moshi_hot_sts_pipeline_frame": (C.c_int, [P, P, P, P, P]),
+    "moshi_hot_sts_pipeline_end": (C.c_int, [P, P]),
     "moshi_hot_offset": (C.c_int64, [P]),
     "moshi_hot_weight_bytes": (C.c_size_t, [P, C.c_int]),
     "moshi_hot_read_last": (C.c_int, [P, C.c_char_p, P, C.c_int64]),

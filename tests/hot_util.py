@@ -41,6 +41,26 @@ class Model:
         r = L.moshi_hot_sts_frame(self.m, pcm.ctypes.data, C.byref(txt), aud, out.ctypes.data)
         return r, txt.value, list(aud)[:self.cfg.dep_q], out
 
+    def sts_pipeline(self, frames):
+        """the software-pipelined loop over `frames` (moshi_hot_sts_pipeline_*): -> per frame (produced, text, audio tokens, pcm) like sts_frame"""
+        frames = [np.ascontiguousarray(f, np.float32) for f in frames]
+        res = []
+        pcm_of = {}
+        L.moshi_hot_sts_pipeline_begin(self.m, frames[0].ctypes.data)
+        for k in range(len(frames)):
+            txt = C.c_int32(-7)
+            aud = (C.c_int32 * 32)()
+            prev = np.zeros(1920, np.float32)
+            nxt = frames[k + 1].ctypes.data if k + 1 < len(frames) else None
+            r = L.moshi_hot_sts_pipeline_frame(self.m, nxt, C.byref(txt), aud, prev.ctypes.data)
+            if r & 2:
+                pcm_of[k - 1] = prev
+            res.append([r & 1, txt.value, list(aud)[:self.cfg.dep_q]])
+        last = np.zeros(1920, np.float32)
+        if L.moshi_hot_sts_pipeline_end(self.m, last.ctypes.data):
+            pcm_of[len(frames) - 1] = last
+        return [tuple(r) + (pcm_of.get(k, np.zeros(1920, np.float32)),) for k, r in enumerate(res)]
+
     def lm_step(self, in_audio):
         ia = (C.c_int32 * 32)(*in_audio)
         txt = C.c_int32(-7)

@@ -33,6 +33,26 @@ def test_driver_is_deterministic_in_seed():
     assert runs[0] == runs[1] and runs[0] != runs[2]
 
 
+def test_pipelined_frame_loop_equals_the_serial_loop_on_the_host_device():
+    # moshi_hot_sts_pipeline_* (include/moshi_hot.h): call k steps the LM on frame k, decodes frame k - 1 and encodes frame k + 1. On the host device
+    # there is one stream (codec_stream is ignored), which pins the protocol itself: outputs arrive one call later, nothing else changes.
+    rng = np.random.default_rng(3)
+    frames = [rng.standard_normal(1920).astype(np.float32) * 0.1 for _ in range(6)]
+    cfg = hu.hot.tiny(hu.L, layers=1)
+    m = hu.Model("oracle", cfg)
+    serial = [m.sts_frame(f) for f in frames]
+    m.free()
+    cfg.codec_stream = 1
+    m = hu.Model("oracle", cfg)
+    piped = m.sts_pipeline(frames)
+    m.free()
+    assert serial[0][0] == 0 and all(a[0] for a in serial[1:])
+    for a, b in zip(serial, piped):
+        assert a[:3] == b[:3]
+        if a[0]:
+            assert np.array_equal(a[3], b[3])
+
+
 def test_codec_round_trip_runs_and_is_finite():
     cfg = hu.hot.tiny(hu.L)
     cfg.enable_lm = 0

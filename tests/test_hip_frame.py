@@ -130,6 +130,28 @@ def test_sts_frames_match_oracle():
             assert hu.rel_err(a[3], b[3]) < PCM_TOL, f"frame {i}: pcm rel err {hu.rel_err(a[3], b[3]):.2e}"
 
 
+@pytest.mark.parametrize("streams", [1, 2])
+def test_pipelined_frame_loop_is_bit_identical_to_the_serial_loop(streams):
+    # moshi_hot_sts_pipeline_*: LM of frame k beside decode of k - 1 and encode of k + 1 (on a second command stream when codec_stream = 1).
+    # Every graph consumes the same inputs and states in the same order, so tokens and PCM are the serial loop's, bit for bit.
+    rng = np.random.default_rng(21)
+    frames = [rng.standard_normal(1920).astype(np.float32) * 0.1 for _ in range(9)]
+    cfg = hu.hot.tiny(hu.L)
+    m = hu.Model("hip", cfg, seed=0)
+    serial = [m.sts_frame(f) for f in frames]
+    m.free()
+    cfg2 = hu.hot.tiny(hu.L)
+    cfg2.codec_stream = int(streams == 2)
+    m = hu.Model("hip", cfg2, seed=0)
+    piped = m.sts_pipeline(frames)
+    m.free()
+    assert any(a[0] for a in serial)
+    for i, (a, b) in enumerate(zip(serial, piped)):
+        assert a[0] == b[0] and a[1] == b[1] and a[2] == b[2], f"frame {i}: serial {a[:3]} vs pipelined {b[:3]}"
+        if a[0]:
+            assert np.array_equal(a[3], b[3]), f"frame {i}: pcm differs, max {np.abs(a[3] - b[3]).max():.3e}"
+
+
 def test_mimi_codec_crosses_t2_mask_quirk():
     # Mimi transformers have T = 2, capacity 250: after 125 frames bias_pattern_index takes its second branch
     # (SURVEY.md §5 quirk). Codes in -> pcm out, 130 frames, decoder only.
