@@ -175,6 +175,7 @@ def main():
         cfg.temp, cfg.temp_text = 0.8, 0.7
     pipelined = not args.serial and args.shard == "none" and args.model in ("moshika", "personaplex")
     cfg.codec_stream = int(pipelined)
+    cfg.chain_depth = int(pipelined)
     shard = None
     if args.shard == "depth":
         if args.model not in ("moshika", "personaplex"):
@@ -409,6 +410,7 @@ def main():
         def quick(make_cfg, fill=0, steps=40):
             c2 = make_cfg()
             c2.codec_stream = int(pipelined)
+            c2.chain_depth = int(pipelined)
             mm = L.moshi_hot_create(be, C.byref(c2), 0)
             if fill:
                 L.moshi_hot_set_context_fill(mm, fill)

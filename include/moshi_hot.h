@@ -70,6 +70,11 @@ struct moshi_hot_config {
     // (ggml_backend_mi355x_init_stream), so that moshi_hot_sts_pipeline_frame overlaps the codec of neighbouring frames with the LM step.
     // Ignored (one stream) on any other backend. Results are the same either way.
     int32_t codec_stream;
+    // 1: the Depth graph takes the text token straight from the Temporal graph's sampler output in device memory and is queued right behind it - one host
+    // wait per LM step instead of two - and the next frame's Temporal step inputs (mask row, RoPE phase, ring slot: functions of the stream position
+    // only) are queued behind the Depth graph. Same graphs otherwise, same tokens. Not with a text hook, a Depth hook, demux or delay_steps (the
+    // reference's host code inspects the text token between the two graphs there, lm.h:880-921).
+    int32_t chain_depth;
 };
 
 typedef struct moshi_hot_model moshi_hot_model_t;

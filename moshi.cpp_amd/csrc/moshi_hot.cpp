@@ -662,6 +662,7 @@ struct moshi_hot_model {
     T emb_right_idx = nullptr, emb_right_scale = nullptr, dep_right_idx = nullptr, dep_right_scale = nullptr;
     moshi_hot_text_hook_t text_hook = nullptr; void * text_hook_user = nullptr;
     T transformer_out = nullptr;   // state F32[dim] (lm.h:434)
+    T text_state = nullptr;        // chain_depth: state I32[1], the sampled text token handed from the Temporal to the Depth graph the way transformer_out is
     Builder * g_temporal = nullptr; std::vector<T> emb_idx, emb_scale; T sampler_out = nullptr, text_logits = nullptr, g_transformer_out = nullptr, g_transformer_in = nullptr, g_stack_out = nullptr;
     Builder * g_depth = nullptr; T dep_text_idx = nullptr, dep_text_scale = nullptr, dep_tokens = nullptr; std::vector<T> dep_logits;
     // Depth codebook shard (moshi_hot.h): per-step graphs, import graphs, the two messages, the device-side token vector
@@ -687,6 +688,7 @@ struct moshi_hot_model {
     std::vector<int32_t> tokens_tmp;
     // software-pipelined frame loop (moshi_hot_sts_pipeline_*): codes of the frame the next LM step consumes, tokens of the frame still to be decoded
     std::vector<int32_t> pipe_codes, pipe_tokens; bool pipe_have_codes = false, pipe_have_tokens = false;
+    bool temporal_staged = false;                  // chain_depth: the next frame's Temporal step inputs (mask row, RoPE phase, ring slot) are already queued
     std::function<void()> after_temporal_launch;   // runs once the Temporal graph is queued, before its text token is waited for
     int32_t last_text = 0; std::vector<int32_t> last_audio;   // raw (un-delayed) tokens of the last step
     // optional per-phase wall-clock (moshi_hot_set_timing): 0 mimi encode, 1 temporal, 2 depth, 3 mimi decode
@@ -823,6 +825,7 @@ void build_temporal_graph(moshi_hot_model * m) {
     g.expand(ggml_cpy(g, x, m->transformer_out));
     m->sampler_out = sample_token(g, m->text_logits, c.temp_text, c.top_k_text);
     g.expand(m->sampler_out);
+    if (m->text_state) g.expand(ggml_cpy(g, ggml_reshape_1d(g, m->sampler_out, 1), m->text_state));
     g.alloc();
 }
 
@@ -832,6 +835,11 @@ void build_depth_graph(moshi_hot_model * m) {
     m->g_depth = new Builder(m->be, 256);
     Builder & g = *m->g_depth;
     m->dep_text_idx = g.tensor(GGML_TYPE_I32, 1);
+    if (c.chain_depth) {
+        // the text token is taken from the state tensor the Temporal graph copies its sample into: no host round trip between the graphs
+        GGML_ASSERT(!c.demux_second_stream && !c.delay_steps && m->text_state && m->sampler_out->type == GGML_TYPE_I32 && ggml_nelements(m->sampler_out) == 1);
+        m->dep_text_idx = m->text_state;
+    }
     T last;
     if (c.demux_second_stream) {
         m->dep_right_idx = g.tensor(GGML_TYPE_I32, 1); m->dep_right_scale = g.tensor(GGML_TYPE_F32, 1);
@@ -1030,6 +1038,7 @@ extern "C" moshi_hot_model_t * moshi_hot_create(ggml_backend_t backend, const st
         m->text_linear = W.add("lm.text_linear.weight", lt, c.dim, c.text_card, 1, qgen(1.f / sqrtf((float) c.dim)));
         }
         m->transformer_out = state(m, GGML_TYPE_F32, c.dim);
+        if (c.chain_depth) m->text_state = state(m, GGML_TYPE_I32, 1);
         if (c.condition_sum) m->cond_sum = state(m, GGML_TYPE_F32, c.dim);
         if (c.cross_attention) m->cond_cross = state(m, GGML_TYPE_F32, c.dim, c.cross_len);
         for (int k = 0; k < c.extra_heads; k++)
@@ -1197,12 +1206,20 @@ void depth_step(moshi_hot_model * m, int32_t text_token, std::vector<int32_t> & 
     else {
         int32_t id = text_token; const float sc = id == -1 ? 0.f : 1.f;
         if (id < 0) id = 0;
-        ggml_backend_tensor_set(m->dep_text_idx, &id, 0, 4);
+        if (!m->cfg.chain_depth) ggml_backend_tensor_set(m->dep_text_idx, &id, 0, 4);
         ggml_backend_tensor_set(m->dep_text_scale, &sc, 0, 4);
     }
     m->g_depth->compute();
+    if (m->cfg.chain_depth && !m->temporal_staged) {
+        // the next frame's Temporal step inputs do not depend on this frame's samples: queue them behind the Depth graph, off the host's critical path
+        transformer_graph_step(*m->scratch, m->temporal, 1);
+        m->scratch->compute_scratch();
+        m->temporal_staged = true;
+    }
     ggml_backend_tensor_get(m->dep_tokens, audio.data(), 0, audio.size() * 4);
 }
+// any other user of the Temporal stream position first takes back a step staged by depth_step
+void unstage_temporal(moshi_hot_model * m) { if (m->temporal_staged) { m->temporal.offset -= 1; m->temporal_staged = false; } }
 }
 
 // ---- tensor-parallel Temporal stack ---------------------------------------------------------------------------
@@ -1374,6 +1391,9 @@ extern "C" int moshi_hot_lm_step_n(moshi_hot_model_t * m, const int32_t * tokens
 
     if (!m->g_temporal) build_temporal_graph(m);
     int32_t text_token = 0;
+    // chain_depth: the Depth graph reads the sampled text token on the device; it is queued right behind the Temporal graph and both results are read afterwards
+    const bool chain = c.chain_depth && c.dep_q > 0 && !m->depth_hook;
+    GGML_ASSERT(!(c.chain_depth && (m->text_hook || m->depth_hook)) && "chain_depth: the text token never visits the host between the two graphs");
     {
     PhaseTimer pt(m, 1);
     // moshi_lmmodel_text_token_embed_step (lm.h:586-607): -1 -> scale 0, negative ids -> row 0
@@ -1385,18 +1405,24 @@ extern "C" int moshi_hot_lm_step_n(moshi_hot_model_t * m, const int32_t * tokens
         ggml_backend_tensor_set(m->emb_idx[(size_t) i], &id, 0, 4);
         ggml_backend_tensor_set(m->emb_scale[(size_t) i], &sc, 0, 4);
     }
-    transformer_graph_step(*m->scratch, m->temporal, 1);
-    m->scratch->compute_scratch();
+    if (m->temporal_staged) m->temporal_staged = false;
+    else {
+        transformer_graph_step(*m->scratch, m->temporal, 1);
+        m->scratch->compute_scratch();
+    }
     m->g_temporal->compute();
     if (m->after_temporal_launch) { m->after_temporal_launch(); m->after_temporal_launch = nullptr; }
-    ggml_backend_tensor_get(m->sampler_out, &text_token, 0, 4);
+    if (!chain) ggml_backend_tensor_get(m->sampler_out, &text_token, 0, 4);
     }
     if (m->text_hook) text_token = m->text_hook(m->text_hook_user, m->offset, text_token);   // on_text_hook (lm.h:880-900)
 
     std::vector<int32_t> audio((size_t) c.dep_q, 0);   // int_audio_tokens.resize(lm->dep_q) (lm.h:902)
     const bool replace = m->offset < c.delay_steps;    // depformer_replace_tokens (src/moshi.cpp:905)
     if (c.dep_q > 0) {
-        if (!replace) { if (m->depth_hook) m->depth_hook(m->depth_hook_user, text_token, audio.data()); else depth_step(m, text_token, audio); }
+        if (!replace) {
+            if (m->depth_hook) m->depth_hook(m->depth_hook_user, text_token, audio.data()); else depth_step(m, text_token, audio);
+            if (chain) ggml_backend_tensor_get(m->sampler_out, &text_token, 0, 4);
+        }
         else for (auto & a : audio) a = -1;            // lm.h:910-913
         if (c.delay_steps)                             // on_audio_hook (lm.h:915-921)
             for (int q = 0; q < c.dep_q; q++) if (m->offset < c.delays[q + 1] + c.delay_steps) audio[(size_t) q] = -1;
@@ -1434,6 +1460,7 @@ extern "C" int moshi_hot_lm_step(moshi_hot_model_t * m, const int32_t * in_audio
 }
 
 extern "C" void moshi_hot_lm_step_embedding(moshi_hot_model_t * m, const float * embedding) {
+    unstage_temporal(m);
     const moshi_hot_config & c = m->cfg;
     Builder & s = *m->scratch;
     int32_t sampled = 0;
@@ -1481,6 +1508,7 @@ extern "C" void moshi_hot_set_text_hook(moshi_hot_model_t * m, moshi_hot_text_ho
 // frame before it is read. Falls back to single provided frames where a chunk would wrap the ring (the T > 1 mask table is only
 // causal before the wrap, torch.h:170-223).
 extern "C" void moshi_hot_prefill(moshi_hot_model_t * m, const int32_t * tokens, int n_frames, int chunk) {
+    unstage_temporal(m);
     const moshi_hot_config & c = m->cfg;
     const int ncb = c.n_q + 1, CT = (int) m->cache.size();
     GGML_ASSERT(ncb - (c.personaplex ? 8 : c.dep_q) - 1 > 0 && !c.demux_second_stream && !c.cross_attention);
@@ -1641,7 +1669,7 @@ extern "C" void moshi_hot_force_last(moshi_hot_model_t * m, int32_t text_token, 
     m->cache[(size_t) wpos][0] = text_token;
     for (int q = 0; q < m->cfg.dep_q; q++) m->cache[(size_t) wpos][(size_t) (q + 1)] = audio_tokens[q];
 }
-extern "C" void moshi_hot_set_context_fill(moshi_hot_model_t * m, int64_t offset) { m->temporal.offset = (int) offset; }
+extern "C" void moshi_hot_set_context_fill(moshi_hot_model_t * m, int64_t offset) { unstage_temporal(m); m->temporal.offset = (int) offset; }
 
 extern "C" int moshi_hot_layer_probe(moshi_hot_model_t * m, int which, int layer, int weight_set, const float * x_in, int offset, float * x_out,
                                      moshi_hot_node_visitor_t visit, void * user) {

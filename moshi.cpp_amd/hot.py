@@ -18,7 +18,7 @@ class Config(C.Structure):
                                          "condition_sum", "dep_schedule_len")] + \
                [("dep_schedule", C.c_int32 * MAX_CB), ("update_scale", C.c_float),
                 ("dep_shard_rank", C.c_int32), ("dep_shard_world", C.c_int32), ("depth_only", C.c_int32),
-                ("tp_rank", C.c_int32), ("tp_world", C.c_int32), ("codec_stream", C.c_int32)]
+                ("tp_rank", C.c_int32), ("tp_world", C.c_int32), ("codec_stream", C.c_int32), ("chain_depth", C.c_int32)]
 
     @property
     def io_dep_q(self):

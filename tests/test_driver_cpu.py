@@ -43,6 +43,7 @@ def test_pipelined_frame_loop_equals_the_serial_loop_on_the_host_device():
     serial = [m.sts_frame(f) for f in frames]
     m.free()
     cfg.codec_stream = 1
+    cfg.chain_depth = 1           # the Depth graph reads the text token from the Temporal graph's sampler output; the next step's inputs are staged early
     m = hu.Model("oracle", cfg)
     piped = m.sts_pipeline(frames)
     m.free()
@@ -51,6 +52,19 @@ def test_pipelined_frame_loop_equals_the_serial_loop_on_the_host_device():
         assert a[:3] == b[:3]
         if a[0]:
             assert np.array_equal(a[3], b[3])
+    # a staged step is taken back by whatever else moves the Temporal stream position: chained steps, then a prefill, then steps again
+    cfg3 = hu.hot.tiny_personaplex(hu.L, layers=1)
+    prompt = [[int(rng.integers(0, cfg3.text_card))] + rng.integers(0, cfg3.card, cfg3.n_q).tolist() for _ in range(3)]
+    seqs = []
+    for ch in (0, 1):
+        cfg3.chain_depth = ch
+        m = hu.Model("oracle", cfg3)
+        o = [m.lm_step([1] * 8) for _ in range(2)]
+        m.prefill(prompt, 2)
+        o += [m.lm_step([2] * 8) for _ in range(3)]
+        seqs.append(o)
+        m.free()
+    assert seqs[0] == seqs[1]
 
 
 def test_codec_round_trip_runs_and_is_finite():

@@ -130,8 +130,8 @@ def test_sts_frames_match_oracle():
             assert hu.rel_err(a[3], b[3]) < PCM_TOL, f"frame {i}: pcm rel err {hu.rel_err(a[3], b[3]):.2e}"
 
 
-@pytest.mark.parametrize("streams", [1, 2])
-def test_pipelined_frame_loop_is_bit_identical_to_the_serial_loop(streams):
+@pytest.mark.parametrize("streams,chain", [(1, 0), (2, 0), (2, 1), (1, 1)])
+def test_pipelined_frame_loop_is_bit_identical_to_the_serial_loop(streams, chain):
     # moshi_hot_sts_pipeline_*: LM of frame k beside decode of k - 1 and encode of k + 1 (on a second command stream when codec_stream = 1).
     # Every graph consumes the same inputs and states in the same order, so tokens and PCM are the serial loop's, bit for bit.
     rng = np.random.default_rng(21)
@@ -142,6 +142,7 @@ def test_pipelined_frame_loop_is_bit_identical_to_the_serial_loop(streams):
     m.free()
     cfg2 = hu.hot.tiny(hu.L)
     cfg2.codec_stream = int(streams == 2)
+    cfg2.chain_depth = chain      # text token handed from the Temporal to the Depth graph on the device, next step's inputs staged behind the Depth graph
     m = hu.Model("hip", cfg2, seed=0)
     piped = m.sts_pipeline(frames)
     m.free()
