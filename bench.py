@@ -175,7 +175,7 @@ def main():
         cfg.temp, cfg.temp_text = 0.8, 0.7
     pipelined = not args.serial and args.shard == "none" and args.model in ("moshika", "personaplex")
     cfg.codec_stream = int(pipelined)
-    cfg.chain_depth = int(pipelined)
+    cfg.chain_depth = 2 if pipelined else 0      # run-ahead: the LM stream never waits for the host (include/moshi_hot.h)
     shard = None
     if args.shard == "depth":
         if args.model not in ("moshika", "personaplex"):
@@ -295,8 +295,9 @@ def main():
                                 .get(args.model, "moshi-sts --bench loop: mimi encode + Temporal step + %d Depth steps + mimi decode, ") % cfg.dep_q) +
                                "%s %s, 1 audio stream per GPU, %s, ctx capacity %d" % (args.model, args.quant, "sampled (temp 0.8 / 0.7, top-k 250 / 25)" if args.sampled else "greedy", cfg.context),
                    "context_fill_start": args.context_fill,
-                   "frame_loop": "software-pipelined over 2 HIP streams: LM step of frame k beside mimi decode of frame k-1 and mimi encode of frame k+1; same graphs, "
-                                 "inputs, states and outputs as the serial loop (--serial), one of each per step" if pipelined else "serial: encode -> LM -> decode of one frame per step",
+                   "frame_loop": "software-pipelined over 2 HIP streams with run-ahead: the LM step of frame k is queued behind the one of frame k-1 (sampled tokens reach "
+                                 "the next Temporal graph through device memory; the host reads them one step late), mimi decode of frame k-1 and mimi encode of frame k+1 "
+                                 "run beside it; same graphs, inputs, states and outputs as the serial loop (--serial), one LM step + one encode + one decode per step" if pipelined else "serial: encode -> LM -> decode of one frame per step",
                    "parallelism": ("Depth codebook shard: step k on rank k %% %d, replicated 8-slot ring, 1 + dep_q broadcasts per frame" % world) if shard is not None
                                   else "independent stream replica per GPU" if world > 1 else "1 GPU",
                    "device": dev_desc},
@@ -410,7 +411,7 @@ def main():
         def quick(make_cfg, fill=0, steps=40):
             c2 = make_cfg()
             c2.codec_stream = int(pipelined)
-            c2.chain_depth = int(pipelined)
+            c2.chain_depth = 2 if pipelined and not c2.personaplex else int(pipelined)
             mm = L.moshi_hot_create(be, C.byref(c2), 0)
             if fill:
                 L.moshi_hot_set_context_fill(mm, fill)

@@ -89,6 +89,15 @@ GGML_API bool    ggml_backend_buffer_is_host (ggml_backend_buffer_t buffer);
 // ---- data movement (src/context.h:308, 643) ------------------------------------------------------
 GGML_API void ggml_backend_tensor_set   (      struct ggml_tensor * tensor, const void * data, size_t offset, size_t size);
 GGML_API void ggml_backend_tensor_get   (const struct ggml_tensor * tensor,       void * data, size_t offset, size_t size);
+// upstream ggml's stream-ordered read-back and events (ggml-backend.h; the reference itself only uses the blocking calls): the copy is queued behind
+// the work already submitted to `backend`; `data` is filled once ggml_backend_synchronize(backend) or ggml_backend_event_synchronize of an event
+// recorded after it has returned. Used by the run-ahead frame loop (moshi_hot.h) to take a step's tokens without idling the stream.
+GGML_API void ggml_backend_tensor_get_async(ggml_backend_t backend, const struct ggml_tensor * tensor, void * data, size_t offset, size_t size);
+typedef struct ggml_backend_event * ggml_backend_event_t;
+GGML_API ggml_backend_event_t ggml_backend_event_new(ggml_backend_dev_t device);
+GGML_API void ggml_backend_event_free(ggml_backend_event_t event);
+GGML_API void ggml_backend_event_record(ggml_backend_event_t event, ggml_backend_t backend);
+GGML_API void ggml_backend_event_synchronize(ggml_backend_event_t event);
 GGML_API void ggml_backend_tensor_memset(      struct ggml_tensor * tensor, uint8_t value,     size_t offset, size_t size);
 GGML_API void ggml_backend_tensor_copy  (struct ggml_tensor * src, struct ggml_tensor * dst);
 
@@ -125,7 +134,8 @@ GGML_API void * ggml_backend_mi355x_get_stream(ggml_backend_t backend);
 // A second command stream on the same GPU: a backend handle with its own HIP stream, upload queue and plan cache. Graphs submitted through it run
 // concurrently with those of `base` (the codec of neighbouring frames beside the LM step, moshi_hot.h "software-pipelined frame loop"); buffers
 // allocated through either handle are ordinary device memory usable by both - ordering between the two streams is the caller's (host round trips
-// through ggml_backend_tensor_get / ggml_backend_synchronize). Returns NULL when `base` is not an MI355X backend. Free with ggml_backend_free.
+// through ggml_backend_tensor_get / ggml_backend_synchronize). It starts with the flags in force on `base`. Returns NULL when `base` is not an MI355X
+// backend. Free with ggml_backend_free.
 GGML_API ggml_backend_t ggml_backend_mi355x_init_stream(ggml_backend_t base);
 
 #ifdef __cplusplus

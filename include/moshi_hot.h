@@ -74,6 +74,9 @@ struct moshi_hot_config {
     // wait per LM step instead of two - and the next frame's Temporal step inputs (mask row, RoPE phase, ring slot: functions of the stream position
     // only) are queued behind the Depth graph. Same graphs otherwise, same tokens. Not with a text hook, a Depth hook, demux or delay_steps (the
     // reference's host code inspects the text token between the two graphs there, lm.h:880-921).
+    // 2: additionally the Temporal graph's embedding indices of the model's own codebooks are views of the same device-side token state, and
+    // moshi_hot_sts_pipeline_frame runs AHEAD: step k is queued before step k - 1's tokens have been read (moshika-shaped models only; anything else
+    // falls back to blocking steps behind the same calls).
     int32_t chain_depth;
 };
 
@@ -125,12 +128,14 @@ GGML_API int moshi_hot_sts_frame(moshi_hot_model_t * m, const float * pcm_in, in
 
 // The moshi-sts --bench loop software-pipelined (tools/moshi-sts.cpp:770-808 feeds every frame without waiting for playback): the LM step of
 // frame k runs on the backend's stream while the codec stream (config.codec_stream) decodes frame k - 1 and encodes frame k + 1. begin: encodes
-// frame 0. frame: pcm_next = input of frame k + 1 (NULL: none follows); returns bit 0 = text_token / audio_tokens of frame k are valid, bit 1 =
-// pcm_prev holds the output of frame k - 1. end: decodes the last frame (returns 1 if there was one). Tokens and PCM are bit-identical to
-// moshi_hot_sts_frame's: every graph consumes the same inputs and states in the same order, only on two streams.
+// frame 0. frame: pcm_next = input of frame k + 1 (NULL: none follows); returns bit 0 = text_token / audio_tokens are valid, bit 1 = pcm_prev holds
+// the output of frame k - 1, bit 2 = run-ahead (chain_depth = 2): the tokens are frame k - 1's too, because the LM step of frame k was queued behind
+// the previous one before the host looked at that one's tokens (they reach the next Temporal graph through device memory; the LM stream never waits
+// for the host). end: finishes what is outstanding: bit 0 = tokens of the last frame (run-ahead only), bit 1 = pcm_last is the last frame's output.
+// Tokens and PCM are bit-identical to moshi_hot_sts_frame's: every graph consumes the same inputs and states in the same order.
 GGML_API void moshi_hot_sts_pipeline_begin(moshi_hot_model_t * m, const float * pcm0);
 GGML_API int  moshi_hot_sts_pipeline_frame(moshi_hot_model_t * m, const float * pcm_next, int32_t * text_token, int32_t * audio_tokens, float * pcm_prev);
-GGML_API int  moshi_hot_sts_pipeline_end(moshi_hot_model_t * m, float * pcm_last);
+GGML_API int  moshi_hot_sts_pipeline_end(moshi_hot_model_t * m, int32_t * text_token, int32_t * audio_tokens, float * pcm_last);
 
 // introspection for tests / bench
 GGML_API int64_t moshi_hot_offset(moshi_hot_model_t * m);                      // frames stepped so far

@@ -135,6 +135,10 @@ SIGNATURES = {
     "ggml_backend_graph_compute": (I, [P, P]), "ggml_backend_supports_op": (B, [P, TP]),
     "ggml_backend_mi355x_get_stats": (None, [P, C.POINTER(Stats)]), "ggml_backend_mi355x_set_flags": (None, [P, I]), "ggml_backend_mi355x_set_capture": (None, [P, I]),
     "ggml_backend_mi355x_get_stream": (P, [P]),
+    "ggml_backend_mi355x_init_stream": (P, [P]),
+    "ggml_backend_tensor_get_async": (None, [P, TP, P, Z, Z]),
+    "ggml_backend_event_new": (P, [P]), "ggml_backend_event_free": (None, [P]), "ggml_backend_event_record": (None, [P, P]),
+    "ggml_backend_event_synchronize": (None, [P]),
     "ggml_backend_mi355x_get_kernel_profile": (None, [P, C.POINTER(KernelProfile)]),
     # ggml-cpu.h
     "ggml_backend_cpu_init": (P, []), "ggml_backend_is_cpu": (B, [P]), "ggml_backend_cpu_set_n_threads": (None, [P, I]),

@@ -86,6 +86,18 @@ extern "C" const char * ggml_backend_name(ggml_backend_t b) { return b->iface.ge
 extern "C" void ggml_backend_free(ggml_backend_t b) { if (b) b->iface.free(b); }
 extern "C" ggml_backend_dev_t ggml_backend_get_device(ggml_backend_t b) { return b->device; }
 extern "C" void ggml_backend_synchronize(ggml_backend_t b) { if (b->iface.synchronize) b->iface.synchronize(b); }
+extern "C" void ggml_backend_tensor_get_async(ggml_backend_t b, const struct ggml_tensor * tensor, void * data, size_t offset, size_t size) {
+    if (b->iface.get_tensor_async) b->iface.get_tensor_async(b, tensor, data, offset, size);
+    else ggml_backend_tensor_get(tensor, data, offset, size);     // a backend without streams: done on return
+}
+extern "C" ggml_backend_event_t ggml_backend_event_new(ggml_backend_dev_t device) {
+    ggml_backend_event * e = new ggml_backend_event;
+    e->device = device; e->context = NULL; e->synchronize = NULL; e->free_context = NULL;
+    return e;
+}
+extern "C" void ggml_backend_event_free(ggml_backend_event_t e) { if (!e) return; if (e->free_context) e->free_context(e); delete e; }
+extern "C" void ggml_backend_event_record(ggml_backend_event_t e, ggml_backend_t b) { if (b->iface.event_record) b->iface.event_record(b, e); }
+extern "C" void ggml_backend_event_synchronize(ggml_backend_event_t e) { if (e->synchronize) e->synchronize(e); }
 extern "C" bool ggml_backend_supports_op(ggml_backend_t b, const struct ggml_tensor * op) {
     return b->iface.supports_op ? b->iface.supports_op(b, op) : false;
 }

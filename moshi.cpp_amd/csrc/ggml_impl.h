@@ -49,6 +49,16 @@ struct ggml_backend_i {
     ggml_backend_buffer_t (*alloc_buffer)(ggml_backend_t backend, size_t size);
     enum ggml_status (*graph_compute)(ggml_backend_t backend, struct ggml_cgraph * cgraph);
     bool (*supports_op)(ggml_backend_t backend, const struct ggml_tensor * op);
+    // optional (NULL: blocking fall-backs): stream-ordered read-back completed by synchronize / an event recorded after it
+    void (*get_tensor_async)(ggml_backend_t backend, const struct ggml_tensor * t, void * data, size_t offset, size_t size);
+    void (*event_record)(ggml_backend_t backend, ggml_backend_event_t event);
+};
+
+struct ggml_backend_event {
+    ggml_backend_dev_t device;
+    void * context;                                       // backend private, created at the first record
+    void (*synchronize)(ggml_backend_event_t event);      // set by the backend that recorded it (NULL: nothing pending)
+    void (*free_context)(ggml_backend_event_t event);
 };
 
 struct ggml_backend {

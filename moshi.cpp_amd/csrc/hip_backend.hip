@@ -21,6 +21,7 @@
 
 #include <algorithm>
 #include <functional>
+#include <deque>
 #include <map>
 #include <memory>
 #include <string>
@@ -34,6 +35,8 @@
 #define UPLOAD_BLOB_BYTES  (64 * 1024)
 #define UPLOAD_MAX_DESCS   1024
 #define READBACK_PINNED_BYTES (64 * 1024)
+#define AGET_SLOTS 64
+#define AGET_SLOT_BYTES 256
 #define UPLOAD_SMALL_MAX   16384   // the 7.7 KB PCM frame rides the batched path too (a pageable hipMemcpy + sync otherwise)
 
 struct plan_t;
@@ -69,6 +72,12 @@ struct hip_ctx {
     volatile unsigned * err_host = nullptr;
     unsigned * err_dev = nullptr;
     char * readback = nullptr;   // pinned staging for small device -> host reads
+    // stream-ordered small read-backs (ggml_backend_tensor_get_async): staged in pinned slots, handed to the caller's memory by the synchronize / event
+    // wait that covers them
+    struct async_get { void * dst; size_t size; int slot; uint64_t seq; };
+    char * aget_pinned = nullptr;
+    std::deque<async_get> aget_pending;
+    uint64_t aget_seq = 0;
     bool in_use = false;         // stream contexts only: handed out by ggml_backend_mi355x_init_stream, returned by ggml_backend_free
     ggml_backend_device dev_obj;
 };
@@ -90,6 +99,7 @@ static void ctx_init_lazy(hip_ctx * c) {
         HIP_CHECK(hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
     }
     HIP_CHECK(hipHostMalloc((void **) &c->readback, READBACK_PINNED_BYTES, hipHostMallocDefault));
+    HIP_CHECK(hipHostMalloc((void **) &c->aget_pinned, AGET_SLOTS * AGET_SLOT_BYTES, hipHostMallocDefault));
     HIP_CHECK(hipHostMalloc((void **) &c->err_host, 64, hipHostMallocMapped));
     c->err_host[0] = 0u;
     HIP_CHECK(hipHostGetDevicePointer((void **) &c->err_dev, (void *) c->err_host, 0));
@@ -190,6 +200,15 @@ static void queue_upload(hip_ctx * c, void * dst, const void * src, size_t size)
 // ---------------------------------------------------------------------------------------------------
 struct hip_buffer_ctx { hip_ctx * c; size_t actual; };
 
+// the stream has reached (at least) read-back `upto`: copy the staged bytes to where the callers asked for them
+static void deliver_async_gets(hip_ctx * c, uint64_t upto) {
+    while (!c->aget_pending.empty() && c->aget_pending.front().seq <= upto) {
+        const hip_ctx::async_get & g = c->aget_pending.front();
+        memcpy(g.dst, c->aget_pinned + (size_t) g.slot * AGET_SLOT_BYTES, g.size);
+        c->aget_pending.pop_front();
+    }
+}
+
 static void evict_plans_of_buffer(hip_ctx * c, const ggml_backend_buffer * b);
 
 static void hip_buf_free(ggml_backend_buffer_t b) {
@@ -225,6 +244,7 @@ static void hip_buf_get(ggml_backend_buffer_t b, const struct ggml_tensor * t, v
         HIP_CHECK(hipMemcpyAsync(data, (const char *) t->data + offset, size, hipMemcpyDeviceToHost, c->stream));
         HIP_CHECK(hipStreamSynchronize(c->stream));
     }
+    deliver_async_gets(c, c->aget_seq);
     check_device_error(c);
 }
 static void hip_buf_memset(ggml_backend_buffer_t b, struct ggml_tensor * t, uint8_t v, size_t offset, size_t size) {
@@ -1793,6 +1813,43 @@ static void hip_backend_sync(ggml_backend_t b) {
     set_device(c);
     flush_uploads(c);
     HIP_CHECK(hipStreamSynchronize(c->stream));
+    deliver_async_gets(c, c->aget_seq);
+}
+// ggml_backend_tensor_get_async: a copy queued behind the submitted work into a pinned slot; larger reads take the blocking path
+static void hip_get_tensor_async(ggml_backend_t b, const struct ggml_tensor * t, void * data, size_t offset, size_t size) {
+    hip_ctx * c = (hip_ctx *) b->context;
+    if (size > AGET_SLOT_BYTES) { ggml_backend_tensor_get(t, data, offset, size); return; }
+    ctx_init_lazy(c);
+    set_device(c);
+    flush_uploads(c);
+    if (c->aget_pending.size() >= AGET_SLOTS) { HIP_CHECK(hipStreamSynchronize(c->stream)); deliver_async_gets(c, c->aget_seq); }
+    const uint64_t seq = ++c->aget_seq;
+    const int slot = (int) (seq % AGET_SLOTS);
+    HIP_CHECK(hipMemcpyAsync(c->aget_pinned + (size_t) slot * AGET_SLOT_BYTES, (const char *) t->data + offset, size, hipMemcpyDeviceToHost, c->stream));
+    c->aget_pending.push_back({ data, size, slot, seq });
+}
+struct hip_event_ctx { hipEvent_t ev; hip_ctx * c; uint64_t seq; };
+static void hip_event_sync(ggml_backend_event_t e) {
+    hip_event_ctx * h = (hip_event_ctx *) e->context;
+    set_device(h->c);
+    HIP_CHECK(hipEventSynchronize(h->ev));
+    deliver_async_gets(h->c, h->seq);
+    check_device_error(h->c);
+}
+static void hip_event_free(ggml_backend_event_t e) { hip_event_ctx * h = (hip_event_ctx *) e->context; if (h) { (void) hipEventDestroy(h->ev); delete h; } e->context = NULL; }
+static void hip_event_record(ggml_backend_t b, ggml_backend_event_t e) {
+    hip_ctx * c = (hip_ctx *) b->context;
+    ctx_init_lazy(c);
+    set_device(c);
+    hip_event_ctx * h = (hip_event_ctx *) e->context;
+    if (!h) {
+        h = new hip_event_ctx;
+        HIP_CHECK(hipEventCreateWithFlags(&h->ev, hipEventDisableTiming));
+        e->context = h; e->synchronize = hip_event_sync; e->free_context = hip_event_free;
+    }
+    flush_uploads(c);
+    h->c = c; h->seq = c->aget_seq;
+    HIP_CHECK(hipEventRecord(h->ev, c->stream));
 }
 static bool hip_supports_op(ggml_backend_t, const struct ggml_tensor * op) {
     switch (op->op) {
@@ -1826,7 +1883,7 @@ static ggml_backend_t hip_dev_init(ggml_backend_dev_t d, const char *) {
     if (c->flags != 0) { HIP_CHECK(hipStreamSynchronize(c->stream)); for (auto & kv : c->plans) plan_free(c, kv.second); c->plans.clear(); c->flags = 0; }
     c->stats = {};
     auto * b = new ggml_backend;
-    b->iface = { hip_backend_name, hip_backend_free, hip_backend_sync, hip_alloc_buffer, hip_graph_compute, hip_supports_op };
+    b->iface = { hip_backend_name, hip_backend_free, hip_backend_sync, hip_alloc_buffer, hip_graph_compute, hip_supports_op, hip_get_tensor_async, hip_event_record };
     b->device = d;
     b->context = c;
     return b;
@@ -1897,5 +1954,8 @@ extern "C" ggml_backend_t ggml_backend_mi355x_init_stream(ggml_backend_t base) {
         stream_contexts().push_back(c);
     }
     c->in_use = true;
-    return c->dev_obj.iface.init_backend(&c->dev_obj, NULL);
+    ggml_backend_t b = c->dev_obj.iface.init_backend(&c->dev_obj, NULL);
+    c->flags = b0->flags;             // the debug flags in force on `base` (no fusion / no hipGraph / ...) apply to its sibling stream too
+    c->no_capture = b0->no_capture;
+    return b;
 }

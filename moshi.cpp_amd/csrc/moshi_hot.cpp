@@ -13,6 +13,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <deque>
 #include <functional>
 #include <map>
 #include <string>
@@ -662,7 +663,15 @@ struct moshi_hot_model {
     T emb_right_idx = nullptr, emb_right_scale = nullptr, dep_right_idx = nullptr, dep_right_scale = nullptr;
     moshi_hot_text_hook_t text_hook = nullptr; void * text_hook_user = nullptr;
     T transformer_out = nullptr;   // state F32[dim] (lm.h:434)
-    T text_state = nullptr;        // chain_depth: state I32[1], the sampled text token handed from the Temporal to the Depth graph the way transformer_out is
+    // chain_depth: state I32[1 + dep_q] = the tokens sampled by the last step (text, then the Depth chain's), handed between the graphs on the device the way
+    // transformer_out is: the Depth graph takes its text index from [0] and samples into [1..]; the Temporal graph's embedding indices of those codebooks
+    // are views of it, so the next step can be queued before the host has seen the tokens (run-ahead)
+    T tok_state = nullptr;
+    // run-ahead (chain_depth = 2): steps queued but not yet completed on the host, oldest first
+    struct InFlight { bool done = false; int ok = 0; std::vector<int32_t> raw; int32_t out_text = 0; std::vector<int32_t> out_audio; ggml_backend_event_t ev = nullptr; };
+    std::deque<InFlight> inflight;
+    std::vector<ggml_backend_event_t> ev_pool;
+    int tok_state_for = -1;        // the step whose model-side inputs tok_state holds (the samples of step tok_state_for - 1), -1: unknown (provided / forced frames)
     Builder * g_temporal = nullptr; std::vector<T> emb_idx, emb_scale; T sampler_out = nullptr, text_logits = nullptr, g_transformer_out = nullptr, g_transformer_in = nullptr, g_stack_out = nullptr;
     Builder * g_depth = nullptr; T dep_text_idx = nullptr, dep_text_scale = nullptr, dep_tokens = nullptr; std::vector<T> dep_logits;
     // Depth codebook shard (moshi_hot.h): per-step graphs, import graphs, the two messages, the device-side token vector
@@ -801,7 +810,8 @@ void build_temporal_graph(moshi_hot_model * m) {
     m->g_temporal = new Builder(m->be, 256);
     Builder & g = *m->g_temporal;
     auto embed = [&](T table) {   // moshi_scaled_embedding_build (lm_utils.h:157-170)
-        T idx = g.tensor(GGML_TYPE_I32, 1), scale = g.tensor(GGML_TYPE_F32, 1);
+        const int i = (int) m->emb_idx.size();
+        T idx = m->tok_state && i <= c.dep_q ? ggml_view_1d(g, m->tok_state, 1, (size_t) i * 4) : g.tensor(GGML_TYPE_I32, 1), scale = g.tensor(GGML_TYPE_F32, 1);
         m->emb_idx.push_back(idx); m->emb_scale.push_back(scale);
         return ggml_mul(g, ggml_get_rows(g, table, idx), scale);
     };
@@ -825,7 +835,7 @@ void build_temporal_graph(moshi_hot_model * m) {
     g.expand(ggml_cpy(g, x, m->transformer_out));
     m->sampler_out = sample_token(g, m->text_logits, c.temp_text, c.top_k_text);
     g.expand(m->sampler_out);
-    if (m->text_state) g.expand(ggml_cpy(g, ggml_reshape_1d(g, m->sampler_out, 1), m->text_state));
+    if (m->tok_state) g.expand(ggml_cpy(g, ggml_reshape_1d(g, m->sampler_out, 1), ggml_view_1d(g, m->tok_state, 1, 0)));
     g.alloc();
 }
 
@@ -837,8 +847,8 @@ void build_depth_graph(moshi_hot_model * m) {
     m->dep_text_idx = g.tensor(GGML_TYPE_I32, 1);
     if (c.chain_depth) {
         // the text token is taken from the state tensor the Temporal graph copies its sample into: no host round trip between the graphs
-        GGML_ASSERT(!c.demux_second_stream && !c.delay_steps && m->text_state && m->sampler_out->type == GGML_TYPE_I32 && ggml_nelements(m->sampler_out) == 1);
-        m->dep_text_idx = m->text_state;
+        GGML_ASSERT(!c.demux_second_stream && !c.delay_steps && m->tok_state && m->sampler_out->type == GGML_TYPE_I32 && ggml_nelements(m->sampler_out) == 1);
+        m->dep_text_idx = ggml_view_1d(g, m->tok_state, 1, 0);
     }
     T last;
     if (c.demux_second_stream) {
@@ -851,7 +861,7 @@ void build_depth_graph(moshi_hot_model * m) {
         last = ggml_mul(g, ggml_get_rows(g, m->depformer_text_emb, m->dep_text_idx), m->dep_text_scale);
         if (m->dep_text_low_rank) last = linear(g, m->dep_text_low_rank, last);
     }
-    T tokens = g.tensor(GGML_TYPE_I32, c.dep_q);
+    T tokens = m->tok_state ? ggml_view_1d(g, m->tok_state, c.dep_q, 4) : g.tensor(GGML_TYPE_I32, c.dep_q);
     T view = nullptr, next = nullptr;
     for (int k = 0; k < c.dep_q; k++) {
         if (k > 0) {   // moshi_scaled_embedding_chained (lm_utils.h:208-217)
@@ -1038,7 +1048,7 @@ extern "C" moshi_hot_model_t * moshi_hot_create(ggml_backend_t backend, const st
         m->text_linear = W.add("lm.text_linear.weight", lt, c.dim, c.text_card, 1, qgen(1.f / sqrtf((float) c.dim)));
         }
         m->transformer_out = state(m, GGML_TYPE_F32, c.dim);
-        if (c.chain_depth) m->text_state = state(m, GGML_TYPE_I32, 1);
+        if (c.chain_depth) m->tok_state = state(m, GGML_TYPE_I32, 1 + c.dep_q);
         if (c.condition_sum) m->cond_sum = state(m, GGML_TYPE_F32, c.dim);
         if (c.cross_attention) m->cond_cross = state(m, GGML_TYPE_F32, c.dim, c.cross_len);
         for (int k = 0; k < c.extra_heads; k++)
@@ -1130,6 +1140,9 @@ extern "C" moshi_hot_model_t * moshi_hot_create(ggml_backend_t backend, const st
 
 extern "C" void moshi_hot_free(moshi_hot_model_t * m) {
     if (!m) return;
+    ggml_backend_synchronize(m->be);
+    for (auto & f : m->inflight) if (f.ev) ggml_backend_event_free(f.ev);
+    for (auto e : m->ev_pool) ggml_backend_event_free(e);
     if (m->own_codec_be) ggml_backend_synchronize(m->be_codec);
     delete m->g_temporal; delete m->g_depth; delete m->g_dec; delete m->g_enc; if (m->scratch_codec != m->scratch) delete m->scratch_codec; delete m->scratch; delete m->g_shard_begin;
     for (auto * b : m->g_shard_step) delete b;
@@ -1370,6 +1383,40 @@ extern "C" void moshi_hot_depth_shard_import(moshi_hot_model_t * m, int k) {
 extern "C" void moshi_hot_depth_shard_tokens(moshi_hot_model_t * m, int32_t * out, int n) { ggml_backend_tensor_get(m->shard_tokens, out, 0, (size_t) n * 4); }
 extern "C" void moshi_hot_set_depth_hook(moshi_hot_model_t * m, moshi_hot_depth_hook_t fn, void * user) { m->depth_hook = fn; m->depth_hook_user = user; }
 
+namespace {
+// the half of moshi_lmgen_step that follows the sampling (lm.h:930-979): ring write, stream position, delayed read-out
+int lm_finish(moshi_hot_model * m, int32_t text_token, std::vector<int32_t> audio, bool provided, bool replace, int32_t * text_token_out, int32_t * out_audio, float * vad) {
+    const moshi_hot_config & c = m->cfg;
+    const int CT = (int) m->cache.size();
+    const int dep_q = c.personaplex ? 8 : c.dep_q, dep_q_1 = dep_q + 1;
+    m->last_text = text_token; m->last_audio = audio;
+    m->offset++;
+    if (!provided) {                      // lm.h:935-943
+        const int wpos = m->offset % CT;
+        m->cache[(size_t) wpos][0] = text_token;
+        for (int q = 0; q < c.dep_q; q++) m->cache[(size_t) wpos][(size_t) (q + 1)] = audio[(size_t) q];
+    }
+    if (m->offset <= m->max_delay || replace) return 0;       // lm.h:950
+    int idx = (m->offset - m->max_delay + c.delays[0]) % CT;   // lm.h:954-959
+    *text_token_out = m->cache[(size_t) idx][0];
+    for (int i = 1; i < dep_q_1; i++) {
+        idx = (m->offset - m->max_delay + c.delays[i]) % CT;
+        audio[(size_t) (i - 1)] = m->cache[(size_t) idx][(size_t) i];
+    }
+    for (int i = 0; i < dep_q; i++) out_audio[i] = audio[(size_t) i];
+    for (int32_t x : audio) if (x == -1) return 0;             // all lm->dep_q entries, the tail holding this frame's raw samples (lm.h:961-964)
+    if (vad) {                                                 // lm.h:966-976
+        if (m->extra_heads.size() > 2) {
+            Builder & s = *m->scratch;
+            T sm = ggml_soft_max(s, linear(s, m->extra_heads[2], m->transformer_out));
+            s.expand_read(ggml_view_1d(s, sm, 1, 0), vad);
+            s.compute_scratch();
+        } else *vad = 0.f;
+    }
+    return 1;
+}
+}  // namespace
+
 extern "C" int moshi_hot_lm_step_n(moshi_hot_model_t * m, const int32_t * tokens, int n_tokens, int32_t * text_token_out, int32_t * out_audio, float * vad) {
     const moshi_hot_config & c = m->cfg;
     const int ncb = c.n_q + 1, CT = (int) m->cache.size();
@@ -1427,32 +1474,87 @@ extern "C" int moshi_hot_lm_step_n(moshi_hot_model_t * m, const int32_t * tokens
         if (c.delay_steps)                             // on_audio_hook (lm.h:915-921)
             for (int q = 0; q < c.dep_q; q++) if (m->offset < c.delays[q + 1] + c.delay_steps) audio[(size_t) q] = -1;
     }
-    m->last_text = text_token; m->last_audio = audio;
-    m->offset++;
-    if (!provided) {                      // lm.h:935-943
-        const int wpos = m->offset % CT;
-        m->cache[(size_t) wpos][0] = text_token;
-        for (int q = 0; q < c.dep_q; q++) m->cache[(size_t) wpos][(size_t) (q + 1)] = audio[(size_t) q];
-    }
-    if (m->offset <= m->max_delay || replace) return 0;       // lm.h:950
-    int idx = (m->offset - m->max_delay + c.delays[0]) % CT;   // lm.h:954-959
-    *text_token_out = m->cache[(size_t) idx][0];
-    for (int i = 1; i < dep_q_1; i++) {
-        idx = (m->offset - m->max_delay + c.delays[i]) % CT;
-        audio[(size_t) (i - 1)] = m->cache[(size_t) idx][(size_t) i];
-    }
-    for (int i = 0; i < dep_q; i++) out_audio[i] = audio[(size_t) i];
-    for (int32_t x : audio) if (x == -1) return 0;             // all lm->dep_q entries, the tail holding this frame's raw samples (lm.h:961-964)
-    if (vad) {                                                 // lm.h:966-976
-        if (m->extra_heads.size() > 2) {
-            Builder & s = *m->scratch;
-            T sm = ggml_soft_max(s, linear(s, m->extra_heads[2], m->transformer_out));
-            s.expand_read(ggml_view_1d(s, sm, 1, 0), vad);
-            s.compute_scratch();
-        } else *vad = 0.f;
-    }
-    return 1;
+    m->tok_state_for = provided ? -1 : m->offset + 1;
+    return lm_finish(m, text_token, audio, provided, replace, text_token_out, out_audio, vad);
 }
+
+// ---- run-ahead (chain_depth = 2) ---------------------------------------------------------------------------------------------------------------
+// A step's model-side inputs (the text and Depth tokens of the previous step) reach the Temporal graph through tok_state in device memory, so step q can
+// be QUEUED - other speaker's codes uploaded, Temporal graph, Depth graph, the next step's mask row / RoPE phase / ring slot, a stream-ordered read of the
+// token state, an event - while step q - 1 is still running; lm_complete then waits for the oldest event and does the host half (delay ring, read-out)
+// exactly as moshi_lmgen_step orders it. The stream never waits for the host. Steps that cannot run ahead (the first max-delay frames whose inputs are
+// the initial tokens, anything after provided / forced tokens, timing mode, hooks, PersonaPlex whose user columns are rewritten from the samples) are
+// stepped synchronously through moshi_hot_lm_step_n and parked in the same queue, so callers see one protocol.
+namespace {
+bool run_ahead_config(const moshi_hot_model * m) {
+    const moshi_hot_config & c = m->cfg;
+    return c.chain_depth == 2 && m->tok_state && !c.personaplex && c.dep_q > 0 && !c.demux_second_stream && !c.delay_steps && !c.extra_heads &&
+           !m->text_hook && !m->depth_hook && c.dep_shard_world <= 1;
+}
+ggml_backend_event_t take_event(moshi_hot_model * m) {
+    if (!m->ev_pool.empty()) { ggml_backend_event_t e = m->ev_pool.back(); m->ev_pool.pop_back(); return e; }
+    return ggml_backend_event_new(ggml_backend_get_device(m->be));
+}
+void lm_finish_entry(moshi_hot_model * m, moshi_hot_model::InFlight & f) {
+    if (f.done) return;
+    ggml_backend_event_synchronize(f.ev);
+    m->ev_pool.push_back(f.ev); f.ev = nullptr;
+    std::vector<int32_t> audio(f.raw.begin() + 1, f.raw.end());
+    f.ok = lm_finish(m, f.raw[0], audio, false, false, &f.out_text, f.out_audio.data(), nullptr);
+    f.done = true;
+}
+void lm_queue(moshi_hot_model * m, const int32_t * user_codes) {
+    const moshi_hot_config & c = m->cfg;
+    const int ncb = c.n_q + 1, CT = (int) m->cache.size(), dep_q_1 = c.dep_q + 1, needed = ncb - dep_q_1;
+    int q = m->offset;                                   // this step's stream position: completed steps + those still running
+    for (auto & o : m->inflight) if (!o.done) q++;
+    bool steady = run_ahead_config(m) && !m->timing && m->g_temporal && m->g_depth && m->tok_state_for == q;
+    for (int i = 0; steady && i <= c.dep_q; i++) if (q <= c.delays[i]) steady = false;   // an initial token is still due on a model column
+    m->inflight.emplace_back();
+    moshi_hot_model::InFlight & f = m->inflight.back();
+    f.out_audio.assign((size_t) c.dep_q + 8, 0);
+    if (!steady) {
+        for (auto & o : m->inflight) if (&o != &f) lm_finish_entry(m, o);   // older steps complete first: the blocking step needs the stream position they leave
+        f.ok = moshi_hot_lm_step_n(m, user_codes, needed, &f.out_text, f.out_audio.data(), nullptr);
+        f.done = true;
+        return;
+    }
+    // other speaker's codes enter the delay ring at step q (lm.h:819-824); their columns of the input row go up from the host as ever
+    for (int i = 0; i < needed; i++) m->cache[(size_t) ((q + c.delays[dep_q_1 + i]) % CT)][(size_t) (dep_q_1 + i)] = user_codes[i];
+    const int pos = q % CT;
+    for (int i = dep_q_1; i < ncb; i++) {
+        int32_t id = q <= c.delays[i] ? m->initial[(size_t) i] : m->cache[(size_t) pos][(size_t) i];
+        const float sc = id == -1 ? 0.f : 1.f;
+        if (id < 0) id = 0;
+        ggml_backend_tensor_set(m->emb_idx[(size_t) i], &id, 0, 4);
+        ggml_backend_tensor_set(m->emb_scale[(size_t) i], &sc, 0, 4);
+    }
+    { const float one = 1.f; for (int i = 0; i <= c.dep_q; i++) ggml_backend_tensor_set(m->emb_scale[(size_t) i], &one, 0, 4); }   // sampled ids are never -1
+    if (m->temporal_staged) m->temporal_staged = false;
+    else { transformer_graph_step(*m->scratch, m->temporal, 1); m->scratch->compute_scratch(); }
+    m->g_temporal->compute();
+    if (m->after_temporal_launch) { m->after_temporal_launch(); m->after_temporal_launch = nullptr; }
+    { const float one = 1.f; ggml_backend_tensor_set(m->dep_text_scale, &one, 0, 4); }
+    m->g_depth->compute();                      // text index: tok_state[0] on the device
+    transformer_graph_step(*m->scratch, m->temporal, 1);
+    m->scratch->compute_scratch();
+    m->temporal_staged = true;
+    f.raw.assign((size_t) c.dep_q + 1, 0);
+    f.ev = take_event(m);
+    ggml_backend_tensor_get_async(m->be, m->tok_state, f.raw.data(), 0, f.raw.size() * 4);
+    ggml_backend_event_record(f.ev, m->be);
+    m->tok_state_for = q + 1;
+}
+int lm_complete(moshi_hot_model * m, int32_t * text_token, int32_t * out_audio) {
+    GGML_ASSERT(!m->inflight.empty());
+    moshi_hot_model::InFlight & f = m->inflight.front();
+    lm_finish_entry(m, f);
+    const int ok = f.ok;
+    if (ok) { *text_token = f.out_text; memcpy(out_audio, f.out_audio.data(), (size_t) (m->cfg.personaplex ? 8 : m->cfg.dep_q) * sizeof(int32_t)); }
+    m->inflight.pop_front();
+    return ok;
+}
+}  // namespace
 
 extern "C" int moshi_hot_lm_step(moshi_hot_model_t * m, const int32_t * in_audio, int32_t * text_token_out, int32_t * out_audio) {
     const int io_dep_q = m->cfg.personaplex ? 8 : m->cfg.dep_q;
@@ -1461,6 +1563,7 @@ extern "C" int moshi_hot_lm_step(moshi_hot_model_t * m, const int32_t * in_audio
 
 extern "C" void moshi_hot_lm_step_embedding(moshi_hot_model_t * m, const float * embedding) {
     unstage_temporal(m);
+    m->tok_state_for = -1;
     const moshi_hot_config & c = m->cfg;
     Builder & s = *m->scratch;
     int32_t sampled = 0;
@@ -1509,6 +1612,7 @@ extern "C" void moshi_hot_set_text_hook(moshi_hot_model_t * m, moshi_hot_text_ho
 // causal before the wrap, torch.h:170-223).
 extern "C" void moshi_hot_prefill(moshi_hot_model_t * m, const int32_t * tokens, int n_frames, int chunk) {
     unstage_temporal(m);
+    m->tok_state_for = -1;
     const moshi_hot_config & c = m->cfg;
     const int ncb = c.n_q + 1, CT = (int) m->cache.size();
     GGML_ASSERT(ncb - (c.personaplex ? 8 : c.dep_q) - 1 > 0 && !c.demux_second_stream && !c.cross_attention);
@@ -1614,6 +1718,19 @@ extern "C" void moshi_hot_sts_pipeline_begin(moshi_hot_model_t * m, const float 
 }
 extern "C" int moshi_hot_sts_pipeline_frame(moshi_hot_model_t * m, const float * pcm_next, int32_t * text_token, int32_t * audio_tokens, float * pcm_prev) {
     GGML_ASSERT(m->pipe_have_codes && "moshi_hot_sts_pipeline_begin first");
+    if (m->cfg.chain_depth == 2 && m->tok_state) {
+        // run-ahead: the LM step of frame k is queued behind the one of frame k - 1 before that one's tokens are looked at; the tokens (and, as
+        // ever, the PCM) this call hands back are frame k - 1's
+        lm_queue(m, m->pipe_codes.data());                                              // frame k
+        const bool have_prev = m->inflight.size() > 1;
+        const int ok = have_prev ? lm_complete(m, text_token, audio_tokens) : 0;       // frame k - 1
+        if (ok) mimi_decode_launch(m, audio_tokens);
+        if (pcm_next) mimi_encode_launch(m, pcm_next);                                  // frame k + 1
+        if (ok) mimi_decode_finish(m, pcm_prev);
+        if (pcm_next) mimi_encode_finish(m, m->pipe_codes.data());
+        m->pipe_have_codes = pcm_next != nullptr;
+        return (ok ? 3 : 0) | 4;
+    }
     const bool dec = m->pipe_have_tokens;
     // the LM stream is the critical path: its Temporal graph is queued first, the codec launches follow while it runs
     m->after_temporal_launch = [m, dec, pcm_next]() {
@@ -1628,11 +1745,19 @@ extern "C" int moshi_hot_sts_pipeline_frame(moshi_hot_model_t * m, const float *
     if (ok) memcpy(m->pipe_tokens.data(), audio_tokens, (size_t) (m->cfg.personaplex ? 8 : m->cfg.dep_q) * sizeof(int32_t));
     return (ok ? 1 : 0) | (dec ? 2 : 0);
 }
-extern "C" int moshi_hot_sts_pipeline_end(moshi_hot_model_t * m, float * pcm_last) {
+extern "C" int moshi_hot_sts_pipeline_end(moshi_hot_model_t * m, int32_t * text_token, int32_t * audio_tokens, float * pcm_last) {
+    if (m->cfg.chain_depth == 2 && m->tok_state) {
+        int r = 0;
+        while (!m->inflight.empty()) {           // at most one step is outstanding
+            const int ok = lm_complete(m, text_token, audio_tokens);
+            if (ok) { moshi_hot_mimi_decode(m, audio_tokens, pcm_last); r = 3; }
+        }
+        return r;
+    }
     if (!m->pipe_have_tokens) return 0;
     moshi_hot_mimi_decode(m, m->pipe_tokens.data(), pcm_last);
     m->pipe_have_tokens = false;
-    return 1;
+    return 2;
 }
 
 extern "C" int64_t moshi_hot_offset(moshi_hot_model_t * m) { return m->offset; }
@@ -1668,6 +1793,7 @@ extern "C" void moshi_hot_force_last(moshi_hot_model_t * m, int32_t text_token, 
     const int wpos = m->offset % (int) m->cache.size();
     m->cache[(size_t) wpos][0] = text_token;
     for (int q = 0; q < m->cfg.dep_q; q++) m->cache[(size_t) wpos][(size_t) (q + 1)] = audio_tokens[q];
+    m->tok_state_for = -1;   // the device-side token state still holds the model's own samples
 }
 extern "C" void moshi_hot_set_context_fill(moshi_hot_model_t * m, int64_t offset) { unstage_temporal(m); m->temporal.offset = (int) offset; }
 

@@ -44,20 +44,28 @@ class Model:
     def sts_pipeline(self, frames):
         """the software-pipelined loop over `frames` (moshi_hot_sts_pipeline_*): -> per frame (produced, text, audio tokens, pcm) like sts_frame"""
         frames = [np.ascontiguousarray(f, np.float32) for f in frames]
-        res = []
+        res = [[0, -7, [0] * self.cfg.dep_q] for _ in frames]
         pcm_of = {}
         L.moshi_hot_sts_pipeline_begin(self.m, frames[0].ctypes.data)
+        lag = 0
         for k in range(len(frames)):
             txt = C.c_int32(-7)
             aud = (C.c_int32 * 32)()
             prev = np.zeros(1920, np.float32)
             nxt = frames[k + 1].ctypes.data if k + 1 < len(frames) else None
             r = L.moshi_hot_sts_pipeline_frame(self.m, nxt, C.byref(txt), aud, prev.ctypes.data)
+            lag = 1 if r & 4 else 0          # run-ahead: the tokens are frame k - 1's
             if r & 2:
                 pcm_of[k - 1] = prev
-            res.append([r & 1, txt.value, list(aud)[:self.cfg.dep_q]])
+            if k - lag >= 0 and (r & 1 or not lag):
+                res[k - lag] = [r & 1, txt.value, list(aud)[:self.cfg.dep_q]]
         last = np.zeros(1920, np.float32)
-        if L.moshi_hot_sts_pipeline_end(self.m, last.ctypes.data):
+        txt = C.c_int32(-7)
+        aud = (C.c_int32 * 32)()
+        r = L.moshi_hot_sts_pipeline_end(self.m, C.byref(txt), aud, last.ctypes.data)
+        if r & 1:
+            res[len(frames) - 1] = [1, txt.value, list(aud)[:self.cfg.dep_q]]
+        if r & 2:
             pcm_of[len(frames) - 1] = last
         return [tuple(r) + (pcm_of.get(k, np.zeros(1920, np.float32)),) for k, r in enumerate(res)]
 

@@ -33,17 +33,20 @@ def test_driver_is_deterministic_in_seed():
     assert runs[0] == runs[1] and runs[0] != runs[2]
 
 
-def test_pipelined_frame_loop_equals_the_serial_loop_on_the_host_device():
+@pytest.mark.parametrize("chain", [0, 1, 2])
+def test_pipelined_frame_loop_equals_the_serial_loop_on_the_host_device(chain):
     # moshi_hot_sts_pipeline_* (include/moshi_hot.h): call k steps the LM on frame k, decodes frame k - 1 and encodes frame k + 1. On the host device
     # there is one stream (codec_stream is ignored), which pins the protocol itself: outputs arrive one call later, nothing else changes.
+    # chain 1: the Depth graph reads the text token from the device-side token state, the next step's inputs are staged early.
+    # chain 2: run-ahead - the Temporal graph takes the previous step's samples from that state too, step k is queued before step k - 1 is read.
     rng = np.random.default_rng(3)
-    frames = [rng.standard_normal(1920).astype(np.float32) * 0.1 for _ in range(6)]
+    frames = [rng.standard_normal(1920).astype(np.float32) * 0.1 for _ in range(8)]
     cfg = hu.hot.tiny(hu.L, layers=1)
     m = hu.Model("oracle", cfg)
     serial = [m.sts_frame(f) for f in frames]
     m.free()
     cfg.codec_stream = 1
-    cfg.chain_depth = 1           # the Depth graph reads the text token from the Temporal graph's sampler output; the next step's inputs are staged early
+    cfg.chain_depth = chain
     m = hu.Model("oracle", cfg)
     piped = m.sts_pipeline(frames)
     m.free()
@@ -56,7 +59,7 @@ def test_pipelined_frame_loop_equals_the_serial_loop_on_the_host_device():
     cfg3 = hu.hot.tiny_personaplex(hu.L, layers=1)
     prompt = [[int(rng.integers(0, cfg3.text_card))] + rng.integers(0, cfg3.card, cfg3.n_q).tolist() for _ in range(3)]
     seqs = []
-    for ch in (0, 1):
+    for ch in (0, 1, 2):
         cfg3.chain_depth = ch
         m = hu.Model("oracle", cfg3)
         o = [m.lm_step([1] * 8) for _ in range(2)]
@@ -64,7 +67,7 @@ def test_pipelined_frame_loop_equals_the_serial_loop_on_the_host_device():
         o += [m.lm_step([2] * 8) for _ in range(3)]
         seqs.append(o)
         m.free()
-    assert seqs[0] == seqs[1]
+    assert seqs[0] == seqs[1] == seqs[2]
 
 
 def test_codec_round_trip_runs_and_is_finite():

@@ -386,6 +386,46 @@ def test_batched_q4k_matmul_int8_mfma(K, M, T):
     gu.compare(build3, atol_rel=2e-6)
 
 
+def test_second_command_stream_and_stream_ordered_read_back():
+    # ggml_backend_mi355x_init_stream: a backend handle with its own HIP stream / plan cache on the same GPU; buffers of either handle are plain device
+    # memory to both. ggml_backend_tensor_get_async + ggml_backend_event_*: the copy is queued behind the submitted graphs and handed over by the
+    # event wait (the run-ahead frame loop reads a step's tokens this way).
+    import ctypes as C
+    L = gu.lib()
+    g = gu.Graph("hip")
+    try:
+        x = g.input(np.arange(16, dtype=np.float32))
+        y = g.scale(g.add(x, x), 0.5)
+        z = g.sqr(y)
+        g.build([z])
+        g.alloc()
+        be2 = L.ggml_backend_mi355x_init_stream(g.backend)
+        assert be2 and L.ggml_backend_name(be2) != L.ggml_backend_name(g.backend)
+        assert L.ggml_backend_mi355x_get_stream(be2) != L.ggml_backend_mi355x_get_stream(g.backend)
+        ev = L.ggml_backend_event_new(L.ggml_backend_get_device(g.backend))
+        for rep in range(3):                                    # plan, capture, replay - on the second stream
+            g.set(x, np.arange(16, dtype=np.float32) + rep)
+            L.ggml_backend_synchronize(g.backend)               # the upload went through the first handle's queue
+            assert L.ggml_backend_graph_compute(be2, g.graph) == 0
+            out = (C.c_float * 16)()
+            L.ggml_backend_tensor_get_async(be2, z, out, 0, 64)
+            L.ggml_backend_event_record(ev, be2)
+            L.ggml_backend_event_synchronize(ev)
+            assert np.array_equal(np.array(out[:]), (np.arange(16, dtype=np.float32) + rep) ** 2), rep
+        # several reads in flight, delivered in order by one synchronize
+        outs = [(C.c_float * 4)() for _ in range(5)]
+        for i, o in enumerate(outs):
+            L.ggml_backend_tensor_get_async(be2, z, o, 16 * (i % 4), 16)
+        L.ggml_backend_synchronize(be2)
+        for i, o in enumerate(outs):
+            assert np.array_equal(np.array(o[:]), (np.arange(4 * (i % 4), 4 * (i % 4) + 4, dtype=np.float32) + 2) ** 2)
+        L.ggml_backend_event_free(ev)
+        L.ggml_backend_free(be2)
+        assert L.ggml_backend_mi355x_init_stream(L.ggml_backend_init_by_type(gu.pkg.DEV_CPU, None)) is None    # other backends: NULL, the caller keeps one stream
+    finally:
+        g.free()
+
+
 @pytest.mark.parametrize("wt", ["f32", "q8_0"])
 def test_voice_condition_graph(wt):
     # the one-shot conditioning graph of moshi-tts (src/moshi.cpp:296-366): two (embedding row -> output projection) terms summed into
