@@ -406,6 +406,8 @@ def main():
         except Exception as e:  # the baseline is auxiliary; never lose the GPU number over it
             result["cpu_baseline"] = {"value": None, "unit": "frames/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e}"}
 
+    if rank == 0 and m is not None:
+        result["frames_stepped_total"] = int(L.moshi_hot_offset(m)) - int(args.context_fill)   # warm-up + timed + the phase / serial / roofline passes (profile summaries divide by it)
     if rank == 0 and world == 1 and shard is None and not args.no_extras and args.model == "moshika" and args.quant == "q4_k" and not args.sampled and not args.context_fill:
         # not the headline: the same loop (a) with the reference's --bench sampling defaults, (b) from a nearly full ring, (c) at BASELINE configs[4]
         def quick(make_cfg, fill=0, steps=40):

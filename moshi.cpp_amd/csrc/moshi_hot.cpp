@@ -1417,7 +1417,9 @@ int lm_finish(moshi_hot_model * m, int32_t text_token, std::vector<int32_t> audi
 }
 }  // namespace
 
+namespace { void lm_finish_entry(moshi_hot_model * m, moshi_hot_model::InFlight & f); }
 extern "C" int moshi_hot_lm_step_n(moshi_hot_model_t * m, const int32_t * tokens, int n_tokens, int32_t * text_token_out, int32_t * out_audio, float * vad) {
+    for (auto & o : m->inflight) lm_finish_entry(m, o);   // a blocking step behind run-ahead ones: those finish first (their results stay parked for lm_complete)
     const moshi_hot_config & c = m->cfg;
     const int ncb = c.n_q + 1, CT = (int) m->cache.size();
     const int dep_q = c.personaplex ? 8 : c.dep_q, dep_q_1 = dep_q + 1;   // lm.h:802-805
@@ -1496,7 +1498,7 @@ ggml_backend_event_t take_event(moshi_hot_model * m) {
     return ggml_backend_event_new(ggml_backend_get_device(m->be));
 }
 void lm_finish_entry(moshi_hot_model * m, moshi_hot_model::InFlight & f) {
-    if (f.done) return;
+    if (f.done || !f.ev) return;   // (no event: the entry of a blocking step that is being taken right now)
     ggml_backend_event_synchronize(f.ev);
     m->ev_pool.push_back(f.ev); f.ev = nullptr;
     std::vector<int32_t> audio(f.raw.begin() + 1, f.raw.end());

@@ -8,7 +8,7 @@ rocprofv3 --kernel-trace --stats -d gpurun_out/${R}_trace -o t --output-format c
 f=$(find gpurun_out/${R}_trace -name "*kernel_stats.csv" | head -1)
 python3 tests/profile_summary.py stats $f gpurun_out/${R}_bench_kernel_stats_eager.csv
 t=$(find gpurun_out/${R}_trace -name "*kernel_trace.csv" | head -1)
-python3 tests/trace_summary.py $t 37 > gpurun_out/${R}_bench_kernel_trace_summary.txt 2>&1
+python3 tests/trace_summary.py $t $(python3 -c "import json; print(json.load(open('gpurun_out/${R}_bench_eager_under_rocprof.json'))['frames_stepped_total'])") > gpurun_out/${R}_bench_kernel_trace_summary.txt 2>&1
 rm -rf gpurun_out/${R}_trace
 rocprofv3 --pmc FETCH_SIZE -d gpurun_out/${R}_pmc -o p --output-format csv -- python3 bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-extras --no-roofline --backend-flags 2 > gpurun_out/${R}_pmc_bench.json 2> gpurun_out/${R}_pmc.err
 c=$(find gpurun_out/${R}_pmc -name "*counter_collection.csv" | head -1)

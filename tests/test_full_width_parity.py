@@ -209,6 +209,34 @@ def test_mimi_encoder_32_levels_133_frames_codes():
     assert len(codes_seen) > 100, "degenerate input: the codes barely vary"
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("sampled", [False, True])
+def test_run_ahead_frame_loop_at_the_benchmark_configuration_is_bit_identical_to_the_serial_loop(sampled):
+    # bench.py's default loop (two command streams, text token and Depth samples fed back through the device-side token state, step k queued before
+    # step k - 1 is read) against the reference's serial order, at the full moshika-7B q4_k configuration with the codec, 40 frames: same tokens, same PCM.
+    # Sampled mode draws its noise from the host's rand() per graph submit (src/context.h:456-480): same sequence in both orders when seeded alike.
+    import ctypes
+    libc = ctypes.CDLL(None)
+    rng = np.random.default_rng(77)
+    frames = [(rng.standard_normal(1920) * 0.05).astype(np.float32) for _ in range(40)]
+    out = []
+    for piped in (False, True):
+        cfg = hu.hot.moshika(L)
+        cfg.context = 200
+        if sampled:
+            cfg.temp, cfg.temp_text = 0.8, 0.7
+        cfg.codec_stream, cfg.chain_depth = (1, 2) if piped else (0, 0)
+        libc.srand(1234)
+        m = hu.Model("hip", cfg, seed=0)
+        out.append(m.sts_pipeline(frames) if piped else [m.sts_frame(f) for f in frames])
+        m.free()
+    assert sum(a[0] for a in out[0]) >= 38
+    for i, (a, b) in enumerate(zip(*out)):
+        assert a[:3] == b[:3], f"frame {i}: serial {a[:3]} vs run-ahead {b[:3]}"
+        if a[0]:
+            assert np.array_equal(a[3], b[3]), f"frame {i}: pcm differs"
+
+
 def test_freed_model_then_a_different_config_never_replays_a_stale_plan():
     # plans are cached by graph address and validated by a hash of everything the planner reads; a model that is freed and replaced by one
     # with another configuration (allocations land on recycled host and device addresses) must plan afresh and still match the oracle

@@ -396,7 +396,7 @@ def test_second_command_stream_and_stream_ordered_read_back():
     try:
         x = g.input(np.arange(16, dtype=np.float32))
         y = g.scale(g.add(x, x), 0.5)
-        z = g.sqr(y)
+        z = g.mul(y, y)
         g.build([z])
         g.alloc()
         be2 = L.ggml_backend_mi355x_init_stream(g.backend)
