@@ -1932,31 +1932,37 @@ attn_decode_kernel(attn_args a_in, attn_split_ws w) {
 #pragma unroll
         for (int w_ = 1; w_ < ATTN_NW; w_++) gmax = fmaxf(gmax, sh_f[w_]);
         if (multi) {
-            // publish (this workgroup's scores, at most one per thread: SLOTS <= 256 = ATTN_THREADS), arrive, wait for the other P - 1
-            // workgroups of this head, then pull everybody's scores
+            // publish (this workgroup's scores, at most one per thread: SLOTS <= 256 = ATTN_THREADS, and from thread 0 its maximum - the two returning
+            // exchanges are in flight together), arrive, wait for the other P - 1 workgroups of this head, then pull everybody's scores and maxima with
+            // all loads in flight at once. Every agent-scope access is a full memory round trip (~2 us at long context): four of them in a row here,
+            // seven before this was restructured (stamps 3 -> 4 at 2 800 live slots: 14.3 us of a 33 us kernel)
             {
                 const int c = c_lo + tid;
-                if (c < c_hi) xchg_agent_wait(w.scores + (int64_t) h * C + c, sc[c]);
+                float o1 = 0.f, o2 = 0.f;
+                if (c < c_hi) o1 = __hip_atomic_exchange(w.scores + (int64_t) h * C + c, sc[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (tid == 0) o2 = __hip_atomic_exchange(w.pmax + h * S + s_idx, gmax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                asm volatile("" :: "v"(o1), "v"(o2));   // both complete at the coherence point (xchg_agent_wait's reasoning)
             }
             __syncthreads();
             if (tid == 0) {
-                xchg_agent_wait(w.pmax + h * S + s_idx, gmax);
-                atomicAdd(w.arrive + h, 1u);
-                int spins = 0;
-                while (ld_agent(w.arrive + h) < (unsigned) P && ++spins < (1 << 22)) __builtin_amdgcn_s_sleep(2);
-                if (spins >= (1 << 22) && w.err) *w.err = 1u;   // host-visible: the backend aborts at the next read-back
+                const unsigned before = atomicAdd(w.arrive + h, 1u);
+                if (before + 1u < (unsigned) P) {          // (the last to arrive has nothing to wait for)
+                    int spins = 0;
+                    while (ld_agent(w.arrive + h) < (unsigned) P && ++spins < (1 << 22)) __builtin_amdgcn_s_sleep(2);
+                    if (spins >= (1 << 22) && w.err) *w.err = 1u;   // host-visible: the backend aborts at the next read-back
+                }
             }
             __syncthreads();
-            // (coherent loads cost a full memory round trip each: request them eight at a time)
-            for (int c0 = tid; c0 < n_end; c0 += 8 * ATTN_THREADS) {
-                float v[8];
-#pragma unroll
-                for (int u = 0; u < 8; u++) { const int c = c0 + u * ATTN_THREADS; v[u] = ld_agent(w.scores + (int64_t) h * C + (c < n_end ? c : n_end - 1)); }
-#pragma unroll
-                for (int u = 0; u < 8; u++) { const int c = c0 + u * ATTN_THREADS; if (c < n_end && (c < c_lo || c >= c_hi)) sc[c] = v[u]; }
-            }
             {
                 const float pm = ld_agent(w.pmax + h * S + (lane < P ? lane : 0));   // P <= C / 128 = 24 < 64
+                constexpr int PULL = 12;                                             // C <= 3 072 at 256 threads: one batch
+                for (int c0 = tid; c0 < n_end; c0 += PULL * ATTN_THREADS) {
+                    float v[PULL];
+#pragma unroll
+                    for (int u = 0; u < PULL; u++) { const int c = c0 + u * ATTN_THREADS; v[u] = ld_agent(w.scores + (int64_t) h * C + (c < n_end ? c : n_end - 1)); }
+#pragma unroll
+                    for (int u = 0; u < PULL; u++) { const int c = c0 + u * ATTN_THREADS; if (c < n_end && (c < c_lo || c >= c_hi)) sc[c] = v[u]; }
+                }
                 gmax = fmaxf(gmax, wave_allmax_f32(lane < P ? pm : -INFINITY));
             }
             __syncthreads();
