@@ -121,6 +121,7 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus}")
     dist = None
+    emit = lambda line: print(line, flush=True)
     if world > 1:
         import torch
         import torch.distributed as dist
@@ -128,6 +129,11 @@ def main():
         torch.cuda.set_device(dev_index)
         # One backend for the whole job, decided collectively: every rank first joins a host-side gloo group; RCCL is then tried by
         # all ranks and the outcome is agreed on over gloo (MIN of the success flags), so no rank is ever left alone in an RCCL barrier.
+        # (stdout carries ONE JSON line: the gloo transport's connection banners, printed from C++ on fd 1, go to stderr)
+        sys.stdout.flush()
+        _fd1 = os.dup(1)
+        os.dup2(2, 1)
+        emit = lambda line: os.write(_fd1, (line + "\n").encode())
         dist.init_process_group("gloo")
         ctl = dist.group.WORLD
         if args.dist_backend == "nccl":
@@ -326,11 +332,11 @@ def main():
         if pipelined:
             # the same model stepped serially (one frame's encode -> LM -> decode, each waited for): what the pipelining buys
             ns = min(args.steps, 60)
-            barrier()
+            L.ggml_backend_synchronize(be); device_sync()       # (this rank only: not a collective)
             t1 = time.perf_counter()
             for _ in range(ns):
                 frame_serial()
-            barrier()
+            L.ggml_backend_synchronize(be); device_sync()
             result["serial_loop"] = {"value": round(ns / (time.perf_counter() - t1), 2), "unit": "frames/s", "steps": ns}
 
     if shard is not None:
@@ -453,7 +459,7 @@ def main():
     if m is not None:
         L.moshi_hot_free(m)
     if rank == 0:
-        print(json.dumps(result), flush=True)
+        emit(json.dumps(result))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
