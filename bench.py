@@ -413,13 +413,13 @@ def main():
             result["cpu_baseline"] = {"value": None, "unit": "frames/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e}"}
 
     if rank == 0 and m is not None:
-        result["frames_stepped_total"] = int(L.moshi_hot_offset(m)) - int(args.context_fill)   # warm-up + timed + the phase / serial / roofline passes (profile summaries divide by it)
+        result["frames_stepped_total"] = int(L.moshi_hot_offset(m))   # warm-up + timed + the phase / serial / roofline passes (profile summaries divide by it)
     if rank == 0 and world == 1 and shard is None and not args.no_extras and args.model == "moshika" and args.quant == "q4_k" and not args.sampled and not args.context_fill:
         # not the headline: the same loop (a) with the reference's --bench sampling defaults, (b) from a nearly full ring, (c) at BASELINE configs[4]
         def quick(make_cfg, fill=0, steps=40):
             c2 = make_cfg()
             c2.codec_stream = int(pipelined)
-            c2.chain_depth = 2 if pipelined and not c2.personaplex else int(pipelined)
+            c2.chain_depth = 2 if pipelined else 0
             mm = L.moshi_hot_create(be, C.byref(c2), 0)
             if fill:
                 L.moshi_hot_set_context_fill(mm, fill)

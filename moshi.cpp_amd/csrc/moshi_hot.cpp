@@ -1490,7 +1490,7 @@ extern "C" int moshi_hot_lm_step_n(moshi_hot_model_t * m, const int32_t * tokens
 namespace {
 bool run_ahead_config(const moshi_hot_model * m) {
     const moshi_hot_config & c = m->cfg;
-    return c.chain_depth == 2 && m->tok_state && !c.personaplex && c.dep_q > 0 && !c.demux_second_stream && !c.delay_steps && !c.extra_heads &&
+    return c.chain_depth == 2 && m->tok_state && c.dep_q > 0 && !c.demux_second_stream && !c.delay_steps && !c.extra_heads &&
            !m->text_hook && !m->depth_hook && c.dep_shard_world <= 1;
 }
 ggml_backend_event_t take_event(moshi_hot_model * m) {
@@ -1507,11 +1507,16 @@ void lm_finish_entry(moshi_hot_model * m, moshi_hot_model::InFlight & f) {
 }
 void lm_queue(moshi_hot_model * m, const int32_t * user_codes) {
     const moshi_hot_config & c = m->cfg;
-    const int ncb = c.n_q + 1, CT = (int) m->cache.size(), dep_q_1 = c.dep_q + 1, needed = ncb - dep_q_1;
+    // (PersonaPlex: the Depth chain samples all 16 codebooks, the protocol takes the other speaker's 8 and hands back the model's 8, lm.h:802-805)
+    const int ncb = c.n_q + 1, CT = (int) m->cache.size(), dep_q_1 = (c.personaplex ? 8 : c.dep_q) + 1, needed = ncb - dep_q_1;
+    // column i of the input row comes from the device-side token state when the Depth chain samples it and the host would read that sample back: the
+    // model's own columns always; one of the other speaker's only where the sample of step q - 1 lands on the ring row AFTER the code received at step
+    // q - 1 (delay >= 1: the code went to that row first). With delay 0 the code received at step q overwrites the sample: host value.
+    auto from_device = [&](int i) { return i < dep_q_1 || (i <= c.dep_q && c.delays[i] > 0); };
     int q = m->offset;                                   // this step's stream position: completed steps + those still running
     for (auto & o : m->inflight) if (!o.done) q++;
     bool steady = run_ahead_config(m) && !m->timing && m->g_temporal && m->g_depth && m->tok_state_for == q;
-    for (int i = 0; steady && i <= c.dep_q; i++) if (q <= c.delays[i]) steady = false;   // an initial token is still due on a model column
+    for (int i = 0; steady && i < ncb; i++) if (from_device(i) && q <= c.delays[i]) steady = false;   // an initial token is still due on such a column
     m->inflight.emplace_back();
     moshi_hot_model::InFlight & f = m->inflight.back();
     f.out_audio.assign((size_t) c.dep_q + 8, 0);
@@ -1524,14 +1529,14 @@ void lm_queue(moshi_hot_model * m, const int32_t * user_codes) {
     // other speaker's codes enter the delay ring at step q (lm.h:819-824); their columns of the input row go up from the host as ever
     for (int i = 0; i < needed; i++) m->cache[(size_t) ((q + c.delays[dep_q_1 + i]) % CT)][(size_t) (dep_q_1 + i)] = user_codes[i];
     const int pos = q % CT;
-    for (int i = dep_q_1; i < ncb; i++) {
+    for (int i = 0; i < ncb; i++) {
         int32_t id = q <= c.delays[i] ? m->initial[(size_t) i] : m->cache[(size_t) pos][(size_t) i];
-        const float sc = id == -1 ? 0.f : 1.f;
+        float sc = id == -1 ? 0.f : 1.f;
         if (id < 0) id = 0;
-        ggml_backend_tensor_set(m->emb_idx[(size_t) i], &id, 0, 4);
+        if (from_device(i)) sc = 1.f;                                   // sampled ids are never -1
+        else ggml_backend_tensor_set(m->emb_idx[(size_t) i], &id, 0, 4);
         ggml_backend_tensor_set(m->emb_scale[(size_t) i], &sc, 0, 4);
     }
-    { const float one = 1.f; for (int i = 0; i <= c.dep_q; i++) ggml_backend_tensor_set(m->emb_scale[(size_t) i], &one, 0, 4); }   // sampled ids are never -1
     if (m->temporal_staged) m->temporal_staged = false;
     else { transformer_graph_step(*m->scratch, m->temporal, 1); m->scratch->compute_scratch(); }
     m->g_temporal->compute();

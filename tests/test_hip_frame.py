@@ -130,17 +130,18 @@ def test_sts_frames_match_oracle():
             assert hu.rel_err(a[3], b[3]) < PCM_TOL, f"frame {i}: pcm rel err {hu.rel_err(a[3], b[3]):.2e}"
 
 
-@pytest.mark.parametrize("streams,chain", [(1, 0), (2, 0), (2, 1), (1, 1), (2, 2), (1, 2)])
-def test_pipelined_frame_loop_is_bit_identical_to_the_serial_loop(streams, chain):
+@pytest.mark.parametrize("streams,chain,model", [(1, 0, "tiny"), (2, 0, "tiny"), (2, 1, "tiny"), (1, 1, "tiny"), (2, 2, "tiny"), (1, 2, "tiny"), (2, 2, "personaplex")])
+def test_pipelined_frame_loop_is_bit_identical_to_the_serial_loop(streams, chain, model):
     # moshi_hot_sts_pipeline_*: LM of frame k beside decode of k - 1 and encode of k + 1 (on a second command stream when codec_stream = 1).
     # Every graph consumes the same inputs and states in the same order, so tokens and PCM are the serial loop's, bit for bit.
     rng = np.random.default_rng(21)
     frames = [rng.standard_normal(1920).astype(np.float32) * 0.1 for _ in range(14)]
-    cfg = hu.hot.tiny(hu.L)
+    make = (lambda: hu.hot.tiny(hu.L)) if model == "tiny" else (lambda: hu.hot.tiny_personaplex(hu.L))
+    cfg = make()
     m = hu.Model("hip", cfg, seed=0)
     serial = [m.sts_frame(f) for f in frames]
     m.free()
-    cfg2 = hu.hot.tiny(hu.L)
+    cfg2 = make()
     cfg2.codec_stream = int(streams == 2)
     cfg2.chain_depth = chain      # 1: text token handed from the Temporal to the Depth graph on the device, next step's inputs staged behind the Depth graph;
                                   # 2: run-ahead - the samples reach the next Temporal graph through device memory, step k is queued before step k - 1 is read
