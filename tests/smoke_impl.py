@@ -19,4 +19,11 @@ def run():
         assert a[:3] == b[:3], f"token mismatch: oracle {a[:3]} vs MI355X {b[:3]}"
         if a[0]:
             assert hu.rel_err(a[3], b[3]) < 1e-2
+    # the same frames through bench.py's default loop (two command streams, run-ahead): bit-identical to the serial loop
+    cfg.codec_stream, cfg.chain_depth = 1, 2
+    m = hu.Model("hip", cfg, seed=0)
+    piped = m.sts_pipeline(frames)
+    m.free()
+    for a, b in zip(out["hip"], piped):
+        assert a[:3] == b[:3] and (not a[0] or np.array_equal(a[3], b[3])), f"pipelined loop differs: {a[:3]} vs {b[:3]}"
     print("smoke ok:", [o[:3] for o in out["hip"]])
