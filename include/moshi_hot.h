@@ -104,6 +104,9 @@ GGML_API int moshi_hot_lm_step(moshi_hot_model_t * m, const int32_t * in_audio, 
 // the model still steps but its samples are not written to the delay ring: PersonaPlex prompt frames (lm.h:1063-1075, 1088-1097).
 // Otherwise tokens = the other speaker's (n_q - dep_q) codes as in moshi_hot_lm_step. vad (may be NULL): softmax(extra_heads[2]·transformer_out)[0].
 GGML_API int moshi_hot_lm_step_n(moshi_hot_model_t * m, const int32_t * tokens, int n_tokens, int32_t * text_token, int32_t * out_audio, float * vad);
+// The LM step alone under run-ahead (config.chain_depth = 2; the codec-free half of moshi_hot_sts_pipeline_frame): queues the step of in_audio behind
+// the previous one and returns the PREVIOUS step's result (1 / 0 like moshi_hot_lm_step, -1 when there is none yet). in_audio = NULL drains the last step.
+GGML_API int moshi_hot_lm_step_run_ahead(moshi_hot_model_t * m, const int32_t * in_audio, int32_t * text_token, int32_t * out_audio);
 // tts conditions: sum F32[dim] (may be NULL) and cross F32[dim * cross_len] (may be NULL); the cross-attention K/V of every layer are
 // computed once here (init(), transformer.h:343-396). Call before the first step.
 GGML_API void moshi_hot_set_conditions(moshi_hot_model_t * m, const float * sum, const float * cross);

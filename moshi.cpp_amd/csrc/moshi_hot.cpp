@@ -1563,6 +1563,13 @@ int lm_complete(moshi_hot_model * m, int32_t * text_token, int32_t * out_audio) 
 }
 }  // namespace
 
+extern "C" int moshi_hot_lm_step_run_ahead(moshi_hot_model_t * m, const int32_t * in_audio, int32_t * text_token_out, int32_t * out_audio) {
+    if (in_audio) lm_queue(m, in_audio);
+    const size_t keep = in_audio ? 1 : 0;
+    if (m->inflight.size() <= keep) return -1;          // nothing older to hand back yet
+    return lm_complete(m, text_token_out, out_audio);
+}
+
 extern "C" int moshi_hot_lm_step(moshi_hot_model_t * m, const int32_t * in_audio, int32_t * text_token_out, int32_t * out_audio) {
     const int io_dep_q = m->cfg.personaplex ? 8 : m->cfg.dep_q;
     return moshi_hot_lm_step_n(m, in_audio, m->cfg.n_q - io_dep_q, text_token_out, out_audio, nullptr);

@@ -31,6 +31,7 @@ SIGNATURES = {
     "moshi_hot_config_moshika": (None, [C.POINTER(Config)]),
     "moshi_hot_config_personaplex": (None, [C.POINTER(Config)]),
     "moshi_hot_lm_step_n": (C.c_int, [P, P, C.c_int, P, P, P]),
+    "moshi_hot_lm_step_run_ahead": (C.c_int, [P, P, P, P]),
     "moshi_hot_lm_step_embedding": (None, [P, P]),
     "moshi_hot_set_conditions": (None, [P, P, P]),
     "moshi_hot_prefill": (None, [P, P, C.c_int, C.c_int]),
