@@ -135,7 +135,7 @@ def test_pipelined_frame_loop_is_bit_identical_to_the_serial_loop(streams, chain
     # moshi_hot_sts_pipeline_*: LM of frame k beside decode of k - 1 and encode of k + 1 (on a second command stream when codec_stream = 1).
     # Every graph consumes the same inputs and states in the same order, so tokens and PCM are the serial loop's, bit for bit.
     rng = np.random.default_rng(21)
-    frames = [rng.standard_normal(1920).astype(np.float32) * 0.1 for _ in range(14)]
+    frames = [rng.standard_normal(1920).astype(np.float32) * 0.1 for _ in range(30 if chain == 2 else 14)]   # 30 frames cross the Temporal ring's wrap (context 24)
     make = (lambda: hu.hot.tiny(hu.L)) if model == "tiny" else (lambda: hu.hot.tiny_personaplex(hu.L))
     cfg = make()
     m = hu.Model("hip", cfg, seed=0)
