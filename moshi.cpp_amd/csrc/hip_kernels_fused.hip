@@ -2180,6 +2180,10 @@ void k_cross_attn(hipStream_t s, const xattn_args & a) {
 // embedding sum: out = (((e_0 + e_1) + e_2) + ...), e_i = dequant(table_i[row idx_i]) * scale_i
 // (src/moshi/models/lm.h:555-584, lm_utils.h:157-170); same left-to-right float order as the graph
 // ---------------------------------------------------------------------------------------------------
+// TYPE: the ggml type every table shares (-1: mixed). With a runtime type the dequantisation is a switch per term, the compiler keeps each term's
+// loads inside its own branch and the 17 terms of the Temporal graph's first kernel become 17 dependent round trips (22 us, every frame, in front of
+// everything else); with the type known the row elements of all terms are requested together.
+template <int TYPE>
 __global__ void embed_sum_kernel(embed_sum_args a) {
     const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= a.K) return;
@@ -2197,7 +2201,7 @@ __global__ void embed_sum_kernel(embed_sum_args a) {
     for (int t = 0; t < EMBED_SUM_MAX; t++) {
         const embed_src & e = a.src[t < a.n ? t : 0];
         if (r[t] < 0 || r[t] >= e.n_rows) r[t] = 0;
-        v[t] = dequant_elem(e.table + r[t] * e.row_bytes, e.type, i);
+        v[t] = dequant_elem(e.table + r[t] * e.row_bytes, TYPE >= 0 ? TYPE : e.type, i);
     }
     float acc = 0.f;
 #pragma unroll
@@ -2210,7 +2214,17 @@ __global__ void embed_sum_kernel(embed_sum_args a) {
     a.out[i] = acc;
 }
 void k_embed_sum(hipStream_t s, const embed_sum_args & a) {
-    embed_sum_kernel<<<(int) ((a.K + 255) / 256), 256, 0, s>>>(a);
+    int type = a.n > 0 ? a.src[0].type : -1;
+    for (int t = 1; t < a.n; t++) if (a.src[t].type != type) type = -1;
+    const int grid = (int) ((a.K + 255) / 256);
+    switch (type) {
+        case GGML_TYPE_Q4_0: embed_sum_kernel<GGML_TYPE_Q4_0><<<grid, 256, 0, s>>>(a); break;
+        case GGML_TYPE_Q8_0: embed_sum_kernel<GGML_TYPE_Q8_0><<<grid, 256, 0, s>>>(a); break;
+        case GGML_TYPE_F32:  embed_sum_kernel<GGML_TYPE_F32><<<grid, 256, 0, s>>>(a); break;
+        case GGML_TYPE_BF16: embed_sum_kernel<GGML_TYPE_BF16><<<grid, 256, 0, s>>>(a); break;
+        case GGML_TYPE_F16:  embed_sum_kernel<GGML_TYPE_F16><<<grid, 256, 0, s>>>(a); break;
+        default:             embed_sum_kernel<-1><<<grid, 256, 0, s>>>(a); break;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------
