@@ -626,8 +626,15 @@ static bool match_matvec(const analysis & an, int pos, mv_group & grp) {
     while ((b->op == GGML_OP_VIEW || b->op == GGML_OP_RESHAPE) && uses_of(an, b) == 1 && b->src[0]->data == b->data &&
            ggml_nelements(b->src[0]) == ggml_nelements(b) && ggml_is_contiguous(b->src[0])) b = b->src[0];
 
-    // prologue 1: b = alpha * rms_norm(x), private to this mat-vec
-    if (a.ncols == 1 && b->op == GGML_OP_MUL && is_f32_vec(b, K) && uses_of(an, b) == 1 && (!is_qblock(mm->src[0]->type) || K <= 4096)) {
+    // prologue 1: b = alpha * rms_norm(x), private to this mat-vec - or shared with exactly one cpy(b -> contiguous F32 tensor) issued right before the
+    // mat-vec (the Temporal head: out_norm feeds text_linear and is kept as the `transformer_out` state, lm.h:434): workgroup 0 writes the copy
+    const ggml_tensor * side_cpy = nullptr;
+    if (a.ncols == 1 && b->op == GGML_OP_MUL && uses_of(an, b) == 2 && pos > 0 && is_qblock(mm->src[0]->type)) {
+        const ggml_tensor * cp = an.g->nodes[pos - 1];
+        if (cp->op == GGML_OP_CPY && cp->src[0] == b && cp->type == GGML_TYPE_F32 && ggml_is_contiguous(cp) && ggml_nelements(cp) == K && cp->data &&
+            !an.skip[(size_t) (pos - 1)]) side_cpy = cp;
+    }
+    if (a.ncols == 1 && b->op == GGML_OP_MUL && is_f32_vec(b, K) && (uses_of(an, b) == 1 || side_cpy) && (!is_qblock(mm->src[0]->type) || K <= 4096)) {
         const ggml_tensor * al = b->src[0], * nr = b->src[1];
         if (nr->op != GGML_OP_RMS_NORM) std::swap(al, nr);
         if (nr->op == GGML_OP_RMS_NORM && uses_of(an, nr) == 1 && is_f32_vec(al, K) && is_f32_vec(nr->src[0], K)) {
@@ -636,6 +643,7 @@ static bool match_matvec(const analysis & an, int pos, mv_group & grp) {
             a.alpha = (const float *) al->data;
             a.eps = ggml_get_op_params_f32(nr, 0);
             grp.members.push_back(pos_of(an, b)); grp.members.push_back(pos_of(an, nr));
+            if (side_cpy) { a.x_out = (float *) side_cpy->data; grp.members.push_back(pos - 1); }
             have_x = true;
         }
     }
@@ -1561,6 +1569,23 @@ static plan_t * build_plan(hip_ctx * c, ggml_cgraph * g) {
             const embed_sum_args a = grp.a;
             at_pos[i].push_back([=](hipStream_t s) { k_embed_sum(s, a); });
             p->n_fused += (int) grp.members.size();
+        }
+        // timestep table of add(a, b): one launch (the Temporal graph's RoPE phase: add(arange, offset) -> timestep_embedding)
+        for (int i = 0; i < g->n_nodes; i++) {
+            const ggml_tensor * n = g->nodes[i];
+            if (an.skip[(size_t) i] || n->op != GGML_OP_TIMESTEP_EMBEDDING) continue;
+            const ggml_tensor * ad = n->src[0];
+            const int pa = pos_of(an, ad);
+            if (ad->op != GGML_OP_ADD || pa < 0 || an.skip[(size_t) pa] || uses_of(an, ad) != 1 || ad->view_src || ad->type != GGML_TYPE_F32) continue;
+            const ggml_tensor * x = ad->src[0], * y = ad->src[1];
+            if (x->type != GGML_TYPE_F32 || y->type != GGML_TYPE_F32 || !ggml_is_contiguous(x) || !ggml_is_contiguous(y) || !ggml_are_same_shape(x, ad) ||
+                ggml_nelements(ad) != ad->ne[0] || !(ggml_nelements(y) == ggml_nelements(ad) || ggml_nelements(y) == 1)) continue;
+            an.skip[(size_t) i] = an.skip[(size_t) pa] = 1;
+            const tdesc d = make_tdesc(n), tx = make_tdesc(x);
+            const float * yp = (const float *) y->data; const int yn = (int) ggml_nelements(y);
+            const int dim = n->op_params[0], mp = n->op_params[1];
+            at_pos[i].push_back([=](hipStream_t s) { k_timestep_embedding(s, d, tx, dim, mp, yp, yn); });
+            p->n_fused += 2;
         }
         // mat-vecs with prologue / epilogue
         std::unordered_map<const void *, float *> paired_gate;   // storage of a linear_in output h (never materialised) -> g = silu(h_l) * h_r

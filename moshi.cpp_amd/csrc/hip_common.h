@@ -49,7 +49,7 @@ void k_set_rows(hipStream_t s, tdesc dst, tdesc src, tdesc idx);
 void k_im2col(hipStream_t s, tdesc dst, tdesc x, int64_t K, int s0, int p0, int d0);
 size_t k_conv_transpose_1d_ws_size(const struct ggml_tensor * w, const struct ggml_tensor * x);
 void k_conv_transpose_1d(hipStream_t s, tdesc dst, tdesc w, tdesc x, int s0, void * ws);
-void k_timestep_embedding(hipStream_t s, tdesc dst, tdesc ts, int dim, int max_period);
+void k_timestep_embedding(hipStream_t s, tdesc dst, tdesc ts, int dim, int max_period, const float * addend = nullptr, int addend_n = 0);
 // generic matrix product: activation rows are first converted to the weight type's dot type
 // (q8_K / q8_0 / f16 / bf16) into `ws` (size from k_mul_mat_ws_size), then dotted
 size_t k_mul_mat_ws_size(const struct ggml_tensor * a, const struct ggml_tensor * b);

@@ -752,11 +752,13 @@ void k_conv_tail(hipStream_t s, float * prev, int TP, tdesc x, int pre_elu) {
     if (TP > 0) conv_tail_kernel<<<(int) ((x.ne[1] + 63) / 64), 64, 0, s>>>(prev, TP, x, pre_elu);
 }
 
-__global__ void timestep_embedding_kernel(tdesc dst, tdesc ts, int dim, int max_period) {
+// addend (optional): the timesteps are ts[i] + addend[i or 0] - the `add(arange, offset)` in front of the node (moshi_get_timestep_embedding, rope.h:8-20) folded in
+__global__ void timestep_embedding_kernel(tdesc dst, tdesc ts, int dim, int max_period, const float * addend, int addend_n) {
     const int64_t i = blockIdx.x;
     const int half = dim / 2;
     float * e = (float *) at(dst, 0, i, 0, 0);
-    const float t = *(const float *) at(ts, i, 0, 0, 0);
+    float t = *(const float *) at(ts, i, 0, 0, 0);
+    if (addend) t = t + addend[addend_n == 1 ? 0 : i];
     for (int j = threadIdx.x; j < half; j += blockDim.x) {
         // float transcendentals evaluated in double and rounded once: the 1-ulp differences between the
         // device's expf and a host libm would otherwise be amplified by t (up to the context length)
@@ -768,8 +770,8 @@ __global__ void timestep_embedding_kernel(tdesc dst, tdesc ts, int dim, int max_
     }
     if (threadIdx.x == 0 && (dim & 1)) e[2 * half] = 0.f;
 }
-void k_timestep_embedding(hipStream_t s, tdesc dst, tdesc ts, int dim, int max_period) {
-    if (ts.ne[0]) timestep_embedding_kernel<<<(int) ts.ne[0], 64, 0, s>>>(dst, ts, dim, max_period);
+void k_timestep_embedding(hipStream_t s, tdesc dst, tdesc ts, int dim, int max_period, const float * addend, int addend_n) {
+    if (ts.ne[0]) timestep_embedding_kernel<<<(int) ts.ne[0], 64, 0, s>>>(dst, ts, dim, max_period, addend, addend_n);
 }
 
 // ---------------------------------------------------------------------------------------------------
