@@ -1570,6 +1570,21 @@ static plan_t * build_plan(hip_ctx * c, ggml_cgraph * g) {
             at_pos[i].push_back([=](hipStream_t s) { k_embed_sum(s, a); });
             p->n_fused += (int) grp.members.size();
         }
+        // cpy(cont(x), dst): copy the strided source straight into dst (the per-step mask row: cont(view of the bias table) -> cpy into the graph input,
+        // transformer.h:1259-1289 - two launches on the LM stream in front of every Temporal graph)
+        for (int i = 0; i < g->n_nodes; i++) {
+            const ggml_tensor * n = g->nodes[i];
+            if (an.skip[(size_t) i] || n->op != GGML_OP_CPY) continue;
+            const ggml_tensor * ct = n->src[0];
+            const int pc = pos_of(an, ct);
+            if (ct->op != GGML_OP_CONT || pc < 0 || an.skip[(size_t) pc] || uses_of(an, ct) != 1 || ct->view_src) continue;
+            if (ct->type != GGML_TYPE_F32 || n->type != GGML_TYPE_F32 || ct->src[0]->type != GGML_TYPE_F32 || !ggml_are_same_shape(ct, ct->src[0]) ||
+                !ggml_are_same_shape(n, ct) || !ggml_is_contiguous(n)) continue;
+            an.skip[(size_t) i] = an.skip[(size_t) pc] = 1;
+            const tdesc d = make_tdesc(n), x = make_tdesc(ct->src[0]);
+            at_pos[i].push_back([=](hipStream_t s) { k_cpy(s, d, x); });
+            p->n_fused += 2;
+        }
         // timestep table of add(a, b): one launch (the Temporal graph's RoPE phase: add(arange, offset) -> timestep_embedding)
         for (int i = 0; i < g->n_nodes; i++) {
             const ggml_tensor * n = g->nodes[i];
