@@ -98,6 +98,7 @@ GGML_API ggml_backend_event_t ggml_backend_event_new(ggml_backend_dev_t device);
 GGML_API void ggml_backend_event_free(ggml_backend_event_t event);
 GGML_API void ggml_backend_event_record(ggml_backend_event_t event, ggml_backend_t backend);
 GGML_API void ggml_backend_event_synchronize(ggml_backend_event_t event);
+GGML_API void ggml_backend_event_wait(ggml_backend_t backend, ggml_backend_event_t event);   // work submitted to `backend` after this call runs after the event (device-side wait)
 GGML_API void ggml_backend_tensor_memset(      struct ggml_tensor * tensor, uint8_t value,     size_t offset, size_t size);
 GGML_API void ggml_backend_tensor_copy  (struct ggml_tensor * src, struct ggml_tensor * dst);
 

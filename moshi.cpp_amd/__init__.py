@@ -139,6 +139,7 @@ SIGNATURES = {
     "ggml_backend_tensor_get_async": (None, [P, TP, P, Z, Z]),
     "ggml_backend_event_new": (P, [P]), "ggml_backend_event_free": (None, [P]), "ggml_backend_event_record": (None, [P, P]),
     "ggml_backend_event_synchronize": (None, [P]),
+    "ggml_backend_event_wait": (None, [P, P]),
     "ggml_backend_mi355x_get_kernel_profile": (None, [P, C.POINTER(KernelProfile)]),
     # ggml-cpu.h
     "ggml_backend_cpu_init": (P, []), "ggml_backend_is_cpu": (B, [P]), "ggml_backend_cpu_set_n_threads": (None, [P, I]),

@@ -98,6 +98,9 @@ extern "C" ggml_backend_event_t ggml_backend_event_new(ggml_backend_dev_t device
 extern "C" void ggml_backend_event_free(ggml_backend_event_t e) { if (!e) return; if (e->free_context) e->free_context(e); delete e; }
 extern "C" void ggml_backend_event_record(ggml_backend_event_t e, ggml_backend_t b) { if (b->iface.event_record) b->iface.event_record(b, e); }
 extern "C" void ggml_backend_event_synchronize(ggml_backend_event_t e) { if (e->synchronize) e->synchronize(e); }
+extern "C" void ggml_backend_event_wait(ggml_backend_t b, ggml_backend_event_t e) {
+    if (b->iface.event_wait) b->iface.event_wait(b, e); else ggml_backend_event_synchronize(e);   // no streams: the host waits instead
+}
 extern "C" bool ggml_backend_supports_op(ggml_backend_t b, const struct ggml_tensor * op) {
     return b->iface.supports_op ? b->iface.supports_op(b, op) : false;
 }

@@ -52,6 +52,7 @@ struct ggml_backend_i {
     // optional (NULL: blocking fall-backs): stream-ordered read-back completed by synchronize / an event recorded after it
     void (*get_tensor_async)(ggml_backend_t backend, const struct ggml_tensor * t, void * data, size_t offset, size_t size);
     void (*event_record)(ggml_backend_t backend, ggml_backend_event_t event);
+    void (*event_wait)(ggml_backend_t backend, ggml_backend_event_t event);
 };
 
 struct ggml_backend_event {

@@ -1891,6 +1891,15 @@ static void hip_event_record(ggml_backend_t b, ggml_backend_event_t e) {
     h->c = c; h->seq = c->aget_seq;
     HIP_CHECK(hipEventRecord(h->ev, c->stream));
 }
+static void hip_event_wait(ggml_backend_t b, ggml_backend_event_t e) {
+    hip_ctx * c = (hip_ctx *) b->context;
+    hip_event_ctx * h = (hip_event_ctx *) e->context;
+    if (!h) return;                      // never recorded: nothing to wait for
+    ctx_init_lazy(c);
+    set_device(c);
+    flush_uploads(c);
+    HIP_CHECK(hipStreamWaitEvent(c->stream, h->ev, 0));
+}
 static bool hip_supports_op(ggml_backend_t, const struct ggml_tensor * op) {
     switch (op->op) {
         case GGML_OP_CPY: case GGML_OP_CONT: case GGML_OP_DUP:
@@ -1923,7 +1932,7 @@ static ggml_backend_t hip_dev_init(ggml_backend_dev_t d, const char *) {
     if (c->flags != 0) { HIP_CHECK(hipStreamSynchronize(c->stream)); for (auto & kv : c->plans) plan_free(c, kv.second); c->plans.clear(); c->flags = 0; }
     c->stats = {};
     auto * b = new ggml_backend;
-    b->iface = { hip_backend_name, hip_backend_free, hip_backend_sync, hip_alloc_buffer, hip_graph_compute, hip_supports_op, hip_get_tensor_async, hip_event_record };
+    b->iface = { hip_backend_name, hip_backend_free, hip_backend_sync, hip_alloc_buffer, hip_graph_compute, hip_supports_op, hip_get_tensor_async, hip_event_record, hip_event_wait };
     b->device = d;
     b->context = c;
     return b;

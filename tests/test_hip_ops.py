@@ -412,6 +412,10 @@ def test_second_command_stream_and_stream_ordered_read_back():
             L.ggml_backend_event_record(ev, be2)
             L.ggml_backend_event_synchronize(ev)
             assert np.array_equal(np.array(out[:]), (np.arange(16, dtype=np.float32) + rep) ** 2), rep
+        # device-side ordering between the two streams: the first handle's stream waits for the event recorded on the second
+        L.ggml_backend_event_record(ev, be2)
+        L.ggml_backend_event_wait(g.backend, ev)
+        L.ggml_backend_synchronize(g.backend)
         # several reads in flight, delivered in order by one synchronize
         outs = [(C.c_float * 4)() for _ in range(5)]
         for i, o in enumerate(outs):
