@@ -386,6 +386,26 @@ def test_batched_q4k_matmul_int8_mfma(K, M, T):
     gu.compare(build3, atol_rel=2e-6)
 
 
+def test_codebook_centroid_graph_on_the_device():
+    # the load-time graph that turns a safetensors checkpoint's (embedding_sum, cluster_usage) into the RVQ centroids (core_vq.h:58-85):
+    # clamp(usage, 1e-5, inf) -> cont(transpose) -> div(embedding_sum, .) -> copy into the separately allocated embedding tensor. A loader whose scratch
+    # context sits on the MI355X backend gets the same bytes as on the host device.
+    r = np.random.default_rng(12)
+    card, dim = 2048, 256
+    usage = np.abs(r.standard_normal(card)).astype(np.float32) * 50
+    usage[r.integers(0, card, 40)] = 0.0                      # dead codes: the clamp's reason
+    esum = (r.standard_normal((card, dim)) * 30).astype(np.float32)
+
+    def build(g):
+        cl = g.clamp(g.input(usage), 1e-5, float("inf"))
+        ct = g.cont(g.transpose(cl))
+        emb = g.div(g.input(esum), ct)
+        return [g.cpy(emb, g.new(F32, dim, card))]
+    ref, got, _ = gu.compare(build, rtol=0, atol_rel=0)
+    assert np.array_equal(ref[0], got[0])
+    assert np.isfinite(got[0]).all() and np.abs(got[0]).max() > 1e5     # the dead codes divide by 1e-5
+
+
 def test_second_command_stream_and_stream_ordered_read_back():
     # ggml_backend_mi355x_init_stream: a backend handle with its own HIP stream / plan cache on the same GPU; buffers of either handle are plain device
     # memory to both. ggml_backend_tensor_get_async + ggml_backend_event_*: the copy is queued behind the submitted graphs and handed over by the
