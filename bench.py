@@ -179,9 +179,10 @@ def main():
         cfg.linear_type = {"q8_0": 8, "q4_0": 2}[args.quant]   # ggml_type ids
     if args.sampled:
         cfg.temp, cfg.temp_text = 0.8, 0.7
-    pipelined = not args.serial and args.shard == "none" and args.model in ("moshika", "personaplex")
+    pipelined = not args.serial and args.shard == "none"
     cfg.codec_stream = int(pipelined)
-    cfg.chain_depth = 2 if pipelined else 0      # run-ahead: the LM stream never waits for the host (include/moshi_hot.h)
+    # run-ahead: the LM stream never waits for the host (include/moshi_hot.h); tts / stt shapes (text hook, no Depth) overlap their codec half only
+    cfg.chain_depth = 2 if pipelined and args.model in ("moshika", "personaplex") else 0
     shard = None
     if args.shard == "depth":
         if args.model not in ("moshika", "personaplex"):
@@ -217,18 +218,30 @@ def main():
         aud64 = (C.c_int32 * 64)()
         none_in = (C.c_int32 * 1)()
 
-        def frame():
+        def frame_serial():
             if L.moshi_hot_lm_step_n(m, none_in, 0, C.byref(txt), aud64, None):
                 L.moshi_hot_mimi_decode(m, aud64, out.ctypes.data)
             return 1
+        frame = frame_serial
+        if pipelined:          # decode of frame k - 1 beside the LM step of frame k
+            L.moshi_hot_sts_pipeline_begin(m, None)
+
+            def frame():
+                return L.moshi_hot_sts_pipeline_frame(m, None, C.byref(txt), aud64, out.ctypes.data)
     elif args.model == "stt_like":    # moshi-stt loop (tools/moshi-stt.cpp:552-719): Mimi encode (32 levels) + LM step with the VAD head
         codes = (C.c_int32 * 64)()
         aud64 = (C.c_int32 * 64)()
         vad = C.c_float()
 
-        def frame():
+        def frame_serial():
             L.moshi_hot_mimi_encode(m, pcm.ctypes.data, codes)
             return L.moshi_hot_lm_step_n(m, codes, cfg.n_q, C.byref(txt), aud64, C.byref(vad))
+        frame = frame_serial
+        if pipelined:          # encode of frame k + 1 beside the LM step (+ VAD head) of frame k
+            L.moshi_hot_sts_pipeline_begin(m, pcm.ctypes.data)
+
+            def frame():
+                return L.moshi_hot_sts_pipeline_frame(m, pcm.ctypes.data, C.byref(txt), aud64, out.ctypes.data)
     else:
         def frame_serial():
             return L.moshi_hot_sts_frame(m, pcm.ctypes.data, C.byref(txt), aud, out.ctypes.data)
@@ -301,7 +314,8 @@ def main():
                                 .get(args.model, "moshi-sts --bench loop: mimi encode + Temporal step + %d Depth steps + mimi decode, ") % cfg.dep_q) +
                                "%s %s, 1 audio stream per GPU, %s, ctx capacity %d" % (args.model, args.quant, "sampled (temp 0.8 / 0.7, top-k 250 / 25)" if args.sampled else "greedy", cfg.context),
                    "context_fill_start": args.context_fill,
-                   "frame_loop": "software-pipelined over 2 HIP streams with run-ahead: the LM step of frame k is queued behind the one of frame k-1 (sampled tokens reach "
+                   "frame_loop": ("software-pipelined over 2 HIP streams: the codec half of the neighbouring frame runs beside the LM step (--serial: one after the other)"
+                                  if pipelined and not cfg.chain_depth else "") or "software-pipelined over 2 HIP streams with run-ahead: the LM step of frame k is queued behind the one of frame k-1 (sampled tokens reach "
                                  "the next Temporal graph through device memory; the host reads them one step late), mimi decode of frame k-1 and mimi encode of frame k+1 "
                                  "run beside it; same graphs, inputs, states and outputs as the serial loop (--serial), one LM step + one encode + one decode per step" if pipelined else "serial: encode -> LM -> decode of one frame per step",
                    "parallelism": ("Depth codebook shard: step k on rank k %% %d, replicated 8-slot ring, 1 + dep_q broadcasts per frame" % world) if shard is not None

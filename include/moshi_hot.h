@@ -139,6 +139,9 @@ GGML_API int moshi_hot_sts_frame(moshi_hot_model_t * m, const float * pcm_in, in
 GGML_API void moshi_hot_sts_pipeline_begin(moshi_hot_model_t * m, const float * pcm0);
 GGML_API int  moshi_hot_sts_pipeline_frame(moshi_hot_model_t * m, const float * pcm_next, int32_t * text_token, int32_t * audio_tokens, float * pcm_prev);
 GGML_API int  moshi_hot_sts_pipeline_end(moshi_hot_model_t * m, int32_t * text_token, int32_t * audio_tokens, float * pcm_last);
+// stt / tts shaped models run the same loop with the codec half they have (encode of frame k + 1, or decode of frame k - 1, beside the LM step of frame k);
+// the VAD head's probability of the last stepped frame (lm.h:966-976) is read here
+GGML_API float moshi_hot_sts_pipeline_vad(moshi_hot_model_t * m);
 
 // introspection for tests / bench
 GGML_API int64_t moshi_hot_offset(moshi_hot_model_t * m);                      // frames stepped so far

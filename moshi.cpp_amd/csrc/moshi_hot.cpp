@@ -696,7 +696,7 @@ struct moshi_hot_model {
 
     std::vector<int32_t> tokens_tmp;
     // software-pipelined frame loop (moshi_hot_sts_pipeline_*): codes of the frame the next LM step consumes, tokens of the frame still to be decoded
-    std::vector<int32_t> pipe_codes, pipe_tokens; bool pipe_have_codes = false, pipe_have_tokens = false;
+    std::vector<int32_t> pipe_codes, pipe_tokens; bool pipe_have_codes = false, pipe_have_tokens = false; float pipe_vad = 0.f;
     bool temporal_staged = false;                  // chain_depth: the next frame's Temporal step inputs (mask row, RoPE phase, ring slot) are already queued
     std::function<void()> after_temporal_launch;   // runs once the Temporal graph is queued, before its text token is waited for
     int32_t last_text = 0; std::vector<int32_t> last_audio;   // raw (un-delayed) tokens of the last step
@@ -1726,7 +1726,7 @@ extern "C" int moshi_hot_sts_frame(moshi_hot_model_t * m, const float * pcm_in, 
 // (encode 0, 1, 2 ...; decode 0, 1, 2 ...; LM 0, 1, 2 ...), so tokens and PCM are bit-identical; the hand-offs are host round trips (codes and
 // tokens are a few integers). Without a second stream the calls degenerate to the serial order.
 extern "C" void moshi_hot_sts_pipeline_begin(moshi_hot_model_t * m, const float * pcm0) {
-    moshi_hot_mimi_encode(m, pcm0, m->pipe_codes.data());
+    if (m->cfg.enable_mimi_encoder) moshi_hot_mimi_encode(m, pcm0, m->pipe_codes.data());     // (a model without encoder - tts - steps on no input codes)
     m->pipe_have_codes = true;
     m->pipe_have_tokens = false;
 }
@@ -1747,16 +1747,20 @@ extern "C" int moshi_hot_sts_pipeline_frame(moshi_hot_model_t * m, const float *
         m->pipe_have_codes = pcm_next != nullptr;
         return (ok ? 3 : 0) | 4;
     }
-    const bool dec = m->pipe_have_tokens;
+    // (stt has no decoder, tts no encoder: the halves that exist are overlapped)
+    const bool dec = m->pipe_have_tokens && m->cfg.enable_mimi_decoder;
+    if (!m->cfg.enable_mimi_encoder) pcm_next = nullptr;
     // the LM stream is the critical path: its Temporal graph is queued first, the codec launches follow while it runs
     m->after_temporal_launch = [m, dec, pcm_next]() {
         if (dec) mimi_decode_launch(m, m->pipe_tokens.data());          // frame k - 1
         if (pcm_next) mimi_encode_launch(m, pcm_next);                  // frame k + 1
     };
-    const int ok = moshi_hot_lm_step(m, m->pipe_codes.data(), text_token, audio_tokens);   // frame k (blocks on the LM stream only)
+    const int io = m->cfg.personaplex ? 8 : m->cfg.dep_q;
+    const int ok = moshi_hot_lm_step_n(m, m->pipe_codes.data(), m->cfg.n_q - io, text_token, audio_tokens,
+                                       m->extra_heads.size() > 2 ? &m->pipe_vad : nullptr);   // frame k (blocks on the LM stream only)
     if (dec) mimi_decode_finish(m, pcm_prev);
     if (pcm_next) mimi_encode_finish(m, m->pipe_codes.data());
-    m->pipe_have_codes = pcm_next != nullptr;
+    m->pipe_have_codes = pcm_next != nullptr || !m->cfg.enable_mimi_encoder;
     m->pipe_have_tokens = ok != 0;
     if (ok) memcpy(m->pipe_tokens.data(), audio_tokens, (size_t) (m->cfg.personaplex ? 8 : m->cfg.dep_q) * sizeof(int32_t));
     return (ok ? 1 : 0) | (dec ? 2 : 0);
@@ -1770,12 +1774,13 @@ extern "C" int moshi_hot_sts_pipeline_end(moshi_hot_model_t * m, int32_t * text_
         }
         return r;
     }
-    if (!m->pipe_have_tokens) return 0;
+    if (!m->pipe_have_tokens || !m->cfg.enable_mimi_decoder) return 0;
     moshi_hot_mimi_decode(m, m->pipe_tokens.data(), pcm_last);
     m->pipe_have_tokens = false;
     return 2;
 }
 
+extern "C" float moshi_hot_sts_pipeline_vad(moshi_hot_model_t * m) { return m->pipe_vad; }
 extern "C" int64_t moshi_hot_offset(moshi_hot_model_t * m) { return m->offset; }
 extern "C" void moshi_hot_last_raw_tokens(moshi_hot_model_t * m, int32_t * text_token, int32_t * audio_tokens) {
     *text_token = m->last_text;

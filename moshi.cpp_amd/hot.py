@@ -48,6 +48,7 @@ SIGNATURES = {
     "moshi_hot_sts_pipeline_begin": (None, [P, P]),
     "moshi_hot_sts_pipeline_frame": (C.c_int, [P, P, P, P, P]),
     "moshi_hot_sts_pipeline_end": (C.c_int, [P, P, P, P]),
+    "moshi_hot_sts_pipeline_vad": (C.c_float, [P]),
     "moshi_hot_offset": (C.c_int64, [P]),
     "moshi_hot_weight_bytes": (C.c_size_t, [P, C.c_int]),
     "moshi_hot_read_last": (C.c_int, [P, C.c_char_p, P, C.c_int64]),

@@ -9,6 +9,8 @@ Bars (BASELINE.json north_star):
     1e-2 of max (the reference's own accepted backend tolerance, src/replay.h:333-341) on the short free-running
     sequences; teacher-forced long runs assert the distribution (median < 1e-4, 80 % of steps < 1e-2);
   * codec samples within 1e-2 of max |sample| (median far lower)."""
+import ctypes as C
+
 import numpy as np
 import pytest
 
@@ -153,6 +155,75 @@ def test_pipelined_frame_loop_is_bit_identical_to_the_serial_loop(streams, chain
         assert a[0] == b[0] and a[1] == b[1] and a[2] == b[2], f"frame {i}: serial {a[:3]} vs pipelined {b[:3]}"
         if a[0]:
             assert np.array_equal(a[3], b[3]), f"frame {i}: pcm differs, max {np.abs(a[3] - b[3]).max():.3e}"
+
+
+@pytest.mark.parametrize("shape", ["stt", "tts"])
+def test_pipelined_loop_with_half_a_codec_equals_the_serial_one(shape):
+    # stt-shaped (no Depth transformer, VAD head, encoder only) and tts-shaped (text hook, conditions, decoder only) models through the same pipelined calls:
+    # the codec half they have runs on the second stream beside the LM step of the neighbouring frame; tokens, VAD probabilities and PCM as in the serial order
+    rng = np.random.default_rng(31)
+    n = 10
+    frames = [rng.standard_normal(1920).astype(np.float32) * 0.1 for _ in range(n)]
+
+    def make():
+        if shape == "stt":
+            cfg = hu.hot.tiny(hu.L, dep_q=0, n_q=8)
+            cfg.extra_heads, cfg.extra_heads_dim = 3, 6
+            cfg.enable_mimi_decoder = 0
+            cfg.mimi_n_q = 8
+        else:
+            cfg = hu.hot.tiny_tts(hu.L)
+            cfg.enable_mimi_encoder = 0
+            cfg.mimi_n_q = cfg.dep_q
+        return cfg
+    res = []
+    for piped in (False, True):
+        cfg = make()
+        cfg.codec_stream = int(piped)
+        m = hu.Model("hip", cfg, seed=0)
+        if shape == "tts":
+            hu.set_conditions(m, cfg)
+            hu.set_text_hook(m, lambda offset, sampled: int((offset * 13) % cfg.text_card))
+        txt, aud, out = C.c_int32(-7), (C.c_int32 * 64)(), np.zeros(1920, np.float32)
+        got = []
+        if not piped:
+            codes, vad = (C.c_int32 * 64)(), C.c_float(-1.0)
+            for f in frames:
+                out[:] = 0
+                if shape == "stt":
+                    hu.L.moshi_hot_mimi_encode(m.m, f.ctypes.data, codes)
+                    r = hu.L.moshi_hot_lm_step_n(m.m, codes, cfg.n_q, C.byref(txt), aud, C.byref(vad))
+                    got.append((r, txt.value if r else None, round(vad.value, 7) if r else None, None))
+                else:
+                    r = hu.L.moshi_hot_lm_step_n(m.m, codes, 0, C.byref(txt), aud, None)
+                    if r:
+                        hu.L.moshi_hot_mimi_decode(m.m, aud, out.ctypes.data)
+                    got.append((r, (txt.value, list(aud)[:cfg.dep_q]) if r else None, None, out.copy() if r else None))
+        else:
+            hu.L.moshi_hot_sts_pipeline_begin(m.m, frames[0].ctypes.data if shape == "stt" else None)
+            pcm_of = {}
+            for k in range(n):
+                prev = np.zeros(1920, np.float32)
+                nxt = frames[k + 1].ctypes.data if (shape == "stt" and k + 1 < n) else None
+                r = hu.L.moshi_hot_sts_pipeline_frame(m.m, nxt, C.byref(txt), aud, prev.ctypes.data)
+                if r & 2:
+                    pcm_of[k - 1] = prev
+                if shape == "stt":
+                    got.append((r & 1, txt.value if r & 1 else None, round(hu.L.moshi_hot_sts_pipeline_vad(m.m), 7) if r & 1 else None, None))
+                else:
+                    got.append([r & 1, (txt.value, list(aud)[:cfg.dep_q]) if r & 1 else None, None, None])
+            last = np.zeros(1920, np.float32)
+            if hu.L.moshi_hot_sts_pipeline_end(m.m, C.byref(txt), aud, last.ctypes.data) & 2:
+                pcm_of[n - 1] = last
+            if shape == "tts":
+                got = [(g[0], g[1], None, pcm_of.get(k) if g[0] else None) for k, g in enumerate(got)]
+        m.free()
+        res.append(got)
+    assert sum(g[0] for g in res[0]) >= n - 6
+    for k, (a, b) in enumerate(zip(*res)):
+        assert a[:3] == b[:3], f"frame {k}: serial {a[:3]} vs pipelined {b[:3]}"
+        if a[3] is not None:
+            assert b[3] is not None and np.array_equal(a[3], b[3]), f"frame {k}: pcm differs"
 
 
 def test_mimi_codec_crosses_t2_mask_quirk():
