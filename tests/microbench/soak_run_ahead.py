@@ -16,9 +16,16 @@ def digest(res):
     return h.hexdigest()[:16]
 out = []
 for mode in ("serial", "run-ahead", "run-ahead"):
-    cfg = hu.hot.moshika(L)
+    cfg = hu.hot.personaplex(L) if os.environ.get("MODEL") == "personaplex" else hu.hot.moshika(L)
+    if os.environ.get("CONTEXT"):
+        cfg.context = int(os.environ["CONTEXT"])
+    if os.environ.get("SAMPLED"):          # the reference's --bench temperatures
+        cfg.temp, cfg.temp_text = 0.8, 0.7
     cfg.codec_stream, cfg.chain_depth = (0, 0) if mode == "serial" else (1, 2)
     m = hu.Model("hip", cfg, seed=0)
+    if os.environ.get("SAMPLED"):          # host rand() reseeded per run, AFTER the model (and with it the HIP runtime, which draws from rand() while it starts) is up
+        import ctypes
+        ctypes.CDLL(None).srand(4321)
     t0 = time.perf_counter()
     res = m.sts_pipeline(frames) if mode != "serial" else [m.sts_frame(f) for f in frames]
     dt = time.perf_counter() - t0
