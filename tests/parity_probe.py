@@ -91,7 +91,10 @@ def q8_0(v):
     d = (amax / np.float32(127.0)).astype(np.float32)
     idv = np.where(d != 0, np.float32(1.0) / np.where(d != 0, d, 1), 0).astype(np.float32)
     p = (v * idv[:, None]).astype(np.float32)
-    return (np.sign(p) * np.floor(np.abs(p) + np.float32(0.5))).astype(np.int32).reshape(-1)   # roundf: half away from zero
+    q = (np.sign(p) * np.floor(np.abs(p) + np.float32(0.5))).astype(np.int32).reshape(-1)   # roundf: half away from zero
+    # the block scale is stored as F16: when the block maximum differs by a float ulp the stored scale can land on the neighbouring F16 value (2^-11
+    # relative) with every quant unchanged - a rounding site of its own, reported as one more "element" per block
+    return np.concatenate([q, d.astype(np.float16).view(np.uint16).astype(np.int32)])
 
 
 def rounded(v, wtype):

@@ -28,8 +28,7 @@ def lm_only(cfg):
     return cfg
 
 
-def test_every_full_width_layer_node_by_node_teacher_forced():
-    cfg = lm_only(hu.hot.moshika(L))
+def _probe_every_layer(cfg, depth_steps=6, flip_budget=0.002):
     ref = hu.Model("oracle", cfg, seed=0)
     dev = hu.Model("hip", cfg, seed=0)
     rng = np.random.default_rng(11)
@@ -70,15 +69,29 @@ def test_every_full_width_layer_node_by_node_teacher_forced():
             x = one(0, layer, 0, x, offset, f"temporal layer {layer} offset {offset}")
     # Depth: the chain's first six steps as the cached graph runs them - step k uses weight set k and ring slot k, and attends to the rows
     # steps 0..k-1 of this same run left in the ring of 8 (lm.h:505-527)
-    for step in range(6):
+    for step in range(depth_steps):
         x = (rng.standard_normal(cfg.dep_dim) * 2).astype(np.float32)
         for layer in range(cfg.dep_layers):
             x = one(1, layer, step, x, step, f"depth layer {layer} step {step}")
     ref.free(); dev.free()
     print("full-width node parity:", tot, f"worst clean {worst_clean:.2e} worst tainted {worst_tainted:.2e}; flipped sites: {flipped_sites[:12]}")
     assert tot["clean"] >= 0.25 * tot["nodes"], "too few nodes were compared without a flip upstream"
-    assert tot["flips"] <= 0.002 * 4096 * tot["sites"] / 8, f"{tot['flips']} rounding flips over {tot['sites']} sites"
+    assert tot["flips"] <= flip_budget * cfg.dim * tot["sites"] / 8, f"{tot['flips']} rounding flips over {tot['sites']} sites"
     assert tot["hidden"] <= 0.25 * tot["fused_nodes"], f"{tot['hidden']} of {tot['fused_nodes']} fused outputs moved without a flip seen in the per-node run"
+
+
+def test_every_full_width_layer_node_by_node_teacher_forced():
+    _probe_every_layer(lm_only(hu.hot.moshika(L)))
+
+
+@pytest.mark.parametrize("lt", ["q8_0", "q4_0"])
+def test_2048_wide_q8_0_and_q4_0_layers_node_by_node(lt):
+    # the tts / stt width (dim 2048, 16 heads, feed-forward 5632; configs[1] is `-q q8_0`, Q4_0 is the loader's fall-back type) with Q8_0 / Q4_0 linears:
+    # activations round to Q8_0 blocks of 32 (F16 scale) in front of every mat-vec - the other rounding site ggml has besides Q8_K and the BF16 ring
+    cfg = lm_only(hu.hot.moshika(L))
+    cfg.dim, cfg.num_heads, cfg.num_layers, cfg.ffn_hidden, cfg.context = 2048, 16, 6, 5632, 500
+    cfg.linear_type = {"q8_0": 8, "q4_0": 2}[lt]
+    _probe_every_layer(cfg, depth_steps=3)
 
 
 def test_contractive_full_config_free_running_greedy_is_bit_exact():
