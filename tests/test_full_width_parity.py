@@ -104,10 +104,23 @@ def test_contractive_full_config_free_running_greedy_is_bit_exact():
     # update_scale 1/16). Asserted: logits within QSTEP_TOL = 3e-3 (eight such steps; measured max 1.8e-3, median 1.1e-3), greedy ids bit-exact. A sample may differ from the oracle's
     # only where the ORACLE's own logits hold the two candidates closer than twice the observed disagreement (at most 4 such provable ties per
     # run, each counted, after which both runs continue from the oracle's token).
-    QSTEP_TOL = 3e-3
     cfg = lm_only(hu.hot.moshika(L))
     cfg.update_scale = 1.0 / 256
-    steps = 32
+    _contractive_free_run(cfg, 32)
+
+
+@pytest.mark.parametrize("lt", ["q8_0", "q4_0"])
+def test_contractive_2048_wide_q8_0_q4_0_free_running_greedy_is_bit_exact(lt):
+    # the same free-running bar at the tts / stt width with Q8_0 / Q4_0 linears (16 layers, the full Depth chain): BASELINE.json configs[1] is `-q q8_0`
+    cfg = lm_only(hu.hot.moshika(L))
+    cfg.dim, cfg.num_heads, cfg.num_layers, cfg.ffn_hidden, cfg.context = 2048, 16, 16, 5632, 500
+    cfg.linear_type = {"q8_0": 8, "q4_0": 2}[lt]
+    cfg.update_scale = 1.0 / 256
+    _contractive_free_run(cfg, 32)
+
+
+def _contractive_free_run(cfg, steps):
+    QSTEP_TOL = 3e-3
     rng = np.random.default_rng(21)
     inputs = [rng.integers(0, cfg.card, cfg.n_q - cfg.dep_q).tolist() for _ in range(steps)]
     ref, dev = hu.Model("oracle", cfg, seed=0), hu.Model("hip", cfg, seed=0)
