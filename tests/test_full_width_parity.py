@@ -119,10 +119,18 @@ def test_contractive_2048_wide_q8_0_q4_0_free_running_greedy_is_bit_exact(lt):
     _contractive_free_run(cfg, 32)
 
 
+def test_contractive_personaplex_free_running_greedy_is_bit_exact():
+    # BASELINE.json configs[4]: 17 codebooks, 16 chained Depth steps whose ring of 8 wraps inside every frame, the other speaker's 8 codes per frame
+    cfg = lm_only(hu.hot.personaplex(L))
+    cfg.context = 200
+    cfg.update_scale = 1.0 / 256
+    _contractive_free_run(cfg, 16)
+
+
 def _contractive_free_run(cfg, steps):
     QSTEP_TOL = 3e-3
     rng = np.random.default_rng(21)
-    inputs = [rng.integers(0, cfg.card, cfg.n_q - cfg.dep_q).tolist() for _ in range(steps)]
+    inputs = [rng.integers(0, cfg.card, cfg.n_q - cfg.io_dep_q).tolist() for _ in range(steps)]
     ref, dev = hu.Model("oracle", cfg, seed=0), hu.Model("hip", cfg, seed=0)
     te, de, ties, seen = [], [], 0, set()
     for i, ia in enumerate(inputs):
