@@ -760,7 +760,7 @@ void make_transformer(moshi_hot_model * m, Transformer & tr, const std::string &
             L.norm_cross = { false, 0.0f, W.add(p + "norm_cross.weight", GGML_TYPE_F32, dim, 1, 1, ones),
                              W.add(p + "norm_cross.bias", GGML_TYPE_F32, dim, 1, 1, [](T t, Rng & r, std::vector<uint8_t> & o) { gen_normal(t, r, o, 0.02f); }) };
             L.cross_in = W.add(p + "cross_attention.in_projs.0.weight", wtype, dim, 3 * dim, 1, qgen(s_in));
-            L.cross_out = W.add(p + "cross_attention.out_projs.0.weight", wtype, dim, dim, 1, qgen(s_in));
+            L.cross_out = W.add(p + "cross_attention.out_projs.0.weight", wtype, dim, dim, 1, qgen(s_in * upd));   // a residual update like out_proj / linear_out
             L.k_cross = state(m, GGML_TYPE_F32, dim / heads, cross_len, heads);
             L.v_cross = state(m, GGML_TYPE_F32, dim / heads, cross_len, heads);
         }

@@ -134,11 +134,25 @@ def test_contractive_stt_shaped_free_running_text_is_bit_exact():
     _contractive_free_run(cfg, 32)
 
 
-def _contractive_free_run(cfg, steps):
-    QSTEP_TOL = 3e-3
+def test_contractive_tts_shaped_free_running_greedy_is_bit_exact():
+    # BASELINE.json configs[1] at full size (hot.tts_like: dim 2048, 16 layers with cross-attention over a 64-row condition, demuxed text embeddings,
+    # low-rank Depth embeddings, 32 chained Depth steps on a per-step weight schedule, delay_steps 16, Q8_0 everywhere), the text stream forced by a hook
+    # as the TTS state machine does (lm.h:880-900). 24 frames: 16 with the Depth transformer held back (src/moshi.cpp:905), 8 with it running.
+    cfg = lm_only(hu.hot.tts_like(L))
+    cfg.update_scale = 1.0 / 256
+
+    def setup(m):
+        hu.set_conditions(m, cfg)
+        hu.set_text_hook(m, lambda offset, sampled: int((offset * 13) % cfg.text_card))
+    _contractive_free_run(cfg, 24, setup=setup)
+
+
+def _contractive_free_run(cfg, steps, setup=None, QSTEP_TOL=3e-3):
     rng = np.random.default_rng(21)
     inputs = [rng.integers(0, cfg.card, cfg.n_q - cfg.io_dep_q).tolist() for _ in range(steps)]
     ref, dev = hu.Model("oracle", cfg, seed=0), hu.Model("hip", cfg, seed=0)
+    if setup:
+        setup(ref); setup(dev)
     te, de, ties, seen = [], [], 0, set()
     for i, ia in enumerate(inputs):
         ra, rb = ref.lm_step(ia), dev.lm_step(ia)
@@ -151,8 +165,8 @@ def _contractive_free_run(cfg, steps):
             assert float(la[ta] - la[tb]) <= 2 * te[-1] * float(np.abs(la).max()), f"frame {i}: text token {tb} vs {ta} is not a tie in the oracle's logits"
             ties += 1; diverged = True
         for k in range(cfg.dep_q):
-            if diverged:
-                break                       # later Depth steps are conditioned on the diverged token
+            if diverged or da[k] == -1:
+                break                       # later Depth steps are conditioned on the diverged token; -1: the Depth transformer is held back (delay_steps)
             xa, xb = ref.read(f"dep_logits{k}", cfg.card), dev.read(f"dep_logits{k}", cfg.card)
             e = hu.rel_err(xa, xb)
             de.append(e)
@@ -167,7 +181,7 @@ def _contractive_free_run(cfg, steps):
             dev.force_last(ta, da)          # continue both runs from the oracle's samples
         else:
             assert ra == rb, f"frame {i}: delayed outputs differ"
-        seen.update(da)
+        seen.update(t for t in da if t >= 0)
     assert dev.stats().graph_replays > 0
     ref.free(); dev.free()
     assert ties <= 4, f"{ties} near-tie divergences in {steps} frames"
