@@ -1,0 +1,44 @@
+"""bench.py's output contract: ONE JSON line on stdout with the fields the driver reads (metric / value / unit / n_gpus / steps / warmup / ms_per_step /
+higher_is_better / scaling / vs_baseline / dtype / data / config.workload) plus `roofline` and, at N = 1, `cpu_baseline`."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_bench_parses_its_arguments_and_hashes_its_sources():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--help"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and "--serial" in out.stdout and "--shard" in out.stdout and "--gpus" in out.stdout
+    sys.path.insert(0, ROOT)
+    import bench
+    sha = bench.source_sha()
+    assert len(sha) == 16 and sha == bench.source_sha()
+    with open(os.path.join(ROOT, "profiles", "r02_pmc_fetch_size.json")) as f:
+        pmc = json.load(f)
+    assert {"source_sha", "matvec_q4k_kernel"} <= set(pmc) and pmc["matvec_q4k_kernel"]["fetch_bytes_per_launch"] > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("extra", [[], ["--serial"]])
+def test_bench_prints_one_json_line_with_the_contract_fields(extra):
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "6", "--warmup", "5", "--no-cpu-baseline", "--no-extras"] + extra
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert k in d, k
+    assert d["unit"] == "frames/s" and d["n_gpus"] == 1 and d["steps"] == 6 and d["warmup"] == 5 and d["higher_is_better"] is True and d["scaling"] == "weak"
+    assert d["vs_baseline"] is None and d["data"] == "synthetic" and "moshika" in d["metric"] and "q4_k" in d["metric"]
+    assert "workload" in d["config"] and "model" not in d["config"] and d["config"]["frame_loop"].startswith("serial") == bool(extra)
+    assert 50 < d["value"] < 2000 and abs(d["ms_per_step"] * d["value"] - 1000) < 5
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and r["kernel"] == "matvec_q4k_kernel"
+    assert r["launches_per_frame"] == 337 and 0.05 < r["frac"] < 1.0
+    if not extra:
+        assert d["serial_loop"]["value"] < d["value"]          # the two-stream run-ahead loop beats the serial one on the same model
