@@ -226,6 +226,13 @@ def test_pipelined_loop_with_half_a_codec_equals_the_serial_one(shape):
             assert b[3] is not None and np.array_equal(a[3], b[3]), f"frame {k}: pcm differs"
 
 
+def test_temporal_stack_on_the_device_matches_the_pytorch_restatement():
+    # tests/golden/temporal_stack.npz was computed by PyTorch (tests/golden/make_module_golden.py), not by the oracle: the MI355X kernels (fused and one
+    # per node) against an independent implementation of the architecture, F32 weights, 9 frames across the ring wrap
+    import test_oracle_golden as tg
+    assert tg._run_temporal_stack_fixture("hip", 2e-6) < 1e-6
+
+
 def test_mimi_codec_crosses_t2_mask_quirk():
     # Mimi transformers have T = 2, capacity 250: after 125 frames bias_pattern_index takes its second branch
     # (SURVEY.md §5 quirk). Codes in -> pcm out, 130 frames, decoder only.

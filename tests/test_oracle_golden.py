@@ -172,3 +172,30 @@ def test_activation_quantisers_exact():
     blk = out.reshape(-1, 34)
     assert np.array_equal(blk[:, 2:].view(np.int8).reshape(-1), Q["x_q80_q"].reshape(-1))
     assert np.array_equal(blk[:, 0:2].view(np.float16).astype(np.float32).reshape(-1), Q["x_q80_d"])
+
+
+# ---- module level: the Temporal transformer stack stepped through the frame driver vs a PyTorch restatement of the architecture ------------------------------
+def _run_temporal_stack_fixture(kind, tol):
+    """tests/golden/temporal_stack.npz (generator: tests/golden/make_module_golden.py): 9 provided frames through a 2-layer F32 model whose ring of 6 wraps;
+    the driver's stack input must equal the stored one bit for bit (same tokens, same synthetic weights), its outputs the PyTorch ones within tol."""
+    import hot_util as hu
+    M = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "temporal_stack.npz"))
+    cfg = hu.hot.tiny(hu.L, linear_type=F32, embed_type=F32, layers=2, context=6)
+    cfg.enable_mimi_encoder = cfg.enable_mimi_decoder = 0
+    m = hu.Model(kind, cfg, seed=0)
+    worst = 0.0
+    for step, tokens in enumerate(M["tokens"]):
+        m.lm_step_n(tokens.tolist())
+        assert np.array_equal(m.read("transformer_in", cfg.dim), M["x_in"][step]), f"step {step}: the stack's input differs from the fixture's"
+        e1 = hu.rel_err(M["transformer_out"][step], m.read("transformer_out", cfg.dim))
+        e2 = hu.rel_err(M["text_logits"][step], m.read("text_logits", cfg.text_card))
+        worst = max(worst, e1, e2)
+        assert e1 < tol and e2 < tol, f"step {step}: transformer_out {e1:.2e}, text logits {e2:.2e} vs the PyTorch restatement"
+    m.free()
+    return worst
+
+
+def test_temporal_stack_through_the_driver_matches_the_pytorch_restatement():
+    # RMSNorm, in_proj, interleaved RoPE, BF16 ring rows written with set_rows, masked soft_max, P x V, out_proj, gated SiLU FFN, residuals, out_norm,
+    # text_linear - the driver's graph construction (restating transformer.h / rope.h / gating.h / torch.h) on the oracle's op semantics
+    assert _run_temporal_stack_fixture("oracle", 1e-6) < 5e-7
