@@ -233,6 +233,13 @@ def test_temporal_stack_on_the_device_matches_the_pytorch_restatement():
     assert tg._run_temporal_stack_fixture("hip", 2e-6) < 1e-6
 
 
+def test_streaming_mimi_encoder_on_the_device_matches_the_offline_pytorch_restatement():
+    # the device's streaming encoder against the PyTorch fixture (computed offline over the whole signal, not by the oracle)
+    import test_oracle_golden as tg
+    same, worst = tg._run_mimi_encoder_fixture("hip")
+    assert same >= 0.9 and worst < 1e-2, (same, worst)      # (a code may sit on a centroid tie; the CPU oracle reproduces all of them)
+
+
 def test_mimi_codec_crosses_t2_mask_quirk():
     # Mimi transformers have T = 2, capacity 250: after 125 frames bias_pattern_index takes its second branch
     # (SURVEY.md §5 quirk). Codes in -> pcm out, 130 frames, decoder only.

@@ -199,3 +199,31 @@ def test_temporal_stack_through_the_driver_matches_the_pytorch_restatement():
     # RMSNorm, in_proj, interleaved RoPE, BF16 ring rows written with set_rows, masked soft_max, P x V, out_proj, gated SiLU FFN, residuals, out_norm,
     # text_linear - the driver's graph construction (restating transformer.h / rope.h / gating.h / torch.h) on the oracle's op semantics
     assert _run_temporal_stack_fixture("oracle", 1e-6) < 5e-7
+
+
+# ---- module level: the streaming Mimi encoder through the frame driver vs an OFFLINE PyTorch restatement ------------------------------------------------------
+def _run_mimi_encoder_fixture(kind):
+    """tests/golden/mimi_encoder.npz (generator: tests/golden/make_mimi_golden.py): 5 frames of audio; PyTorch ran the whole signal at once through causal
+    convolutions, causal attention and the split residual VQ. -> (fraction of codes equal, worst latent error of the frames)"""
+    import hot_util as hu
+    M = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "mimi_encoder.npz"))
+    cfg = hu.hot.tiny(hu.L)
+    cfg.enable_lm = cfg.enable_mimi_decoder = 0
+    m = hu.Model(kind, cfg, seed=0)
+    n = M["codes"].shape[0]
+    same, worst = 0, 0.0
+    for i in range(n):
+        codes = m.mimi_encode(M["pcm"][i * 1920:(i + 1) * 1920])
+        same += int(sum(int(a == b) for a, b in zip(codes, M["codes"][i].tolist())))
+        worst = max(worst, hu.rel_err(M["latent_first"][:, i], m.read("enc_latent_first", 256)))
+    m.free()
+    return same / M["codes"].size, worst
+
+
+def test_streaming_mimi_encoder_matches_the_offline_pytorch_restatement():
+    # frame-by-frame streaming (carried conv tails, BF16 ring attention, T = 2 rows per frame) == the whole signal through causal convolutions and causal
+    # attention; ELU, GELU through ggml's F16 table, LayerNorm, layer scale, F16 im2col convolutions, nearest-centroid residual VQ. The synthetic network is
+    # sensitive (a 1e-7 perturbation of one convolution's accumulation moves the latent by 3e-3, tests/golden/make_mimi_golden.py), so the latent bar is 1e-2;
+    # the codes - what the codec hands on - are equal.
+    same, worst = _run_mimi_encoder_fixture("oracle")
+    assert same == 1.0 and worst < 1e-2, (same, worst)
