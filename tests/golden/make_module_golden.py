@@ -65,6 +65,22 @@ def main():
                       gin=weight(m, p + "gating.linear_in.weight", 2 * F, D), gout=weight(m, p + "gating.linear_out.weight", D, F)))
     out_norm = weight(m, "lm.out_norm.alpha", 1, D)[0]
     text_linear = weight(m, "lm.text_linear.weight", cfg.text_card, D)
+    # the Depth transformer: dep_q chained steps per frame, step k with its own weight set k, attending to the rows steps 0 .. k-1 of the same frame
+    # left in a ring of dep_q slots (no RoPE); input of step k = depformer_in[k] . transformer_out + embedding of the previous step's token (lm.h:446-553)
+    DD, DH_, DF, Q = cfg.dep_dim, cfg.dep_heads, cfg.dep_ffn_hidden, cfg.dep_q
+    DW = []
+    for l in range(cfg.dep_layers):
+        p = f"lm.depformer.layers.{l}."
+        DW.append(dict(n1=weight(m, p + "norm1.alpha", 1, DD)[0], n2=weight(m, p + "norm2.alpha", 1, DD)[0],
+                       inp=[weight(m, p + f"self_attn.in_projs.{k}.weight", 3 * DD, DD) for k in range(Q)],
+                       out=[weight(m, p + f"self_attn.out_projs.{k}.weight", DD, DD) for k in range(Q)],
+                       gin=[weight(m, p + f"gating.{k}.linear_in.weight", 2 * DF, DD) for k in range(Q)],
+                       gout=[weight(m, p + f"gating.{k}.linear_out.weight", DD, DF) for k in range(Q)]))
+    dep_in = [weight(m, f"lm.depformer_in.{k}.weight", DD, D) for k in range(Q)]
+    dep_heads_w = [weight(m, f"lm.linears.{k}.weight", cfg.card, DD) for k in range(Q)]
+    dep_text_emb = weight(m, "lm.depformer_text_emb.weight", cfg.text_card + 1, DD)
+    dep_emb = [weight(m, f"lm.depformer_emb.{k}.weight", cfg.card + 1, DD) for k in range(Q - 1)]
+    dep_logits, dep_tokens, text_tokens = [], [], []
     kc = [torch.zeros(H, Cap, Dh) for _ in W]
     vc = [torch.zeros(H, Cap, Dh) for _ in W]
     theta = torch.exp(-np.log(float(cfg.max_period)) * torch.arange(Dh // 2, dtype=torch.float32) / (Dh // 2))
@@ -104,10 +120,46 @@ def main():
         outs.append(y.numpy().copy())
         logits.append(dot_f32(text_linear, y).numpy().copy())
         got_out, got_logits = m.read("transformer_out", D), m.read("text_logits", cfg.text_card)
+        # ---- Depth chain of this frame, fed the DRIVER's transformer_out and sampled text token (stored in the fixture as inputs) ----
+        t_out = torch.from_numpy(got_out.copy())
+        text_tok, drv_audio = m.last_raw()
+        text_tokens.append(text_tok)
+        DDh = DD // DH_
+        dkc = [torch.zeros(DH_, Q, DDh) for _ in DW]
+        dvc = [torch.zeros(DH_, Q, DDh) for _ in DW]
+        prev, frame_logits, frame_toks = None, [], []
+        for k in range(Q):
+            emb = dep_text_emb[text_tok] if k == 0 else dep_emb[k - 1][prev]
+            xd = dot_f32(dep_in[k], t_out) + emb
+            for l, w in enumerate(DW):
+                h = rms_norm(xd, w["n1"], 1e-8)
+                qkv = dot_f32(w["inp"][k], h)
+                q, kk, v = qkv[:DD].view(DH_, DDh), qkv[DD:2 * DD].view(DH_, DDh), qkv[2 * DD:].view(DH_, DDh)
+                dkc[l][:, k] = bf16(kk); dvc[l][:, k] = bf16(v)
+                qb = bf16(q)
+                sc_ = (dkc[l][:, :k + 1] * qb[:, None, :]).to(torch.float64).sum(-1).to(torch.float32) * torch.tensor(1.0 / np.sqrt(DDh), dtype=torch.float32)
+                e = torch.exp(sc_ - sc_.max(-1, keepdim=True).values)
+                pb = bf16(e * (1.0 / e.to(torch.float64).sum(-1, keepdim=True)).to(torch.float32))
+                o = (dvc[l][:, :k + 1] * pb[:, :, None]).to(torch.float64).sum(1).to(torch.float32)
+                xd = xd + dot_f32(w["out"][k], o.reshape(DD))
+                h = rms_norm(xd, w["n2"], 1e-8)
+                g_ = dot_f32(w["gin"][k], h)
+                left, right = g_[:DF], g_[DF:]
+                xd = xd + dot_f32(w["gout"][k], (left / (1.0 + torch.exp(-left))) * right)
+            lg = dot_f32(dep_heads_w[k], xd)
+            frame_logits.append(lg.numpy().copy())
+            mx = lg.max()
+            prev = int(torch.nonzero(lg == mx)[-1])          # ggml_vec_argmax_f32: the last maximum
+            frame_toks.append(prev)
+        dep_logits.append(np.array(frame_logits)); dep_tokens.append(frame_toks)
+        de = max(hu.rel_err(frame_logits[k], m.read(f"dep_logits{k}", cfg.card)) for k in range(Q))
+        print(f"         depth chain: worst logits rel err {de:.2e}; tokens pytorch {frame_toks} driver {drv_audio}")
+        assert frame_toks == drv_audio
         print(f"step {step}: transformer_out rel err {hu.rel_err(outs[-1], got_out):.2e}, text logits {hu.rel_err(logits[-1], got_logits):.2e}")
     m.free()
     np.savez_compressed(os.path.join(HERE, "temporal_stack.npz"), tokens=np.array(toks, np.int32), x_in=np.array(xs), transformer_out=np.array(outs),
-                        text_logits=np.array(logits))
+                        text_logits=np.array(logits), text_tokens=np.array(text_tokens, np.int32), dep_logits=np.array(dep_logits),
+                        dep_tokens=np.array(dep_tokens, np.int32))
     print("wrote temporal_stack.npz")
 
 

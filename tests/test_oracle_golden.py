@@ -191,13 +191,21 @@ def _run_temporal_stack_fixture(kind, tol):
         e2 = hu.rel_err(M["text_logits"][step], m.read("text_logits", cfg.text_card))
         worst = max(worst, e1, e2)
         assert e1 < tol and e2 < tol, f"step {step}: transformer_out {e1:.2e}, text logits {e2:.2e} vs the PyTorch restatement"
+        # the chained Depth transformer of the same frame (PyTorch was fed the stored transformer_out and text token: the driver must have produced those)
+        text_tok, audio = m.last_raw()
+        assert text_tok == int(M["text_tokens"][step]) and audio == M["dep_tokens"][step].tolist(), f"step {step}: tokens {text_tok} {audio}"
+        for k in range(cfg.dep_q):
+            e3 = hu.rel_err(M["dep_logits"][step][k], m.read(f"dep_logits{k}", cfg.card))
+            worst = max(worst, e3)
+            assert e3 < tol, f"step {step} depth step {k}: logits {e3:.2e} vs the PyTorch restatement"
     m.free()
     return worst
 
 
 def test_temporal_stack_through_the_driver_matches_the_pytorch_restatement():
     # RMSNorm, in_proj, interleaved RoPE, BF16 ring rows written with set_rows, masked soft_max, P x V, out_proj, gated SiLU FFN, residuals, out_norm,
-    # text_linear - the driver's graph construction (restating transformer.h / rope.h / gating.h / torch.h) on the oracle's op semantics
+    # text_linear, then the chained Depth transformer (per-step weight sets, ring of dep_q slots, embedding of the previous step's token, greedy samples) -
+    # the driver's graph construction (restating transformer.h / rope.h / gating.h / torch.h) on the oracle's op semantics
     assert _run_temporal_stack_fixture("oracle", 1e-6) < 5e-7
 
 
