@@ -41,7 +41,8 @@ def tensor(m, name):
         a = np.zeros(n, np.float32)
     L.ggml_backend_tensor_get(t, a.ctypes.data, 0, a.nbytes)
     a = a.astype(np.float32).reshape(shape)                                        # ggml ne (k, cin, cout, 1) -> [1, cout, cin, k]
-    while a.ndim > 1 and a.shape[0] == 1:
+    keep = 3 if (".conv" in name or "_proj.weight" in name) and name.endswith("weight") else 1
+    while a.ndim > keep and a.shape[0] == 1:
         a = a[0]
     return torch.from_numpy(a.copy())
 
@@ -130,6 +131,52 @@ def rvq_encode(m, stack, n_levels, x):
     return torch.stack(codes), lat
 
 
+def causal_conv_transpose(x, w, b, stride, groups=1):
+    """x [Cin, T] -> [Cout, T * stride]: the full transposed convolution with its last k - stride samples (the part a later input would still add to) cut off"""
+    k = w.shape[-1]
+    y = F.conv_transpose1d(x.to(torch.float64)[None], w.to(torch.float64), None, stride=stride, groups=groups)[0].to(torch.float32)
+    y = y[:, :x.shape[1] * stride]
+    return y + b[:, None] if b is not None else y
+
+
+def decoder_main():
+    """tests/golden/mimi_decoder.npz: codes -> RVQ decode (sum of centroids, 1x1 output projections) -> depthwise stride-2 upsampling -> 8 transformer layers ->
+    SEANet decoder (transposed convolutions with overlap-add, residual blocks) -> 1920 samples per frame; PyTorch offline vs the driver streaming"""
+    cfg = hu.hot.tiny(L)
+    cfg.enable_lm = cfg.enable_mimi_encoder = 0
+    m = hu.Model("oracle", cfg, seed=0)
+    rng = np.random.default_rng(9)
+    codes = rng.integers(0, cfg.mimi_codebook_size, (FRAMES, cfg.mimi_n_q)).astype(np.int32)
+    got = np.concatenate([m.mimi_decode(c.tolist()) for c in codes])
+    w = lambda n: tensor(m, n)
+
+    def rvq_decode(stack, cs):                     # cs [levels, T]
+        q = None
+        for i in range(cs.shape[0]):
+            e = w(f"mimi.quantizer.{stack}.vq.layers.{i}._codebook.embedding")[torch.from_numpy(cs[i].astype(np.int64))].T      # [256, T]
+            q = e if q is None else q + e
+        return causal_conv(q, w(f"mimi.quantizer.{stack}.output_proj.weight"), None, 1)
+    ct = codes.T
+    x = rvq_decode("rvq_first", ct[:1]) + rvq_decode("rvq_rest", ct[1:])                                                    # [512, FRAMES]
+    x = causal_conv_transpose(x, w("mimi.upsample.convtr.weight"), None, 2, groups=512)                                     # [512, 2 FRAMES]
+    x = transformer(m, "mimi.decoder_transformer.transformer", x)
+    x = elu(causal_conv(x, w("mimi.decoder.model.0.conv.weight"), w("mimi.decoder.model.0.conv.bias").reshape(-1), 1))
+    for i, st in enumerate((8, 6, 5, 4)):
+        p = f"mimi.decoder.model.{2 + 3 * i}.convtr."
+        x = causal_conv_transpose(x, w(p + "weight"), w(p + "bias").reshape(-1), st)
+        p = f"mimi.decoder.model.{3 + 3 * i}.block."
+        v = causal_conv(elu(x), w(p + "1.conv.weight"), w(p + "1.conv.bias").reshape(-1), 1)
+        v = causal_conv(elu(v), w(p + "3.conv.weight"), w(p + "3.conv.bias").reshape(-1), 1)
+        x = elu(x + v)
+    x = causal_conv(x, w("mimi.decoder.model.14.conv.weight"), w("mimi.decoder.model.14.conv.bias").reshape(-1), 1)        # [1, 1920 FRAMES]
+    m.free()
+    pcm = x[0].numpy()
+    for i in range(FRAMES):
+        print(f"decoder frame {i}: pcm rel err {hu.rel_err(pcm[i * 1920:(i + 1) * 1920], got[i * 1920:(i + 1) * 1920]):.2e}")
+    np.savez_compressed(os.path.join(HERE, "mimi_decoder.npz"), codes=codes, pcm=pcm)
+    print("wrote mimi_decoder.npz")
+
+
 def main():
     cfg = make_cfg()
     m = hu.Model("oracle", cfg, seed=0)
@@ -164,3 +211,4 @@ def main():
 
 if __name__ == "__main__":
     main()
+    decoder_main()

@@ -240,6 +240,11 @@ def test_streaming_mimi_encoder_on_the_device_matches_the_offline_pytorch_restat
     assert same >= 0.9 and worst < 1e-2, (same, worst)      # (a code may sit on a centroid tie; the CPU oracle reproduces all of them)
 
 
+def test_streaming_mimi_decoder_on_the_device_matches_the_offline_pytorch_restatement():
+    import test_oracle_golden as tg
+    assert tg._run_mimi_decoder_fixture("hip") < 3e-3
+
+
 def test_mimi_codec_crosses_t2_mask_quirk():
     # Mimi transformers have T = 2, capacity 250: after 125 frames bias_pattern_index takes its second branch
     # (SURVEY.md §5 quirk). Codes in -> pcm out, 130 frames, decoder only.

@@ -235,3 +235,24 @@ def test_streaming_mimi_encoder_matches_the_offline_pytorch_restatement():
     # the codes - what the codec hands on - are equal.
     same, worst = _run_mimi_encoder_fixture("oracle")
     assert same == 1.0 and worst < 1e-2, (same, worst)
+
+
+def _run_mimi_decoder_fixture(kind):
+    """tests/golden/mimi_decoder.npz: 5 frames of codes; PyTorch decoded them offline (RVQ sums, 1x1 projections, depthwise upsampling, transformer, transposed
+    convolutions cut causally, residual blocks). -> worst per-frame PCM error of the driver's streaming decoder"""
+    import hot_util as hu
+    M = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "mimi_decoder.npz"))
+    cfg = hu.hot.tiny(hu.L)
+    cfg.enable_lm = cfg.enable_mimi_encoder = 0
+    m = hu.Model(kind, cfg, seed=0)
+    worst = 0.0
+    for i, c in enumerate(M["codes"]):
+        worst = max(worst, hu.rel_err(M["pcm"][i * 1920:(i + 1) * 1920], m.mimi_decode(c.tolist())))
+    m.free()
+    return worst
+
+
+def test_streaming_mimi_decoder_matches_the_offline_pytorch_restatement():
+    # streaming transposed convolutions (overlap-add with the carried partial, conv.h:240-310) == the full transposed convolution cut causally; the depthwise
+    # upsampling written as per-tap multiplies (conv.h:262-278) == a grouped conv_transpose1d
+    assert _run_mimi_decoder_fixture("oracle") < 2e-3
