@@ -292,6 +292,22 @@ def test_sampler_chain_top_k_with_given_noise():
     gu.compare(build)
 
 
+@pytest.mark.parametrize("n,k,temp", [(2048, 250, 0.8), (32000, 25, 0.7)])
+def test_fused_sampler_against_the_numpy_restatement(n, k, temp):
+    # the fused sampling kernel (soft-max, radix select of the k-th largest, rank sort, p / noise, last-maximum arg-max) against the numpy restatement of
+    # moshi_sample_token directly - the bench's two shapes (audio: 2048 logits, top-k 250, temperature 0.8; text: 32000, 25, 0.7), ties inside the top-k included
+    import test_oracle_golden as tg
+    r = np.random.default_rng(n + k + 1)
+    for trial in range(4):
+        logits = (r.standard_normal((1, n)) * 3).astype(np.float32)
+        if trial == 3:
+            logits[0, 11] = logits[0, 900] = logits[0, 5] = logits.max() + 0.5
+        noise = r.exponential(1.0, (1, k)).astype(np.float32)
+        (tok, idx), st = gu.run_graph("hip", lambda g: tg._sample_token_graph(g, logits, noise, temp, k))
+        want_tok, want_idx = tg._sample_token_numpy(logits[0], noise[0], temp, k)
+        assert int(np.asarray(tok).reshape(-1)[0]) == want_tok, trial
+
+
 # ---- the large-matrix launch shape of the block mat-vec (one workgroup of 8 waves per CU, >= 1536 tiles) and the prologue /
 # ---- epilogue variants that only occur at moshika's real widths
 @pytest.mark.parametrize("wtype", [Q4_K, Q8_0, Q4_0])

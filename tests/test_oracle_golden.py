@@ -256,3 +256,43 @@ def test_streaming_mimi_decoder_matches_the_offline_pytorch_restatement():
     # streaming transposed convolutions (overlap-add with the carried partial, conv.h:240-310) == the full transposed convolution cut causally; the depthwise
     # upsampling written as per-tap multiplies (conv.h:262-278) == a grouped conv_transpose1d
     assert _run_mimi_decoder_fixture("oracle") < 2e-3
+
+
+# ---- sampling with temperature (moshi_sample_token, sampling.h:4-64) vs a numpy restatement --------------------------------------------------------------
+def _sample_token_graph(g, logits, noise, temp, k):
+    lg = g.input(logits)
+    probs = g.soft_max(g.scale(lg, 1.0 / temp))
+    indices = g.argsort_top_k(probs, k)
+    rows = g.get_rows(g.cont(g.permute(probs, 1, 0, 2, 3)), indices)
+    p2 = g.permute(rows, 1, 0, 2, 3)
+    in2 = g.reshape_2d(p2, p2.contents.ne[0], p2.contents.ne[1] * p2.contents.ne[2] * p2.contents.ne[3])
+    q = g.div(in2, g.input(noise))
+    nxt = g.argmax(q)
+    nxt4 = g.reshape_4d(nxt, nxt.contents.ne[0], p2.contents.ne[1], p2.contents.ne[2], p2.contents.ne[3])
+    return [g.get_rows(g.cont(g.permute(indices, 1, 0, 2, 3)), nxt4), g.cont(indices)]
+
+
+def _sample_token_numpy(logits, noise, temp, k):
+    """softmax(logits / temp) -> the k largest in descending order (equal values: ascending index) -> divide by the exponential noise -> arg-max (the last
+    maximum) -> that candidate's index: the Gumbel-style top-k sampler of the reference, with the noise given"""
+    z = (logits.astype(np.float32) * np.float32(1.0 / temp)).astype(np.float32)
+    e = np.exp(z - z.max()).astype(np.float32)
+    p = (e * np.float32(1.0 / e.astype(np.float64).sum())).astype(np.float32)
+    order = np.lexsort((np.arange(p.size), -p))[:k]
+    q = (p[order] / noise).astype(np.float32)
+    j = int(np.flatnonzero(q == q.max())[-1])
+    return int(order[j]), order
+
+
+@pytest.mark.parametrize("n,k,temp", [(2048, 250, 0.8), (32000, 25, 0.7), (500, 10, 1.3)])
+def test_sample_token_chain_matches_the_numpy_restatement(n, k, temp):
+    r = np.random.default_rng(n + k)
+    for trial in range(3):
+        logits = (r.standard_normal((1, n)) * 3).astype(np.float32)
+        if trial == 2:
+            logits[0, 7] = logits[0, 100] = logits[0, 3] = logits.max() + 1.0          # equal probabilities inside the top-k: index order decides
+        noise = r.exponential(1.0, (1, k)).astype(np.float32)
+        tok, idx = oracle(lambda g: _sample_token_graph(g, logits, noise, temp, k))
+        want_tok, want_idx = _sample_token_numpy(logits[0], noise[0], temp, k)
+        assert np.array_equal(np.asarray(idx).reshape(-1), want_idx), trial
+        assert int(np.asarray(tok).reshape(-1)[0]) == want_tok, trial
