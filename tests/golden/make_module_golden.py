@@ -25,8 +25,14 @@ F32 = hu.pkg.F32
 STEPS = 9
 
 
+sys.path.insert(0, HERE)
+import block_arith as ba  # noqa: E402
+
+LINEAR = F32                   # set by main(): F32, or Q4_K for the quantised fixture (every linear a Q4_K matrix, activations rounded to Q8_K)
+
+
 def make_cfg():
-    cfg = hu.hot.tiny(L, linear_type=F32, embed_type=F32, layers=2, context=6)     # ring of 6: steps 6.. wrap it
+    cfg = hu.hot.tiny(L, linear_type=LINEAR, embed_type=F32, layers=2, context=6)     # ring of 6: steps 6.. wrap it
     cfg.enable_mimi_encoder = cfg.enable_mimi_decoder = 0
     return cfg
 
@@ -34,6 +40,11 @@ def make_cfg():
 def weight(m, name, rows, cols):
     t = C.cast(L.moshi_hot_weight(m.m, name.encode()), hu.pkg.TP)
     assert t, name
+    if t.contents.type == hu.pkg.Q4_K:          # raw super-blocks: the products go through tests/golden/block_arith.py (numpy, from the block layout alone)
+        raw = np.zeros((rows, cols // 256 * 144), np.uint8)
+        L.ggml_backend_tensor_get(t, raw.ctypes.data, 0, raw.nbytes)
+        return raw
+    assert t.contents.type == F32, (name, t.contents.type)
     w = np.zeros((rows, cols), np.float32)
     L.ggml_backend_tensor_get(t, w.ctypes.data, 0, w.nbytes)
     return torch.from_numpy(w)
@@ -43,7 +54,9 @@ def bf16(x):
     return x.to(torch.bfloat16).to(torch.float32)
 
 
-def dot_f32(W, x):          # rows of W against x: float products, double sums (ggml_vec_dot_f32)
+def dot_f32(W, x):          # rows of W against x: float products, double sums (ggml_vec_dot_f32); Q4_K rows: x -> Q8_K, integer sub-block dots
+    if isinstance(W, np.ndarray):
+        return torch.from_numpy(ba.matvec_q4k(W, x.numpy().astype(np.float32)))
     return (W * x[None, :]).to(torch.float64).sum(-1).to(torch.float32)
 
 
@@ -52,7 +65,9 @@ def rms_norm(x, alpha, eps):
     return alpha * (x * (1.0 / torch.sqrt(ms.to(torch.float32) + eps)))
 
 
-def main():
+def main(linear=F32, out_name="temporal_stack.npz"):
+    global LINEAR
+    LINEAR = linear
     cfg = make_cfg()
     m = hu.Model("oracle", cfg, seed=0)
     D, H, Cap, F = cfg.dim, cfg.num_heads, cfg.context, cfg.ffn_hidden
@@ -151,17 +166,19 @@ def main():
             mx = lg.max()
             prev = int(torch.nonzero(lg == mx)[-1])          # ggml_vec_argmax_f32: the last maximum
             frame_toks.append(prev)
+            prev = drv_audio[k]                              # (teacher-forced: the next step embeds the DRIVER's token, stored in the fixture)
         dep_logits.append(np.array(frame_logits)); dep_tokens.append(frame_toks)
         de = max(hu.rel_err(frame_logits[k], m.read(f"dep_logits{k}", cfg.card)) for k in range(Q))
         print(f"         depth chain: worst logits rel err {de:.2e}; tokens pytorch {frame_toks} driver {drv_audio}")
-        assert frame_toks == drv_audio
+        assert frame_toks == drv_audio or linear != F32, "F32: the tokens must be identical"
         print(f"step {step}: transformer_out rel err {hu.rel_err(outs[-1], got_out):.2e}, text logits {hu.rel_err(logits[-1], got_logits):.2e}")
     m.free()
-    np.savez_compressed(os.path.join(HERE, "temporal_stack.npz"), tokens=np.array(toks, np.int32), x_in=np.array(xs), transformer_out=np.array(outs),
+    np.savez_compressed(os.path.join(HERE, out_name), tokens=np.array(toks, np.int32), x_in=np.array(xs), transformer_out=np.array(outs),
                         text_logits=np.array(logits), text_tokens=np.array(text_tokens, np.int32), dep_logits=np.array(dep_logits),
                         dep_tokens=np.array(dep_tokens, np.int32))
-    print("wrote temporal_stack.npz")
+    print("wrote", out_name)
 
 
 if __name__ == "__main__":
     main()
+    main(hu.pkg.Q4_K, "temporal_stack_q4k.npz")

@@ -175,6 +175,36 @@ def test_activation_quantisers_exact():
 
 
 # ---- module level: the Temporal transformer stack stepped through the frame driver vs a PyTorch restatement of the architecture ------------------------------
+def _run_quantised_stack_fixture(kind):
+    """tests/golden/temporal_stack_q4k.npz: the same frames with every linear a Q4_K matrix; the restatement's products go through tests/golden/block_arith.py
+    (numpy, written from the block layouts: Q8_K activation rounding, integer sub-block dots, float scale combination). Two implementations that agree to 2e-7
+    part by a quantiser step wherever an activation sits on a rounding tie (two such events in the fixture's own comparison), so: every quantity within 3e-2,
+    the median at float noise, few events. -> (all errors, tokens equal?)"""
+    import hot_util as hu
+    M = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "temporal_stack_q4k.npz"))
+    cfg = hu.hot.tiny(hu.L, linear_type=hu.pkg.Q4_K, embed_type=F32, layers=2, context=6)
+    cfg.enable_mimi_encoder = cfg.enable_mimi_decoder = 0
+    m = hu.Model(kind, cfg, seed=0)
+    errs, tokens_equal = [], True
+    for step, tokens in enumerate(M["tokens"]):
+        m.lm_step_n(tokens.tolist())
+        assert np.array_equal(m.read("transformer_in", cfg.dim), M["x_in"][step])
+        errs.append(hu.rel_err(M["transformer_out"][step], m.read("transformer_out", cfg.dim)))
+        errs.append(hu.rel_err(M["text_logits"][step], m.read("text_logits", cfg.text_card)))
+        text_tok, audio = m.last_raw()
+        tokens_equal &= text_tok == int(M["text_tokens"][step]) and audio == M["dep_tokens"][step].tolist()
+        if text_tok != int(M["text_tokens"][step]) or audio != M["dep_tokens"][step].tolist():
+            break                                   # the Depth chain of the fixture was teacher-forced with other tokens from here on
+        errs += [hu.rel_err(M["dep_logits"][step][k], m.read(f"dep_logits{k}", cfg.card)) for k in range(cfg.dep_q)]
+    m.free()
+    return np.array(errs), tokens_equal
+
+
+def test_quantised_stack_through_the_driver_matches_the_block_arithmetic_restatement():
+    errs, tokens_equal = _run_quantised_stack_fixture("oracle")
+    assert tokens_equal and errs.max() < 3e-2 and np.median(errs) < 1e-6 and (errs > 1e-5).sum() <= 4, (errs.max(), np.median(errs), (errs > 1e-5).sum())
+
+
 def _run_temporal_stack_fixture(kind, tol):
     """tests/golden/temporal_stack.npz (generator: tests/golden/make_module_golden.py): 9 provided frames through a 2-layer F32 model whose ring of 6 wraps;
     the driver's stack input must equal the stored one bit for bit (same tokens, same synthetic weights), its outputs the PyTorch ones within tol."""
