@@ -392,6 +392,13 @@ def main():
                                   "kernel": "matvec_q4k_kernel", "launches_per_frame": int(kp.launches // 3),
                                   "avg_launch_us": round(1e6 * kp.seconds / kp.launches, 3),
                                   "algorithmic_bytes_per_launch": int(kp.bytes // kp.launches)}
+            # the same measurement split by instantiation family (rocprofv3 lists them as separate kernels): the large matrices stream, the small ones wait
+            names = ("lds_staged_tiles: matvec_q4k_kernel<.., WS=0> (Temporal matrices, text head)", "register_streaming: matvec_q4k_kernel<.., WS=1> (Depth transformer)")
+            result["roofline_by_variant"] = {names[v]: {"achieved": round(kp.variant_bytes[v] / kp.variant_seconds[v] / 1e9, 1), "unit": "GB/s",
+                                                        "frac": round(kp.variant_bytes[v] / kp.variant_seconds[v] / 1e9 / HBM_PEAK_GBPS, 4),
+                                                        "launches_per_frame": int(kp.variant_launches[v] // 3), "avg_launch_us": round(1e6 * kp.variant_seconds[v] / kp.variant_launches[v], 3),
+                                                        "algorithmic_bytes_per_launch": int(kp.variant_bytes[v] // kp.variant_launches[v])}
+                                             for v in range(2) if kp.variant_launches[v]}
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         # the same frame loop on the host cores through the CPU oracle (a port of ggml's CPU semantics; the reference's

@@ -122,6 +122,11 @@ struct ggml_mi355x_kernel_profile {
     double  seconds;    // sum of per-dispatch kernel begin -> end times
     int64_t launches;
     int64_t bytes;      // algorithmic bytes: weight bytes each launch streams (rows x row size)
+    // the same three by instantiation family of the kernel: [0] LDS-staged tiles (matvec_q4k_kernel<.., WS = 0>: the Temporal matrices and the text head),
+    // [1] register streaming (<.., WS = 1>: the Depth transformer's small matrices)
+    double  variant_seconds[2];
+    int64_t variant_launches[2];
+    int64_t variant_bytes[2];
 };
 GGML_API void ggml_backend_mi355x_get_kernel_profile(ggml_backend_t backend, struct ggml_mi355x_kernel_profile * out);
 // bit flags, default 0: 1 = disable fusion (one kernel per node), 2 = disable hipGraph capture, 4 = disable upload batching,

@@ -65,6 +65,7 @@ struct hip_ctx {
     // flag 8: per-launch timing of the dominant kernel
     mv_profile prof = { nullptr, 0, 0 };
     double prof_seconds = 0; int64_t prof_launches = 0, prof_bytes = 0;
+    double prof_seconds_v[2] = { 0, 0 }; int64_t prof_launches_v[2] = { 0, 0 }, prof_bytes_v[2] = { 0, 0 };   // the same, by kernel variant
     // cached plans keyed by cgraph pointer
     std::unordered_map<const ggml_cgraph *, plan_t *> plans;
     uint64_t orphan_clock = 0;
@@ -1767,6 +1768,8 @@ static void run_steps_profiled(hip_ctx * c, plan_t * p) {
         c->prof_seconds += (double) ms * 1e-3;
         c->prof_launches++;
         c->prof_bytes += c->prof.recs[i].bytes;
+        const int v = c->prof.recs[i].variant ? 1 : 0;
+        c->prof_seconds_v[v] += (double) ms * 1e-3; c->prof_launches_v[v]++; c->prof_bytes_v[v] += c->prof.recs[i].bytes;
     }
 }
 
@@ -1984,6 +1987,7 @@ extern "C" void ggml_backend_mi355x_set_flags(ggml_backend_t b, int flags) {
 extern "C" void ggml_backend_mi355x_get_kernel_profile(ggml_backend_t b, struct ggml_mi355x_kernel_profile * out) {
     hip_ctx * c = ctx_of(b);
     out->seconds = c->prof_seconds; out->launches = c->prof_launches; out->bytes = c->prof_bytes;
+    for (int v = 0; v < 2; v++) { out->variant_seconds[v] = c->prof_seconds_v[v]; out->variant_launches[v] = c->prof_launches_v[v]; out->variant_bytes[v] = c->prof_bytes_v[v]; }
 }
 extern "C" void * ggml_backend_mi355x_get_stream(ggml_backend_t b) { hip_ctx * c = ctx_of(b); ctx_init_lazy(c); return (void *) c->stream; }
 extern "C" ggml_backend_t ggml_backend_mi355x_init_stream(ggml_backend_t base) {

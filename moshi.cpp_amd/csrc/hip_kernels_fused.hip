@@ -1612,6 +1612,7 @@ void k_matvec(hipStream_t s, const mv_args & a) {
         if (g_mv_profile && g_mv_profile->used < g_mv_profile->capacity) {
             mv_profile::rec & r = g_mv_profile->recs[g_mv_profile->used++];
             r.bytes = a.M * a.row_bytes;
+            r.variant = direct ? 1 : 0;
             hipExtLaunchKernelGGL(kern, dim3(grid), dim3(threads), smem, s, r.start, r.stop, 0, a, rows, at);
             return;
         }
