@@ -238,6 +238,8 @@ def test_streaming_mimi_encoder_on_the_device_matches_the_offline_pytorch_restat
     import test_oracle_golden as tg
     same, worst = tg._run_mimi_encoder_fixture("hip")
     assert same >= 0.9 and worst < 1e-2, (same, worst)      # (a code may sit on a centroid tie; the CPU oracle reproduces all of them)
+    same, worst = tg._run_mimi_encoder_fixture("hip", full=True)
+    assert same >= 0.85 and worst < 1e-2, (same, worst)     # 8 levels of 2048 centroids: a first-level tie would move that frame's later levels too
 
 
 def test_quantised_stack_on_the_device_matches_the_block_arithmetic_restatement():

@@ -240,13 +240,16 @@ def test_temporal_stack_through_the_driver_matches_the_pytorch_restatement():
 
 
 # ---- module level: the streaming Mimi encoder through the frame driver vs an OFFLINE PyTorch restatement ------------------------------------------------------
-def _run_mimi_encoder_fixture(kind):
-    """tests/golden/mimi_encoder.npz (generator: tests/golden/make_mimi_golden.py): 5 frames of audio; PyTorch ran the whole signal at once through causal
+def _run_mimi_encoder_fixture(kind, full=False):
+    """full: tests/golden/mimi_encoder_full.npz - the benchmark's quantiser (8 levels of 2048 centroids) instead of the test model's 3 x 64.
+    tests/golden/mimi_encoder.npz (generator: tests/golden/make_mimi_golden.py): 5 frames of audio; PyTorch ran the whole signal at once through causal
     convolutions, causal attention and the split residual VQ. -> (fraction of codes equal, worst latent error of the frames)"""
     import hot_util as hu
-    M = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "mimi_encoder.npz"))
+    M = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "mimi_encoder_full.npz" if full else "mimi_encoder.npz"))
     cfg = hu.hot.tiny(hu.L)
     cfg.enable_lm = cfg.enable_mimi_decoder = 0
+    if full:
+        cfg.mimi_n_q, cfg.mimi_codebook_size = 8, 2048
     m = hu.Model(kind, cfg, seed=0)
     n = M["codes"].shape[0]
     same, worst = 0, 0.0
@@ -264,6 +267,8 @@ def test_streaming_mimi_encoder_matches_the_offline_pytorch_restatement():
     # sensitive (a 1e-7 perturbation of one convolution's accumulation moves the latent by 3e-3, tests/golden/make_mimi_golden.py), so the latent bar is 1e-2;
     # the codes - what the codec hands on - are equal.
     same, worst = _run_mimi_encoder_fixture("oracle")
+    assert same == 1.0 and worst < 1e-2, (same, worst)
+    same, worst = _run_mimi_encoder_fixture("oracle", full=True)          # 8 x 2048: all 40 codes of the 5 frames
     assert same == 1.0 and worst < 1e-2, (same, worst)
 
 
