@@ -31,7 +31,15 @@ import block_arith as ba  # noqa: E402
 LINEAR = F32                   # set by main(): F32, or Q4_K for the quantised fixture (every linear a Q4_K matrix, activations rounded to Q8_K)
 
 
+MODEL = "tiny"                 # or "personaplex": 17 codebooks, 16 chained Depth steps over a ring of 8 that wraps inside every frame
+
+
 def make_cfg():
+    if MODEL == "personaplex":
+        cfg = hu.hot.tiny_personaplex(L, linear_type=LINEAR, embed_type=F32, layers=2)
+        cfg.context = 6
+        cfg.enable_mimi_encoder = cfg.enable_mimi_decoder = 0
+        return cfg
     cfg = hu.hot.tiny(L, linear_type=LINEAR, embed_type=F32, layers=2, context=6)     # ring of 6: steps 6.. wrap it
     cfg.enable_mimi_encoder = cfg.enable_mimi_decoder = 0
     return cfg
@@ -65,9 +73,9 @@ def rms_norm(x, alpha, eps):
     return alpha * (x * (1.0 / torch.sqrt(ms.to(torch.float32) + eps)))
 
 
-def main(linear=F32, out_name="temporal_stack.npz"):
-    global LINEAR
-    LINEAR = linear
+def main(linear=F32, out_name="temporal_stack.npz", model="tiny"):
+    global LINEAR, MODEL
+    LINEAR, MODEL = linear, model
     cfg = make_cfg()
     m = hu.Model("oracle", cfg, seed=0)
     D, H, Cap, F = cfg.dim, cfg.num_heads, cfg.context, cfg.ffn_hidden
@@ -140,8 +148,9 @@ def main(linear=F32, out_name="temporal_stack.npz"):
         text_tok, drv_audio = m.last_raw()
         text_tokens.append(text_tok)
         DDh = DD // DH_
-        dkc = [torch.zeros(DH_, Q, DDh) for _ in DW]
-        dvc = [torch.zeros(DH_, Q, DDh) for _ in DW]
+        Cd = cfg.dep_context if cfg.dep_context > 0 else Q          # the Depth ring: dep_q slots, or fewer - then it wraps inside the frame (PersonaPlex: 16 steps over 8)
+        dkc = [torch.zeros(DH_, Cd, DDh) for _ in DW]
+        dvc = [torch.zeros(DH_, Cd, DDh) for _ in DW]
         prev, frame_logits, frame_toks = None, [], []
         for k in range(Q):
             emb = dep_text_emb[text_tok] if k == 0 else dep_emb[k - 1][prev]
@@ -150,12 +159,13 @@ def main(linear=F32, out_name="temporal_stack.npz"):
                 h = rms_norm(xd, w["n1"], 1e-8)
                 qkv = dot_f32(w["inp"][k], h)
                 q, kk, v = qkv[:DD].view(DH_, DDh), qkv[DD:2 * DD].view(DH_, DDh), qkv[2 * DD:].view(DH_, DDh)
-                dkc[l][:, k] = bf16(kk); dvc[l][:, k] = bf16(v)
+                dkc[l][:, k % Cd] = bf16(kk); dvc[l][:, k % Cd] = bf16(v)
                 qb = bf16(q)
-                sc_ = (dkc[l][:, :k + 1] * qb[:, None, :]).to(torch.float64).sum(-1).to(torch.float32) * torch.tensor(1.0 / np.sqrt(DDh), dtype=torch.float32)
+                nl = min(k + 1, Cd)                                     # slots 0 .. k while the ring fills, all of it afterwards (torch.h:205-223 for T = 1)
+                sc_ = (dkc[l][:, :nl] * qb[:, None, :]).to(torch.float64).sum(-1).to(torch.float32) * torch.tensor(1.0 / np.sqrt(DDh), dtype=torch.float32)
                 e = torch.exp(sc_ - sc_.max(-1, keepdim=True).values)
                 pb = bf16(e * (1.0 / e.to(torch.float64).sum(-1, keepdim=True)).to(torch.float32))
-                o = (dvc[l][:, :k + 1] * pb[:, :, None]).to(torch.float64).sum(1).to(torch.float32)
+                o = (dvc[l][:, :nl] * pb[:, :, None]).to(torch.float64).sum(1).to(torch.float32)
                 xd = xd + dot_f32(w["out"][k], o.reshape(DD))
                 h = rms_norm(xd, w["n2"], 1e-8)
                 g_ = dot_f32(w["gin"][k], h)
@@ -174,7 +184,8 @@ def main(linear=F32, out_name="temporal_stack.npz"):
         print(f"step {step}: transformer_out rel err {hu.rel_err(outs[-1], got_out):.2e}, text logits {hu.rel_err(logits[-1], got_logits):.2e}")
     m.free()
     np.savez_compressed(os.path.join(HERE, out_name), tokens=np.array(toks, np.int32), x_in=np.array(xs), transformer_out=np.array(outs),
-                        text_logits=np.array(logits), text_tokens=np.array(text_tokens, np.int32), dep_logits=np.array(dep_logits),
+                        text_logits=np.array(logits), text_tokens=np.array(text_tokens, np.int32),
+                        dep_logits=np.array(dep_logits)[:, :, ::max(1, cfg.card // 64)],      # (every 32nd logit of a 2048-entry head: the fixture stays small)
                         dep_tokens=np.array(dep_tokens, np.int32))
     print("wrote", out_name)
 
@@ -182,3 +193,4 @@ def main(linear=F32, out_name="temporal_stack.npz"):
 if __name__ == "__main__":
     main()
     main(hu.pkg.Q4_K, "temporal_stack_q4k.npz")
+    main(F32, "temporal_stack_personaplex.npz", model="personaplex")

@@ -205,12 +205,17 @@ def test_quantised_stack_through_the_driver_matches_the_block_arithmetic_restate
     assert tokens_equal and errs.max() < 3e-2 and np.median(errs) < 1e-6 and (errs > 1e-5).sum() <= 4, (errs.max(), np.median(errs), (errs > 1e-5).sum())
 
 
-def _run_temporal_stack_fixture(kind, tol):
+def _run_temporal_stack_fixture(kind, tol, model="tiny"):
     """tests/golden/temporal_stack.npz (generator: tests/golden/make_module_golden.py): 9 provided frames through a 2-layer F32 model whose ring of 6 wraps;
-    the driver's stack input must equal the stored one bit for bit (same tokens, same synthetic weights), its outputs the PyTorch ones within tol."""
+    the driver's stack input must equal the stored one bit for bit (same tokens, same synthetic weights), its outputs the PyTorch ones within tol.
+    model = "personaplex": temporal_stack_personaplex.npz - 17 codebooks, 16 chained Depth steps over a ring of 8 that wraps inside every frame."""
     import hot_util as hu
-    M = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "temporal_stack.npz"))
-    cfg = hu.hot.tiny(hu.L, linear_type=F32, embed_type=F32, layers=2, context=6)
+    M = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "temporal_stack.npz" if model == "tiny" else "temporal_stack_personaplex.npz"))
+    if model == "tiny":
+        cfg = hu.hot.tiny(hu.L, linear_type=F32, embed_type=F32, layers=2, context=6)
+    else:
+        cfg = hu.hot.tiny_personaplex(hu.L, linear_type=F32, embed_type=F32, layers=2)
+        cfg.context = 6
     cfg.enable_mimi_encoder = cfg.enable_mimi_decoder = 0
     m = hu.Model(kind, cfg, seed=0)
     worst = 0.0
@@ -225,7 +230,8 @@ def _run_temporal_stack_fixture(kind, tol):
         text_tok, audio = m.last_raw()
         assert text_tok == int(M["text_tokens"][step]) and audio == M["dep_tokens"][step].tolist(), f"step {step}: tokens {text_tok} {audio}"
         for k in range(cfg.dep_q):
-            e3 = hu.rel_err(M["dep_logits"][step][k], m.read(f"dep_logits{k}", cfg.card))
+            got = m.read(f"dep_logits{k}", cfg.card)
+            e3 = float(np.abs(M["dep_logits"][step][k] - got[::max(1, cfg.card // 64)]).max() / max(np.abs(got).max(), 1e-30))
             worst = max(worst, e3)
             assert e3 < tol, f"step {step} depth step {k}: logits {e3:.2e} vs the PyTorch restatement"
     m.free()
@@ -237,6 +243,7 @@ def test_temporal_stack_through_the_driver_matches_the_pytorch_restatement():
     # text_linear, then the chained Depth transformer (per-step weight sets, ring of dep_q slots, embedding of the previous step's token, greedy samples) -
     # the driver's graph construction (restating transformer.h / rope.h / gating.h / torch.h) on the oracle's op semantics
     assert _run_temporal_stack_fixture("oracle", 1e-6) < 5e-7
+    assert _run_temporal_stack_fixture("oracle", 1e-6, model="personaplex") < 5e-7       # the Depth ring of 8 wraps inside each frame's 16 steps
 
 
 # ---- module level: the streaming Mimi encoder through the frame driver vs an OFFLINE PyTorch restatement ------------------------------------------------------
