@@ -205,10 +205,12 @@ def test_quantised_stack_through_the_driver_matches_the_block_arithmetic_restate
     assert tokens_equal and errs.max() < 3e-2 and np.median(errs) < 1e-6 and (errs > 1e-5).sum() <= 4, (errs.max(), np.median(errs), (errs > 1e-5).sum())
 
 
-def _run_temporal_stack_fixture(kind, tol, model="tiny"):
+def _run_temporal_stack_fixture(kind, tol, model="tiny", events=None):
     """tests/golden/temporal_stack.npz (generator: tests/golden/make_module_golden.py): 9 provided frames through a 2-layer F32 model whose ring of 6 wraps;
     the driver's stack input must equal the stored one bit for bit (same tokens, same synthetic weights), its outputs the PyTorch ones within tol.
-    model = "personaplex": temporal_stack_personaplex.npz - 17 codebooks, 16 chained Depth steps over a ring of 8 that wraps inside every frame."""
+    model = "personaplex": temporal_stack_personaplex.npz - 17 codebooks, 16 chained Depth steps over a ring of 8 that wraps inside every frame.
+    events: a list that receives the errors beyond tol instead of failing on them (the K / V / probability roundings to BF16 are discontinuous: an implementation
+    that differs by float re-association can land on the other side of a tie, 5e-5 on that step's logits)."""
     import hot_util as hu
     M = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "temporal_stack.npz" if model == "tiny" else "temporal_stack_personaplex.npz"))
     if model == "tiny":
@@ -232,6 +234,9 @@ def _run_temporal_stack_fixture(kind, tol, model="tiny"):
         for k in range(cfg.dep_q):
             got = m.read(f"dep_logits{k}", cfg.card)
             e3 = float(np.abs(M["dep_logits"][step][k] - got[::max(1, cfg.card // 64)]).max() / max(np.abs(got).max(), 1e-30))
+            if events is not None and e3 >= tol:
+                events.append(e3)
+                continue
             worst = max(worst, e3)
             assert e3 < tol, f"step {step} depth step {k}: logits {e3:.2e} vs the PyTorch restatement"
     m.free()
