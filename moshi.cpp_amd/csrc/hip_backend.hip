@@ -1605,9 +1605,10 @@ static plan_t * build_plan(hip_ctx * c, ggml_cgraph * g) {
         }
         // mat-vecs with prologue / epilogue
         std::unordered_map<const void *, float *> paired_gate;   // storage of a linear_in output h (never materialised) -> g = silu(h_l) * h_r
-        // opt-in (MI355X_PAIRED_GATE=1): measured neutral on moshika - the gate kernel it removes (-2.3 us per layer) is paid back by linear_out quantising
-        // its 44 activation blocks in every workgroup (+1.8 us), profiles/r02_frame_stamps_paired_gate.txt
-        static const bool no_pair = getenv("MI355X_PAIRED_GATE") == nullptr;
+        // on by default (MI355X_PAIRED_GATE=0 turns it off): the gate kernel it removes (-2.3 us per layer) is mostly paid back by linear_out quantising its 44
+        // activation blocks in every workgroup (+1.8 us, profiles/r02_frame_stamps_paired_gate.txt) - neutral while the frame waited for the host between graphs,
+        // +1.1 % once the LM graphs run back to back (354.7 -> 358.7 frames/s, profiles/r02_ab_paired_gate_run_ahead.txt)
+        static const bool no_pair = getenv("MI355X_PAIRED_GATE") != nullptr && atoi(getenv("MI355X_PAIRED_GATE")) == 0;
         static const bool no_batched_fusion = getenv("MI355X_NO_BATCHED_MM") != nullptr || getenv("MI355X_NO_BATCHED_FUSION") != nullptr;
         for (int i = 0; i < g->n_nodes; i++) {
             if (an.skip[(size_t) i] || g->nodes[i]->op != GGML_OP_MUL_MAT) continue;
