@@ -475,6 +475,16 @@ def main():
                 "context_fill_2800_of_3000_frames_per_s": quick(lambda: hot.moshika(L), fill=2800),
                 "personaplex_ctx2000_fill_1900_frames_per_s": quick(pp_cfg, fill=1900),
             }
+            # the shapes of BASELINE.json configs[1] / configs[2] (hot.tts_like / hot.stt_like), each in a child process of its own (their loops differ: text hook +
+            # conditions + decode only; encode + VAD head only)
+            import subprocess
+            for name in ("tts_like", "stt_like"):
+                cmd = [sys.executable, os.path.abspath(__file__), "--model", name, "--steps", "40", "--warmup", "6", "--no-cpu-baseline", "--no-roofline", "--no-extras"]
+                if args.serial:
+                    cmd.append("--serial")
+                out = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+                line = [l for l in out.stdout.splitlines() if l.startswith("{")]
+                result["extras"][name + "_frames_per_s"] = json.loads(line[-1])["value"] if out.returncode == 0 and line else None
         except Exception as e:
             result["extras"] = {"error": str(e)}
     if m is not None:
