@@ -115,6 +115,7 @@ struct ggml_mi355x_stats {
     int64_t fused_nodes_in_last_plan;
     int64_t nodes_in_last_plan;
     int64_t uploads_batched;     // small tensor_set calls folded into one scatter launch
+    int64_t chained_matvecs_in_last_plan;   // block mat-vecs of the last plan that run inside persistent chain launches (hip_chain.hip)
 };
 GGML_API void ggml_backend_mi355x_get_stats(ggml_backend_t backend, struct ggml_mi355x_stats * stats);
 // accumulated HIP-event timings of the dominant kernel (Q4_K mat-vec), collected while flag 8 is set
@@ -130,7 +131,7 @@ struct ggml_mi355x_kernel_profile {
 };
 GGML_API void ggml_backend_mi355x_get_kernel_profile(ggml_backend_t backend, struct ggml_mi355x_kernel_profile * out);
 // bit flags, default 0: 1 = disable fusion (one kernel per node), 2 = disable hipGraph capture, 4 = disable upload batching,
-// 8 = profile mode (eager launches, per-dispatch HIP events on matvec_q4k_kernel)
+// 8 = profile mode (eager launches, per-dispatch HIP events on matvec_q4k_kernel), 16 = no persistent chain launches (one launch per mat-vec)
 GGML_API void ggml_backend_mi355x_set_flags(ggml_backend_t backend, int flags);
 // hipGraph capture of repeated graphs on / off without touching cached plans (off: a repeated graph still reuses its plan, launched eagerly -
 // for sequences of same-shaped one-off graphs such as prompt-prefill chunks, where a capture costs more than it saves). No-op on other backends.

@@ -108,7 +108,7 @@ static void ctx_init_lazy(hip_ctx * c) {
 
 static void check_device_error(hip_ctx * c) {
     if (c->err_host && c->err_host[0] != 0u)
-        GGML_ABORT("mi355x backend: a kernel gave up a bounded wait (code %u: 1 = split attention head barrier); results are invalid", c->err_host[0]);
+        GGML_ABORT("mi355x backend: a kernel gave up a bounded wait (code %u: 1 = split attention head barrier, 2 = chain engine hand-off); results are invalid", c->err_host[0]);
 }
 
 // ---- pool -----------------------------------------------------------------------------------------
@@ -281,9 +281,17 @@ static ggml_backend_buffer_t hip_alloc_buffer(ggml_backend_t backend, size_t siz
 // plans
 // ---------------------------------------------------------------------------------------------------
 typedef std::function<void(hipStream_t)> step_fn;
+// one launch of a plan. Block mat-vecs keep their arguments visible: runs of consecutive small ones are merged into persistent chain launches
+// (hip_chain.hip) once the whole plan is laid out
+struct pstep {
+    step_fn fn; bool is_mv = false; mv_args mv;
+    template <typename F> pstep(F f) : fn(std::move(f)) { memset(&mv, 0, sizeof(mv)); }
+    pstep(const mv_args & a) : fn([a](hipStream_t s) { k_matvec(s, a); }), is_mv(true), mv(a) {}
+};
 
 struct plan_t {
-    std::vector<step_fn> steps;
+    std::vector<pstep> steps;
+    std::vector<chain_plan *> chains;
     std::vector<std::pair<void *, size_t>> workspaces;
     std::vector<std::unique_ptr<attn_args>> attn_copies;
     std::vector<const ggml_backend_buffer *> buffers;   // every buffer a node / leaf of the planned graph lives in: freeing one orphans the plan
@@ -291,13 +299,14 @@ struct plan_t {
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
     uint64_t hash = 0;
-    int n_nodes = 0, n_fused = 0;
+    int n_nodes = 0, n_fused = 0, n_chained = 0;
 };
 
 static void plan_free(hip_ctx * c, plan_t * p) {
     if (p->exec) (void) hipGraphExecDestroy(p->exec);
     if (p->graph) (void) hipGraphDestroy(p->graph);
     for (auto & w : p->workspaces) pool_free(c, w.first, w.second);
+    for (chain_plan * ch : p->chains) k_chain_free(ch);
     delete p;
 }
 
@@ -474,7 +483,7 @@ struct emitter {
         p->workspaces.push_back({ w, actual });
         return w;
     }
-    void push(step_fn f) { p->steps.push_back(std::move(f)); }
+    void push(step_fn f) { p->steps.push_back(pstep(std::move(f))); }
 };
 
 static bool is_qblock(enum ggml_type t) { return t == GGML_TYPE_Q4_K || t == GGML_TYPE_Q8_0 || t == GGML_TYPE_Q4_0; }
@@ -1480,7 +1489,7 @@ static plan_t * build_plan(hip_ctx * c, ggml_cgraph * g) {
     const bool fuse = !(c->flags & 1);
 
     // fused groups, keyed by the position at which they are emitted
-    std::map<int, std::vector<step_fn>> at_pos;
+    std::map<int, std::vector<pstep>> at_pos;
     std::vector<attn_group> attn_groups;
     static const bool no_attn_prologue = getenv("MI355X_NO_ATTN_PROLOGUE") != nullptr;
     static const bool no_argmax_epilogue = getenv("MI355X_NO_ARGMAX_EPILOGUE") != nullptr;
@@ -1709,7 +1718,7 @@ static plan_t * build_plan(hip_ctx * c, ggml_cgraph * g) {
                 a.prologue = MV_PREQ8K;
                 a.x = (const float *) blocks;
             }
-            at_pos[grp.emit_pos].push_back([=](hipStream_t s) { k_matvec(s, a); });
+            at_pos[grp.emit_pos].push_back(pstep(a));
             if (grp.members.size() > 1) p->n_fused += (int) grp.members.size();
         }
     }
@@ -1746,10 +1755,37 @@ static plan_t * build_plan(hip_ctx * c, ggml_cgraph * g) {
         auto it = at_pos.find(i);
         if (it != at_pos.end()) for (auto & f : it->second) p->steps.push_back(f);
     }
+    // Persistent chains: a run of consecutive block mat-vecs each of which waits on its predecessor (the chained Depth transformer,
+    // lm.h:446-553: 26 mat-vecs per step, 8 / 16 steps per graph) becomes ONE launch of the chain engine (hip_chain.hip).
+    if (fuse && !(c->flags & 16)) {
+        std::vector<pstep> merged;
+        size_t i = 0;
+        while (i < p->steps.size()) {
+            if (!p->steps[i].is_mv) { merged.push_back(std::move(p->steps[i])); i++; continue; }
+            size_t e = i;
+            while (e < p->steps.size() && p->steps[e].is_mv) e++;
+            std::vector<mv_args> run;
+            for (size_t k = i; k < e; k++) run.push_back(p->steps[k].mv);
+            size_t k = 0;
+            while (k < run.size()) {
+                const int len = k_chain_accept(run.data() + k, (int) (run.size() - k));
+                if (len <= 0) { merged.push_back(std::move(p->steps[i + k])); k++; continue; }
+                void * ws = em.ws(k_chain_ws_size(run.data() + k, len));
+                chain_plan * ch = k_chain_create(c->stream, run.data() + k, len, ws, c->err_dev);
+                p->chains.push_back(ch);
+                merged.push_back(pstep([ch](hipStream_t s) { k_chain_launch(s, ch); }));
+                p->n_chained += len;
+                if (dump) fprintf(stderr, "plan: %d consecutive mat-vecs -> one chain launch (%.1f MB of weights)\n", len, (double) k_chain_weight_bytes(ch) / 1e6);
+                k += (size_t) len;
+            }
+            i = e;
+        }
+        p->steps.swap(merged);
+    }
     return p;
 }
 
-static void run_steps(hip_ctx * c, plan_t * p) { for (auto & f : p->steps) f(c->stream); }
+static void run_steps(hip_ctx * c, plan_t * p) { for (auto & st : p->steps) st.fn(c->stream); }
 
 // flag 8: launch eagerly with start/stop events on every matvec_q4k_kernel dispatch and accumulate
 static void run_steps_profiled(hip_ctx * c, plan_t * p) {
@@ -1795,6 +1831,7 @@ static enum ggml_status hip_graph_compute(ggml_backend_t backend, struct ggml_cg
         c->stats.kernels_in_last_plan = (int64_t) p->steps.size();
         c->stats.nodes_in_last_plan = p->n_nodes;
         c->stats.fused_nodes_in_last_plan = p->n_fused;
+        c->stats.chained_matvecs_in_last_plan = p->n_chained;
         plan_free(c, p);   // workspaces return to the pool; reuse is stream-ordered
         return GGML_STATUS_SUCCESS;
     }
@@ -1833,6 +1870,7 @@ static enum ggml_status hip_graph_compute(ggml_backend_t backend, struct ggml_cg
     c->stats.kernels_in_last_plan = (int64_t) p->steps.size();
     c->stats.nodes_in_last_plan = p->n_nodes;
     c->stats.fused_nodes_in_last_plan = p->n_fused;
+    c->stats.chained_matvecs_in_last_plan = p->n_chained;
     return GGML_STATUS_SUCCESS;
 }
 

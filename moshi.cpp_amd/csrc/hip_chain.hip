@@ -1,0 +1,824 @@
+// hip_chain.hip — the persistent chain engine: a run of dependent small Q4_K mat-vecs (the chained Depth transformer of moshi.cpp,
+// /root/reference/src/moshi/models/lm.h:446-553: depformer_in -> 6 x {in_proj, attention + out_proj, linear_in, linear_out} -> linears[k] ->
+// arg-max -> next step's embedding, 26 mat-vecs per step, 8 / 16 / 32 steps per frame) executed by ONE launch instead of one launch per mat-vec.
+//
+// Why: each of those mat-vecs moves 0.6 - 3.2 MB. As separate launches they cost 2.3 - 4.9 us in the kernel plus 1.4 - 1.8 us of boundary
+// (profiles/r02_frame_stamps_in_graph.txt) - 137 us per step for 47 MB, 0.04 of the HBM roofline. What a step needs is (a) its weights streamed
+// once and (b) 26 all-to-all hand-offs of a <= 12 KB vector. Here:
+//   * G workgroups (default 64, one per CU, 9 waves each) stay resident for the whole run; workgroup g owns the same contiguous block of rows
+//     of every matrix, so its share of a matrix is one contiguous byte range of the Q4_K stream;
+//   * wave 8 of each workgroup is a LOADER: it copies the workgroup's byte ranges of ALL phases, in order, into an LDS ring with LDS-DMA
+//     (global_load_lds_dwordx4, nontemporal), running ahead of the consumers by the ring's capacity - the weights of phase p + 1 (and p + 2) are
+//     in flight or landed while phase p waits for its input, which is what a kernel boundary can never do;
+//   * waves 0-7 are CONSUMERS: gather the previous phase's vector, run the prologue (RMS norm / attention over the 8-slot ring / plain),
+//     quantise to Q8_K exactly as matvec_q4k_kernel does, dot their super-blocks out of the ring (8 lanes per super-block, the WS = 1 arithmetic),
+//     reduce rows in the same fixed order and publish their rows;
+//   * the hand-off is data-tagged: every published float travels as one 8-byte {tag, value} granule written by one agent-scope (sc1) store and
+//     polled with agent-scope loads - the data IS the flag, there is no grid barrier, no fence and no separate counter on the critical path
+//     (cdna_hip_programming.md Guideline 16, form R2). tag = launch sequence number << 12 | phase index + 1: never 0, never repeated in a slot;
+//   * the greedy sample (ggml's last-maximum arg-max) travels as one (value, index) candidate per workgroup; every workgroup merges them itself.
+// Arithmetic is the unchained kernels' to the bit: same Q8_K rounding, same per-super-block float expression, same 16-lane row sums, same
+// attention (attn_small_wave) - tests/test_chain_engine.py compares the two plans bit for bit.
+#include "hip_common.h"
+#include "hip_device.h"
+#include "hip_mv_device.h"
+
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+
+#define CH_NCW       8                    // consumer waves per workgroup
+#define CH_THREADS   ((CH_NCW + 1) * 64)  // + 1 loader wave
+#define CH_SLOT      1024                 // bytes per ring slot = one wave-wide LDS-DMA (16 B per lane)
+#define CH_XF_MAX    4096                 // floats: longest vector handed from one phase to the next
+#define CH_PART_MAX  2048                 // super-block partial sums per workgroup and phase
+#define CH_RES_MAX   256                  // rows per workgroup and phase
+#define CH_ATTW      1408                 // floats of attention scratch per consumer wave: 2 heads x (q | k | v) + 2 x 8 slots x 64 products
+#define CH_SPIN_MAX  (1u << 24)
+
+typedef unsigned long long u64;
+
+struct chain_phase {
+    const char * w; long long row_bytes;
+    int K, M, nb, rows_wg;     // rows_wg: rows per workgroup (paired: rows of EACH half)
+    long long pair_F;          // > 0: W is linear_in [K, 2 F] of a gated FFN; a workgroup takes the same rows of both halves and hands on silu(l) * r
+    int prologue;              // MV_PLAIN / MV_RMSNORM / MV_ATTN
+    int x_chain;               // 1: x is the vector the previous phase published; 0: x is read from memory (produced before this launch)
+    const float * x; const float * alpha; float eps;
+    int attn;                  // MV_ATTN: index into chain_params::attns
+    int q_off, k_off, v_off;   //          offsets of head 0's q / k / v inside the previous phase's vector
+    int res;                   // residual: 0 none, 1 the rows this workgroup kept from an earlier phase, 2 memory
+    const float * residual;
+    embed_src emb; int emb_chain;   // one embedding row added in the epilogue; emb_chain: its index is the previous phase's arg-max
+    int save;                  // keep this phase's rows in the workgroup for a later residual
+    int argmax;                // reduce the rows to arg-max candidates (ggml_vec_argmax_f32: the LAST maximum)
+    int32_t * argmax_out[2];
+    float * y;                 // the ggml node's own storage (always written, plain stores: nothing inside the launch reads it)
+    int n_pub;                 // values handed to the next phase: 0, M, or pair_F
+};
+
+struct chain_params {
+    const chain_phase * phases; int n_phases;
+    const attn_args * attns;
+    u64 * gbuf;                // [2][CH_XF_MAX] granules, by phase parity
+    u64 * cand;                // [2][2 * grid] arg-max candidates {tag, value bits}, {tag, index}
+    unsigned * launch_seq;     // bumped by workgroup 0 at the end of every launch
+    unsigned * err;            // host-visible error word (bounded waits)
+    int ring_slots, throttle;
+};
+
+// ---- small helpers ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned lds_load(unsigned * p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void lds_store(unsigned * p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+
+// The phase table and the attention descriptors are written by the host before the launch and never during it: read them through the constant
+// address space (scalar loads, no vector-memory wait in front of every phase). Pointers taken out of a descriptor lose their address space, so
+// they are cast back to global explicitly (a flat access would tie up both memory counters).
+typedef const __attribute__((address_space(4))) struct chain_phase * cphase_ptr;
+typedef const __attribute__((address_space(4))) attn_args * cattn_ptr;
+#define GLOBAL_AS __attribute__((address_space(1)))
+template <typename T> __device__ __forceinline__ GLOBAL_AS T * gp(T * p) { return (GLOBAL_AS T *) p; }
+template <typename T> __device__ __forceinline__ const GLOBAL_AS T * gp(const T * p) { return (const GLOBAL_AS T *) p; }
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void * p, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, (int) bytes, 0x00020000);
+}
+// agent-scope (sc1) 16-byte load / 8-byte store / 2-byte store: past this CU's L1, served at the device's coherence point
+__device__ __forceinline__ u32x4 ld16_agent(__amdgpu_buffer_rsrc_t r, unsigned byte_off) { return __builtin_amdgcn_raw_buffer_load_b128(r, (int) byte_off, 0, 16); }
+__device__ __forceinline__ void st_granule(u64 * p, unsigned tag, unsigned value) {
+    __hip_atomic_store(p, ((u64) tag << 32) | (u64) value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+struct chain_ctl {            // LDS control block
+    unsigned filled;          // ring slots whose DMA has landed (absolute count, loader -> consumers)
+    unsigned freed;           // ring slots the consumers are done with (absolute count, consumers -> loader)
+    unsigned sync;            // consumer-wave rendezvous counter (monotonic)
+    unsigned failed;          // a bounded wait gave up: everybody leaves
+    int token;                // merged arg-max of the previous phase
+    unsigned pad[3];
+    double sumsq[CH_NCW];
+    float am_v[CH_NCW]; int am_i[CH_NCW];
+};
+
+// rendezvous of the CH_NCW consumer waves through an LDS counter (the loader wave never takes part, so s_barrier cannot be used)
+__device__ __forceinline__ bool csync(chain_ctl * ctl, unsigned & target, int lane) {
+    target += CH_NCW;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    if (lane == 0) __hip_atomic_fetch_add(&ctl->sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    unsigned spins = 0;
+    bool ok = true;
+    while (lds_load(&ctl->sync) < target) {
+        if (++spins > CH_SPIN_MAX || lds_load(&ctl->failed)) { ok = false; break; }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+    return ok;
+}
+
+// Gather `n` (even) tagged values into dst[0..n) (LDS). Every consumer wave sweeps its own 128-value slices with 16-byte agent-scope loads
+// (two granules each; all of a sweep's loads are issued before the first tag is looked at) until all its tags match; values go to LDS as they
+// are. Returns false when the wait gave up.
+template <int NIT>
+__device__ __forceinline__ bool gather_vector_n(__amdgpu_buffer_rsrc_t gb, unsigned base_bytes, int npairs, unsigned tag, float * dst, int wave, int lane, chain_ctl * ctl) {
+    unsigned spins = 0;
+    for (;;) {
+        u32x4 g[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; it++) {
+            const int pi = (it * CH_NCW + wave) * 64 + lane;
+            g[it] = ld16_agent(gb, base_bytes + (unsigned) (pi < npairs ? pi : npairs - 1) * 16u);
+        }
+        bool ok = true;
+#pragma unroll
+        for (int it = 0; it < NIT; it++) ok = ok && g[it].y == tag && g[it].w == tag;
+        if (__all(ok)) {
+#pragma unroll
+            for (int it = 0; it < NIT; it++) {
+                const int pi = (it * CH_NCW + wave) * 64 + lane;
+                if (pi < npairs) *(float2 *) (dst + 2 * pi) = make_float2(__uint_as_float(g[it].x), __uint_as_float(g[it].z));
+            }
+            return true;
+        }
+        if (++spins > CH_SPIN_MAX || lds_load(&ctl->failed)) return false;
+        __builtin_amdgcn_s_sleep(1);
+    }
+}
+__device__ __forceinline__ bool gather_vector(__amdgpu_buffer_rsrc_t gb, unsigned base_bytes, int n, unsigned tag, float * dst, int wave, int lane, chain_ctl * ctl) {
+    const int npairs = n >> 1, nit = (npairs + CH_NCW * 64 - 1) / (CH_NCW * 64);
+    static_assert(CH_XF_MAX <= 4 * CH_NCW * 128, "gather_vector: four sweeps per wave cover the longest hand-off");
+    switch (nit) {
+        case 1:  return gather_vector_n<1>(gb, base_bytes, npairs, tag, dst, wave, lane, ctl);
+        case 2:  return gather_vector_n<2>(gb, base_bytes, npairs, tag, dst, wave, lane, ctl);
+        case 3:  return gather_vector_n<3>(gb, base_bytes, npairs, tag, dst, wave, lane, ctl);
+        default: return gather_vector_n<4>(gb, base_bytes, npairs, tag, dst, wave, lane, ctl);
+    }
+}
+
+// Attention of 2 consecutive heads by one wave for a single new token over a ring of <= 8 slots of 64: attn_small_wave<2> of hip_kernels_fused.hip
+// with the new token's q / k / v taken from LDS (the in_proj rows just gathered), the ring rows passed in (requested with agent-scope loads BEFORE
+// the hand-off wait: they were written by earlier phases) and the ring write done with agent-scope stores. Same arithmetic in the same order.
+__device__ __forceinline__ void chain_attn_ring_loads(const attn_args & a, int h0, int lane, u32x4 kq[2], u32x4 vq[2], __amdgpu_buffer_rsrc_t kr, __amdgpu_buffer_rsrc_t vr) {
+    const int sub = lane / 8, dl = (lane % 8) * 8;
+    const int cc = sub < a.C ? sub : a.C - 1;
+#pragma unroll
+    for (int hh = 0; hh < 2; hh++) {
+        const int h = h0 + hh;
+        kq[hh] = ld16_agent(kr, (unsigned) ((int64_t) h * a.k_nb2 + (int64_t) cc * a.k_nb1 + dl * 2));
+        vq[hh] = ld16_agent(vr, (unsigned) ((int64_t) h * a.v_nb2 + (int64_t) cc * a.v_nb1 + dl * 2));
+    }
+}
+__device__ __forceinline__ void chain_attn_wave(const attn_args & a, const float * qb, const float * kb, const float * vb, int h0, int lane, float * wbuf, float * xa,
+                                                const u32x4 kq[2], const u32x4 vq[2], bool write_cache, __amdgpu_buffer_rsrc_t kr, __amdgpu_buffer_rsrc_t vr,
+                                                int slot, float m, float rc, float rs) {
+    constexpr int NH = 2, LPS = 8, half = 32;
+    const int C = a.C;
+    const int sub = lane / LPS, dl = (lane % LPS) * 8;
+    const int c = sub;
+    const int j = lane, p = j < half ? j : j - half;
+    float qr[NH], qi[NH], kr_[NH], ki[NH], vv[NH];
+#pragma unroll
+    for (int hh = 0; hh < NH; hh++) {
+        const int h = h0 + hh;
+        const float * q = qb + (int64_t) h * a.q_hs, * k = kb + (int64_t) h * a.k_hs, * v = vb + (int64_t) h * a.v_hs;
+        if (a.rot) { qr[hh] = q[2 * p]; qi[hh] = q[2 * p + 1]; kr_[hh] = k[2 * p]; ki[hh] = k[2 * p + 1]; }
+        else { qr[hh] = q[j]; qi[hh] = 0.f; kr_[hh] = k[j]; ki[hh] = 0.f; }
+        vv[hh] = v[j];
+    }
+    const bool live = c < C && m > -INFINITY;
+    const bool fresh = slot == c;
+#pragma unroll
+    for (int hh = 0; hh < NH; hh++) {
+        float qo, ko;
+        if (a.rot) {
+            if (j < half) { qo = qr[hh] * rc - qi[hh] * rs; ko = kr_[hh] * rc - ki[hh] * rs; }
+            else          { qo = qr[hh] * rs + qi[hh] * rc; ko = kr_[hh] * rs + ki[hh] * rc; }
+        } else { qo = qr[hh]; ko = kr_[hh]; }
+        const uint16_t kbv = f2bf(ko), vbv = f2bf(vv[hh]);
+        float * wb = wbuf + hh * 192;
+        wb[j] = bf2f(f2bf(qo)); wb[64 + j] = bf2f(kbv); wb[128 + j] = bf2f(vbv);
+        if (write_cache && slot >= 0 && slot < C) {
+            const int h = h0 + hh;
+            __builtin_amdgcn_raw_buffer_store_b16((short) kbv, kr, (int) ((int64_t) h * a.k_nb2 + (int64_t) slot * a.k_nb1 + j * 2), 0, 16);
+            __builtin_amdgcn_raw_buffer_store_b16((short) vbv, vr, (int) ((int64_t) h * a.v_nb2 + (int64_t) slot * a.v_nb1 + j * 2), 0, 16);
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    float * prod = wbuf + NH * 192;
+#pragma unroll
+    for (int hq = 0; hq < 2; hq++) {
+        const int hh = hq;
+        const float * qf = wbuf + hh * 192, * knew = qf + 64, * vnew = qf + 128;
+        float qv[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) qv[i] = qf[dl + i];
+        double acc = 0;
+        if (live) {
+            if (fresh) {
+#pragma unroll
+                for (int i = 0; i < 8; i++) acc += (double) (knew[dl + i] * qv[i]);
+            } else {
+                const uint32_t kw[4] = { kq[hh].x, kq[hh].y, kq[hh].z, kq[hh].w };
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    acc += (double) (bf2f((uint16_t) (kw[i] & 0xffff)) * qv[2 * i]);
+                    acc += (double) (bf2f((uint16_t) (kw[i] >> 16)) * qv[2 * i + 1]);
+                }
+            }
+        }
+        acc = group_allsum_f64(acc, LPS);
+        const float sv = live ? (float) acc * a.scale + m : -INFINITY;
+        const float gmax = wave_allmax_f32(sv);
+        const float e = sv > -INFINITY ? expf(sv - gmax) : 0.f;
+        double lsum = (lane % LPS) == 0 ? (double) e : 0.0;
+        lsum = wave_allsum_f64(lsum);
+        const float inv = (float) (1.0 / lsum);
+        const float pr = bf2f(f2bf(e * inv));
+        float pf[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) pf[i] = 0.f;
+        if (pr != 0.f) {
+            if (fresh) {
+#pragma unroll
+                for (int i = 0; i < 8; i++) pf[i] = vnew[dl + i] * pr;
+            } else {
+                const uint32_t vw[4] = { vq[hh].x, vq[hh].y, vq[hh].z, vq[hh].w };
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    pf[2 * i]     = bf2f((uint16_t) (vw[i] & 0xffff)) * pr;
+                    pf[2 * i + 1] = bf2f((uint16_t) (vw[i] >> 16)) * pr;
+                }
+            }
+        }
+        float * dst = prod + hq * 512 + sub * 64 + dl;
+        *(float4 *) dst = make_float4(pf[0], pf[1], pf[2], pf[3]);
+        *(float4 *) (dst + 4) = make_float4(pf[4], pf[5], pf[6], pf[7]);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int hq = 0; hq < 2; hq++) {
+        double tot = 0;
+#pragma unroll
+        for (int c2 = 0; c2 < 8; c2++) tot += (double) prod[hq * 512 + c2 * 64 + lane];
+        xa[hq * 64 + lane] = (float) tot;
+    }
+}
+
+// merge of arg-max candidates: larger value wins, equal values -> larger index (= the last maximum of the whole row)
+__device__ __forceinline__ void am_merge(float & best, int & bi, float ov, int oi) { if (ov > best || (ov == best && oi > bi)) { best = ov; bi = oi; } }
+__device__ __forceinline__ void am_wave(float & best, int & bi) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const float ov = __shfl_xor(best, o, 64); const int oi = __shfl_xor(bi, o, 64); am_merge(best, bi, ov, oi); }
+}
+// one wave reads every workgroup's candidate of `tag` and merges them; false when the wait gave up
+__device__ __forceinline__ bool gather_token(__amdgpu_buffer_rsrc_t cb, unsigned base_bytes, int grid, unsigned tag, int lane, chain_ctl * ctl, int & token) {
+    unsigned spins = 0;
+    for (;;) {
+        float best = -INFINITY; int bi = -1;
+        bool ok = true;
+        for (int g0 = 0; g0 < grid; g0 += 64) {
+            const int g = g0 + lane;
+            const u32x4 c = ld16_agent(cb, base_bytes + (unsigned) (g < grid ? g : grid - 1) * 16u);
+            ok = ok && c.y == tag && c.w == tag;
+            if (g < grid) am_merge(best, bi, __uint_as_float(c.x), (int) c.z);
+        }
+        if (__all(ok)) { am_wave(best, bi); token = bi < 0 ? 0 : bi; return true; }
+        if (++spins > CH_SPIN_MAX || lds_load(&ctl->failed)) return false;
+        __builtin_amdgcn_s_sleep(1);
+    }
+}
+
+// one attention descriptor out of the constant-address-space table, field by field (scalar loads)
+__device__ __forceinline__ attn_args load_attn(cattn_ptr p) {
+    attn_args a;
+    a.q = p->q; a.k = p->k; a.v = p->v;
+    a.q_ts = p->q_ts; a.q_hs = p->q_hs; a.k_ts = p->k_ts; a.k_hs = p->k_hs; a.v_ts = p->v_ts; a.v_hs = p->v_hs;
+    a.rot = p->rot; a.mask = p->mask; a.index = p->index; a.kcache = p->kcache; a.vcache = p->vcache;
+    a.k_nb1 = p->k_nb1; a.k_nb2 = p->k_nb2; a.v_nb1 = p->v_nb1; a.v_nb2 = p->v_nb2;
+    a.H = p->H; a.D = p->D; a.C = p->C; a.T = p->T; a.scale = p->scale; a.out = p->out; a.out_ts = p->out_ts; a.n_groups = p->n_groups; a.write_only = p->write_only;
+    return a;
+}
+// dequant_elem (hip_device.h) for a row known to live in global memory
+__device__ __forceinline__ float dequant_elem_g(const GLOBAL_AS char * row, int type, int64_t i) {
+    switch (type) {
+        case GGML_TYPE_F32:  return ((const GLOBAL_AS float *) row)[i];
+        case GGML_TYPE_F16:  return h2f(((const GLOBAL_AS uint16_t *) row)[i]);
+        case GGML_TYPE_BF16: return bf2f(((const GLOBAL_AS uint16_t *) row)[i]);
+        case GGML_TYPE_Q8_0: { const GLOBAL_AS block_q8_0 * b = (const GLOBAL_AS block_q8_0 *) row + i / 32; return b->qs[i % 32] * h2f(b->d); }
+        case GGML_TYPE_Q4_0: {
+            const GLOBAL_AS block_q4_0 * b = (const GLOBAL_AS block_q4_0 *) row + i / 32;
+            const int j = (int) (i % 32);
+            const int q = j < 16 ? (b->qs[j] & 0x0F) : (b->qs[j - 16] >> 4);
+            return (q - 8) * h2f(b->d);
+        }
+        case GGML_TYPE_Q4_K: {
+            const GLOBAL_AS block_q4_K * b = (const GLOBAL_AS block_q4_K *) row + i / 256;
+            const int j = (int) (i % 256);
+            const int sub = j / 32, l = j % 32;
+            uint32_t sc[2], mn[2];
+            const GLOBAL_AS uint32_t * sw = (const GLOBAL_AS uint32_t *) b->scales;
+            q4k_unpack_scales_w(sw[0], sw[1], sw[2], sc, mn);
+            const uint32_t s = (sc[sub >> 2] >> (8 * (sub & 3))) & 0xff, m = (mn[sub >> 2] >> (8 * (sub & 3))) & 0xff;
+            const uint8_t qb = b->qs[(sub >> 1) * 32 + l];
+            const int q = (sub & 1) ? (qb >> 4) : (qb & 0xF);
+            const float d = h2f(b->d) * (float) s, mm = h2f(b->dmin) * (float) m;
+            return d * (float) q - mm;
+        }
+        default: return NAN;
+    }
+}
+
+// ---- the kernel -----------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(CH_THREADS) matvec_chain_kernel(chain_params P) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int RS = P.ring_slots;
+    char * ring = smem;
+    xblk * xs = (xblk *) (ring + (size_t) RS * CH_SLOT);
+    float * xf = (float *) (xs + 16);
+    float * part = xf + CH_XF_MAX;
+    float * xres = part + CH_PART_MAX;
+    float * xa = xres + CH_RES_MAX;
+    float * attw = xa + 1024;
+    chain_ctl * ctl = (chain_ctl *) (attw + CH_NCW * CH_ATTW);
+
+    if (tid == 0) { ctl->filled = 0; ctl->freed = 0; ctl->sync = 0; ctl->failed = 0; ctl->token = 0; }
+    __syncthreads();   // the only workgroup barrier: all nine waves are still in step here
+
+    const int wg = blockIdx.x, grid = gridDim.x;
+    const cphase_ptr PH = (cphase_ptr) P.phases;
+    const cattn_ptr AT = (cattn_ptr) P.attns;
+    const unsigned launch = *gp(P.launch_seq);
+    const unsigned tag_base = launch << 12;
+
+    // ================================================= loader wave =================================================
+    if (wave == CH_NCW) {
+        unsigned issued = 0, freed = 0, spins = 0;
+        for (int p = 0; p < P.n_phases; p++) {
+            const auto & ph = PH[p];
+            const int nseg = ph.pair_F > 0 ? 2 : 1;
+            const long long rows_total = ph.pair_F > 0 ? ph.pair_F : (long long) ph.M;
+            const long long row0 = (long long) wg * ph.rows_wg;
+            const int rows = (int) (rows_total - row0 < ph.rows_wg ? (rows_total - row0 > 0 ? rows_total - row0 : 0) : ph.rows_wg);
+            const unsigned bytes = (unsigned) rows * (unsigned) ph.row_bytes;
+            const int nsl = (int) ((bytes + CH_SLOT - 1) / CH_SLOT);
+            for (int seg = 0; seg < nseg; seg++) {
+                const GLOBAL_AS char * src = gp(ph.w) + (row0 + (seg ? ph.pair_F : 0)) * ph.row_bytes;
+                for (int s = 0; s < nsl; s++) {
+                    if (issued - freed >= (unsigned) RS) {
+                        // ring full: everything issued so far may as well be waited for and published, then wait for the consumers
+                        wait_vmcnt<0>();
+                        if (lane == 0) lds_store(&ctl->filled, issued);
+                        while (issued - (freed = lds_load(&ctl->freed)) >= (unsigned) RS) {
+                            if (++spins > CH_SPIN_MAX || lds_load(&ctl->failed)) { if (lane == 0) { lds_store(&ctl->failed, 1u); *gp(P.err) = 2u; } return; }
+                            __builtin_amdgcn_s_sleep(2);
+                        }
+                    }
+                    unsigned off = (unsigned) s * CH_SLOT + (unsigned) lane * 16u;
+                    if (off >= bytes) off = bytes - 16u;
+                    __builtin_amdgcn_global_load_lds((const GLOBAL_AS void *) (src + off),
+                                                     (__attribute__((address_space(3))) void *) (ring + (size_t) (issued % (unsigned) RS) * CH_SLOT), 16, 0, 2 /* nt */);
+                    issued++;
+                    // throttle: at most `throttle` fills outstanding, so the consumers' own gathers are not queued behind a long burst
+                    // (MI355X_MICROARCH.md gather-pass); everything older has landed and is published
+                    const int th = P.throttle;
+                    if (th <= 8) { wait_vmcnt<8>(); if (issued > 8 && lane == 0) lds_store(&ctl->filled, issued - 8); }
+                    else if (th <= 16) { wait_vmcnt<16>(); if (issued > 16 && lane == 0) lds_store(&ctl->filled, issued - 16); }
+                    else if (th <= 32) { wait_vmcnt<32>(); if (issued > 32 && lane == 0) lds_store(&ctl->filled, issued - 32); }
+                    else { wait_vmcnt<48>(); if (issued > 48 && lane == 0) lds_store(&ctl->filled, issued - 48); }
+                }
+            }
+        }
+        wait_vmcnt<0>();
+        if (lane == 0) lds_store(&ctl->filled, issued);
+        return;
+    }
+
+    // ================================================= consumer waves ==============================================
+    unsigned sync_target = 0, chunk_abs = 0;   // chunk_abs: absolute ring slot at which the current phase's first segment starts
+    const __amdgpu_buffer_rsrc_t gb = make_rsrc(P.gbuf, 2u * CH_XF_MAX * 8u);
+    const __amdgpu_buffer_rsrc_t cb = make_rsrc(P.cand, 2u * 2u * (unsigned) grid * 8u);
+    const unsigned ring_bytes = (unsigned) RS * CH_SLOT;
+    bool alive = true;
+
+    for (int p = 0; p < P.n_phases && alive; p++) {
+        const auto & ph = PH[p];
+        const unsigned tag_in = tag_base | (unsigned) p, tag_out = tag_base | (unsigned) (p + 1);
+        const int nb = ph.nb, K = ph.K;
+        const bool paired = ph.pair_F > 0;
+        const long long rows_total = paired ? ph.pair_F : (long long) ph.M;
+        const long long row0 = (long long) wg * ph.rows_wg;
+        const int rows = (int) (rows_total - row0 < ph.rows_wg ? (rows_total - row0 > 0 ? rows_total - row0 : 0) : ph.rows_wg);
+        const unsigned seg_bytes = (unsigned) rows * (unsigned) ph.row_bytes;
+        const unsigned seg_slots = (seg_bytes + CH_SLOT - 1) / CH_SLOT;
+        const unsigned chunk_end = chunk_abs + (paired ? 2u : 1u) * seg_slots;
+        const int nblk_seg = rows * nb, nblk = paired ? 2 * nblk_seg : nblk_seg;
+
+        // ---- loads that do not depend on the previous phase go out before the hand-off wait
+        // prologue weights (alpha) of this wave's blocks
+        f32x4 al[2];
+#pragma unroll
+        for (int r = 0; r < 2; r++) {
+            const int b = wave + r * CH_NCW;
+            al[r] = (f32x4) { 1.f, 1.f, 1.f, 1.f };
+            if (ph.prologue == MV_RMSNORM && b < nb) al[r] = *(const GLOBAL_AS f32x4 *) (ph.alpha + b * 256 + lane * 4);
+        }
+        // x from memory
+        f32x4 xm[2];
+#pragma unroll
+        for (int r = 0; r < 2; r++) {
+            const int b = wave + r * CH_NCW;
+            xm[r] = (f32x4) { 0.f, 0.f, 0.f, 0.f };
+            if (!ph.x_chain && b < nb) xm[r] = *(const GLOBAL_AS f32x4 *) (ph.x + b * 256 + lane * 4);
+        }
+        // attention: ring rows, mask, slot, rotation
+        u32x4 kq[2], vq[2];
+        int at_slot = 0; float at_m = 0.f, at_rc = 1.f, at_rs = 0.f;
+        __amdgpu_buffer_rsrc_t kr = gb, vr = gb;
+        if (ph.prologue == MV_ATTN) {
+            const attn_args at = load_attn(AT + ph.attn);
+            kr = make_rsrc(at.kcache, (unsigned) ((int64_t) at.H * at.k_nb2));
+            vr = make_rsrc(at.vcache, (unsigned) ((int64_t) at.H * at.v_nb2));
+            chain_attn_ring_loads(at, wave * 2, lane, kq, vq, kr, vr);
+            const int sub = lane / 8, cc = sub < at.C ? sub : at.C - 1, pp = lane < 32 ? lane : lane - 32;
+            at_slot = gp(at.index)[0];
+            at_m = gp(at.mask)[cc];
+            if (at.rot) { at_rc = gp(at.rot)[pp]; at_rs = gp(at.rot)[32 + pp]; }
+        }
+
+        // ---- stage 1: the activation vector -> Q8_K blocks in xs
+        const float * xsrc = xf;   // LDS source of the blocks (xf: gathered vector, xa: attention output)
+        if (ph.x_chain) {
+            const int n_in = PH[p - 1].n_pub;
+            if (!gather_vector(gb, (unsigned) ((p - 1) & 1) * (CH_XF_MAX * 8u), n_in, tag_in, xf, wave, lane, ctl)) { alive = false; break; }
+            if (!csync(ctl, sync_target, lane)) { alive = false; break; }
+            if (ph.prologue == MV_ATTN) {
+                const attn_args at = load_attn(AT + ph.attn);
+                chain_attn_wave(at, xf + ph.q_off, xf + ph.k_off, xf + ph.v_off, wave * 2, lane, attw + wave * CH_ATTW, xa + wave * 128, kq, vq, wg == 0, kr, vr,
+                                at_slot, at_m, at_rc, at_rs);
+                if (!csync(ctl, sync_target, lane)) { alive = false; break; }
+                xsrc = xa;
+            }
+        }
+        float v[2][4];
+#pragma unroll
+        for (int r = 0; r < 2; r++) {
+            const int b = wave + r * CH_NCW;
+            f32x4 t = xm[r];
+            if (ph.x_chain && b < nb) t = *(const f32x4 *) (xsrc + b * 256 + lane * 4);
+            v[r][0] = t.x; v[r][1] = t.y; v[r][2] = t.z; v[r][3] = t.w;
+        }
+        if (ph.prologue == MV_RMSNORM) {
+            // matvec_q4k_kernel's order: per-thread squares in double, wave butterfly, waves added in index order
+            double acc = 0;
+#pragma unroll
+            for (int r = 0; r < 2; r++)
+#pragma unroll
+                for (int k = 0; k < 4; k++) acc += (double) (v[r][k] * v[r][k]);
+            acc = wave_allsum_f64(acc);
+            if (lane == 0) ctl->sumsq[wave] = acc;
+            if (!csync(ctl, sync_target, lane)) { alive = false; break; }
+            double tot = 0;
+#pragma unroll
+            for (int w = 0; w < CH_NCW; w++) tot += ctl->sumsq[w];
+            const float mean = (float) (tot / (double) K);
+            const float scale = 1.0f / sqrtf(mean + ph.eps);
+#pragma unroll
+            for (int r = 0; r < 2; r++) {
+                const float a4[4] = { al[r].x, al[r].y, al[r].z, al[r].w };
+#pragma unroll
+                for (int k = 0; k < 4; k++) v[r][k] = a4[k] * (v[r][k] * scale);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 2; r++) {
+            const int b = wave + r * CH_NCW;
+            if (b < nb) quantize_block_q8k(xs + b, v[r], lane);
+        }
+        if (!csync(ctl, sync_target, lane)) { alive = false; break; }
+
+        // ---- stage 2: super-block dots out of the ring (the WS = 1 arithmetic of matvec_q4k_kernel: 8 lanes per super-block)
+        {
+            unsigned spins = 0;
+            while (lds_load(&ctl->filled) < chunk_end) {
+                if (++spins > CH_SPIN_MAX || lds_load(&ctl->failed)) { alive = false; break; }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            if (!alive) break;
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+        }
+        const unsigned base0 = (chunk_abs % (unsigned) RS) * CH_SLOT, base1 = ((chunk_abs + seg_slots) % (unsigned) RS) * CH_SLOT;
+        for (int p0 = 0; p0 < nblk; p0 += CH_NCW * 8) {
+            const int sb = p0 + wave * 8 + (lane >> 3);
+            const int sbc = sb < nblk ? sb : nblk - 1;
+            const int j8 = lane & 7, g32 = j8 >> 1, hf = j8 & 1;
+            unsigned o = sbc < nblk_seg ? base0 + (unsigned) sbc * 144u : base1 + (unsigned) (sbc - nblk_seg) * 144u;
+            if (o >= ring_bytes) o -= ring_bytes;
+            unsigned oq = o + 16u + 16u * (unsigned) j8;
+            if (oq >= ring_bytes) oq -= ring_bytes;
+            const u32x4 dh = *(const u32x4 *) (ring + o), dq = *(const u32x4 *) (ring + oq);
+            const xblk * xb = xs + (sbc % nb);
+            const uint32_t hw[4] = { dh.x, dh.y, dh.z, dh.w };
+            uint32_t sc[2], mn[2];
+            q4k_unpack_scales_w(hw[1], hw[2], hw[3], sc, mn);
+            const u32x4 ylo = *(const u32x4 *) (xb->q + 64 * g32 + 16 * hf), yhi = *(const u32x4 *) (xb->q + 64 * g32 + 32 + 16 * hf);
+            const uint32_t qw[4] = { dq.x, dq.y, dq.z, dq.w }, yl[4] = { ylo.x, ylo.y, ylo.z, ylo.w }, yh[4] = { yhi.x, yhi.y, yhi.z, yhi.w };
+            int lo = 0, hi = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                lo = dot4_i8((int) (qw[k] & 0x0F0F0F0Fu), (int) yl[k], lo);
+                hi = dot4_i8((int) ((qw[k] >> 4) & 0x0F0F0F0Fu), (int) yh[k], hi);
+            }
+            const int i0 = 2 * g32, i1 = 2 * g32 + 1;
+            const int s0 = (int) ((sc[i0 >> 2] >> (8 * (i0 & 3))) & 0xff), s1 = (int) ((sc[i1 >> 2] >> (8 * (i1 & 3))) & 0xff);
+            int isum = __mul24(s0, lo) + __mul24(s1, hi);
+            const uint32_t bs2 = *(const uint32_t *) (xb->bsums + 2 * j8);
+            const int bs = (int) (int16_t) (bs2 & 0xffff) + (int) (int16_t) (bs2 >> 16);
+            int msum = __mul24((int) ((mn[j8 >> 2] >> (8 * (j8 & 3))) & 0xff), bs);
+            isum += dpp_i32<DPP_QUAD_XOR1>(isum); msum += dpp_i32<DPP_QUAD_XOR1>(msum);
+            isum += dpp_i32<DPP_QUAD_XOR2>(isum); msum += dpp_i32<DPP_QUAD_XOR2>(msum);
+            isum += dpp_i32<DPP_HALF_MIRROR>(isum); msum += dpp_i32<DPP_HALF_MIRROR>(msum);
+            if (j8 == 0 && sb < nblk) {
+                const float d = h2f((uint16_t) (hw[0] & 0xffff)) * xb->d, dmin = h2f((uint16_t) (hw[0] >> 16)) * xb->d;
+                part[sb] = d * (float) isum - dmin * (float) msum;
+            }
+        }
+        // the token this phase's epilogue needs (the previous phase's arg-max): wave 0 merges the candidates while the others finish their dots
+        if (ph.emb_chain && wave == 0) {
+            int token = 0;
+            if (!gather_token(cb, (unsigned) ((p - 1) & 1) * (2u * (unsigned) grid * 8u), grid, tag_in, lane, ctl, token)) { alive = false; break; }
+            if (lane == 0) {
+                ctl->token = token;
+                if (wg == 0) { const auto & pp = PH[p - 1]; if (pp.argmax_out[0]) *gp(pp.argmax_out[0]) = token; if (pp.argmax_out[1]) *gp(pp.argmax_out[1]) = token; }
+            }
+        }
+        if (!csync(ctl, sync_target, lane)) { alive = false; break; }
+        if (wave == 0 && lane == 0) lds_store(&ctl->freed, chunk_end);   // every wave is past its last ring read
+        chunk_abs = chunk_end;
+
+        // ---- stage 3: fixed-order row sums, epilogue, publication
+        const unsigned pub_base = (unsigned) (p & 1) * CH_XF_MAX;
+        float best = -INFINITY; int bi = -1;
+        if (paired) {
+            for (int rr = tid >> 4; rr < rows; rr += CH_NCW * 4) {
+                float sl = 0.f, sr = 0.f;
+                for (int j = tid & 15; j < nb; j += 16) { sl += part[rr * nb + j]; sr += part[(rows + rr) * nb + j]; }
+                sl = row16_allsum_f32(sl); sr = row16_allsum_f32(sr);
+                if ((tid & 15) == 0) {
+                    const float g = (sl / (1.0f + expf(-sl))) * sr;
+                    if (ph.n_pub) st_granule(P.gbuf + pub_base + row0 + rr, tag_out, __float_as_uint(g));
+                    gp(ph.y)[row0 + rr] = sl; gp(ph.y)[ph.pair_F + row0 + rr] = sr;
+                }
+            }
+        } else {
+            float emb_scale = 1.f; const GLOBAL_AS char * emb_row = nullptr;
+            if (ph.emb.table) {
+                int64_t r = ph.emb_chain ? (int64_t) ctl->token : (int64_t) *gp(ph.emb.index);
+                if (r < 0 || r >= ph.emb.n_rows) r = 0;
+                emb_row = gp(ph.emb.table) + r * ph.emb.row_bytes;
+                if (ph.emb.scale) emb_scale = *gp(ph.emb.scale);
+            }
+            for (int rr = tid >> 4; rr < rows; rr += CH_NCW * 4) {
+                float sum = 0.f;
+                for (int j = tid & 15; j < nb; j += 16) sum += part[rr * nb + j];
+                sum = row16_allsum_f32(sum);
+                if ((tid & 15) == 0) {
+                    const int64_t row = row0 + rr;
+                    if (ph.res == 1) sum = xres[rr] + sum;
+                    else if (ph.res == 2) sum = gp(ph.residual)[row] + sum;
+                    else if (emb_row) {
+                        float e = dequant_elem_g(emb_row, ph.emb.type, row);
+                        if (ph.emb.scale) e = e * emb_scale;
+                        sum = sum + e;
+                    }
+                    if (ph.save) xres[rr] = sum;
+                    if (ph.n_pub) st_granule(P.gbuf + pub_base + row, tag_out, __float_as_uint(sum));
+                    gp(ph.y)[row] = sum;
+                    if (sum >= best) { best = sum; bi = (int) row; }   // rows ascend per thread: '>=' keeps the last maximum
+                }
+            }
+        }
+        if (ph.argmax) {
+            am_wave(best, bi);
+            if (lane == 0) { ctl->am_v[wave] = best; ctl->am_i[wave] = bi; }
+            if (!csync(ctl, sync_target, lane)) { alive = false; break; }
+            if (tid == 0) {
+                for (int w = 1; w < CH_NCW; w++) am_merge(best, bi, ctl->am_v[w], ctl->am_i[w]);
+                u64 * c = P.cand + (size_t) (p & 1) * 2 * grid + 2 * wg;
+                st_granule(c, tag_out, __float_as_uint(best));
+                st_granule(c + 1, tag_out, (unsigned) bi);
+            }
+        }
+    }
+
+    // the chain ends in an arg-max: workgroup 0 merges the candidates and writes the token
+    if (alive && wg == 0 && wave == 0 && PH[P.n_phases - 1].argmax) {
+        const int p = P.n_phases;
+        int token = 0;
+        if (gather_token(cb, (unsigned) ((p - 1) & 1) * (2u * (unsigned) grid * 8u), grid, tag_base | (unsigned) p, lane, ctl, token)) {
+            const auto & pp = PH[p - 1];
+            if (lane == 0) { if (pp.argmax_out[0]) *gp(pp.argmax_out[0]) = token; if (pp.argmax_out[1]) *gp(pp.argmax_out[1]) = token; }
+        } else alive = false;
+    }
+    if (!alive) {
+        if (lane == 0) { lds_store(&ctl->failed, 1u); *gp(P.err) = 2u; }
+        return;
+    }
+    if (wg == 0 && tid == 0) *gp(P.launch_seq) = launch + 1u;
+}
+
+// ---- host side -----------------------------------------------------------------------------------------------------------------
+static int chain_env(const char * name, int def) { const char * v = getenv(name); return v ? atoi(v) : def; }
+static int chain_grid() { static const int g = chain_env("MI355X_CHAIN_GRID", 64); return g < 8 ? 8 : g > 256 ? 256 : g; }
+static int chain_ring_slots() { static const int r = chain_env("MI355X_CHAIN_RING", 80); return r < 16 ? 16 : r > 80 ? 80 : r; }
+
+struct chain_plan {
+    chain_params P;
+    int grid; size_t smem;
+    std::vector<chain_phase> phases;
+    std::vector<attn_args> attns;
+};
+
+static bool overlaps(const void * a, size_t an, const void * b, size_t bn) {
+    return (const char *) a < (const char *) b + bn && (const char *) b < (const char *) a + an;
+}
+
+// Greedy prefix: the first `len` of the n consecutive mat-vecs that one launch can execute. Fills `out` / `attns` (host form) and returns len
+// (0: none). Rules: every phase but the first waits on its predecessor (x is the predecessor's output, or its embedding index is the
+// predecessor's arg-max) - that is what lets two hand-off buffers alternate by phase parity; anything a phase reads that an earlier phase of
+// the run writes must travel by one of the in-launch mechanisms (hand-off vector, kept rows, arg-max candidates) or the run is cut there.
+static int chain_analyse(const mv_args * mv, int n, std::vector<chain_phase> & out, std::vector<attn_args> & attns) {
+    const int G = chain_grid(), RS = chain_ring_slots();
+    out.clear(); attns.clear();
+    std::vector<int> res_from;   // phase whose rows a phase adds as its residual (-1: none / memory)
+    auto ybytes = [&](int j) { return (size_t) out[(size_t) j].M * 4; };
+    for (int i = 0; i < n; i++) {
+        const mv_args & a = mv[i];
+        chain_phase ph;
+        memset(&ph, 0, sizeof(ph));
+        // ---- the mat-vec itself
+        if (a.wtype != GGML_TYPE_Q4_K || a.ncols != 1 || a.K % 256 != 0 || a.K > 4096 || a.pair_F != 0 || a.x_out || a.out_scale || a.out_act) break;
+        if (!a.ticket && (a.argmax_out[0] || a.argmax_out[1])) break;
+        if (a.row_bytes != (a.K / 256) * 144 || ((uintptr_t) a.w & 15)) break;
+        if (!(a.prologue == MV_PLAIN || a.prologue == MV_RMSNORM || a.prologue == MV_GATE_SILU || a.prologue == MV_ATTN)) break;
+        if ((a.M * (a.K / 256) + 63) / 64 > 512) break;   // the large matrices keep their own LDS-tile kernel
+        ph.w = a.w; ph.row_bytes = a.row_bytes; ph.K = (int) a.K; ph.M = (int) a.M; ph.nb = (int) (a.K / 256);
+        ph.rows_wg = (int) ((a.M + G - 1) / G);
+        ph.prologue = a.prologue; ph.x = a.x; ph.alpha = a.alpha; ph.eps = a.eps; ph.y = a.y;
+        ph.attn = -1;
+        if (ph.rows_wg > CH_RES_MAX || ph.rows_wg * ph.nb > CH_PART_MAX) break;
+        bool bad = false;
+        // ---- where x comes from
+        if (a.prologue != MV_ATTN) {
+            const size_t xn = (size_t) (a.prologue == MV_GATE_SILU ? 2 * a.K : a.K) * 4;
+            int x_from = -1;
+            for (int j = 0; j < i; j++) if (overlaps(a.x, xn, out[(size_t) j].y, ybytes(j))) { if (x_from >= 0) bad = true; x_from = j; }
+            if (x_from >= 0) {
+                const chain_phase & pj = out[(size_t) x_from];
+                if (x_from != i - 1 || a.x != pj.y || xn != ybytes(x_from) || pj.argmax || pj.pair_F) bad = true;
+            }
+            if (bad) break;
+            if (a.prologue == MV_GATE_SILU) {
+                // silu(h[:K]) * h[K:] with h = the previous phase's output: that phase takes the paired form and hands on the K gate values
+                if (x_from < 0) break;
+                chain_phase & pj = out[(size_t) x_from];
+                if (pj.res || pj.emb.table || pj.argmax || res_from.back() >= 0) break;
+                const int rw = (int) ((a.K + G - 1) / G);
+                if (rw > CH_RES_MAX || 2 * rw * pj.nb > CH_PART_MAX) break;
+                pj.pair_F = a.K; pj.rows_wg = rw;
+                ph.prologue = MV_PLAIN;
+            }
+            ph.x_chain = x_from >= 0;
+        } else {
+            // q / k / v are slices of the previous phase's output (in_proj); workgroup 0 writes the new row to the ring
+            if (i == 0 || !a.attn) break;
+            const attn_args & at = *a.attn;
+            const chain_phase & pj = out[(size_t) i - 1];
+            if (at.T != 1 || at.D != 64 || at.H != 2 * CH_NCW || at.C < 1 || at.C > 8 || (int64_t) at.H * at.D != a.K || pj.argmax || pj.pair_F) break;
+            const float * lo = pj.y, * hi = pj.y + pj.M;
+            auto inside = [&](const float * q, int64_t hs) { return hs >= 0 && q >= lo && q + (at.H - 1) * hs + at.D <= hi; };
+            if (!inside(at.q, at.q_hs) || !inside(at.k, at.k_hs) || !inside(at.v, at.v_hs)) break;
+            ph.q_off = (int) (at.q - lo); ph.k_off = (int) (at.k - lo); ph.v_off = (int) (at.v - lo);
+            ph.attn = (int) attns.size();
+            ph.x_chain = 1;
+        }
+        // ---- epilogue
+        int rf = -1;
+        if (a.residual) {
+            for (int j = 0; j < i; j++) if (overlaps(a.residual, (size_t) a.M * 4, out[(size_t) j].y, ybytes(j))) rf = j;
+            if (rf >= 0) {
+                const chain_phase & pj = out[(size_t) rf];
+                if (a.residual != pj.y || pj.M != ph.M || pj.rows_wg != ph.rows_wg || pj.pair_F || pj.argmax) break;
+                ph.res = 1;
+            } else ph.res = 2;
+            ph.residual = a.residual;
+        }
+        if (a.res_embed.table) {
+            ph.emb = a.res_embed;
+            for (int j = 0; j < i; j++) {
+                const chain_phase & pj = out[(size_t) j];
+                if (pj.argmax && ((const void *) a.res_embed.index == (const void *) pj.argmax_out[0] || (const void *) a.res_embed.index == (const void *) pj.argmax_out[1])) {
+                    if (j != i - 1) bad = true;
+                    ph.emb_chain = 1;
+                }
+                if (a.res_embed.scale && overlaps(a.res_embed.scale, 4, pj.y, ybytes(j))) bad = true;
+            }
+            if (bad) break;
+        }
+        if (a.ticket) { ph.argmax = 1; ph.argmax_out[0] = a.argmax_out[0]; ph.argmax_out[1] = a.argmax_out[1]; }
+        if (i > 0) {
+            const chain_phase & pj = out[(size_t) i - 1];
+            if (ph.x_chain == ph.emb_chain) break;            // exactly one hand-off from the predecessor
+            if (pj.argmax != ph.emb_chain) break;             // an arg-max is consumed by the very next phase (or ends the run)
+        } else if (ph.x_chain || ph.emb_chain) break;
+        if (ph.attn >= 0) attns.push_back(*a.attn);
+        out.push_back(ph);
+        res_from.push_back(rf);
+    }
+    int len = (int) out.size();
+    // kept rows: a residual taken from the run must be the rows of the most recent phase that keeps any; cut the run where that fails
+    for (;;) {
+        for (int i = 0; i < len; i++) out[(size_t) i].save = 0;
+        for (int i = 0; i < len; i++) if (out[(size_t) i].res == 1) out[(size_t) res_from[(size_t) i]].save = 1;
+        int cut = len;
+        for (int i = 0; i < len && cut == len; i++) {
+            const chain_phase & ph = out[(size_t) i];
+            if (ph.res == 1) {
+                int src = -1;
+                for (int j = i - 1; j >= 0; j--) if (out[(size_t) j].save) { src = j; break; }
+                if (src != res_from[(size_t) i]) cut = i;
+            }
+            const unsigned seg = ((unsigned) ph.rows_wg * (unsigned) ph.row_bytes + CH_SLOT - 1) / CH_SLOT;
+            if ((int) ((ph.pair_F ? 2u : 1u) * seg) > RS) cut = i;
+        }
+        while (cut > 0 && out[(size_t) cut - 1].pair_F) cut--;   // a paired phase needs its consumer
+        if (cut == len) break;
+        len = cut;
+    }
+    out.resize((size_t) len);
+    int na = 0;
+    for (int i = 0; i < len; i++) {
+        chain_phase & ph = out[(size_t) i];
+        const bool next_x = i + 1 < len && out[(size_t) i + 1].x_chain;
+        ph.n_pub = next_x ? (ph.pair_F ? (int) ph.pair_F : ph.M) : 0;
+        if (ph.n_pub > CH_XF_MAX || (ph.n_pub & 1)) return chain_analyse(mv, i, out, attns);   // (cannot hand this vector on: end the run in front of it)
+        if (ph.attn >= 0) na++;
+    }
+    attns.resize((size_t) na);
+    return len;
+}
+
+int k_chain_accept(const mv_args * mv, int n) {
+    static const int on = chain_env("MI355X_CHAIN", 1), min_len = chain_env("MI355X_CHAIN_MIN", 4);
+    if (!on || n < min_len) return 0;
+    std::vector<chain_phase> ph; std::vector<attn_args> at;
+    const int len = chain_analyse(mv, n, ph, at);
+    return len >= min_len ? len : 0;
+}
+
+static size_t chain_tables_bytes(int n, int na) { return GGML_PAD((size_t) n * sizeof(chain_phase), 256) + GGML_PAD((size_t) (na ? na : 1) * sizeof(attn_args), 256); }
+static size_t chain_state_bytes(int grid) { return 256 + 2 * (size_t) CH_XF_MAX * 8 + 2 * 2 * (size_t) grid * 8; }
+size_t k_chain_ws_size(const mv_args * mv, int n) {
+    std::vector<chain_phase> ph; std::vector<attn_args> at;
+    const int len = chain_analyse(mv, n, ph, at);
+    return chain_tables_bytes(len, (int) at.size()) + chain_state_bytes(chain_grid());
+}
+
+chain_plan * k_chain_create(hipStream_t s, const mv_args * mv, int n, void * ws, unsigned * err) {
+    chain_plan * c = new chain_plan;
+    const int len = chain_analyse(mv, n, c->phases, c->attns);
+    GGML_ASSERT(len == n && "k_chain_create: pass exactly the run k_chain_accept took");
+    c->grid = chain_grid();
+    const int RS = chain_ring_slots();
+    char * base = (char *) ws;
+    chain_phase * d_ph = (chain_phase *) base;
+    attn_args * d_at = (attn_args *) (base + GGML_PAD((size_t) n * sizeof(chain_phase), 256));
+    char * state = base + chain_tables_bytes(n, (int) c->attns.size());
+    HIP_CHECK(hipMemcpyAsync(d_ph, c->phases.data(), (size_t) n * sizeof(chain_phase), hipMemcpyHostToDevice, s));
+    if (!c->attns.empty()) HIP_CHECK(hipMemcpyAsync(d_at, c->attns.data(), c->attns.size() * sizeof(attn_args), hipMemcpyHostToDevice, s));
+    HIP_CHECK(hipMemsetAsync(state, 0, chain_state_bytes(c->grid), s));
+    HIP_CHECK(hipStreamSynchronize(s));   // the host vectors above may go away with the plan
+    c->P.phases = d_ph; c->P.n_phases = n; c->P.attns = d_at;
+    c->P.launch_seq = (unsigned *) state;
+    c->P.gbuf = (u64 *) (state + 256);
+    c->P.cand = c->P.gbuf + 2 * CH_XF_MAX;
+    c->P.err = err;
+    c->P.ring_slots = RS;
+    c->P.throttle = chain_env("MI355X_CHAIN_THROTTLE", 32);
+    c->smem = (size_t) RS * CH_SLOT + 16 * XBLK_BYTES + (size_t) (CH_XF_MAX + CH_PART_MAX + CH_RES_MAX + 1024 + CH_NCW * CH_ATTW) * 4 + sizeof(chain_ctl);
+    GGML_ASSERT(c->smem <= 160 * 1024);
+    static bool granted = false;
+    if (!granted) { HIP_CHECK(hipFuncSetAttribute((const void *) matvec_chain_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); granted = true; }
+    return c;
+}
+void k_chain_free(chain_plan * c) { delete c; }
+int k_chain_length(const chain_plan * c) { return c->P.n_phases; }
+int64_t k_chain_weight_bytes(const chain_plan * c) { int64_t b = 0; for (auto & ph : c->phases) b += (int64_t) ph.M * ph.row_bytes; return b; }
+
+void k_chain_launch(hipStream_t s, const chain_plan * c) {
+    matvec_chain_kernel<<<c->grid, CH_THREADS, c->smem, s>>>(c->P);
+}

@@ -105,6 +105,16 @@ struct mv_args {
     // intermediate and the separate gate kernel disappear.
     int64_t     pair_F;         // 0 = off
 };
+// Persistent chain engine (hip_chain.hip): a run of consecutive, dependent small Q4_K mat-vecs executed by ONE launch - resident workgroups,
+// a loader wave streaming every phase's weights through an LDS ring ahead of the dependency chain, data-tagged hand-offs between phases.
+struct chain_plan;
+int    k_chain_accept(const mv_args * mv, int n);     // how many of the n consecutive mat-vecs (in launch order) one chain launch can take (0: none)
+size_t k_chain_ws_size(const mv_args * mv, int n);    // device workspace for exactly that run (tables + hand-off buffers)
+chain_plan * k_chain_create(hipStream_t s, const mv_args * mv, int n, void * ws, unsigned * err);
+void   k_chain_launch(hipStream_t s, const chain_plan * c);
+void   k_chain_free(chain_plan * c);
+int    k_chain_length(const chain_plan * c);
+int64_t k_chain_weight_bytes(const chain_plan * c);
 bool k_matvec_supported(int wtype, int64_t K, int64_t M);
 bool k_matvec_pair_ok(int wtype, int64_t K, int64_t F);
 // optional per-launch timing of the dominant kernel (matvec_q4k_kernel) with HIP start/stop events that are

@@ -16,6 +16,7 @@
 // agree with the oracle to float-summation-order noise.
 #include "hip_common.h"
 #include "hip_device.h"
+#include "hip_mv_device.h"
 #include <hip/hip_ext.h>
 #include <stdlib.h>
 #include <map>
@@ -55,11 +56,7 @@ __device__ float block_rms_scale(const float * x, int64_t K, float eps, double *
 // ---------------------------------------------------------------------------------------------------
 // Q4_K mat-vec
 // ---------------------------------------------------------------------------------------------------
-#define XBLK_BYTES 304   // 256 q8 + 16 bsums (int16) + d (f32) + pad: 76-dword stride => conflict-free b128 reads
 #define TILE_BYTES 9216  // 64 super-blocks of 144 B = 9 wave-wide 16-byte loads
-
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // diagnostic builds only. -DMV_STAMPS (tests/microbench/mv_bench.hip): per-phase s_memtime stamps of wave 0 of each workgroup.
 // -DMV_LOG (tests/microbench/frame_stamps.py): one record per LAUNCH, taken by workgroup 0 / wave 0 - phase stamps, start / end in
@@ -87,8 +84,6 @@ __device__ unsigned long long g_mv_real[4096][2];
 #define MV_STAMP(i) do {} while (0)
 #endif
 
-struct xblk { int8_t q[256]; int16_t bsums[16]; float d; float pad[3]; };
-static_assert(sizeof(xblk) == XBLK_BYTES && offsetof(xblk, bsums) == 256 && offsetof(xblk, d) == 288, "xblk layout");
 
 // Weight formats of the block mat-vec. A lane always owns 256 consecutive weights of one row: one Q4_K super-block, or eight
 // consecutive Q8_0 / Q4_0 blocks (K % 256 == 0 for every linear of the models). Activations are quantised the way ggml's CPU
@@ -169,27 +164,6 @@ __device__ __forceinline__ float q40_q80_sb_dot(const char * wb, const xblk80 * 
     return sumf;
 }
 
-// quantise the 256 values held by one wave (4 per lane, contiguous) to a Q8_K block in LDS
-__device__ __forceinline__ void quantize_block_q8k(xblk * dst, const float v[4], int lane) {
-    // the signed value of largest magnitude (ggml: iscale = -127 / max); when +a and -a tie the sign is immaterial
-    float amax = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
-    float smax = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
-    amax = wave_allmax_f32(amax);
-    smax = wave_allmax_f32(smax);
-    const float mx = smax == amax ? amax : -amax;
-    int q[4] = { 0, 0, 0, 0 };
-    float d = 0.f;
-    if (amax != 0.f) {
-        const float iscale = -127.f / mx;
-#pragma unroll
-        for (int k = 0; k < 4; k++) { const int qi = nearest_int_dev(iscale * v[k]); q[k] = qi < 127 ? qi : 127; }
-        d = 1.f / iscale;
-    }
-    *(uint32_t *) (dst->q + lane * 4) = (uint32_t) (q[0] & 0xff) | ((uint32_t) (q[1] & 0xff) << 8) | ((uint32_t) (q[2] & 0xff) << 16) | ((uint32_t) (q[3] & 0xff) << 24);
-    const int s4 = quad_allsum_i32(q[0] + q[1] + q[2] + q[3]);
-    if ((lane & 3) == 0) dst->bsums[lane >> 2] = (int16_t) s4;
-    if (lane == 0) dst->d = d;
-}
 
 // Attention of NH (2 or 4) consecutive heads by ONE wave, for a single new token over a short ring (C <= 8 slots of D = 64): the Depth
 // transformer's shape. Same arithmetic, in the same order, as attn_decode_kernel below restricted to the one wave that has work

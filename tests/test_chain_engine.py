@@ -1,0 +1,107 @@
+"""The persistent chain engine (moshi.cpp_amd/csrc/hip_chain.hip): runs of dependent small Q4_K mat-vecs - the chained Depth transformer of
+/root/reference/src/moshi/models/lm.h:446-553 - executed by one launch. It performs the arithmetic of the one-launch-per-mat-vec plan in the same
+order, so the two plans (backend flag 16 switches the chains off) must agree BIT FOR BIT, and both must agree with the oracle."""
+import numpy as np
+import pytest
+
+import hot_util as hu
+
+pytestmark = pytest.mark.gpu
+
+
+def depth_at_real_width(dep_q=4, layers=2, n_q=8):
+    # the Depth transformer at its real width (1024 = 16 heads x 64, gated FFN 2816): the shape whose out_proj recomputes the short-ring attention
+    cfg = hu.hot.tiny(hu.L, dep_q=dep_q, n_q=n_q)
+    cfg.dep_dim, cfg.dep_heads, cfg.dep_layers, cfg.dep_ffn_hidden = 1024, 16, layers, 2816
+    cfg.enable_mimi_encoder = cfg.enable_mimi_decoder = 0
+    return cfg
+
+
+def run(kind, cfg, steps, flags=0, seed=3):
+    m = hu.Model(kind, cfg, seed=0, flags=flags)
+    rng = np.random.default_rng(seed)
+    rec = []
+    n_in = cfg.n_q - cfg.io_dep_q
+    for _ in range(steps):
+        ia = rng.integers(0, cfg.card, n_in).tolist()
+        r, txt, aud = m.lm_step(ia)
+        rec.append((r, txt, aud, m.read("text_logits", cfg.text_card).copy(), [m.read(f"dep_logits{k}", cfg.card).copy() for k in range(cfg.dep_q)]))
+    st = m.stats() if kind == "hip" else None
+    m.free()
+    return rec, st
+
+
+def assert_bit_identical(a, b, what):
+    for i, (x, y) in enumerate(zip(a, b)):
+        assert x[:3] == y[:3], f"{what} step {i}: tokens {x[:3]} vs {y[:3]}"
+        assert np.array_equal(x[3], y[3]), f"{what} step {i}: text logits differ"
+        for k, (u, v) in enumerate(zip(x[4], y[4])):
+            assert np.array_equal(u, v), f"{what} step {i} depth {k}: logits differ by {np.abs(u - v).max():.3e}"
+
+
+def test_chained_depth_equals_one_launch_per_matvec_bit_for_bit_and_the_oracle():
+    cfg = depth_at_real_width()
+    steps = 10
+    chained, st = run("hip", cfg, steps)
+    assert st.chained_matvecs_in_last_plan >= 4 * (1 + 4 * 2 + 1) - 1, f"the Depth graph was not chained ({st.chained_matvecs_in_last_plan} mat-vecs)"
+    plain, st0 = run("hip", cfg, steps, flags=16)
+    assert st0.chained_matvecs_in_last_plan == 0
+    assert_bit_identical(plain, chained, "chain vs launches")
+    ref, _ = run("oracle", cfg, steps)
+    for i, (a, b) in enumerate(zip(ref, chained)):
+        assert a[:3] == b[:3], f"step {i}: greedy tokens differ from the oracle: {a[:3]} vs {b[:3]}"
+    errs = np.array([max(hu.rel_err(a[3], b[3]), max(hu.rel_err(u, v) for u, v in zip(a[4], b[4]))) for a, b in zip(ref, chained)])
+    assert np.median(errs) < 1e-5 and errs.max() < 0.1, f"logit errors vs oracle {errs}"
+
+
+def test_chain_replayed_from_a_hipgraph_many_times_stays_identical():
+    # tags are derived from a launch counter kept on the device: 40 replays of the captured launch against 40 eager unchained runs
+    cfg = depth_at_real_width(dep_q=3, layers=1, n_q=6)
+    chained, st = run("hip", cfg, 40)
+    assert st.graph_replays > 0 and st.chained_matvecs_in_last_plan > 0
+    plain, _ = run("hip", cfg, 40, flags=16 | 2)
+    assert_bit_identical(plain, chained, "replayed chain vs eager launches")
+
+
+@pytest.mark.parametrize("which", ["moshika", "personaplex"])
+def test_full_size_depth_chain_is_bit_identical_to_launches(which):
+    # the benchmark's own Depth transformer (6 layers, 8 steps; PersonaPlex: 16 steps whose ring of 8 wraps inside the launch) over a small Temporal stack
+    cfg = hu.hot.moshika(hu.L) if which == "moshika" else hu.hot.personaplex(hu.L)
+    cfg.num_layers, cfg.context = 2, 64
+    cfg.enable_mimi_encoder = cfg.enable_mimi_decoder = 0
+    chained, st = run("hip", cfg, 6)
+    per_step = 1 + 4 * cfg.dep_layers + 1
+    assert st.chained_matvecs_in_last_plan == cfg.dep_q * per_step, f"{st.chained_matvecs_in_last_plan} of {cfg.dep_q * per_step} Depth mat-vecs chained"
+    plain, _ = run("hip", cfg, 6, flags=16)
+    assert_bit_identical(plain, chained, which)
+
+
+def test_small_width_runs_between_attention_launches_are_chained_too():
+    # 256-wide Depth transformer: attention stays a launch of its own, the four mat-vecs between two of them form a chain whose first phase reads memory
+    cfg = hu.hot.tiny(hu.L)
+    cfg.enable_mimi_encoder = cfg.enable_mimi_decoder = 0
+    chained, st = run("hip", cfg, 8)
+    plain, _ = run("hip", cfg, 8, flags=16)
+    assert st.chained_matvecs_in_last_plan > 0
+    assert_bit_identical(plain, chained, "tiny")
+
+
+def test_sampled_mode_chains_each_step_separately():
+    # temp > 0: a sampler launch sits between the steps, so each step is a chain of its own that ends in plain logits
+    import ctypes
+    libc = ctypes.CDLL(None)
+    cfg = depth_at_real_width(dep_q=3, layers=1, n_q=6)
+    cfg.temp, cfg.temp_text, cfg.top_k, cfg.top_k_text = 0.8, 0.7, 20, 10
+    out = {}
+    for flags in (0, 16):
+        m = hu.Model("hip", cfg, seed=0, flags=flags)
+        rng = np.random.default_rng(7)
+        rec = []
+        for i in range(8):
+            libc.srand(1000 + i)
+            r, txt, aud = m.lm_step(rng.integers(0, cfg.card, cfg.n_q - cfg.io_dep_q).tolist())
+            rec.append((r, txt, aud, m.read("text_logits", cfg.text_card).copy(), [m.read(f"dep_logits{k}", cfg.card).copy() for k in range(cfg.dep_q)]))
+        out[flags] = (rec, m.stats())
+        m.free()
+    assert out[0][1].chained_matvecs_in_last_plan > 0
+    assert_bit_identical(out[16][0], out[0][0], "sampled")
