@@ -1590,6 +1590,11 @@ static plan_t * build_plan(hip_ctx * c, ggml_cgraph * g) {
             if (ct->op != GGML_OP_CONT || pc < 0 || an.skip[(size_t) pc] || uses_of(an, ct) != 1 || ct->view_src) continue;
             if (ct->type != GGML_TYPE_F32 || n->type != GGML_TYPE_F32 || ct->src[0]->type != GGML_TYPE_F32 || !ggml_are_same_shape(ct, ct->src[0]) ||
                 !ggml_are_same_shape(n, ct) || !ggml_is_contiguous(n)) continue;
+            // the strided source is read at the cpy's position instead of the cont's: nothing in between may write through an alias (set_rows, a cpy into
+            // a view of the same table), or the fold would copy newer data than the cont saw
+            bool writer_between = false;
+            for (int j = pc + 1; j < i; j++) if (writes_through_alias(g->nodes[j])) writer_between = true;
+            if (writer_between) continue;
             an.skip[(size_t) i] = an.skip[(size_t) pc] = 1;
             const tdesc d = make_tdesc(n), x = make_tdesc(ct->src[0]);
             at_pos[i].push_back([=](hipStream_t s) { k_cpy(s, d, x); });
@@ -1614,6 +1619,7 @@ static plan_t * build_plan(hip_ctx * c, ggml_cgraph * g) {
         }
         // mat-vecs with prologue / epilogue
         std::unordered_map<const void *, float *> paired_gate;   // storage of a linear_in output h (never materialised) -> g = silu(h_l) * h_r
+        size_t paired_consumed = 0;
         // on by default (MI355X_PAIRED_GATE=0 turns it off): the gate kernel it removes (-2.3 us per layer) is mostly paid back by linear_out quantising its 44
         // activation blocks in every workgroup (+1.8 us, profiles/r02_frame_stamps_paired_gate.txt) - neutral while the frame waited for the host between graphs,
         // +1.1 % once the LM graphs run back to back (354.7 -> 358.7 frames/s, profiles/r02_ab_paired_gate_run_ahead.txt)
@@ -1692,8 +1698,17 @@ static plan_t * build_plan(hip_ctx * c, ggml_cgraph * g) {
                     if (sl && sl->op == GGML_OP_UNARY && sl->op_params[0] == GGML_UNARY_OP_SILU && uses_of(an, sl) == 1 && ml && ml->op == GGML_OP_MUL &&
                         ml->src[0] == sl && ml->src[1] == r && uses_of(an, ml) == 1) {
                         const ggml_tensor * mo = sole_consumer(an, ml);
+                        // the pairing is decided HERE, for both sides: the consumer's own match is run now and must come out as the gated prologue over this
+                        // very h with none of its members claimed by another group - otherwise h has to be written and nothing is redirected
+                        bool consumer_ok = false;
                         if (mo && mo->op == GGML_OP_MUL_MAT && mo->src[1] == ml && is_qblock(mo->src[0]->type) && mo->src[0]->ne[0] == F && F > 4096 &&
                             !an.skip[(size_t) pos_of(an, mo)]) {
+                            mv_group cg;
+                            const int mpos = pos_of(an, mo);
+                            consumer_ok = match_matvec(an, mpos, cg) && cg.a.prologue == MV_GATE_SILU && (const void *) cg.a.x == h->data && cg.a.K == F && cg.a.ncols == 1;
+                            for (int m2 : cg.members) if (m2 < 0 || (m2 != mpos && an.skip[(size_t) m2])) consumer_ok = false;
+                        }
+                        if (consumer_ok) {
                             float * gbuf = (float *) em.ws((size_t) F * 4);
                             a.pair_F = F;
                             a.y = gbuf;
@@ -1705,6 +1720,7 @@ static plan_t * build_plan(hip_ctx * c, ggml_cgraph * g) {
             if (a.prologue == MV_GATE_SILU && is_qblock((enum ggml_type) a.wtype) && a.K > 4096 && paired_gate.count((const void *) a.x)) {
                 // the producer already wrote g = silu(left) * right: plain activation, quantised in this kernel's prologue
                 const float * gbuf = paired_gate[(const void *) a.x];
+                paired_consumed++;
                 a.prologue = MV_PLAIN;
                 a.x = gbuf;
                 a.x_cs = a.K;
@@ -1721,6 +1737,7 @@ static plan_t * build_plan(hip_ctx * c, ggml_cgraph * g) {
             at_pos[grp.emit_pos].push_back(pstep(a));
             if (grp.members.size() > 1) p->n_fused += (int) grp.members.size();
         }
+        GGML_ASSERT(paired_consumed == paired_gate.size() && "a linear_in was redirected to the paired gate form but its linear_out did not pick the gate vector up");
     }
     for (auto & ag : attn_groups) {
         if (ag.emit_pos < 0) continue;

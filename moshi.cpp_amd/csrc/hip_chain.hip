@@ -38,6 +38,24 @@
 
 typedef unsigned long long u64;
 
+// diagnostic build only (-DCH_LOG, tests/microbench/chain_stamps.py): wave 0 of the first and the last workgroup log s_memrealtime (10 ns ticks)
+// at the stages of every phase of the last launch
+#if defined(CH_LOG)
+__device__ u64 g_ch_log[3][512][12];   // [0] workgroup 0 wave 0, [1] last workgroup wave 0, [2] workgroup 0 loader wave
+#define CH_STAMP(i) do { if (wave == 0 && lane == 0 && (wg == 0 || wg == grid - 1) && p < 512) { u64 t_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); g_ch_log[wg == 0 ? 0 : 1][p][i] = t_; } } while (0)
+__device__ unsigned g_ch_log_n[512][2];
+#define CH_LSTAMP(i) do { if (loader && lane == 0 && wg == 0 && p < 512) { u64 t_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); g_ch_log[2][p][i] = t_; } } while (0)
+extern "C" __attribute__((visibility("default"))) int mi355x_chain_log_read(u64 * out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ch_log), sizeof(g_ch_log)) == hipSuccess ? 0 : -1;
+}
+extern "C" __attribute__((visibility("default"))) int mi355x_chain_log_read_n(unsigned * out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ch_log_n), sizeof(g_ch_log_n)) == hipSuccess ? 0 : -1;
+}
+#else
+#define CH_STAMP(i) do {} while (0)
+#define CH_LSTAMP(i) do {} while (0)
+#endif
+
 struct chain_phase {
     const char * w; long long row_bytes;
     int K, M, nb, rows_wg;     // rows_wg: rows per workgroup (paired: rows of EACH half)
@@ -64,7 +82,7 @@ struct chain_params {
     u64 * cand;                // [2][2 * grid] arg-max candidates {tag, value bits}, {tag, index}
     unsigned * launch_seq;     // bumped by workgroup 0 at the end of every launch
     unsigned * err;            // host-visible error word (bounded waits)
-    int ring_slots, throttle;
+    int ring_slots, throttle, quota_dots;   // throttle: fills per loader turn; quota_dots: fills issued beside the dot stage
 };
 
 // ---- small helpers ---------------------------------------------------------------------------------------------------------
@@ -92,29 +110,12 @@ __device__ __forceinline__ void st_granule(u64 * p, unsigned tag, unsigned value
 }
 
 struct chain_ctl {            // LDS control block
-    unsigned filled;          // ring slots whose DMA has landed (absolute count, loader -> consumers)
-    unsigned freed;           // ring slots the consumers are done with (absolute count, consumers -> loader)
-    unsigned sync;            // consumer-wave rendezvous counter (monotonic)
-    unsigned failed;          // a bounded wait gave up: everybody leaves
+    unsigned failed;          // a bounded wait gave up: everybody leaves (checked behind every workgroup barrier)
     int token;                // merged arg-max of the previous phase
-    unsigned pad[3];
+    unsigned pad[2];
     double sumsq[CH_NCW];
     float am_v[CH_NCW]; int am_i[CH_NCW];
 };
-
-// rendezvous of the CH_NCW consumer waves through an LDS counter (the loader wave never takes part, so s_barrier cannot be used)
-__device__ __forceinline__ bool csync(chain_ctl * ctl, unsigned & target, int lane) {
-    target += CH_NCW;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
-    if (lane == 0) __hip_atomic_fetch_add(&ctl->sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    unsigned spins = 0;
-    bool ok = true;
-    while (lds_load(&ctl->sync) < target) {
-        if (++spins > CH_SPIN_MAX || lds_load(&ctl->failed)) { ok = false; break; }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
-    return ok;
-}
 
 // Gather `n` (even) tagged values into dst[0..n) (LDS). Every consumer wave sweeps its own 128-value slices with 16-byte agent-scope loads
 // (two granules each; all of a sweep's loads are issued before the first tag is looked at) until all its tags match; values go to LDS as they
@@ -333,9 +334,45 @@ __device__ __forceinline__ float dequant_elem_g(const GLOBAL_AS char * row, int 
 }
 
 // ---- the kernel -----------------------------------------------------------------------------------------------------------------
+// One wave-wide LDS-DMA fill: lane l copies 16 bytes from its own global address to LDS byte address lds_dst + 16 l (nontemporal: every CU reads its
+// weights once). Written as asm on purpose: behind the builtin form the compiler, knowing that the DMA writes LDS, puts a conservative
+// s_waitcnt vmcnt(0) in front of every later LDS access of the wave - the loader would drain its whole run-ahead at each barrier (and, through the
+// common code path, so would the consumers). M0 carries the LDS address and is compiler-reserved, so it is saved and restored in the same statement
+// (cdna_hip_programming.md 5.7). Completion is counted by hand: wait_vmcnt_atmost() before the barrier that hands the chunk to the consumers.
+__device__ __forceinline__ void lds_dma_16(const GLOBAL_AS char * base /* wave-uniform */, unsigned voff, unsigned lds_dst /* wave-uniform */) {
+    // M0 is left holding the LDS address: the loader's code path has no other user of it (no movrel, no sendmsg, no builtin DMA), and saving /
+    // restoring it around every fill put two more M0 accesses behind a vector-memory instruction that has to read it first
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %2 nt" :: "v"(voff), "s"(lds_dst), "s"(base) : "memory");
+}
+
+// wait until at most n of this wave's vector-memory operations are outstanding, exactly (n >= 63: nothing to wait for - the counter cannot hold more)
+__device__ __forceinline__ void wait_vmcnt_exact(unsigned n) {
+#define W1(k) case k: wait_vmcnt<k>(); break;
+#define W8(k) W1(k) W1(k + 1) W1(k + 2) W1(k + 3) W1(k + 4) W1(k + 5) W1(k + 6) W1(k + 7)
+    switch (n) { W8(0) W8(8) W8(16) W8(24) W8(32) W8(40) W8(48) W1(56) W1(57) W1(58) W1(59) W1(60) W1(61) W1(62) default: break; }
+#undef W8
+#undef W1
+}
+
+// wait until at most n of this wave's vector-memory operations are outstanding (n rounded DOWN to an encodable step: waits for a little more)
+__device__ __forceinline__ void wait_vmcnt_atmost(unsigned n) {
+    if (n >= 56) wait_vmcnt<56>(); else if (n >= 48) wait_vmcnt<48>(); else if (n >= 40) wait_vmcnt<40>(); else if (n >= 32) wait_vmcnt<32>();
+    else if (n >= 24) wait_vmcnt<24>(); else if (n >= 16) wait_vmcnt<16>(); else if (n >= 12) wait_vmcnt<12>(); else if (n >= 8) wait_vmcnt<8>();
+    else if (n >= 4) wait_vmcnt<4>(); else if (n >= 2) wait_vmcnt<2>(); else if (n >= 1) wait_vmcnt<1>(); else wait_vmcnt<0>();
+}
+
+// Workgroup rendezvous: ALL nine waves (the loader too) meet at the hardware barrier. An earlier form kept the loader out of it and let the consumer
+// waves meet through an LDS counter: 0.3 us per rendezvous, five per phase, with the spinning waves taking issue slots from the working ones
+// (gpurun_out/r3_stamps2.txt). Returns false when some wave has given up a bounded wait: everybody leaves together.
+__device__ __forceinline__ bool wg_barrier(chain_ctl * ctl) {
+    lds_barrier();
+    return lds_load(&ctl->failed) == 0u;
+}
+
 __global__ void __launch_bounds__(CH_THREADS) matvec_chain_kernel(chain_params P) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // said to be uniform: role branches become scalar branches and the loader's cursor lives in SGPRs
     const int RS = P.ring_slots;
     char * ring = smem;
     xblk * xs = (xblk *) (ring + (size_t) RS * CH_SLOT);
@@ -346,8 +383,8 @@ __global__ void __launch_bounds__(CH_THREADS) matvec_chain_kernel(chain_params P
     float * attw = xa + 1024;
     chain_ctl * ctl = (chain_ctl *) (attw + CH_NCW * CH_ATTW);
 
-    if (tid == 0) { ctl->filled = 0; ctl->freed = 0; ctl->sync = 0; ctl->failed = 0; ctl->token = 0; }
-    __syncthreads();   // the only workgroup barrier: all nine waves are still in step here
+    if (tid == 0) { ctl->failed = 0; ctl->token = 0; }
+    __syncthreads();
 
     const int wg = blockIdx.x, grid = gridDim.x;
     const cphase_ptr PH = (cphase_ptr) P.phases;
@@ -355,57 +392,98 @@ __global__ void __launch_bounds__(CH_THREADS) matvec_chain_kernel(chain_params P
     const unsigned launch = *gp(P.launch_seq);
     const unsigned tag_base = launch << 12;
 
+    const unsigned ring_lds = (unsigned) (uintptr_t) (__attribute__((address_space(3))) char *) ring;
+    // loader state (all wave-uniform): the next slot to issue is slot ls of segment lseg of phase lp; rpos = issued % RS
+    unsigned issued = 0, rpos = 0; int lp = 0, lseg = 0, ls = 0, seg_nsl = -1;
+    unsigned seg_bytes = 0; const GLOBAL_AS char * seg_base = nullptr;
+    auto seg_setup = [&]() {   // segment (lp, lseg) of this workgroup: base address, bytes, slots
+        const auto & ph = PH[lp];
+        const long long rows_total = ph.pair_F > 0 ? ph.pair_F : (long long) ph.M;
+        const long long row0 = (long long) wg * ph.rows_wg;
+        const int rows = (int) (rows_total - row0 < ph.rows_wg ? (rows_total - row0 > 0 ? rows_total - row0 : 0) : ph.rows_wg);
+        seg_bytes = (unsigned) rows * (unsigned) ph.row_bytes;
+        seg_nsl = (int) ((seg_bytes + CH_SLOT - 1) / CH_SLOT);
+        seg_base = gp(ph.w) + (row0 + (lseg ? ph.pair_F : 0)) * ph.row_bytes;
+    };
+    // Issue fills up to (not including) absolute slot `limit`, at most `quota` of them, in phase order. Never waits: the loader shares the hardware
+    // barriers with the consumers, so a pump that blocked on landings held the whole workgroup up. One fill costs the wave ~50 - 100 cycles of issue
+    // (tests/microbench/lds_dma_rate.hip), so the loop around it is kept to a handful of scalar instructions.
+    auto pump = [&](unsigned limit, int quota) {
+        int n = (int) (limit - issued) < quota ? (int) (limit - issued) : quota;
+        while (n > 0 && lp < P.n_phases) {
+            if (seg_nsl < 0) seg_setup();
+            if (ls >= seg_nsl) {
+                ls = 0; seg_nsl = -1;
+                if (++lseg >= (PH[lp].pair_F > 0 ? 2 : 1)) { lseg = 0; lp++; }
+                continue;
+            }
+            const int m = n < seg_nsl - ls ? n : seg_nsl - ls;
+            unsigned voff = (unsigned) ls * CH_SLOT + (unsigned) lane * 16u;
+            for (int i = 0; i < m; i++) {
+                lds_dma_16(seg_base, voff < seg_bytes ? voff : seg_bytes - 16u, ring_lds + rpos * CH_SLOT);
+                voff += CH_SLOT;
+                if (++rpos == (unsigned) RS) rpos = 0;
+            }
+            ls += m; issued += (unsigned) m; n -= m;
+        }
+    };
+
     // ================================================= loader wave =================================================
+    // Its own code path: in a path shared with the consumers the compiler's vector-memory waits (for the consumers' loads and stores, which this wave
+    // never executes) land in the fill loop and drain the run-ahead (an s_waitcnt vmcnt(1) per fill in one build). The loop mirrors the consumers'
+    // barrier sequence phase by phase: hand-off [, attention] [, norm], blocks ready, dots done [, arg-max].
     if (wave == CH_NCW) {
-        unsigned issued = 0, freed = 0, spins = 0;
+        unsigned chunk_abs = 0;
         for (int p = 0; p < P.n_phases; p++) {
             const auto & ph = PH[p];
-            const int nseg = ph.pair_F > 0 ? 2 : 1;
-            const long long rows_total = ph.pair_F > 0 ? ph.pair_F : (long long) ph.M;
+            const bool paired = ph.pair_F > 0;
+            const long long rows_total = paired ? ph.pair_F : (long long) ph.M;
             const long long row0 = (long long) wg * ph.rows_wg;
             const int rows = (int) (rows_total - row0 < ph.rows_wg ? (rows_total - row0 > 0 ? rows_total - row0 : 0) : ph.rows_wg);
-            const unsigned bytes = (unsigned) rows * (unsigned) ph.row_bytes;
-            const int nsl = (int) ((bytes + CH_SLOT - 1) / CH_SLOT);
-            for (int seg = 0; seg < nseg; seg++) {
-                const GLOBAL_AS char * src = gp(ph.w) + (row0 + (seg ? ph.pair_F : 0)) * ph.row_bytes;
-                for (int s = 0; s < nsl; s++) {
-                    if (issued - freed >= (unsigned) RS) {
-                        // ring full: everything issued so far may as well be waited for and published, then wait for the consumers
-                        wait_vmcnt<0>();
-                        if (lane == 0) lds_store(&ctl->filled, issued);
-                        while (issued - (freed = lds_load(&ctl->freed)) >= (unsigned) RS) {
-                            if (++spins > CH_SPIN_MAX || lds_load(&ctl->failed)) { if (lane == 0) { lds_store(&ctl->failed, 1u); *gp(P.err) = 2u; } return; }
-                            __builtin_amdgcn_s_sleep(2);
-                        }
-                    }
-                    unsigned off = (unsigned) s * CH_SLOT + (unsigned) lane * 16u;
-                    if (off >= bytes) off = bytes - 16u;
-                    __builtin_amdgcn_global_load_lds((const GLOBAL_AS void *) (src + off),
-                                                     (__attribute__((address_space(3))) void *) (ring + (size_t) (issued % (unsigned) RS) * CH_SLOT), 16, 0, 2 /* nt */);
-                    issued++;
-                    // throttle: at most `throttle` fills outstanding, so the consumers' own gathers are not queued behind a long burst
-                    // (MI355X_MICROARCH.md gather-pass); everything older has landed and is published
-                    const int th = P.throttle;
-                    if (th <= 8) { wait_vmcnt<8>(); if (issued > 8 && lane == 0) lds_store(&ctl->filled, issued - 8); }
-                    else if (th <= 16) { wait_vmcnt<16>(); if (issued > 16 && lane == 0) lds_store(&ctl->filled, issued - 16); }
-                    else if (th <= 32) { wait_vmcnt<32>(); if (issued > 32 && lane == 0) lds_store(&ctl->filled, issued - 32); }
-                    else { wait_vmcnt<48>(); if (issued > 48 && lane == 0) lds_store(&ctl->filled, issued - 48); }
-                }
-            }
+            const unsigned seg_slots = ((unsigned) rows * (unsigned) ph.row_bytes + CH_SLOT - 1) / CH_SLOT;
+            const unsigned chunk_end = chunk_abs + (paired ? 2u : 1u) * seg_slots;
+            const bool loader = true;
+            (void) loader;
+            // This phase's chunk first: issued in full (normally long ago) and landed - an exact count, so that younger fills stay in flight. Then
+            // new fills, while the workgroup waits for the other workgroups' rows anyway (the hand-off) and, below, beside the dot stage.
+            CH_LSTAMP(0);
+            pump(chunk_end, 1 << 20);
+            CH_LSTAMP(1);
+            wait_vmcnt_exact(issued - chunk_end);
+            CH_LSTAMP(2);
+            pump(chunk_abs + (unsigned) RS, P.throttle);
+            CH_LSTAMP(3);
+#if defined(CH_LOG)
+            if (lane == 0 && wg == 0 && p < 512) { g_ch_log_n[p][0] = issued; g_ch_log_n[p][1] = chunk_end; }
+#endif
+            // the consumers' scalar reads of the NEXT phase's descriptor (three 64-byte lines, each a scalar-cache miss of several hundred ns in
+            // front of their pre-loads) are taken off their path: this wave touches the lines one phase early; the scalar cache is shared by the CU
+            if (p + 1 < P.n_phases) { const auto & nx = PH[p + 1]; asm volatile("" :: "s"(nx.K), "s"(nx.res), "s"(nx.n_pub), "s"(nx.argmax));
+                if (nx.prologue == MV_ATTN) { const auto & na = AT[nx.attn]; asm volatile("" :: "s"(na.q_ts), "s"(na.index), "s"(na.write_only)); } }
+            if (ph.x_chain && ph.prologue == MV_ATTN && !wg_barrier(ctl)) return;  // q / k / v gathered (other phases take their blocks into registers)
+            if (ph.x_chain && ph.prologue == MV_ATTN && !wg_barrier(ctl)) return; // attention done
+            if (ph.prologue == MV_RMSNORM && !wg_barrier(ctl)) return;           // sums of squares
+            if (!wg_barrier(ctl)) return;                                        // blocks ready, chunk landed
+            CH_LSTAMP(5);
+            if (P.quota_dots > 0) pump(chunk_abs + (unsigned) RS, P.quota_dots);
+            CH_LSTAMP(6);
+            if (!wg_barrier(ctl)) return;                                        // dots done: the chunk is free
+            chunk_abs = chunk_end;
+            if (ph.argmax && !wg_barrier(ctl)) return;                           // arg-max candidates of the waves
         }
-        wait_vmcnt<0>();
-        if (lane == 0) lds_store(&ctl->filled, issued);
         return;
     }
 
     // ================================================= consumer waves ==============================================
-    unsigned sync_target = 0, chunk_abs = 0;   // chunk_abs: absolute ring slot at which the current phase's first segment starts
+    unsigned chunk_abs = 0;   // absolute ring slot at which the current phase's first segment starts
     const __amdgpu_buffer_rsrc_t gb = make_rsrc(P.gbuf, 2u * CH_XF_MAX * 8u);
     const __amdgpu_buffer_rsrc_t cb = make_rsrc(P.cand, 2u * 2u * (unsigned) grid * 8u);
     const unsigned ring_bytes = (unsigned) RS * CH_SLOT;
     bool alive = true;
+    constexpr bool loader = false;
+    auto give_up = [&]() { if (lane == 0) { lds_store(&ctl->failed, 1u); *gp(P.err) = 2u; } };
 
-    for (int p = 0; p < P.n_phases && alive; p++) {
+    for (int p = 0; p < P.n_phases; p++) {
         const auto & ph = PH[p];
         const unsigned tag_in = tag_base | (unsigned) p, tag_out = tag_base | (unsigned) (p + 1);
         const int nb = ph.nb, K = ph.K;
@@ -417,29 +495,42 @@ __global__ void __launch_bounds__(CH_THREADS) matvec_chain_kernel(chain_params P
         const unsigned seg_slots = (seg_bytes + CH_SLOT - 1) / CH_SLOT;
         const unsigned chunk_end = chunk_abs + (paired ? 2u : 1u) * seg_slots;
         const int nblk_seg = rows * nb, nblk = paired ? 2 * nblk_seg : nblk_seg;
+        const bool is_attn = ph.prologue == MV_ATTN, is_rms = ph.prologue == MV_RMSNORM;
 
-        // ---- loads that do not depend on the previous phase go out before the hand-off wait
-        // prologue weights (alpha) of this wave's blocks
-        f32x4 al[2];
+        CH_STAMP(0);
+
+        // ---- the hand-off poll goes out first; the loads that do not depend on the previous phase (norm weights, x from memory, the attention's
+        // ring rows) ride behind it. A phase without attention takes its blocks straight into registers: block b = 256 values = lane l's granules
+        // 4 l .. 4 l + 3 = two 16-byte loads, waves take blocks w, w + 8 - no LDS staging, no rendezvous before the norm.
+        const bool in_regs = ph.x_chain && !is_attn;
+        const unsigned in_base = (unsigned) ((p - 1) & 1) * (CH_XF_MAX * 8u);
+        const bool has0 = wave < nb, has1 = wave + CH_NCW < nb;   // (wave-uniform) only waves that own a block poll: every poll is a fabric read
+        u32x4 gq[2][2];
+        gq[0][0] = gq[0][1] = gq[1][0] = gq[1][1] = (u32x4) { 0u, tag_in, 0u, tag_in };
+        auto issue_poll = [&]() {
+            if (has0) {
+                const unsigned o0 = in_base + ((unsigned) wave * 256u + (unsigned) lane * 4u) * 8u;
+                gq[0][0] = ld16_agent(gb, o0); gq[0][1] = ld16_agent(gb, o0 + 16u);
+                if (has1) {
+                    const unsigned o1 = o0 + CH_NCW * 256u * 8u;
+                    gq[1][0] = ld16_agent(gb, o1); gq[1][1] = ld16_agent(gb, o1 + 16u);
+                }
+            }
+        };
+        if (in_regs) issue_poll();
+        f32x4 al[2], xm[2];
+        u32x4 kq[2], vq[2];
+        int at_slot = 0; float at_m = 0.f, at_rc = 1.f, at_rs = 0.f;
+        __amdgpu_buffer_rsrc_t kr = gb, vr = gb;
 #pragma unroll
         for (int r = 0; r < 2; r++) {
             const int b = wave + r * CH_NCW;
             al[r] = (f32x4) { 1.f, 1.f, 1.f, 1.f };
-            if (ph.prologue == MV_RMSNORM && b < nb) al[r] = *(const GLOBAL_AS f32x4 *) (ph.alpha + b * 256 + lane * 4);
-        }
-        // x from memory
-        f32x4 xm[2];
-#pragma unroll
-        for (int r = 0; r < 2; r++) {
-            const int b = wave + r * CH_NCW;
+            if (is_rms && b < nb) al[r] = *(const GLOBAL_AS f32x4 *) (ph.alpha + b * 256 + lane * 4);
             xm[r] = (f32x4) { 0.f, 0.f, 0.f, 0.f };
             if (!ph.x_chain && b < nb) xm[r] = *(const GLOBAL_AS f32x4 *) (ph.x + b * 256 + lane * 4);
         }
-        // attention: ring rows, mask, slot, rotation
-        u32x4 kq[2], vq[2];
-        int at_slot = 0; float at_m = 0.f, at_rc = 1.f, at_rs = 0.f;
-        __amdgpu_buffer_rsrc_t kr = gb, vr = gb;
-        if (ph.prologue == MV_ATTN) {
+        if (is_attn) {
             const attn_args at = load_attn(AT + ph.attn);
             kr = make_rsrc(at.kcache, (unsigned) ((int64_t) at.H * at.k_nb2));
             vr = make_rsrc(at.vcache, (unsigned) ((int64_t) at.H * at.v_nb2));
@@ -449,163 +540,186 @@ __global__ void __launch_bounds__(CH_THREADS) matvec_chain_kernel(chain_params P
             at_m = gp(at.mask)[cc];
             if (at.rot) { at_rc = gp(at.rot)[pp]; at_rs = gp(at.rot)[32 + pp]; }
         }
+        CH_STAMP(1);
 
         // ---- stage 1: the activation vector -> Q8_K blocks in xs
-        const float * xsrc = xf;   // LDS source of the blocks (xf: gathered vector, xa: attention output)
-        if (ph.x_chain) {
-            const int n_in = PH[p - 1].n_pub;
-            if (!gather_vector(gb, (unsigned) ((p - 1) & 1) * (CH_XF_MAX * 8u), n_in, tag_in, xf, wave, lane, ctl)) { alive = false; break; }
-            if (!csync(ctl, sync_target, lane)) { alive = false; break; }
-            if (ph.prologue == MV_ATTN) {
+        const float * xsrc = xf;   // LDS source of the blocks of an attention phase (xa: attention output)
+        if (in_regs) {
+            unsigned spins = 0;
+            for (;;) {
+                bool ok = true;
+#pragma unroll
+                for (int r = 0; r < 2; r++) ok = ok && gq[r][0].y == tag_in && gq[r][0].w == tag_in && gq[r][1].y == tag_in && gq[r][1].w == tag_in;
+                if (__all(ok)) break;
+                if (++spins > CH_SPIN_MAX || lds_load(&ctl->failed)) { give_up(); break; }
+                __builtin_amdgcn_s_sleep(1);
+                issue_poll();
+            }
+            CH_STAMP(2);
+        } else if (ph.x_chain) {
+            if (!gather_vector(gb, in_base, PH[p - 1].n_pub, tag_in, xf, wave, lane, ctl)) give_up();
+            CH_STAMP(2);
+            if (!wg_barrier(ctl)) { alive = false; break; }
+            {
                 const attn_args at = load_attn(AT + ph.attn);
                 chain_attn_wave(at, xf + ph.q_off, xf + ph.k_off, xf + ph.v_off, wave * 2, lane, attw + wave * CH_ATTW, xa + wave * 128, kq, vq, wg == 0, kr, vr,
                                 at_slot, at_m, at_rc, at_rs);
-                if (!csync(ctl, sync_target, lane)) { alive = false; break; }
-                xsrc = xa;
             }
+            if (!wg_barrier(ctl)) { alive = false; break; }
+            xsrc = xa;
         }
+        CH_STAMP(3);
         float v[2][4];
 #pragma unroll
         for (int r = 0; r < 2; r++) {
             const int b = wave + r * CH_NCW;
             f32x4 t = xm[r];
-            if (ph.x_chain && b < nb) t = *(const f32x4 *) (xsrc + b * 256 + lane * 4);
+            if (in_regs) t = (f32x4) { __uint_as_float(gq[r][0].x), __uint_as_float(gq[r][0].z), __uint_as_float(gq[r][1].x), __uint_as_float(gq[r][1].z) };
+            else if (ph.x_chain && b < nb) t = *(const f32x4 *) (xsrc + b * 256 + lane * 4);
+            if (b >= nb) t = (f32x4) { 0.f, 0.f, 0.f, 0.f };   // (a clamped re-read does not count towards the norm)
             v[r][0] = t.x; v[r][1] = t.y; v[r][2] = t.z; v[r][3] = t.w;
         }
-        if (ph.prologue == MV_RMSNORM) {
+        if (is_rms) {
             // matvec_q4k_kernel's order: per-thread squares in double, wave butterfly, waves added in index order
-            double acc = 0;
+            if (!loader) {
+                double acc = 0;
 #pragma unroll
-            for (int r = 0; r < 2; r++)
+                for (int r = 0; r < 2; r++)
 #pragma unroll
-                for (int k = 0; k < 4; k++) acc += (double) (v[r][k] * v[r][k]);
-            acc = wave_allsum_f64(acc);
-            if (lane == 0) ctl->sumsq[wave] = acc;
-            if (!csync(ctl, sync_target, lane)) { alive = false; break; }
-            double tot = 0;
+                    for (int k = 0; k < 4; k++) acc += (double) (v[r][k] * v[r][k]);
+                acc = wave_allsum_f64(acc);
+                if (lane == 0) ctl->sumsq[wave] = acc;
+            }
+            if (!wg_barrier(ctl)) { alive = false; break; }
+            if (!loader) {
+                double tot = 0;
 #pragma unroll
-            for (int w = 0; w < CH_NCW; w++) tot += ctl->sumsq[w];
-            const float mean = (float) (tot / (double) K);
-            const float scale = 1.0f / sqrtf(mean + ph.eps);
+                for (int w = 0; w < CH_NCW; w++) tot += ctl->sumsq[w];
+                const float mean = (float) (tot / (double) K);
+                const float scale = 1.0f / sqrtf(mean + ph.eps);
+#pragma unroll
+                for (int r = 0; r < 2; r++) {
+                    const float a4[4] = { al[r].x, al[r].y, al[r].z, al[r].w };
+#pragma unroll
+                    for (int k = 0; k < 4; k++) v[r][k] = a4[k] * (v[r][k] * scale);
+                }
+            }
+        }
+        if (!loader) {
 #pragma unroll
             for (int r = 0; r < 2; r++) {
-                const float a4[4] = { al[r].x, al[r].y, al[r].z, al[r].w };
-#pragma unroll
-                for (int k = 0; k < 4; k++) v[r][k] = a4[k] * (v[r][k] * scale);
+                const int b = wave + r * CH_NCW;
+                if (b < nb) quantize_block_q8k(xs + b, v[r], lane);
             }
         }
-#pragma unroll
-        for (int r = 0; r < 2; r++) {
-            const int b = wave + r * CH_NCW;
-            if (b < nb) quantize_block_q8k(xs + b, v[r], lane);
-        }
-        if (!csync(ctl, sync_target, lane)) { alive = false; break; }
+        CH_STAMP(4);
+        if (!wg_barrier(ctl)) { alive = false; break; }
+        CH_STAMP(5);
 
         // ---- stage 2: super-block dots out of the ring (the WS = 1 arithmetic of matvec_q4k_kernel: 8 lanes per super-block)
-        {
-            unsigned spins = 0;
-            while (lds_load(&ctl->filled) < chunk_end) {
-                if (++spins > CH_SPIN_MAX || lds_load(&ctl->failed)) { alive = false; break; }
-                __builtin_amdgcn_s_sleep(1);
-            }
-            if (!alive) break;
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
-        }
-        const unsigned base0 = (chunk_abs % (unsigned) RS) * CH_SLOT, base1 = ((chunk_abs + seg_slots) % (unsigned) RS) * CH_SLOT;
-        for (int p0 = 0; p0 < nblk; p0 += CH_NCW * 8) {
-            const int sb = p0 + wave * 8 + (lane >> 3);
-            const int sbc = sb < nblk ? sb : nblk - 1;
-            const int j8 = lane & 7, g32 = j8 >> 1, hf = j8 & 1;
-            unsigned o = sbc < nblk_seg ? base0 + (unsigned) sbc * 144u : base1 + (unsigned) (sbc - nblk_seg) * 144u;
-            if (o >= ring_bytes) o -= ring_bytes;
-            unsigned oq = o + 16u + 16u * (unsigned) j8;
-            if (oq >= ring_bytes) oq -= ring_bytes;
-            const u32x4 dh = *(const u32x4 *) (ring + o), dq = *(const u32x4 *) (ring + oq);
-            const xblk * xb = xs + (sbc % nb);
-            const uint32_t hw[4] = { dh.x, dh.y, dh.z, dh.w };
-            uint32_t sc[2], mn[2];
-            q4k_unpack_scales_w(hw[1], hw[2], hw[3], sc, mn);
-            const u32x4 ylo = *(const u32x4 *) (xb->q + 64 * g32 + 16 * hf), yhi = *(const u32x4 *) (xb->q + 64 * g32 + 32 + 16 * hf);
-            const uint32_t qw[4] = { dq.x, dq.y, dq.z, dq.w }, yl[4] = { ylo.x, ylo.y, ylo.z, ylo.w }, yh[4] = { yhi.x, yhi.y, yhi.z, yhi.w };
-            int lo = 0, hi = 0;
+        if (!loader) {
+            const unsigned base0 = (chunk_abs % (unsigned) RS) * CH_SLOT, base1 = ((chunk_abs + seg_slots) % (unsigned) RS) * CH_SLOT;
+            for (int p0 = 0; p0 < nblk; p0 += CH_NCW * 8) {
+                const int sb = p0 + wave * 8 + (lane >> 3);
+                const int sbc = sb < nblk ? sb : nblk - 1;
+                const int j8 = lane & 7, g32 = j8 >> 1, hf = j8 & 1;
+                unsigned o = sbc < nblk_seg ? base0 + (unsigned) sbc * 144u : base1 + (unsigned) (sbc - nblk_seg) * 144u;
+                if (o >= ring_bytes) o -= ring_bytes;
+                unsigned oq = o + 16u + 16u * (unsigned) j8;
+                if (oq >= ring_bytes) oq -= ring_bytes;
+                const u32x4 dh = *(const u32x4 *) (ring + o), dq = *(const u32x4 *) (ring + oq);
+                const xblk * xb = xs + (sbc % nb);
+                const uint32_t hw[4] = { dh.x, dh.y, dh.z, dh.w };
+                uint32_t sc[2], mn[2];
+                q4k_unpack_scales_w(hw[1], hw[2], hw[3], sc, mn);
+                const u32x4 ylo = *(const u32x4 *) (xb->q + 64 * g32 + 16 * hf), yhi = *(const u32x4 *) (xb->q + 64 * g32 + 32 + 16 * hf);
+                const uint32_t qw[4] = { dq.x, dq.y, dq.z, dq.w }, yl[4] = { ylo.x, ylo.y, ylo.z, ylo.w }, yh[4] = { yhi.x, yhi.y, yhi.z, yhi.w };
+                int lo = 0, hi = 0;
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
-                lo = dot4_i8((int) (qw[k] & 0x0F0F0F0Fu), (int) yl[k], lo);
-                hi = dot4_i8((int) ((qw[k] >> 4) & 0x0F0F0F0Fu), (int) yh[k], hi);
+                for (int k = 0; k < 4; k++) {
+                    lo = dot4_i8((int) (qw[k] & 0x0F0F0F0Fu), (int) yl[k], lo);
+                    hi = dot4_i8((int) ((qw[k] >> 4) & 0x0F0F0F0Fu), (int) yh[k], hi);
+                }
+                const int i0 = 2 * g32, i1 = 2 * g32 + 1;
+                const int s0 = (int) ((sc[i0 >> 2] >> (8 * (i0 & 3))) & 0xff), s1 = (int) ((sc[i1 >> 2] >> (8 * (i1 & 3))) & 0xff);
+                int isum = __mul24(s0, lo) + __mul24(s1, hi);
+                const uint32_t bs2 = *(const uint32_t *) (xb->bsums + 2 * j8);
+                const int bs = (int) (int16_t) (bs2 & 0xffff) + (int) (int16_t) (bs2 >> 16);
+                int msum = __mul24((int) ((mn[j8 >> 2] >> (8 * (j8 & 3))) & 0xff), bs);
+                isum += dpp_i32<DPP_QUAD_XOR1>(isum); msum += dpp_i32<DPP_QUAD_XOR1>(msum);
+                isum += dpp_i32<DPP_QUAD_XOR2>(isum); msum += dpp_i32<DPP_QUAD_XOR2>(msum);
+                isum += dpp_i32<DPP_HALF_MIRROR>(isum); msum += dpp_i32<DPP_HALF_MIRROR>(msum);
+                if (j8 == 0 && sb < nblk) {
+                    const float d = h2f((uint16_t) (hw[0] & 0xffff)) * xb->d, dmin = h2f((uint16_t) (hw[0] >> 16)) * xb->d;
+                    part[sb] = d * (float) isum - dmin * (float) msum;
+                }
             }
-            const int i0 = 2 * g32, i1 = 2 * g32 + 1;
-            const int s0 = (int) ((sc[i0 >> 2] >> (8 * (i0 & 3))) & 0xff), s1 = (int) ((sc[i1 >> 2] >> (8 * (i1 & 3))) & 0xff);
-            int isum = __mul24(s0, lo) + __mul24(s1, hi);
-            const uint32_t bs2 = *(const uint32_t *) (xb->bsums + 2 * j8);
-            const int bs = (int) (int16_t) (bs2 & 0xffff) + (int) (int16_t) (bs2 >> 16);
-            int msum = __mul24((int) ((mn[j8 >> 2] >> (8 * (j8 & 3))) & 0xff), bs);
-            isum += dpp_i32<DPP_QUAD_XOR1>(isum); msum += dpp_i32<DPP_QUAD_XOR1>(msum);
-            isum += dpp_i32<DPP_QUAD_XOR2>(isum); msum += dpp_i32<DPP_QUAD_XOR2>(msum);
-            isum += dpp_i32<DPP_HALF_MIRROR>(isum); msum += dpp_i32<DPP_HALF_MIRROR>(msum);
-            if (j8 == 0 && sb < nblk) {
-                const float d = h2f((uint16_t) (hw[0] & 0xffff)) * xb->d, dmin = h2f((uint16_t) (hw[0] >> 16)) * xb->d;
-                part[sb] = d * (float) isum - dmin * (float) msum;
+            CH_STAMP(6);
+            // the token this phase's epilogue needs (the previous phase's arg-max): wave 0 merges the candidates
+            if (ph.emb_chain && wave == 0) {
+                int token = 0;
+                if (!gather_token(cb, (unsigned) ((p - 1) & 1) * (2u * (unsigned) grid * 8u), grid, tag_in, lane, ctl, token)) give_up();
+                if (lane == 0) {
+                    ctl->token = token;
+                    if (wg == 0) { const auto & pp = PH[p - 1]; if (pp.argmax_out[0]) *gp(pp.argmax_out[0]) = token; if (pp.argmax_out[1]) *gp(pp.argmax_out[1]) = token; }
+                }
             }
         }
-        // the token this phase's epilogue needs (the previous phase's arg-max): wave 0 merges the candidates while the others finish their dots
-        if (ph.emb_chain && wave == 0) {
-            int token = 0;
-            if (!gather_token(cb, (unsigned) ((p - 1) & 1) * (2u * (unsigned) grid * 8u), grid, tag_in, lane, ctl, token)) { alive = false; break; }
-            if (lane == 0) {
-                ctl->token = token;
-                if (wg == 0) { const auto & pp = PH[p - 1]; if (pp.argmax_out[0]) *gp(pp.argmax_out[0]) = token; if (pp.argmax_out[1]) *gp(pp.argmax_out[1]) = token; }
-            }
-        }
-        if (!csync(ctl, sync_target, lane)) { alive = false; break; }
-        if (wave == 0 && lane == 0) lds_store(&ctl->freed, chunk_end);   // every wave is past its last ring read
+        if (!wg_barrier(ctl)) { alive = false; break; }   // partial sums and token visible; every wave is past its last ring read of this chunk
+        CH_STAMP(7);
         chunk_abs = chunk_end;
 
         // ---- stage 3: fixed-order row sums, epilogue, publication
         const unsigned pub_base = (unsigned) (p & 1) * CH_XF_MAX;
         float best = -INFINITY; int bi = -1;
-        if (paired) {
-            for (int rr = tid >> 4; rr < rows; rr += CH_NCW * 4) {
-                float sl = 0.f, sr = 0.f;
-                for (int j = tid & 15; j < nb; j += 16) { sl += part[rr * nb + j]; sr += part[(rows + rr) * nb + j]; }
-                sl = row16_allsum_f32(sl); sr = row16_allsum_f32(sr);
-                if ((tid & 15) == 0) {
-                    const float g = (sl / (1.0f + expf(-sl))) * sr;
-                    if (ph.n_pub) st_granule(P.gbuf + pub_base + row0 + rr, tag_out, __float_as_uint(g));
-                    gp(ph.y)[row0 + rr] = sl; gp(ph.y)[ph.pair_F + row0 + rr] = sr;
-                }
-            }
-        } else {
-            float emb_scale = 1.f; const GLOBAL_AS char * emb_row = nullptr;
-            if (ph.emb.table) {
-                int64_t r = ph.emb_chain ? (int64_t) ctl->token : (int64_t) *gp(ph.emb.index);
-                if (r < 0 || r >= ph.emb.n_rows) r = 0;
-                emb_row = gp(ph.emb.table) + r * ph.emb.row_bytes;
-                if (ph.emb.scale) emb_scale = *gp(ph.emb.scale);
-            }
-            for (int rr = tid >> 4; rr < rows; rr += CH_NCW * 4) {
-                float sum = 0.f;
-                for (int j = tid & 15; j < nb; j += 16) sum += part[rr * nb + j];
-                sum = row16_allsum_f32(sum);
-                if ((tid & 15) == 0) {
-                    const int64_t row = row0 + rr;
-                    if (ph.res == 1) sum = xres[rr] + sum;
-                    else if (ph.res == 2) sum = gp(ph.residual)[row] + sum;
-                    else if (emb_row) {
-                        float e = dequant_elem_g(emb_row, ph.emb.type, row);
-                        if (ph.emb.scale) e = e * emb_scale;
-                        sum = sum + e;
+        if (!loader) {
+            if (paired) {
+                for (int rr = tid >> 4; rr < rows; rr += CH_NCW * 4) {
+                    float sl = 0.f, sr = 0.f;
+                    for (int j = tid & 15; j < nb; j += 16) { sl += part[rr * nb + j]; sr += part[(rows + rr) * nb + j]; }
+                    sl = row16_allsum_f32(sl); sr = row16_allsum_f32(sr);
+                    if ((tid & 15) == 0) {
+                        const float g = (sl / (1.0f + expf(-sl))) * sr;
+                        if (ph.n_pub) st_granule(P.gbuf + pub_base + row0 + rr, tag_out, __float_as_uint(g));
+                        gp(ph.y)[row0 + rr] = sl; gp(ph.y)[ph.pair_F + row0 + rr] = sr;
                     }
-                    if (ph.save) xres[rr] = sum;
-                    if (ph.n_pub) st_granule(P.gbuf + pub_base + row, tag_out, __float_as_uint(sum));
-                    gp(ph.y)[row] = sum;
-                    if (sum >= best) { best = sum; bi = (int) row; }   // rows ascend per thread: '>=' keeps the last maximum
+                }
+            } else {
+                float emb_scale = 1.f; const GLOBAL_AS char * emb_row = nullptr;
+                if (ph.emb.table) {
+                    int64_t r = ph.emb_chain ? (int64_t) ctl->token : (int64_t) *gp(ph.emb.index);
+                    if (r < 0 || r >= ph.emb.n_rows) r = 0;
+                    emb_row = gp(ph.emb.table) + r * ph.emb.row_bytes;
+                    if (ph.emb.scale) emb_scale = *gp(ph.emb.scale);
+                }
+                for (int rr = tid >> 4; rr < rows; rr += CH_NCW * 4) {
+                    float sum = 0.f;
+                    for (int j = tid & 15; j < nb; j += 16) sum += part[rr * nb + j];
+                    sum = row16_allsum_f32(sum);
+                    if ((tid & 15) == 0) {
+                        const int64_t row = row0 + rr;
+                        if (ph.res == 1) sum = xres[rr] + sum;
+                        else if (ph.res == 2) sum = gp(ph.residual)[row] + sum;
+                        else if (emb_row) {
+                            float e = dequant_elem_g(emb_row, ph.emb.type, row);
+                            if (ph.emb.scale) e = e * emb_scale;
+                            sum = sum + e;
+                        }
+                        if (ph.save) xres[rr] = sum;
+                        if (ph.n_pub) st_granule(P.gbuf + pub_base + row, tag_out, __float_as_uint(sum));
+                        gp(ph.y)[row] = sum;
+                        if (sum >= best) { best = sum; bi = (int) row; }   // rows ascend per thread: '>=' keeps the last maximum
+                    }
                 }
             }
         }
+        CH_STAMP(8);
         if (ph.argmax) {
-            am_wave(best, bi);
-            if (lane == 0) { ctl->am_v[wave] = best; ctl->am_i[wave] = bi; }
-            if (!csync(ctl, sync_target, lane)) { alive = false; break; }
+            if (!loader) {
+                am_wave(best, bi);
+                if (lane == 0) { ctl->am_v[wave] = best; ctl->am_i[wave] = bi; }
+            }
+            if (!wg_barrier(ctl)) { alive = false; break; }
             if (tid == 0) {
                 for (int w = 1; w < CH_NCW; w++) am_merge(best, bi, ctl->am_v[w], ctl->am_i[w]);
                 u64 * c = P.cand + (size_t) (p & 1) * 2 * grid + 2 * wg;
@@ -614,19 +728,16 @@ __global__ void __launch_bounds__(CH_THREADS) matvec_chain_kernel(chain_params P
             }
         }
     }
+    if (!alive) return;
 
     // the chain ends in an arg-max: workgroup 0 merges the candidates and writes the token
-    if (alive && wg == 0 && wave == 0 && PH[P.n_phases - 1].argmax) {
+    if (wg == 0 && wave == 0 && PH[P.n_phases - 1].argmax) {
         const int p = P.n_phases;
         int token = 0;
         if (gather_token(cb, (unsigned) ((p - 1) & 1) * (2u * (unsigned) grid * 8u), grid, tag_base | (unsigned) p, lane, ctl, token)) {
             const auto & pp = PH[p - 1];
             if (lane == 0) { if (pp.argmax_out[0]) *gp(pp.argmax_out[0]) = token; if (pp.argmax_out[1]) *gp(pp.argmax_out[1]) = token; }
-        } else alive = false;
-    }
-    if (!alive) {
-        if (lane == 0) { lds_store(&ctl->failed, 1u); *gp(P.err) = 2u; }
-        return;
+        } else { give_up(); return; }
     }
     if (wg == 0 && tid == 0) *gp(P.launch_seq) = launch + 1u;
 }
@@ -808,7 +919,8 @@ chain_plan * k_chain_create(hipStream_t s, const mv_args * mv, int n, void * ws,
     c->P.cand = c->P.gbuf + 2 * CH_XF_MAX;
     c->P.err = err;
     c->P.ring_slots = RS;
-    c->P.throttle = chain_env("MI355X_CHAIN_THROTTLE", 32);
+    c->P.throttle = chain_env("MI355X_CHAIN_THROTTLE", 24);
+    c->P.quota_dots = chain_env("MI355X_CHAIN_QUOTA_DOTS", 16);
     c->smem = (size_t) RS * CH_SLOT + 16 * XBLK_BYTES + (size_t) (CH_XF_MAX + CH_PART_MAX + CH_RES_MAX + 1024 + CH_NCW * CH_ATTW) * 4 + sizeof(chain_ctl);
     GGML_ASSERT(c->smem <= 160 * 1024);
     static bool granted = false;

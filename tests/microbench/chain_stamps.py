@@ -1,0 +1,46 @@
+"""In-kernel timeline of the persistent chain engine (needs the -DCH_LOG build: tests/microbench/build_stamped_lib.sh, then
+MI355X_LIB=tests/microbench/ab/libggml-mi355x-log.so python tests/microbench/chain_stamps.py). Wave 0 of the first and last workgroup stamp
+s_memrealtime (10 ns ticks) at the stages of every phase of the last Depth launch."""
+import ctypes as C, os, sys
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")); sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
+import numpy as np
+import hot_util as hu
+L = hu.L
+cfg = hu.hot.moshika(L) if os.environ.get("MODEL", "moshika") == "moshika" else hu.hot.personaplex(L)
+cfg.enable_mimi_encoder = cfg.enable_mimi_decoder = 0
+m = hu.Model("hip", cfg, seed=0)
+rng = np.random.default_rng(0)
+for _ in range(8):
+    m.lm_step(rng.integers(0, cfg.card, cfg.n_q - cfg.io_dep_q).tolist())
+L.ggml_backend_synchronize(m.be)
+lib = L.ggml
+buf = (C.c_ulonglong * (3 * 512 * 12))()
+assert lib.mi355x_chain_log_read(buf) == 0
+rec = np.frombuffer(buf, np.uint64).reshape(3, 512, 12).astype(np.int64)
+names = ["start", "pre-loads", "gathered", "attn/sync", "xs ready", "ring ok", "dots", "dot sync", "published"]
+n = int((rec[0, :, 0] > 0).sum())
+t0 = rec[0, 0, 0]
+print(f"{n} phases; launch span (workgroup 0) {(rec[0, n - 1, 8] - t0) / 100.0:.1f} us")
+per = 26
+show = int(sys.argv[1]) if len(sys.argv) > 1 else 2 * per
+print("phase |  start us | " + " | ".join(f"{x:>9s}" for x in names[1:]) + " | last wg start-lag")
+for p in range(min(n, show)):
+    r = rec[0, p]
+    d = [(r[i] - r[i - 1]) / 100.0 if r[i] and r[i - 1] else 0.0 for i in range(1, 9)]
+    print(f"{p:5d} | {(r[0] - t0) / 100.0:9.2f} | " + " | ".join(f"{x:9.2f}" for x in d) + f" | {(rec[1, p, 0] - r[0]) / 100.0:8.2f}")
+dur = np.array([(rec[0, p + 1, 0] - rec[0, p, 0]) / 100.0 for p in range(n - 1)])
+stage = np.array([[(rec[0, p, i] - rec[0, p, i - 1]) / 100.0 if rec[0, p, i] and rec[0, p, i - 1] else 0.0 for i in range(1, 9)] for p in range(n)])
+print("mean per phase us:", f"{dur.mean():.2f}", "| by stage:", " ".join(f"{names[i + 1]}={stage[:, i].mean():.2f}" for i in range(8)))
+for k in range(per):
+    sel = np.arange(k, n - 1, per)
+    print(f"  phase {k:2d} of a step: {dur[sel].mean():6.2f} us  stages " + " ".join(f"{stage[sel, i].mean():5.2f}" for i in range(8)))
+
+nb = (C.c_uint * (512 * 2))()
+lib.mi355x_chain_log_read_n(nb)
+cnt = np.frombuffer(nb, np.uint32).reshape(512, 2).astype(np.int64)
+print("loader wave of workgroup 0 (us): forced pump | landing wait | pump | pump beside dots ; slots issued beyond the chunk")
+lo = rec[2]
+for p in range(min(n, int(sys.argv[2]) if len(sys.argv) > 2 else 30)):
+    r = lo[p]
+    f = lambda a, b: (r[b] - r[a]) / 100.0 if r[a] and r[b] else 0.0
+    print(f"{p:5d} | {f(0, 1):6.2f} | {f(1, 2):6.2f} | {f(2, 3):6.2f} | {f(5, 6):6.2f} ; ahead {cnt[p, 0] - cnt[p, 1]:4d}  (wave-0 start {(rec[0, p, 0] - t0) / 100.0:8.2f}, loader turn ends {(r[3] - t0) / 100.0:8.2f})")
