@@ -1774,7 +1774,7 @@ static plan_t * build_plan(hip_ctx * c, ggml_cgraph * g) {
     }
     // Persistent chains: a run of consecutive block mat-vecs each of which waits on its predecessor (the chained Depth transformer,
     // lm.h:446-553: 26 mat-vecs per step, 8 / 16 steps per graph) becomes ONE launch of the chain engine (hip_chain.hip).
-    if (fuse && !(c->flags & 16)) {
+    if (fuse && !(c->flags & 16) && ((c->flags & 32) || k_chain_default_on())) {
         std::vector<pstep> merged;
         size_t i = 0;
         while (i < p->steps.size()) {

@@ -5,14 +5,14 @@
 // Why: each of those mat-vecs moves 0.6 - 3.2 MB. As separate launches they cost 2.3 - 4.9 us in the kernel plus 1.4 - 1.8 us of boundary
 // (profiles/r02_frame_stamps_in_graph.txt) - 137 us per step for 47 MB, 0.04 of the HBM roofline. What a step needs is (a) its weights streamed
 // once and (b) 26 all-to-all hand-offs of a <= 12 KB vector. Here:
-//   * G workgroups (default 64, one per CU, 9 waves each) stay resident for the whole run; workgroup g owns the same contiguous block of rows
-//     of every matrix, so its share of a matrix is one contiguous byte range of the Q4_K stream;
-//   * wave 8 of each workgroup is a LOADER: it copies the workgroup's byte ranges of ALL phases, in order, into an LDS ring with LDS-DMA
-//     (global_load_lds_dwordx4, nontemporal), running ahead of the consumers by the ring's capacity - the weights of phase p + 1 (and p + 2) are
-//     in flight or landed while phase p waits for its input, which is what a kernel boundary can never do;
-//   * waves 0-7 are CONSUMERS: gather the previous phase's vector, run the prologue (RMS norm / attention over the 8-slot ring / plain),
-//     quantise to Q8_K exactly as matvec_q4k_kernel does, dot their super-blocks out of the ring (8 lanes per super-block, the WS = 1 arithmetic),
-//     reduce rows in the same fixed order and publish their rows;
+//   * G workgroups of 8 waves stay resident for the whole run; workgroup g owns the same contiguous block of rows of every matrix;
+//   * the weights of phase p + 1 are requested - straight into registers, 8 lanes per super-block, nontemporal - as soon as a wave has finished
+//     the dot products of phase p, i.e. BEFORE the phase's results are handed on: they are in flight across the hand-off, which is what a kernel
+//     boundary can never do. (A first form streamed them through an LDS ring with a dedicated LDS-DMA loader wave; one fill costs that wave
+//     50 - 150 cycles of issue, tests/microbench/lds_dma_rate.hip, and through the shared barriers every workgroup ended up waiting for its loader:
+//     gpurun_out/r3_sweep*.log.)
+//   * every wave gathers the previous phase's vector itself, runs the prologue (RMS norm / attention over the 8-slot ring / plain), quantises to
+//     Q8_K exactly as matvec_q4k_kernel does, dots its super-blocks (the WS = 1 arithmetic), reduces rows in the same fixed order, publishes its rows;
 //   * the hand-off is data-tagged: every published float travels as one 8-byte {tag, value} granule written by one agent-scope (sc1) store and
 //     polled with agent-scope loads - the data IS the flag, there is no grid barrier, no fence and no separate counter on the critical path
 //     (cdna_hip_programming.md Guideline 16, form R2). tag = launch sequence number << 12 | phase index + 1: never 0, never repeated in a slot;
@@ -25,11 +25,12 @@
 
 #include <stdlib.h>
 #include <string.h>
+#include <type_traits>
 #include <vector>
 
 #define CH_NCW       8                    // consumer waves per workgroup
-#define CH_THREADS   ((CH_NCW + 1) * 64)  // + 1 loader wave
-#define CH_SLOT      1024                 // bytes per ring slot = one wave-wide LDS-DMA (16 B per lane)
+#define CH_THREADS   (CH_NCW * 64)
+#define CH_PMAX      6                    // passes of 64 super-blocks a workgroup can hold in registers per phase: rows * nb <= CH_PMAX * 64
 #define CH_XF_MAX    4096                 // floats: longest vector handed from one phase to the next
 #define CH_PART_MAX  2048                 // super-block partial sums per workgroup and phase
 #define CH_RES_MAX   256                  // rows per workgroup and phase
@@ -41,19 +42,13 @@ typedef unsigned long long u64;
 // diagnostic build only (-DCH_LOG, tests/microbench/chain_stamps.py): wave 0 of the first and the last workgroup log s_memrealtime (10 ns ticks)
 // at the stages of every phase of the last launch
 #if defined(CH_LOG)
-__device__ u64 g_ch_log[3][512][12];   // [0] workgroup 0 wave 0, [1] last workgroup wave 0, [2] workgroup 0 loader wave
+__device__ u64 g_ch_log[2][512][12];   // [0] workgroup 0 wave 0, [1] last workgroup wave 0
 #define CH_STAMP(i) do { if (wave == 0 && lane == 0 && (wg == 0 || wg == grid - 1) && p < 512) { u64 t_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); g_ch_log[wg == 0 ? 0 : 1][p][i] = t_; } } while (0)
-__device__ unsigned g_ch_log_n[512][2];
-#define CH_LSTAMP(i) do { if (loader && lane == 0 && wg == 0 && p < 512) { u64 t_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); g_ch_log[2][p][i] = t_; } } while (0)
 extern "C" __attribute__((visibility("default"))) int mi355x_chain_log_read(u64 * out) {
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ch_log), sizeof(g_ch_log)) == hipSuccess ? 0 : -1;
 }
-extern "C" __attribute__((visibility("default"))) int mi355x_chain_log_read_n(unsigned * out) {
-    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ch_log_n), sizeof(g_ch_log_n)) == hipSuccess ? 0 : -1;
-}
 #else
 #define CH_STAMP(i) do {} while (0)
-#define CH_LSTAMP(i) do {} while (0)
 #endif
 
 struct chain_phase {
@@ -73,16 +68,20 @@ struct chain_phase {
     int32_t * argmax_out[2];
     float * y;                 // the ggml node's own storage (always written, plain stores: nothing inside the launch reads it)
     int n_pub;                 // values handed to the next phase: 0, M, or pair_F
+    int n_in;                  // values the previous phase handed on
+    int32_t * prev_out[2];     // emb_chain: where the previous phase's merged arg-max (the token) is stored
+    attn_args at;              // MV_ATTN: the attention whose output is x
+    char pad_[16];
 };
+static_assert(sizeof(chain_phase) % 16 == 0 && sizeof(chain_phase) <= 26 * 16, "a descriptor is staged through LDS by 16-byte lanes");
+#define CH_DESC_DWORDS ((int) (sizeof(chain_phase) / 4))
 
 struct chain_params {
     const chain_phase * phases; int n_phases;
-    const attn_args * attns;
     u64 * gbuf;                // [2][CH_XF_MAX] granules, by phase parity
     u64 * cand;                // [2][2 * grid] arg-max candidates {tag, value bits}, {tag, index}
     unsigned * launch_seq;     // bumped by workgroup 0 at the end of every launch
     unsigned * err;            // host-visible error word (bounded waits)
-    int ring_slots, throttle, quota_dots;   // throttle: fills per loader turn; quota_dots: fills issued beside the dot stage
 };
 
 // ---- small helpers ---------------------------------------------------------------------------------------------------------
@@ -269,6 +268,16 @@ __device__ __forceinline__ void chain_attn_wave(const attn_args & a, const float
     }
 }
 
+// one field of a descriptor parked in LDS, as a wave-uniform (scalar) value
+template <typename T> __device__ __forceinline__ T desc_field(const unsigned * base, int dw) {
+    static_assert(sizeof(T) == 4 || sizeof(T) == 8, "descriptor fields are 4 or 8 bytes");
+    unsigned w[2] = { (unsigned) __builtin_amdgcn_readfirstlane(base[dw]), 0u };
+    if (sizeof(T) == 8) w[1] = (unsigned) __builtin_amdgcn_readfirstlane(base[dw + 1]);
+    T r;
+    __builtin_memcpy(&r, w, sizeof(T));
+    return r;
+}
+
 // merge of arg-max candidates: larger value wins, equal values -> larger index (= the last maximum of the whole row)
 __device__ __forceinline__ void am_merge(float & best, int & bi, float ov, int oi) { if (ov > best || (ov == best && oi > bi)) { best = ov; bi = oi; } }
 __device__ __forceinline__ void am_wave(float & best, int & bi) {
@@ -334,36 +343,8 @@ __device__ __forceinline__ float dequant_elem_g(const GLOBAL_AS char * row, int 
 }
 
 // ---- the kernel -----------------------------------------------------------------------------------------------------------------
-// One wave-wide LDS-DMA fill: lane l copies 16 bytes from its own global address to LDS byte address lds_dst + 16 l (nontemporal: every CU reads its
-// weights once). Written as asm on purpose: behind the builtin form the compiler, knowing that the DMA writes LDS, puts a conservative
-// s_waitcnt vmcnt(0) in front of every later LDS access of the wave - the loader would drain its whole run-ahead at each barrier (and, through the
-// common code path, so would the consumers). M0 carries the LDS address and is compiler-reserved, so it is saved and restored in the same statement
-// (cdna_hip_programming.md 5.7). Completion is counted by hand: wait_vmcnt_atmost() before the barrier that hands the chunk to the consumers.
-__device__ __forceinline__ void lds_dma_16(const GLOBAL_AS char * base /* wave-uniform */, unsigned voff, unsigned lds_dst /* wave-uniform */) {
-    // M0 is left holding the LDS address: the loader's code path has no other user of it (no movrel, no sendmsg, no builtin DMA), and saving /
-    // restoring it around every fill put two more M0 accesses behind a vector-memory instruction that has to read it first
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %2 nt" :: "v"(voff), "s"(lds_dst), "s"(base) : "memory");
-}
-
-// wait until at most n of this wave's vector-memory operations are outstanding, exactly (n >= 63: nothing to wait for - the counter cannot hold more)
-__device__ __forceinline__ void wait_vmcnt_exact(unsigned n) {
-#define W1(k) case k: wait_vmcnt<k>(); break;
-#define W8(k) W1(k) W1(k + 1) W1(k + 2) W1(k + 3) W1(k + 4) W1(k + 5) W1(k + 6) W1(k + 7)
-    switch (n) { W8(0) W8(8) W8(16) W8(24) W8(32) W8(40) W8(48) W1(56) W1(57) W1(58) W1(59) W1(60) W1(61) W1(62) default: break; }
-#undef W8
-#undef W1
-}
-
-// wait until at most n of this wave's vector-memory operations are outstanding (n rounded DOWN to an encodable step: waits for a little more)
-__device__ __forceinline__ void wait_vmcnt_atmost(unsigned n) {
-    if (n >= 56) wait_vmcnt<56>(); else if (n >= 48) wait_vmcnt<48>(); else if (n >= 40) wait_vmcnt<40>(); else if (n >= 32) wait_vmcnt<32>();
-    else if (n >= 24) wait_vmcnt<24>(); else if (n >= 16) wait_vmcnt<16>(); else if (n >= 12) wait_vmcnt<12>(); else if (n >= 8) wait_vmcnt<8>();
-    else if (n >= 4) wait_vmcnt<4>(); else if (n >= 2) wait_vmcnt<2>(); else if (n >= 1) wait_vmcnt<1>(); else wait_vmcnt<0>();
-}
-
-// Workgroup rendezvous: ALL nine waves (the loader too) meet at the hardware barrier. An earlier form kept the loader out of it and let the consumer
-// waves meet through an LDS counter: 0.3 us per rendezvous, five per phase, with the spinning waves taking issue slots from the working ones
-// (gpurun_out/r3_stamps2.txt). Returns false when some wave has given up a bounded wait: everybody leaves together.
+// Workgroup rendezvous at the hardware barrier (LDS traffic only is waited for: loads and stores stay in flight across it). Returns false when some
+// wave has given up a bounded wait: everybody leaves together.
 __device__ __forceinline__ bool wg_barrier(chain_ctl * ctl) {
     lds_barrier();
     return lds_load(&ctl->failed) == 0u;
@@ -372,128 +353,99 @@ __device__ __forceinline__ bool wg_barrier(chain_ctl * ctl) {
 __global__ void __launch_bounds__(CH_THREADS) matvec_chain_kernel(chain_params P) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // said to be uniform: role branches become scalar branches and the loader's cursor lives in SGPRs
-    const int RS = P.ring_slots;
-    char * ring = smem;
-    xblk * xs = (xblk *) (ring + (size_t) RS * CH_SLOT);
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    xblk * xs = (xblk *) smem;
     float * xf = (float *) (xs + 16);
     float * part = xf + CH_XF_MAX;
     float * xres = part + CH_PART_MAX;
     float * xa = xres + CH_RES_MAX;
     float * attw = xa + 1024;
     chain_ctl * ctl = (chain_ctl *) (attw + CH_NCW * CH_ATTW);
+    unsigned * desc = (unsigned *) (ctl + 1);   // [3][CH_DESC_DWORDS]: the descriptors of phases p - 1, p, p + 1 (by p % 3)
 
+    // Descriptors reach the waves through LDS: read from the table with scalar loads they cost every wave several dependent scalar-cache misses at
+    // the head of every phase (~1 us of the 5.7 us phase, gpurun_out/r3_sweep10.log). Wave 7 fetches phase p + 1's descriptor with ONE vector load at
+    // the head of phase p and parks it in LDS before the "blocks ready" barrier; everybody copies it to scalar registers from there.
+    const GLOBAL_AS u32x4 * desc_src = (const GLOBAL_AS u32x4 *) P.phases;
+    constexpr int DL = CH_DESC_DWORDS / 4;   // 16-byte lanes per descriptor
     if (tid == 0) { ctl->failed = 0; ctl->token = 0; }
+    if (wave == 7 && lane < DL) ((u32x4 *) desc)[lane] = desc_src[lane];
     __syncthreads();
 
     const int wg = blockIdx.x, grid = gridDim.x;
-    const cphase_ptr PH = (cphase_ptr) P.phases;
-    const cattn_ptr AT = (cattn_ptr) P.attns;
     const unsigned launch = *gp(P.launch_seq);
     const unsigned tag_base = launch << 12;
-
-    const unsigned ring_lds = (unsigned) (uintptr_t) (__attribute__((address_space(3))) char *) ring;
-    // loader state (all wave-uniform): the next slot to issue is slot ls of segment lseg of phase lp; rpos = issued % RS
-    unsigned issued = 0, rpos = 0; int lp = 0, lseg = 0, ls = 0, seg_nsl = -1;
-    unsigned seg_bytes = 0; const GLOBAL_AS char * seg_base = nullptr;
-    auto seg_setup = [&]() {   // segment (lp, lseg) of this workgroup: base address, bytes, slots
-        const auto & ph = PH[lp];
-        const long long rows_total = ph.pair_F > 0 ? ph.pair_F : (long long) ph.M;
-        const long long row0 = (long long) wg * ph.rows_wg;
-        const int rows = (int) (rows_total - row0 < ph.rows_wg ? (rows_total - row0 > 0 ? rows_total - row0 : 0) : ph.rows_wg);
-        seg_bytes = (unsigned) rows * (unsigned) ph.row_bytes;
-        seg_nsl = (int) ((seg_bytes + CH_SLOT - 1) / CH_SLOT);
-        seg_base = gp(ph.w) + (row0 + (lseg ? ph.pair_F : 0)) * ph.row_bytes;
+    // LDS -> scalar registers, field by field: only what a phase actually uses is read (a whole-struct copy is ~100 LDS words plus as many
+    // v_readfirstlane and cost 0.7 us per phase, gpurun_out/r3_sweep11.log)
+#define CH_LD(d, base, f) (d).f = desc_field<typename std::remove_reference<decltype((d).f)>::type>(base, (int) (offsetof(chain_phase, f) / 4))
+    auto read_desc_weights = [&](int q, chain_phase & d) {   // what request_weights needs
+        const unsigned * b = desc + (q % 3) * CH_DESC_DWORDS;
+        CH_LD(d, b, w); CH_LD(d, b, row_bytes); CH_LD(d, b, M); CH_LD(d, b, nb); CH_LD(d, b, rows_wg); CH_LD(d, b, pair_F);
     };
-    // Issue fills up to (not including) absolute slot `limit`, at most `quota` of them, in phase order. Never waits: the loader shares the hardware
-    // barriers with the consumers, so a pump that blocked on landings held the whole workgroup up. One fill costs the wave ~50 - 100 cycles of issue
-    // (tests/microbench/lds_dma_rate.hip), so the loop around it is kept to a handful of scalar instructions.
-    auto pump = [&](unsigned limit, int quota) {
-        int n = (int) (limit - issued) < quota ? (int) (limit - issued) : quota;
-        while (n > 0 && lp < P.n_phases) {
-            if (seg_nsl < 0) seg_setup();
-            if (ls >= seg_nsl) {
-                ls = 0; seg_nsl = -1;
-                if (++lseg >= (PH[lp].pair_F > 0 ? 2 : 1)) { lseg = 0; lp++; }
-                continue;
-            }
-            const int m = n < seg_nsl - ls ? n : seg_nsl - ls;
-            unsigned voff = (unsigned) ls * CH_SLOT + (unsigned) lane * 16u;
-            for (int i = 0; i < m; i++) {
-                lds_dma_16(seg_base, voff < seg_bytes ? voff : seg_bytes - 16u, ring_lds + rpos * CH_SLOT);
-                voff += CH_SLOT;
-                if (++rpos == (unsigned) RS) rpos = 0;
-            }
-            ls += m; issued += (unsigned) m; n -= m;
+    // head: what the prologue and the dot stage use; tail: what the epilogue uses, read where it starts (short-lived scalars: the kernel is at the
+    // scalar-register limit, and a field kept from the head of the phase is a spill and a reload)
+    auto read_desc = [&](int q, chain_phase & d) {
+        const unsigned * b = desc + (q % 3) * CH_DESC_DWORDS;
+        CH_LD(d, b, K); CH_LD(d, b, M); CH_LD(d, b, nb); CH_LD(d, b, rows_wg); CH_LD(d, b, pair_F); CH_LD(d, b, prologue); CH_LD(d, b, x_chain);
+        CH_LD(d, b, x); CH_LD(d, b, alpha); CH_LD(d, b, eps); CH_LD(d, b, n_in); CH_LD(d, b, emb_chain); CH_LD(d, b, argmax);
+        if (d.prologue == MV_ATTN) {
+            CH_LD(d, b, q_off); CH_LD(d, b, k_off); CH_LD(d, b, v_off);
+            CH_LD(d, b, at.q_hs); CH_LD(d, b, at.k_hs); CH_LD(d, b, at.v_hs); CH_LD(d, b, at.rot); CH_LD(d, b, at.mask); CH_LD(d, b, at.index);
+            CH_LD(d, b, at.kcache); CH_LD(d, b, at.vcache); CH_LD(d, b, at.k_nb1); CH_LD(d, b, at.k_nb2); CH_LD(d, b, at.v_nb1); CH_LD(d, b, at.v_nb2);
+            CH_LD(d, b, at.H); CH_LD(d, b, at.C); CH_LD(d, b, at.scale);
         }
     };
-
-    // ================================================= loader wave =================================================
-    // Its own code path: in a path shared with the consumers the compiler's vector-memory waits (for the consumers' loads and stores, which this wave
-    // never executes) land in the fill loop and drain the run-ahead (an s_waitcnt vmcnt(1) per fill in one build). The loop mirrors the consumers'
-    // barrier sequence phase by phase: hand-off [, attention] [, norm], blocks ready, dots done [, arg-max].
-    if (wave == CH_NCW) {
-        unsigned chunk_abs = 0;
-        for (int p = 0; p < P.n_phases; p++) {
-            const auto & ph = PH[p];
-            const bool paired = ph.pair_F > 0;
-            const long long rows_total = paired ? ph.pair_F : (long long) ph.M;
-            const long long row0 = (long long) wg * ph.rows_wg;
-            const int rows = (int) (rows_total - row0 < ph.rows_wg ? (rows_total - row0 > 0 ? rows_total - row0 : 0) : ph.rows_wg);
-            const unsigned seg_slots = ((unsigned) rows * (unsigned) ph.row_bytes + CH_SLOT - 1) / CH_SLOT;
-            const unsigned chunk_end = chunk_abs + (paired ? 2u : 1u) * seg_slots;
-            const bool loader = true;
-            (void) loader;
-            // This phase's chunk first: issued in full (normally long ago) and landed - an exact count, so that younger fills stay in flight. Then
-            // new fills, while the workgroup waits for the other workgroups' rows anyway (the hand-off) and, below, beside the dot stage.
-            CH_LSTAMP(0);
-            pump(chunk_end, 1 << 20);
-            CH_LSTAMP(1);
-            wait_vmcnt_exact(issued - chunk_end);
-            CH_LSTAMP(2);
-            pump(chunk_abs + (unsigned) RS, P.throttle);
-            CH_LSTAMP(3);
-#if defined(CH_LOG)
-            if (lane == 0 && wg == 0 && p < 512) { g_ch_log_n[p][0] = issued; g_ch_log_n[p][1] = chunk_end; }
-#endif
-            // the consumers' scalar reads of the NEXT phase's descriptor (three 64-byte lines, each a scalar-cache miss of several hundred ns in
-            // front of their pre-loads) are taken off their path: this wave touches the lines one phase early; the scalar cache is shared by the CU
-            if (p + 1 < P.n_phases) { const auto & nx = PH[p + 1]; asm volatile("" :: "s"(nx.K), "s"(nx.res), "s"(nx.n_pub), "s"(nx.argmax));
-                if (nx.prologue == MV_ATTN) { const auto & na = AT[nx.attn]; asm volatile("" :: "s"(na.q_ts), "s"(na.index), "s"(na.write_only)); } }
-            if (ph.x_chain && ph.prologue == MV_ATTN && !wg_barrier(ctl)) return;  // q / k / v gathered (other phases take their blocks into registers)
-            if (ph.x_chain && ph.prologue == MV_ATTN && !wg_barrier(ctl)) return; // attention done
-            if (ph.prologue == MV_RMSNORM && !wg_barrier(ctl)) return;           // sums of squares
-            if (!wg_barrier(ctl)) return;                                        // blocks ready, chunk landed
-            CH_LSTAMP(5);
-            if (P.quota_dots > 0) pump(chunk_abs + (unsigned) RS, P.quota_dots);
-            CH_LSTAMP(6);
-            if (!wg_barrier(ctl)) return;                                        // dots done: the chunk is free
-            chunk_abs = chunk_end;
-            if (ph.argmax && !wg_barrier(ctl)) return;                           // arg-max candidates of the waves
+    auto read_desc_tail = [&](int q, chain_phase & d) {
+        const unsigned * b = desc + (q % 3) * CH_DESC_DWORDS;
+        CH_LD(d, b, res); CH_LD(d, b, residual); CH_LD(d, b, save); CH_LD(d, b, y); CH_LD(d, b, n_pub);
+        CH_LD(d, b, emb.table); CH_LD(d, b, emb.row_bytes); CH_LD(d, b, emb.n_rows); CH_LD(d, b, emb.type); CH_LD(d, b, emb.index); CH_LD(d, b, emb.scale);
+    };
+    // The weights of ONE phase live in registers: pass ps covers super-blocks 64 ps .. 64 ps + 63 of the workgroup's rows, 8 lanes per super-block -
+    // every lane of a group holds the 16-byte header (d, dmin, 6-bit scales: one fetch for the group) and its own 16-byte nibble chunk.
+    u32x4 wh[CH_PMAX], wq[CH_PMAX];
+    auto request_weights = [&](const chain_phase & pq) {   // that phase's super-blocks of this workgroup
+        const bool pr = pq.pair_F > 0;
+        const long long rt = pr ? pq.pair_F : (long long) pq.M;
+        const long long r0 = (long long) wg * pq.rows_wg;
+        const int rw = (int) (rt - r0 < pq.rows_wg ? (rt - r0 > 0 ? rt - r0 : 0) : pq.rows_wg);
+        const int nseg = rw * pq.nb, nall = pr ? 2 * nseg : nseg;
+        const GLOBAL_AS u32x4 * w0 = (const GLOBAL_AS u32x4 *) (gp(pq.w) + r0 * pq.row_bytes);
+        const GLOBAL_AS u32x4 * w1 = (const GLOBAL_AS u32x4 *) (gp(pq.w) + (r0 + pq.pair_F) * pq.row_bytes);
+#pragma unroll
+        for (int ps = 0; ps < CH_PMAX; ps++) {
+            if (ps * (CH_NCW * 8) < nall) {   // (wave-uniform)
+                const int sb = ps * (CH_NCW * 8) + wave * 8 + (lane >> 3);
+                const int sbc = sb < nall ? sb : nall - 1;
+                const GLOBAL_AS u32x4 * src = sbc < nseg ? w0 + sbc * 9 : w1 + (sbc - nseg) * 9;
+                wh[ps] = __builtin_nontemporal_load(src);
+                wq[ps] = __builtin_nontemporal_load(src + 1 + (lane & 7));
+            }
         }
-        return;
+    };
+    {
+        chain_phase first;
+        read_desc_weights(0, first);
+        request_weights(first);
     }
 
-    // ================================================= consumer waves ==============================================
-    unsigned chunk_abs = 0;   // absolute ring slot at which the current phase's first segment starts
     const __amdgpu_buffer_rsrc_t gb = make_rsrc(P.gbuf, 2u * CH_XF_MAX * 8u);
     const __amdgpu_buffer_rsrc_t cb = make_rsrc(P.cand, 2u * 2u * (unsigned) grid * 8u);
-    const unsigned ring_bytes = (unsigned) RS * CH_SLOT;
     bool alive = true;
-    constexpr bool loader = false;
     auto give_up = [&]() { if (lane == 0) { lds_store(&ctl->failed, 1u); *gp(P.err) = 2u; } };
 
     for (int p = 0; p < P.n_phases; p++) {
-        const auto & ph = PH[p];
+        chain_phase ph;
+        read_desc(p, ph);
+        // wave 7 asks for the next descriptor now; it is parked in LDS before this phase's "blocks ready" barrier
+        u32x4 next_desc = (u32x4) { 0u, 0u, 0u, 0u };
+        const bool stage_next = wave == 7 && p + 1 < P.n_phases;
+        if (stage_next && lane < DL) next_desc = desc_src[(p + 1) * DL + lane];
         const unsigned tag_in = tag_base | (unsigned) p, tag_out = tag_base | (unsigned) (p + 1);
         const int nb = ph.nb, K = ph.K;
         const bool paired = ph.pair_F > 0;
         const long long rows_total = paired ? ph.pair_F : (long long) ph.M;
         const long long row0 = (long long) wg * ph.rows_wg;
         const int rows = (int) (rows_total - row0 < ph.rows_wg ? (rows_total - row0 > 0 ? rows_total - row0 : 0) : ph.rows_wg);
-        const unsigned seg_bytes = (unsigned) rows * (unsigned) ph.row_bytes;
-        const unsigned seg_slots = (seg_bytes + CH_SLOT - 1) / CH_SLOT;
-        const unsigned chunk_end = chunk_abs + (paired ? 2u : 1u) * seg_slots;
         const int nblk_seg = rows * nb, nblk = paired ? 2 * nblk_seg : nblk_seg;
         const bool is_attn = ph.prologue == MV_ATTN, is_rms = ph.prologue == MV_RMSNORM;
 
@@ -531,7 +483,7 @@ __global__ void __launch_bounds__(CH_THREADS) matvec_chain_kernel(chain_params P
             if (!ph.x_chain && b < nb) xm[r] = *(const GLOBAL_AS f32x4 *) (ph.x + b * 256 + lane * 4);
         }
         if (is_attn) {
-            const attn_args at = load_attn(AT + ph.attn);
+            const attn_args & at = ph.at;
             kr = make_rsrc(at.kcache, (unsigned) ((int64_t) at.H * at.k_nb2));
             vr = make_rsrc(at.vcache, (unsigned) ((int64_t) at.H * at.v_nb2));
             chain_attn_ring_loads(at, wave * 2, lane, kq, vq, kr, vr);
@@ -557,12 +509,11 @@ __global__ void __launch_bounds__(CH_THREADS) matvec_chain_kernel(chain_params P
             }
             CH_STAMP(2);
         } else if (ph.x_chain) {
-            if (!gather_vector(gb, in_base, PH[p - 1].n_pub, tag_in, xf, wave, lane, ctl)) give_up();
+            if (!gather_vector(gb, in_base, ph.n_in, tag_in, xf, wave, lane, ctl)) give_up();
             CH_STAMP(2);
             if (!wg_barrier(ctl)) { alive = false; break; }
             {
-                const attn_args at = load_attn(AT + ph.attn);
-                chain_attn_wave(at, xf + ph.q_off, xf + ph.k_off, xf + ph.v_off, wave * 2, lane, attw + wave * CH_ATTW, xa + wave * 128, kq, vq, wg == 0, kr, vr,
+                chain_attn_wave(ph.at, xf + ph.q_off, xf + ph.k_off, xf + ph.v_off, wave * 2, lane, attw + wave * CH_ATTW, xa + wave * 128, kq, vq, wg == 0, kr, vr,
                                 at_slot, at_m, at_rc, at_rs);
             }
             if (!wg_barrier(ctl)) { alive = false; break; }
@@ -581,59 +532,59 @@ __global__ void __launch_bounds__(CH_THREADS) matvec_chain_kernel(chain_params P
         }
         if (is_rms) {
             // matvec_q4k_kernel's order: per-thread squares in double, wave butterfly, waves added in index order
-            if (!loader) {
+            {
                 double acc = 0;
 #pragma unroll
                 for (int r = 0; r < 2; r++)
+                    if (wave + r * CH_NCW < nb)   // (wave-uniform; a block that does not exist would add exact zeros)
 #pragma unroll
-                    for (int k = 0; k < 4; k++) acc += (double) (v[r][k] * v[r][k]);
+                        for (int k = 0; k < 4; k++) acc += (double) (v[r][k] * v[r][k]);
                 acc = wave_allsum_f64(acc);
                 if (lane == 0) ctl->sumsq[wave] = acc;
             }
             if (!wg_barrier(ctl)) { alive = false; break; }
-            if (!loader) {
+            {
                 double tot = 0;
 #pragma unroll
                 for (int w = 0; w < CH_NCW; w++) tot += ctl->sumsq[w];
-                const float mean = (float) (tot / (double) K);
+                // (K a power of two - every norm of the Depth transformer: the product is the quotient, exactly, without the f64 division's chain)
+                const float mean = (K & (K - 1)) == 0 ? (float) (tot * (1.0 / (double) K)) : (float) (tot / (double) K);
                 const float scale = 1.0f / sqrtf(mean + ph.eps);
 #pragma unroll
                 for (int r = 0; r < 2; r++) {
+                    if (wave + r * CH_NCW >= nb) continue;
                     const float a4[4] = { al[r].x, al[r].y, al[r].z, al[r].w };
 #pragma unroll
                     for (int k = 0; k < 4; k++) v[r][k] = a4[k] * (v[r][k] * scale);
                 }
             }
         }
-        if (!loader) {
+        {
 #pragma unroll
             for (int r = 0; r < 2; r++) {
                 const int b = wave + r * CH_NCW;
                 if (b < nb) quantize_block_q8k(xs + b, v[r], lane);
             }
         }
+        if (stage_next && lane < DL) ((u32x4 *) (desc + ((p + 1) % 3) * CH_DESC_DWORDS))[lane] = next_desc;
         CH_STAMP(4);
         if (!wg_barrier(ctl)) { alive = false; break; }
         CH_STAMP(5);
 
-        // ---- stage 2: super-block dots out of the ring (the WS = 1 arithmetic of matvec_q4k_kernel: 8 lanes per super-block)
-        if (!loader) {
-            const unsigned base0 = (chunk_abs % (unsigned) RS) * CH_SLOT, base1 = ((chunk_abs + seg_slots) % (unsigned) RS) * CH_SLOT;
-            for (int p0 = 0; p0 < nblk; p0 += CH_NCW * 8) {
-                const int sb = p0 + wave * 8 + (lane >> 3);
+        // ---- stage 2: super-block dots out of the registers (the WS = 1 arithmetic of matvec_q4k_kernel: 8 lanes per super-block)
+        {
+#pragma unroll
+            for (int ps = 0; ps < CH_PMAX; ps++) {
+                if (ps * (CH_NCW * 8) >= nblk) break;
+                const int sb = ps * (CH_NCW * 8) + wave * 8 + (lane >> 3);
                 const int sbc = sb < nblk ? sb : nblk - 1;
                 const int j8 = lane & 7, g32 = j8 >> 1, hf = j8 & 1;
-                unsigned o = sbc < nblk_seg ? base0 + (unsigned) sbc * 144u : base1 + (unsigned) (sbc - nblk_seg) * 144u;
-                if (o >= ring_bytes) o -= ring_bytes;
-                unsigned oq = o + 16u + 16u * (unsigned) j8;
-                if (oq >= ring_bytes) oq -= ring_bytes;
-                const u32x4 dh = *(const u32x4 *) (ring + o), dq = *(const u32x4 *) (ring + oq);
                 const xblk * xb = xs + (sbc % nb);
-                const uint32_t hw[4] = { dh.x, dh.y, dh.z, dh.w };
+                const uint32_t hw[4] = { wh[ps].x, wh[ps].y, wh[ps].z, wh[ps].w };
                 uint32_t sc[2], mn[2];
                 q4k_unpack_scales_w(hw[1], hw[2], hw[3], sc, mn);
                 const u32x4 ylo = *(const u32x4 *) (xb->q + 64 * g32 + 16 * hf), yhi = *(const u32x4 *) (xb->q + 64 * g32 + 32 + 16 * hf);
-                const uint32_t qw[4] = { dq.x, dq.y, dq.z, dq.w }, yl[4] = { ylo.x, ylo.y, ylo.z, ylo.w }, yh[4] = { yhi.x, yhi.y, yhi.z, yhi.w };
+                const uint32_t qw[4] = { wq[ps].x, wq[ps].y, wq[ps].z, wq[ps].w }, yl[4] = { ylo.x, ylo.y, ylo.z, ylo.w }, yh[4] = { yhi.x, yhi.y, yhi.z, yhi.w };
                 int lo = 0, hi = 0;
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
@@ -654,6 +605,8 @@ __global__ void __launch_bounds__(CH_THREADS) matvec_chain_kernel(chain_params P
                     part[sb] = d * (float) isum - dmin * (float) msum;
                 }
             }
+            // the next phase's weights go out now: this wave's registers are free again, and the request has the whole hand-off to land in
+            if (p + 1 < P.n_phases) { chain_phase nx; read_desc_weights(p + 1, nx); request_weights(nx); }
             CH_STAMP(6);
             // the token this phase's epilogue needs (the previous phase's arg-max): wave 0 merges the candidates
             if (ph.emb_chain && wave == 0) {
@@ -661,18 +614,23 @@ __global__ void __launch_bounds__(CH_THREADS) matvec_chain_kernel(chain_params P
                 if (!gather_token(cb, (unsigned) ((p - 1) & 1) * (2u * (unsigned) grid * 8u), grid, tag_in, lane, ctl, token)) give_up();
                 if (lane == 0) {
                     ctl->token = token;
-                    if (wg == 0) { const auto & pp = PH[p - 1]; if (pp.argmax_out[0]) *gp(pp.argmax_out[0]) = token; if (pp.argmax_out[1]) *gp(pp.argmax_out[1]) = token; }
+                    if (wg == 0) {
+                        const unsigned * db = desc + (p % 3) * CH_DESC_DWORDS;
+                        CH_LD(ph, db, prev_out[0]); CH_LD(ph, db, prev_out[1]);
+                        if (ph.prev_out[0]) *gp(ph.prev_out[0]) = token;
+                        if (ph.prev_out[1]) *gp(ph.prev_out[1]) = token;
+                    }
                 }
             }
         }
-        if (!wg_barrier(ctl)) { alive = false; break; }   // partial sums and token visible; every wave is past its last ring read of this chunk
+        if (!wg_barrier(ctl)) { alive = false; break; }   // partial sums and token visible
         CH_STAMP(7);
-        chunk_abs = chunk_end;
+        read_desc_tail(p, ph);   // (moving these reads in front of the barrier does not help: every wave does them, there is no slack to hide them in)
 
         // ---- stage 3: fixed-order row sums, epilogue, publication
         const unsigned pub_base = (unsigned) (p & 1) * CH_XF_MAX;
         float best = -INFINITY; int bi = -1;
-        if (!loader) {
+        {
             if (paired) {
                 for (int rr = tid >> 4; rr < rows; rr += CH_NCW * 4) {
                     float sl = 0.f, sr = 0.f;
@@ -715,7 +673,7 @@ __global__ void __launch_bounds__(CH_THREADS) matvec_chain_kernel(chain_params P
         }
         CH_STAMP(8);
         if (ph.argmax) {
-            if (!loader) {
+            {
                 am_wave(best, bi);
                 if (lane == 0) { ctl->am_v[wave] = best; ctl->am_i[wave] = bi; }
             }
@@ -731,12 +689,13 @@ __global__ void __launch_bounds__(CH_THREADS) matvec_chain_kernel(chain_params P
     if (!alive) return;
 
     // the chain ends in an arg-max: workgroup 0 merges the candidates and writes the token
-    if (wg == 0 && wave == 0 && PH[P.n_phases - 1].argmax) {
+    chain_phase last;
+    { const unsigned * b = desc + ((P.n_phases - 1) % 3) * CH_DESC_DWORDS; CH_LD(last, b, argmax); CH_LD(last, b, argmax_out[0]); CH_LD(last, b, argmax_out[1]); }
+    if (wg == 0 && wave == 0 && last.argmax) {
         const int p = P.n_phases;
         int token = 0;
         if (gather_token(cb, (unsigned) ((p - 1) & 1) * (2u * (unsigned) grid * 8u), grid, tag_base | (unsigned) p, lane, ctl, token)) {
-            const auto & pp = PH[p - 1];
-            if (lane == 0) { if (pp.argmax_out[0]) *gp(pp.argmax_out[0]) = token; if (pp.argmax_out[1]) *gp(pp.argmax_out[1]) = token; }
+            if (lane == 0) { if (last.argmax_out[0]) *gp(last.argmax_out[0]) = token; if (last.argmax_out[1]) *gp(last.argmax_out[1]) = token; }
         } else { give_up(); return; }
     }
     if (wg == 0 && tid == 0) *gp(P.launch_seq) = launch + 1u;
@@ -744,8 +703,8 @@ __global__ void __launch_bounds__(CH_THREADS) matvec_chain_kernel(chain_params P
 
 // ---- host side -----------------------------------------------------------------------------------------------------------------
 static int chain_env(const char * name, int def) { const char * v = getenv(name); return v ? atoi(v) : def; }
-static int chain_grid() { static const int g = chain_env("MI355X_CHAIN_GRID", 64); return g < 8 ? 8 : g > 256 ? 256 : g; }
-static int chain_ring_slots() { static const int r = chain_env("MI355X_CHAIN_RING", 80); return r < 16 ? 16 : r > 80 ? 80 : r; }
+bool k_chain_default_on() { static const int on = chain_env("MI355X_CHAIN", 0); return on != 0; }
+static int chain_grid() { static const int g = chain_env("MI355X_CHAIN_GRID", 256); return g < 8 ? 8 : g > 256 ? 256 : g; }
 
 struct chain_plan {
     chain_params P;
@@ -763,7 +722,7 @@ static bool overlaps(const void * a, size_t an, const void * b, size_t bn) {
 // predecessor's arg-max) - that is what lets two hand-off buffers alternate by phase parity; anything a phase reads that an earlier phase of
 // the run writes must travel by one of the in-launch mechanisms (hand-off vector, kept rows, arg-max candidates) or the run is cut there.
 static int chain_analyse(const mv_args * mv, int n, std::vector<chain_phase> & out, std::vector<attn_args> & attns) {
-    const int G = chain_grid(), RS = chain_ring_slots();
+    const int G = chain_grid();
     out.clear(); attns.clear();
     std::vector<int> res_from;   // phase whose rows a phase adds as its residual (-1: none / memory)
     auto ybytes = [&](int j) { return (size_t) out[(size_t) j].M * 4; };
@@ -863,8 +822,7 @@ static int chain_analyse(const mv_args * mv, int n, std::vector<chain_phase> & o
                 for (int j = i - 1; j >= 0; j--) if (out[(size_t) j].save) { src = j; break; }
                 if (src != res_from[(size_t) i]) cut = i;
             }
-            const unsigned seg = ((unsigned) ph.rows_wg * (unsigned) ph.row_bytes + CH_SLOT - 1) / CH_SLOT;
-            if ((int) ((ph.pair_F ? 2u : 1u) * seg) > RS) cut = i;
+            if ((ph.pair_F ? 2 : 1) * ph.rows_wg * ph.nb > CH_PMAX * CH_NCW * 8) cut = i;   // a phase's super-blocks must fit the registers
         }
         while (cut > 0 && out[(size_t) cut - 1].pair_F) cut--;   // a paired phase needs its consumer
         if (cut == len) break;
@@ -884,14 +842,14 @@ static int chain_analyse(const mv_args * mv, int n, std::vector<chain_phase> & o
 }
 
 int k_chain_accept(const mv_args * mv, int n) {
-    static const int on = chain_env("MI355X_CHAIN", 1), min_len = chain_env("MI355X_CHAIN_MIN", 4);
-    if (!on || n < min_len) return 0;
+    static const int min_len = chain_env("MI355X_CHAIN_MIN", 4);
+    if (n < min_len) return 0;
     std::vector<chain_phase> ph; std::vector<attn_args> at;
     const int len = chain_analyse(mv, n, ph, at);
     return len >= min_len ? len : 0;
 }
 
-static size_t chain_tables_bytes(int n, int na) { return GGML_PAD((size_t) n * sizeof(chain_phase), 256) + GGML_PAD((size_t) (na ? na : 1) * sizeof(attn_args), 256); }
+static size_t chain_tables_bytes(int n, int) { return GGML_PAD((size_t) n * sizeof(chain_phase), 256); }
 static size_t chain_state_bytes(int grid) { return 256 + 2 * (size_t) CH_XF_MAX * 8 + 2 * 2 * (size_t) grid * 8; }
 size_t k_chain_ws_size(const mv_args * mv, int n) {
     std::vector<chain_phase> ph; std::vector<attn_args> at;
@@ -904,24 +862,27 @@ chain_plan * k_chain_create(hipStream_t s, const mv_args * mv, int n, void * ws,
     const int len = chain_analyse(mv, n, c->phases, c->attns);
     GGML_ASSERT(len == n && "k_chain_create: pass exactly the run k_chain_accept took");
     c->grid = chain_grid();
-    const int RS = chain_ring_slots();
     char * base = (char *) ws;
     chain_phase * d_ph = (chain_phase *) base;
-    attn_args * d_at = (attn_args *) (base + GGML_PAD((size_t) n * sizeof(chain_phase), 256));
     char * state = base + chain_tables_bytes(n, (int) c->attns.size());
+    {
+        int ai = 0;
+        for (int i = 0; i < n; i++) {
+            chain_phase & ph = c->phases[(size_t) i];
+            if (ph.attn >= 0) ph.at = c->attns[(size_t) ai++];
+            ph.n_in = i > 0 ? c->phases[(size_t) i - 1].n_pub : 0;
+            if (ph.emb_chain) { ph.prev_out[0] = c->phases[(size_t) i - 1].argmax_out[0]; ph.prev_out[1] = c->phases[(size_t) i - 1].argmax_out[1]; }
+        }
+    }
     HIP_CHECK(hipMemcpyAsync(d_ph, c->phases.data(), (size_t) n * sizeof(chain_phase), hipMemcpyHostToDevice, s));
-    if (!c->attns.empty()) HIP_CHECK(hipMemcpyAsync(d_at, c->attns.data(), c->attns.size() * sizeof(attn_args), hipMemcpyHostToDevice, s));
     HIP_CHECK(hipMemsetAsync(state, 0, chain_state_bytes(c->grid), s));
     HIP_CHECK(hipStreamSynchronize(s));   // the host vectors above may go away with the plan
-    c->P.phases = d_ph; c->P.n_phases = n; c->P.attns = d_at;
+    c->P.phases = d_ph; c->P.n_phases = n;
     c->P.launch_seq = (unsigned *) state;
     c->P.gbuf = (u64 *) (state + 256);
     c->P.cand = c->P.gbuf + 2 * CH_XF_MAX;
     c->P.err = err;
-    c->P.ring_slots = RS;
-    c->P.throttle = chain_env("MI355X_CHAIN_THROTTLE", 24);
-    c->P.quota_dots = chain_env("MI355X_CHAIN_QUOTA_DOTS", 16);
-    c->smem = (size_t) RS * CH_SLOT + 16 * XBLK_BYTES + (size_t) (CH_XF_MAX + CH_PART_MAX + CH_RES_MAX + 1024 + CH_NCW * CH_ATTW) * 4 + sizeof(chain_ctl);
+    c->smem = 16 * XBLK_BYTES + (size_t) (CH_XF_MAX + CH_PART_MAX + CH_RES_MAX + 1024 + CH_NCW * CH_ATTW) * 4 + sizeof(chain_ctl) + 3 * sizeof(chain_phase);
     GGML_ASSERT(c->smem <= 160 * 1024);
     static bool granted = false;
     if (!granted) { HIP_CHECK(hipFuncSetAttribute((const void *) matvec_chain_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); granted = true; }

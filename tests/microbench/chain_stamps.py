@@ -14,10 +14,10 @@ for _ in range(8):
     m.lm_step(rng.integers(0, cfg.card, cfg.n_q - cfg.io_dep_q).tolist())
 L.ggml_backend_synchronize(m.be)
 lib = L.ggml
-buf = (C.c_ulonglong * (3 * 512 * 12))()
+buf = (C.c_ulonglong * (2 * 512 * 12))()
 assert lib.mi355x_chain_log_read(buf) == 0
-rec = np.frombuffer(buf, np.uint64).reshape(3, 512, 12).astype(np.int64)
-names = ["start", "pre-loads", "gathered", "attn/sync", "xs ready", "ring ok", "dots", "dot sync", "published"]
+rec = np.frombuffer(buf, np.uint64).reshape(2, 512, 12).astype(np.int64)
+names = ["start", "pre-loads", "gathered", "attention", "blocks", "barrier", "dots+req", "dot sync", "published"]
 n = int((rec[0, :, 0] > 0).sum())
 t0 = rec[0, 0, 0]
 print(f"{n} phases; launch span (workgroup 0) {(rec[0, n - 1, 8] - t0) / 100.0:.1f} us")
@@ -35,12 +35,3 @@ for k in range(per):
     sel = np.arange(k, n - 1, per)
     print(f"  phase {k:2d} of a step: {dur[sel].mean():6.2f} us  stages " + " ".join(f"{stage[sel, i].mean():5.2f}" for i in range(8)))
 
-nb = (C.c_uint * (512 * 2))()
-lib.mi355x_chain_log_read_n(nb)
-cnt = np.frombuffer(nb, np.uint32).reshape(512, 2).astype(np.int64)
-print("loader wave of workgroup 0 (us): forced pump | landing wait | pump | pump beside dots ; slots issued beyond the chunk")
-lo = rec[2]
-for p in range(min(n, int(sys.argv[2]) if len(sys.argv) > 2 else 30)):
-    r = lo[p]
-    f = lambda a, b: (r[b] - r[a]) / 100.0 if r[a] and r[b] else 0.0
-    print(f"{p:5d} | {f(0, 1):6.2f} | {f(1, 2):6.2f} | {f(2, 3):6.2f} | {f(5, 6):6.2f} ; ahead {cnt[p, 0] - cnt[p, 1]:4d}  (wave-0 start {(rec[0, p, 0] - t0) / 100.0:8.2f}, loader turn ends {(r[3] - t0) / 100.0:8.2f})")
