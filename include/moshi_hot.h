@@ -159,6 +159,10 @@ GGML_API void    moshi_hot_get_timing(moshi_hot_model_t * m, double * us_per_cal
 // teacher forcing for parity runs: overwrite the tokens the last moshi_hot_lm_step wrote into the delay ring
 GGML_API void    moshi_hot_force_last(moshi_hot_model_t * m, int32_t text_token, const int32_t * audio_tokens);
 GGML_API void    moshi_hot_set_context_fill(moshi_hot_model_t * m, int64_t offset); // jump the Temporal ring to a given fill level (bench only)
+// write the same pseudo-random BF16 rows (approximately N(0, scale^2), a function of seed / which / layer / position only) into EVERY slot of the K and V
+// rings (transformer.h:156-172) of one layer (layer >= 0) or of all layers (-1) of the Temporal (which = 0) or Depth (1) transformer: two executors
+// filled alike hold identical caches, so attention over hundreds or thousands of live slots can be compared node by node (tests only)
+GGML_API void    moshi_hot_fill_ring(moshi_hot_model_t * m, int which, int layer, uint64_t seed, float scale);
 // Parity probe: ONE transformer layer (moshi_streaming_transformer_layer, transformer.h:910-1039) of the Temporal (which = 0) or Depth
 // (which = 1, with weight set `weight_set`) stack on the scratch context, fed x_in F32[dim] at stream position `offset` (mask row, RoPE
 // phase and ring slot as transformer.h:1182-1215 computes them), over the model's own weights and KV ring of that layer (the new K / V

@@ -1818,6 +1818,33 @@ extern "C" void moshi_hot_force_last(moshi_hot_model_t * m, int32_t text_token, 
 }
 extern "C" void moshi_hot_set_context_fill(moshi_hot_model_t * m, int64_t offset) { unstage_temporal(m); m->temporal.offset = (int) offset; }
 
+// identical pseudo-random BF16 rows in every slot of the K / V rings (tests: long-context attention against the oracle over a known cache)
+extern "C" void moshi_hot_fill_ring(moshi_hot_model_t * m, int which, int layer, uint64_t seed, float scale) {
+    Transformer & tr = which == 0 ? m->temporal : m->depth;
+    for (int l = 0; l < (int) tr.layers.size(); l++) {
+        if (layer >= 0 && l != layer) continue;
+        Layer & L = tr.layers[(size_t) l];
+        for (int kv = 0; kv < 2; kv++) {
+            T t = kv == 0 ? L.kcache : L.vcache;
+            if (!t) continue;
+            GGML_ASSERT(t->type == GGML_TYPE_BF16);
+            const size_t n = (size_t) ggml_nelements(t);
+            std::vector<uint16_t> bits(n);
+            uint64_t s = seed * 0x9E3779B97F4A7C15ull + (uint64_t) which * 1000003ull + (uint64_t) l * 7919ull + (uint64_t) kv;
+            for (size_t i = 0; i < n; i++) {
+                // splitmix64 -> sum of four uniforms (variance 1/3, close enough to a bell) -> BF16 by truncation of an exactly representable value
+                s += 0x9E3779B97F4A7C15ull;
+                uint64_t z = s; z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; z ^= z >> 31;
+                const float u = ((float) (z & 0xffff) + (float) ((z >> 16) & 0xffff) + (float) ((z >> 32) & 0xffff) + (float) (z >> 48)) / 65536.0f - 2.0f;
+                const float v = u * 1.7320508f * scale;
+                uint32_t w; memcpy(&w, &v, 4);
+                bits[i] = (uint16_t) (w >> 16);
+            }
+            ggml_backend_tensor_set(t, bits.data(), 0, n * 2);
+        }
+    }
+}
+
 extern "C" int moshi_hot_layer_probe(moshi_hot_model_t * m, int which, int layer, int weight_set, const float * x_in, int offset, float * x_out,
                                      moshi_hot_node_visitor_t visit, void * user) {
     Transformer & tr = which == 0 ? m->temporal : m->depth;

@@ -28,18 +28,26 @@ def lm_only(cfg):
     return cfg
 
 
-def _probe_every_layer(cfg, depth_steps=6, flip_budget=0.002):
-    ref = hu.Model("oracle", cfg, seed=0)
-    dev = hu.Model("hip", cfg, seed=0)
-    rng = np.random.default_rng(11)
-    tot = {"nodes": 0, "clean": 0, "tainted": 0, "flips": 0, "sites": 0, "hidden": 0, "fused_nodes": 0, "fused_clean": 0}
-    worst_clean = worst_tainted = 0.0
-    flipped_sites = []
+class LayerProber:
+    """One layer at a time, three ways - oracle, device with one kernel per node, device with the fused kernels bench.py times - fed the SAME input;
+    rounding flips are counted, clean nodes held to 2e-6, fused outputs may not move without a flip the per-node run shows."""
 
-    ring_flipped = {}   # (which, layer) -> the device's ring holds a row that rounded to another BF16 value than the oracle's
+    def __init__(self, cfg):
+        self.cfg = cfg
+        self.ref = hu.Model("oracle", cfg, seed=0)
+        self.dev = hu.Model("hip", cfg, seed=0)
+        self.tot = {"nodes": 0, "clean": 0, "tainted": 0, "flips": 0, "sites": 0, "hidden": 0, "fused_nodes": 0, "fused_clean": 0}
+        self.worst_clean = self.worst_tainted = 0.0
+        self.flipped_sites = []
+        self.ring_flipped = {}   # (which, layer) -> the device's ring holds a row that rounded to another BF16 value than the oracle's
 
-    def one(which, layer, ws, x, offset, where):
-        nonlocal worst_clean, worst_tainted
+    def fill_rings(self, which, layer, seed, scale=1.0):
+        for m in (self.ref, self.dev):
+            L.moshi_hot_fill_ring(m.m, which, layer, seed, scale)
+        self.ring_flipped.pop((which, layer), None)
+
+    def one(self, which, layer, ws, x, offset, where):
+        ref, dev, tot = self.ref, self.dev, self.tot
         a, ya = pp.probe(ref, which, layer, ws, x, offset)
         L.ggml_backend_mi355x_set_flags(dev.be, 0)                  # the fused kernels of the benchmark (interior nodes never materialise)
         c, yc = pp.probe(dev, which, layer, ws, x, offset)
@@ -48,36 +56,45 @@ def _probe_every_layer(cfg, depth_steps=6, flip_budget=0.002):
         # below a flip the bound is a few quantiser steps: one Q8_K step is 1/127 of a block's maximum, against dot products of K terms, so it
         # weighs ~4x more at the Depth width (K = 1024) than at the Temporal one (K = 4096 / 11264)
         ttol = pp.TAINT_TOL if which == 0 else 5 * pp.TAINT_TOL
-        st = pp.compare_layer(a, b, where + " per-node", taint_tol=ttol, cache_tainted=ring_flipped.get((which, layer), False))
-        sf = pp.compare_layer(a, c, where + " fused", taint_tol=ttol, taint_in=st["taint"], hidden_flips=True, cache_tainted=ring_flipped.get((which, layer), False))
+        tainted = self.ring_flipped.get((which, layer), False)
+        st = pp.compare_layer(a, b, where + " per-node", taint_tol=ttol, cache_tainted=tainted)
+        sf = pp.compare_layer(a, c, where + " fused", taint_tol=ttol, taint_in=st["taint"], hidden_flips=True, cache_tainted=tainted)
         if st["cache_flips"]:
-            ring_flipped[(which, layer)] = True
+            self.ring_flipped[(which, layer)] = True
         assert sf["nodes"] >= 4, f"{where}: only {sf['nodes']} fused outputs were visible"
         assert hu.rel_err(ya, yc) <= ttol
         for k in ("nodes", "clean", "tainted", "flips", "sites"):
             tot[k] += st[k]
         tot["hidden"] += sf["hidden"]; tot["fused_nodes"] += sf["nodes"]; tot["fused_clean"] += sf["clean"]
-        worst_clean = max(worst_clean, st["worst_clean"], sf["worst_clean"])
-        worst_tainted = max(worst_tainted, st["worst_tainted"], sf["worst_tainted"])
-        flipped_sites.extend((where,) + s for s in st["site_flips"] if s[3])
+        self.worst_clean = max(self.worst_clean, st["worst_clean"], sf["worst_clean"])
+        self.worst_tainted = max(self.worst_tainted, st["worst_tainted"], sf["worst_tainted"])
+        self.flipped_sites.extend((where,) + s for s in st["site_flips"] if s[3])
         return ya
 
+    def finish(self, what, flip_budget=0.002, min_clean=0.5, max_hidden=0.02):
+        tot = self.tot
+        self.ref.free(); self.dev.free()
+        print(f"{what}:", tot, f"worst clean {self.worst_clean:.2e} worst tainted {self.worst_tainted:.2e}; flipped sites: {self.flipped_sites[:12]}")
+        assert tot["clean"] >= min_clean * tot["nodes"], "too few nodes were compared without a flip upstream"
+        assert tot["flips"] <= flip_budget * self.cfg.dim * tot["sites"] / 8, f"{tot['flips']} rounding flips over {tot['sites']} sites"
+        assert tot["hidden"] <= max_hidden * tot["fused_nodes"], f"{tot['hidden']} of {tot['fused_nodes']} fused outputs moved without a flip seen in the per-node run"
+
+
+def _probe_every_layer(cfg, depth_steps=6, flip_budget=0.002):
+    pr = LayerProber(cfg)
+    rng = np.random.default_rng(11)
     # Temporal: the oracle's own activations chained through all 32 layers, at ring position 0 (one live slot) and 1 (two: a real soft-max)
     for offset in (0, 1):
         x = (rng.standard_normal(cfg.dim) * 4).astype(np.float32)   # ~ the sum of 17 unit-variance embedding rows
         for layer in range(cfg.num_layers):
-            x = one(0, layer, 0, x, offset, f"temporal layer {layer} offset {offset}")
+            x = pr.one(0, layer, 0, x, offset, f"temporal layer {layer} offset {offset}")
     # Depth: the chain's first six steps as the cached graph runs them - step k uses weight set k and ring slot k, and attends to the rows
     # steps 0..k-1 of this same run left in the ring of 8 (lm.h:505-527)
     for step in range(depth_steps):
         x = (rng.standard_normal(cfg.dep_dim) * 2).astype(np.float32)
         for layer in range(cfg.dep_layers):
-            x = one(1, layer, step, x, step, f"depth layer {layer} step {step}")
-    ref.free(); dev.free()
-    print("full-width node parity:", tot, f"worst clean {worst_clean:.2e} worst tainted {worst_tainted:.2e}; flipped sites: {flipped_sites[:12]}")
-    assert tot["clean"] >= 0.25 * tot["nodes"], "too few nodes were compared without a flip upstream"
-    assert tot["flips"] <= flip_budget * cfg.dim * tot["sites"] / 8, f"{tot['flips']} rounding flips over {tot['sites']} sites"
-    assert tot["hidden"] <= 0.25 * tot["fused_nodes"], f"{tot['hidden']} of {tot['fused_nodes']} fused outputs moved without a flip seen in the per-node run"
+            x = pr.one(1, layer, step, x, step, f"depth layer {layer} step {step}")
+    pr.finish("full-width node parity", flip_budget=flip_budget)
 
 
 def test_every_full_width_layer_node_by_node_teacher_forced():
@@ -92,6 +109,61 @@ def test_2048_wide_q8_0_and_q4_0_layers_node_by_node(lt):
     cfg.dim, cfg.num_heads, cfg.num_layers, cfg.ffn_hidden, cfg.context = 2048, 16, 6, 5632, 500
     cfg.linear_type = {"q8_0": 8, "q4_0": 2}[lt]
     _probe_every_layer(cfg, depth_steps=3)
+
+
+@pytest.mark.parametrize("model", ["moshika", "personaplex_ctx2000"])
+def test_full_width_attention_over_a_prefilled_ring_node_by_node(model):
+    # The long-context regime of the benchmark's extras and of BASELINE.json configs[4] (`-c 2000`): beyond 160 live slots a head is split over
+    # workgroups of 128 / 256 ring slots that exchange scores and partial outputs with agent-scope accesses (attn_decode_kernel<SPLIT>). Both
+    # executors' K / V rings are filled with the SAME pseudo-random BF16 rows (moshi_hot_fill_ring), then single layers are probed at stream positions
+    # that leave 162 ... 3000 slots live, up to and across the ring's wrap (torch.h:162-237, transformer.h:238-249, 558-567) - oracle vs per-node
+    # kernels vs the fused kernels. The ring is refilled before every probe, so no earlier rounding flip taints a later position.
+    cfg = lm_only(hu.hot.moshika(L) if model == "moshika" else hu.hot.personaplex(L))
+    if model != "moshika":
+        cfg.context = 2000
+    C_ = cfg.context
+    offsets = [161, 300, 1100, C_ - 1000, C_ - 100, C_ - 1, C_, C_ + 1, 2 * C_ + 37]
+    pr = LayerProber(cfg)
+    rng = np.random.default_rng(13)
+    for layer in (0, cfg.num_layers // 2 - 3, cfg.num_layers - 1):
+        for offset in offsets:
+            pr.fill_rings(0, layer, seed=100 + layer)
+            x = (rng.standard_normal(cfg.dim) * 4).astype(np.float32)
+            pr.one(0, layer, 0, x, offset, f"temporal layer {layer} offset {offset}")
+    pr.finish(f"{model}: attention over a prefilled ring")
+
+
+def test_contractive_personaplex_at_context_2000_from_a_ring_holding_1900_rows():
+    # BASELINE.json configs[4] at its own context (`-c 2000`): the stream starts at position 1900 over rings prefilled alike on both executors, 16
+    # free-running frames (16 chained Depth steps each): every Temporal layer runs the split attention over 1 900+ live slots inside the real graphs
+    cfg = lm_only(hu.hot.personaplex(L))
+    cfg.context = 2000
+    cfg.update_scale = 1.0 / 256
+
+    def setup(m):
+        L.moshi_hot_fill_ring(m.m, 0, -1, 7, 1.0)
+        L.moshi_hot_set_context_fill(m.m, 1900)
+    _contractive_free_run(cfg, 16, setup=setup)
+
+
+def test_mimi_decoder_8_levels_133_frames_pcm():
+    # the decoder half of the codec at the benchmark's own size over 133 frames: the decoder transformer (ring of 250, T = 2 rows per frame) passes
+    # its capacity at frame 125 and runs the mask's wrapped branch (the T = 2 quirk) for the last 8; PCM within the codec bar throughout, no jump
+    cfg = hu.hot.moshika(L)
+    cfg.enable_lm = 0
+    cfg.enable_mimi_encoder = 0
+    rng = np.random.default_rng(41)
+    codes = [rng.integers(0, cfg.mimi_codebook_size, cfg.mimi_n_q).tolist() for _ in range(133)]
+    ref, dev = hu.Model("oracle", cfg, seed=0), hu.Model("hip", cfg, seed=0)
+    errs = []
+    for i, c in enumerate(codes):
+        a, b = ref.mimi_decode(c), dev.mimi_decode(c)
+        errs.append(hu.rel_err(a, b))
+    ref.free(); dev.free()
+    errs = np.array(errs)
+    print(f"mimi decoder 133 frames: pcm rel err median {np.median(errs):.2e} max {errs.max():.2e}, after the ring wrapped {errs[125:].max():.2e}")
+    assert errs.max() < 3e-3, f"pcm differs by {errs.max():.2e} (frame {int(errs.argmax())})"
+    assert errs[125:].max() <= max(3 * errs[:125].max(), 1e-4), "the PCM error jumps once the decoder ring has wrapped (T = 2 mask quirk)"
 
 
 def test_contractive_full_config_free_running_greedy_is_bit_exact():

@@ -392,38 +392,6 @@ def compare_frame(cfg, ref, got, text_tol, dep_tol, where):
     return compared, equal
 
 
-def test_full_moshika_q4k_config_lm_steps_teacher_forced():
-    # the benchmark configuration itself (tools/moshi-config.json shapes: dim 4096, 32 heads, 32 + 6 layers, context 3000, Q4_K linears,
-    # Q4_0 embeddings): every Temporal / Depth kernel shape bench.py times, against the CPU oracle.
-    # At this width the reference arithmetic amplifies float-summation noise: a 2e-6 difference in a K = 4096 projection rounds a handful
-    # of the 4096 BF16 cache values / Q8_K activations the other way per layer (tests/microbench/node_diff.py shows each flipped value
-    # sitting on a rounding tie), and the ORACLE ITSELF moves by 1.6e-3 after one layer and 2.7e-2 in the text logits after 32 when a
-    # single norm vector is nudged by one float ulp (tests/test_oracle_noise_floor.py, tests/microbench/oracle_sensitivity.py). The
-    # device lands on the same figures (2.6e-2 text, 4..8e-2 Depth), so the bars here are that noise floor with headroom, and a token
-    # may differ from the oracle's only where the oracle's own logits make it a tie within the observed disagreement.
-    cfg = hu.hot.moshika(hu.L)
-    cfg.enable_mimi_encoder = cfg.enable_mimi_decoder = 0
-    steps = 3
-    rng = np.random.default_rng(5)
-    inputs = [rng.integers(0, cfg.card, cfg.n_q - cfg.dep_q).tolist() for _ in range(steps)]
-    rec = {}
-    for kind in ("oracle", "hip"):
-        m = hu.Model(kind, cfg, seed=0)
-        r = []
-        for i, ia in enumerate(inputs):
-            m.lm_step(ia)
-            r.append(snapshot(m, cfg))
-            if kind == "hip":
-                m.force_last(*rec["oracle"][i][0])     # teacher forcing between frames
-        rec[kind] = r
-        m.free()
-    compared = equal = 0
-    for i in range(steps):
-        c, e = compare_frame(cfg, rec["oracle"][i], rec["hip"][i], 0.1, 0.3, f"step {i}")
-        compared += c; equal += e
-    assert equal >= 0.8 * compared, f"only {equal} of {compared} compared greedy tokens equal the oracle's"
-
-
 def test_full_moshika_config_mimi_codec_matches_oracle():
     # the codec at the benchmark configuration (mimi_n_q 8 of 32 codebooks, 2048-entry tables): codes bit-exact, samples within PCM_TOL
     cfg = hu.hot.moshika(hu.L)
