@@ -40,5 +40,7 @@ def test_bench_prints_one_json_line_with_the_contract_fields(extra):
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and r["kernel"] == "matvec_q4k_kernel"
     assert r["launches_per_frame"] == 337 and 0.05 < r["frac"] < 1.0
+    assert 0 <= d["n_fill_avg"] <= 3000 and d["ranks_reporting"] == 1 and d["rccl_world_size"] is None
     if not extra:
         assert d["serial_loop"]["value"] < d["value"]          # the two-stream run-ahead loop beats the serial one on the same model
+        assert d["value_serial"] == d["serial_loop"]["value"]  # what an unchanged reference tool gets, at the top level
