@@ -162,6 +162,10 @@ GGML_API void    moshi_hot_set_context_fill(moshi_hot_model_t * m, int64_t offse
 // write the same pseudo-random BF16 rows (approximately N(0, scale^2), a function of seed / which / layer / position only) into EVERY slot of the K and V
 // rings (transformer.h:156-172) of one layer (layer >= 0) or of all layers (-1) of the Temporal (which = 0) or Depth (1) transformer: two executors
 // filled alike hold identical caches, so attention over hundreds or thousands of live slots can be compared node by node (tests only)
+// the reference's checkpoint path end to end (src/loader.h:85-99, 227-271): write every weight tensor of a model to a GGUF file / build a model whose
+// weights are read back from such a file (names, types and sizes checked against the configuration) instead of being generated
+GGML_API int     moshi_hot_save_gguf(moshi_hot_model_t * m, const char * path);
+GGML_API moshi_hot_model_t * moshi_hot_create_from_gguf(ggml_backend_t backend, const struct moshi_hot_config * cfg, const char * path);
 GGML_API void    moshi_hot_fill_ring(moshi_hot_model_t * m, int which, int layer, uint64_t seed, float scale);
 // Parity probe: ONE transformer layer (moshi_streaming_transformer_layer, transformer.h:910-1039) of the Temporal (which = 0) or Depth
 // (which = 1, with weight set `weight_set`) stack on the scratch context, fed x_in F32[dim] at stream position `offset` (mask row, RoPE
@@ -193,6 +197,8 @@ GGML_API void *  moshi_hot_tp_msg(moshi_hot_model_t * m, int64_t * n_floats);   
 GGML_API void    moshi_hot_tp_begin(moshi_hot_model_t * m, const float * x);            // stack input F32[dim]; advances the stream position (mask row, RoPE phase, ring slot)
 GGML_API void    moshi_hot_tp_segment(moshi_hot_model_t * m, int i);
 GGML_API void    moshi_hot_tp_end(moshi_hot_model_t * m, float * out);                  // stack output F32[dim]
+GGML_API void    moshi_hot_tp_msg_read(moshi_hot_model_t * m, float * out);        // the partial-sum message, host copy out / in: lets ONE process sum the
+GGML_API void    moshi_hot_tp_msg_write(moshi_hot_model_t * m, const float * in);   // partials of several ranks' models (tests without a second GPU)
 // replaces the local chained Depth graph inside moshi_hot_lm_step_n: fn(user, text_token, audio[dep_q]) must fill all dep_q tokens
 typedef void (*moshi_hot_depth_hook_t)(void * user, int32_t text_token, int32_t * audio);
 GGML_API void    moshi_hot_set_depth_hook(moshi_hot_model_t * m, moshi_hot_depth_hook_t fn, void * user);

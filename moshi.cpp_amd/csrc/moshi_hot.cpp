@@ -7,6 +7,7 @@
 // matchers key on and what the oracle executes node by node); the C++ around them is this project's own.
 // Weights are synthetic and deterministic (no model files can reach the build or the GPU box).
 #include "moshi_hot.h"
+#include "gguf.h"
 #include "ggml-cpu.h"
 
 #include <math.h>
@@ -139,6 +140,18 @@ struct Weights {
     size_t bytes[5] = { 0, 0, 0, 0, 0 };
     int part = 0;
 
+    // the name a tensor carries inside the context and inside a GGUF file: the checkpoint name when it fits ggml's name field, else an 8-digit hex
+    // digest of it (WeightLoader::tensor_name, loader.h:120-137: names longer than GGML_MAX_NAME are replaced by a CRC) - unique either way
+    static std::string file_name(const std::string & name) {
+        if (name.size() < GGML_MAX_NAME) return name;
+        uint32_t h = 2166136261u;
+        for (unsigned char ch : name) { h ^= ch; h *= 16777619u; }
+        char buf[16];
+        snprintf(buf, sizeof(buf), "%08x", h);
+        return buf;
+    }
+    std::string gguf_path;     // non-empty: load() reads every tensor's bytes from this file (WeightLoader::load_gguf, loader.h:235-271) instead of generating them
+
     Weights(ggml_backend_t be_, uint64_t seed_, int max_tensors) : be(be_), seed(seed_) {
         ctx = ggml_init({ ggml_tensor_overhead() * (size_t) max_tensors, NULL, true });
     }
@@ -146,7 +159,7 @@ struct Weights {
 
     T add(const std::string & name, enum ggml_type type, int64_t n0, int64_t n1, int64_t n2, std::function<void(T, Rng &, std::vector<uint8_t> &)> gen) {
         T t = ggml_new_tensor_3d(ctx, type, n0, n1, n2);
-        ggml_set_name(t, name.size() < GGML_MAX_NAME ? name.c_str() : name.substr(name.size() - GGML_MAX_NAME + 1).c_str());
+        ggml_set_name(t, file_name(name).c_str());
         todo.push_back({ t, gen, name });
         by_name[name] = t;   // full checkpoint name (ggml names are cut to GGML_MAX_NAME, which makes encoder/decoder tails collide)
         bytes[part] += ggml_nbytes(t);
@@ -167,6 +180,7 @@ struct Weights {
         bytes[part] += ggml_nbytes(t);
         return t;
     }
+    void load_gguf();
     void load() {
         buf = ggml_backend_alloc_ctx_tensors(ctx, be);
         GGML_ASSERT(buf);
@@ -184,6 +198,7 @@ struct Weights {
             ggml_free(fc);
         }
         sliced.clear();
+        if (!gguf_path.empty()) { load_gguf(); todo.clear(); return; }
         for (auto & p : todo) {
             Rng r(name_seed(seed, p.name));
             tmp.resize(ggml_nbytes(p.t));
@@ -193,6 +208,36 @@ struct Weights {
         todo.clear();
     }
 };
+
+// WeightLoader::load_gguf (loader.h:235-271): every tensor of the file is looked up by name in the model's weight context, its bytes are read at
+// data_offset + tensor_offset and uploaded with ggml_backend_tensor_set. Type and size must be the ones the model asked for.
+void Weights::load_gguf() {
+    struct ggml_context * meta = nullptr;
+    gguf_init_params params = { true, &meta };
+    struct gguf_context * gg = gguf_init_from_file(gguf_path.c_str(), params);
+    GGML_ASSERT(gg && "moshi_hot: cannot read the GGUF file");
+    FILE * f = fopen(gguf_path.c_str(), "rb");
+    GGML_ASSERT(f);
+    const size_t data_offset = gguf_get_data_offset(gg);
+    const int n_tensors = (int) gguf_get_n_tensors(gg);
+    std::vector<uint8_t> data;
+    int found = 0;
+    for (int i = 0; i < n_tensors; i++) {
+        const char * name = gguf_get_tensor_name(gg, i);
+        T t = ggml_get_tensor(ctx, name);
+        if (!t) continue;                               // (a file may hold more than this configuration uses)
+        const size_t nbytes = gguf_get_tensor_size(gg, i);
+        GGML_ASSERT(gguf_get_tensor_type(gg, i) == t->type && nbytes == ggml_nbytes(t) && "GGUF tensor does not match the configuration");
+        data.resize(nbytes);
+        GGML_ASSERT(fseek(f, (long) (data_offset + gguf_get_tensor_offset(gg, i)), SEEK_SET) == 0 && fread(data.data(), nbytes, 1, f) == 1);
+        ggml_backend_tensor_set(t, data.data(), 0, nbytes);
+        found++;
+    }
+    fclose(f);
+    GGML_ASSERT(found == (int) todo.size() && "the GGUF file lacks tensors this configuration needs");
+    gguf_free(gg);
+    if (meta) ggml_free(meta);
+}
 
 // generators ------------------------------------------------------------------------------------------------
 void gen_const(T t, float v, std::vector<uint8_t> & out) { float * f = (float *) out.data(); for (int64_t i = 0; i < ggml_nelements(t); i++) f[i] = v; }
@@ -974,12 +1019,25 @@ extern "C" void moshi_hot_config_personaplex(struct moshi_hot_config * c) {
     c->personaplex = 1;
 }
 
-extern "C" moshi_hot_model_t * moshi_hot_create(ggml_backend_t backend, const struct moshi_hot_config * cfg, uint64_t seed) {
+static moshi_hot_model_t * create_model(ggml_backend_t backend, const struct moshi_hot_config * cfg, uint64_t seed, const char * gguf_path);
+extern "C" moshi_hot_model_t * moshi_hot_create(ggml_backend_t backend, const struct moshi_hot_config * cfg, uint64_t seed) { return create_model(backend, cfg, seed, nullptr); }
+// the model's weights come from a GGUF file written by moshi_hot_save_gguf (the reference's `*.gguf` checkpoints: WeightLoader::from_gguf + load_gguf)
+extern "C" moshi_hot_model_t * moshi_hot_create_from_gguf(ggml_backend_t backend, const struct moshi_hot_config * cfg, const char * path) { return create_model(backend, cfg, 0, path); }
+// WeightLoader::save_gguf (loader.h:227-233): every tensor of the weight context, in context order
+extern "C" int moshi_hot_save_gguf(moshi_hot_model_t * m, const char * path) {
+    struct gguf_context * gg = gguf_init_empty();
+    for (T t = ggml_get_first_tensor(m->W->ctx); t; t = ggml_get_next_tensor(m->W->ctx, t)) gguf_add_tensor(gg, t);
+    const bool ok = gguf_write_to_file(gg, path, false);
+    gguf_free(gg);
+    return ok ? 1 : 0;
+}
+static moshi_hot_model_t * create_model(ggml_backend_t backend, const struct moshi_hot_config * cfg, uint64_t seed, const char * gguf_path) {
     moshi_hot_model * m = new moshi_hot_model;
     m->cfg = *cfg;
     m->be = backend;
     const moshi_hot_config & c = m->cfg;
     m->W = new Weights(backend, seed, 4096);
+    if (gguf_path) m->W->gguf_path = gguf_path;
     m->st_ctx = ggml_init({ ggml_tensor_overhead() * 1024, NULL, true });
     m->scratch = new Builder(backend, 16);
     m->be_codec = backend;
@@ -1277,6 +1335,9 @@ extern "C" void moshi_hot_tp_segment(moshi_hot_model_t * m, int i) {
     if ((int) m->g_tp.size() <= i || !m->g_tp[(size_t) i]) build_tp_segment(m, i);
     m->g_tp[(size_t) i]->compute();
 }
+// the partial-sum message through the backend's own transfer calls (a host-side stand-in for the all-reduce: tests that drive several ranks' models in one process)
+extern "C" void moshi_hot_tp_msg_read(moshi_hot_model_t * m, float * out) { GGML_ASSERT(m->tp_msg); ggml_backend_tensor_get(m->tp_msg, out, 0, ggml_nbytes(m->tp_msg)); }
+extern "C" void moshi_hot_tp_msg_write(moshi_hot_model_t * m, const float * in) { GGML_ASSERT(m->tp_msg); ggml_backend_tensor_set(m->tp_msg, in, 0, ggml_nbytes(m->tp_msg)); }
 extern "C" void moshi_hot_tp_end(moshi_hot_model_t * m, float * out) { ggml_backend_tensor_get(m->tp_x, out, 0, (size_t) m->cfg.dim * 4); }
 
 // ---- Depth codebook shard ---------------------------------------------------------------------------------------

@@ -41,6 +41,8 @@ SIGNATURES = {
     "moshi_hot_personaplex_system_prompts_batched": (None, [P, P, C.c_int, C.c_int]),
     "moshi_hot_create": (P, [P, C.POINTER(Config), C.c_uint64]),
     "moshi_hot_free": (None, [P]),
+    "moshi_hot_save_gguf": (C.c_int, [P, C.c_char_p]),
+    "moshi_hot_create_from_gguf": (P, [P, C.POINTER(Config), C.c_char_p]),
     "moshi_hot_mimi_encode": (None, [P, P, P]),
     "moshi_hot_mimi_decode": (None, [P, P, P]),
     "moshi_hot_lm_step": (C.c_int, [P, P, P, P]),
@@ -73,6 +75,8 @@ SIGNATURES = {
     "moshi_hot_tp_begin": (None, [P, P]),
     "moshi_hot_tp_segment": (None, [P, C.c_int]),
     "moshi_hot_tp_end": (None, [P, P]),
+    "moshi_hot_tp_msg_read": (None, [P, P]),
+    "moshi_hot_tp_msg_write": (None, [P, P]),
 }
 DEPTH_HOOK = C.CFUNCTYPE(None, C.c_void_p, C.c_int32, C.POINTER(C.c_int32))
 NODE_VISITOR = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_void_p)

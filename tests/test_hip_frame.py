@@ -676,3 +676,58 @@ def test_tensor_parallel_segments_on_the_device_match_the_oracle():
         m.free()
     for i, (a, b) in enumerate(zip(outs["oracle"], outs["hip"])):
         assert hu.rel_err(a, b) < 1e-5, f"position {i}: {hu.rel_err(a, b):.2e}"
+
+
+@pytest.mark.parametrize("dim,heads,ffn", [(2048, 16, 5632), (4096, 32, 11264)])
+def test_two_tensor_parallel_ranks_run_their_q4k_slices_on_the_device(dim, heads, ffn):
+    # SURVEY.md 8f.2 with tp_world = 2 ON THE DEVICE: rank 0 and rank 1 each hold half of every Temporal matrix (their heads' in_proj rows, the matching
+    # 256-aligned column block of out_proj, half of both linear_in halves and the matching column block of linear_out, their heads' KV ring), cut from
+    # the unsplit synthetic Q4_K matrices. With one GPU in the box the two ranks' models run one after the other on it and the all-reduce is a host-side
+    # sum of their partial vectors; what is checked is what the ranks compute: the 2 L + 1 segment graphs over SLICED weights through the fused HIP
+    # kernels, against the unsplit stack on the oracle, at the tts / stt width and at moshika's (bars of tests/test_temporal_tp_cpu.py).
+    from moshi_cpp_amd import shard
+    base = hu.hot.tiny(hu.L, linear_type=Q4_K, embed_type=Q4_0)
+    base.dim, base.num_heads, base.ffn_hidden, base.num_layers, base.context = dim, heads, ffn, 2, 48
+    base.enable_mimi_encoder = base.enable_mimi_decoder = 0
+
+    def cfg_for(world, rank):
+        c = hu.hot.Config.from_buffer_copy(base)
+        c.tp_world, c.tp_rank = world, rank
+        return c
+    ref_m = hu.Model("oracle", cfg_for(1, 0), seed=0)
+    ref = shard.TemporalTP(hu.L, ref_m.m, ref_m.cfg, 0, 1, None)
+    ranks = [hu.Model("hip", cfg_for(2, r), seed=0) for r in range(2)]
+    full = hu.L.moshi_hot_weight_bytes(ref_m.m, 0)
+    assert all(hu.L.moshi_hot_weight_bytes(m.m, 0) < 0.62 * full for m in ranks), "a rank holds half of every Temporal matrix"
+    rng = np.random.default_rng(8)
+    last = 2 * base.num_layers
+    part = [np.zeros(dim, np.float32) for _ in ranks]
+    errs = []
+    for pos in range(6):
+        x = (rng.standard_normal(dim) * 3).astype(np.float32)
+        want = ref.stack(x)
+        for m in ranks:
+            hu.L.moshi_hot_tp_begin(m.m, x.ctypes.data)
+        for i in range(last + 1):
+            for m in ranks:
+                hu.L.moshi_hot_tp_segment(m.m, i)
+            if i < last:                                  # all_reduce(sum) of the two partial vectors
+                for m, p in zip(ranks, part):
+                    hu.L.moshi_hot_tp_msg_read(m.m, p.ctypes.data)
+                tot = (part[0] + part[1]).astype(np.float32)
+                for m in ranks:
+                    hu.L.moshi_hot_tp_msg_write(m.m, tot.ctypes.data)
+        outs = []
+        for m in ranks:
+            o = np.zeros(dim, np.float32)
+            hu.L.moshi_hot_tp_end(m.m, o.ctypes.data)
+            outs.append(o)
+        assert np.array_equal(outs[0], outs[1]), "both ranks end a stack pass with the same vector"
+        errs.append(hu.rel_err(want, outs[0]))
+    st = ranks[0].stats()
+    assert st.graph_replays > 0, "the segment graphs are cached graphs: from the second stream position on they replay as hipGraphs"
+    for m in ranks + [ref_m]:
+        m.free()
+    # positions without a rounding flip agree to summation noise (measured 2-3e-7); a position where one Q8_K / BF16 value rounds the other way - the summed
+    # partials differ from the unsplit sums by ~1e-7, as between any two correct implementations - moves by a quantiser step (measured 2.7e-3 / 1.1e-2 at 4096)
+    assert np.median(errs) < 1e-5 and max(errs) < 3e-2 and sum(e < 1e-6 for e in errs) >= 3, errs
