@@ -132,7 +132,7 @@ struct ggml_mi355x_kernel_profile {
 GGML_API void ggml_backend_mi355x_get_kernel_profile(ggml_backend_t backend, struct ggml_mi355x_kernel_profile * out);
 // bit flags, default 0: 1 = disable fusion (one kernel per node), 2 = disable hipGraph capture, 4 = disable upload batching,
 // 8 = profile mode (eager launches, per-dispatch HIP events on matvec_q4k_kernel), 16 = no persistent chain launches (one launch per mat-vec),
-// 32 = persistent chain launches on (default: the MI355X_CHAIN environment variable, off)
+// 32 = persistent chain launches on even when the MI355X_CHAIN environment variable says 0 (default: on)
 GGML_API void ggml_backend_mi355x_set_flags(ggml_backend_t backend, int flags);
 // hipGraph capture of repeated graphs on / off without touching cached plans (off: a repeated graph still reuses its plan, launched eagerly -
 // for sequences of same-shaped one-off graphs such as prompt-prefill chunks, where a capture costs more than it saves). No-op on other backends.

@@ -30,7 +30,8 @@
 
 #define CH_NCW       8                    // consumer waves per workgroup
 #define CH_THREADS   (CH_NCW * 64)
-#define CH_PMAX      6                    // passes of 64 super-blocks a workgroup can hold in registers per phase: rows * nb <= CH_PMAX * 64
+// passes of 64 super-blocks a workgroup holds in registers per phase (rows * nb <= passes * 64): fewer rows per workgroup on a larger grid
+#define CH_PMAX_OF(G) ((G) >= 256 ? 2 : (G) >= 128 ? 3 : 6)
 #define CH_XF_MAX    4096                 // floats: longest vector handed from one phase to the next
 #define CH_PART_MAX  2048                 // super-block partial sums per workgroup and phase
 #define CH_RES_MAX   256                  // rows per workgroup and phase
@@ -69,9 +70,10 @@ struct chain_phase {
     float * y;                 // the ggml node's own storage (always written, plain stores: nothing inside the launch reads it)
     int n_pub;                 // values handed to the next phase: 0, M, or pair_F
     int n_in;                  // values the previous phase handed on
+    int kind;                  // 0: shape read from this descriptor; 1..6: one of the compile-time shapes (shape_din .. shape_head)
     int32_t * prev_out[2];     // emb_chain: where the previous phase's merged arg-max (the token) is stored
     attn_args at;              // MV_ATTN: the attention whose output is x
-    char pad_[16];
+    char pad_[8];
 };
 static_assert(sizeof(chain_phase) % 16 == 0 && sizeof(chain_phase) <= 26 * 16, "a descriptor is staged through LDS by 16-byte lanes");
 #define CH_DESC_DWORDS ((int) (sizeof(chain_phase) / 4))
@@ -350,6 +352,22 @@ __device__ __forceinline__ bool wg_barrier(chain_ctl * ctl) {
     return lds_load(&ctl->failed) == 0u;
 }
 
+// Shape of a phase, either read from its descriptor (dyn_shape) or a compile-time constant (the six phase kinds of the Depth transformer of
+// moshika / PersonaPlex, lm.h:446-553 + tools/moshi-config.json: depformer_in 4096 -> 1024, in_proj 1024 -> 3072, out_proj 1024 -> 1024 behind the
+// attention, linear_in 1024 -> 2 x 2816 in the paired form, linear_out 2816 -> 1024, linears[k] 1024 -> 2048). With the shape known to the compiler
+// the phase body loses its generic loops, its shape-dependent branches and most of its descriptor reads: what stays in the descriptor is pointers.
+struct dyn_shape { static constexpr bool S = false; static constexpr int K = 0, M = 0, PAIR = 0, PRO = 0, XCH = 0, RES = 0, EMB = 0, SAVE = 0, AM = 0, PUB = 0; };
+template <int K_, int M_, int PAIR_, int PRO_, int XCH_, int RES_, int EMB_, int SAVE_, int AM_, int PUB_>
+struct fix_shape { static constexpr bool S = true; static constexpr int K = K_, M = M_, PAIR = PAIR_, PRO = PRO_, XCH = XCH_, RES = RES_, EMB = EMB_, SAVE = SAVE_, AM = AM_, PUB = PUB_; };
+//                   K     M     pair  prologue     x_chain res emb save argmax n_pub
+typedef fix_shape<4096, 1024,    0, MV_PLAIN,   0, 0, 1, 1, 0, 1024> shape_din;
+typedef fix_shape<1024, 3072,    0, MV_RMSNORM, 1, 0, 0, 0, 0, 3072> shape_inproj;
+typedef fix_shape<1024, 1024,    0, MV_ATTN,    1, 1, 0, 1, 0, 1024> shape_outproj;
+typedef fix_shape<1024, 5632, 2816, MV_RMSNORM, 1, 0, 0, 0, 0, 2816> shape_linin;
+typedef fix_shape<2816, 1024,    0, MV_PLAIN,   1, 1, 0, 1, 0, 1024> shape_linout;
+typedef fix_shape<1024, 2048,    0, MV_RMSNORM, 1, 0, 0, 0, 1,    0> shape_head;
+
+template <int G>
 __global__ void __launch_bounds__(CH_THREADS) matvec_chain_kernel(chain_params P) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -402,6 +420,7 @@ __global__ void __launch_bounds__(CH_THREADS) matvec_chain_kernel(chain_params P
     };
     // The weights of ONE phase live in registers: pass ps covers super-blocks 64 ps .. 64 ps + 63 of the workgroup's rows, 8 lanes per super-block -
     // every lane of a group holds the 16-byte header (d, dmin, 6-bit scales: one fetch for the group) and its own 16-byte nibble chunk.
+    constexpr int CH_PMAX = CH_PMAX_OF(G);
     u32x4 wh[CH_PMAX], wq[CH_PMAX];
     auto request_weights = [&](const chain_phase & pq) {   // that phase's super-blocks of this workgroup
         const bool pr = pq.pair_F > 0;
@@ -433,28 +452,50 @@ __global__ void __launch_bounds__(CH_THREADS) matvec_chain_kernel(chain_params P
     bool alive = true;
     auto give_up = [&]() { if (lane == 0) { lds_store(&ctl->failed, 1u); *gp(P.err) = 2u; } };
 
-    for (int p = 0; p < P.n_phases; p++) {
+    // one phase; SH = its shape (dyn_shape: everything from the descriptor). Returns false when the workgroup has to leave.
+    auto phase = [&](auto shape_tag, int p) -> bool {
+        using SH = decltype(shape_tag);
+        CH_STAMP(10);
         chain_phase ph;
-        read_desc(p, ph);
+        const unsigned * dbase = desc + (p % 3) * CH_DESC_DWORDS;
+        if (!SH::S) read_desc(p, ph);
+        else {
+            // pointers only (and what the shape does not fix)
+            if (!SH::XCH) CH_LD(ph, dbase, x);
+            if (SH::PRO == MV_RMSNORM) { CH_LD(ph, dbase, alpha); CH_LD(ph, dbase, eps); }
+            if (SH::EMB) CH_LD(ph, dbase, emb_chain);
+            if (SH::PRO == MV_ATTN) {
+                CH_LD(ph, dbase, q_off); CH_LD(ph, dbase, k_off); CH_LD(ph, dbase, v_off);
+                CH_LD(ph, dbase, at.q_hs); CH_LD(ph, dbase, at.k_hs); CH_LD(ph, dbase, at.v_hs); CH_LD(ph, dbase, at.rot); CH_LD(ph, dbase, at.mask); CH_LD(ph, dbase, at.index);
+                CH_LD(ph, dbase, at.kcache); CH_LD(ph, dbase, at.vcache); CH_LD(ph, dbase, at.k_nb1); CH_LD(ph, dbase, at.k_nb2); CH_LD(ph, dbase, at.v_nb1); CH_LD(ph, dbase, at.v_nb2);
+                CH_LD(ph, dbase, at.H); CH_LD(ph, dbase, at.C); CH_LD(ph, dbase, at.scale);
+            }
+        }
         // wave 7 asks for the next descriptor now; it is parked in LDS before this phase's "blocks ready" barrier
         u32x4 next_desc = (u32x4) { 0u, 0u, 0u, 0u };
         const bool stage_next = wave == 7 && p + 1 < P.n_phases;
         if (stage_next && lane < DL) next_desc = desc_src[(p + 1) * DL + lane];
         const unsigned tag_in = tag_base | (unsigned) p, tag_out = tag_base | (unsigned) (p + 1);
-        const int nb = ph.nb, K = ph.K;
-        const bool paired = ph.pair_F > 0;
-        const long long rows_total = paired ? ph.pair_F : (long long) ph.M;
-        const long long row0 = (long long) wg * ph.rows_wg;
-        const int rows = (int) (rows_total - row0 < ph.rows_wg ? (rows_total - row0 > 0 ? rows_total - row0 : 0) : ph.rows_wg);
+        const int nb = SH::S ? SH::K / 256 : ph.nb, K = SH::S ? SH::K : ph.K;
+        const bool paired = SH::S ? SH::PAIR > 0 : ph.pair_F > 0;
+        const long long pair_F = SH::S ? (long long) SH::PAIR : ph.pair_F;
+        const int rows_wg = SH::S ? (SH::PAIR ? SH::PAIR : SH::M) / G : ph.rows_wg;
+        const long long rows_total = paired ? pair_F : (long long) (SH::S ? SH::M : ph.M);
+        const long long row0 = (long long) wg * rows_wg;
+        const int rows = SH::S ? rows_wg : (int) (rows_total - row0 < rows_wg ? (rows_total - row0 > 0 ? rows_total - row0 : 0) : rows_wg);
         const int nblk_seg = rows * nb, nblk = paired ? 2 * nblk_seg : nblk_seg;
-        const bool is_attn = ph.prologue == MV_ATTN, is_rms = ph.prologue == MV_RMSNORM;
+        const bool is_attn = (SH::S ? SH::PRO : ph.prologue) == MV_ATTN, is_rms = (SH::S ? SH::PRO : ph.prologue) == MV_RMSNORM;
+        const bool x_chain = SH::S ? SH::XCH != 0 : ph.x_chain != 0;
+        const bool emb_chain = SH::S ? (SH::EMB && ph.emb_chain) : ph.emb_chain != 0;
+        const bool has_argmax = SH::S ? SH::AM != 0 : ph.argmax != 0;
+        const int n_in = SH::S ? (SH::PRO == MV_ATTN ? 3 * SH::K : SH::K) : ph.n_in;
 
         CH_STAMP(0);
 
         // ---- the hand-off poll goes out first; the loads that do not depend on the previous phase (norm weights, x from memory, the attention's
         // ring rows) ride behind it. A phase without attention takes its blocks straight into registers: block b = 256 values = lane l's granules
         // 4 l .. 4 l + 3 = two 16-byte loads, waves take blocks w, w + 8 - no LDS staging, no rendezvous before the norm.
-        const bool in_regs = ph.x_chain && !is_attn;
+        const bool in_regs = x_chain && !is_attn;
         const unsigned in_base = (unsigned) ((p - 1) & 1) * (CH_XF_MAX * 8u);
         const bool has0 = wave < nb, has1 = wave + CH_NCW < nb;   // (wave-uniform) only waves that own a block poll: every poll is a fabric read
         u32x4 gq[2][2];
@@ -480,7 +521,7 @@ __global__ void __launch_bounds__(CH_THREADS) matvec_chain_kernel(chain_params P
             al[r] = (f32x4) { 1.f, 1.f, 1.f, 1.f };
             if (is_rms && b < nb) al[r] = *(const GLOBAL_AS f32x4 *) (ph.alpha + b * 256 + lane * 4);
             xm[r] = (f32x4) { 0.f, 0.f, 0.f, 0.f };
-            if (!ph.x_chain && b < nb) xm[r] = *(const GLOBAL_AS f32x4 *) (ph.x + b * 256 + lane * 4);
+            if (!x_chain && b < nb) xm[r] = *(const GLOBAL_AS f32x4 *) (ph.x + b * 256 + lane * 4);
         }
         if (is_attn) {
             const attn_args & at = ph.at;
@@ -508,15 +549,15 @@ __global__ void __launch_bounds__(CH_THREADS) matvec_chain_kernel(chain_params P
                 issue_poll();
             }
             CH_STAMP(2);
-        } else if (ph.x_chain) {
-            if (!gather_vector(gb, in_base, ph.n_in, tag_in, xf, wave, lane, ctl)) give_up();
+        } else if (x_chain) {
+            if (!gather_vector(gb, in_base, n_in, tag_in, xf, wave, lane, ctl)) give_up();
             CH_STAMP(2);
-            if (!wg_barrier(ctl)) { alive = false; break; }
+            if (!wg_barrier(ctl)) return false;
             {
                 chain_attn_wave(ph.at, xf + ph.q_off, xf + ph.k_off, xf + ph.v_off, wave * 2, lane, attw + wave * CH_ATTW, xa + wave * 128, kq, vq, wg == 0, kr, vr,
                                 at_slot, at_m, at_rc, at_rs);
             }
-            if (!wg_barrier(ctl)) { alive = false; break; }
+            if (!wg_barrier(ctl)) return false;
             xsrc = xa;
         }
         CH_STAMP(3);
@@ -526,7 +567,7 @@ __global__ void __launch_bounds__(CH_THREADS) matvec_chain_kernel(chain_params P
             const int b = wave + r * CH_NCW;
             f32x4 t = xm[r];
             if (in_regs) t = (f32x4) { __uint_as_float(gq[r][0].x), __uint_as_float(gq[r][0].z), __uint_as_float(gq[r][1].x), __uint_as_float(gq[r][1].z) };
-            else if (ph.x_chain && b < nb) t = *(const f32x4 *) (xsrc + b * 256 + lane * 4);
+            else if (x_chain && b < nb) t = *(const f32x4 *) (xsrc + b * 256 + lane * 4);
             if (b >= nb) t = (f32x4) { 0.f, 0.f, 0.f, 0.f };   // (a clamped re-read does not count towards the norm)
             v[r][0] = t.x; v[r][1] = t.y; v[r][2] = t.z; v[r][3] = t.w;
         }
@@ -542,7 +583,7 @@ __global__ void __launch_bounds__(CH_THREADS) matvec_chain_kernel(chain_params P
                 acc = wave_allsum_f64(acc);
                 if (lane == 0) ctl->sumsq[wave] = acc;
             }
-            if (!wg_barrier(ctl)) { alive = false; break; }
+            if (!wg_barrier(ctl)) return false;
             {
                 double tot = 0;
 #pragma unroll
@@ -568,7 +609,7 @@ __global__ void __launch_bounds__(CH_THREADS) matvec_chain_kernel(chain_params P
         }
         if (stage_next && lane < DL) ((u32x4 *) (desc + ((p + 1) % 3) * CH_DESC_DWORDS))[lane] = next_desc;
         CH_STAMP(4);
-        if (!wg_barrier(ctl)) { alive = false; break; }
+        if (!wg_barrier(ctl)) return false;
         CH_STAMP(5);
 
         // ---- stage 2: super-block dots out of the registers (the WS = 1 arithmetic of matvec_q4k_kernel: 8 lanes per super-block)
@@ -609,7 +650,7 @@ __global__ void __launch_bounds__(CH_THREADS) matvec_chain_kernel(chain_params P
             if (p + 1 < P.n_phases) { chain_phase nx; read_desc_weights(p + 1, nx); request_weights(nx); }
             CH_STAMP(6);
             // the token this phase's epilogue needs (the previous phase's arg-max): wave 0 merges the candidates
-            if (ph.emb_chain && wave == 0) {
+            if (emb_chain && wave == 0) {
                 int token = 0;
                 if (!gather_token(cb, (unsigned) ((p - 1) & 1) * (2u * (unsigned) grid * 8u), grid, tag_in, lane, ctl, token)) give_up();
                 if (lane == 0) {
@@ -623,9 +664,17 @@ __global__ void __launch_bounds__(CH_THREADS) matvec_chain_kernel(chain_params P
                 }
             }
         }
-        if (!wg_barrier(ctl)) { alive = false; break; }   // partial sums and token visible
+        if (!wg_barrier(ctl)) return false;   // partial sums and token visible
         CH_STAMP(7);
-        read_desc_tail(p, ph);   // (moving these reads in front of the barrier does not help: every wave does them, there is no slack to hide them in)
+        if (!SH::S) read_desc_tail(p, ph);
+        else {
+            CH_LD(ph, dbase, y);
+            if (SH::EMB) { CH_LD(ph, dbase, emb.table); CH_LD(ph, dbase, emb.row_bytes); CH_LD(ph, dbase, emb.n_rows); CH_LD(ph, dbase, emb.type); CH_LD(ph, dbase, emb.index); CH_LD(ph, dbase, emb.scale); }
+        }
+        const int res = SH::S ? SH::RES : ph.res;
+        const bool save = SH::S ? SH::SAVE != 0 : ph.save != 0;
+        const int n_pub = SH::S ? SH::PUB : ph.n_pub;
+        const bool has_emb = SH::S ? SH::EMB != 0 : ph.emb.table != nullptr;
 
         // ---- stage 3: fixed-order row sums, epilogue, publication
         const unsigned pub_base = (unsigned) (p & 1) * CH_XF_MAX;
@@ -638,14 +687,14 @@ __global__ void __launch_bounds__(CH_THREADS) matvec_chain_kernel(chain_params P
                     sl = row16_allsum_f32(sl); sr = row16_allsum_f32(sr);
                     if ((tid & 15) == 0) {
                         const float g = (sl / (1.0f + expf(-sl))) * sr;
-                        if (ph.n_pub) st_granule(P.gbuf + pub_base + row0 + rr, tag_out, __float_as_uint(g));
-                        gp(ph.y)[row0 + rr] = sl; gp(ph.y)[ph.pair_F + row0 + rr] = sr;
+                        if (n_pub) st_granule(P.gbuf + pub_base + row0 + rr, tag_out, __float_as_uint(g));
+                        gp(ph.y)[row0 + rr] = sl; gp(ph.y)[pair_F + row0 + rr] = sr;
                     }
                 }
             } else {
                 float emb_scale = 1.f; const GLOBAL_AS char * emb_row = nullptr;
-                if (ph.emb.table) {
-                    int64_t r = ph.emb_chain ? (int64_t) ctl->token : (int64_t) *gp(ph.emb.index);
+                if (has_emb) {
+                    int64_t r = emb_chain ? (int64_t) ctl->token : (int64_t) *gp(ph.emb.index);
                     if (r < 0 || r >= ph.emb.n_rows) r = 0;
                     emb_row = gp(ph.emb.table) + r * ph.emb.row_bytes;
                     if (ph.emb.scale) emb_scale = *gp(ph.emb.scale);
@@ -656,15 +705,15 @@ __global__ void __launch_bounds__(CH_THREADS) matvec_chain_kernel(chain_params P
                     sum = row16_allsum_f32(sum);
                     if ((tid & 15) == 0) {
                         const int64_t row = row0 + rr;
-                        if (ph.res == 1) sum = xres[rr] + sum;
-                        else if (ph.res == 2) sum = gp(ph.residual)[row] + sum;
+                        if (res == 1) sum = xres[rr] + sum;
+                        else if (res == 2) sum = gp(ph.residual)[row] + sum;
                         else if (emb_row) {
                             float e = dequant_elem_g(emb_row, ph.emb.type, row);
                             if (ph.emb.scale) e = e * emb_scale;
                             sum = sum + e;
                         }
-                        if (ph.save) xres[rr] = sum;
-                        if (ph.n_pub) st_granule(P.gbuf + pub_base + row, tag_out, __float_as_uint(sum));
+                        if (save) xres[rr] = sum;
+                        if (n_pub) st_granule(P.gbuf + pub_base + row, tag_out, __float_as_uint(sum));
                         gp(ph.y)[row] = sum;
                         if (sum >= best) { best = sum; bi = (int) row; }   // rows ascend per thread: '>=' keeps the last maximum
                     }
@@ -672,18 +721,32 @@ __global__ void __launch_bounds__(CH_THREADS) matvec_chain_kernel(chain_params P
             }
         }
         CH_STAMP(8);
-        if (ph.argmax) {
+        if (has_argmax) {
             {
                 am_wave(best, bi);
                 if (lane == 0) { ctl->am_v[wave] = best; ctl->am_i[wave] = bi; }
             }
-            if (!wg_barrier(ctl)) { alive = false; break; }
+            if (!wg_barrier(ctl)) return false;
             if (tid == 0) {
                 for (int w = 1; w < CH_NCW; w++) am_merge(best, bi, ctl->am_v[w], ctl->am_i[w]);
                 u64 * c = P.cand + (size_t) (p & 1) * 2 * grid + 2 * wg;
                 st_granule(c, tag_out, __float_as_uint(best));
                 st_granule(c + 1, tag_out, (unsigned) bi);
             }
+        }
+        CH_STAMP(9);
+        return true;
+    };
+    for (int p = 0; p < P.n_phases && alive; p++) {
+        const int kind = (int) __builtin_amdgcn_readfirstlane(desc[(p % 3) * CH_DESC_DWORDS + offsetof(chain_phase, kind) / 4]);
+        switch (kind) {
+            case 1:  alive = phase(shape_din(), p); break;
+            case 2:  alive = phase(shape_inproj(), p); break;
+            case 3:  alive = phase(shape_outproj(), p); break;
+            case 4:  alive = phase(shape_linin(), p); break;
+            case 5:  alive = phase(shape_linout(), p); break;
+            case 6:  alive = phase(shape_head(), p); break;
+            default: alive = phase(dyn_shape(), p); break;
         }
     }
     if (!alive) return;
@@ -703,7 +766,7 @@ __global__ void __launch_bounds__(CH_THREADS) matvec_chain_kernel(chain_params P
 
 // ---- host side -----------------------------------------------------------------------------------------------------------------
 static int chain_env(const char * name, int def) { const char * v = getenv(name); return v ? atoi(v) : def; }
-bool k_chain_default_on() { static const int on = chain_env("MI355X_CHAIN", 0); return on != 0; }
+bool k_chain_default_on() { static const int on = chain_env("MI355X_CHAIN", 1); return on != 0; }
 static int chain_grid() { static const int g = chain_env("MI355X_CHAIN_GRID", 256); return g < 8 ? 8 : g > 256 ? 256 : g; }
 
 struct chain_plan {
@@ -822,7 +885,7 @@ static int chain_analyse(const mv_args * mv, int n, std::vector<chain_phase> & o
                 for (int j = i - 1; j >= 0; j--) if (out[(size_t) j].save) { src = j; break; }
                 if (src != res_from[(size_t) i]) cut = i;
             }
-            if ((ph.pair_F ? 2 : 1) * ph.rows_wg * ph.nb > CH_PMAX * CH_NCW * 8) cut = i;   // a phase's super-blocks must fit the registers
+            if ((ph.pair_F ? 2 : 1) * ph.rows_wg * ph.nb > CH_PMAX_OF(G) * CH_NCW * 8) cut = i;   // a phase's super-blocks must fit the registers
         }
         while (cut > 0 && out[(size_t) cut - 1].pair_F) cut--;   // a paired phase needs its consumer
         if (cut == len) break;
@@ -857,6 +920,27 @@ size_t k_chain_ws_size(const mv_args * mv, int n) {
     return chain_tables_bytes(len, (int) at.size()) + chain_state_bytes(chain_grid());
 }
 
+// which compile-time shape (1..6, see shape_din .. shape_head) a phase matches exactly, 0: none - its shape is read from the descriptor
+template <class SH> static bool shape_is(const chain_phase & ph, int grid) {
+    const int rows_total = SH::PAIR ? SH::PAIR : SH::M;
+    return ph.K == SH::K && ph.M == SH::M && ph.pair_F == SH::PAIR && ph.prologue == SH::PRO && ph.x_chain == SH::XCH && ph.res == SH::RES &&
+           (ph.emb.table != nullptr) == (SH::EMB != 0) && ph.save <= SH::SAVE && ph.argmax == SH::AM && ph.n_pub == SH::PUB &&
+           rows_total % grid == 0 && ph.rows_wg == rows_total / grid && ph.n_in == (SH::XCH ? (SH::PRO == MV_ATTN ? 3 * SH::K : SH::K) : ph.n_in) &&
+           ph.row_bytes == (SH::K / 256) * 144;
+}
+static int chain_shape_kind(const chain_phase & ph, int grid) {
+    static const int on = chain_env("MI355X_CHAIN_SHAPES", 0x7e);   // bit k: phase kind k may use its compile-time shape
+    if (!on || !(grid == 64 || grid == 128 || grid == 256)) return 0;
+    int k = 0;
+    if (shape_is<shape_din>(ph, grid)) k = 1;
+    else if (shape_is<shape_inproj>(ph, grid)) k = 2;
+    else if (shape_is<shape_outproj>(ph, grid)) k = 3;
+    else if (shape_is<shape_linin>(ph, grid)) k = 4;
+    else if (shape_is<shape_linout>(ph, grid)) k = 5;
+    else if (shape_is<shape_head>(ph, grid)) k = 6;
+    return (on >> k) & 1 ? k : 0;
+}
+
 chain_plan * k_chain_create(hipStream_t s, const mv_args * mv, int n, void * ws, unsigned * err) {
     chain_plan * c = new chain_plan;
     const int len = chain_analyse(mv, n, c->phases, c->attns);
@@ -871,6 +955,7 @@ chain_plan * k_chain_create(hipStream_t s, const mv_args * mv, int n, void * ws,
             chain_phase & ph = c->phases[(size_t) i];
             if (ph.attn >= 0) ph.at = c->attns[(size_t) ai++];
             ph.n_in = i > 0 ? c->phases[(size_t) i - 1].n_pub : 0;
+            ph.kind = chain_shape_kind(ph, c->grid);
             if (ph.emb_chain) { ph.prev_out[0] = c->phases[(size_t) i - 1].argmax_out[0]; ph.prev_out[1] = c->phases[(size_t) i - 1].argmax_out[1]; }
         }
     }
@@ -885,7 +970,12 @@ chain_plan * k_chain_create(hipStream_t s, const mv_args * mv, int n, void * ws,
     c->smem = 16 * XBLK_BYTES + (size_t) (CH_XF_MAX + CH_PART_MAX + CH_RES_MAX + 1024 + CH_NCW * CH_ATTW) * 4 + sizeof(chain_ctl) + 3 * sizeof(chain_phase);
     GGML_ASSERT(c->smem <= 160 * 1024);
     static bool granted = false;
-    if (!granted) { HIP_CHECK(hipFuncSetAttribute((const void *) matvec_chain_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); granted = true; }
+    if (!granted) {
+        HIP_CHECK(hipFuncSetAttribute((const void *) matvec_chain_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIP_CHECK(hipFuncSetAttribute((const void *) matvec_chain_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIP_CHECK(hipFuncSetAttribute((const void *) matvec_chain_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        granted = true;
+    }
     return c;
 }
 void k_chain_free(chain_plan * c) { delete c; }
@@ -893,5 +983,8 @@ int k_chain_length(const chain_plan * c) { return c->P.n_phases; }
 int64_t k_chain_weight_bytes(const chain_plan * c) { int64_t b = 0; for (auto & ph : c->phases) b += (int64_t) ph.M * ph.row_bytes; return b; }
 
 void k_chain_launch(hipStream_t s, const chain_plan * c) {
-    matvec_chain_kernel<<<c->grid, CH_THREADS, c->smem, s>>>(c->P);
+    // (the template argument only matters to phases with a compile-time shape; any other grid runs every phase from its descriptor)
+    if (c->grid == 256) matvec_chain_kernel<256><<<c->grid, CH_THREADS, c->smem, s>>>(c->P);
+    else if (c->grid == 128) matvec_chain_kernel<128><<<c->grid, CH_THREADS, c->smem, s>>>(c->P);
+    else matvec_chain_kernel<64><<<c->grid, CH_THREADS, c->smem, s>>>(c->P);
 }

@@ -108,7 +108,7 @@ struct mv_args {
 // Persistent chain engine (hip_chain.hip): a run of consecutive, dependent small Q4_K mat-vecs executed by ONE launch - resident workgroups,
 // a loader wave streaming every phase's weights through an LDS ring ahead of the dependency chain, data-tagged hand-offs between phases.
 struct chain_plan;
-bool   k_chain_default_on();                         // MI355X_CHAIN=1 (default off: measured at parity with launches)
+bool   k_chain_default_on();                         // MI355X_CHAIN (default 1; 0 = one launch per mat-vec)
 int    k_chain_accept(const mv_args * mv, int n);     // how many of the n consecutive mat-vecs (in launch order) one chain launch can take (0: none)
 size_t k_chain_ws_size(const mv_args * mv, int n);    // device workspace for exactly that run (tables + hand-off buffers)
 chain_plan * k_chain_create(hipStream_t s, const mv_args * mv, int n, void * ws, unsigned * err);

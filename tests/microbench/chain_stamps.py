@@ -30,6 +30,10 @@ for p in range(min(n, show)):
     print(f"{p:5d} | {(r[0] - t0) / 100.0:9.2f} | " + " | ".join(f"{x:9.2f}" for x in d) + f" | {(rec[1, p, 0] - r[0]) / 100.0:8.2f}")
 dur = np.array([(rec[0, p + 1, 0] - rec[0, p, 0]) / 100.0 for p in range(n - 1)])
 stage = np.array([[(rec[0, p, i] - rec[0, p, i - 1]) / 100.0 if rec[0, p, i] and rec[0, p, i - 1] else 0.0 for i in range(1, 9)] for p in range(n)])
+head = np.array([(rec[0, p, 0] - rec[0, p, 10]) / 100.0 for p in range(n)])
+tail = np.array([(rec[0, p, 9] - rec[0, p, 8]) / 100.0 for p in range(n)])
+between = np.array([(rec[0, p + 1, 10] - rec[0, p, 9]) / 100.0 for p in range(n - 1)])
+print(f"descriptor reads at the head of a phase {head.mean():.2f} us, arg-max tail {tail.mean():.2f} us, between phases (kind dispatch) {between.mean():.2f} us")
 print("mean per phase us:", f"{dur.mean():.2f}", "| by stage:", " ".join(f"{names[i + 1]}={stage[:, i].mean():.2f}" for i in range(8)))
 for k in range(per):
     sel = np.arange(k, n - 1, per)
