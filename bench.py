@@ -402,12 +402,18 @@ def main():
                                   "avg_launch_us": round(1e6 * kp.seconds / kp.launches, 3),
                                   "algorithmic_bytes_per_launch": int(kp.bytes // kp.launches)}
             # the same measurement split by instantiation family (rocprofv3 lists them as separate kernels): the large matrices stream, the small ones wait
-            names = ("lds_staged_tiles: matvec_q4k_kernel<.., WS=0> (Temporal matrices, text head)", "register_streaming: matvec_q4k_kernel<.., WS=1> (Depth transformer)")
+            names = ("lds_staged_tiles: matvec_q4k_kernel<.., WS=0> (Temporal matrices, text head)", "register_streaming: matvec_q4k_kernel<.., WS=1> (small matrices outside a chain)")
             result["roofline_by_variant"] = {names[v]: {"achieved": round(kp.variant_bytes[v] / kp.variant_seconds[v] / 1e9, 1), "unit": "GB/s",
                                                         "frac": round(kp.variant_bytes[v] / kp.variant_seconds[v] / 1e9 / HBM_PEAK_GBPS, 4),
                                                         "launches_per_frame": int(kp.variant_launches[v] // 3), "avg_launch_us": round(1e6 * kp.variant_seconds[v] / kp.variant_launches[v], 3),
                                                         "algorithmic_bytes_per_launch": int(kp.variant_bytes[v] // kp.variant_launches[v])}
                                              for v in range(2) if kp.variant_launches[v]}
+            if kp.chain_launches:
+                # the chained Depth transformer (lm.h:446-553) as persistent launches: weights streamed once per launch, ~208 dependent phases inside it
+                result["roofline_by_variant"]["persistent_chain: matvec_chain_kernel (Depth transformer, %d mat-vecs per launch)" % (kp.chain_phases // kp.chain_launches)] = {
+                    "achieved": round(kp.chain_bytes / kp.chain_seconds / 1e9, 1), "unit": "GB/s", "frac": round(kp.chain_bytes / kp.chain_seconds / 1e9 / HBM_PEAK_GBPS, 4),
+                    "launches_per_frame": int(kp.chain_launches // 3), "avg_launch_us": round(1e6 * kp.chain_seconds / kp.chain_launches, 3),
+                    "algorithmic_bytes_per_launch": int(kp.chain_bytes // kp.chain_launches), "us_per_phase": round(1e6 * kp.chain_seconds / kp.chain_phases, 3)}
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         # the same frame loop on the host cores through the CPU oracle (a port of ggml's CPU semantics; the reference's

@@ -128,6 +128,11 @@ struct ggml_mi355x_kernel_profile {
     double  variant_seconds[2];
     int64_t variant_launches[2];
     int64_t variant_bytes[2];
+    // persistent chain launches (matvec_chain_kernel: the chained Depth transformer's mat-vecs as one launch), timed between two stream events
+    double  chain_seconds;
+    int64_t chain_launches;
+    int64_t chain_bytes;      // weight bytes the launch streams
+    int64_t chain_phases;     // mat-vecs (phases) inside those launches
 };
 GGML_API void ggml_backend_mi355x_get_kernel_profile(ggml_backend_t backend, struct ggml_mi355x_kernel_profile * out);
 // bit flags, default 0: 1 = disable fusion (one kernel per node), 2 = disable hipGraph capture, 4 = disable upload batching,

@@ -66,6 +66,8 @@ struct hip_ctx {
     mv_profile prof = { nullptr, 0, 0 };
     double prof_seconds = 0; int64_t prof_launches = 0, prof_bytes = 0;
     double prof_seconds_v[2] = { 0, 0 }; int64_t prof_launches_v[2] = { 0, 0 }, prof_bytes_v[2] = { 0, 0 };   // the same, by kernel variant
+    double prof_chain_seconds = 0; int64_t prof_chain_launches = 0, prof_chain_bytes = 0, prof_chain_phases = 0;   // persistent chain launches (matvec_chain_kernel), stream events
+    hipEvent_t chain_ev[2] = { nullptr, nullptr };
     // cached plans keyed by cgraph pointer
     std::unordered_map<const ggml_cgraph *, plan_t *> plans;
     uint64_t orphan_clock = 0;
@@ -285,6 +287,7 @@ typedef std::function<void(hipStream_t)> step_fn;
 // (hip_chain.hip) once the whole plan is laid out
 struct pstep {
     step_fn fn; bool is_mv = false; mv_args mv;
+    chain_plan * chain = nullptr;   // a persistent chain launch (timed on its own in profile mode)
     template <typename F> pstep(F f) : fn(std::move(f)) { memset(&mv, 0, sizeof(mv)); }
     pstep(const mv_args & a) : fn([a](hipStream_t s) { k_matvec(s, a); }), is_mv(true), mv(a) {}
 };
@@ -1791,6 +1794,7 @@ static plan_t * build_plan(hip_ctx * c, ggml_cgraph * g) {
                 chain_plan * ch = k_chain_create(c->stream, run.data() + k, len, ws, c->err_dev);
                 p->chains.push_back(ch);
                 merged.push_back(pstep([ch](hipStream_t s) { k_chain_launch(s, ch); }));
+                merged.back().chain = ch;
                 p->n_chained += len;
                 if (dump) fprintf(stderr, "plan: %d consecutive mat-vecs -> one chain launch (%.1f MB of weights)\n", len, (double) k_chain_weight_bytes(ch) / 1e6);
                 k += (size_t) len;
@@ -1813,7 +1817,19 @@ static void run_steps_profiled(hip_ctx * c, plan_t * p) {
     }
     c->prof.used = 0;
     k_matvec_set_profile(&c->prof);
-    run_steps(c, p);
+    for (auto & st : p->steps) {
+        if (!st.chain) { st.fn(c->stream); continue; }
+        // a persistent chain launch: one kernel, timed between two stream events
+        if (!c->chain_ev[0]) { HIP_CHECK(hipEventCreate(&c->chain_ev[0])); HIP_CHECK(hipEventCreate(&c->chain_ev[1])); }
+        HIP_CHECK(hipStreamSynchronize(c->stream));
+        HIP_CHECK(hipEventRecord(c->chain_ev[0], c->stream));
+        st.fn(c->stream);
+        HIP_CHECK(hipEventRecord(c->chain_ev[1], c->stream));
+        HIP_CHECK(hipEventSynchronize(c->chain_ev[1]));
+        float ms = 0;
+        HIP_CHECK(hipEventElapsedTime(&ms, c->chain_ev[0], c->chain_ev[1]));
+        c->prof_chain_seconds += (double) ms * 1e-3; c->prof_chain_launches++; c->prof_chain_bytes += k_chain_weight_bytes(st.chain); c->prof_chain_phases += k_chain_length(st.chain);
+    }
     k_matvec_set_profile(nullptr);
     HIP_CHECK(hipStreamSynchronize(c->stream));
     for (int i = 0; i < c->prof.used; i++) {
@@ -2044,6 +2060,7 @@ extern "C" void ggml_backend_mi355x_get_kernel_profile(ggml_backend_t b, struct 
     hip_ctx * c = ctx_of(b);
     out->seconds = c->prof_seconds; out->launches = c->prof_launches; out->bytes = c->prof_bytes;
     for (int v = 0; v < 2; v++) { out->variant_seconds[v] = c->prof_seconds_v[v]; out->variant_launches[v] = c->prof_launches_v[v]; out->variant_bytes[v] = c->prof_bytes_v[v]; }
+    out->chain_seconds = c->prof_chain_seconds; out->chain_launches = c->prof_chain_launches; out->chain_bytes = c->prof_chain_bytes; out->chain_phases = c->prof_chain_phases;
 }
 extern "C" void * ggml_backend_mi355x_get_stream(ggml_backend_t b) { hip_ctx * c = ctx_of(b); ctx_init_lazy(c); return (void *) c->stream; }
 extern "C" ggml_backend_t ggml_backend_mi355x_init_stream(ggml_backend_t base) {
