@@ -27,6 +27,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 from __graft_entry__ import load_oracle, load_package  # noqa: E402
 
+PMC_FILE = "r03_pmc_fetch_size.json"   # rocprofv3 --pmc FETCH_SIZE pass of this command (tests/microbench/take_profiles.sh), stamped with the kernel sources' hash
 HBM_PEAK_GBPS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 
 
@@ -386,12 +387,12 @@ def main():
         # corrected as MI355X_MICROARCH.md prescribes); counters cannot be read from inside the timed process
         traffic, traffic_note = None, "no counter file for these sources"
         try:
-            with open(os.path.join(ROOT, "profiles", "r02_pmc_fetch_size.json")) as f:
+            with open(os.path.join(ROOT, "profiles", PMC_FILE)) as f:
                 pmc = json.load(f)
             if pmc.get("source_sha") == source_sha():
-                traffic, traffic_note = pmc["matvec_q4k_kernel"]["fetch_bytes_per_launch"], "profiles/r02_pmc_fetch_size.json (rocprofv3 --pmc FETCH_SIZE, x2 gfx950 correction)"
+                traffic, traffic_note = pmc["matvec_q4k_kernel"]["fetch_bytes_per_launch"], "profiles/%s (rocprofv3 --pmc FETCH_SIZE, x2 gfx950 correction)" % PMC_FILE
             else:
-                traffic_note = "profiles/r02_pmc_fetch_size.json was taken from other sources (%s, now %s): refused" % (pmc.get("source_sha"), source_sha())
+                traffic_note = "profiles/%s was taken from other sources (%s, now %s): refused" % (PMC_FILE, pmc.get("source_sha"), source_sha())
         except Exception:
             pass
         if kp.launches:

@@ -17,7 +17,7 @@ def test_bench_parses_its_arguments_and_hashes_its_sources():
     import bench
     sha = bench.source_sha()
     assert len(sha) == 16 and sha == bench.source_sha()
-    with open(os.path.join(ROOT, "profiles", "r02_pmc_fetch_size.json")) as f:
+    with open(os.path.join(ROOT, "profiles", bench.PMC_FILE)) as f:
         pmc = json.load(f)
     assert {"source_sha", "matvec_q4k_kernel"} <= set(pmc) and pmc["matvec_q4k_kernel"]["fetch_bytes_per_launch"] > 0
 
