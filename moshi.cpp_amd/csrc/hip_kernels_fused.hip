@@ -1648,7 +1648,10 @@ void k_matvec(hipStream_t s, const mv_args & a) {
 // the probabilities are bit-identical to the single-workgroup path; P x V partials -> global; the last workgroup to arrive adds
 // them in slot order. The wait cannot deadlock: workgroups are dispatched in blockIdx order and a head's workgroups are
 // contiguous, so the lowest unfinished head always has all of its workgroups resident (the spin is bounded regardless).
-struct attn_split_ws { float * scores; float * pmax; double * opart; unsigned * arrive; unsigned * done; int S; unsigned * err; int slots; int single_max; int big_min; };
+// (round 3) hand-offs are data-tagged: a score / a half of a partial-output double travels as one 8-byte {tag, value} granule written by one agent-scope
+// store and polled with agent-scope loads (cdna_hip_programming.md Guideline 16, form R2) - no returning exchanges, no arrival counter, no second hop
+// to learn that the counter has moved. tag = the head's launch sequence number + 1, bumped by the workgroup that merges the head.
+struct attn_split_ws { unsigned long long * gscores; unsigned long long * gpart; unsigned * seq; int S; unsigned * err; int slots; int single_max; int big_min; };
 
 #if defined(MV_LOG)
 #define AT_STAMP(i) do { if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { if ((i) == 0) at_log_id = atomicAdd(&g_mv_launch, 1u) & 8191u; unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); g_mv_log[at_log_id][i] = t_; \
@@ -1677,8 +1680,11 @@ attn_decode_kernel(attn_args a_in, attn_split_ws w) {
         a.out += (int64_t) t0 * a.out_ts;
     }
     // passes whose ring rows are requested before the first wait (the rest streams in batches of the same size in the pass loops)
+    // NB: rows per later batch. A split workgroup owns at most 2 x w.slots = 256 slots = 16 passes: after the NPRE it asked for at entry, ALL the others go out
+    // in one batch (K before the scores; V right behind the scores, landing during the head-wide hand-off) - one memory round trip each instead of three.
+    constexpr int NB = SPLIT ? 12 : ATTN_NPRE;
     constexpr int NPRE = ATTN_NPRE;   // A/B at bench level: 4 beats 2 and 8 for the split kernel at empty, 600-slot and full context (registers vs round trips)
-    const int D = a.D, C = a.C, T = a.T;
+    const int D = SPLIT ? 128 : a.D, C = a.C, T = SPLIT ? 1 : a.T;   // (attn_use_split: one query row, 128-wide heads - known to the compiler)
     const int S = SPLIT ? w.S : 1;
     const int h = SPLIT ? (int) blockIdx.x / S : (int) blockIdx.x, s_idx = SPLIT ? (int) blockIdx.x % S : 0;
     // the range a workgroup owns adapts to the live length: w.slots (small) up to w.big_min live slots, twice that beyond - short
@@ -1697,9 +1703,9 @@ attn_decode_kernel(attn_args a_in, attn_split_ws w) {
     __shared__ double sh_d[ATTN_NW];
     __shared__ int sh_i[ATTN_NW];
     __shared__ int sh_slot[ATTN_MAX_T];
-    __shared__ int s_last;
 
     char * kc = a.kcache + (int64_t) h * a.k_nb2, * vc = a.vcache + (int64_t) h * a.v_nb2;
+    const unsigned tag = SPLIT ? w.seq[h] + 1u : 0u;   // this launch's hand-off tag for the head (never 0; written back by the head's merger at the very end)
     const int LPS = D / 8;              // lanes per slot (16 for D=128, 8 for D=64): 8 dims (16 B) per lane
     const int SPW = 64 / LPS;           // slots per wave-instruction
     const int sub = lane / LPS, dl = (lane % LPS) * 8;
@@ -1782,6 +1788,16 @@ attn_decode_kernel(attn_args a_in, attn_split_ws w) {
             in_q0[u] = q[2 * p]; in_q1[u] = q[2 * p + 1]; in_k0[u] = k[2 * p]; in_k1[u] = k[2 * p + 1];
         } else { in_c[u] = 1.f; in_s[u] = 0.f; in_q0[u] = q[j]; in_q1[u] = 0.f; in_k0[u] = k[j]; in_k1[u] = 0.f; }
     }
+    // The mask row of the head's first workgroup is requested BEFORE the ring rows (and looked at behind them): vector loads return in order, so a scan
+    // issued behind the 2 x NPRE ring-row requests only saw its L2-resident mask once those HBM rows had landed (2.9 us from kernel entry to "loads
+    // issued" at 2 800 live slots, profiles/r03_frame_stamps_fill_2800.txt) - and the live length decides everything that follows.
+    const bool scan_fast = (!SPLIT || s_idx == 0) && (C & 3) == 0 && (((uintptr_t) a.mask) & 15) == 0 && T * (C / 4) <= 3 * ATTN_THREADS;
+    float4 m4pre[3];
+    if (scan_fast) {
+        const int row4 = C / 4, n4 = T * row4;
+#pragma unroll
+        for (int u = 0; u < 3; u++) { const int e = tid + u * ATTN_THREADS; m4pre[u] = ((const float4 *) a.mask)[e < n4 ? e : n4 - 1]; }
+    }
     // ring rows of the first passes; valid memory for every slot < C, discarded where the mask says -inf
     uint4 kpre[NPRE], vpre[NPRE];
 #pragma unroll
@@ -1792,7 +1808,19 @@ attn_decode_kernel(attn_args a_in, attn_split_ws w) {
         if (pi < ATTN_NPRE) vpre[pi] = *(const uint4 *) (vc + (int64_t) cc * a.v_nb1 + dl * 2);   // later V passes: after the scores (registers)
     }
     int last_live = -1;
-    if (!SPLIT || s_idx == 0) last_live = scan_last_live(0);
+    if (scan_fast) {
+        const int row4 = C / 4, n4 = T * row4;
+#pragma unroll
+        for (int u = 0; u < 3; u++) {
+            const int e = tid + u * ATTN_THREADS;
+            if (e < n4) {
+                ((float4 *) msk)[e] = m4pre[u];
+                const int i4 = e % row4;
+                const int hi = m4pre[u].w > -INFINITY ? 3 : m4pre[u].z > -INFINITY ? 2 : m4pre[u].y > -INFINITY ? 1 : m4pre[u].x > -INFINITY ? 0 : -1;
+                if (hi >= 0) last_live = max(last_live, i4 * 4 + hi);
+            }
+        }
+    } else if (!SPLIT || s_idx == 0) last_live = scan_last_live(0);
     __builtin_amdgcn_sched_barrier(0);
     AT_STAMP(1);
 
@@ -1826,6 +1854,7 @@ attn_decode_kernel(attn_args a_in, attn_split_ws w) {
     const int P = SPLIT && n_end > w.single_max ? (n_end + SLOTS - 1) / SLOTS : 1;   // participating workgroups of this head
     const bool multi = SPLIT && P > 1;
     const int c_lo = multi ? c_base : 0, c_hi = multi ? min(n_end, c_base + SLOTS) : n_end;   // slots whose K / V rows this workgroup reads
+    const int c_last = c_hi > 0 ? c_hi - 1 : 0;   // last row of the range (address clamp of the batched requests)
     // a prefetched row may be the slot that was just rewritten (last writer wins, like set_rows): take it from LDS instead
     auto pack_row = [&](const float * src) {
         uint4 r;
@@ -1867,34 +1896,45 @@ attn_decode_kernel(attn_args a_in, attn_split_ws w) {
                 lmax = fmaxf(lmax, sv);
             }
         };
+        // further slots: NB rows requested together, then consumed (one memory round trip per batch, not per pass). A split workgroup asks for its one
+        // later batch BEFORE it scores the rows it requested at entry.
+        uint4 kb[NB];
+        auto request_k_batch = [&](int cb) {
+#pragma unroll
+            for (int pi = 0; pi < NB; pi++) {
+                const int c0 = cb + wave * SPW + pi * ATTN_NW * SPW, c = c0 + sub;
+                // Unconditional, back to back (a request under a branch gets an s_waitcnt vmcnt(0) in front of it from the compiler: twelve serial round trips);
+                // passes beyond the range ask for its last row again (a cache hit) and are not used.
+                kb[pi] = *(const uint4 *) (kc + (int64_t) (c < c_last ? c : c_last) * a.k_nb1 + dl * 2);
+                if (SPLIT) __builtin_amdgcn_sched_barrier(0);   // requests in pass order: the first pass's row must not be the last one asked for
+            }
+        };
+        const int cb_first = c_lo + NPRE * ATTN_NW * SPW;
+        if (SPLIT) request_k_batch(cb_first);
 #pragma unroll
         for (int pi = 0; pi < NPRE; pi++) {
             const int c0 = c_lo + wave * SPW + pi * ATTN_NW * SPW;
             if (c0 < c_hi) score_pass(c0, kpre[pi]);
         }
-        // further slots: NPRE rows requested together, then consumed (one memory round trip per batch, not per pass)
-        for (int cb = c_lo + NPRE * ATTN_NW * SPW; cb < c_hi; cb += NPRE * ATTN_NW * SPW) {
-            uint4 kb[NPRE];
+        for (int cb = cb_first; cb < c_hi; cb += NB * ATTN_NW * SPW) {
+            if (!SPLIT || cb != cb_first) request_k_batch(cb);
 #pragma unroll
-            for (int pi = 0; pi < NPRE; pi++) {
-                const int c = cb + wave * SPW + pi * ATTN_NW * SPW + sub, f = fresh_of(c);
-                kb[pi] = *(const uint4 *) (kc + (int64_t) (c < C ? c : C - 1) * a.k_nb1 + dl * 2);
-                if (f >= 0) kb[pi] = pack_row(knew + f * D + dl);
-            }
-#pragma unroll
-            for (int pi = 0; pi < NPRE; pi++) {
-                const int c0 = cb + wave * SPW + pi * ATTN_NW * SPW;
-                if (c0 < c_hi) score_pass(c0, kb[pi]);
+            for (int pi = 0; pi < NB; pi++) {
+                const int c0 = cb + wave * SPW + pi * ATTN_NW * SPW, f = fresh_of(c0 + sub);
+                if (c0 < c_hi) {
+                    if (f >= 0) kb[pi] = pack_row(knew + f * D + dl);
+                    score_pass(c0, kb[pi]);
+                }
             }
         }
-        if (NPRE > ATTN_NPRE) {
-            // the remaining V rows of a split workgroup go out now (the K registers are free) and arrive during the head-wide wait
+        // the first later batch of V rows of a split workgroup goes out now (the K registers are free) and arrives during the head-wide hand-off
+        uint4 vb0[SPLIT ? NB : 1];
+        if (SPLIT) {
 #pragma unroll
-            for (int pi = ATTN_NPRE; pi < NPRE; pi++) {
-                const int c = c_base + wave * SPW + pi * ATTN_NW * SPW + sub;
-                vpre[pi] = *(const uint4 *) (vc + (int64_t) (c < C ? c : C - 1) * a.v_nb1 + dl * 2);
-                const int f = fresh_of(c);
-                if (f >= 0) vpre[pi] = pack_row(vnew + f * D + dl);
+            for (int pi = 0; pi < NB; pi++) {
+                const int c0 = c_lo + (NPRE + pi) * ATTN_NW * SPW + wave * SPW, c = c0 + sub;
+                vb0[pi] = *(const uint4 *) (vc + (int64_t) (c < c_last ? c : c_last) * a.v_nb1 + dl * 2);   // (fresh row: patched where it is used)
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
         AT_STAMP(10);
@@ -1907,40 +1947,49 @@ attn_decode_kernel(attn_args a_in, attn_split_ws w) {
 #pragma unroll
         for (int w_ = 1; w_ < ATTN_NW; w_++) gmax = fmaxf(gmax, sh_f[w_]);
         if (multi) {
-            // publish (this workgroup's scores, at most one per thread: SLOTS <= 256 = ATTN_THREADS, and from thread 0 its maximum - the two returning
-            // exchanges are in flight together), arrive, wait for the other P - 1 workgroups of this head, then pull everybody's scores and maxima with
-            // all loads in flight at once. Every agent-scope access is a full memory round trip (~2 us at long context): four of them in a row here,
-            // seven before this was restructured (stamps 3 -> 4 at 2 800 live slots: 14.3 us of a 33 us kernel)
+            // publish this workgroup's scores (at most one per thread: SLOTS <= 256 = ATTN_THREADS) as tagged granules - plain agent-scope stores, nothing to
+            // wait for - then pull everybody else's the same way: every thread polls ITS OWN granules until their tags are this launch's. The head-wide
+            // maximum is the maximum over all pulled scores. (Before: returning exchanges + arrival counter + poll + pull = four dependent memory round
+            // trips of ~2 us at long context, 14.3 us of a 33 us kernel at 2 800 live slots, profiles/r02_frame_stamps_fill_2800.txt.)
             {
                 const int c = c_lo + tid;
-                float o1 = 0.f, o2 = 0.f;
-                if (c < c_hi) o1 = __hip_atomic_exchange(w.scores + (int64_t) h * C + c, sc[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (tid == 0) o2 = __hip_atomic_exchange(w.pmax + h * S + s_idx, gmax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                asm volatile("" :: "v"(o1), "v"(o2));   // both complete at the coherence point (xchg_agent_wait's reasoning)
+                if (c < c_hi) __hip_atomic_store(w.gscores + (int64_t) h * C + c, ((unsigned long long) tag << 32) | (unsigned long long) __float_as_uint(sc[c]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-            __syncthreads();
-            if (tid == 0) {
-                const unsigned before = atomicAdd(w.arrive + h, 1u);
-                if (before + 1u < (unsigned) P) {          // (the last to arrive has nothing to wait for)
-                    int spins = 0;
-                    while (ld_agent(w.arrive + h) < (unsigned) P && ++spins < (1 << 22)) __builtin_amdgcn_s_sleep(2);
-                    if (spins >= (1 << 22) && w.err) *w.err = 1u;   // host-visible: the backend aborts at the next read-back
-                }
-            }
-            __syncthreads();
             {
-                const float pm = ld_agent(w.pmax + h * S + (lane < P ? lane : 0));   // P <= C / 128 = 24 < 64
                 constexpr int PULL = 12;                                             // C <= 3 072 at 256 threads: one batch
+                float omax = -INFINITY;
                 for (int c0 = tid; c0 < n_end; c0 += PULL * ATTN_THREADS) {
-                    float v[PULL];
+                    unsigned long long g[PULL];
+                    int spins = 0;
+                    for (;;) {
 #pragma unroll
-                    for (int u = 0; u < PULL; u++) { const int c = c0 + u * ATTN_THREADS; v[u] = ld_agent(w.scores + (int64_t) h * C + (c < n_end ? c : n_end - 1)); }
+                        for (int u = 0; u < PULL; u++) {
+                            const int c = c0 + u * ATTN_THREADS;
+                            g[u] = __hip_atomic_load(w.gscores + (int64_t) h * C + (c < n_end ? c : n_end - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
+                        bool ok = true;
 #pragma unroll
-                    for (int u = 0; u < PULL; u++) { const int c = c0 + u * ATTN_THREADS; if (c < n_end && (c < c_lo || c >= c_hi)) sc[c] = v[u]; }
+                        for (int u = 0; u < PULL; u++) {
+                            const int c = c0 + u * ATTN_THREADS;
+                            if (c < n_end && (c < c_lo || c >= c_hi)) ok = ok && (unsigned) (g[u] >> 32) == tag;   // (own slots come from LDS)
+                        }
+                        if (ok) break;
+                        if (++spins >= (1 << 20)) { if (w.err) *w.err = 1u; break; }   // host-visible: the backend aborts at the next read-back
+                        __builtin_amdgcn_s_sleep(1);
+                    }
+#pragma unroll
+                    for (int u = 0; u < PULL; u++) {
+                        const int c = c0 + u * ATTN_THREADS;
+                        if (c < n_end && (c < c_lo || c >= c_hi)) { const float v = __uint_as_float((unsigned) g[u]); sc[c] = v; omax = fmaxf(omax, v); }
+                    }
                 }
-                gmax = fmaxf(gmax, wave_allmax_f32(lane < P ? pm : -INFINITY));
+                omax = wave_allmax_f32(omax);
+                __syncthreads();                       // (sh_f was read above)
+                if (lane == 0) sh_f[wave] = omax;
+                __syncthreads();
+#pragma unroll
+                for (int w_ = 0; w_ < ATTN_NW; w_++) gmax = fmaxf(gmax, sh_f[w_]);
             }
-            __syncthreads();
         }
 
         // 3. soft_max: exp in float, sum in double, scale by (float)(1/sum), round to BF16 for the V product
@@ -1979,18 +2028,30 @@ attn_decode_kernel(attn_args a_in, attn_split_ws w) {
             const int c0 = c_lo + wave * SPW + pi * ATTN_NW * SPW;
             if (c0 < c_hi) pv_pass(c0, vpre[pi]);
         }
-        for (int cb = c_lo + NPRE * ATTN_NW * SPW; cb < c_hi; cb += NPRE * ATTN_NW * SPW) {
-            uint4 vb[NPRE];
+        if (SPLIT) {
 #pragma unroll
-            for (int pi = 0; pi < NPRE; pi++) {
-                const int c = cb + wave * SPW + pi * ATTN_NW * SPW + sub, f = fresh_of(c);
-                vb[pi] = *(const uint4 *) (vc + (int64_t) (c < C ? c : C - 1) * a.v_nb1 + dl * 2);
-                if (f >= 0) vb[pi] = pack_row(vnew + f * D + dl);
+            for (int pi = 0; pi < NB; pi++) {
+                const int c0 = c_lo + (NPRE + pi) * ATTN_NW * SPW + wave * SPW, f = fresh_of(c0 + sub);
+                if (c0 < c_hi) {
+                    if (f >= 0) vb0[pi] = pack_row(vnew + f * D + dl);
+                    pv_pass(c0, vb0[pi]);
+                }
+            }
+        }
+        for (int cb = c_lo + (SPLIT ? NPRE + NB : NPRE) * ATTN_NW * SPW; cb < c_hi; cb += NB * ATTN_NW * SPW) {
+            uint4 vb[NB];
+#pragma unroll
+            for (int pi = 0; pi < NB; pi++) {
+                const int c0 = cb + wave * SPW + pi * ATTN_NW * SPW, c = c0 + sub;
+                vb[pi] = *(const uint4 *) (vc + (int64_t) (c < c_last ? c : c_last) * a.v_nb1 + dl * 2);
             }
 #pragma unroll
-            for (int pi = 0; pi < NPRE; pi++) {
-                const int c0 = cb + wave * SPW + pi * ATTN_NW * SPW;
-                if (c0 < c_hi) pv_pass(c0, vb[pi]);
+            for (int pi = 0; pi < NB; pi++) {
+                const int c0 = cb + wave * SPW + pi * ATTN_NW * SPW, f = fresh_of(c0 + sub);
+                if (c0 < c_hi) {
+                    if (f >= 0) vb[pi] = pack_row(vnew + f * D + dl);
+                    pv_pass(c0, vb[pi]);
+                }
             }
         }
         AT_STAMP(5);
@@ -2002,28 +2063,43 @@ attn_decode_kernel(attn_args a_in, attn_split_ws w) {
             double tot = 0;
 #pragma unroll 8
             for (int g = 0; g < ATTN_NW * SPW; g++) tot += red[g * D + j];   // fixed order: wave-major, slot group minor
-            if (multi) xchg_agent_wait(w.opart + ((int64_t) h * S + s_idx) * D + j, tot);
-            else a.out[(int64_t) t * a.out_ts + (int64_t) h * D + j] = (float) tot;
+            if (multi) {
+                unsigned long long * gp = w.gpart + (((int64_t) h * S + s_idx) * D + j) * 2;
+                const unsigned long long bits = (unsigned long long) __double_as_longlong(tot);
+                __hip_atomic_store(gp, ((unsigned long long) tag << 32) | (bits & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(gp + 1, ((unsigned long long) tag << 32) | (bits >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else a.out[(int64_t) t * a.out_ts + (int64_t) h * D + j] = (float) tot;
         }
-        if (multi) {
-            // the last of the P workgroups to get here adds the partial outputs in slot order and re-arms the counters
-            __syncthreads();   // every thread's partial-output exchange has completed (xchg_agent_wait)
-            if (tid == 0) s_last = atomicAdd(w.done + h, 1u) == (unsigned) (P - 1);
-            __syncthreads();
-            if (s_last) {
-                for (int j = tid; j < D; j += ATTN_THREADS) {
-                    double tot = 0;
-                    for (int q0 = 0; q0 < P; q0 += 8) {
-                        double v[8];
+        if (multi && s_idx == 0) {
+            // the head's first workgroup adds the P partial outputs in slot order (its own included: read back like the others), polling each granule pair
+            // until it carries this launch's tag; then it bumps the head's sequence number - every workgroup has long read it, and a workgroup publishes its
+            // partial only after it has finished reading the scores
+            for (int j = tid; j < D; j += ATTN_THREADS) {
+                double tot = 0;
+                for (int q0 = 0; q0 < P; q0 += 8) {
+                    unsigned long long lo[8], hi[8];
+                    int spins = 0;
+                    for (;;) {
 #pragma unroll
-                        for (int u = 0; u < 8; u++) v[u] = ld_agent(w.opart + ((int64_t) h * S + (q0 + u < P ? q0 + u : P - 1)) * D + j);
+                        for (int u = 0; u < 8; u++) {
+                            const unsigned long long * gp = w.gpart + (((int64_t) h * S + (q0 + u < P ? q0 + u : P - 1)) * D + j) * 2;
+                            lo[u] = __hip_atomic_load(gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            hi[u] = __hip_atomic_load(gp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
+                        bool ok = true;
 #pragma unroll
-                        for (int u = 0; u < 8; u++) if (q0 + u < P) tot += v[u];   // slot order
+                        for (int u = 0; u < 8; u++) ok = ok && (unsigned) (lo[u] >> 32) == tag && (unsigned) (hi[u] >> 32) == tag;
+                        if (ok) break;
+                        if (++spins >= (1 << 20)) { if (w.err) *w.err = 1u; break; }
+                        __builtin_amdgcn_s_sleep(1);
                     }
-                    a.out[(int64_t) t * a.out_ts + (int64_t) h * D + j] = (float) tot;
+#pragma unroll
+                    for (int u = 0; u < 8; u++) if (q0 + u < P) tot += __longlong_as_double((long long) ((lo[u] & 0xffffffffull) | (hi[u] << 32)));   // slot order
                 }
-                if (tid == 0) { st_agent(w.arrive + h, 0u); st_agent(w.done + h, 0u); }
+                a.out[(int64_t) t * a.out_ts + (int64_t) h * D + j] = (float) tot;
             }
+            __syncthreads();
+            if (tid == 0) w.seq[h] = tag;   // (plain store: read by the next launch)
         }
         __syncthreads();
     }
@@ -2035,7 +2111,7 @@ static int attn_split_slots() { static const int v = env_int("MI355X_ATTN_SLOTS"
 size_t k_attn_decode_ws_size(const attn_args & a) {
     if (!attn_use_split(a)) return 0;
     const size_t S = (size_t) (a.C + attn_split_slots() - 1) / attn_split_slots();
-    return (size_t) a.H * a.C * 4 + (size_t) a.H * S * 4 + (size_t) a.H * S * a.D * 8 + (size_t) a.H * 8 + 256;
+    return 256 + (((size_t) a.H * 4 + 255) & ~(size_t) 255) + (size_t) a.H * a.C * 8 + (size_t) a.H * S * a.D * 16;   // per-head sequence numbers | score granules | partial-output granules
 }
 void k_attn_decode(hipStream_t s, const attn_args & a, void * ws, unsigned * err) {
     const int Tg = a.n_groups > 1 ? ATTN_MAX_T : a.T;   // rows per workgroup
@@ -2055,16 +2131,15 @@ void k_attn_decode(hipStream_t s, const attn_args & a, void * ws, unsigned * err
         }
     }
     static const int single_max = env_int("MI355X_ATTN_SINGLE_MAX", ATTN_SINGLE_MAX), big_min = env_int("MI355X_ATTN_BIG_MIN", ATTN_SPLIT_BIG_MIN);
-    attn_split_ws w = { nullptr, nullptr, nullptr, nullptr, nullptr, 1, err, ATTN_SPLIT_SLOTS, single_max, big_min };
+    attn_split_ws w = { nullptr, nullptr, nullptr, 1, err, ATTN_SPLIT_SLOTS, single_max, big_min };
     if (ws && attn_use_split(a)) {
         const int S = (a.C + attn_split_slots() - 1) / attn_split_slots();
         w.slots = attn_split_slots();
         GGML_ASSERT(a.D == 128 && "split prefetch depth is sized for 16 slots per pass");
         char * p = (char *) ws;
-        w.arrive = (unsigned *) p; w.done = w.arrive + a.H; p += ((size_t) a.H * 8 + 255) & ~(size_t) 255;
-        w.opart = (double *) p; p += (size_t) a.H * S * a.D * 8;
-        w.scores = (float *) p; p += (size_t) a.H * a.C * 4;
-        w.pmax = (float *) p;
+        w.seq = (unsigned *) p; p += ((size_t) a.H * 4 + 255) & ~(size_t) 255;
+        w.gscores = (unsigned long long *) p; p += (size_t) a.H * a.C * 8;
+        w.gpart = (unsigned long long *) p;
         w.S = S;
         attn_decode_kernel<true, ATTN_NW_BASE><<<a.H * S, ATTN_NW_BASE * 64, smem, s>>>(a, w);
         return;
