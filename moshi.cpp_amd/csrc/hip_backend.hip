@@ -66,6 +66,7 @@ struct hip_ctx {
     mv_profile prof = { nullptr, 0, 0 };
     double prof_seconds = 0; int64_t prof_launches = 0, prof_bytes = 0;
     double prof_seconds_v[2] = { 0, 0 }; int64_t prof_launches_v[2] = { 0, 0 }, prof_bytes_v[2] = { 0, 0 };   // the same, by kernel variant
+    double prof_stream_seconds = 0; int64_t prof_stream_launches = 0, prof_stream_bytes = 0, prof_stream_phases = 0;   // persistent stream launches (matvec_stream_kernel)
     double prof_chain_seconds = 0; int64_t prof_chain_launches = 0, prof_chain_bytes = 0, prof_chain_phases = 0;   // persistent chain launches (matvec_chain_kernel), stream events
     hipEvent_t chain_ev[2] = { nullptr, nullptr };
     // cached plans keyed by cgraph pointer
@@ -110,7 +111,7 @@ static void ctx_init_lazy(hip_ctx * c) {
 
 static void check_device_error(hip_ctx * c) {
     if (c->err_host && c->err_host[0] != 0u)
-        GGML_ABORT("mi355x backend: a kernel gave up a bounded wait (code %u: 1 = split attention head barrier, 2 = chain engine hand-off); results are invalid", c->err_host[0]);
+        GGML_ABORT("mi355x backend: a kernel gave up a bounded wait (code %u: 1 = split attention head barrier, 2 = chain engine hand-off, 3 = stream engine hand-off); results are invalid", c->err_host[0]);
 }
 
 // ---- pool -----------------------------------------------------------------------------------------
@@ -288,6 +289,7 @@ typedef std::function<void(hipStream_t)> step_fn;
 struct pstep {
     step_fn fn; bool is_mv = false; mv_args mv;
     chain_plan * chain = nullptr;   // a persistent chain launch (timed on its own in profile mode)
+    stream_plan * stream = nullptr; // a persistent stream launch (hip_stream.hip; likewise)
     template <typename F> pstep(F f) : fn(std::move(f)) { memset(&mv, 0, sizeof(mv)); }
     pstep(const mv_args & a) : fn([a](hipStream_t s) { k_matvec(s, a); }), is_mv(true), mv(a) {}
 };
@@ -295,6 +297,7 @@ struct pstep {
 struct plan_t {
     std::vector<pstep> steps;
     std::vector<chain_plan *> chains;
+    std::vector<stream_plan *> streams;
     std::vector<std::pair<void *, size_t>> workspaces;
     std::vector<std::unique_ptr<attn_args>> attn_copies;
     std::vector<const ggml_backend_buffer *> buffers;   // every buffer a node / leaf of the planned graph lives in: freeing one orphans the plan
@@ -302,7 +305,7 @@ struct plan_t {
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
     uint64_t hash = 0;
-    int n_nodes = 0, n_fused = 0, n_chained = 0;
+    int n_nodes = 0, n_fused = 0, n_chained = 0, n_streamed = 0;
 };
 
 static void plan_free(hip_ctx * c, plan_t * p) {
@@ -310,6 +313,7 @@ static void plan_free(hip_ctx * c, plan_t * p) {
     if (p->graph) (void) hipGraphDestroy(p->graph);
     for (auto & w : p->workspaces) pool_free(c, w.first, w.second);
     for (chain_plan * ch : p->chains) k_chain_free(ch);
+    for (stream_plan * sp : p->streams) k_stream_free(sp);
     delete p;
 }
 
@@ -1789,7 +1793,22 @@ static plan_t * build_plan(hip_ctx * c, ggml_cgraph * g) {
             size_t k = 0;
             while (k < run.size()) {
                 const int len = k_chain_accept(run.data() + k, (int) (run.size() - k));
-                if (len <= 0) { merged.push_back(std::move(p->steps[i + k])); k++; continue; }
+                if (len <= 0) {
+                    // not the chain engine's: a run of LARGE mat-vecs (a Temporal layer between two attention launches) goes to the stream engine
+                    const int slen = (c->flags & 64) || !((c->flags & 128) || k_stream_default_on()) ? 0 : k_stream_accept(run.data() + k, (int) (run.size() - k));
+                    if (slen > 0) {
+                        void * ws = em.ws(k_stream_ws_size(run.data() + k, slen));
+                        stream_plan * sp = k_stream_create(c->stream, run.data() + k, slen, ws, c->err_dev);
+                        p->streams.push_back(sp);
+                        merged.push_back(pstep([sp](hipStream_t s) { k_stream_launch(s, sp); }));
+                        merged.back().stream = sp;
+                        p->n_streamed += slen; c->stats.streamed_matvecs_planned += slen;
+                        if (dump) fprintf(stderr, "plan: %d consecutive mat-vecs -> one stream launch (%.1f MB of weights)\n", slen, (double) k_stream_weight_bytes(sp) / 1e6);
+                        k += (size_t) slen;
+                        continue;
+                    }
+                    merged.push_back(std::move(p->steps[i + k])); k++; continue;
+                }
                 void * ws = em.ws(k_chain_ws_size(run.data() + k, len));
                 chain_plan * ch = k_chain_create(c->stream, run.data() + k, len, ws, c->err_dev);
                 p->chains.push_back(ch);
@@ -1818,7 +1837,7 @@ static void run_steps_profiled(hip_ctx * c, plan_t * p) {
     c->prof.used = 0;
     k_matvec_set_profile(&c->prof);
     for (auto & st : p->steps) {
-        if (!st.chain) { st.fn(c->stream); continue; }
+        if (!st.chain && !st.stream) { st.fn(c->stream); continue; }
         // a persistent chain launch: one kernel, timed between two stream events
         if (!c->chain_ev[0]) { HIP_CHECK(hipEventCreate(&c->chain_ev[0])); HIP_CHECK(hipEventCreate(&c->chain_ev[1])); }
         HIP_CHECK(hipStreamSynchronize(c->stream));
@@ -1828,7 +1847,8 @@ static void run_steps_profiled(hip_ctx * c, plan_t * p) {
         HIP_CHECK(hipEventSynchronize(c->chain_ev[1]));
         float ms = 0;
         HIP_CHECK(hipEventElapsedTime(&ms, c->chain_ev[0], c->chain_ev[1]));
-        c->prof_chain_seconds += (double) ms * 1e-3; c->prof_chain_launches++; c->prof_chain_bytes += k_chain_weight_bytes(st.chain); c->prof_chain_phases += k_chain_length(st.chain);
+        if (st.chain) { c->prof_chain_seconds += (double) ms * 1e-3; c->prof_chain_launches++; c->prof_chain_bytes += k_chain_weight_bytes(st.chain); c->prof_chain_phases += k_chain_length(st.chain); }
+        else { c->prof_stream_seconds += (double) ms * 1e-3; c->prof_stream_launches++; c->prof_stream_bytes += k_stream_weight_bytes(st.stream); c->prof_stream_phases += k_stream_length(st.stream); }
     }
     k_matvec_set_profile(nullptr);
     HIP_CHECK(hipStreamSynchronize(c->stream));
@@ -2060,6 +2080,7 @@ extern "C" void ggml_backend_mi355x_get_kernel_profile(ggml_backend_t b, struct 
     hip_ctx * c = ctx_of(b);
     out->seconds = c->prof_seconds; out->launches = c->prof_launches; out->bytes = c->prof_bytes;
     for (int v = 0; v < 2; v++) { out->variant_seconds[v] = c->prof_seconds_v[v]; out->variant_launches[v] = c->prof_launches_v[v]; out->variant_bytes[v] = c->prof_bytes_v[v]; }
+    out->stream_seconds = c->prof_stream_seconds; out->stream_launches = c->prof_stream_launches; out->stream_bytes = c->prof_stream_bytes; out->stream_phases = c->prof_stream_phases;
     out->chain_seconds = c->prof_chain_seconds; out->chain_launches = c->prof_chain_launches; out->chain_bytes = c->prof_chain_bytes; out->chain_phases = c->prof_chain_phases;
 }
 extern "C" void * ggml_backend_mi355x_get_stream(ggml_backend_t b) { hip_ctx * c = ctx_of(b); ctx_init_lazy(c); return (void *) c->stream; }

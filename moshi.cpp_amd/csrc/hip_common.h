@@ -116,6 +116,17 @@ void   k_chain_launch(hipStream_t s, const chain_plan * c);
 void   k_chain_free(chain_plan * c);
 int    k_chain_length(const chain_plan * c);
 int64_t k_chain_weight_bytes(const chain_plan * c);
+// Persistent stream engine (hip_stream.hip): a run of consecutive LARGE Q4_K mat-vecs (the Temporal layer between two attention launches) executed by
+// ONE launch whose weight requests run through the phase boundaries. Same calling pattern as the chain engine.
+struct stream_plan;
+bool   k_stream_default_on();                        // MI355X_STREAM
+int    k_stream_accept(const mv_args * mv, int n);
+size_t k_stream_ws_size(const mv_args * mv, int n);
+stream_plan * k_stream_create(hipStream_t s, const mv_args * mv, int n, void * ws, unsigned * err);
+void   k_stream_launch(hipStream_t s, const stream_plan * c);
+void   k_stream_free(stream_plan * c);
+int    k_stream_length(const stream_plan * c);
+int64_t k_stream_weight_bytes(const stream_plan * c);
 bool k_matvec_supported(int wtype, int64_t K, int64_t M);
 bool k_matvec_pair_ok(int wtype, int64_t K, int64_t F);
 // optional per-launch timing of the dominant kernel (matvec_q4k_kernel) with HIP start/stop events that are
