@@ -1,19 +1,25 @@
-// hip_stream.hip — the persistent stream engine: the run of LARGE Q4_K mat-vecs between two attention launches of the Temporal transformer
-// (/root/reference/src/moshi/modules/transformer.h:300-420, StreamingTransformerLayer: out_proj + residual -> norm2 + gated linear_in ->
-// linear_out + residual -> next layer's norm1 + in_proj; 116 MB of weights per layer at 4096 / 11264) executed by ONE launch.
+// hip_stream.hip — the persistent stream engine (EXPERIMENT, off by default: MI355X_STREAM=1 or backend flag 128 switch it on): the run of LARGE
+// Q4_K mat-vecs between two attention launches of the Temporal transformer (/root/reference/src/moshi/modules/transformer.h:300-420,
+// StreamingTransformerLayer: out_proj + residual -> norm2 + gated linear_in -> linear_out + residual -> next layer's norm1 + in_proj; 116 MB of
+// weights per layer at 4096 / 11264) executed by ONE launch.
 //
-// Why: as four launches a layer's mat-vecs take 5.6 + 14 + 9.7 + 10 us in the kernel (1.7 - 3.7 TB/s, profiles/r03_bench_kernel_trace_summary.txt)
-// plus four boundaries of 1.5 - 2.3 us: every launch ramps its HBM stream up from nothing and drains it before the next one may start, although
-// the NEXT matrix's bytes never depended on anything. Here 256 workgroups of 8 waves stay resident across the run and every wave keeps a RING of
-// eight passes (8 x 1 152 B per wave, 72 KB per CU) of weight requests in flight that runs straight THROUGH the phase boundaries: while a phase's
-// rows are summed, published and the next activation vector is gathered, normed and quantised, the next matrix is already on its way.
-//   * work unit = super-block (144 B), 8 lanes per super-block, a pass = 8 super-blocks per wave (the WS = 1 arithmetic of matvec_q4k_kernel);
-//     workgroup g owns rows [g M / 256, (g + 1) M / 256) of every matrix (paired gate: the same rows of both halves), its super-blocks are dealt to
-//     the waves pass by pass; the ring is two halves of four passes, refilled slot by slot right after a slot is consumed;
-//   * hand-offs are the chain engine's (hip_chain.hip): every output float is published as one 8-byte {tag, value} granule by an agent-scope store,
-//     consumers poll the granules they need until the tags are this launch's and this phase's - no grid barrier, no fence, no counter;
-//   * arithmetic is the unchained kernels' to the bit (Q8_K rounding, per-super-block float expression, 16-lane strided row sums, the RMS norm's
-//     summation order), so tests/test_stream_engine.py compares the two plans bit for bit.
+// Idea: as four launches a layer's mat-vecs ramp their HBM stream up from nothing and drain it four times, although the NEXT matrix's bytes never
+// depended on anything. Here 256 workgroups stay resident across the run:
+//   * 8 STREAMER waves per workgroup each keep a ring of eight passes (a pass = 8 super-blocks of 144 B, 8 lanes per super-block - the WS = 1
+//     arithmetic of matvec_q4k_kernel) of weight requests in flight that runs straight THROUGH the phase boundaries. Wave w owns rows
+//     [w rows / 8, (w + 1) rows / 8) of the workgroup's rows of every matrix, so row sums, epilogue and publication need no workgroup barrier;
+//   * 4 GATHERER waves per workgroup have nothing but hand-off polls in their vector-memory queue: they sweep the previous phase's output (the chain
+//     engine's 8-byte {tag, value} granules, hip_chain.hip), run the RMS norm in matvec_q4k_kernel's summation order, quantise to Q8_K into LDS and
+//     release the streamers through an LDS counter. No workgroup barrier after the table copy, no grid barrier, no fence;
+//   * arithmetic is the unchained kernels' to the bit: tests/test_stream_engine.py compares the two plans bit for bit.
+//
+// Measured (profiles/r03_stream_engine_stamps.txt): inside a phase the ring streams at 5.6 - 6 TB/s, but a phase boundary costs 5 - 9 us - wave skew
+// inside the workgroup (1 - 3.5 us: 5 vs 6 row pairs per wave in linear_in), one sweep of the granules (2 us per 6 blocks: with ~72 KB per CU of
+// weight requests queued in the fabric a poll's round trip IS the ring's depth, whichever wave issues it), norm + quantisation (1.7 - 2.6 us on
+// four waves) - against ~2 us of kernel boundary plus ~3.5 us of ramp for a separate launch. Net: Temporal 2 050 us per frame with the engine, 1 600 us
+// without. The lesson matches the chain engine's: an all-to-all hand-off between 256 workgroups under full HBM load is not cheaper than a kernel
+// boundary on this chip; a deeper ring buys throughput and pays it back in poll latency. Kept for the measurement and as the base of an LDS-staged
+// variant (requests paced to ~32 KB per CU in flight, landed tiles parked in LDS across the boundary).
 #include "hip_common.h"
 #include "hip_device.h"
 #include "hip_mv_device.h"
@@ -25,22 +31,27 @@
 
 typedef unsigned long long u64;
 
-#define ST_NW        8
-#define ST_THREADS   (ST_NW * 64)
+#define ST_NW        8                    // streamer waves: weights -> dots -> rows -> publication
+#define ST_NG        4                    // gatherer waves: hand-off polls -> norm -> Q8_K blocks
+#define ST_THREADS   ((ST_NW + ST_NG) * 64)
 #define ST_GRID      256
 #define ST_NB_MAX    44                   // K <= 11264
 #define ST_K_MAX     (ST_NB_MAX * 256)
-#define ST_SB_MAX    1408                 // super-blocks per workgroup and phase (linear_in: 2 x 44 rows x 16)
-#define ST_ROWS_MAX  96                   // rows per workgroup and phase (both halves of a paired phase)
+#define ST_PASS_MAX  24                   // passes per wave and phase (linear_in: 6 row pairs x 16 super-blocks x 2 / 8)
+#define ST_SBW       (ST_PASS_MAX * 8)    // super-blocks per wave and phase
+#define ST_RW_MAX    12                   // rows per wave and phase (one half of a paired phase)
 #define ST_PH_MAX    8                    // phases per launch
-#define ST_RND_MAX   64                   // rounds (4 passes per wave) per launch
+#ifndef ST_RH
+#define ST_RH        4                    // passes per half of the ring (a round)
+#endif
+#define ST_RND_MAX   128                  // rounds per launch
 #define ST_SPIN_MAX  (1u << 22)
 
 struct st_phase {
     const char * w; long long row_bytes;
     const float * x; const float * alpha; const float * residual; float * y;
     long long pair_F;            // > 0: paired gate - rows [0, F) and [F, 2 F) of W, y receives silu(l) * r (F values)
-    int K, nb, rows, nsb;        // rows: per workgroup (paired: per half); nsb: super-blocks per workgroup (both halves)
+    int K, nb, rows, rows_prev;  // rows: per workgroup (paired: per half); rows_prev: rows per workgroup of the phase whose output is x (sentinels)
     int prologue, x_chain, res, res_src;   // res: 0 none, 1 rows kept in LDS by phase res_src, 2 memory
     int n_pub, n_pass; float eps, inv_nb;
     int pad_[6];
@@ -51,11 +62,12 @@ struct st_params {
     const st_phase * phases; const int2 * rounds;   // rounds[r] = (phase, first pass of the round inside the phase)
     int n_phases, n_rounds;
     u64 * gbuf;                 // [2][ST_K_MAX] granules
+    u64 * flags;                // [2][ST_GRID] one granule per workgroup and phase parity: "this workgroup has published its rows" (a hint: the data granules carry the proof)
     unsigned * launch_seq;
     unsigned * err;
 };
 
-struct st_ctl { unsigned failed; unsigned pad[3]; double sumsq[ST_NW]; };
+struct st_ctl { unsigned failed; unsigned blocks_ready; unsigned norm_count; unsigned pub_count; unsigned go; unsigned pad[3]; double sumsq[ST_NW]; };
 
 #define GLOBAL_AS __attribute__((address_space(1)))
 template <typename T> __device__ __forceinline__ GLOBAL_AS T * gp(T * p) { return (GLOBAL_AS T *) p; }
@@ -71,8 +83,9 @@ template <typename T> __device__ __forceinline__ T st_uniform(T v) {
 }
 
 #if defined(ST_LOG)
-__device__ u64 g_st_log[2][64][8];   // [0] workgroup 0, [1] last workgroup; wave 0: per phase: 0 prologue start, 1 x ready, 2 blocks ready, 3 dots done, 4 epilogue done
-#define ST_STAMP(i) do { if (wave == 0 && lane == 0 && (wg == 0 || wg == (int) gridDim.x - 1) && p < 64) { u64 t_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); \
+// [0] workgroup 0, [1] last workgroup; per phase: streamer wave 0: 0 phase start, 1 blocks ready, 2 dots done, 3 published; gatherer 0: 4 start, 5 sentinels, 6 gathered, 7 blocks written
+__device__ u64 g_st_log[2][64][8];
+#define ST_STAMP(i) do { if (lane == 0 && (wave == 0 || wave == ST_NW) && (wg == 0 || wg == (int) gridDim.x - 1) && p < 64) { u64 t_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); \
     g_st_log[wg ? 1 : 0][p][i] = t_; } } while (0)
 extern "C" __attribute__((visibility("default"))) void mi355x_stream_log_read(unsigned long long * dst) { (void) hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_st_log), sizeof(g_st_log)); }
 #else
@@ -85,27 +98,154 @@ __global__ void __launch_bounds__(ST_THREADS) matvec_stream_kernel(st_params P) 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wg = blockIdx.x;
     xblk * xs = (xblk *) smem;                                  // [2][ST_NB_MAX] Q8_K blocks of the current / next activation vector
-    float * part = (float *) (xs + 2 * ST_NB_MAX);              // [ST_SB_MAX] super-block partial sums of the current phase
-    float * ysave = part + ST_SB_MAX;                           // [ST_PH_MAX][ST_ROWS_MAX] this workgroup's output rows, per phase (residuals of later phases)
-    st_ctl * ctl = (st_ctl *) (ysave + ST_PH_MAX * ST_ROWS_MAX);
+    float * part = (float *) (xs + 2 * ST_NB_MAX);              // [ST_NW][ST_SBW] super-block partial sums, private to the streamer wave that owns the rows
+    float * ysave = part + ST_NW * ST_SBW;                      // [ST_PH_MAX][ST_NW][ST_RW_MAX] a wave's output rows, per phase (residuals of later phases)
+    st_ctl * ctl = (st_ctl *) (ysave + ST_PH_MAX * ST_NW * ST_RW_MAX);
     st_phase * phl = (st_phase *) (ctl + 1);                    // the descriptors
-    int2 * rnd = (int2 *) (phl + ST_PH_MAX);                    // [n_rounds + 2]: (phase, first pass)
+    int2 * rnd = (int2 *) (phl + ST_PH_MAX);                    // [n_rounds]: (phase, first pass)
 
     {   // tables -> LDS
         const int n16 = P.n_phases * (int) (sizeof(st_phase) / 16);
         for (int i = tid; i < n16; i += ST_THREADS) ((u32x4 *) phl)[i] = ((const GLOBAL_AS u32x4 *) P.phases)[i];
         for (int i = tid; i < P.n_rounds; i += ST_THREADS) ((u64 *) rnd)[i] = ((const GLOBAL_AS u64 *) P.rounds)[i];
-        if (tid == 0) ctl->failed = 0;
+        if (tid == 0) { ctl->failed = 0; ctl->blocks_ready = 0; ctl->norm_count = 0; ctl->pub_count = 0; ctl->go = 0; }
     }
-    __syncthreads();
+    __syncthreads();   // the only workgroup-wide barrier: from here on streamers and gatherers meet through LDS counters
     const unsigned launch = *gp(P.launch_seq);
     const unsigned tag_base = launch << 12;
-    const __amdgpu_buffer_rsrc_t gb = st_rsrc(P.gbuf, 2u * ST_K_MAX * 8u);
     auto give_up = [&]() { if (lane == 0) { __hip_atomic_store(&ctl->failed, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); *gp(P.err) = 3u; } };
-    auto barrier_ok = [&]() { lds_barrier(); return st_lds_load(&ctl->failed) == 0u; };
 
+    if (wave >= ST_NW) {
+        // ================================================= gatherers =========================================================================
+        // Their vector-memory queue holds nothing but hand-off polls, so a poll returns in one fabric round trip (a streamer's would return behind its
+        // sixteen outstanding weight requests: ~ the ring's depth, 3.5 us). Gatherer g takes blocks g, g + 4, ...: polls their granules, runs the norm in
+        // matvec_q4k_kernel's summation order (virtual wave w = blocks w, w + 8: gatherer g holds virtual waves g and g + 4 whole), quantises to Q8_K.
+        const int gw = wave - ST_NW;
+        const __amdgpu_buffer_rsrc_t gb = st_rsrc(P.gbuf, 2u * ST_K_MAX * 8u);
+        unsigned norm_epoch = 0;
+        for (int p = 0; p < P.n_phases; p++) {
+            const st_phase * d = phl + p;
+            const int nb = st_uniform(d->nb), K = st_uniform(d->K);
+            const int prologue = st_uniform(d->prologue), x_chain = st_uniform(d->x_chain);
+            const unsigned tag_in = tag_base | (unsigned) p;
+            const unsigned in_base = (unsigned) ((p - 1) & 1) * (ST_K_MAX * 8u);
+            xblk * xcur = xs + (p & 1) * ST_NB_MAX;
+            const float * xp = st_uniform(d->x); const float * ap = st_uniform(d->alpha);
+            ST_STAMP(4);
+            if (x_chain) {
+                // ... and wait (LDS) until this workgroup's own streamers have published the previous phase: the workgroups run in step, so that is when
+                // the others' rows start to appear - sweeping the data granules any earlier only loads the fabric for the whole length of the dot phase
+                unsigned spins = 0;
+                while (st_lds_load(&ctl->pub_count) < (unsigned) (ST_NW * p)) {
+                    if (++spins > ST_SPIN_MAX || st_lds_load(&ctl->failed)) { give_up(); break; }
+                    __builtin_amdgcn_s_sleep(2);
+                }
+            }
+            ST_STAMP(5);
+            auto chunk = [&](auto xb_tag, int i0) {   // blocks gw + 4 (i0 + i), i < XB
+                constexpr int XB = decltype(xb_tag)::value;
+                float v[XB][4];
+                f32x4 al[XB];
+#pragma unroll
+                for (int i = 0; i < XB; i++) {
+                    const int b = gw + ST_NG * (i0 + i), bc = b < nb ? b : nb - 1;
+                    al[i] = (f32x4) { 1.f, 1.f, 1.f, 1.f };
+                    if (prologue == MV_RMSNORM) al[i] = *(const GLOBAL_AS f32x4 *) (gp(ap) + bc * 256 + lane * 4);
+                }
+                if (x_chain) {
+                    u32x4 g[XB][2];
+                    unsigned spins = 0;
+                    for (;;) {
+#pragma unroll
+                        for (int i = 0; i < XB; i++) {
+                            const int b = gw + ST_NG * (i0 + i), bc = b < nb ? b : nb - 1;
+                            const unsigned o = in_base + ((unsigned) bc * 256u + (unsigned) lane * 4u) * 8u;
+                            g[i][0] = st_ld16_agent(gb, o); g[i][1] = st_ld16_agent(gb, o + 16u);
+                        }
+                        bool ok = true;
+#pragma unroll
+                        for (int i = 0; i < XB; i++) ok = ok && g[i][0].y == tag_in && g[i][0].w == tag_in && g[i][1].y == tag_in && g[i][1].w == tag_in;
+                        if (__all(ok)) break;
+                        if (++spins > ST_SPIN_MAX || st_lds_load(&ctl->failed)) { give_up(); break; }
+                        __builtin_amdgcn_s_sleep(1);
+                    }
+#pragma unroll
+                    for (int i = 0; i < XB; i++) {
+                        v[i][0] = __uint_as_float(g[i][0].x); v[i][1] = __uint_as_float(g[i][0].z); v[i][2] = __uint_as_float(g[i][1].x); v[i][3] = __uint_as_float(g[i][1].z);
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < XB; i++) {
+                        const int b = gw + ST_NG * (i0 + i), bc = b < nb ? b : nb - 1;
+                        const f32x4 t = *(const GLOBAL_AS f32x4 *) (gp(xp) + bc * 256 + lane * 4);
+                        v[i][0] = t.x; v[i][1] = t.y; v[i][2] = t.z; v[i][3] = t.w;
+                    }
+                }
+                ST_STAMP(6);
+                if (XB == 4 && prologue == MV_RMSNORM) {
+                    // matvec_q4k_kernel's order: thread (w, lane) adds the squares of its values of block w, then of block w + 8, in double; wave butterfly;
+                    // the eight waves' sums are added in index order. (K <= 4096: blocks i = 0 .. 3 of this gatherer are w = gw: {0, 2}, w = gw + 4: {1, 3}.)
+#pragma unroll
+                    for (int h = 0; h < 2; h++) {
+                        double acc = 0;
+#pragma unroll
+                        for (int jj = 0; jj < 2; jj++) {
+                            const int i = h + 2 * jj;
+                            if (gw + ST_NG * i < nb)
+#pragma unroll
+                                for (int k = 0; k < 4; k++) acc += (double) (v[i][k] * v[i][k]);
+                        }
+                        acc = wave_allsum_f64(acc);
+                        if (lane == 0) ctl->sumsq[gw + ST_NG * h] = acc;
+                    }
+                    norm_epoch++;
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                    if (lane == 0) __hip_atomic_fetch_add(&ctl->norm_count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    unsigned spins = 0;
+                    while (st_lds_load(&ctl->norm_count) < ST_NG * norm_epoch) {
+                        if (++spins > ST_SPIN_MAX || st_lds_load(&ctl->failed)) { give_up(); break; }
+                        __builtin_amdgcn_s_sleep(1);
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                    double tot = 0;
+#pragma unroll
+                    for (int w = 0; w < ST_NW; w++) tot += ctl->sumsq[w];
+                    const float mean = (float) (tot / (double) K);
+                    const float scale = 1.0f / sqrtf(mean + st_uniform(d->eps));
+#pragma unroll
+                    for (int i = 0; i < XB; i++) {
+                        const float a4[4] = { al[i].x, al[i].y, al[i].z, al[i].w };
+#pragma unroll
+                        for (int k = 0; k < 4; k++) v[i][k] = a4[k] * (v[i][k] * scale);
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < XB; i++) {
+                    const int b = gw + ST_NG * (i0 + i);
+                    if (b < nb) quantize_block_q8k(xcur + b, v[i], lane);
+                }
+            };
+            if (nb <= 4 * ST_NG) chunk(std::integral_constant<int, 4>(), 0);
+            else for (int i0 = 0; gw + ST_NG * i0 < nb; i0 += 6) chunk(std::integral_constant<int, 6>(), i0);
+            ST_STAMP(7);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            if (lane == 0) __hip_atomic_fetch_add(&ctl->blocks_ready, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (st_lds_load(&ctl->failed)) return;
+        }
+        return;
+    }
+
+    // ===================================================== streamers ===========================================================================
     // ---- the ring: slot s holds the header (d, dmin, 6-bit scales) and this lane's 16-byte nibble chunk of one super-block
-    u32x4 wh[8], wq[8];
+    u32x4 wh[2 * ST_RH], wq[2 * ST_RH];
+    // Wave w owns rows [w rows / 8, (w + 1) rows / 8) of the workgroup's rows (paired: of both halves): every super-block of a row is its own, so the
+    // row sums need no workgroup barrier. Its super-blocks, half by half and row by row, are dealt eight to a pass.
+    struct wave_rows { int r_lo, nrow, nseg, nsb; };
+    auto rows_of = [&](int rows, int nb, bool paired) {
+        wave_rows r;
+        r.r_lo = (wave * rows) >> 3; r.nrow = (((wave + 1) * rows) >> 3) - r.r_lo; r.nseg = r.nrow * nb; r.nsb = paired ? 2 * r.nseg : r.nseg;
+        return r;
+    };
     // request pass (round R, slot i of the round) into ring slot H * 4 + i. Beyond the last round every lane asks for the same 16 bytes (one request, unused).
     auto request_round = [&](int R, auto half_tag) {
         constexpr int H = decltype(half_tag)::value;
@@ -115,23 +255,23 @@ __global__ void __launch_bounds__(ST_THREADS) matvec_stream_kernel(st_params P) 
         const st_phase * d = phl + q;
         const char * w = st_uniform(d->w);
         const long long row_bytes = st_uniform(d->row_bytes), pair_F = st_uniform(d->pair_F);
-        const int nb = st_uniform(d->nb), rows = st_uniform(d->rows), nsb = st_uniform(d->nsb);
+        const int nb = st_uniform(d->nb), rows = st_uniform(d->rows);
         const float inv_nb = st_uniform(d->inv_nb);
-        const long long row0 = (long long) wg * rows;
-        const int nseg = rows * nb;
+        const wave_rows wr = rows_of(rows, nb, pair_F > 0);
+        const long long row0 = (long long) wg * rows + wr.r_lo;
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const int sb = ((j0 + i) * ST_NW + wave) * 8 + (lane >> 3);
-            const bool use = real && sb < nsb;
-            const int sbc = sb < nsb ? sb : nsb - 1;
-            const int up = sbc >= nseg ? 1 : 0;                      // second half of a paired phase
-            const int sl = sbc - up * nseg;
+        for (int i = 0; i < ST_RH; i++) {
+            const int sb = (j0 + i) * 8 + (lane >> 3);
+            const bool use = real && sb < wr.nsb;
+            const int sbc = sb < wr.nsb ? sb : wr.nsb - 1;
+            const int up = sbc >= wr.nseg ? 1 : 0;                   // second half of a paired phase
+            const int sl = sbc - up * wr.nseg;
             const int r = (int) (((float) sl + 0.5f) * inv_nb), b = sl - r * nb;
             const GLOBAL_AS u32x4 * src = (const GLOBAL_AS u32x4 *) (gp(w) + (row0 + r + (up ? pair_F : 0ll)) * row_bytes) + b * 9;
             const GLOBAL_AS u32x4 * hsrc = use ? src : (const GLOBAL_AS u32x4 *) gp(w);
             const GLOBAL_AS u32x4 * qsrc = use ? src + 1 + (lane & 7) : (const GLOBAL_AS u32x4 *) gp(w);
-            wh[H * 4 + i] = __builtin_nontemporal_load(hsrc);
-            wq[H * 4 + i] = __builtin_nontemporal_load(qsrc);
+            wh[H * ST_RH + i] = __builtin_nontemporal_load(hsrc);
+            wq[H * ST_RH + i] = __builtin_nontemporal_load(qsrc);
         }
     };
     typedef std::integral_constant<int, 0> half0;
@@ -140,118 +280,52 @@ __global__ void __launch_bounds__(ST_THREADS) matvec_stream_kernel(st_params P) 
     request_round(0, half0());
     request_round(1, half1());
 
+    float * wpart = part + wave * ST_SBW;
     int R = 0;   // rounds consumed so far (whole launch)
-    bool alive = true;
-    for (int p = 0; p < P.n_phases && alive; p++) {
+    for (int p = 0; p < P.n_phases; p++) {
         const st_phase * d = phl + p;
-        const int nb = st_uniform(d->nb), K = st_uniform(d->K), rows = st_uniform(d->rows), nsb = st_uniform(d->nsb);
+        const int nb = st_uniform(d->nb), rows = st_uniform(d->rows);
         const long long pair_F = st_uniform(d->pair_F);
         const bool paired = pair_F > 0;
-        const int prologue = st_uniform(d->prologue), x_chain = st_uniform(d->x_chain);
-        const unsigned tag_in = tag_base | (unsigned) p, tag_out = tag_base | (unsigned) (p + 1);
-        xblk * xcur = xs + (p & 1) * ST_NB_MAX;
+        const unsigned tag_out = tag_base | (unsigned) (p + 1);
+        const xblk * xcur = xs + (p & 1) * ST_NB_MAX;
         const int res = st_uniform(d->res), n_pub = st_uniform(d->n_pub);
         float * y = st_uniform(d->y);
-        const long long row0 = (long long) wg * rows;
+        const wave_rows wr = rows_of(rows, nb, paired);
+        const long long row0 = (long long) wg * rows + wr.r_lo;
+        const float inv_nb = st_uniform(d->inv_nb);
         ST_STAMP(0);
-        // a residual that comes from memory is asked for now (its round trip used to sit, exposed, at the very end of the phase)
+        // a residual that comes from memory is asked for now (its round trip used to sit, exposed, at the very end of the phase): lane group g of
+        // sweep k adds it to row 4 k + g
         float res_pre[3];
         {
             const float * rp = res == 2 ? st_uniform(d->residual) : (const float *) y;   // (no branch around a load) y is valid memory of the same extent
 #pragma unroll
             for (int k = 0; k < 3; k++) {
-                const int rr = (tid >> 4) + k * (ST_NW * 4);
-                res_pre[k] = gp(rp)[row0 + (rr < rows ? rr : 0)];
+                const int rr = (lane >> 4) + 4 * k;
+                res_pre[k] = gp(rp)[row0 + (rr < wr.nrow ? rr : 0)];
             }
         }
-
-        // ---- prologue: the activation vector -> Q8_K blocks. Wave w takes blocks w, w + 8, ... (matvec_q4k_kernel's assignment: the norm's sums match).
-        auto gather = [&](auto xj_tag) -> bool {
-            constexpr int XJ = decltype(xj_tag)::value;
-            float v[XJ][4];
-            f32x4 al[XJ];
-            const float * xp = st_uniform(d->x); const float * ap = st_uniform(d->alpha);
-#pragma unroll
-            for (int j = 0; j < XJ; j++) {
-                const int b = j * ST_NW + wave, bc = b < nb ? b : nb - 1;
-                al[j] = (f32x4) { 1.f, 1.f, 1.f, 1.f };
-                if (prologue == MV_RMSNORM) al[j] = *(const GLOBAL_AS f32x4 *) (gp(ap) + bc * 256 + lane * 4);
+        // ---- wait for this phase's Q8_K blocks (the gatherers write them)
+        {
+            unsigned spins = 0;
+            while (st_lds_load(&ctl->blocks_ready) < (unsigned) (ST_NG * (p + 1))) {
+                if (++spins > ST_SPIN_MAX || st_lds_load(&ctl->failed)) { give_up(); break; }
+                __builtin_amdgcn_s_sleep(1);
             }
-            if (x_chain) {
-                const unsigned in_base = (unsigned) ((p - 1) & 1) * (ST_K_MAX * 8u);
-                u32x4 g[XJ][2];
-                unsigned spins = 0;
-                for (;;) {
-#pragma unroll
-                    for (int j = 0; j < XJ; j++) {
-                        const int b = j * ST_NW + wave, bc = b < nb ? b : nb - 1;
-                        const unsigned o = in_base + ((unsigned) bc * 256u + (unsigned) lane * 4u) * 8u;
-                        g[j][0] = st_ld16_agent(gb, o); g[j][1] = st_ld16_agent(gb, o + 16u);
-                    }
-                    bool ok = true;
-#pragma unroll
-                    for (int j = 0; j < XJ; j++) ok = ok && g[j][0].y == tag_in && g[j][0].w == tag_in && g[j][1].y == tag_in && g[j][1].w == tag_in;
-                    if (__all(ok)) break;
-                    if (++spins > ST_SPIN_MAX || st_lds_load(&ctl->failed)) { give_up(); break; }
-                    __builtin_amdgcn_s_sleep(1);
-                }
-#pragma unroll
-                for (int j = 0; j < XJ; j++) {
-                    v[j][0] = __uint_as_float(g[j][0].x); v[j][1] = __uint_as_float(g[j][0].z); v[j][2] = __uint_as_float(g[j][1].x); v[j][3] = __uint_as_float(g[j][1].z);
-                }
-            } else {
-#pragma unroll
-                for (int j = 0; j < XJ; j++) {
-                    const int b = j * ST_NW + wave, bc = b < nb ? b : nb - 1;
-                    const f32x4 t = *(const GLOBAL_AS f32x4 *) (gp(xp) + bc * 256 + lane * 4);
-                    v[j][0] = t.x; v[j][1] = t.y; v[j][2] = t.z; v[j][3] = t.w;
-                }
-            }
-            ST_STAMP(1);
-            if (prologue == MV_RMSNORM) {
-                // matvec_q4k_kernel's order: per-thread squares in double (blocks ascending), wave butterfly, waves added in index order
-                double acc = 0;
-#pragma unroll
-                for (int j = 0; j < XJ; j++)
-                    if (j * ST_NW + wave < nb)
-#pragma unroll
-                        for (int k = 0; k < 4; k++) acc += (double) (v[j][k] * v[j][k]);
-                acc = wave_allsum_f64(acc);
-                if (lane == 0) ctl->sumsq[wave] = acc;
-                if (!barrier_ok()) return false;
-                double tot = 0;
-#pragma unroll
-                for (int w = 0; w < ST_NW; w++) tot += ctl->sumsq[w];
-                const float mean = (float) (tot / (double) K);
-                const float scale = 1.0f / sqrtf(mean + st_uniform(d->eps));
-#pragma unroll
-                for (int j = 0; j < XJ; j++) {
-                    const float a4[4] = { al[j].x, al[j].y, al[j].z, al[j].w };
-#pragma unroll
-                    for (int k = 0; k < 4; k++) v[j][k] = a4[k] * (v[j][k] * scale);
-                }
-            }
-#pragma unroll
-            for (int j = 0; j < XJ; j++) {
-                const int b = j * ST_NW + wave;
-                if (b < nb) quantize_block_q8k(xcur + b, v[j], lane);
-            }
-            return true;
-        };
-        if (nb <= 2 * ST_NW) { if (!gather(std::integral_constant<int, 2>())) return; }
-        else                 { if (!gather(std::integral_constant<int, 6>())) return; }
-        if (!barrier_ok()) return;
-        ST_STAMP(2);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            if (st_lds_load(&ctl->failed)) return;
+        }
+        ST_STAMP(1);
 
         // ---- the dots: rounds of four passes out of one half of the ring; a slot is asked for again (two rounds ahead) as soon as it has been used
-        const int n_rounds_p = st_uniform(d->n_pass) >> 2;
+        const int n_rounds_p = st_uniform(d->n_pass) / ST_RH;
         auto consume = [&](const u32x4 whs, const u32x4 wqs, int pass) {
-            const int sb = (pass * ST_NW + wave) * 8 + (lane >> 3);
-            if (pass * (ST_NW * 8) >= nsb) return;   // (uniform) a padding pass
-            const int sbc = sb < nsb ? sb : nsb - 1;
-            const int nseg = rows * nb;
-            const int sl = sbc >= nseg ? sbc - nseg : sbc;
-            const int r = (int) (((float) sl + 0.5f) * st_uniform(d->inv_nb)), b = sl - r * nb;
+            if (pass * 8 >= wr.nsb) return;   // (uniform) a padding pass
+            const int sb = pass * 8 + (lane >> 3);
+            const int sbc = sb < wr.nsb ? sb : wr.nsb - 1;
+            const int sl = sbc >= wr.nseg ? sbc - wr.nseg : sbc;
+            const int r = (int) (((float) sl + 0.5f) * inv_nb), b = sl - r * nb;
             const int j8 = lane & 7, g32 = j8 >> 1, hf = j8 & 1;
             const xblk * xb = xcur + b;
             const uint32_t hw[4] = { whs.x, whs.y, whs.z, whs.w };
@@ -274,15 +348,15 @@ __global__ void __launch_bounds__(ST_THREADS) matvec_stream_kernel(st_params P) 
             isum += dpp_i32<DPP_QUAD_XOR1>(isum); msum += dpp_i32<DPP_QUAD_XOR1>(msum);
             isum += dpp_i32<DPP_QUAD_XOR2>(isum); msum += dpp_i32<DPP_QUAD_XOR2>(msum);
             isum += dpp_i32<DPP_HALF_MIRROR>(isum); msum += dpp_i32<DPP_HALF_MIRROR>(msum);
-            if (j8 == 0 && sb < nsb) {
+            if (j8 == 0 && sb < wr.nsb) {
                 const float dd = h2f((uint16_t) (hw[0] & 0xffff)) * xb->d, dmin = h2f((uint16_t) (hw[0] >> 16)) * xb->d;
-                part[sb] = dd * (float) isum - dmin * (float) msum;
+                wpart[sb] = dd * (float) isum - dmin * (float) msum;
             }
         };
         auto round = [&](int r, auto half_tag) {
             constexpr int H = decltype(half_tag)::value;
 #pragma unroll
-            for (int i = 0; i < 4; i++) consume(wh[H * 4 + i], wq[H * 4 + i], r * 4 + i);
+            for (int i = 0; i < ST_RH; i++) consume(wh[H * ST_RH + i], wq[H * ST_RH + i], r * ST_RH + i);
             request_round(R + 2, half_tag);
             R++;
         };
@@ -296,41 +370,42 @@ __global__ void __launch_bounds__(ST_THREADS) matvec_stream_kernel(st_params P) 
                 if (r < n_rounds_p) round(r, half0());
             }
         }
-        ST_STAMP(3);
-        if (!barrier_ok()) return;
+        ST_STAMP(2);
+        // the wave's own partial sums: LDS operations of one wave execute in order; the fence only keeps the compiler from moving them
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
-        // ---- fixed-order row sums (16 lanes per row, strided partials, butterfly), epilogue, publication
+        // ---- fixed-order row sums (16 lanes per row, strided partials, butterfly - matvec_q4k_kernel's), epilogue, publication
         u64 * pub = P.gbuf + (size_t) (p & 1) * ST_K_MAX;
-        if (paired) {
-            for (int rr = tid >> 4; rr < rows; rr += ST_NW * 4) {
-                float sl = 0.f, sr = 0.f;
-                for (int j = tid & 15; j < nb; j += 16) { sl += part[rr * nb + j]; sr += part[(rows + rr) * nb + j]; }
-                sl = row16_allsum_f32(sl); sr = row16_allsum_f32(sr);
-                if ((tid & 15) == 0) {
-                    const float g = (sl / (1.0f + expf(-sl))) * sr;
-                    if (n_pub) st_publish(pub + row0 + rr, tag_out, __float_as_uint(g));
-                    gp(y)[row0 + rr] = g;
+        float * ysv = ysave + (p * ST_NW + wave) * ST_RW_MAX;
+        const float * ysrc = ysave + (st_uniform(d->res_src) * ST_NW + wave) * ST_RW_MAX;
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const int rr = (lane >> 4) + 4 * k;
+            if (4 * k >= wr.nrow) break;   // (uniform)
+            const int rc = rr < wr.nrow ? rr : wr.nrow - 1;
+            float sl = 0.f, sr = 0.f;
+            for (int j = lane & 15; j < nb; j += 16) { sl += wpart[rc * nb + j]; if (paired) sr += wpart[wr.nseg + rc * nb + j]; }
+            sl = row16_allsum_f32(sl);
+            if (paired) sr = row16_allsum_f32(sr);
+            if ((lane & 15) == 0 && rr < wr.nrow) {
+                const long long row = row0 + rr;
+                float out;
+                if (paired) out = (sl / (1.0f + expf(-sl))) * sr;
+                else {
+                    out = sl;
+                    if (res == 1) out = ysrc[rr] + out;
+                    else if (res == 2) out = res_pre[k] + out;
+                    ysv[rr] = out;
                 }
-            }
-        } else {
-            const float * ys = ysave + st_uniform(d->res_src) * ST_ROWS_MAX;
-            int kq = 0;
-            for (int rr = tid >> 4; rr < rows; rr += ST_NW * 4, kq++) {
-                float sum = 0.f;
-                for (int j = tid & 15; j < nb; j += 16) sum += part[rr * nb + j];
-                sum = row16_allsum_f32(sum);
-                if ((tid & 15) == 0) {
-                    const long long row = row0 + rr;
-                    if (res == 1) sum = ys[rr] + sum;
-                    else if (res == 2) sum = (kq == 0 ? res_pre[0] : kq == 1 ? res_pre[1] : res_pre[2]) + sum;
-                    ysave[p * ST_ROWS_MAX + rr] = sum;
-                    if (n_pub) st_publish(pub + row, tag_out, __float_as_uint(sum));
-                    gp(y)[row] = sum;
-                }
+                if (n_pub) st_publish(pub + row, tag_out, __float_as_uint(out));
+                gp(y)[row] = out;
             }
         }
-        ST_STAMP(4);
-        // (part and ysave are next written behind the next phase's "blocks ready" barrier)
+        // (the gatherers start sweeping the next phase's granules when their own workgroup's streamers are through)
+        if (lane == 0) __hip_atomic_fetch_add(&ctl->pub_count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        ST_STAMP(3);
     }
     if (wg == 0 && tid == 0) *gp(P.launch_seq) = launch + 1u;
 }
@@ -366,12 +441,13 @@ static int stream_analyse(const mv_args * mv, int n, std::vector<st_phase> & out
         if (a.pair_F > 0 && (a.M != 2 * a.pair_F || a.residual)) { ST_WHY(5); break; }
         if (rows_total % ST_GRID != 0) { ST_WHY(6); break; }
         const int rows = (int) (rows_total / ST_GRID);
-        const int nsb = rows * nb * (a.pair_F > 0 ? 2 : 1);
-        if (nsb > ST_SB_MAX || rows * (a.pair_F > 0 ? 2 : 1) > ST_ROWS_MAX || nsb < ST_NW * 8 * 2) { ST_WHY(7); break; }   // (at least two passes per wave: anything smaller is the chain engine's)
+        const int rows_w = (rows + ST_NW - 1) / ST_NW;                              // most rows a streamer wave owns
+        const int passes = (rows_w * nb * (a.pair_F > 0 ? 2 : 1) + 7) / 8;          // its passes (8 super-blocks each)
+        if (rows < ST_NW || rows_w > ST_RW_MAX || passes > ST_PASS_MAX || passes < 2) { ST_WHY(7); break; }   // (anything smaller is the chain engine's)
         st_phase ph;
         memset(&ph, 0, sizeof(ph));
         ph.w = a.w; ph.row_bytes = a.row_bytes; ph.x = a.x; ph.alpha = a.alpha; ph.residual = a.residual; ph.y = a.y; ph.pair_F = a.pair_F;
-        ph.K = (int) a.K; ph.nb = nb; ph.rows = rows; ph.nsb = nsb; ph.prologue = a.prologue; ph.eps = a.eps; ph.inv_nb = 1.0f / (float) nb;
+        ph.K = (int) a.K; ph.nb = nb; ph.rows = rows; ph.rows_prev = i > 0 ? out[(size_t) i - 1].rows : 0; ph.prologue = a.prologue; ph.eps = a.eps; ph.inv_nb = 1.0f / (float) nb;
         const size_t ybytes = (size_t) rows_total * 4, xbytes = (size_t) a.K * 4;
         // what this phase reads against what earlier phases of the run write
         ph.x_chain = 0; ph.res = a.residual ? 2 : 0; ph.res_src = 0;
@@ -396,11 +472,10 @@ static int stream_analyse(const mv_args * mv, int n, std::vector<st_phase> & out
         if (st_overlaps(a.y, ybytes, a.x, xbytes) || (a.alpha && st_overlaps(a.y, ybytes, a.alpha, xbytes))) { ST_WHY(11); break; }
         if (a.residual && a.residual != a.y && st_overlaps(a.y, ybytes, a.residual, ybytes)) { ST_WHY(12); break; }
         if (st_overlaps(a.y, ybytes, a.w, (size_t) a.M * a.row_bytes)) { ST_WHY(13); break; }
-        const int passes = (nsb + ST_NW * 8 - 1) / (ST_NW * 8);
-        ph.n_pass = (passes + 3) & ~3;
-        if (n_rounds + ph.n_pass / 4 > ST_RND_MAX) { ST_WHY(14); break; }
-        for (int r = 0; r < ph.n_pass / 4; r++) rounds.push_back(make_int2(i, r * 4));
-        n_rounds += ph.n_pass / 4;
+        ph.n_pass = (passes + ST_RH - 1) / ST_RH * ST_RH;
+        if (n_rounds + ph.n_pass / ST_RH > ST_RND_MAX) { ST_WHY(14); break; }
+        for (int r = 0; r < ph.n_pass / ST_RH; r++) rounds.push_back(make_int2(i, r * ST_RH));
+        n_rounds += ph.n_pass / ST_RH;
         ph.n_pub = 0;
         if (i > 0) out[(size_t) i - 1].n_pub = (int) a.K;
         out.push_back(ph);
@@ -416,7 +491,7 @@ int k_stream_accept(const mv_args * mv, int n) {
     return len >= min_len ? len : 0;
 }
 static size_t st_tables_bytes() { return GGML_PAD((size_t) ST_PH_MAX * sizeof(st_phase), 256) + GGML_PAD((size_t) ST_RND_MAX * sizeof(int2), 256); }
-static size_t st_state_bytes() { return 256 + 2 * (size_t) ST_K_MAX * 8; }
+static size_t st_state_bytes() { return 256 + 2 * (size_t) ST_K_MAX * 8 + 2 * (size_t) ST_GRID * 8; }
 size_t k_stream_ws_size(const mv_args *, int) { return st_tables_bytes() + st_state_bytes(); }
 
 stream_plan * k_stream_create(hipStream_t s, const mv_args * mv, int n, void * ws, unsigned * err) {
@@ -434,8 +509,9 @@ stream_plan * k_stream_create(hipStream_t s, const mv_args * mv, int n, void * w
     c->P.phases = d_ph; c->P.rounds = d_rd; c->P.n_phases = n; c->P.n_rounds = (int) c->rounds.size();
     c->P.launch_seq = (unsigned *) state;
     c->P.gbuf = (u64 *) (state + 256);
+    c->P.flags = c->P.gbuf + 2 * ST_K_MAX;
     c->P.err = err;
-    c->smem = 2 * ST_NB_MAX * XBLK_BYTES + (size_t) (ST_SB_MAX + ST_PH_MAX * ST_ROWS_MAX) * 4 + sizeof(st_ctl) + ST_PH_MAX * sizeof(st_phase) + (ST_RND_MAX + 2) * sizeof(int2);
+    c->smem = 2 * ST_NB_MAX * XBLK_BYTES + (size_t) (ST_NW * ST_SBW + ST_PH_MAX * ST_NW * ST_RW_MAX) * 4 + sizeof(st_ctl) + ST_PH_MAX * sizeof(st_phase) + (ST_RND_MAX + 2) * sizeof(int2);
     GGML_ASSERT(c->smem <= 64 * 1024);
     return c;
 }

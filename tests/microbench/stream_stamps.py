@@ -18,14 +18,12 @@ lib = L.ggml
 buf = (C.c_ulonglong * (2 * 64 * 8))()
 lib.mi355x_stream_log_read(buf)
 rec = np.frombuffer(buf, np.uint64).reshape(2, 64, 8).astype(np.int64)
-names = ["start", "x ready", "blocks", "dots", "published"]
 for wgi, label in ((0, "workgroup 0"), (1, "last workgroup")):
     r = rec[wgi]
     n = int((r[:, 0] > 0).sum())
     t0 = r[0, 0]
-    print(f"{label}: {n} phases, span {(r[n - 1, 4] - t0) / 100.0:.2f} us")
-    print("phase |  start us | " + " | ".join(f"{x:>9s}" for x in names[1:]) + " | to next start")
+    print(f"{label}: {n} phases (times in us from the first streamer stamp)")
+    print("phase | streamer: start  blocks-ready  dots-done  published | gatherer: start  own-wg-pub  gathered  blocks-written")
     for p in range(n):
-        d = [(r[p, i] - r[p, i - 1]) / 100.0 for i in range(1, 5)]
-        nxt = (r[p + 1, 0] - r[p, 4]) / 100.0 if p + 1 < n else 0.0
-        print(f"{p:5d} | {(r[p, 0] - t0) / 100.0:9.2f} | " + " | ".join(f"{x:9.2f}" for x in d) + f" | {nxt:8.2f}")
+        t = [(r[p, i] - t0) / 100.0 for i in range(8)]
+        print(f"{p:5d} | {t[0]:15.2f} {t[1]:13.2f} {t[2]:10.2f} {t[3]:10.2f} | {t[4]:15.2f} {t[5]:10.2f} {t[6]:9.2f} {t[7]:15.2f}")
