@@ -166,6 +166,8 @@ GGML_API void    moshi_hot_set_context_fill(moshi_hot_model_t * m, int64_t offse
 // weights are read back from such a file (names, types and sizes checked against the configuration) instead of being generated
 GGML_API int     moshi_hot_save_gguf(moshi_hot_model_t * m, const char * path);
 GGML_API moshi_hot_model_t * moshi_hot_create_from_gguf(ggml_backend_t backend, const struct moshi_hot_config * cfg, const char * path);
+// test hook: the host-side delay ring (rows x (n_q + 1) int32, row-major) -> dst; returns the value count (dst NULL: just the count)
+GGML_API int     moshi_hot_host_ring(moshi_hot_model_t * m, int32_t * dst, int max_values);
 GGML_API void    moshi_hot_fill_ring(moshi_hot_model_t * m, int which, int layer, uint64_t seed, float scale);
 // Parity probe: ONE transformer layer (moshi_streaming_transformer_layer, transformer.h:910-1039) of the Temporal (which = 0) or Depth
 // (which = 1, with weight set `weight_set`) stack on the scratch context, fed x_in F32[dim] at stream position `offset` (mask row, RoPE

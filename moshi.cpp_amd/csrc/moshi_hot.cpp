@@ -713,7 +713,7 @@ struct moshi_hot_model {
     // are views of it, so the next step can be queued before the host has seen the tokens (run-ahead)
     T tok_state = nullptr;
     // run-ahead (chain_depth = 2): steps queued but not yet completed on the host, oldest first
-    struct InFlight { bool done = false; int ok = 0; std::vector<int32_t> raw; int32_t out_text = 0; std::vector<int32_t> out_audio; ggml_backend_event_t ev = nullptr; };
+    struct InFlight { bool done = false; bool steady = false; int ok = 0; std::vector<int32_t> raw; int32_t out_text = 0; std::vector<int32_t> out_audio; ggml_backend_event_t ev = nullptr; };
     std::deque<InFlight> inflight;
     std::vector<ggml_backend_event_t> ev_pool;
     int tok_state_for = -1;        // the step whose model-side inputs tok_state holds (the samples of step tok_state_for - 1), -1: unknown (provided / forced frames)
@@ -1442,11 +1442,18 @@ extern "C" void moshi_hot_depth_shard_import(moshi_hot_model_t * m, int k) {
     m->g_shard_import[(size_t) k]->compute();
 }
 extern "C" void moshi_hot_depth_shard_tokens(moshi_hot_model_t * m, int32_t * out, int n) { ggml_backend_tensor_get(m->shard_tokens, out, 0, (size_t) n * 4); }
+extern "C" int moshi_hot_host_ring(moshi_hot_model_t * m, int32_t * dst, int max_values) {
+    // the host-side delay ring of moshi_lmgen (lm.h:819-824, 935-943), row-major [rows][n_q + 1]; returns the number of values (0 when dst is too small)
+    const int rows = (int) m->cache.size(), cols = rows ? (int) m->cache[0].size() : 0;
+    if (!dst || rows * cols > max_values) return dst ? 0 : rows * cols;
+    for (int r = 0; r < rows; r++) for (int q = 0; q < cols; q++) dst[r * cols + q] = m->cache[(size_t) r][(size_t) q];
+    return rows * cols;
+}
 extern "C" void moshi_hot_set_depth_hook(moshi_hot_model_t * m, moshi_hot_depth_hook_t fn, void * user) { m->depth_hook = fn; m->depth_hook_user = user; }
 
 namespace {
 // the half of moshi_lmgen_step that follows the sampling (lm.h:930-979): ring write, stream position, delayed read-out
-int lm_finish(moshi_hot_model * m, int32_t text_token, std::vector<int32_t> audio, bool provided, bool replace, int32_t * text_token_out, int32_t * out_audio, float * vad) {
+int lm_finish(moshi_hot_model * m, int32_t text_token, std::vector<int32_t> audio, bool provided, bool replace, int32_t * text_token_out, int32_t * out_audio, float * vad, bool newer_step_queued = false) {
     const moshi_hot_config & c = m->cfg;
     const int CT = (int) m->cache.size();
     const int dep_q = c.personaplex ? 8 : c.dep_q, dep_q_1 = dep_q + 1;
@@ -1455,7 +1462,12 @@ int lm_finish(moshi_hot_model * m, int32_t text_token, std::vector<int32_t> audi
     if (!provided) {                      // lm.h:935-943
         const int wpos = m->offset % CT;
         m->cache[(size_t) wpos][0] = text_token;
-        for (int q = 0; q < c.dep_q; q++) m->cache[(size_t) wpos][(size_t) (q + 1)] = audio[(size_t) q];
+        for (int q = 0; q < c.dep_q; q++) {
+            // Run-ahead: the NEXT step has already been queued and has put the other speaker's delay-0 codes into this very row (lm.h:819-824); in the
+            // serial order this write comes first and those codes land on top of it. Leave them: the ring then holds what the serial loop's holds.
+            if (newer_step_queued && q + 1 >= dep_q_1 && c.delays[q + 1] == 0) continue;
+            m->cache[(size_t) wpos][(size_t) (q + 1)] = audio[(size_t) q];
+        }
     }
     if (m->offset <= m->max_delay || replace) return 0;       // lm.h:950
     int idx = (m->offset - m->max_delay + c.delays[0]) % CT;   // lm.h:954-959
@@ -1563,7 +1575,9 @@ void lm_finish_entry(moshi_hot_model * m, moshi_hot_model::InFlight & f) {
     ggml_backend_event_synchronize(f.ev);
     m->ev_pool.push_back(f.ev); f.ev = nullptr;
     std::vector<int32_t> audio(f.raw.begin() + 1, f.raw.end());
-    f.ok = lm_finish(m, f.raw[0], audio, false, false, &f.out_text, f.out_audio.data(), nullptr);
+    bool newer = false, seen = false;
+    for (auto & o : m->inflight) { if (&o == &f) seen = true; else if (seen && o.steady) newer = true; }
+    f.ok = lm_finish(m, f.raw[0], audio, false, false, &f.out_text, f.out_audio.data(), nullptr, newer);
     f.done = true;
 }
 void lm_queue(moshi_hot_model * m, const int32_t * user_codes) {
@@ -1588,6 +1602,7 @@ void lm_queue(moshi_hot_model * m, const int32_t * user_codes) {
         return;
     }
     // other speaker's codes enter the delay ring at step q (lm.h:819-824); their columns of the input row go up from the host as ever
+    f.steady = true;
     for (int i = 0; i < needed; i++) m->cache[(size_t) ((q + c.delays[dep_q_1 + i]) % CT)][(size_t) (dep_q_1 + i)] = user_codes[i];
     const int pos = q % CT;
     for (int i = 0; i < ncb; i++) {

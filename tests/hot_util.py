@@ -41,6 +41,13 @@ class Model:
         r = L.moshi_hot_sts_frame(self.m, pcm.ctypes.data, C.byref(txt), aud, out.ctypes.data)
         return r, txt.value, list(aud)[:self.cfg.dep_q], out
 
+    def host_ring(self):
+        """the host-side delay ring of the LM generator, [rows, n_q + 1] int32"""
+        n = L.moshi_hot_host_ring(self.m, None, 0)
+        buf = np.zeros(n, np.int32)
+        assert L.moshi_hot_host_ring(self.m, buf.ctypes.data, n) == n
+        return buf.reshape(-1, self.cfg.n_q + 1)
+
     def sts_pipeline(self, frames):
         """the software-pipelined loop over `frames` (moshi_hot_sts_pipeline_*): -> per frame (produced, text, audio tokens, pcm) like sts_frame"""
         frames = [np.ascontiguousarray(f, np.float32) for f in frames]

@@ -142,6 +142,7 @@ def test_pipelined_frame_loop_is_bit_identical_to_the_serial_loop(streams, chain
     cfg = make()
     m = hu.Model("hip", cfg, seed=0)
     serial = [m.sts_frame(f) for f in frames]
+    ring_serial = m.host_ring()
     m.free()
     cfg2 = make()
     cfg2.codec_stream = int(streams == 2)
@@ -149,8 +150,12 @@ def test_pipelined_frame_loop_is_bit_identical_to_the_serial_loop(streams, chain
                                   # 2: run-ahead - the samples reach the next Temporal graph through device memory, step k is queued before step k - 1 is read
     m = hu.Model("hip", cfg2, seed=0)
     piped = m.sts_pipeline(frames)
+    ring_piped = m.host_ring()
     m.free()
     assert any(a[0] for a in serial)
+    # the host-side delay ring too (PersonaPlex: the other speaker's delay-0 codes share a row with the previous step's samples; run-ahead writes them in
+    # the opposite order and must still leave the serial loop's ring)
+    assert np.array_equal(ring_serial, ring_piped), f"host delay ring differs at {np.argwhere(ring_serial != ring_piped)[:8].tolist()}"
     for i, (a, b) in enumerate(zip(serial, piped)):
         assert a[0] == b[0] and a[1] == b[1] and a[2] == b[2], f"frame {i}: serial {a[:3]} vs pipelined {b[:3]}"
         if a[0]:
