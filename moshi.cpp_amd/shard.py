@@ -9,8 +9,16 @@ Rank r holds the Depth weights of the steps k with k % world == r (include/moshi
 The collectives are `torch.distributed.broadcast` on tensors that ALIAS the C side's message storage (device memory on the MI355X backend, so
 RCCL moves them GPU to GPU over xGMI; host memory on the CPU device, for the gloo test): torch is transport plumbing only, the C-ABI carries no
 torch type. There is no other data-path collective. The chain stays serial, so this is a strong-scaling (latency) experiment, reported as such.
+
+EXPERIMENTAL on devices: the RCCL legs have only run under gloo (host memory, tests/test_depth_shard_cpu.py, tests/test_temporal_tp_cpu.py) and as a
+one-GPU dry run - no multi-GPU box has been available to this project. Stream ordering on the device relies on ProcessGroupNCCL's wait() making the
+current (external = the backend's) stream wait for the collective; MI355X_SHARD_HOST_SYNC=1 adds a host-side stream synchronisation after every
+collective for a first bring-up on real hardware.
 """
 import ctypes as C
+import os
+
+_HOST_SYNC = os.environ.get("MI355X_SHARD_HOST_SYNC", "0") not in ("", "0")
 
 
 class _DeviceBlock:
@@ -49,6 +57,8 @@ class DepthShard:
         if self.stream is not None:
             with self.torch.cuda.stream(self.stream):
                 self.dist.broadcast(t, src=src, group=self.group)
+            if _HOST_SYNC:
+                self.stream.synchronize()
         else:
             self.dist.broadcast(t, src=src, group=self.group)
         self.hops += 1
@@ -123,6 +133,8 @@ class TemporalTP:
                 if self.stream is not None:
                     with self.torch.cuda.stream(self.stream):
                         self.dist.all_reduce(self.msg, group=self.group)
+                    if _HOST_SYNC:
+                        self.stream.synchronize()
                 else:
                     self.dist.all_reduce(self.msg, group=self.group)
                 self.reductions += 1
