@@ -430,7 +430,8 @@ static bool st_overlaps(const void * a, size_t an, const void * b, size_t bn) {
 static int stream_analyse(const mv_args * mv, int n, std::vector<st_phase> & out, std::vector<int2> & rounds) {
     out.clear(); rounds.clear();
     int n_rounds = 0;
-    for (int i = 0; i < n && i < ST_PH_MAX; i++) {
+    static const int max_len = st_env("MI355X_STREAM_MAX", ST_PH_MAX), min_pass = st_env("MI355X_STREAM_MIN_PASSES", 2);
+    for (int i = 0; i < n && i < ST_PH_MAX && i < max_len; i++) {
         const mv_args & a = mv[i];
         if (a.wtype != GGML_TYPE_Q4_K || a.ncols != 1 || a.K % 256 != 0 || a.K / 256 > ST_NB_MAX || a.row_bytes != (a.K / 256) * 144) { ST_WHY(1); break; }
         if (a.prologue != MV_PLAIN && a.prologue != MV_RMSNORM) { ST_WHY(2); break; }
@@ -443,7 +444,7 @@ static int stream_analyse(const mv_args * mv, int n, std::vector<st_phase> & out
         const int rows = (int) (rows_total / ST_GRID);
         const int rows_w = (rows + ST_NW - 1) / ST_NW;                              // most rows a streamer wave owns
         const int passes = (rows_w * nb * (a.pair_F > 0 ? 2 : 1) + 7) / 8;          // its passes (8 super-blocks each)
-        if (rows < ST_NW || rows_w > ST_RW_MAX || passes > ST_PASS_MAX || passes < 2) { ST_WHY(7); break; }   // (anything smaller is the chain engine's)
+        if (rows < ST_NW || rows_w > ST_RW_MAX || passes > ST_PASS_MAX || passes < min_pass) { ST_WHY(7); break; }   // (anything smaller is the chain engine's)
         st_phase ph;
         memset(&ph, 0, sizeof(ph));
         ph.w = a.w; ph.row_bytes = a.row_bytes; ph.x = a.x; ph.alpha = a.alpha; ph.residual = a.residual; ph.y = a.y; ph.pair_F = a.pair_F;
