@@ -1660,6 +1660,9 @@ struct attn_split_ws { unsigned long long * gscores; unsigned long long * gpart;
 #else
 #define AT_STAMP(i) do {} while (0)
 #endif
+#ifndef ATTN_V_EARLY
+#define ATTN_V_EARLY 0   // A/B (profiles/r03_ab_attn_v_request_point.txt): the later V rows requested with the later K rows (1: fill 2 800 290 frames/s - they compete with the K rows the scores wait for) or behind the scores (0: 319)
+#endif
 template <bool SPLIT, int NWA>
 __global__ void __launch_bounds__(NWA * 64) __attribute__((amdgpu_waves_per_eu(2)))   // >= 2 workgroups per CU: the split grid (<= 512) is resident
 attn_decode_kernel(attn_args a_in, attn_split_ws w) {
@@ -1911,6 +1914,16 @@ attn_decode_kernel(attn_args a_in, attn_split_ws w) {
         };
         const int cb_first = c_lo + NPRE * ATTN_NW * SPW;
         if (SPLIT) request_k_batch(cb_first);
+        // ... and its later V rows right behind them (registers are there: two workgroups of four waves per CU): they land during the scores and the hand-off
+        uint4 vb0[SPLIT ? NB : 1];
+        if (SPLIT && ATTN_V_EARLY) {
+#pragma unroll
+            for (int pi = 0; pi < NB; pi++) {
+                const int c0 = c_lo + (NPRE + pi) * ATTN_NW * SPW + wave * SPW, c = c0 + sub;
+                vb0[pi] = *(const uint4 *) (vc + (int64_t) (c < c_last ? c : c_last) * a.v_nb1 + dl * 2);   // (fresh row: patched where it is used)
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
 #pragma unroll
         for (int pi = 0; pi < NPRE; pi++) {
             const int c0 = c_lo + wave * SPW + pi * ATTN_NW * SPW;
@@ -1927,13 +1940,11 @@ attn_decode_kernel(attn_args a_in, attn_split_ws w) {
                 }
             }
         }
-        // the first later batch of V rows of a split workgroup goes out now (the K registers are free) and arrives during the head-wide hand-off
-        uint4 vb0[SPLIT ? NB : 1];
-        if (SPLIT) {
+        if (SPLIT && !ATTN_V_EARLY) {
 #pragma unroll
             for (int pi = 0; pi < NB; pi++) {
                 const int c0 = c_lo + (NPRE + pi) * ATTN_NW * SPW + wave * SPW, c = c0 + sub;
-                vb0[pi] = *(const uint4 *) (vc + (int64_t) (c < c_last ? c : c_last) * a.v_nb1 + dl * 2);   // (fresh row: patched where it is used)
+                vb0[pi] = *(const uint4 *) (vc + (int64_t) (c < c_last ? c : c_last) * a.v_nb1 + dl * 2);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
