@@ -1633,6 +1633,9 @@ void k_matvec(hipStream_t s, const mv_args & a) {
 // transformers' 250-slot rings of D = 64 (8 x NPRE x 8 = 256 slots, the whole ring, are in flight from kernel entry: Mimi -30 us each way)
 #define ATTN_NW_BASE 4
 #define ATTN_NW_WIDE 8
+#ifndef ATTN_SPLIT_NW_DEFAULT
+#define ATTN_SPLIT_NW_DEFAULT 4
+#endif
 #define ATTN_MAX_T 4
 #define ATTN_NPRE 4      // ring-slot passes whose K and V rows are requested at kernel entry (4 passes x 4 waves x SPW slots)
 
@@ -1685,7 +1688,7 @@ attn_decode_kernel(attn_args a_in, attn_split_ws w) {
     // passes whose ring rows are requested before the first wait (the rest streams in batches of the same size in the pass loops)
     // NB: rows per later batch. A split workgroup owns at most 2 x w.slots = 256 slots = 16 passes: after the NPRE it asked for at entry, ALL the others go out
     // in one batch (K before the scores; V right behind the scores, landing during the head-wide hand-off) - one memory round trip each instead of three.
-    constexpr int NB = SPLIT ? 12 : ATTN_NPRE;
+    constexpr int NB = SPLIT ? (NWA == 8 ? 8 : 12) : ATTN_NPRE;   // (8 waves: 32 slots per pass, 2 x 192 slots = 12 passes)
     constexpr int NPRE = ATTN_NPRE;   // A/B at bench level: 4 beats 2 and 8 for the split kernel at empty, 600-slot and full context (registers vs round trips)
     const int D = SPLIT ? 128 : a.D, C = a.C, T = SPLIT ? 1 : a.T;   // (attn_use_split: one query row, 128-wide heads - known to the compiler)
     const int S = SPLIT ? w.S : 1;
@@ -1967,7 +1970,7 @@ attn_decode_kernel(attn_args a_in, attn_split_ws w) {
                 if (c < c_hi) __hip_atomic_store(w.gscores + (int64_t) h * C + c, ((unsigned long long) tag << 32) | (unsigned long long) __float_as_uint(sc[c]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             {
-                constexpr int PULL = 12;                                             // C <= 3 072 at 256 threads: one batch
+                constexpr int PULL = 3072 / ATTN_THREADS;                            // C <= 3 072: one batch
                 float omax = -INFINITY;
                 for (int c0 = tid; c0 < n_end; c0 += PULL * ATTN_THREADS) {
                     unsigned long long g[PULL];
@@ -2118,7 +2121,9 @@ attn_decode_kernel(attn_args a_in, attn_split_ws w) {
 }
 
 static bool attn_use_split(const attn_args & a) { return a.T == 1 && a.n_groups <= 1 && a.D == 128 && a.C >= ATTN_SPLIT_MIN_C; }
-static int attn_split_slots() { static const int v = env_int("MI355X_ATTN_SLOTS", ATTN_SPLIT_SLOTS); return v < 64 ? 64 : v; }
+// waves per split workgroup: 4 (ranges of 128 / 256 slots: up to 12 workgroups per head at 3 000 slots = 384 on 256 CUs) or 8 (192 / 384 slots: 8 per head = one per CU)
+static int attn_split_nw() { static const int v = env_int("MI355X_ATTN_SPLIT_NW", ATTN_SPLIT_NW_DEFAULT); return v == 8 ? 8 : 4; }
+static int attn_split_slots() { static const int v = env_int("MI355X_ATTN_SLOTS", attn_split_nw() == 8 ? 192 : ATTN_SPLIT_SLOTS); return v < 64 ? 64 : v > 32 * attn_split_nw() ? 32 * attn_split_nw() : v; }
 size_t k_attn_decode_ws_size(const attn_args & a) {
     if (!attn_use_split(a)) return 0;
     const size_t S = (size_t) (a.C + attn_split_slots() - 1) / attn_split_slots();
@@ -2130,20 +2135,22 @@ void k_attn_decode(hipStream_t s, const attn_args & a, void * ws, unsigned * err
     GGML_ASSERT(a.n_groups <= 1 || a.n_groups == (a.T + 3) / 4);
     static const int wide_on = env_int("MI355X_ATTN_WIDE", 1);
     const bool wide = wide_on && a.D <= 64 && a.C >= 128;
-    const size_t smem = (size_t) a.C * 4 + (size_t) Tg * a.D * 4 * 3 + (size_t) (wide ? ATTN_NW_WIDE : ATTN_NW_BASE) * 64 * 8 * 8 + 16 + (size_t) Tg * a.C * 4 + (size_t) env_int("MI355X_ATTN_LDS_PAD", 0);
+    const bool split = ws && attn_use_split(a);
+    const int split_nw = attn_split_nw();
+    const size_t smem = (size_t) a.C * 4 + (size_t) Tg * a.D * 4 * 3 + (size_t) (split ? split_nw : wide ? ATTN_NW_WIDE : ATTN_NW_BASE) * 64 * 8 * 8 + 16 + (size_t) Tg * a.C * 4 + (size_t) env_int("MI355X_ATTN_LDS_PAD", 0);
     GGML_ASSERT(smem <= 160 * 1024);
     if (smem > 64 * 1024) {   // > 64 KB of dynamic LDS needs a one-time opt-in per kernel
-        static size_t granted[3] = { 0, 0, 0 };
-        const int which = ws && attn_use_split(a) ? 1 : wide ? 2 : 0;
+        static size_t granted[4] = { 0, 0, 0, 0 };
+        const int which = split ? (split_nw == 8 ? 3 : 1) : wide ? 2 : 0;
         if (granted[which] < smem) {
-            HIP_CHECK(hipFuncSetAttribute(which == 1 ? (const void *) attn_decode_kernel<true, ATTN_NW_BASE> : which == 2 ? (const void *) attn_decode_kernel<false, ATTN_NW_WIDE> : (const void *) attn_decode_kernel<false, ATTN_NW_BASE>,
+            HIP_CHECK(hipFuncSetAttribute(which == 3 ? (const void *) attn_decode_kernel<true, ATTN_NW_WIDE> : which == 1 ? (const void *) attn_decode_kernel<true, ATTN_NW_BASE> : which == 2 ? (const void *) attn_decode_kernel<false, ATTN_NW_WIDE> : (const void *) attn_decode_kernel<false, ATTN_NW_BASE>,
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int) smem));
             granted[which] = smem;
         }
     }
     static const int single_max = env_int("MI355X_ATTN_SINGLE_MAX", ATTN_SINGLE_MAX), big_min = env_int("MI355X_ATTN_BIG_MIN", ATTN_SPLIT_BIG_MIN);
     attn_split_ws w = { nullptr, nullptr, nullptr, 1, err, ATTN_SPLIT_SLOTS, single_max, big_min };
-    if (ws && attn_use_split(a)) {
+    if (split) {
         const int S = (a.C + attn_split_slots() - 1) / attn_split_slots();
         w.slots = attn_split_slots();
         GGML_ASSERT(a.D == 128 && "split prefetch depth is sized for 16 slots per pass");
@@ -2152,7 +2159,8 @@ void k_attn_decode(hipStream_t s, const attn_args & a, void * ws, unsigned * err
         w.gscores = (unsigned long long *) p; p += (size_t) a.H * a.C * 8;
         w.gpart = (unsigned long long *) p;
         w.S = S;
-        attn_decode_kernel<true, ATTN_NW_BASE><<<a.H * S, ATTN_NW_BASE * 64, smem, s>>>(a, w);
+        if (split_nw == 8) attn_decode_kernel<true, ATTN_NW_WIDE><<<a.H * S, ATTN_NW_WIDE * 64, smem, s>>>(a, w);
+        else               attn_decode_kernel<true, ATTN_NW_BASE><<<a.H * S, ATTN_NW_BASE * 64, smem, s>>>(a, w);
         return;
     }
     const dim3 grid((unsigned) a.H, (unsigned) (a.n_groups > 1 ? a.n_groups : 1));
