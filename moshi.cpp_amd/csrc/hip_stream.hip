@@ -18,8 +18,13 @@
 // weight requests queued in the fabric a poll's round trip IS the ring's depth, whichever wave issues it), norm + quantisation (1.7 - 2.6 us on
 // four waves) - against ~2 us of kernel boundary plus ~3.5 us of ramp for a separate launch. Net: Temporal 2 050 us per frame with the engine, 1 600 us
 // without. The lesson matches the chain engine's: an all-to-all hand-off between 256 workgroups under full HBM load is not cheaper than a kernel
-// boundary on this chip; a deeper ring buys throughput and pays it back in poll latency. Kept for the measurement and as the base of an LDS-staged
-// variant (requests paced to ~32 KB per CU in flight, landed tiles parked in LDS across the boundary).
+// boundary on this chip; a deeper ring buys throughput and pays it back in poll latency.
+// The LDS-staged variant was built and measured too (not kept: this file is the register-ring form): every streamer wave's weight bytes as one stream
+// of 1 KB chunks dropped by LDS-DMA (global_load_lds_dwordx4) into a private 14 KB LDS ring, requests paced to 5 chunks in flight per wave
+// (s_waitcnt vmcnt(4) in front of every request) and issued also while the wave waits for the next phase's blocks, eight gatherer waves. Bit-identical
+// as well; LM step 3 130 us against 2 889 for this form and 2 413 for one launch per mat-vec: the paced stream reaches 4.1 TB/s inside a phase, and the
+// hand-off is no shorter with the fabric kept busy through it (poll sweep 2.3 - 4.3 us, wave skew up to 6.5 us in linear_in, norm + quantisation
+// 1.6 - 3 us) - longer than the 5 us of stream a 14 KB ring per wave can absorb.
 #include "hip_common.h"
 #include "hip_device.h"
 #include "hip_mv_device.h"
