@@ -180,8 +180,9 @@ GGML_API int     moshi_hot_layer_probe(moshi_hot_model_t * m, int which, int lay
                                        moshi_hot_node_visitor_t visit, void * user);
 
 // ---- Depth codebook shard: one frame = begin, then for k = 0 .. dep_q-1 the owner runs `step` and everybody else `import` ---------------
-// The 8-slot Depth ring is REPLICATED on every rank; what an owner hands on per step is one message F32[2 * dep_layers * dep_dim + 8]:
-// its new K and V ring rows of all layers (BF16 values widened exactly) and the sampled token (+ the frame's stop flag in word 1 of the tail).
+// The 8-slot Depth ring is REPLICATED on every rank; what an owner hands on per step is one message of dep_layers * dep_dim + 8 32-bit words:
+// its new K and V ring rows of all layers as the BF16 values the ring stores (2 * dep_layers * dep_dim of them: 24 KB at 6 x 1024) and, in the tail,
+// the sampled token as F32 (+ the frame's stop flag in word 1 of the tail).
 // The transport between ranks is the caller's (torch.distributed over RCCL / xGMI in bench.py, gloo in the CPU test): the message lives in
 // one tensor whose storage pointer is returned here - a device pointer on the MI355X backend - so it can be handed to a collective as is.
 GGML_API void *  moshi_hot_depth_shard_msg(moshi_hot_model_t * m, int64_t * n_floats);        // step message (rows + token)

@@ -1142,7 +1142,7 @@ static moshi_hot_model_t * create_model(ggml_backend_t backend, const struct mos
             make_transformer(m, m->depth, "lm.depformer", c.dep_dim, c.dep_heads, c.dep_layers, c.dep_ffn_hidden, c.dep_context ? c.dep_context : c.dep_schedule_len, 0, n_sets, false, lt);
             for (int i = 0; i < c.dep_schedule_len; i++) m->depth.schedule.push_back(c.dep_schedule[i]);
             if (c.dep_shard_world >= 1) {   // shard messages + the device-side token vector (zero-filled states)
-                m->shard_msg = state(m, GGML_TYPE_F32, 2 * (int64_t) c.dep_layers * c.dep_dim + 8);
+                m->shard_msg = state(m, GGML_TYPE_F32, (int64_t) c.dep_layers * c.dep_dim + 8);   // 2 x layers x dim BF16 ring values, then the token (F32)
                 m->shard_tout = state(m, GGML_TYPE_F32, (int64_t) c.dim + 8);
                 m->shard_tokens = state(m, GGML_TYPE_I32, c.dep_q);
             }
@@ -1345,8 +1345,13 @@ namespace {
 // ring rows of slot `slot` of one cache tensor [D, C, H] <-> a dense [D, 1, H] F32 window of the step message
 T ring_rows(Builder & g, T cache, int slot) { return ggml_view_3d(g, cache, cache->ne[0], 1, cache->ne[2], cache->nb[1], cache->nb[2], (size_t) slot * cache->nb[1]); }
 T msg_rows(Builder & g, T msg, T like, int64_t index) {
+    // A BF16 window into the (F32-typed) message: the ring rows travel as they are stored - 2 x layers x dim BF16 values = 24 KB per hop for the 1024-wide
+    // Depth transformer, half of what the F32 form moved, and bit for bit what the importing rank's ring then holds.
     const int64_t n = like->ne[0] * like->ne[2];
-    return ggml_view_3d(g, msg, like->ne[0], 1, like->ne[2], (size_t) like->ne[0] * 4, (size_t) like->ne[0] * 4, (size_t) (index * n) * 4);
+    GGML_ASSERT(like->type == GGML_TYPE_BF16 && like->ne[0] % 2 == 0);
+    T v = ggml_view_3d(g, msg, like->ne[0] / 2, 1, like->ne[2], (size_t) like->ne[0] * 2, (size_t) like->ne[0] * 2, (size_t) (index * n) * 2);
+    v->type = GGML_TYPE_BF16; v->ne[0] = like->ne[0]; v->nb[0] = 2;
+    return v;
 }
 // one Depth step as its own cached graph: the body of the chained loop (lm.h:505-527) for step k, the previous token read from the token
 // vector, plus the packing of this step's message
@@ -1376,7 +1381,7 @@ void build_shard_step(moshi_hot_model * m, int k) {
         T rows = ring_rows(g, cache, slot);
         g.expand(ggml_cpy(g, rows, msg_rows(g, m->shard_msg, rows, w++)));
     }
-    g.expand(ggml_cpy(g, next, ggml_view_1d(g, m->shard_msg, 1, (size_t) (2 * c.dep_layers * c.dep_dim) * 4)));
+    g.expand(ggml_cpy(g, next, ggml_view_1d(g, m->shard_msg, 1, (size_t) (c.dep_layers * c.dep_dim) * 4)));
     g.alloc();
     if ((int) m->g_shard_step.size() <= k) m->g_shard_step.resize((size_t) k + 1, nullptr);
     m->g_shard_step[(size_t) k] = b;
@@ -1389,9 +1394,9 @@ void build_shard_import(moshi_hot_model * m, int k) {
     int64_t w = 0;
     for (auto & L : m->depth.layers) for (T cache : { L.kcache, L.vcache }) {
         T rows = ring_rows(g, cache, slot);
-        g.expand(ggml_cpy(g, msg_rows(g, m->shard_msg, rows, w++), rows));   // F32 -> BF16 of BF16-valued floats: exact
+        g.expand(ggml_cpy(g, msg_rows(g, m->shard_msg, rows, w++), rows));   // BF16 -> BF16
     }
-    g.expand(ggml_cpy(g, ggml_view_1d(g, m->shard_msg, 1, (size_t) (2 * c.dep_layers * c.dep_dim) * 4), ggml_view_1d(g, m->shard_tokens, 1, (size_t) k * 4)));
+    g.expand(ggml_cpy(g, ggml_view_1d(g, m->shard_msg, 1, (size_t) (c.dep_layers * c.dep_dim) * 4), ggml_view_1d(g, m->shard_tokens, 1, (size_t) k * 4)));
     g.alloc();
     if ((int) m->g_shard_import.size() <= k) m->g_shard_import.resize((size_t) k + 1, nullptr);
     m->g_shard_import[(size_t) k] = b;

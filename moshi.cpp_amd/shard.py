@@ -4,7 +4,7 @@ the per-step weight sets of lm_default.h:136-146,187-216).
 Rank r holds the Depth weights of the steps k with k % world == r (include/moshi_hot.h, dep_shard_*). Per frame:
   1. the Temporal owner (rank 0) broadcasts `transformer_out` (F32[dim] + a "more frames" flag);
   2. for k = 0 .. dep_q-1: the owner of step k runs it (6 layers + head + sample) and broadcasts ONE message - its new K / V ring rows of all
-     layers (2 x 6 x 1024 values) and the sampled token; every other rank writes them into its replica of the 8-slot ring / token vector;
+     layers (2 x 6 x 1024 BF16 values, as the ring stores them: 24 KB) and the sampled token; every other rank writes them into its replica of the 8-slot ring / token vector;
   3. rank 0 reads the dep_q tokens.
 The collectives are `torch.distributed.broadcast` on tensors that ALIAS the C side's message storage (device memory on the MI355X backend, so
 RCCL moves them GPU to GPU over xGMI; host memory on the CPU device, for the gloo test): torch is transport plumbing only, the C-ABI carries no
