@@ -736,3 +736,18 @@ def test_two_tensor_parallel_ranks_run_their_q4k_slices_on_the_device(dim, heads
     # positions without a rounding flip agree to summation noise (measured 2-3e-7); a position where one Q8_K / BF16 value rounds the other way - the summed
     # partials differ from the unsplit sums by ~1e-7, as between any two correct implementations - moves by a quantiser step (measured 2.7e-3 / 1.1e-2 at 4096)
     assert np.median(errs) < 1e-5 and max(errs) < 3e-2 and sum(e < 1e-6 for e in errs) >= 3, errs
+
+
+def test_split_attention_with_eight_wave_workgroups_passes_the_long_ring_tests():
+    # MI355X_ATTN_SPLIT_NW=8 (192 / 384-slot ranges, one workgroup per CU at 3 000 slots; profiles/r03_ab_attn_split_width.txt) is a shipped option: the
+    # long-ring parity tests of this file and the pre-filled-ring probe of test_full_width_parity.py run against it in a child process (the choice is read once per process)
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, MI355X_ATTN_SPLIT_NW="8")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider",
+                        os.path.join(here, "test_hip_frame.py"), os.path.join(here, "test_full_width_parity.py"),
+                        "-k", "long_ring_split_attention or long_context_decode or prefilled_ring_node_by_node"],
+                       capture_output=True, text=True, env=env, timeout=1500, cwd=os.path.dirname(here))
+    assert r.returncode == 0 and " passed" in r.stdout and "failed" not in r.stdout, (r.stdout + r.stderr)[-3000:]
