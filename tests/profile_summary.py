@@ -2,6 +2,7 @@
 
     python tests/profile_summary.py stats  <kernel_stats.csv> <out.csv>          # per-kernel totals (as rocprofv3 --stats wrote them)
     python tests/profile_summary.py pmc    <counter_collection.csv> <out.json>   # FETCH_SIZE per launch of every kernel
+    python tests/profile_summary.py counters <out.txt> <counter_collection.csv> [more.csv ...]   # any counters: per kernel, per launch averages
 
 FETCH_SIZE is reported in KB and, on gfx950, counts 64 B per 128-B request of a wide streaming read
 (MI355X_MICROARCH.md "HBM"): bytes = 2 x 1024 x FETCH_SIZE.
@@ -44,5 +45,37 @@ def pmc(src, dst):
     json.dump(out, open(dst, "w"), indent=1)
 
 
+def counters(dst, *srcs):
+    """per kernel (top 12 by launches x waves): average of every collected counter per launch, plus the derived average vector-memory latency
+    SQ_INST_LEVEL_VMEM / SQ_INSTS_VMEM_RD (cycles an issued vector-memory read stays outstanding) where both were collected"""
+    agg = collections.defaultdict(lambda: collections.defaultdict(lambda: [0, 0.0]))
+    for src in srcs:
+        for r in csv.DictReader(open(src)):
+            k = r["Kernel_Name"].split("(")[0]
+            c = agg[k][r["Counter_Name"]]
+            c[0] += 1
+            c[1] += float(r["Counter_Value"])
+    names = sorted({c for k in agg for c in agg[k]})
+    order = sorted(agg, key=lambda k: -max(v[0] for v in agg[k].values()))
+    with open(dst, "w") as f:
+        f.write("# per launch averages; counters collected in separate rocprofv3 --pmc passes of the same command (eager launches)\n")
+        for k in order[:14]:
+            n = max(v[0] for v in agg[k].values())
+            f.write(f"{k}  launches {n}\n")
+            for c in names:
+                if c in agg[k]:
+                    f.write(f"    {c:28s} {agg[k][c][1] / agg[k][c][0]:16.1f}\n")
+            a = agg[k]
+            if "SQ_INST_LEVEL_VMEM" in a and "SQ_INSTS_VMEM_RD" in a and a["SQ_INSTS_VMEM_RD"][1] > 0:
+                f.write(f"    {'-> cycles per vmem read':28s} {a['SQ_INST_LEVEL_VMEM'][1] / a['SQ_INST_LEVEL_VMEM'][0] / (a['SQ_INSTS_VMEM_RD'][1] / a['SQ_INSTS_VMEM_RD'][0]):16.1f}\n")
+            if "SQ_WAIT_INST_ANY" in a and "SQ_WAVE_CYCLES" in a and a["SQ_WAVE_CYCLES"][1] > 0:
+                f.write(f"    {'-> waiting / wave cycles':28s} {a['SQ_WAIT_INST_ANY'][1] / a['SQ_WAIT_INST_ANY'][0] / (a['SQ_WAVE_CYCLES'][1] / a['SQ_WAVE_CYCLES'][0]):16.3f}\n")
+            if "SQ_ACTIVE_INST_VALU" in a and "SQ_WAVE_CYCLES" in a and a["SQ_WAVE_CYCLES"][1] > 0:
+                f.write(f"    {'-> VALU active / wave cycles':28s} {a['SQ_ACTIVE_INST_VALU'][1] / a['SQ_ACTIVE_INST_VALU'][0] / (a['SQ_WAVE_CYCLES'][1] / a['SQ_WAVE_CYCLES'][0]):16.3f}\n")
+
+
 if __name__ == "__main__":
-    {"stats": stats, "pmc": pmc}[sys.argv[1]](sys.argv[2], sys.argv[3])
+    if sys.argv[1] == "counters":
+        counters(sys.argv[2], *sys.argv[3:])
+    else:
+        {"stats": stats, "pmc": pmc}[sys.argv[1]](sys.argv[2], sys.argv[3])
