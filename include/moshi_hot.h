@@ -166,6 +166,9 @@ GGML_API void    moshi_hot_set_context_fill(moshi_hot_model_t * m, int64_t offse
 // weights are read back from such a file (names, types and sizes checked against the configuration) instead of being generated
 GGML_API int     moshi_hot_save_gguf(moshi_hot_model_t * m, const char * path);
 GGML_API moshi_hot_model_t * moshi_hot_create_from_gguf(ggml_backend_t backend, const struct moshi_hot_config * cfg, const char * path);
+// the name a checkpoint tensor carries inside a GGUF file (WeightLoader::tensor_name, src/loader.h:120-137): the name itself below GGML_MAX_NAME characters,
+// else the reference's 8-character CRC digest (src/crc-bbf.h). out receives at most n - 1 characters + NUL; returns the length of the file name
+GGML_API int     moshi_hot_tensor_file_name(const char * checkpoint_name, char * out, int n);
 // test hook: the host-side delay ring (rows x (n_q + 1) int32, row-major) -> dst; returns the value count (dst NULL: just the count)
 GGML_API int     moshi_hot_host_ring(moshi_hot_model_t * m, int32_t * dst, int max_values);
 GGML_API void    moshi_hot_fill_ring(moshi_hot_model_t * m, int which, int layer, uint64_t seed, float scale);

@@ -83,6 +83,7 @@ struct hip_ctx {
     std::deque<async_get> aget_pending;
     uint64_t aget_seq = 0;
     bool in_use = false;         // stream contexts only: handed out by ggml_backend_mi355x_init_stream, returned by ggml_backend_free
+    int usable_cus = 0;          // compute units this context's stream may use: the device's count, or MI355X_STREAM_CUS of them (CU-masked stream)
     ggml_backend_device dev_obj;
 };
 
@@ -96,7 +97,23 @@ static void set_device(hip_ctx * c) { HIP_CHECK(hipSetDevice(c->device)); }
 static void ctx_init_lazy(hip_ctx * c) {
     if (c->stream) return;
     set_device(c);
-    HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    {
+        hipDeviceProp_t prop;
+        HIP_CHECK(hipGetDeviceProperties(&prop, c->device));
+        c->usable_cus = prop.multiProcessorCount;
+        // MI355X_STREAM_CUS=n: confine this backend's stream to n compute units, spread round-robin over the XCDs (hipExtStreamCreateWithCUMask) - the shape
+        // of a CU-masked or partitioned deployment. Kernels whose workgroups wait for each other (persistent chains, the fused attention + out_proj launch,
+        // split attention) are planned against this number and fall back to plain launches when their grid cannot be resident (build_plan).
+        const char * e = getenv("MI355X_STREAM_CUS");
+        const int lim = e ? atoi(e) : 0;
+        if (lim > 0 && lim < prop.multiProcessorCount) {
+            std::vector<uint32_t> mask((size_t) (prop.multiProcessorCount + 31) / 32, 0u);
+            for (int i = 0; i < lim; i++) mask[(size_t) i / 32] |= 1u << (i % 32);
+            HIP_CHECK(hipExtStreamCreateWithCUMask(&c->stream, (uint32_t) mask.size(), mask.data()));
+            c->usable_cus = lim;
+        }
+    }
+    if (!c->stream) HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     for (auto & s : c->slots) {
         HIP_CHECK(hipHostMalloc((void **) &s.blob, UPLOAD_BLOB_BYTES, hipHostMallocMapped));
         HIP_CHECK(hipHostMalloc((void **) &s.descs, UPLOAD_MAX_DESCS * sizeof(upload_desc), hipHostMallocMapped));
@@ -1486,7 +1503,17 @@ static bool match_sampler(const analysis & an, int pos, step_group & grp) {
 }
 
 // ---- plan construction --------------------------------------------------------------------------------------
-static plan_t * build_plan(hip_ctx * c, ggml_cgraph * g) {
+// Kernels whose workgroups wait for each other inside a launch (persistent chains, the fused attention + out_proj launch) need their WHOLE grid resident.
+// Two such launches from two streams of one device could interleave their dispatch and each keep the other's workgroups off the compute units, so only ONE
+// context per device plans them: the first that asks (the LM stream; the codec stream's graphs have no such runs today). Released with the context.
+static hip_ctx * g_spin_owner[64];
+static bool spin_kernels_allowed(hip_ctx * c) {
+    if (c->device < 0 || c->device >= 64) return false;
+    if (!g_spin_owner[c->device]) g_spin_owner[c->device] = c;
+    return g_spin_owner[c->device] == c;
+}
+
+static plan_t * build_plan(hip_ctx * c, ggml_cgraph * g, bool keep = true) {
     plan_t * p = new plan_t;
     p->n_nodes = g->n_nodes;
     emitter em = { c, p };
@@ -1762,7 +1789,7 @@ static plan_t * build_plan(hip_ctx * c, ggml_cgraph * g) {
             continue;
         }
         void * ws = nullptr;
-        if (const size_t n = k_attn_decode_ws_size(a)) { ws = em.ws(n); HIP_CHECK(hipMemsetAsync(ws, 0, n, c->stream)); }   // arrival counters start at zero
+        if (const size_t n = k_attn_split_resident(a, c->usable_cus) ? k_attn_decode_ws_size(a) : 0) { ws = em.ws(n); HIP_CHECK(hipMemsetAsync(ws, 0, n, c->stream)); }   // sequence numbers start at zero
         at_pos[ag.emit_pos].insert(at_pos[ag.emit_pos].begin(), [=](hipStream_t s) { k_attn_decode(s, a, ws, err); });
     }
     const bool dump = getenv("MI355X_DUMP_PLAN") != nullptr;
@@ -1781,7 +1808,9 @@ static plan_t * build_plan(hip_ctx * c, ggml_cgraph * g) {
     }
     // Persistent chains: a run of consecutive block mat-vecs each of which waits on its predecessor (the chained Depth transformer,
     // lm.h:446-553: 26 mat-vecs per step, 8 / 16 steps per graph) becomes ONE launch of the chain engine (hip_chain.hip).
-    if (fuse && !(c->flags & 16) && ((c->flags & 32) || k_chain_default_on())) {
+    // (only for plans that are kept - cached graphs, profile mode: a one-off plan is launched once and freed at once, a chain's tables would be built,
+    // uploaded and torn down per compute)
+    if (fuse && keep && !(c->flags & 16) && ((c->flags & 32) || k_chain_default_on()) && spin_kernels_allowed(c)) {
         std::vector<pstep> merged;
         size_t i = 0;
         while (i < p->steps.size()) {
@@ -1792,7 +1821,7 @@ static plan_t * build_plan(hip_ctx * c, ggml_cgraph * g) {
             for (size_t k = i; k < e; k++) run.push_back(p->steps[k].mv);
             size_t k = 0;
             while (k < run.size()) {
-                const int len = k_chain_accept(run.data() + k, (int) (run.size() - k));
+                const int len = k_chain_accept(run.data() + k, (int) (run.size() - k), c->usable_cus);
                 if (len <= 0) {
                     // not the chain engine's: a run of LARGE mat-vecs (a Temporal layer between two attention launches) goes to the stream engine
                     const int slen = (c->flags & 64) || !((c->flags & 128) || k_stream_default_on()) ? 0 : k_stream_accept(run.data() + k, (int) (run.size() - k));
@@ -1809,8 +1838,8 @@ static plan_t * build_plan(hip_ctx * c, ggml_cgraph * g) {
                     }
                     merged.push_back(std::move(p->steps[i + k])); k++; continue;
                 }
-                void * ws = em.ws(k_chain_ws_size(run.data() + k, len));
-                chain_plan * ch = k_chain_create(c->stream, run.data() + k, len, ws, c->err_dev);
+                void * ws = em.ws(k_chain_ws_size(run.data() + k, len, c->usable_cus));
+                chain_plan * ch = k_chain_create(c->stream, run.data() + k, len, ws, c->err_dev, c->usable_cus);
                 p->chains.push_back(ch);
                 merged.push_back(pstep([ch](hipStream_t s) { k_chain_launch(s, ch); }));
                 merged.back().chain = ch;
@@ -1879,7 +1908,7 @@ static enum ggml_status hip_graph_compute(ggml_backend_t backend, struct ggml_cg
     }
     const bool cacheable = g->n_nodes >= 32;
     if (!cacheable) {
-        plan_t * p = build_plan(c, g);
+        plan_t * p = build_plan(c, g, false);
         run_steps(c, p);
         c->stats.kernels_in_last_plan = (int64_t) p->steps.size();
         c->stats.nodes_in_last_plan = p->n_nodes;
@@ -1939,6 +1968,7 @@ static void hip_backend_free(ggml_backend_t b) {
         for (auto & kv : c->plans) plan_free(c, kv.second);
         c->plans.clear();
     }
+    if (c->device >= 0 && c->device < 64 && g_spin_owner[c->device] == c) g_spin_owner[c->device] = nullptr;   // (its plans are gone)
     c->in_use = false;
     delete b;
 }

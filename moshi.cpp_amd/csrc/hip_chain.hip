@@ -26,6 +26,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <type_traits>
+#include <map>
 #include <vector>
 
 #define CH_NCW       8                    // consumer waves per workgroup
@@ -37,6 +38,7 @@
 #define CH_RES_MAX   256                  // rows per workgroup and phase
 #define CH_ATTW      1408                 // floats of attention scratch per consumer wave: 2 heads x (q | k | v) + 2 x 8 slots x 64 products
 #define CH_SPIN_MAX  (1u << 24)
+#define CH_MAX_PHASES 4095                // tag = launch << 12 | phase + 1
 
 typedef unsigned long long u64;
 
@@ -646,6 +648,10 @@ __global__ void __launch_bounds__(CH_THREADS) matvec_chain_kernel(chain_params P
                     part[sb] = d * (float) isum - dmin * (float) msum;
                 }
             }
+            // workgroup 0 wrote the new K / V ring rows of an attention phase with agent-scope stores: they are drained HERE - nothing else of this wave
+            // is in flight at this point, the stores went out a microsecond ago - so that every publication of this phase (st_granule below) and of all
+            // later ones follows them (Guideline 16 R1: sc1 payload, vmcnt(0) in every storing wave, then the signal). Readers touch the rows 26+ phases on.
+            if (is_attn && wg == 0) wait_vmcnt<0>();
             // the next phase's weights go out now: this wave's registers are free again, and the request has the whole hand-off to land in
             if (p + 1 < P.n_phases) { chain_phase nx; read_desc_weights(p + 1, nx); request_weights(nx); }
             CH_STAMP(6);
@@ -767,7 +773,39 @@ __global__ void __launch_bounds__(CH_THREADS) matvec_chain_kernel(chain_params P
 // ---- host side -----------------------------------------------------------------------------------------------------------------
 static int chain_env(const char * name, int def) { const char * v = getenv(name); return v ? atoi(v) : def; }
 bool k_chain_default_on() { static const int on = chain_env("MI355X_CHAIN", 1); return on != 0; }
-static int chain_grid() { static const int g = chain_env("MI355X_CHAIN_GRID", 256); return g < 8 ? 8 : g > 256 ? 256 : g; }
+static size_t chain_smem() { return 16 * XBLK_BYTES + (size_t) (CH_XF_MAX + CH_PART_MAX + CH_RES_MAX + 1024 + CH_NCW * CH_ATTW) * 4 + sizeof(chain_ctl) + 3 * sizeof(chain_phase); }
+// The chain kernel's workgroups spin on each other's granules: ALL of them must be resident at once. The grid is therefore a function of the device (and
+// of the compute units the caller's stream may use): the largest of 256 / 128 / 64 - capped by MI355X_CHAIN_GRID - that
+// hipOccupancyMaxActiveBlocksPerMultiprocessor x usable CUs can hold; 0 when not even 64 fit (partitioned or CU-masked devices): the planner then
+// keeps one launch per mat-vec. MI355X_CHAIN_GRID_FORCE (tests) skips the check.
+static int chain_grid_for(int usable_cus) {
+    static const int want = chain_env("MI355X_CHAIN_GRID", 256), force = chain_env("MI355X_CHAIN_GRID_FORCE", 0);
+    const int cap = want < 8 ? 8 : want > 256 ? 256 : want;
+    if (force) return cap;
+    static std::map<int, int> memo;
+    auto it = memo.find(usable_cus);
+    if (it != memo.end()) return it->second;
+    static bool granted = false;
+    if (!granted) {
+        HIP_CHECK(hipFuncSetAttribute((const void *) matvec_chain_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIP_CHECK(hipFuncSetAttribute((const void *) matvec_chain_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIP_CHECK(hipFuncSetAttribute((const void *) matvec_chain_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        granted = true;
+    }
+    int grid = 0;
+    const int cands[4] = { cap, 256, 128, 64 };
+    for (int k = 0; k < 4 && !grid; k++) {
+        const int g = cands[k];
+        if (g > cap) continue;
+        int per_cu = 0;
+        const void * fn = g == 256 ? (const void *) matvec_chain_kernel<256> : g == 128 ? (const void *) matvec_chain_kernel<128> : (const void *) matvec_chain_kernel<64>;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, CH_THREADS, chain_smem()) != hipSuccess) per_cu = 0;
+        if ((long long) per_cu * usable_cus >= g) grid = g;
+    }
+    if (chain_env("MI355X_CHAIN_VERBOSE", 0)) fprintf(stderr, "chain engine: %d usable CUs -> grid %d\n", usable_cus, grid);
+    memo[usable_cus] = grid;
+    return grid;
+}
 
 struct chain_plan {
     chain_params P;
@@ -784,12 +822,11 @@ static bool overlaps(const void * a, size_t an, const void * b, size_t bn) {
 // (0: none). Rules: every phase but the first waits on its predecessor (x is the predecessor's output, or its embedding index is the
 // predecessor's arg-max) - that is what lets two hand-off buffers alternate by phase parity; anything a phase reads that an earlier phase of
 // the run writes must travel by one of the in-launch mechanisms (hand-off vector, kept rows, arg-max candidates) or the run is cut there.
-static int chain_analyse(const mv_args * mv, int n, std::vector<chain_phase> & out, std::vector<attn_args> & attns) {
-    const int G = chain_grid();
+static int chain_analyse(const mv_args * mv, int n, int G, std::vector<chain_phase> & out, std::vector<attn_args> & attns) {
     out.clear(); attns.clear();
     std::vector<int> res_from;   // phase whose rows a phase adds as its residual (-1: none / memory)
     auto ybytes = [&](int j) { return (size_t) out[(size_t) j].M * 4; };
-    for (int i = 0; i < n; i++) {
+    for (int i = 0; i < n && i < CH_MAX_PHASES; i++) {   // (the hand-off tag keeps 12 bits for the phase index + 1)
         const mv_args & a = mv[i];
         chain_phase ph;
         memset(&ph, 0, sizeof(ph));
@@ -897,27 +934,30 @@ static int chain_analyse(const mv_args * mv, int n, std::vector<chain_phase> & o
         chain_phase & ph = out[(size_t) i];
         const bool next_x = i + 1 < len && out[(size_t) i + 1].x_chain;
         ph.n_pub = next_x ? (ph.pair_F ? (int) ph.pair_F : ph.M) : 0;
-        if (ph.n_pub > CH_XF_MAX || (ph.n_pub & 1)) return chain_analyse(mv, i, out, attns);   // (cannot hand this vector on: end the run in front of it)
+        if (ph.n_pub > CH_XF_MAX || (ph.n_pub & 1)) return chain_analyse(mv, i, G, out, attns);   // (cannot hand this vector on: end the run in front of it)
         if (ph.attn >= 0) na++;
     }
     attns.resize((size_t) na);
     return len;
 }
 
-int k_chain_accept(const mv_args * mv, int n) {
+int k_chain_accept(const mv_args * mv, int n, int usable_cus) {
     static const int min_len = chain_env("MI355X_CHAIN_MIN", 4);
     if (n < min_len) return 0;
+    const int G = chain_grid_for(usable_cus);
+    if (G <= 0) return 0;   // the grid cannot be resident on this device / stream: one launch per mat-vec
     std::vector<chain_phase> ph; std::vector<attn_args> at;
-    const int len = chain_analyse(mv, n, ph, at);
+    const int len = chain_analyse(mv, n, G, ph, at);
     return len >= min_len ? len : 0;
 }
 
 static size_t chain_tables_bytes(int n, int) { return GGML_PAD((size_t) n * sizeof(chain_phase), 256); }
 static size_t chain_state_bytes(int grid) { return 256 + 2 * (size_t) CH_XF_MAX * 8 + 2 * 2 * (size_t) grid * 8; }
-size_t k_chain_ws_size(const mv_args * mv, int n) {
+size_t k_chain_ws_size(const mv_args * mv, int n, int usable_cus) {
     std::vector<chain_phase> ph; std::vector<attn_args> at;
-    const int len = chain_analyse(mv, n, ph, at);
-    return chain_tables_bytes(len, (int) at.size()) + chain_state_bytes(chain_grid());
+    const int G = chain_grid_for(usable_cus);
+    const int len = chain_analyse(mv, n, G, ph, at);
+    return chain_tables_bytes(len, (int) at.size()) + chain_state_bytes(G);
 }
 
 // which compile-time shape (1..6, see shape_din .. shape_head) a phase matches exactly, 0: none - its shape is read from the descriptor
@@ -941,11 +981,12 @@ static int chain_shape_kind(const chain_phase & ph, int grid) {
     return (on >> k) & 1 ? k : 0;
 }
 
-chain_plan * k_chain_create(hipStream_t s, const mv_args * mv, int n, void * ws, unsigned * err) {
+chain_plan * k_chain_create(hipStream_t s, const mv_args * mv, int n, void * ws, unsigned * err, int usable_cus) {
     chain_plan * c = new chain_plan;
-    const int len = chain_analyse(mv, n, c->phases, c->attns);
+    c->grid = chain_grid_for(usable_cus);
+    GGML_ASSERT(c->grid > 0 && n <= CH_MAX_PHASES);
+    const int len = chain_analyse(mv, n, c->grid, c->phases, c->attns);
     GGML_ASSERT(len == n && "k_chain_create: pass exactly the run k_chain_accept took");
-    c->grid = chain_grid();
     char * base = (char *) ws;
     chain_phase * d_ph = (chain_phase *) base;
     char * state = base + chain_tables_bytes(n, (int) c->attns.size());
@@ -959,23 +1000,16 @@ chain_plan * k_chain_create(hipStream_t s, const mv_args * mv, int n, void * ws,
             if (ph.emb_chain) { ph.prev_out[0] = c->phases[(size_t) i - 1].argmax_out[0]; ph.prev_out[1] = c->phases[(size_t) i - 1].argmax_out[1]; }
         }
     }
+    // the table is uploaded from the plan's own vector (pageable memory: the runtime stages it before returning); the host copy lives as long as the plan
     HIP_CHECK(hipMemcpyAsync(d_ph, c->phases.data(), (size_t) n * sizeof(chain_phase), hipMemcpyHostToDevice, s));
     HIP_CHECK(hipMemsetAsync(state, 0, chain_state_bytes(c->grid), s));
-    HIP_CHECK(hipStreamSynchronize(s));   // the host vectors above may go away with the plan
     c->P.phases = d_ph; c->P.n_phases = n;
     c->P.launch_seq = (unsigned *) state;
     c->P.gbuf = (u64 *) (state + 256);
     c->P.cand = c->P.gbuf + 2 * CH_XF_MAX;
     c->P.err = err;
-    c->smem = 16 * XBLK_BYTES + (size_t) (CH_XF_MAX + CH_PART_MAX + CH_RES_MAX + 1024 + CH_NCW * CH_ATTW) * 4 + sizeof(chain_ctl) + 3 * sizeof(chain_phase);
+    c->smem = chain_smem();
     GGML_ASSERT(c->smem <= 160 * 1024);
-    static bool granted = false;
-    if (!granted) {
-        HIP_CHECK(hipFuncSetAttribute((const void *) matvec_chain_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        HIP_CHECK(hipFuncSetAttribute((const void *) matvec_chain_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        HIP_CHECK(hipFuncSetAttribute((const void *) matvec_chain_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        granted = true;
-    }
     return c;
 }
 void k_chain_free(chain_plan * c) { delete c; }

@@ -109,9 +109,11 @@ struct mv_args {
 // a loader wave streaming every phase's weights through an LDS ring ahead of the dependency chain, data-tagged hand-offs between phases.
 struct chain_plan;
 bool   k_chain_default_on();                         // MI355X_CHAIN (default 1; 0 = one launch per mat-vec)
-int    k_chain_accept(const mv_args * mv, int n);     // how many of the n consecutive mat-vecs (in launch order) one chain launch can take (0: none)
-size_t k_chain_ws_size(const mv_args * mv, int n);    // device workspace for exactly that run (tables + hand-off buffers)
-chain_plan * k_chain_create(hipStream_t s, const mv_args * mv, int n, void * ws, unsigned * err);
+// usable_cus: the compute units the launching stream may use (the device's count, or fewer on a CU-masked stream): the engine's workgroups wait for each
+// other, so a chain is only taken when its whole grid is resident there (hipOccupancyMaxActiveBlocksPerMultiprocessor x usable_cus >= grid; 256 / 128 / 64)
+int    k_chain_accept(const mv_args * mv, int n, int usable_cus);     // how many of the n consecutive mat-vecs (in launch order) one chain launch can take (0: none)
+size_t k_chain_ws_size(const mv_args * mv, int n, int usable_cus);    // device workspace for exactly that run (tables + hand-off buffers)
+chain_plan * k_chain_create(hipStream_t s, const mv_args * mv, int n, void * ws, unsigned * err, int usable_cus);
 void   k_chain_launch(hipStream_t s, const chain_plan * c);
 void   k_chain_free(chain_plan * c);
 int    k_chain_length(const chain_plan * c);
@@ -176,6 +178,7 @@ struct attn_args {
 #define ATTN_SPLIT_BIG_MIN 1024   // ... doubled when more than this many slots are live (bench sweeps at 230 / 600 / 2900 live slots)
 #define ATTN_SINGLE_MAX 160       // up to this many live slots the head's first workgroup does everything alone
 size_t k_attn_decode_ws_size(const attn_args & a);
+bool k_attn_split_resident(const attn_args & a, int usable_cus);   // may a head be split over workgroups that wait for each other on this many compute units?
 void k_attn_decode(hipStream_t s, const attn_args & a, void * ws = nullptr, unsigned * err = nullptr);   // *err <- 1 if a head-wide wait timed out
 
 // single-token cross-attention over cached F32 K / V [D, Tc, H] without a mask (moshi_streaming_multihead_cross_attention,

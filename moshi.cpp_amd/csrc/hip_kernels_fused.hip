@@ -2129,6 +2129,27 @@ size_t k_attn_decode_ws_size(const attn_args & a) {
     const size_t S = (size_t) (a.C + attn_split_slots() - 1) / attn_split_slots();
     return 256 + (((size_t) a.H * 4 + 255) & ~(size_t) 255) + (size_t) a.H * a.C * 8 + (size_t) a.H * S * a.D * 16;   // per-head sequence numbers | score granules | partial-output granules
 }
+static size_t attn_smem_bytes(const attn_args & a, bool split, bool wide) {
+    const int Tg = a.n_groups > 1 ? ATTN_MAX_T : a.T;
+    return (size_t) a.C * 4 + (size_t) Tg * a.D * 4 * 3 + (size_t) (split ? attn_split_nw() : wide ? ATTN_NW_WIDE : ATTN_NW_BASE) * 64 * 8 * 8 + 16 + (size_t) Tg * a.C * 4 + (size_t) env_int("MI355X_ATTN_LDS_PAD", 0);
+}
+// The split kernel's workgroups of one head wait for each other (scores, partial outputs): the planner only hands it a workspace - i.e. only splits - when
+// the WHOLE grid (H x ceil(C / slots) workgroups) can be resident on the compute units the stream may use; otherwise a head stays one workgroup (correct at
+// every length, slower at long context). HIP promises no dispatch order, so nothing weaker than full residency is assumed.
+bool k_attn_split_resident(const attn_args & a, int usable_cus) {
+    if (!attn_use_split(a)) return false;
+    if (env_int("MI355X_ATTN_SPLIT_FORCE", 0)) return true;
+    const int nw = attn_split_nw();
+    const size_t smem = attn_smem_bytes(a, true, false);
+    const void * fn = nw == 8 ? (const void *) attn_decode_kernel<true, ATTN_NW_WIDE> : (const void *) attn_decode_kernel<true, ATTN_NW_BASE>;
+    if (smem > 64 * 1024 && hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int) smem) != hipSuccess) return false;
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, nw * 64, smem) != hipSuccess) return false;
+    const long long grid = (long long) a.H * ((a.C + attn_split_slots() - 1) / attn_split_slots());
+    const bool ok = (long long) per_cu * usable_cus >= grid;
+    if (env_int("MI355X_CHAIN_VERBOSE", 0)) fprintf(stderr, "split attention: grid %lld, %d per CU x %d CUs -> %s\n", grid, per_cu, usable_cus, ok ? "split" : "one workgroup per head");
+    return ok;
+}
 void k_attn_decode(hipStream_t s, const attn_args & a, void * ws, unsigned * err) {
     const int Tg = a.n_groups > 1 ? ATTN_MAX_T : a.T;   // rows per workgroup
     GGML_ASSERT(a.D % 8 == 0 && 64 % (a.D / 8) == 0 && a.D <= 512 && a.T >= 1 && Tg <= ATTN_MAX_T && Tg * a.D <= 2 * ATTN_NW_BASE * 64);
@@ -2137,7 +2158,7 @@ void k_attn_decode(hipStream_t s, const attn_args & a, void * ws, unsigned * err
     const bool wide = wide_on && a.D <= 64 && a.C >= 128;
     const bool split = ws && attn_use_split(a);
     const int split_nw = attn_split_nw();
-    const size_t smem = (size_t) a.C * 4 + (size_t) Tg * a.D * 4 * 3 + (size_t) (split ? split_nw : wide ? ATTN_NW_WIDE : ATTN_NW_BASE) * 64 * 8 * 8 + 16 + (size_t) Tg * a.C * 4 + (size_t) env_int("MI355X_ATTN_LDS_PAD", 0);
+    const size_t smem = attn_smem_bytes(a, split, wide);
     GGML_ASSERT(smem <= 160 * 1024);
     if (smem > 64 * 1024) {   // > 64 KB of dynamic LDS needs a one-time opt-in per kernel
         static size_t granted[4] = { 0, 0, 0, 0 };

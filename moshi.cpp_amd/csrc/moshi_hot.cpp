@@ -142,13 +142,24 @@ struct Weights {
 
     // the name a tensor carries inside the context and inside a GGUF file: the checkpoint name when it fits ggml's name field, else an 8-digit hex
     // digest of it (WeightLoader::tensor_name, loader.h:120-137: names longer than GGML_MAX_NAME are replaced by a CRC) - unique either way
+    // Byte-identical to the reference: the digest is the IEEE 802.3 CRC-32 of the name (src/crc-bbf.h: width 32, poly 0x04c11db7, reflected in and
+    // out, xor-in / xor-out 0xffffffff - i.e. zlib's crc32, restated here in its reflected bit-serial form) and the eight characters are what
+    // loader.h:128-135 prints: character i is the LOW nibble of byte i of the 64-bit crc_t (the high-nibble assignment of that loop is overwritten),
+    // so a name becomes four hex digits followed by "0000". Files written by the reference's tools therefore resolve here and vice versa.
+    static uint32_t name_crc32(const std::string & name) {
+        uint32_t crc = 0xffffffffu;
+        for (unsigned char ch : name) {
+            crc ^= ch;
+            for (int b = 0; b < 8; b++) crc = (crc >> 1) ^ (0xedb88320u & (0u - (crc & 1u)));
+        }
+        return crc ^ 0xffffffffu;
+    }
     static std::string file_name(const std::string & name) {
         if (name.size() < GGML_MAX_NAME) return name;
-        uint32_t h = 2166136261u;
-        for (unsigned char ch : name) { h ^= ch; h *= 16777619u; }
-        char buf[16];
-        snprintf(buf, sizeof(buf), "%08x", h);
-        return buf;
+        uint64_t crc = name_crc32(name);
+        std::string out(8, '0');
+        for (int i = 0; i < 8; i++) { out[(size_t) i] = "0123456789abcdef"[crc & 0xf]; crc >>= 8; }
+        return out;
     }
     std::string gguf_path;     // non-empty: load() reads every tensor's bytes from this file (WeightLoader::load_gguf, loader.h:235-271) instead of generating them
 
@@ -222,10 +233,17 @@ void Weights::load_gguf() {
     const int n_tensors = (int) gguf_get_n_tensors(gg);
     std::vector<uint8_t> data;
     int found = 0;
+    // Only the tensors this load still has to fill count (tensor-parallel slices were cut from generated matrices above and are not in `todo`). Two long
+    // names can share a digest (the reference keeps 16 bits of the CRC, loader.h:128-135): tensors of one file name are then taken in file order,
+    // which is the order gguf_add_tensor saw them in, i.e. `todo` order - the round trip of a file written from this context stays exact.
+    std::map<std::string, std::deque<T>> want;
+    for (auto & p : todo) want[ggml_get_name(p.t)].push_back(p.t);
     for (int i = 0; i < n_tensors; i++) {
         const char * name = gguf_get_tensor_name(gg, i);
-        T t = ggml_get_tensor(ctx, name);
-        if (!t) continue;                               // (a file may hold more than this configuration uses)
+        auto it = want.find(name);
+        if (it == want.end() || it->second.empty()) continue;   // (a file may hold more than this configuration uses)
+        T t = it->second.front();
+        it->second.pop_front();
         const size_t nbytes = gguf_get_tensor_size(gg, i);
         GGML_ASSERT(gguf_get_tensor_type(gg, i) == t->type && nbytes == ggml_nbytes(t) && "GGUF tensor does not match the configuration");
         data.resize(nbytes);
@@ -1030,6 +1048,11 @@ extern "C" int moshi_hot_save_gguf(moshi_hot_model_t * m, const char * path) {
     const bool ok = gguf_write_to_file(gg, path, false);
     gguf_free(gg);
     return ok ? 1 : 0;
+}
+extern "C" int moshi_hot_tensor_file_name(const char * checkpoint_name, char * out, int n) {
+    const std::string f = Weights::file_name(checkpoint_name);
+    if (out && n > 0) { strncpy(out, f.c_str(), (size_t) n - 1); out[n - 1] = 0; }
+    return (int) f.size();
 }
 static moshi_hot_model_t * create_model(ggml_backend_t backend, const struct moshi_hot_config * cfg, uint64_t seed, const char * gguf_path) {
     moshi_hot_model * m = new moshi_hot_model;

@@ -43,6 +43,7 @@ SIGNATURES = {
     "moshi_hot_free": (None, [P]),
     "moshi_hot_save_gguf": (C.c_int, [P, C.c_char_p]),
     "moshi_hot_create_from_gguf": (P, [P, C.POINTER(Config), C.c_char_p]),
+    "moshi_hot_tensor_file_name": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int]),
     "moshi_hot_mimi_encode": (None, [P, P, P]),
     "moshi_hot_mimi_decode": (None, [P, P, P]),
     "moshi_hot_lm_step": (C.c_int, [P, P, P, P]),

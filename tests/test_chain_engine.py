@@ -105,3 +105,71 @@ def test_sampled_mode_chains_each_step_separately():
         m.free()
     assert out[32][1].chained_matvecs_in_last_plan > 0
     assert_bit_identical(out[16][0], out[32][0], "sampled")
+
+
+CHILD = r"""
+import hashlib, json, sys
+import numpy as np
+sys.path.insert(0, {tests!r})
+import hot_util as hu
+import test_chain_engine as tc
+which = sys.argv[1]
+if which == "depth":
+    cfg = tc.depth_at_real_width()
+    rec, st = tc.run("hip", cfg, 6)
+else:   # a long ring: the Temporal attention would be split over workgroups that wait for each other
+    cfg = hu.hot.tiny(hu.L)
+    cfg.dim, cfg.num_heads, cfg.context = 512, 4, 1200
+    cfg.enable_mimi_encoder = cfg.enable_mimi_decoder = 0
+    m = hu.Model("hip", cfg, seed=0, flags=32)
+    hu.L.moshi_hot_fill_ring(m.m, 0, -1, 5, 1.0)
+    hu.L.moshi_hot_set_context_fill(m.m, 900)
+    rng = np.random.default_rng(3)
+    rec = []
+    for _ in range(4):
+        r, txt, aud = m.lm_step(rng.integers(0, cfg.card, cfg.n_q - cfg.io_dep_q).tolist())
+        rec.append((r, txt, aud, m.read("text_logits", cfg.text_card).copy(), []))
+    st = m.stats()
+    m.free()
+h = hashlib.sha256()
+for r in rec:
+    h.update(repr(r[:3]).encode()); h.update(r[3].tobytes())
+    for d in r[4]: h.update(d.tobytes())
+print(json.dumps({{"digest": h.hexdigest(), "chained": int(st.chained_matvecs_in_last_plan)}}))
+"""
+
+
+def _child(which, env_extra):
+    import json, os, subprocess, sys
+    env = dict(os.environ)
+    env.update(env_extra)
+    tests = os.path.dirname(os.path.abspath(__file__))
+    out = subprocess.run([sys.executable, "-c", CHILD.format(tests=tests), which], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, f"child failed (a bounded wait aborts the process):\n{out.stdout[-2000:]}\n{out.stderr[-4000:]}"
+    return json.loads(out.stdout.strip().splitlines()[-1]), out.stderr
+
+
+@pytest.mark.parametrize("which", ["depth", "long_ring"])
+def test_grids_that_cannot_be_resident_fall_back_to_plain_launches(which):
+    """ADVICE r3 / VERDICT r3 item 6: the chain kernel's (and the split attention's) workgroups wait for each other, so the whole grid must be resident. On a
+    stream confined to 16 compute units (hipExtStreamCreateWithCUMask, MI355X_STREAM_CUS) with the 256-workgroup chain grid asked for, the planner must
+    notice at plan time (hipOccupancyMaxActiveBlocksPerMultiprocessor x usable CUs < grid) and keep one launch per mat-vec / one workgroup per head -
+    same bits, no bounded-wait abort (the reference ignores ggml_status, /root/reference/src/context.h:538-544)."""
+    full, log_full = _child(which, {"MI355X_CHAIN_VERBOSE": "1"})
+    if which == "long_ring":
+        assert "-> split" in log_full, log_full[-1500:]   # (the whole chip holds the split grid: the fast path is what the bench runs)
+    masked, log = _child(which, {"MI355X_STREAM_CUS": "16", "MI355X_CHAIN_GRID": "256", "MI355X_CHAIN_VERBOSE": "1"})
+    assert masked["digest"] == full["digest"], "results on the CU-masked stream differ"
+    if which == "depth":
+        assert full["chained"] > 0 and masked["chained"] == 0, (full, masked)
+        assert "16 usable CUs -> grid 0" in log, log[-1500:]
+    else:
+        assert "one workgroup per head" in log, log[-1500:]
+
+
+def test_a_smaller_chain_grid_is_chosen_when_only_that_fits():
+    # 72 compute units hold the 64-workgroup instance (not 128 / 256): same bits as the full-chip grid
+    full, _ = _child("depth", {})
+    part, log = _child("depth", {"MI355X_STREAM_CUS": "72", "MI355X_CHAIN_VERBOSE": "1"})
+    assert part["digest"] == full["digest"] and part["chained"] > 0, (full, part, log[-800:])
+    assert "72 usable CUs -> grid 64" in log, log[-1500:]

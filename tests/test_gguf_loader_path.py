@@ -73,6 +73,33 @@ def test_a_model_read_back_from_its_gguf_file_is_the_same_model_on_the_host_devi
     src.free(); back.free()
 
 
+def reference_digest(name):
+    """WeightLoader::tensor_name (loader.h:120-137) over src/crc-bbf.h, restated on zlib: crc-bbf is the IEEE CRC-32 (width 32, poly 0x04c11db7, reflected,
+    xor-in / xor-out 0xffffffff) = zlib.crc32; the reference's hex loop keeps the LOW nibble of each of the eight bytes of its 64-bit crc_t."""
+    import zlib
+    if len(name) < 64:                                  # GGML_MAX_NAME
+        return name
+    crc = zlib.crc32(name.encode())
+    return "".join("0123456789abcdef"[(crc >> (8 * i)) & 0xf] for i in range(8))
+
+
+def test_long_tensor_names_become_the_reference_crc_digest():
+    def ours(name):
+        buf = C.create_string_buffer(80)
+        n = L.moshi_hot_tensor_file_name(name.encode(), buf, 80)
+        assert n == len(buf.value)
+        return buf.value.decode()
+    assert reference_digest("123456789" * 8) == "04180000"   # CRC-32 0x8811a440: bytes 40 a4 11 88 -> low nibbles 0 4 1 8, then the four zero bytes of crc_t
+    names = ["lm.transformer.layers.0.self_attn.in_projs.weight", "x" * 63, "x" * 64, "123456789" * 8,
+             "mimi.decoder_transformer.transformer.layers.7.self_attn.out_projs.0.weight.extra.long.suffix",
+             "lm.depformer.layers.5.gating.15.linear_out.weight.and.then.some.more.characters.to.cross.the.limit"]
+    rng = np.random.default_rng(3)
+    names += ["".join(chr(int(c)) for c in rng.integers(33, 127, size=int(n))) for n in rng.integers(64, 200, size=40)]
+    for n in names:
+        assert ours(n) == reference_digest(n), n
+    assert ours("x" * 63) == "x" * 63 and len(ours("x" * 64)) == 8 and ours("x" * 64).endswith("0000")
+
+
 @pytest.mark.gpu
 def test_gguf_checkpoint_uploaded_to_the_device_and_run_against_the_oracle(tmp_path):
     cfg = config()
