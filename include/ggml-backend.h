@@ -117,6 +117,7 @@ struct ggml_mi355x_stats {
     int64_t uploads_batched;     // small tensor_set calls folded into one scatter launch
     int64_t chained_matvecs_in_last_plan;   // block mat-vecs of the last plan that run inside persistent chain launches (hip_chain.hip)
     int64_t streamed_matvecs_planned;  // block mat-vecs placed inside persistent stream launches (hip_stream.hip: the large mat-vecs of a Temporal layer), summed over every plan built so far
+    int64_t attention_folds_planned;   // attention blocks running as the first stage of their out_proj launch (attn_outproj_kernel), summed over every plan built so far
 };
 GGML_API void ggml_backend_mi355x_get_stats(ggml_backend_t backend, struct ggml_mi355x_stats * stats);
 // accumulated HIP-event timings of the dominant kernel (Q4_K mat-vec), collected while flag 8 is set

@@ -322,7 +322,7 @@ struct plan_t {
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
     uint64_t hash = 0;
-    int n_nodes = 0, n_fused = 0, n_chained = 0, n_streamed = 0;
+    int n_nodes = 0, n_fused = 0, n_chained = 0, n_streamed = 0, n_attn_folded = 0;
 };
 
 static void plan_free(hip_ctx * c, plan_t * p) {
@@ -1507,11 +1507,13 @@ static bool match_sampler(const analysis & an, int pos, step_group & grp) {
 // Two such launches from two streams of one device could interleave their dispatch and each keep the other's workgroups off the compute units, so only ONE
 // context per device plans them: the first that asks (the LM stream; the codec stream's graphs have no such runs today). Released with the context.
 static hip_ctx * g_spin_owner[64];
+// (asked only when a plan is about to CONTAIN such a launch: a context that never plans one never claims the device)
 static bool spin_kernels_allowed(hip_ctx * c) {
     if (c->device < 0 || c->device >= 64) return false;
     if (!g_spin_owner[c->device]) g_spin_owner[c->device] = c;
     return g_spin_owner[c->device] == c;
 }
+static bool spin_kernels_possible(const hip_ctx * c) { return c->device >= 0 && c->device < 64 && (!g_spin_owner[c->device] || g_spin_owner[c->device] == c); }
 
 static plan_t * build_plan(hip_ctx * c, ggml_cgraph * g, bool keep = true) {
     plan_t * p = new plan_t;
@@ -1714,6 +1716,27 @@ static plan_t * build_plan(hip_ctx * c, ggml_cgraph * g, bool keep = true) {
                     break;
                 }
             }
+            if (a.prologue == MV_PLAIN && a.wtype == GGML_TYPE_Q4_K && a.ncols == 1 && keep && !(c->flags & 256)) {
+                // x is the output of the layer's single-token attention over a LONG ring (Temporal transformer, transformer.h:543-576): the attention runs as the
+                // first stage of this projection's own 256-workgroup launch (attn_outproj_kernel) instead of as a launch in front of it
+                bool folded = false;
+                for (auto & ag : attn_groups) {
+                    const attn_args & at = ag.a;
+                    if (ag.emit_pos < 0 || (const float *) at.out != a.x || ag.emit_pos > grp.emit_pos || uses_of(an, g->nodes[ag.emit_pos]) != 1) continue;
+                    if (!k_attn_outproj_supported(a, at, c->usable_cus) || !spin_kernels_allowed(c)) continue;
+                    const size_t wn = k_attn_outproj_ws_size(a, at);
+                    void * ws = em.ws(wn);
+                    HIP_CHECK(hipMemsetAsync(ws, 0, wn, c->stream));
+                    unsigned * err = c->err_dev;
+                    const mv_args am = a; const attn_args aa = at;
+                    at_pos[grp.emit_pos].push_back([=](hipStream_t s) { k_attn_outproj(s, am, aa, ws, err); });
+                    ag.emit_pos = -1;
+                    p->n_fused += 1; p->n_attn_folded++; c->stats.attention_folds_planned++;
+                    folded = true;
+                    break;
+                }
+                if (folded) { if (grp.members.size() > 1) p->n_fused += (int) grp.members.size(); continue; }
+            }
             if (!no_pair && a.prologue != MV_GATE_SILU && a.ncols == 1 && a.residual == nullptr && a.res_embed.table == nullptr && a.ticket == nullptr &&
                 a.M % 2 == 0 && k_matvec_pair_ok(a.wtype, a.K, a.M / 2) && grp.emit_pos == i) {
                 // linear_in of a gated FFN whose only readers are the silu(left) * right pair feeding a long linear_out: let every workgroup take
@@ -1810,7 +1833,7 @@ static plan_t * build_plan(hip_ctx * c, ggml_cgraph * g, bool keep = true) {
     // lm.h:446-553: 26 mat-vecs per step, 8 / 16 steps per graph) becomes ONE launch of the chain engine (hip_chain.hip).
     // (only for plans that are kept - cached graphs, profile mode: a one-off plan is launched once and freed at once, a chain's tables would be built,
     // uploaded and torn down per compute)
-    if (fuse && keep && !(c->flags & 16) && ((c->flags & 32) || k_chain_default_on()) && spin_kernels_allowed(c)) {
+    if (fuse && keep && !(c->flags & 16) && ((c->flags & 32) || k_chain_default_on()) && spin_kernels_possible(c)) {
         std::vector<pstep> merged;
         size_t i = 0;
         while (i < p->steps.size()) {
@@ -1821,7 +1844,8 @@ static plan_t * build_plan(hip_ctx * c, ggml_cgraph * g, bool keep = true) {
             for (size_t k = i; k < e; k++) run.push_back(p->steps[k].mv);
             size_t k = 0;
             while (k < run.size()) {
-                const int len = k_chain_accept(run.data() + k, (int) (run.size() - k), c->usable_cus);
+                int len = k_chain_accept(run.data() + k, (int) (run.size() - k), c->usable_cus);
+                if (len > 0 && !spin_kernels_allowed(c)) len = 0;
                 if (len <= 0) {
                     // not the chain engine's: a run of LARGE mat-vecs (a Temporal layer between two attention launches) goes to the stream engine
                     const int slen = (c->flags & 64) || !((c->flags & 128) || k_stream_default_on()) ? 0 : k_stream_accept(run.data() + k, (int) (run.size() - k));

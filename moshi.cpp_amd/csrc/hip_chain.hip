@@ -75,7 +75,6 @@ struct chain_phase {
     int kind;                  // 0: shape read from this descriptor; 1..6: one of the compile-time shapes (shape_din .. shape_head)
     int32_t * prev_out[2];     // emb_chain: where the previous phase's merged arg-max (the token) is stored
     attn_args at;              // MV_ATTN: the attention whose output is x
-    char pad_[8];
 };
 static_assert(sizeof(chain_phase) % 16 == 0 && sizeof(chain_phase) <= 26 * 16, "a descriptor is staged through LDS by 16-byte lanes");
 #define CH_DESC_DWORDS ((int) (sizeof(chain_phase) / 4))

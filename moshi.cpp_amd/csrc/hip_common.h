@@ -169,6 +169,10 @@ struct attn_args {
     // 4 g .. 4 g + 3. Launched twice: write_only = 1 puts every row's K / V into the ring, then all groups attend concurrently
     // (their own rows come from registers, earlier groups' rows from the ring, later rows are masked).
     int n_groups, write_only;
+    // 2 <= T <= 4 new rows (the codec transformers step two 25 Hz frames per call): row_split = 1 gives every query row its own workgroup (blockIdx.y = t).
+    // Every workgroup rotates ALL T new rows (its scores of a later row need the earlier rows' K / V, which it takes from its own LDS, never from the
+    // ring); only the workgroup of row 0 writes the ring. The two rows' score -> soft_max -> P x V chains then run side by side instead of back to back.
+    int row_split;
 };
 // Long rings (C >= ATTN_SPLIT_MIN_C, T = 1) are split over ceil(C / ATTN_SPLIT_SLOTS) workgroups per head; `ws` (zeroed once,
 // k_attn_decode_ws_size bytes) carries scores, partial outputs and the per-head arrival counters between them. ws may be NULL
@@ -180,6 +184,13 @@ struct attn_args {
 size_t k_attn_decode_ws_size(const attn_args & a);
 bool k_attn_split_resident(const attn_args & a, int usable_cus);   // may a head be split over workgroups that wait for each other on this many compute units?
 void k_attn_decode(hipStream_t s, const attn_args & a, void * ws = nullptr, unsigned * err = nullptr);   // *err <- 1 if a head-wide wait timed out
+
+// attention + the mat-vec that consumes it (the Temporal layer's out_proj + residual) as ONE launch of 256 resident workgroups: `a` is the plain Q4_K
+// mat-vec whose x is `at`'s output. supported(): shapes, and whether the whole grid fits the compute units the stream may use (its workgroups wait
+// for each other). ws: k_attn_outproj_ws_size bytes, zeroed once.
+bool   k_attn_outproj_supported(const mv_args & a, const attn_args & at, int usable_cus);
+size_t k_attn_outproj_ws_size(const mv_args & a, const attn_args & at);
+void   k_attn_outproj(hipStream_t s, const mv_args & a, const attn_args & at, void * ws, unsigned * err);
 
 // single-token cross-attention over cached F32 K / V [D, Tc, H] without a mask (moshi_streaming_multihead_cross_attention,
 // transformer.h:714-762): scores = K q (float products, double sums), soft_max(scale * s), out = sum_t p_t V_t; one workgroup per head

@@ -1666,18 +1666,21 @@ struct attn_split_ws { unsigned long long * gscores; unsigned long long * gpart;
 #ifndef ATTN_V_EARLY
 #define ATTN_V_EARLY 0   // A/B (profiles/r03_ab_attn_v_request_point.txt): the later V rows requested with the later K rows (1: fill 2 800 290 frames/s - they compete with the K rows the scores wait for) or behind the scores (0: 319)
 #endif
-template <bool SPLIT, int NWA>
-__global__ void __launch_bounds__(NWA * 64) __attribute__((amdgpu_waves_per_eu(2)))   // >= 2 workgroups per CU: the split grid (<= 512) is resident
-attn_decode_kernel(attn_args a_in, attn_split_ws w) {
+// The body of the attention kernels, shared by attn_decode_kernel (one launch per attention block) and attn_outproj_kernel (FOLD: the Temporal layer's
+// attention as the first stage of its out_proj launch, below). h / s_idx: the head and the part of the head this workgroup takes (S parts per head);
+// group_y: blockIdx.y of the batched-prefill launches. FOLD: the merged output of head h is ALSO published as 8-byte {fold_tag, value} granules at
+// fold_out[h * D + j] (Guideline 16 R2) for the mat-vec stage of every workgroup of the launch. Returns when this workgroup has no (more) part in it.
+template <bool SPLIT, int NWA, bool FOLD>
+__device__ __forceinline__ void attn_decode_body(const attn_args & a_in, const attn_split_ws & w, char * smem, const int h, const int s_idx, const int group_y,
+                                                 unsigned long long * fold_out, const unsigned fold_tag) {
     constexpr int ATTN_NW = NWA, ATTN_THREADS = NWA * 64;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
 #if defined(MV_LOG)
     unsigned at_log_id = 0;
 #endif
     AT_STAMP(0);
     attn_args a = a_in;
     if (!SPLIT && a.n_groups > 1) {   // rows 4 g .. 4 g + 3 of a longer block
-        const int t0 = 4 * (int) blockIdx.y;
+        const int t0 = 4 * group_y;
         a.T = a.T - t0 < 4 ? a.T - t0 : 4;
         a.q += (int64_t) t0 * a.q_ts; a.k += (int64_t) t0 * a.k_ts; a.v += (int64_t) t0 * a.v_ts;
         if (a.rot) a.rot += (int64_t) t0 * a.D;
@@ -1692,7 +1695,6 @@ attn_decode_kernel(attn_args a_in, attn_split_ws w) {
     constexpr int NPRE = ATTN_NPRE;   // A/B at bench level: 4 beats 2 and 8 for the split kernel at empty, 600-slot and full context (registers vs round trips)
     const int D = SPLIT ? 128 : a.D, C = a.C, T = SPLIT ? 1 : a.T;   // (attn_use_split: one query row, 128-wide heads - known to the compiler)
     const int S = SPLIT ? w.S : 1;
-    const int h = SPLIT ? (int) blockIdx.x / S : (int) blockIdx.x, s_idx = SPLIT ? (int) blockIdx.x % S : 0;
     // the range a workgroup owns adapts to the live length: w.slots (small) up to w.big_min live slots, twice that beyond - short
     // ranges cut the per-workgroup round trips at a few hundred slots, long ones the number of participants at a few thousand.
     // The grid is sized for the small range; with the big one the upper half of a head's workgroups simply leaves after the scan.
@@ -1766,6 +1768,7 @@ attn_decode_kernel(attn_args a_in, attn_split_ws w) {
     // A split workgroup other than the head's first only has work when something at or beyond its first slot is live; that
     // same scan yields n_end. It finds out BEFORE touching the ring (at short context 11 of 12 workgroups leave here).
     int n_end = 0;
+    if (FOLD && !SPLIT && s_idx > 0) return;   // (a short ring: the head's first workgroup does everything, the other parts go straight to the mat-vec stage)
     if (SPLIT && s_idx > 0) {
         n_end = block_max_i32(scan_last_live(c_base)) + 1;      // exact whenever it exceeds c_base, which is all that matters below
         if (n_end > w.big_min) { SLOTS *= 2; c_base = s_idx * SLOTS; }
@@ -1847,7 +1850,7 @@ attn_decode_kernel(attn_args a_in, attn_split_ws w) {
             knew[e] = bf2f(kb);
             vnew[e] = bf2f(vb);
             const int slot = slot_t[t < ATTN_MAX_T ? t : 0];
-            if (s_idx == 0 && slot >= 0 && slot < C) {
+            if (s_idx == 0 && (SPLIT || !a.row_split || group_y == 0) && slot >= 0 && slot < C) {
                 ((uint16_t *) (kc + (int64_t) slot * a.k_nb1))[j] = kb;
                 ((uint16_t *) (vc + (int64_t) slot * a.v_nb1))[j] = vb;
             }
@@ -1876,7 +1879,8 @@ attn_decode_kernel(attn_args a_in, attn_split_ws w) {
     }
     AT_STAMP(8);
 
-    for (int t = 0; t < T; t++) {
+    const int t_first = (!SPLIT && a.row_split) ? group_y : 0, t_last = (!SPLIT && a.row_split) ? group_y + 1 : T;   // (row_split: this workgroup's query row only)
+    for (int t = t_first; t < t_last; t++) {
         const float * mask = msk + t * C;
         // 2. scores
         float qv[8];
@@ -2082,7 +2086,10 @@ attn_decode_kernel(attn_args a_in, attn_split_ws w) {
                 const unsigned long long bits = (unsigned long long) __double_as_longlong(tot);
                 __hip_atomic_store(gp, ((unsigned long long) tag << 32) | (bits & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_store(gp + 1, ((unsigned long long) tag << 32) | (bits >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            } else a.out[(int64_t) t * a.out_ts + (int64_t) h * D + j] = (float) tot;
+            } else {
+                a.out[(int64_t) t * a.out_ts + (int64_t) h * D + j] = (float) tot;
+                if (FOLD) __hip_atomic_store(fold_out + (int64_t) h * D + j, ((unsigned long long) fold_tag << 32) | (unsigned long long) __float_as_uint((float) tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
         if (multi && s_idx == 0) {
             // the head's first workgroup adds the P partial outputs in slot order (its own included: read back like the others), polling each granule pair
@@ -2111,6 +2118,7 @@ attn_decode_kernel(attn_args a_in, attn_split_ws w) {
                     for (int u = 0; u < 8; u++) if (q0 + u < P) tot += __longlong_as_double((long long) ((lo[u] & 0xffffffffull) | (hi[u] << 32)));   // slot order
                 }
                 a.out[(int64_t) t * a.out_ts + (int64_t) h * D + j] = (float) tot;
+                if (FOLD) __hip_atomic_store(fold_out + (int64_t) h * D + j, ((unsigned long long) fold_tag << 32) | (unsigned long long) __float_as_uint((float) tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             __syncthreads();
             if (tid == 0) w.seq[h] = tag;   // (plain store: read by the next launch)
@@ -2118,6 +2126,14 @@ attn_decode_kernel(attn_args a_in, attn_split_ws w) {
         __syncthreads();
     }
     AT_STAMP(7);
+}
+
+template <bool SPLIT, int NWA>
+__global__ void __launch_bounds__(NWA * 64) __attribute__((amdgpu_waves_per_eu(2)))   // >= 2 workgroups per CU: the split grid (<= 512) is resident
+attn_decode_kernel(attn_args a_in, attn_split_ws w) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int S = SPLIT ? w.S : 1;
+    attn_decode_body<SPLIT, NWA, false>(a_in, w, smem, SPLIT ? (int) blockIdx.x / S : (int) blockIdx.x, SPLIT ? (int) blockIdx.x % S : 0, (int) blockIdx.y, nullptr, 0u);
 }
 
 static bool attn_use_split(const attn_args & a) { return a.T == 1 && a.n_groups <= 1 && a.D == 128 && a.C >= ATTN_SPLIT_MIN_C; }
@@ -2184,9 +2200,239 @@ void k_attn_decode(hipStream_t s, const attn_args & a, void * ws, unsigned * err
         else               attn_decode_kernel<true, ATTN_NW_BASE><<<a.H * S, ATTN_NW_BASE * 64, smem, s>>>(a, w);
         return;
     }
-    const dim3 grid((unsigned) a.H, (unsigned) (a.n_groups > 1 ? a.n_groups : 1));
-    if (wide) attn_decode_kernel<false, ATTN_NW_WIDE><<<grid, ATTN_NW_WIDE * 64, smem, s>>>(a, w);
-    else      attn_decode_kernel<false, ATTN_NW_BASE><<<grid, ATTN_NW_BASE * 64, smem, s>>>(a, w);
+    static const int row_split_on = env_int("MI355X_ATTN_ROW_SPLIT", 1);
+    attn_args b = a;
+    b.row_split = row_split_on && a.n_groups <= 1 && a.T >= 2 && a.T <= ATTN_MAX_T && !a.write_only ? 1 : 0;
+    const dim3 grid((unsigned) a.H, (unsigned) (a.n_groups > 1 ? a.n_groups : b.row_split ? a.T : 1));
+    if (wide) attn_decode_kernel<false, ATTN_NW_WIDE><<<grid, ATTN_NW_WIDE * 64, smem, s>>>(b, w);
+    else      attn_decode_kernel<false, ATTN_NW_BASE><<<grid, ATTN_NW_BASE * 64, smem, s>>>(b, w);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// attention + out_proj as ONE launch (the Temporal layer, transformer.h:543-576 + 910-971: SDPA over the ring, then out_proj + residual)
+//
+// As separate launches the pair costs 7.2 us (attention, almost no bytes at short context) + 2.3 us of boundary + 4.6 us (out_proj, 9.4 MB) per layer. Here
+// the mat-vec's own grid - 256 workgroups of 8 waves, one per CU, workgroup g owning rows [g M / 256, (g + 1) M / 256) - runs the attention as its first
+// stage: workgroup g is part g / H of head g % H (so the parts of a head are 8 apart x 4 = on one XCD under round-robin placement: speed only), exactly
+// attn_decode_body's split geometry with S = 256 / H parts per head - the head's first part alone up to ATTN_SINGLE_MAX live slots, the tagged score /
+// partial-output hand-offs beyond. The head's merged output then travels as 8-byte {tag, value} granules (Guideline 16 R2), every workgroup sweeps the K
+// values into registers, quantises them to Q8_K and dots them with its weight rows, which it requested straight into registers (8 lanes per super-block:
+// the WS = 1 arithmetic of matvec_q4k_kernel, bit-identical partials) when it left the attention stage - they land during the hand-off, which a kernel
+// boundary cannot do. tag = a launch counter kept in the workspace + 1: every workgroup reads it first thing, adds itself to an arrival counter once it
+// has, and the workgroup whose add is the last of the launch bumps it - so the bump can never overtake a late starter's read.
+// All 256 workgroups wait for the 32 mergers: the grid must be resident (k_attn_outproj_supported checks the occupancy against the stream's CUs).
+// ---------------------------------------------------------------------------------------------------
+#define FOLD_NW 8
+#define FOLD_GRID 256
+#define FOLD_PMAX 4      // passes of 64 super-blocks a workgroup holds in registers: rows_wg * nb <= 256
+struct fold_ws { unsigned long long * gbuf; unsigned * seq; unsigned * arrive; unsigned * err; };
+#if defined(MV_LOG)
+#define FD_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) { unsigned long long t_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); g_fold_log[fd_id][i] = t_; } } while (0)
+__device__ unsigned long long g_fold_log[4096][8];
+__device__ unsigned g_fold_launch;
+extern "C" __attribute__((visibility("default"))) int mi355x_fold_log_read(unsigned long long * out, int max_records) {
+    unsigned n = 0;
+    if (hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_fold_launch), 4) != hipSuccess) return -1;
+    const int m = (int) (n < 4096u ? n : 4096u) < max_records ? (int) (n < 4096u ? n : 4096u) : max_records;
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fold_log), (size_t) m * 8 * 8) != hipSuccess) return -1;
+    const unsigned z = 0; (void) hipMemcpyToSymbol(HIP_SYMBOL(g_fold_launch), &z, 4);
+    return (int) n;
+}
+#else
+#define FD_STAMP(i) do {} while (0)
+#endif
+
+template <bool SPLIT>
+__global__ void __launch_bounds__(FOLD_NW * 64) attn_outproj_kernel(mv_args a, attn_args at, attn_split_ws w, fold_ws f, int rows_wg) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wg = blockIdx.x, H = at.H;
+#if defined(MV_LOG)
+    __shared__ unsigned fd_id_s;
+    if (wg == 0 && tid == 0) fd_id_s = atomicAdd(&g_fold_launch, 1u) & 4095u;
+    __syncthreads();
+    const unsigned fd_id = wg == 0 ? fd_id_s : 0u;
+#endif
+    FD_STAMP(0);
+    // the launch counter: the kernel's first load, in every thread (one request per wave); it is back with the first data the attention stage waits for
+    const unsigned seq = __hip_atomic_load(f.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned tag = seq + 1u;
+
+    // ---- stage 1: the attention of head wg % H, part wg / H
+    attn_decode_body<SPLIT, FOLD_NW, true>(at, w, smem, wg % H, wg / H, 0, f.gbuf, tag);
+    FD_STAMP(1);
+
+    // ---- stage 2: this workgroup's weight rows -> registers (in flight across the hand-off), the residual of its rows behind them
+    const int nb = (int) (a.K / 256);
+    const int64_t row0 = (int64_t) wg * rows_wg;
+    const int nblk = rows_wg * nb;
+    const u32x4 * wsrc = (const u32x4 *) (a.w + row0 * a.row_bytes);
+    u32x4 wh[FOLD_PMAX], wq[FOLD_PMAX];
+#pragma unroll
+    for (int ps = 0; ps < FOLD_PMAX; ps++) {
+        const int sb = ps * (FOLD_NW * 8) + wave * 8 + (lane >> 3);
+        const u32x4 * src = wsrc + (sb < nblk ? sb : nblk - 1) * 9;
+        wh[ps] = __builtin_nontemporal_load(src);
+        wq[ps] = __builtin_nontemporal_load(src + 1 + (lane & 7));
+    }
+    float res_pre = 0.f;
+    {
+        const int rr = tid >> 4;
+        const float * rp = a.residual ? a.residual : a.y;   // (no branch around a load)
+        res_pre = rp[row0 + (rr < rows_wg ? rr : 0)];
+    }
+    // this workgroup has read the launch counter (its value fed the stage above): arrive. The add's result is looked at after the mat-vec.
+    unsigned arrived = 0u;
+    if (tid == 0) { asm volatile("" :: "v"(seq) : "memory"); arrived = __hip_atomic_fetch_add(f.arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- stage 3: sweep the K attention outputs (block b = 256 values = lane l's granules 4 l .. 4 l + 3 = two 16-byte agent-scope loads; waves take
+    // blocks w and w + 8), quantise to Q8_K in LDS. The attention stage's LDS is free again: every path out of it ends behind a workgroup barrier.
+    xblk * xs = (xblk *) smem;
+    float * part = (float *) (smem + 16 * XBLK_BYTES);
+    const __amdgpu_buffer_rsrc_t gb = __builtin_amdgcn_make_buffer_rsrc((void *) f.gbuf, 0, (int) (a.K * 8), 0x00020000);
+    const bool has0 = wave < nb, has1 = wave + FOLD_NW < nb;
+    u32x4 gq[2][2];
+    gq[0][0] = gq[0][1] = gq[1][0] = gq[1][1] = (u32x4) { 0u, tag, 0u, tag };
+    {
+        unsigned spins = 0;
+        for (;;) {
+            if (has0) {
+                const unsigned o0 = ((unsigned) wave * 256u + (unsigned) lane * 4u) * 8u;
+                gq[0][0] = __builtin_amdgcn_raw_buffer_load_b128(gb, (int) o0, 0, 16); gq[0][1] = __builtin_amdgcn_raw_buffer_load_b128(gb, (int) (o0 + 16u), 0, 16);
+                if (has1) {
+                    const unsigned o1 = o0 + FOLD_NW * 256u * 8u;
+                    gq[1][0] = __builtin_amdgcn_raw_buffer_load_b128(gb, (int) o1, 0, 16); gq[1][1] = __builtin_amdgcn_raw_buffer_load_b128(gb, (int) (o1 + 16u), 0, 16);
+                }
+            }
+            bool ok = true;
+#pragma unroll
+            for (int r = 0; r < 2; r++) ok = ok && gq[r][0].y == tag && gq[r][0].w == tag && gq[r][1].y == tag && gq[r][1].w == tag;
+            if (__all(ok)) break;
+            if (++spins > (1u << 22)) { if (lane == 0 && f.err) *f.err = 4u; break; }   // host-visible: the backend reports it at the next read-back
+            __builtin_amdgcn_s_sleep(1);
+        }
+    }
+    FD_STAMP(2);
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+        const int b = wave + r * FOLD_NW;
+        if (b < nb) {
+            const float v[4] = { __uint_as_float(gq[r][0].x), __uint_as_float(gq[r][0].z), __uint_as_float(gq[r][1].x), __uint_as_float(gq[r][1].z) };
+            quantize_block_q8k(xs + b, v, lane);
+        }
+    }
+    lds_barrier();
+    FD_STAMP(3);
+
+    // ---- stage 4: super-block dots out of the registers (matvec_q4k_kernel's WS = 1 arithmetic)
+#pragma unroll
+    for (int ps = 0; ps < FOLD_PMAX; ps++) {
+        if (ps * (FOLD_NW * 8) >= nblk) break;
+        const int sb = ps * (FOLD_NW * 8) + wave * 8 + (lane >> 3);
+        const int j8 = lane & 7, g32 = j8 >> 1, hf = j8 & 1;
+        const xblk * xb = xs + ((sb < nblk ? sb : nblk - 1) % nb);
+        const uint32_t hw[4] = { wh[ps].x, wh[ps].y, wh[ps].z, wh[ps].w };
+        uint32_t sc[2], mn[2];
+        q4k_unpack_scales_w(hw[1], hw[2], hw[3], sc, mn);
+        const u32x4 ylo = *(const u32x4 *) (xb->q + 64 * g32 + 16 * hf), yhi = *(const u32x4 *) (xb->q + 64 * g32 + 32 + 16 * hf);
+        const uint32_t qw[4] = { wq[ps].x, wq[ps].y, wq[ps].z, wq[ps].w }, yl[4] = { ylo.x, ylo.y, ylo.z, ylo.w }, yh[4] = { yhi.x, yhi.y, yhi.z, yhi.w };
+        int lo = 0, hi = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            lo = dot4_i8((int) (qw[k] & 0x0F0F0F0Fu), (int) yl[k], lo);
+            hi = dot4_i8((int) ((qw[k] >> 4) & 0x0F0F0F0Fu), (int) yh[k], hi);
+        }
+        const int i0 = 2 * g32, i1 = 2 * g32 + 1;
+        const int s0 = (int) ((sc[i0 >> 2] >> (8 * (i0 & 3))) & 0xff), s1 = (int) ((sc[i1 >> 2] >> (8 * (i1 & 3))) & 0xff);
+        int isum = __mul24(s0, lo) + __mul24(s1, hi);
+        const uint32_t bs2 = *(const uint32_t *) (xb->bsums + 2 * j8);
+        const int bs = (int) (int16_t) (bs2 & 0xffff) + (int) (int16_t) (bs2 >> 16);
+        int msum = __mul24((int) ((mn[j8 >> 2] >> (8 * (j8 & 3))) & 0xff), bs);
+        isum += dpp_i32<DPP_QUAD_XOR1>(isum); msum += dpp_i32<DPP_QUAD_XOR1>(msum);
+        isum += dpp_i32<DPP_QUAD_XOR2>(isum); msum += dpp_i32<DPP_QUAD_XOR2>(msum);
+        isum += dpp_i32<DPP_HALF_MIRROR>(isum); msum += dpp_i32<DPP_HALF_MIRROR>(msum);
+        if (j8 == 0 && sb < nblk) {
+            const float d = h2f((uint16_t) (hw[0] & 0xffff)) * xb->d, dmin = h2f((uint16_t) (hw[0] >> 16)) * xb->d;
+            part[sb] = d * (float) isum - dmin * (float) msum;
+        }
+    }
+    lds_barrier();
+    FD_STAMP(4);
+
+    // ---- stage 5: fixed-order row sums (+ residual): 16 lanes per row, as matvec_q4k_kernel's phase 4
+    for (int rr = tid >> 4, kq = 0; rr < rows_wg; rr += FOLD_NW * 4, kq++) {
+        float sum = 0.f;
+        for (int j = tid & 15; j < nb; j += 16) sum += part[rr * nb + j];
+        sum = row16_allsum_f32(sum);
+        if ((tid & 15) == 0) {
+            const int64_t row = row0 + rr;
+            if (a.residual) sum = (kq == 0 ? res_pre : a.residual[row]) + sum;
+            a.y[row] = sum;
+        }
+    }
+    // the workgroup whose arrival was the launch's last bumps the launch counter: every workgroup has read it by then
+    if (tid == 0 && arrived + 1u == tag * (unsigned) gridDim.x) __hip_atomic_store(f.seq, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    FD_STAMP(5);
+}
+
+static int fold_split_S(const attn_args & at) { return FOLD_GRID / at.H; }
+// may the attention stage split a head over its S parts? (the 8-wave split geometry: ranges of `slots` up to big_min live slots, twice that beyond)
+static bool fold_use_split(const attn_args & at) {
+    if (!attn_use_split(at)) return false;
+    static const int big_min = env_int("MI355X_ATTN_BIG_MIN", ATTN_SPLIT_BIG_MIN);
+    const int S = fold_split_S(at), slots = env_int("MI355X_FOLD_SLOTS", 192);
+    return (int64_t) S * slots >= (at.C < big_min ? at.C : big_min) && (int64_t) 2 * S * slots >= at.C;
+}
+static size_t fold_smem_bytes(const attn_args & at, const mv_args & a) {
+    const size_t attn = (size_t) at.C * 4 + (size_t) at.T * at.D * 4 * 3 + (size_t) FOLD_NW * 64 * 8 * 8 + 16 + (size_t) at.T * at.C * 4;
+    const size_t mv = 16 * XBLK_BYTES + (size_t) (a.M / FOLD_GRID) * (size_t) (a.K / 256) * 4;
+    return ((attn > mv ? attn : mv) + 15) & ~(size_t) 15;
+}
+bool k_attn_outproj_supported(const mv_args & a, const attn_args & at, int usable_cus) {
+    static const int on = env_int("MI355X_ATTN_FOLD", 1);
+    if (!on) return false;
+    if (a.wtype != GGML_TYPE_Q4_K || a.ncols != 1 || a.prologue != MV_PLAIN || a.pair_F || a.x_out || a.out_scale || a.out_act || a.ticket || a.res_embed.table ||
+        a.argmax_out[0] || a.argmax_out[1]) return false;
+    if (a.K % 256 != 0 || a.K > 4096 || a.row_bytes != (a.K / 256) * 144 || ((uintptr_t) a.w & 15) || a.M % FOLD_GRID != 0) return false;
+    if ((a.M / FOLD_GRID) * (a.K / 256) > FOLD_PMAX * FOLD_NW * 8 || a.M / FOLD_GRID > FOLD_NW * 4) return false;
+    if (at.C <= 32) return false;   // (the Depth transformer's rings of <= 32 slots: attention recomputed per workgroup / chained, hip_chain.hip)
+    if (at.T != 1 || at.n_groups > 1 || (int64_t) at.H * at.D != a.K || (const float *) at.out != a.x || at.out_ts < a.K) return false;
+    if (at.H < 1 || FOLD_GRID % at.H != 0 || at.D % 8 != 0 || 64 % (at.D / 8) != 0 || at.D > 2 * FOLD_NW * 64) return false;
+    const size_t smem = fold_smem_bytes(at, a);
+    if (smem > 160 * 1024) return false;
+    const void * fn = fold_use_split(at) ? (const void *) attn_outproj_kernel<true> : (const void *) attn_outproj_kernel<false>;
+    if (smem > 64 * 1024 && hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int) smem) != hipSuccess) return false;
+    if (env_int("MI355X_FOLD_FORCE", 0)) return true;
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, FOLD_NW * 64, smem) != hipSuccess) return false;
+    return (long long) per_cu * usable_cus >= FOLD_GRID;   // every workgroup waits for the heads' mergers: the whole grid must be resident
+}
+size_t k_attn_outproj_ws_size(const mv_args & a, const attn_args & at) {
+    size_t n = 256 + (size_t) a.K * 8;
+    if (fold_use_split(at)) n += (((size_t) at.H * 4 + 255) & ~(size_t) 255) + (size_t) at.H * at.C * 8 + (size_t) at.H * fold_split_S(at) * at.D * 16;
+    return n;
+}
+// ws: k_attn_outproj_ws_size bytes, zeroed once by the caller (launch counter, arrival counter, granule tags, per-head sequence numbers)
+void k_attn_outproj(hipStream_t s, const mv_args & a, const attn_args & at, void * ws, unsigned * err) {
+    static const int single_max = env_int("MI355X_ATTN_SINGLE_MAX", ATTN_SINGLE_MAX), big_min = env_int("MI355X_ATTN_BIG_MIN", ATTN_SPLIT_BIG_MIN);
+    char * p = (char *) ws;
+    fold_ws f = { (unsigned long long *) (p + 256), (unsigned *) p, (unsigned *) (p + 64), err };
+    p += 256 + (size_t) a.K * 8;
+    const bool split = fold_use_split(at);
+    attn_split_ws w = { nullptr, nullptr, nullptr, 1, err, ATTN_SPLIT_SLOTS, single_max, big_min };
+    if (split) {
+        w.slots = env_int("MI355X_FOLD_SLOTS", 192);
+        w.S = fold_split_S(at);
+        w.seq = (unsigned *) p; p += ((size_t) at.H * 4 + 255) & ~(size_t) 255;
+        w.gscores = (unsigned long long *) p; p += (size_t) at.H * at.C * 8;
+        w.gpart = (unsigned long long *) p;
+    }
+    const size_t smem = fold_smem_bytes(at, a);
+    const int rows_wg = (int) (a.M / FOLD_GRID);
+    if (split) attn_outproj_kernel<true><<<FOLD_GRID, FOLD_NW * 64, smem, s>>>(a, at, w, f, rows_wg);
+    else       attn_outproj_kernel<false><<<FOLD_GRID, FOLD_NW * 64, smem, s>>>(a, at, w, f, rows_wg);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -2270,15 +2516,15 @@ void k_cross_attn(hipStream_t s, const xattn_args & a) {
 // embedding sum: out = (((e_0 + e_1) + e_2) + ...), e_i = dequant(table_i[row idx_i]) * scale_i
 // (src/moshi/models/lm.h:555-584, lm_utils.h:157-170); same left-to-right float order as the graph
 // ---------------------------------------------------------------------------------------------------
-// TYPE: the ggml type every table shares (-1: mixed). With a runtime type the dequantisation is a switch per term, the compiler keeps each term's
-// loads inside its own branch and the 17 terms of the Temporal graph's first kernel become 17 dependent round trips (22 us, every frame, in front of
-// everything else); with the type known the row elements of all terms are requested together.
+// TYPE: the ggml type every table shares (-1: mixed). Three dependent round trips in all - the 17 row indices and scales (uniform addresses: scalar loads),
+// every term's row element, the store - which takes loads that sit in NO branch: dequant_elem's per-type switch (and, inside it, the low / high nibble
+// choice of a Q4_0 byte) made hipcc wait for each term's loads before it issued the next (24 x s_waitcnt vmcnt(0) in a row: 21 us at the head of every
+// Temporal graph, profiles/r03_bench_kernel_trace_summary.txt). With the type a template parameter the element of every term is ONE scale load + ONE
+// quant load whose addresses are plain arithmetic, all requested before the first is looked at. 64-thread workgroups: 64 of them for a 4096-wide row.
 template <int TYPE>
-__global__ void embed_sum_kernel(embed_sum_args a) {
+__global__ void __launch_bounds__(64) embed_sum_kernel(embed_sum_args a) {
     const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= a.K) return;
-    // three dependent round trips in total (indices, rows, done) instead of one per table: the row index and scale of every
-    // term are requested first, then every row element, then the left-to-right sum
     int64_t r[EMBED_SUM_MAX];
     float sc[EMBED_SUM_MAX], v[EMBED_SUM_MAX];
 #pragma unroll
@@ -2287,11 +2533,33 @@ __global__ void embed_sum_kernel(embed_sum_args a) {
         r[t] = *e.index;
         sc[t] = e.scale ? *e.scale : 1.f;
     }
+    if (TYPE == GGML_TYPE_Q4_0 || TYPE == GGML_TYPE_Q8_0) {
+        constexpr int BB = TYPE == GGML_TYPE_Q4_0 ? 18 : 34;
+        const int64_t boff = (i >> 5) * BB;
+        const int j = (int) (i & 31);
+        const int64_t qoff = boff + 2 + (TYPE == GGML_TYPE_Q4_0 ? (j & 15) : j);
+        uint16_t dh[EMBED_SUM_MAX]; uint8_t qb[EMBED_SUM_MAX];
 #pragma unroll
-    for (int t = 0; t < EMBED_SUM_MAX; t++) {
-        const embed_src & e = a.src[t < a.n ? t : 0];
-        if (r[t] < 0 || r[t] >= e.n_rows) r[t] = 0;
-        v[t] = dequant_elem(e.table + r[t] * e.row_bytes, TYPE >= 0 ? TYPE : e.type, i);
+        for (int t = 0; t < EMBED_SUM_MAX; t++) {
+            const embed_src & e = a.src[t < a.n ? t : 0];
+            const int64_t row = (r[t] < 0 || r[t] >= e.n_rows) ? 0 : r[t];
+            const char * base = e.table + row * e.row_bytes;
+            dh[t] = *(const uint16_t *) (base + boff);
+            qb[t] = *(const uint8_t *) (base + qoff);
+        }
+        __builtin_amdgcn_sched_barrier(0);   // every load above is requested before any is consumed
+#pragma unroll
+        for (int t = 0; t < EMBED_SUM_MAX; t++) {
+            if (TYPE == GGML_TYPE_Q4_0) { const int q = j < 16 ? (qb[t] & 0x0F) : (qb[t] >> 4); v[t] = (q - 8) * h2f(dh[t]); }
+            else v[t] = (int8_t) qb[t] * h2f(dh[t]);
+        }
+    } else {
+#pragma unroll
+        for (int t = 0; t < EMBED_SUM_MAX; t++) {
+            const embed_src & e = a.src[t < a.n ? t : 0];
+            if (r[t] < 0 || r[t] >= e.n_rows) r[t] = 0;
+            v[t] = dequant_elem(e.table + r[t] * e.row_bytes, TYPE >= 0 ? TYPE : e.type, i);
+        }
     }
     float acc = 0.f;
 #pragma unroll
@@ -2306,14 +2574,14 @@ __global__ void embed_sum_kernel(embed_sum_args a) {
 void k_embed_sum(hipStream_t s, const embed_sum_args & a) {
     int type = a.n > 0 ? a.src[0].type : -1;
     for (int t = 1; t < a.n; t++) if (a.src[t].type != type) type = -1;
-    const int grid = (int) ((a.K + 255) / 256);
+    const int grid = (int) ((a.K + 63) / 64);
     switch (type) {
-        case GGML_TYPE_Q4_0: embed_sum_kernel<GGML_TYPE_Q4_0><<<grid, 256, 0, s>>>(a); break;
-        case GGML_TYPE_Q8_0: embed_sum_kernel<GGML_TYPE_Q8_0><<<grid, 256, 0, s>>>(a); break;
-        case GGML_TYPE_F32:  embed_sum_kernel<GGML_TYPE_F32><<<grid, 256, 0, s>>>(a); break;
-        case GGML_TYPE_BF16: embed_sum_kernel<GGML_TYPE_BF16><<<grid, 256, 0, s>>>(a); break;
-        case GGML_TYPE_F16:  embed_sum_kernel<GGML_TYPE_F16><<<grid, 256, 0, s>>>(a); break;
-        default:             embed_sum_kernel<-1><<<grid, 256, 0, s>>>(a); break;
+        case GGML_TYPE_Q4_0: embed_sum_kernel<GGML_TYPE_Q4_0><<<grid, 64, 0, s>>>(a); break;
+        case GGML_TYPE_Q8_0: embed_sum_kernel<GGML_TYPE_Q8_0><<<grid, 64, 0, s>>>(a); break;
+        case GGML_TYPE_F32:  embed_sum_kernel<GGML_TYPE_F32><<<grid, 64, 0, s>>>(a); break;
+        case GGML_TYPE_BF16: embed_sum_kernel<GGML_TYPE_BF16><<<grid, 64, 0, s>>>(a); break;
+        case GGML_TYPE_F16:  embed_sum_kernel<GGML_TYPE_F16><<<grid, 64, 0, s>>>(a); break;
+        default:             embed_sum_kernel<-1><<<grid, 64, 0, s>>>(a); break;
     }
 }
 

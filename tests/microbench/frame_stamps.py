@@ -48,3 +48,15 @@ print(f"sum of in-kernel {tot_k:.0f} us, sum of gaps {tot_g:.0f} us")
 if len(sys.argv) > 1:
     for r in rows[:int(sys.argv[1])]:
         print(r)
+# the folded attention + out_proj launches (attn_outproj_kernel): workgroup 0's s_memrealtime stamps - start, attention stage done, K values gathered,
+# quantised, dots done, end
+if hasattr(lib, "mi355x_fold_log_read"):
+    lib.mi355x_fold_log_read.restype = C.c_int
+    fb = (C.c_ulonglong * (4096 * 8))()
+    nf = lib.mi355x_fold_log_read(fb, 4096)
+    if nf > 0:
+        fr = np.frombuffer(fb, np.uint64).reshape(4096, 8)[:min(nf, 4096)].astype(np.int64)
+        fr = fr[-32:]                                    # the last frame's launches
+        d = np.diff(fr[:, :6], axis=1) / 100.0
+        print(f"{nf} folded launches logged; last 32: in-kernel us (workgroup 0) median: attention {np.median(d[:,0]):.2f}  gather {np.median(d[:,1]):.2f}  quantise {np.median(d[:,2]):.2f}  dots {np.median(d[:,3]):.2f}  row sums {np.median(d[:,4]):.2f}  total {np.median(fr[:,5]-fr[:,0])/100.0:.2f}")
+        print("   launch-to-launch period of the folded kernel (us):", np.round(np.median(np.diff(fr[:, 0])) / 100.0, 2))
