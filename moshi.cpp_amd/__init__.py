@@ -57,14 +57,13 @@ class DevProps(C.Structure):
 class Stats(C.Structure):
     _fields_ = [(n, C.c_int64) for n in ("graphs_computed", "graph_replays", "kernels_in_last_plan",
                                          "fused_nodes_in_last_plan", "nodes_in_last_plan", "uploads_batched", "chained_matvecs_in_last_plan",
-                                         "streamed_matvecs_planned", "attention_folds_planned")]
+                                         "attention_folds_planned")]
 
 
 class KernelProfile(C.Structure):
     _fields_ = [("seconds", C.c_double), ("launches", C.c_int64), ("bytes", C.c_int64),
                 ("variant_seconds", C.c_double * 2), ("variant_launches", C.c_int64 * 2), ("variant_bytes", C.c_int64 * 2),
-                ("chain_seconds", C.c_double), ("chain_launches", C.c_int64), ("chain_bytes", C.c_int64), ("chain_phases", C.c_int64),
-                ("stream_seconds", C.c_double), ("stream_launches", C.c_int64), ("stream_bytes", C.c_int64), ("stream_phases", C.c_int64)]
+                ("chain_seconds", C.c_double), ("chain_launches", C.c_int64), ("chain_bytes", C.c_int64), ("chain_phases", C.c_int64)]
 
 
 class GGUFInitParams(C.Structure):

@@ -66,7 +66,6 @@ struct hip_ctx {
     mv_profile prof = { nullptr, 0, 0 };
     double prof_seconds = 0; int64_t prof_launches = 0, prof_bytes = 0;
     double prof_seconds_v[2] = { 0, 0 }; int64_t prof_launches_v[2] = { 0, 0 }, prof_bytes_v[2] = { 0, 0 };   // the same, by kernel variant
-    double prof_stream_seconds = 0; int64_t prof_stream_launches = 0, prof_stream_bytes = 0, prof_stream_phases = 0;   // persistent stream launches (matvec_stream_kernel)
     double prof_chain_seconds = 0; int64_t prof_chain_launches = 0, prof_chain_bytes = 0, prof_chain_phases = 0;   // persistent chain launches (matvec_chain_kernel), stream events
     hipEvent_t chain_ev[2] = { nullptr, nullptr };
     // cached plans keyed by cgraph pointer
@@ -306,7 +305,6 @@ typedef std::function<void(hipStream_t)> step_fn;
 struct pstep {
     step_fn fn; bool is_mv = false; mv_args mv;
     chain_plan * chain = nullptr;   // a persistent chain launch (timed on its own in profile mode)
-    stream_plan * stream = nullptr; // a persistent stream launch (hip_stream.hip; likewise)
     template <typename F> pstep(F f) : fn(std::move(f)) { memset(&mv, 0, sizeof(mv)); }
     pstep(const mv_args & a) : fn([a](hipStream_t s) { k_matvec(s, a); }), is_mv(true), mv(a) {}
 };
@@ -314,7 +312,6 @@ struct pstep {
 struct plan_t {
     std::vector<pstep> steps;
     std::vector<chain_plan *> chains;
-    std::vector<stream_plan *> streams;
     std::vector<std::pair<void *, size_t>> workspaces;
     std::vector<std::unique_ptr<attn_args>> attn_copies;
     std::vector<const ggml_backend_buffer *> buffers;   // every buffer a node / leaf of the planned graph lives in: freeing one orphans the plan
@@ -322,7 +319,7 @@ struct plan_t {
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
     uint64_t hash = 0;
-    int n_nodes = 0, n_fused = 0, n_chained = 0, n_streamed = 0, n_attn_folded = 0;
+    int n_nodes = 0, n_fused = 0, n_chained = 0, n_attn_folded = 0;
 };
 
 static void plan_free(hip_ctx * c, plan_t * p) {
@@ -330,7 +327,6 @@ static void plan_free(hip_ctx * c, plan_t * p) {
     if (p->graph) (void) hipGraphDestroy(p->graph);
     for (auto & w : p->workspaces) pool_free(c, w.first, w.second);
     for (chain_plan * ch : p->chains) k_chain_free(ch);
-    for (stream_plan * sp : p->streams) k_stream_free(sp);
     delete p;
 }
 
@@ -1716,26 +1712,36 @@ static plan_t * build_plan(hip_ctx * c, ggml_cgraph * g, bool keep = true) {
                     break;
                 }
             }
-            if (a.prologue == MV_PLAIN && a.wtype == GGML_TYPE_Q4_K && a.ncols == 1 && keep && !(c->flags & 256)) {
-                // x is the output of the layer's single-token attention over a LONG ring (Temporal transformer, transformer.h:543-576): the attention runs as the
-                // first stage of this projection's own 256-workgroup launch (attn_outproj_kernel) instead of as a launch in front of it
-                bool folded = false;
+            if (a.prologue == MV_RMSNORM && a.wtype == GGML_TYPE_Q4_K && a.ncols == 1 && keep && !(c->flags & 512) && grp.emit_pos == i) {
+                // the Temporal layer's in_proj, read by nothing but the layer's single-token attention over a LONG ring: the attention runs as the TAIL of
+                // the projection's own launch (inproj_attn_kernel) - emitted where the attention stood; no launch is emitted for the projection itself
+                bool merged = false;
                 for (auto & ag : attn_groups) {
                     const attn_args & at = ag.a;
-                    if (ag.emit_pos < 0 || (const float *) at.out != a.x || ag.emit_pos > grp.emit_pos || uses_of(an, g->nodes[ag.emit_pos]) != 1) continue;
-                    if (!k_attn_outproj_supported(a, at, c->usable_cus) || !spin_kernels_allowed(c)) continue;
-                    const size_t wn = k_attn_outproj_ws_size(a, at);
+                    if (ag.emit_pos < 0 || at.q != a.y || ag.emit_pos < grp.emit_pos) continue;
+                    if (!k_inproj_attn_supported(a, at, c->usable_cus)) continue;
+                    // every reader of the projection's output must be inside the attention block
+                    bool private_y = true;
+                    const ggml_tensor * ynode = g->nodes[i];
+                    for (int j = i + 1; j < g->n_nodes && private_y; j++) {
+                        const ggml_tensor * nj = g->nodes[j];
+                        bool reads = false;
+                        for (int sidx = 0; sidx < GGML_MAX_SRC; sidx++) if (nj->src[sidx] == ynode) reads = true;
+                        if (reads && std::find(ag.members.begin(), ag.members.end(), j) == ag.members.end()) private_y = false;
+                    }
+                    if (!private_y || !spin_kernels_allowed(c)) continue;
+                    const mv_args am = a; const attn_args aa = at;
+                    unsigned * err = c->err_dev;
+                    const size_t wn = k_inproj_attn_ws_size(a, at);
                     void * ws = em.ws(wn);
                     HIP_CHECK(hipMemsetAsync(ws, 0, wn, c->stream));
-                    unsigned * err = c->err_dev;
-                    const mv_args am = a; const attn_args aa = at;
-                    at_pos[grp.emit_pos].push_back([=](hipStream_t s) { k_attn_outproj(s, am, aa, ws, err); });
+                    at_pos[ag.emit_pos].insert(at_pos[ag.emit_pos].begin(), [=](hipStream_t s) { k_inproj_attn(s, am, aa, ws, err); });
                     ag.emit_pos = -1;
                     p->n_fused += 1; p->n_attn_folded++; c->stats.attention_folds_planned++;
-                    folded = true;
+                    merged = true;
                     break;
                 }
-                if (folded) { if (grp.members.size() > 1) p->n_fused += (int) grp.members.size(); continue; }
+                if (merged) { if (grp.members.size() > 1) p->n_fused += (int) grp.members.size(); continue; }
             }
             if (!no_pair && a.prologue != MV_GATE_SILU && a.ncols == 1 && a.residual == nullptr && a.res_embed.table == nullptr && a.ticket == nullptr &&
                 a.M % 2 == 0 && k_matvec_pair_ok(a.wtype, a.K, a.M / 2) && grp.emit_pos == i) {
@@ -1847,19 +1853,6 @@ static plan_t * build_plan(hip_ctx * c, ggml_cgraph * g, bool keep = true) {
                 int len = k_chain_accept(run.data() + k, (int) (run.size() - k), c->usable_cus);
                 if (len > 0 && !spin_kernels_allowed(c)) len = 0;
                 if (len <= 0) {
-                    // not the chain engine's: a run of LARGE mat-vecs (a Temporal layer between two attention launches) goes to the stream engine
-                    const int slen = (c->flags & 64) || !((c->flags & 128) || k_stream_default_on()) ? 0 : k_stream_accept(run.data() + k, (int) (run.size() - k));
-                    if (slen > 0) {
-                        void * ws = em.ws(k_stream_ws_size(run.data() + k, slen));
-                        stream_plan * sp = k_stream_create(c->stream, run.data() + k, slen, ws, c->err_dev);
-                        p->streams.push_back(sp);
-                        merged.push_back(pstep([sp](hipStream_t s) { k_stream_launch(s, sp); }));
-                        merged.back().stream = sp;
-                        p->n_streamed += slen; c->stats.streamed_matvecs_planned += slen;
-                        if (dump) fprintf(stderr, "plan: %d consecutive mat-vecs -> one stream launch (%.1f MB of weights)\n", slen, (double) k_stream_weight_bytes(sp) / 1e6);
-                        k += (size_t) slen;
-                        continue;
-                    }
                     merged.push_back(std::move(p->steps[i + k])); k++; continue;
                 }
                 void * ws = em.ws(k_chain_ws_size(run.data() + k, len, c->usable_cus));
@@ -1890,7 +1883,7 @@ static void run_steps_profiled(hip_ctx * c, plan_t * p) {
     c->prof.used = 0;
     k_matvec_set_profile(&c->prof);
     for (auto & st : p->steps) {
-        if (!st.chain && !st.stream) { st.fn(c->stream); continue; }
+        if (!st.chain) { st.fn(c->stream); continue; }
         // a persistent chain launch: one kernel, timed between two stream events
         if (!c->chain_ev[0]) { HIP_CHECK(hipEventCreate(&c->chain_ev[0])); HIP_CHECK(hipEventCreate(&c->chain_ev[1])); }
         HIP_CHECK(hipStreamSynchronize(c->stream));
@@ -1900,8 +1893,7 @@ static void run_steps_profiled(hip_ctx * c, plan_t * p) {
         HIP_CHECK(hipEventSynchronize(c->chain_ev[1]));
         float ms = 0;
         HIP_CHECK(hipEventElapsedTime(&ms, c->chain_ev[0], c->chain_ev[1]));
-        if (st.chain) { c->prof_chain_seconds += (double) ms * 1e-3; c->prof_chain_launches++; c->prof_chain_bytes += k_chain_weight_bytes(st.chain); c->prof_chain_phases += k_chain_length(st.chain); }
-        else { c->prof_stream_seconds += (double) ms * 1e-3; c->prof_stream_launches++; c->prof_stream_bytes += k_stream_weight_bytes(st.stream); c->prof_stream_phases += k_stream_length(st.stream); }
+        c->prof_chain_seconds += (double) ms * 1e-3; c->prof_chain_launches++; c->prof_chain_bytes += k_chain_weight_bytes(st.chain); c->prof_chain_phases += k_chain_length(st.chain);
     }
     k_matvec_set_profile(nullptr);
     HIP_CHECK(hipStreamSynchronize(c->stream));
@@ -2134,7 +2126,6 @@ extern "C" void ggml_backend_mi355x_get_kernel_profile(ggml_backend_t b, struct 
     hip_ctx * c = ctx_of(b);
     out->seconds = c->prof_seconds; out->launches = c->prof_launches; out->bytes = c->prof_bytes;
     for (int v = 0; v < 2; v++) { out->variant_seconds[v] = c->prof_seconds_v[v]; out->variant_launches[v] = c->prof_launches_v[v]; out->variant_bytes[v] = c->prof_bytes_v[v]; }
-    out->stream_seconds = c->prof_stream_seconds; out->stream_launches = c->prof_stream_launches; out->stream_bytes = c->prof_stream_bytes; out->stream_phases = c->prof_stream_phases;
     out->chain_seconds = c->prof_chain_seconds; out->chain_launches = c->prof_chain_launches; out->chain_bytes = c->prof_chain_bytes; out->chain_phases = c->prof_chain_phases;
 }
 extern "C" void * ggml_backend_mi355x_get_stream(ggml_backend_t b) { hip_ctx * c = ctx_of(b); ctx_init_lazy(c); return (void *) c->stream; }

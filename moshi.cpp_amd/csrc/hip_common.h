@@ -118,17 +118,6 @@ void   k_chain_launch(hipStream_t s, const chain_plan * c);
 void   k_chain_free(chain_plan * c);
 int    k_chain_length(const chain_plan * c);
 int64_t k_chain_weight_bytes(const chain_plan * c);
-// Persistent stream engine (hip_stream.hip): a run of consecutive LARGE Q4_K mat-vecs (the Temporal layer between two attention launches) executed by
-// ONE launch whose weight requests run through the phase boundaries. Same calling pattern as the chain engine.
-struct stream_plan;
-bool   k_stream_default_on();                        // MI355X_STREAM
-int    k_stream_accept(const mv_args * mv, int n);
-size_t k_stream_ws_size(const mv_args * mv, int n);
-stream_plan * k_stream_create(hipStream_t s, const mv_args * mv, int n, void * ws, unsigned * err);
-void   k_stream_launch(hipStream_t s, const stream_plan * c);
-void   k_stream_free(stream_plan * c);
-int    k_stream_length(const stream_plan * c);
-int64_t k_stream_weight_bytes(const stream_plan * c);
 bool k_matvec_supported(int wtype, int64_t K, int64_t M);
 bool k_matvec_pair_ok(int wtype, int64_t K, int64_t F);
 // optional per-launch timing of the dominant kernel (matvec_q4k_kernel) with HIP start/stop events that are
@@ -185,12 +174,12 @@ size_t k_attn_decode_ws_size(const attn_args & a);
 bool k_attn_split_resident(const attn_args & a, int usable_cus);   // may a head be split over workgroups that wait for each other on this many compute units?
 void k_attn_decode(hipStream_t s, const attn_args & a, void * ws = nullptr, unsigned * err = nullptr);   // *err <- 1 if a head-wide wait timed out
 
-// attention + the mat-vec that consumes it (the Temporal layer's out_proj + residual) as ONE launch of 256 resident workgroups: `a` is the plain Q4_K
-// mat-vec whose x is `at`'s output. supported(): shapes, and whether the whole grid fits the compute units the stream may use (its workgroups wait
-// for each other). ws: k_attn_outproj_ws_size bytes, zeroed once.
-bool   k_attn_outproj_supported(const mv_args & a, const attn_args & at, int usable_cus);
-size_t k_attn_outproj_ws_size(const mv_args & a, const attn_args & at);
-void   k_attn_outproj(hipStream_t s, const mv_args & a, const attn_args & at, void * ws, unsigned * err);
+// in_proj + the attention that consumes it as ONE launch of 256 resident workgroups (inproj_attn_kernel): `a` is the RMS-normed Q4_K mat-vec whose output
+// holds `at`'s q | k | v. supported(): shapes, and whether the whole grid fits the compute units the stream may use (the parts of a head wait for each
+// other). ws: k_inproj_attn_ws_size bytes, zeroed once.
+bool   k_inproj_attn_supported(const mv_args & a, const attn_args & at, int usable_cus);
+size_t k_inproj_attn_ws_size(const mv_args & a, const attn_args & at);
+void   k_inproj_attn(hipStream_t s, const mv_args & a, const attn_args & at, void * ws, unsigned * err);
 
 // single-token cross-attention over cached F32 K / V [D, Tc, H] without a mask (moshi_streaming_multihead_cross_attention,
 // transformer.h:714-762): scores = K q (float products, double sums), soft_max(scale * s), out = sum_t p_t V_t; one workgroup per head

@@ -1666,13 +1666,19 @@ struct attn_split_ws { unsigned long long * gscores; unsigned long long * gpart;
 #ifndef ATTN_V_EARLY
 #define ATTN_V_EARLY 0   // A/B (profiles/r03_ab_attn_v_request_point.txt): the later V rows requested with the later K rows (1: fill 2 800 290 frames/s - they compete with the K rows the scores wait for) or behind the scores (0: 319)
 #endif
-// The body of the attention kernels, shared by attn_decode_kernel (one launch per attention block) and attn_outproj_kernel (FOLD: the Temporal layer's
-// attention as the first stage of its out_proj launch, below). h / s_idx: the head and the part of the head this workgroup takes (S parts per head);
-// group_y: blockIdx.y of the batched-prefill launches. FOLD: the merged output of head h is ALSO published as 8-byte {fold_tag, value} granules at
-// fold_out[h * D + j] (Guideline 16 R2) for the mat-vec stage of every workgroup of the launch. Returns when this workgroup has no (more) part in it.
-template <bool SPLIT, int NWA, bool FOLD>
+// The body of the attention kernels, shared by attn_decode_kernel (one launch per attention block) and inproj_attn_kernel (the Temporal layer's attention
+// as the tail of its in_proj launch, below). h / s_idx: the head and the part of the head this workgroup takes (S parts per head); group_y: blockIdx.y of
+// the batched-prefill / row-split launches. Returns when this workgroup has no (more) part in the attention.
+// MODE: AT_PLAIN; AT_GQKV - the new token's q / k / v rows do not come from memory but from 8-byte {gtag, value} granules (Guideline 16 R2) at
+// gq.in[gq.qoff / koff / voff + the element's offset from a.q / a.k / a.v], published by the workgroups of the SAME launch; every thread polls the
+// granules of its own elements.
+#define AT_PLAIN 0
+#define AT_GQKV  2
+struct attn_gqkv { const unsigned long long * in; int64_t qoff, koff, voff; unsigned * err; };
+template <bool SPLIT, int NWA, int MODE>
 __device__ __forceinline__ void attn_decode_body(const attn_args & a_in, const attn_split_ws & w, char * smem, const int h, const int s_idx, const int group_y,
-                                                 unsigned long long * fold_out, const unsigned fold_tag) {
+                                                 const unsigned gtag = 0u, const attn_gqkv gq = attn_gqkv()) {
+    constexpr bool GQKV = (MODE & AT_GQKV) != 0;
     constexpr int ATTN_NW = NWA, ATTN_THREADS = NWA * 64;
 #if defined(MV_LOG)
     unsigned at_log_id = 0;
@@ -1768,7 +1774,7 @@ __device__ __forceinline__ void attn_decode_body(const attn_args & a_in, const a
     // A split workgroup other than the head's first only has work when something at or beyond its first slot is live; that
     // same scan yields n_end. It finds out BEFORE touching the ring (at short context 11 of 12 workgroups leave here).
     int n_end = 0;
-    if (FOLD && !SPLIT && s_idx > 0) return;   // (a short ring: the head's first workgroup does everything, the other parts go straight to the mat-vec stage)
+    if (MODE != AT_PLAIN && !SPLIT && s_idx > 0) return;   // (a short ring: the head's first workgroup does everything, the other parts have no attention work)
     if (SPLIT && s_idx > 0) {
         n_end = block_max_i32(scan_last_live(c_base)) + 1;      // exact whenever it exceeds c_base, which is all that matters below
         if (n_end > w.big_min) { SLOTS *= 2; c_base = s_idx * SLOTS; }
@@ -1790,12 +1796,15 @@ __device__ __forceinline__ void attn_decode_body(const attn_args & a_in, const a
         const float * q = a.q + (int64_t) t * a.q_ts + (int64_t) h * a.q_hs;
         const float * k = a.k + (int64_t) t * a.k_ts + (int64_t) h * a.k_hs;
         const float * v = a.v + (int64_t) t * a.v_ts + (int64_t) h * a.v_hs;
-        in_v[u] = v[j];
+        if (!GQKV) in_v[u] = v[j];
         if (a.rot) {
             const int p = j < half ? j : j - half;
             in_c[u] = a.rot[t * D + p]; in_s[u] = a.rot[t * D + half + p];
-            in_q0[u] = q[2 * p]; in_q1[u] = q[2 * p + 1]; in_k0[u] = k[2 * p]; in_k1[u] = k[2 * p + 1];
-        } else { in_c[u] = 1.f; in_s[u] = 0.f; in_q0[u] = q[j]; in_q1[u] = 0.f; in_k0[u] = k[j]; in_k1[u] = 0.f; }
+            if (!GQKV) { in_q0[u] = q[2 * p]; in_q1[u] = q[2 * p + 1]; in_k0[u] = k[2 * p]; in_k1[u] = k[2 * p + 1]; }
+        } else {
+            in_c[u] = 1.f; in_s[u] = 0.f;
+            if (!GQKV) { in_q0[u] = q[j]; in_q1[u] = 0.f; in_k0[u] = k[j]; in_k1[u] = 0.f; }
+        }
     }
     // The mask row of the head's first workgroup is requested BEFORE the ring rows (and looked at behind them): vector loads return in order, so a scan
     // issued behind the 2 x NPRE ring-row requests only saw its L2-resident mask once those HBM rows had landed (2.9 us from kernel entry to "loads
@@ -1815,6 +1824,35 @@ __device__ __forceinline__ void attn_decode_body(const attn_args & a_in, const a
         const int cc = c < C ? c : C - 1;
         kpre[pi] = *(const uint4 *) (kc + (int64_t) cc * a.k_nb1 + dl * 2);
         if (pi < ATTN_NPRE) vpre[pi] = *(const uint4 *) (vc + (int64_t) cc * a.v_nb1 + dl * 2);   // later V passes: after the scores (registers)
+    }
+    if (GQKV) {
+        // the new rows, from the granules their producers publish (requested behind the ring rows: everything above is in flight while this polls)
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const int e = tid + u * ATTN_THREADS;
+            in_q0[u] = in_q1[u] = in_k0[u] = in_k1[u] = in_v[u] = 0.f;
+            if (e < T * D) {   // (wave-uniform but for the last wave: T * D is a multiple of 64 on this path)
+                const int t = e / D, j = e - t * D, p = j < half ? j : j - half;
+                const int64_t eq = (int64_t) t * a.q_ts + (int64_t) h * a.q_hs, ek = (int64_t) t * a.k_ts + (int64_t) h * a.k_hs, ev = (int64_t) t * a.v_ts + (int64_t) h * a.v_hs;
+                const unsigned long long * gp[5] = { gq.in + gq.qoff + eq + (a.rot ? 2 * p : j), gq.in + gq.qoff + eq + (a.rot ? 2 * p + 1 : j),
+                                                     gq.in + gq.koff + ek + (a.rot ? 2 * p : j), gq.in + gq.koff + ek + (a.rot ? 2 * p + 1 : j), gq.in + gq.voff + ev + j };
+                unsigned long long g[5];
+                int spins = 0;
+                for (;;) {
+#pragma unroll
+                    for (int i = 0; i < 5; i++) g[i] = __hip_atomic_load(gp[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    bool ok = true;
+#pragma unroll
+                    for (int i = 0; i < 5; i++) ok = ok && (unsigned) (g[i] >> 32) == gtag;
+                    if (ok) break;
+                    if (++spins >= (1 << 20)) { if (gq.err) *gq.err = 5u; break; }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                in_q0[u] = __uint_as_float((unsigned) g[0]); in_q1[u] = a.rot ? __uint_as_float((unsigned) g[1]) : 0.f;
+                in_k0[u] = __uint_as_float((unsigned) g[2]); in_k1[u] = a.rot ? __uint_as_float((unsigned) g[3]) : 0.f;
+                in_v[u] = __uint_as_float((unsigned) g[4]);
+            }
+        }
     }
     int last_live = -1;
     if (scan_fast) {
@@ -1920,10 +1958,17 @@ __device__ __forceinline__ void attn_decode_body(const attn_args & a_in, const a
             }
         };
         const int cb_first = c_lo + NPRE * ATTN_NW * SPW;
-        if (SPLIT) request_k_batch(cb_first);
+        // (only when the range reaches beyond the rows requested at entry - wave-uniform: at short context the sixteen clamped re-reads of the range's last
+        // row would sit in the memory pipe in front of every later wait; MI355X_ATTN_LATE_ALWAYS=1 at build time restores the unconditional form)
+#ifndef ATTN_LATE_ALWAYS
+        const bool late_rows = SPLIT && cb_first < c_hi;
+#else
+        const bool late_rows = SPLIT;
+#endif
+        if (late_rows) request_k_batch(cb_first);
         // ... and its later V rows right behind them (registers are there: two workgroups of four waves per CU): they land during the scores and the hand-off
         uint4 vb0[SPLIT ? NB : 1];
-        if (SPLIT && ATTN_V_EARLY) {
+        if (late_rows && ATTN_V_EARLY) {
 #pragma unroll
             for (int pi = 0; pi < NB; pi++) {
                 const int c0 = c_lo + (NPRE + pi) * ATTN_NW * SPW + wave * SPW, c = c0 + sub;
@@ -1947,7 +1992,7 @@ __device__ __forceinline__ void attn_decode_body(const attn_args & a_in, const a
                 }
             }
         }
-        if (SPLIT && !ATTN_V_EARLY) {
+        if (late_rows && !ATTN_V_EARLY) {
 #pragma unroll
             for (int pi = 0; pi < NB; pi++) {
                 const int c0 = c_lo + (NPRE + pi) * ATTN_NW * SPW + wave * SPW, c = c0 + sub;
@@ -2046,7 +2091,7 @@ __device__ __forceinline__ void attn_decode_body(const attn_args & a_in, const a
             const int c0 = c_lo + wave * SPW + pi * ATTN_NW * SPW;
             if (c0 < c_hi) pv_pass(c0, vpre[pi]);
         }
-        if (SPLIT) {
+        if (late_rows) {
 #pragma unroll
             for (int pi = 0; pi < NB; pi++) {
                 const int c0 = c_lo + (NPRE + pi) * ATTN_NW * SPW + wave * SPW, f = fresh_of(c0 + sub);
@@ -2088,7 +2133,6 @@ __device__ __forceinline__ void attn_decode_body(const attn_args & a_in, const a
                 __hip_atomic_store(gp + 1, ((unsigned long long) tag << 32) | (bits >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             } else {
                 a.out[(int64_t) t * a.out_ts + (int64_t) h * D + j] = (float) tot;
-                if (FOLD) __hip_atomic_store(fold_out + (int64_t) h * D + j, ((unsigned long long) fold_tag << 32) | (unsigned long long) __float_as_uint((float) tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
         if (multi && s_idx == 0) {
@@ -2118,7 +2162,6 @@ __device__ __forceinline__ void attn_decode_body(const attn_args & a_in, const a
                     for (int u = 0; u < 8; u++) if (q0 + u < P) tot += __longlong_as_double((long long) ((lo[u] & 0xffffffffull) | (hi[u] << 32)));   // slot order
                 }
                 a.out[(int64_t) t * a.out_ts + (int64_t) h * D + j] = (float) tot;
-                if (FOLD) __hip_atomic_store(fold_out + (int64_t) h * D + j, ((unsigned long long) fold_tag << 32) | (unsigned long long) __float_as_uint((float) tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             __syncthreads();
             if (tid == 0) w.seq[h] = tag;   // (plain store: read by the next launch)
@@ -2133,7 +2176,7 @@ __global__ void __launch_bounds__(NWA * 64) __attribute__((amdgpu_waves_per_eu(2
 attn_decode_kernel(attn_args a_in, attn_split_ws w) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int S = SPLIT ? w.S : 1;
-    attn_decode_body<SPLIT, NWA, false>(a_in, w, smem, SPLIT ? (int) blockIdx.x / S : (int) blockIdx.x, SPLIT ? (int) blockIdx.x % S : 0, (int) blockIdx.y, nullptr, 0u);
+    attn_decode_body<SPLIT, NWA, AT_PLAIN>(a_in, w, smem, SPLIT ? (int) blockIdx.x / S : (int) blockIdx.x, SPLIT ? (int) blockIdx.x % S : 0, (int) blockIdx.y);
 }
 
 static bool attn_use_split(const attn_args & a) { return a.T == 1 && a.n_groups <= 1 && a.D == 128 && a.C >= ATTN_SPLIT_MIN_C; }
@@ -2209,18 +2252,7 @@ void k_attn_decode(hipStream_t s, const attn_args & a, void * ws, unsigned * err
 }
 
 // ---------------------------------------------------------------------------------------------------
-// attention + out_proj as ONE launch (the Temporal layer, transformer.h:543-576 + 910-971: SDPA over the ring, then out_proj + residual)
-//
-// As separate launches the pair costs 7.2 us (attention, almost no bytes at short context) + 2.3 us of boundary + 4.6 us (out_proj, 9.4 MB) per layer. Here
-// the mat-vec's own grid - 256 workgroups of 8 waves, one per CU, workgroup g owning rows [g M / 256, (g + 1) M / 256) - runs the attention as its first
-// stage: workgroup g is part g / H of head g % H (so the parts of a head are 8 apart x 4 = on one XCD under round-robin placement: speed only), exactly
-// attn_decode_body's split geometry with S = 256 / H parts per head - the head's first part alone up to ATTN_SINGLE_MAX live slots, the tagged score /
-// partial-output hand-offs beyond. The head's merged output then travels as 8-byte {tag, value} granules (Guideline 16 R2), every workgroup sweeps the K
-// values into registers, quantises them to Q8_K and dots them with its weight rows, which it requested straight into registers (8 lanes per super-block:
-// the WS = 1 arithmetic of matvec_q4k_kernel, bit-identical partials) when it left the attention stage - they land during the hand-off, which a kernel
-// boundary cannot do. tag = a launch counter kept in the workspace + 1: every workgroup reads it first thing, adds itself to an arrival counter once it
-// has, and the workgroup whose add is the last of the launch bumps it - so the bump can never overtake a late starter's read.
-// All 256 workgroups wait for the 32 mergers: the grid must be resident (k_attn_outproj_supported checks the occupancy against the stream's CUs).
+// merged launches of the Temporal layer: shared definitions (the kernel itself: inproj_attn_kernel below)
 // ---------------------------------------------------------------------------------------------------
 #define FOLD_NW 8
 #define FOLD_GRID 256
@@ -2242,141 +2274,6 @@ extern "C" __attribute__((visibility("default"))) int mi355x_fold_log_read(unsig
 #define FD_STAMP(i) do {} while (0)
 #endif
 
-template <bool SPLIT>
-__global__ void __launch_bounds__(FOLD_NW * 64) attn_outproj_kernel(mv_args a, attn_args at, attn_split_ws w, fold_ws f, int rows_wg) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wg = blockIdx.x, H = at.H;
-#if defined(MV_LOG)
-    __shared__ unsigned fd_id_s;
-    if (wg == 0 && tid == 0) fd_id_s = atomicAdd(&g_fold_launch, 1u) & 4095u;
-    __syncthreads();
-    const unsigned fd_id = wg == 0 ? fd_id_s : 0u;
-#endif
-    FD_STAMP(0);
-    // the launch counter: the kernel's first load, in every thread (one request per wave); it is back with the first data the attention stage waits for
-    const unsigned seq = __hip_atomic_load(f.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const unsigned tag = seq + 1u;
-
-    // ---- stage 1: the attention of head wg % H, part wg / H
-    attn_decode_body<SPLIT, FOLD_NW, true>(at, w, smem, wg % H, wg / H, 0, f.gbuf, tag);
-    FD_STAMP(1);
-
-    // ---- stage 2: this workgroup's weight rows -> registers (in flight across the hand-off), the residual of its rows behind them
-    const int nb = (int) (a.K / 256);
-    const int64_t row0 = (int64_t) wg * rows_wg;
-    const int nblk = rows_wg * nb;
-    const u32x4 * wsrc = (const u32x4 *) (a.w + row0 * a.row_bytes);
-    u32x4 wh[FOLD_PMAX], wq[FOLD_PMAX];
-#pragma unroll
-    for (int ps = 0; ps < FOLD_PMAX; ps++) {
-        const int sb = ps * (FOLD_NW * 8) + wave * 8 + (lane >> 3);
-        const u32x4 * src = wsrc + (sb < nblk ? sb : nblk - 1) * 9;
-        wh[ps] = __builtin_nontemporal_load(src);
-        wq[ps] = __builtin_nontemporal_load(src + 1 + (lane & 7));
-    }
-    float res_pre = 0.f;
-    {
-        const int rr = tid >> 4;
-        const float * rp = a.residual ? a.residual : a.y;   // (no branch around a load)
-        res_pre = rp[row0 + (rr < rows_wg ? rr : 0)];
-    }
-    // this workgroup has read the launch counter (its value fed the stage above): arrive. The add's result is looked at after the mat-vec.
-    unsigned arrived = 0u;
-    if (tid == 0) { asm volatile("" :: "v"(seq) : "memory"); arrived = __hip_atomic_fetch_add(f.arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-    __builtin_amdgcn_sched_barrier(0);
-
-    // ---- stage 3: sweep the K attention outputs (block b = 256 values = lane l's granules 4 l .. 4 l + 3 = two 16-byte agent-scope loads; waves take
-    // blocks w and w + 8), quantise to Q8_K in LDS. The attention stage's LDS is free again: every path out of it ends behind a workgroup barrier.
-    xblk * xs = (xblk *) smem;
-    float * part = (float *) (smem + 16 * XBLK_BYTES);
-    const __amdgpu_buffer_rsrc_t gb = __builtin_amdgcn_make_buffer_rsrc((void *) f.gbuf, 0, (int) (a.K * 8), 0x00020000);
-    const bool has0 = wave < nb, has1 = wave + FOLD_NW < nb;
-    u32x4 gq[2][2];
-    gq[0][0] = gq[0][1] = gq[1][0] = gq[1][1] = (u32x4) { 0u, tag, 0u, tag };
-    {
-        unsigned spins = 0;
-        for (;;) {
-            if (has0) {
-                const unsigned o0 = ((unsigned) wave * 256u + (unsigned) lane * 4u) * 8u;
-                gq[0][0] = __builtin_amdgcn_raw_buffer_load_b128(gb, (int) o0, 0, 16); gq[0][1] = __builtin_amdgcn_raw_buffer_load_b128(gb, (int) (o0 + 16u), 0, 16);
-                if (has1) {
-                    const unsigned o1 = o0 + FOLD_NW * 256u * 8u;
-                    gq[1][0] = __builtin_amdgcn_raw_buffer_load_b128(gb, (int) o1, 0, 16); gq[1][1] = __builtin_amdgcn_raw_buffer_load_b128(gb, (int) (o1 + 16u), 0, 16);
-                }
-            }
-            bool ok = true;
-#pragma unroll
-            for (int r = 0; r < 2; r++) ok = ok && gq[r][0].y == tag && gq[r][0].w == tag && gq[r][1].y == tag && gq[r][1].w == tag;
-            if (__all(ok)) break;
-            if (++spins > (1u << 22)) { if (lane == 0 && f.err) *f.err = 4u; break; }   // host-visible: the backend reports it at the next read-back
-            __builtin_amdgcn_s_sleep(1);
-        }
-    }
-    FD_STAMP(2);
-#pragma unroll
-    for (int r = 0; r < 2; r++) {
-        const int b = wave + r * FOLD_NW;
-        if (b < nb) {
-            const float v[4] = { __uint_as_float(gq[r][0].x), __uint_as_float(gq[r][0].z), __uint_as_float(gq[r][1].x), __uint_as_float(gq[r][1].z) };
-            quantize_block_q8k(xs + b, v, lane);
-        }
-    }
-    lds_barrier();
-    FD_STAMP(3);
-
-    // ---- stage 4: super-block dots out of the registers (matvec_q4k_kernel's WS = 1 arithmetic)
-#pragma unroll
-    for (int ps = 0; ps < FOLD_PMAX; ps++) {
-        if (ps * (FOLD_NW * 8) >= nblk) break;
-        const int sb = ps * (FOLD_NW * 8) + wave * 8 + (lane >> 3);
-        const int j8 = lane & 7, g32 = j8 >> 1, hf = j8 & 1;
-        const xblk * xb = xs + ((sb < nblk ? sb : nblk - 1) % nb);
-        const uint32_t hw[4] = { wh[ps].x, wh[ps].y, wh[ps].z, wh[ps].w };
-        uint32_t sc[2], mn[2];
-        q4k_unpack_scales_w(hw[1], hw[2], hw[3], sc, mn);
-        const u32x4 ylo = *(const u32x4 *) (xb->q + 64 * g32 + 16 * hf), yhi = *(const u32x4 *) (xb->q + 64 * g32 + 32 + 16 * hf);
-        const uint32_t qw[4] = { wq[ps].x, wq[ps].y, wq[ps].z, wq[ps].w }, yl[4] = { ylo.x, ylo.y, ylo.z, ylo.w }, yh[4] = { yhi.x, yhi.y, yhi.z, yhi.w };
-        int lo = 0, hi = 0;
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            lo = dot4_i8((int) (qw[k] & 0x0F0F0F0Fu), (int) yl[k], lo);
-            hi = dot4_i8((int) ((qw[k] >> 4) & 0x0F0F0F0Fu), (int) yh[k], hi);
-        }
-        const int i0 = 2 * g32, i1 = 2 * g32 + 1;
-        const int s0 = (int) ((sc[i0 >> 2] >> (8 * (i0 & 3))) & 0xff), s1 = (int) ((sc[i1 >> 2] >> (8 * (i1 & 3))) & 0xff);
-        int isum = __mul24(s0, lo) + __mul24(s1, hi);
-        const uint32_t bs2 = *(const uint32_t *) (xb->bsums + 2 * j8);
-        const int bs = (int) (int16_t) (bs2 & 0xffff) + (int) (int16_t) (bs2 >> 16);
-        int msum = __mul24((int) ((mn[j8 >> 2] >> (8 * (j8 & 3))) & 0xff), bs);
-        isum += dpp_i32<DPP_QUAD_XOR1>(isum); msum += dpp_i32<DPP_QUAD_XOR1>(msum);
-        isum += dpp_i32<DPP_QUAD_XOR2>(isum); msum += dpp_i32<DPP_QUAD_XOR2>(msum);
-        isum += dpp_i32<DPP_HALF_MIRROR>(isum); msum += dpp_i32<DPP_HALF_MIRROR>(msum);
-        if (j8 == 0 && sb < nblk) {
-            const float d = h2f((uint16_t) (hw[0] & 0xffff)) * xb->d, dmin = h2f((uint16_t) (hw[0] >> 16)) * xb->d;
-            part[sb] = d * (float) isum - dmin * (float) msum;
-        }
-    }
-    lds_barrier();
-    FD_STAMP(4);
-
-    // ---- stage 5: fixed-order row sums (+ residual): 16 lanes per row, as matvec_q4k_kernel's phase 4
-    for (int rr = tid >> 4, kq = 0; rr < rows_wg; rr += FOLD_NW * 4, kq++) {
-        float sum = 0.f;
-        for (int j = tid & 15; j < nb; j += 16) sum += part[rr * nb + j];
-        sum = row16_allsum_f32(sum);
-        if ((tid & 15) == 0) {
-            const int64_t row = row0 + rr;
-            if (a.residual) sum = (kq == 0 ? res_pre : a.residual[row]) + sum;
-            a.y[row] = sum;
-        }
-    }
-    // the workgroup whose arrival was the launch's last bumps the launch counter: every workgroup has read it by then
-    if (tid == 0 && arrived + 1u == tag * (unsigned) gridDim.x) __hip_atomic_store(f.seq, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    FD_STAMP(5);
-}
-
 static int fold_split_S(const attn_args & at) { return FOLD_GRID / at.H; }
 // may the attention stage split a head over its S parts? (the 8-wave split geometry: ranges of `slots` up to big_min live slots, twice that beyond)
 static bool fold_use_split(const attn_args & at) {
@@ -2385,41 +2282,191 @@ static bool fold_use_split(const attn_args & at) {
     const int S = fold_split_S(at), slots = env_int("MI355X_FOLD_SLOTS", 192);
     return (int64_t) S * slots >= (at.C < big_min ? at.C : big_min) && (int64_t) 2 * S * slots >= at.C;
 }
-static size_t fold_smem_bytes(const attn_args & at, const mv_args & a) {
+// ---------------------------------------------------------------------------------------------------
+// in_proj + attention as ONE launch (the Temporal layer, transformer.h:449-576: norm1 -> in_proj -> RoPE -> ring write -> SDPA)
+//
+// As its own launch the attention pays a kernel boundary (2.3 - 2.6 us) and one cold memory round trip for q / k / v before its first useful instruction,
+// 7.3 us in all for almost no bytes at short context. Here it is the TAIL of the in_proj launch: the mat-vec's 256 workgroups are dealt out head-major -
+// workgroup b is part b / H of head b % H and owns rows [16 j, 16 j + 16) of that head's q, k AND v (three row segments of whole tiles; 48 rows = the
+// 12 tiles the plain mapping gives it too) - and run matvec_q4k_kernel<RMSNORM, 8 waves>'s arithmetic on them to the bit (same Q8_K blocks, same tile
+// dots, same 16-lane row sums). Every row sum is written to the in_proj node's storage AND published as an 8-byte {tag, value} granule; the head's
+// workgroups then enter attn_decode_body with the granules as their q / k / v source (AT_GQKV): the ring rows, the mask and the RoPE table are requested
+// first and land while the granules are polled, so the hand-off costs one round trip that the separate launch spent on its cold loads anyway. Split
+// geometry, hand-offs and arithmetic are the attention kernel's own (S = 256 / H parts per head, 8 waves). Workgroups without attention work leave at once.
+// tag = a launch counter in the workspace + 1, read first thing by every workgroup and bumped by the launch's last arriver - so the bump can never overtake a late starter's read.
+// The head's parts wait for each other: the grid must be resident (k_inproj_attn_supported).
+// ---------------------------------------------------------------------------------------------------
+template <bool SPLIT>
+__global__ void __launch_bounds__(FOLD_NW * 64) inproj_attn_kernel(mv_args a, attn_args at, attn_split_ws w, fold_ws f, attn_gqkv gq, int seg_rows, int64_t seg_stride) {
+    constexpr int NW = FOLD_NW, NLOAD = 9, SB = 144, TILE = 64 * SB;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ double sh_red[NW];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x, H = at.H, S = (int) gridDim.x / H;
+    const int h = b % H, part_i = b / H;
+    const int blk = h * S + part_i;                       // head-major: rows [blk * seg_rows, +seg_rows) of each of the three segments
+#if defined(MV_LOG)
+    __shared__ unsigned fd_id_s;
+    if (b == 0 && tid == 0) fd_id_s = atomicAdd(&g_fold_launch, 1u) & 4095u;
+    __syncthreads();
+    const unsigned fd_id = b == 0 ? fd_id_s : 0u;
+#endif
+    FD_STAMP(0);
+    const unsigned seq = __hip_atomic_load(f.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned tag = seq + 1u;
+    const int nb = (int) (a.K / 256), K = (int) a.K;
+    const int rows = 3 * seg_rows, nblk = rows * nb, ntiles = nblk >> 6, tiles_seg = (seg_rows * nb) >> 6;   // (whole tiles per segment: host-checked)
+    xblk * xs = (xblk *) smem;
+    char * stage = smem + nb * XBLK_BYTES + wave * TILE;
+    float * part = (float *) (smem + nb * XBLK_BYTES + NW * TILE);
+    auto tile_src = [&](int t) {   // first 16-byte chunk of tile t
+        const int sg = t / tiles_seg;
+        return (const u32x4 *) (a.w + ((int64_t) sg * seg_stride + (int64_t) blk * seg_rows) * a.row_bytes) + (int64_t) (t - sg * tiles_seg) * (NLOAD * 64);
+    };
+    // ---- mat-vec, phase 1: activation loads, then the first weight tile (matvec_q4k_kernel's order)
+    float4 xv[4], aux[4];
+    bool ok[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int e0 = j * (NW * 256) + tid * 4;
+        ok[j] = e0 < K;
+        const int e = ok[j] ? e0 : K - 4;
+        xv[j] = *(const float4 *) (a.x + e);
+        aux[j] = *(const float4 *) (a.alpha + e);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    u32x4 r[NLOAD];
+    int t = wave;
+    {
+        const bool has_tile = t < ntiles;
+        const u32x4 * src = tile_src(has_tile ? t : 0);
+#pragma unroll
+        for (int i = 0; i < NLOAD; i++) r[i] = __builtin_nontemporal_load(src + (has_tile ? i * 64 + lane : 0));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- phase 2: alpha * rms_norm(x) -> Q8_K blocks (K <= 4096: one batch, the whole vector in registers)
+    {
+        float v[4][4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const float z = ok[j] ? 1.f : 0.f;
+            v[j][0] = xv[j].x * z; v[j][1] = xv[j].y * z; v[j][2] = xv[j].z * z; v[j][3] = xv[j].w * z;
+        }
+        double acc = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+            for (int k = 0; k < 4; k++) acc += (double) (v[j][k] * v[j][k]);
+        acc = wave_allsum_f64(acc);
+        if (lane == 0) sh_red[wave] = acc;
+        __syncthreads();
+        double tot = 0;
+#pragma unroll
+        for (int w_ = 0; w_ < NW; w_++) tot += sh_red[w_];
+        const float mean = (float) (tot / (double) K);
+        const float scale = 1.0f / sqrtf(mean + a.eps);
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const float al[4] = { aux[j].x, aux[j].y, aux[j].z, aux[j].w };
+#pragma unroll
+            for (int k = 0; k < 4; k++) v[j][k] = al[k] * (v[j][k] * scale);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            if (!ok[j]) continue;
+            const int bq = j * NW + wave;
+            if (a.x_out != nullptr && b == 0) *(float4 *) (a.x_out + j * (NW * 256) + tid * 4) = make_float4(v[j][0], v[j][1], v[j][2], v[j][3]);
+            quantize_block_q8k(xs + bq, v[j], lane);
+        }
+    }
+    __syncthreads();
+    FD_STAMP(1);
+    // ---- phase 3: tiles registers -> LDS image -> one super-block per lane (next tile requested first)
+    for (; t < ntiles; t += NW) {
+#pragma unroll
+        for (int i = 0; i < NLOAD; i++) ((u32x4 *) stage)[i * 64 + lane] = r[i];
+        {
+            const int tn = t + NW < ntiles ? t + NW : ntiles - 1;
+            const u32x4 * src = tile_src(tn);
+#pragma unroll
+            for (int i = 0; i < NLOAD; i++) r[i] = __builtin_nontemporal_load(src + i * 64 + lane);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const int bi = t * 64 + lane;
+        const xblk * xb = xs + (bi % nb);
+        part[bi] = q4k_q8k_block_dot((const block_q4_K *) (stage + lane * SB), xb->q, xb->bsums, xb->d);
+        __builtin_amdgcn_wave_barrier();
+    }
+    __syncthreads();
+    FD_STAMP(2);
+    // ---- phase 4: fixed-order row sums; each row goes to the in_proj node's storage and, tagged, to the granule table the attention stage polls
+    for (int rr = tid >> 4; rr < rows; rr += NW * 4) {
+        float sum = 0.f;
+        for (int j = tid & 15; j < nb; j += 16) sum += part[rr * nb + j];
+        sum = row16_allsum_f32(sum);
+        if ((tid & 15) == 0) {
+            const int sg = rr / seg_rows;
+            const int64_t row = (int64_t) sg * seg_stride + (int64_t) blk * seg_rows + (rr - sg * seg_rows);
+            a.y[row] = sum;
+            __hip_atomic_store(f.gbuf + row, ((unsigned long long) tag << 32) | (unsigned long long) __float_as_uint(sum), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    __syncthreads();   // the mat-vec's LDS is the attention stage's from here on
+    FD_STAMP(3);
+    // ---- the attention of head h, part part_i, its new rows taken from the granules
+    attn_decode_body<SPLIT, NW, AT_GQKV>(at, w, smem, h, part_i, 0, tag, gq);
+    FD_STAMP(4);
+    // this workgroup has read the launch counter (long ago): arrive; the launch's last arriver bumps it - nobody can still be about to read the old value.
+    // (Behind the attention stage: the add's round trip must not sit between the row sums and the hand-off.)
+    if (tid == 0) {
+        asm volatile("" :: "v"(seq) : "memory");
+        const unsigned arrived = __hip_atomic_fetch_add(f.arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (arrived + 1u == tag * (unsigned) gridDim.x) __hip_atomic_store(f.seq, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    FD_STAMP(5);
+}
+
+static size_t inproj_attn_smem(const mv_args & a, const attn_args & at, int seg_rows) {
     const size_t attn = (size_t) at.C * 4 + (size_t) at.T * at.D * 4 * 3 + (size_t) FOLD_NW * 64 * 8 * 8 + 16 + (size_t) at.T * at.C * 4;
-    const size_t mv = 16 * XBLK_BYTES + (size_t) (a.M / FOLD_GRID) * (size_t) (a.K / 256) * 4;
+    const size_t mv = (size_t) (a.K / 256) * XBLK_BYTES + (size_t) FOLD_NW * 64 * 144 + (size_t) 3 * seg_rows * (a.K / 256) * 4;
     return ((attn > mv ? attn : mv) + 15) & ~(size_t) 15;
 }
-bool k_attn_outproj_supported(const mv_args & a, const attn_args & at, int usable_cus) {
-    static const int on = env_int("MI355X_ATTN_FOLD", 1);
+// `a`: the in_proj mat-vec (alpha * rms_norm(x) prologue, Q4_K, no epilogue) whose output holds `at`'s q | k | v as three segments of H x D rows
+bool k_inproj_attn_supported(const mv_args & a, const attn_args & at, int usable_cus) {
+    static const int on = env_int("MI355X_INPROJ_ATTN", 1);
     if (!on) return false;
-    if (a.wtype != GGML_TYPE_Q4_K || a.ncols != 1 || a.prologue != MV_PLAIN || a.pair_F || a.x_out || a.out_scale || a.out_act || a.ticket || a.res_embed.table ||
+    if (a.wtype != GGML_TYPE_Q4_K || a.ncols != 1 || a.prologue != MV_RMSNORM || a.pair_F || a.out_scale || a.out_act || a.ticket || a.res_embed.table || a.residual ||
         a.argmax_out[0] || a.argmax_out[1]) return false;
-    if (a.K % 256 != 0 || a.K > 4096 || a.row_bytes != (a.K / 256) * 144 || ((uintptr_t) a.w & 15) || a.M % FOLD_GRID != 0) return false;
-    if ((a.M / FOLD_GRID) * (a.K / 256) > FOLD_PMAX * FOLD_NW * 8 || a.M / FOLD_GRID > FOLD_NW * 4) return false;
-    if (at.C <= 32) return false;   // (the Depth transformer's rings of <= 32 slots: attention recomputed per workgroup / chained, hip_chain.hip)
-    if (at.T != 1 || at.n_groups > 1 || (int64_t) at.H * at.D != a.K || (const float *) at.out != a.x || at.out_ts < a.K) return false;
-    if (at.H < 1 || FOLD_GRID % at.H != 0 || at.D % 8 != 0 || 64 % (at.D / 8) != 0 || at.D > 2 * FOLD_NW * 64) return false;
-    const size_t smem = fold_smem_bytes(at, a);
+    if (a.K % 256 != 0 || a.K > 4096 || a.K < 256 || a.row_bytes != (a.K / 256) * 144 || ((uintptr_t) a.w & 15)) return false;
+    if (at.C <= 32 || at.T != 1 || at.n_groups > 1 || at.H < 1 || FOLD_GRID % at.H != 0 || at.D != 128) return false;
+    const int64_t HD = (int64_t) at.H * at.D;
+    if (a.M != 3 * HD || HD % FOLD_GRID != 0) return false;
+    const int seg_rows = (int) (HD / FOLD_GRID), nb = (int) (a.K / 256);
+    if ((seg_rows * nb) % 64 != 0 || 3 * seg_rows * nb > 4096 || (at.D % seg_rows) != 0 || (seg_rows & 1)) return false;   // whole tiles per segment; a part holds whole RoPE pairs of ONE head
+    // q | k | v are the three H x D segments of y, head-major, one token
+    if (at.q != a.y || at.k != a.y + HD || at.v != a.y + 2 * HD || at.q_hs != at.D || at.k_hs != at.D || at.v_hs != at.D) return false;
+    const size_t smem = inproj_attn_smem(a, at, seg_rows);
     if (smem > 160 * 1024) return false;
-    const void * fn = fold_use_split(at) ? (const void *) attn_outproj_kernel<true> : (const void *) attn_outproj_kernel<false>;
+    const void * fn = fold_use_split(at) ? (const void *) inproj_attn_kernel<true> : (const void *) inproj_attn_kernel<false>;
     if (smem > 64 * 1024 && hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int) smem) != hipSuccess) return false;
     if (env_int("MI355X_FOLD_FORCE", 0)) return true;
     int per_cu = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, FOLD_NW * 64, smem) != hipSuccess) return false;
-    return (long long) per_cu * usable_cus >= FOLD_GRID;   // every workgroup waits for the heads' mergers: the whole grid must be resident
+    return (long long) per_cu * usable_cus >= FOLD_GRID;   // the parts of a head wait for each other: the whole grid must be resident
 }
-size_t k_attn_outproj_ws_size(const mv_args & a, const attn_args & at) {
-    size_t n = 256 + (size_t) a.K * 8;
+size_t k_inproj_attn_ws_size(const mv_args & a, const attn_args & at) {
+    size_t n = 256 + (size_t) a.M * 8;
     if (fold_use_split(at)) n += (((size_t) at.H * 4 + 255) & ~(size_t) 255) + (size_t) at.H * at.C * 8 + (size_t) at.H * fold_split_S(at) * at.D * 16;
     return n;
 }
-// ws: k_attn_outproj_ws_size bytes, zeroed once by the caller (launch counter, arrival counter, granule tags, per-head sequence numbers)
-void k_attn_outproj(hipStream_t s, const mv_args & a, const attn_args & at, void * ws, unsigned * err) {
+// ws: k_inproj_attn_ws_size bytes, zeroed once by the caller (launch counter, arrival counter, granule tags, per-head sequence numbers)
+void k_inproj_attn(hipStream_t s, const mv_args & a, const attn_args & at, void * ws, unsigned * err) {
     static const int single_max = env_int("MI355X_ATTN_SINGLE_MAX", ATTN_SINGLE_MAX), big_min = env_int("MI355X_ATTN_BIG_MIN", ATTN_SPLIT_BIG_MIN);
     char * p = (char *) ws;
     fold_ws f = { (unsigned long long *) (p + 256), (unsigned *) p, (unsigned *) (p + 64), err };
-    p += 256 + (size_t) a.K * 8;
+    p += 256 + (size_t) a.M * 8;
     const bool split = fold_use_split(at);
     attn_split_ws w = { nullptr, nullptr, nullptr, 1, err, ATTN_SPLIT_SLOTS, single_max, big_min };
     if (split) {
@@ -2429,10 +2476,12 @@ void k_attn_outproj(hipStream_t s, const mv_args & a, const attn_args & at, void
         w.gscores = (unsigned long long *) p; p += (size_t) at.H * at.C * 8;
         w.gpart = (unsigned long long *) p;
     }
-    const size_t smem = fold_smem_bytes(at, a);
-    const int rows_wg = (int) (a.M / FOLD_GRID);
-    if (split) attn_outproj_kernel<true><<<FOLD_GRID, FOLD_NW * 64, smem, s>>>(a, at, w, f, rows_wg);
-    else       attn_outproj_kernel<false><<<FOLD_GRID, FOLD_NW * 64, smem, s>>>(a, at, w, f, rows_wg);
+    const int64_t HD = (int64_t) at.H * at.D;
+    const int seg_rows = (int) (HD / FOLD_GRID);
+    const attn_gqkv gq = { f.gbuf, 0, HD, 2 * HD, err };   // granule g holds row g of y; a.q / a.k / a.v start at rows 0 / HD / 2 HD
+    const size_t smem = inproj_attn_smem(a, at, seg_rows);
+    if (split) inproj_attn_kernel<true><<<FOLD_GRID, FOLD_NW * 64, smem, s>>>(a, at, w, f, gq, seg_rows, HD);
+    else       inproj_attn_kernel<false><<<FOLD_GRID, FOLD_NW * 64, smem, s>>>(a, at, w, f, gq, seg_rows, HD);
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -58,5 +58,5 @@ if hasattr(lib, "mi355x_fold_log_read"):
         fr = np.frombuffer(fb, np.uint64).reshape(4096, 8)[:min(nf, 4096)].astype(np.int64)
         fr = fr[-32:]                                    # the last frame's launches
         d = np.diff(fr[:, :6], axis=1) / 100.0
-        print(f"{nf} folded launches logged; last 32: in-kernel us (workgroup 0) median: attention {np.median(d[:,0]):.2f}  gather {np.median(d[:,1]):.2f}  quantise {np.median(d[:,2]):.2f}  dots {np.median(d[:,3]):.2f}  row sums {np.median(d[:,4]):.2f}  total {np.median(fr[:,5]-fr[:,0])/100.0:.2f}")
+        print(f"{nf} merged launches logged; last 32: in-kernel us (workgroup 0) median of the five stage durations (attn_outproj: attention, gather, quantise, dots, row sums; inproj_attn: prologue, tiles, row sums + publish, attention, -): {np.round(np.median(d, axis=0), 2)}  total {np.median(fr[:,5]-fr[:,0])/100.0:.2f}")
         print("   launch-to-launch period of the folded kernel (us):", np.round(np.median(np.diff(fr[:, 0])) / 100.0, 2))
