@@ -53,11 +53,11 @@ def shard_hop_latency(shard, dist, group, L, be, n=200):
     if shard.world == 1:
         return 0.0
     for k in range(8):
-        shard._bcast(shard.msg, k % shard.world)
+        shard.hop(k % shard.world)
     L.ggml_backend_synchronize(be)
     t0 = time.perf_counter()
     for k in range(n):
-        shard._bcast(shard.msg, k % shard.world)
+        shard.hop(k % shard.world)
     L.ggml_backend_synchronize(be)
     return round(1e6 * (time.perf_counter() - t0) / n, 2)
 
@@ -199,8 +199,11 @@ def main():
     if args.shard == "depth":
         from moshi_cpp_amd import shard as shard_mod
         import torch
-        shard = shard_mod.DepthShard(L, m, cfg, rank, world, dist, group=dist_group, device=torch.device("cuda", dev_index),
-                                     stream_ptr=L.ggml_backend_mi355x_get_stream(be))
+        # the hop loop and the RCCL broadcasts run behind the C-ABI (include/moshi_hot.h "the whole sharded frame"); on a gloo control plane (dry runs on one
+        # GPU) the same C loop calls back into torch.distributed over host memory
+        use_rccl = dist is None or dist.get_backend(dist_group) != "gloo"
+        shard = shard_mod.DepthShard(L, m, cfg, rank, world, dist, group=dist_group, device=torch.device("cuda", dev_index) if use_rccl else None,
+                                     staged_device=None if use_rccl else torch.device("cuda", dev_index), backend=be)
         if rank == 0:
             shard.install()
     if args.context_fill:
@@ -368,7 +371,7 @@ def main():
         hop_us = shard_hop_latency(shard, dist, dist_group, L, be)
         reduce_max_time(dist, dt, group=dist_group)
         result["shard"] = {"kind": "depth codebook shard (SURVEY.md 8e)", "ranks": world, "messages_per_frame": 1 + cfg.dep_q,
-                           "message_bytes": int(shard.msg_floats.value * 4), "broadcast_us": hop_us,
+                           "message_bytes": int(shard.msg_floats.value * 4), "broadcast_us": hop_us, "transport": shard.transport,
                            "depth_weight_bytes_this_rank": int(L.moshi_hot_weight_bytes(m, 1))}
         args.no_roofline = True          # flag 8 re-plans graphs eagerly; the roofline line belongs to the default (unsharded) run
         args.no_cpu_baseline = True
@@ -403,12 +406,13 @@ def main():
                                   "avg_launch_us": round(1e6 * kp.seconds / kp.launches, 3),
                                   "algorithmic_bytes_per_launch": int(kp.bytes // kp.launches)}
             # the same measurement split by instantiation family (rocprofv3 lists them as separate kernels): the large matrices stream, the small ones wait
-            names = ("lds_staged_tiles: matvec_q4k_kernel<.., WS=0> (Temporal matrices, text head)", "register_streaming: matvec_q4k_kernel<.., WS=1> (small matrices outside a chain)")
+            names = ("lds_staged_tiles: matvec_q4k_kernel<.., WS=0> (Temporal out_proj / linear_in / linear_out, text head)", "register_streaming: matvec_q4k_kernel<.., WS=1> (small matrices outside a chain)",
+                     "merged: inproj_attn_kernel (Temporal in_proj tiles + RoPE + ring write + attention in one launch)")
             result["roofline_by_variant"] = {names[v]: {"achieved": round(kp.variant_bytes[v] / kp.variant_seconds[v] / 1e9, 1), "unit": "GB/s",
                                                         "frac": round(kp.variant_bytes[v] / kp.variant_seconds[v] / 1e9 / HBM_PEAK_GBPS, 4),
                                                         "launches_per_frame": int(kp.variant_launches[v] // 3), "avg_launch_us": round(1e6 * kp.variant_seconds[v] / kp.variant_launches[v], 3),
                                                         "algorithmic_bytes_per_launch": int(kp.variant_bytes[v] // kp.variant_launches[v])}
-                                             for v in range(2) if kp.variant_launches[v]}
+                                             for v in range(3) if kp.variant_launches[v]}
             if kp.chain_launches:
                 # the chained Depth transformer (lm.h:446-553) as persistent launches: weights streamed once per launch, ~208 dependent phases inside it
                 result["roofline_by_variant"]["persistent_chain: matvec_chain_kernel (Depth transformer, %d mat-vecs per launch)" % (kp.chain_phases // kp.chain_launches)] = {

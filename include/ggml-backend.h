@@ -125,10 +125,11 @@ struct ggml_mi355x_kernel_profile {
     int64_t launches;
     int64_t bytes;      // algorithmic bytes: weight bytes each launch streams (rows x row size)
     // the same three by instantiation family of the kernel: [0] LDS-staged tiles (matvec_q4k_kernel<.., WS = 0>: the Temporal matrices and the text head),
-    // [1] register streaming (<.., WS = 1>: the Depth transformer's small matrices)
-    double  variant_seconds[2];
-    int64_t variant_launches[2];
-    int64_t variant_bytes[2];
+    // [1] register streaming (<.., WS = 1>: the Depth transformer's small matrices), [2] inproj_attn_kernel (the Temporal in_proj's tiles with the layer's
+    // attention as the launch's tail: bytes = the in_proj weights, seconds = the whole launch)
+    double  variant_seconds[3];
+    int64_t variant_launches[3];
+    int64_t variant_bytes[3];
     // persistent chain launches (matvec_chain_kernel: the chained Depth transformer's mat-vecs as one launch), timed between two stream events
     double  chain_seconds;
     int64_t chain_launches;

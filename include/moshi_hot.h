@@ -195,6 +195,23 @@ GGML_API int     moshi_hot_depth_shard_begin_import(moshi_hot_model_t * m);     
 GGML_API void    moshi_hot_depth_shard_step(moshi_hot_model_t * m, int k);                    // owner of step k: one Depth step (lm.h:505-527 body) + pack the message
 GGML_API void    moshi_hot_depth_shard_import(moshi_hot_model_t * m, int k);                  // non-owner: rows -> ring slot k % capacity, token -> token vector
 GGML_API void    moshi_hot_depth_shard_tokens(moshi_hot_model_t * m, int32_t * out, int n);   // the frame's sampled tokens so far
+// The whole sharded frame behind the C-ABI - no interpreter on the critical path: the per-step loop above (owner: step + broadcast, the others: broadcast
+// + import) runs inside these calls, the broadcasts go through ONE transport:
+//   * RCCL, called from here (librccl.so is opened at run time; the harness links no HIP): ncclBroadcast on the backend's own HIP stream
+//     (ggml_backend_mi355x_get_stream), i.e. stream-ordered behind the step's kernels and in front of the next ones - no host synchronisation and no
+//     event per hop. Rank 0 makes the 128-byte unique id, the caller carries it to the other ranks (any side channel), every rank calls _rccl_init.
+//   * or a caller-supplied function (host memory on the CPU device: gloo in tests/test_depth_shard_cpu.py; also a bring-up aid on devices).
+typedef void (*moshi_hot_bcast_t)(void * user, void * data, int64_t bytes, int root);
+GGML_API void    moshi_hot_depth_shard_set_transport(moshi_hot_model_t * m, moshi_hot_bcast_t fn, void * user);
+GGML_API int     moshi_hot_depth_shard_rccl_unique_id(char * id128);                                            // 0 = ok (rank 0)
+GGML_API int     moshi_hot_depth_shard_rccl_init(moshi_hot_model_t * m, int rank, int world, const char * id128); // 0 = ok; every rank, collectively
+GGML_API void    moshi_hot_depth_shard_rccl_free(moshi_hot_model_t * m);
+GGML_API void    moshi_hot_depth_shard_broadcast(moshi_hot_model_t * m, int which, int root);                    // one broadcast of the step (0) / frame (1) message through the transport (latency probes)
+// Temporal owner (rank 0): installs the sharded frame as the Depth half of moshi_hot_lm_step_n (export, broadcast, dep_q hops, read the tokens)
+GGML_API void    moshi_hot_depth_shard_install(moshi_hot_model_t * m);
+GGML_API void    moshi_hot_depth_shard_stop(moshi_hot_model_t * m);                                            // rank 0: tells the other ranks' _serve to return
+GGML_API int64_t moshi_hot_depth_shard_hops(moshi_hot_model_t * m);                                            // broadcasts this rank has taken part in so far
+GGML_API int64_t moshi_hot_depth_shard_serve(moshi_hot_model_t * m);                                           // every other rank: frames served until rank 0 stops
 // ---- tensor-parallel Temporal stack: begin(x) ; for i in 0 .. 2 L: { segment(i) ; [i < 2 L: all-reduce(sum) of the message over the ranks] } ; end(out) ----
 // segment 2 l   : x += message (l > 0) ; message = out_proj_r(attention_r(in_proj_r(norm1(x))))      (this rank's heads, its KV ring shard)
 // segment 2 l+1 : x += message         ; message = linear_out_r(silu * mul of linear_in_r(norm2(x)))  (this rank's F / N hidden units)

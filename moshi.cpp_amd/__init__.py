@@ -62,7 +62,7 @@ class Stats(C.Structure):
 
 class KernelProfile(C.Structure):
     _fields_ = [("seconds", C.c_double), ("launches", C.c_int64), ("bytes", C.c_int64),
-                ("variant_seconds", C.c_double * 2), ("variant_launches", C.c_int64 * 2), ("variant_bytes", C.c_int64 * 2),
+                ("variant_seconds", C.c_double * 3), ("variant_launches", C.c_int64 * 3), ("variant_bytes", C.c_int64 * 3),
                 ("chain_seconds", C.c_double), ("chain_launches", C.c_int64), ("chain_bytes", C.c_int64), ("chain_phases", C.c_int64)]
 
 

@@ -123,7 +123,7 @@ bool k_matvec_pair_ok(int wtype, int64_t K, int64_t F);
 // optional per-launch timing of the dominant kernel (matvec_q4k_kernel) with HIP start/stop events that are
 // attached to the dispatch itself (hipExtLaunchKernelGGL), i.e. kernel begin -> kernel end like a profiler
 struct mv_profile {
-    struct rec { hipEvent_t start, stop; int64_t bytes; int variant; };   // variant: 0 = LDS-staged tiles (the large matrices), 1 = register streaming (WS = 1: the small ones)
+    struct rec { hipEvent_t start, stop; int64_t bytes; int variant; };   // variant: 0 = LDS-staged tiles (the large matrices), 1 = register streaming (WS = 1: the small ones), 2 = inproj_attn_kernel (in_proj tiles + the attention in one launch)
     rec * recs; int capacity; int used;
 };
 void k_matvec_set_profile(mv_profile * p);

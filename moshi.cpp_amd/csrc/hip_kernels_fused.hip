@@ -2480,6 +2480,14 @@ void k_inproj_attn(hipStream_t s, const mv_args & a, const attn_args & at, void 
     const int seg_rows = (int) (HD / FOLD_GRID);
     const attn_gqkv gq = { f.gbuf, 0, HD, 2 * HD, err };   // granule g holds row g of y; a.q / a.k / a.v start at rows 0 / HD / 2 HD
     const size_t smem = inproj_attn_smem(a, at, seg_rows);
+    if (g_mv_profile && g_mv_profile->used < g_mv_profile->capacity) {   // profile mode: events attached to the dispatch, like k_matvec's
+        mv_profile::rec & r = g_mv_profile->recs[g_mv_profile->used++];
+        r.bytes = a.M * a.row_bytes;
+        r.variant = 2;
+        if (split) hipExtLaunchKernelGGL(inproj_attn_kernel<true>, dim3(FOLD_GRID), dim3(FOLD_NW * 64), smem, s, r.start, r.stop, 0, a, at, w, f, gq, seg_rows, HD);
+        else       hipExtLaunchKernelGGL(inproj_attn_kernel<false>, dim3(FOLD_GRID), dim3(FOLD_NW * 64), smem, s, r.start, r.stop, 0, a, at, w, f, gq, seg_rows, HD);
+        return;
+    }
     if (split) inproj_attn_kernel<true><<<FOLD_GRID, FOLD_NW * 64, smem, s>>>(a, at, w, f, gq, seg_rows, HD);
     else       inproj_attn_kernel<false><<<FOLD_GRID, FOLD_NW * 64, smem, s>>>(a, at, w, f, gq, seg_rows, HD);
 }

@@ -10,6 +10,7 @@
 #include "gguf.h"
 #include "ggml-cpu.h"
 
+#include <dlfcn.h>
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
@@ -742,6 +743,12 @@ struct moshi_hot_model {
     T shard_msg = nullptr, shard_tout = nullptr, shard_tokens = nullptr;
     std::vector<T> shard_text_idx, shard_text_scale;
     moshi_hot_depth_hook_t depth_hook = nullptr; void * depth_hook_user = nullptr;
+    // Depth codebook shard: transport of the per-step / per-frame messages (RCCL opened at run time, or a caller's function)
+    moshi_hot_bcast_t shard_bcast = nullptr; void * shard_bcast_user = nullptr;
+    void * rccl_lib = nullptr, * rccl_comm = nullptr;
+    int64_t shard_hops = 0;   // broadcasts issued so far
+    int (*rccl_broadcast)(const void *, void *, size_t, int, int, void *, void *) = nullptr;
+    int (*rccl_comm_destroy)(void *) = nullptr;
     // tensor-parallel Temporal stack (moshi_hot.h): this rank's sliced layers, the replicated stream x, the partial message, one graph per segment
     Transformer temporal_tp; T tp_x = nullptr, tp_msg = nullptr; std::vector<Builder *> g_tp;
     // delay ring (lm.h:715-743)
@@ -1222,6 +1229,7 @@ static moshi_hot_model_t * create_model(ggml_backend_t backend, const struct mos
 extern "C" void moshi_hot_free(moshi_hot_model_t * m) {
     if (!m) return;
     ggml_backend_synchronize(m->be);
+    moshi_hot_depth_shard_rccl_free(m);
     for (auto & f : m->inflight) if (f.ev) ggml_backend_event_free(f.ev);
     for (auto e : m->ev_pool) ggml_backend_event_free(e);
     if (m->own_codec_be) ggml_backend_synchronize(m->be_codec);
@@ -1470,6 +1478,88 @@ extern "C" void moshi_hot_depth_shard_import(moshi_hot_model_t * m, int k) {
     m->g_shard_import[(size_t) k]->compute();
 }
 extern "C" void moshi_hot_depth_shard_tokens(moshi_hot_model_t * m, int32_t * out, int n) { ggml_backend_tensor_get(m->shard_tokens, out, 0, (size_t) n * 4); }
+
+// ---- the sharded frame behind the C-ABI (the loop of lm.h:505-527 spread over ranks) ------------------------------------------
+namespace {
+struct nccl_id { char internal[128]; };   // ncclUniqueId (rccl.h: NCCL_UNIQUE_ID_BYTES = 128), passed BY VALUE to ncclCommInitRank
+void * rccl_open() {
+    static void * lib = nullptr;
+    if (!lib) lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!lib) lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    return lib;
+}
+void shard_broadcast(moshi_hot_model * m, T msg, int root) {
+    const moshi_hot_config & c = m->cfg;
+    if (c.dep_shard_world <= 1 && !m->rccl_comm && !m->shard_bcast) return;   // (one rank and no transport set up: nothing to move)
+    m->shard_hops++;
+    const size_t bytes = ggml_nbytes(msg);
+    if (m->shard_bcast) { m->shard_bcast(m->shard_bcast_user, msg->data, (int64_t) bytes, root); return; }
+    GGML_ASSERT(m->rccl_comm && "moshi_hot depth shard: no transport (moshi_hot_depth_shard_rccl_init or _set_transport first)");
+    // in place on the message tensor's own device storage, on the backend's stream: ordered behind the kernels that packed it and in front of the ones that unpack it
+    const int rc = m->rccl_broadcast(msg->data, msg->data, bytes, /* ncclUint8 */ 1, root, m->rccl_comm, ggml_backend_mi355x_get_stream(m->be));
+    GGML_ASSERT(rc == 0 && "ncclBroadcast failed");
+}
+void shard_chain(moshi_hot_model * m) {
+    const moshi_hot_config & c = m->cfg;
+    for (int k = 0; k < c.dep_q; k++) {
+        const int owner = k % c.dep_shard_world;
+        if (owner == c.dep_shard_rank) moshi_hot_depth_shard_step(m, k);
+        shard_broadcast(m, m->shard_msg, owner);
+        if (owner != c.dep_shard_rank) moshi_hot_depth_shard_import(m, k);
+    }
+}
+void shard_frame_hook(void * user, int32_t text_token, int32_t * audio) {
+    moshi_hot_model * m = (moshi_hot_model *) user;
+    moshi_hot_depth_shard_begin_export(m, text_token, 1);
+    shard_broadcast(m, m->shard_tout, 0);
+    shard_chain(m);
+    moshi_hot_depth_shard_tokens(m, audio, m->cfg.dep_q);
+}
+}  // namespace
+extern "C" void moshi_hot_depth_shard_set_transport(moshi_hot_model_t * m, moshi_hot_bcast_t fn, void * user) { m->shard_bcast = fn; m->shard_bcast_user = user; }
+extern "C" int moshi_hot_depth_shard_rccl_unique_id(char * id128) {
+    void * lib = rccl_open();
+    if (!lib) return -1;
+    auto get_id = (int (*)(nccl_id *)) dlsym(lib, "ncclGetUniqueId");
+    if (!get_id) return -2;
+    nccl_id id;
+    const int rc = get_id(&id);
+    if (rc == 0) memcpy(id128, id.internal, 128);
+    return rc;
+}
+extern "C" int moshi_hot_depth_shard_rccl_init(moshi_hot_model_t * m, int rank, int world, const char * id128) {
+    void * lib = rccl_open();
+    if (!lib) return -1;
+    auto init = (int (*)(void **, int, nccl_id, int)) dlsym(lib, "ncclCommInitRank");
+    m->rccl_broadcast = (int (*)(const void *, void *, size_t, int, int, void *, void *)) dlsym(lib, "ncclBroadcast");
+    m->rccl_comm_destroy = (int (*)(void *)) dlsym(lib, "ncclCommDestroy");
+    if (!init || !m->rccl_broadcast || !m->rccl_comm_destroy) return -2;
+    if (ggml_backend_dev_type(ggml_backend_get_device(m->be)) != GGML_BACKEND_DEVICE_TYPE_GPU) return -3;   // (RCCL needs the MI355X backend's stream; the CPU device takes _set_transport)
+    nccl_id id;
+    memcpy(id.internal, id128, 128);
+    m->rccl_lib = lib;
+    return init(&m->rccl_comm, world, id, rank);
+}
+extern "C" void moshi_hot_depth_shard_rccl_free(moshi_hot_model_t * m) {
+    if (m->rccl_comm && m->rccl_comm_destroy) { ggml_backend_synchronize(m->be); m->rccl_comm_destroy(m->rccl_comm); }
+    m->rccl_comm = nullptr;
+}
+extern "C" void moshi_hot_depth_shard_broadcast(moshi_hot_model_t * m, int which, int root) { shard_broadcast(m, which ? m->shard_tout : m->shard_msg, root); }
+extern "C" int64_t moshi_hot_depth_shard_hops(moshi_hot_model_t * m) { return m->shard_hops; }
+extern "C" void moshi_hot_depth_shard_install(moshi_hot_model_t * m) { moshi_hot_set_depth_hook(m, shard_frame_hook, m); }
+extern "C" void moshi_hot_depth_shard_stop(moshi_hot_model_t * m) {
+    moshi_hot_depth_shard_begin_export(m, 0, 0);
+    shard_broadcast(m, m->shard_tout, 0);
+}
+extern "C" int64_t moshi_hot_depth_shard_serve(moshi_hot_model_t * m) {
+    int64_t frames = 0;
+    for (;;) {
+        shard_broadcast(m, m->shard_tout, 0);
+        if (!moshi_hot_depth_shard_begin_import(m)) return frames;
+        shard_chain(m);
+        frames++;
+    }
+}
 extern "C" int moshi_hot_host_ring(moshi_hot_model_t * m, int32_t * dst, int max_values) {
     // the host-side delay ring of moshi_lmgen (lm.h:819-824, 935-943), row-major [rows][n_q + 1]; returns the number of values (0 when dst is too small)
     const int rows = (int) m->cache.size(), cols = rows ? (int) m->cache[0].size() : 0;

@@ -72,6 +72,15 @@ SIGNATURES = {
     "moshi_hot_depth_shard_step": (None, [P, C.c_int]),
     "moshi_hot_depth_shard_import": (None, [P, C.c_int]),
     "moshi_hot_depth_shard_tokens": (None, [P, P, C.c_int]),
+    "moshi_hot_depth_shard_set_transport": (None, [P, C.c_void_p, C.c_void_p]),
+    "moshi_hot_depth_shard_rccl_unique_id": (C.c_int, [C.c_char_p]),
+    "moshi_hot_depth_shard_rccl_init": (C.c_int, [P, C.c_int, C.c_int, C.c_char_p]),
+    "moshi_hot_depth_shard_rccl_free": (None, [P]),
+    "moshi_hot_depth_shard_broadcast": (None, [P, C.c_int, C.c_int]),
+    "moshi_hot_depth_shard_install": (None, [P]),
+    "moshi_hot_depth_shard_stop": (None, [P]),
+    "moshi_hot_depth_shard_serve": (C.c_int64, [P]),
+    "moshi_hot_depth_shard_hops": (C.c_int64, [P]),
     "moshi_hot_set_depth_hook": (None, [P, P, P]),
     "moshi_hot_tp_msg": (P, [P, C.POINTER(C.c_int64)]),
     "moshi_hot_tp_begin": (None, [P, P]),
@@ -81,6 +90,7 @@ SIGNATURES = {
     "moshi_hot_tp_msg_write": (None, [P, P]),
 }
 DEPTH_HOOK = C.CFUNCTYPE(None, C.c_void_p, C.c_int32, C.POINTER(C.c_int32))
+BCAST_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_int64, C.c_int)
 NODE_VISITOR = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_void_p)
 
 

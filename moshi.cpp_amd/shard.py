@@ -6,19 +6,81 @@ Rank r holds the Depth weights of the steps k with k % world == r (include/moshi
   2. for k = 0 .. dep_q-1: the owner of step k runs it (6 layers + head + sample) and broadcasts ONE message - its new K / V ring rows of all
      layers (2 x 6 x 1024 BF16 values, as the ring stores them: 24 KB) and the sampled token; every other rank writes them into its replica of the 8-slot ring / token vector;
   3. rank 0 reads the dep_q tokens.
-The collectives are `torch.distributed.broadcast` on tensors that ALIAS the C side's message storage (device memory on the MI355X backend, so
-RCCL moves them GPU to GPU over xGMI; host memory on the CPU device, for the gloo test): torch is transport plumbing only, the C-ABI carries no
-torch type. There is no other data-path collective. The chain stays serial, so this is a strong-scaling (latency) experiment, reported as such.
-
-EXPERIMENTAL on devices: the RCCL legs have only run under gloo (host memory, tests/test_depth_shard_cpu.py, tests/test_temporal_tp_cpu.py) and as a
-one-GPU dry run - no multi-GPU box has been available to this project. Stream ordering on the device relies on ProcessGroupNCCL's wait() making the
-current (external = the backend's) stream wait for the collective; MI355X_SHARD_HOST_SYNC=1 adds a host-side stream synchronisation after every
-collective for a first bring-up on real hardware.
+The whole frame - the hop loop included - runs BEHIND THE C-ABI (moshi_hot_depth_shard_install / _serve, include/moshi_hot.h): no interpreter on the
+critical path. On devices the broadcasts are ncclBroadcast calls the harness makes itself (librccl.so opened at run time) on the backend's own HIP stream,
+i.e. stream-ordered between the step's kernels and the import's - no host synchronisation, no event, no torch stream semantics involved. This module
+only carries RCCL's 128-byte unique id from rank 0 to the other ranks (over the caller's torch.distributed control group) and starts the calls.
+On the CPU device (tests/test_depth_shard_cpu.py) the transport is a function this module supplies: torch.distributed.broadcast over gloo on a tensor
+aliasing the message's host storage - the same C loop, a different wire.
+There is no other data-path collective. The chain stays serial, so this is a strong-scaling (latency) experiment, reported as such. The RCCL leg has run
+with a world of ONE rank on the test box (tests/test_hip_frame.py); no multi-GPU box has been available to this project.
 """
 import ctypes as C
-import os
 
-_HOST_SYNC = os.environ.get("MI355X_SHARD_HOST_SYNC", "0") not in ("", "0")
+
+class DepthShard:
+    def __init__(self, L, model, cfg, rank, world, dist, group=None, device=None, stream_ptr=None, staged_device=None, backend=None):
+        """device: the torch device of this rank's GPU -> RCCL from inside the harness. device=None: the caller-supplied transport; the messages are host
+        memory (CPU device) unless staged_device / backend are given (a GPU backend under a gloo control plane: single-GPU dry runs - the message is
+        aliased as a device tensor and the backend is synchronised around every hop)."""
+        from . import hot
+        self.L, self.m, self.cfg, self.rank, self.world, self.dist, self.group = L, model, cfg, rank, world, dist, group
+        self.msg_floats = C.c_int64()
+        L.moshi_hot_depth_shard_msg(model, C.byref(self.msg_floats))
+        self.transport = "none"
+        self._cb = None
+        if world > 1 or device is not None:   # (a single rank WITH a device still sets RCCL up: every hop is then a real, if trivial, ncclBroadcast)
+            if device is not None:
+                # RCCL from inside the harness: rank 0 makes the id, the control group carries it
+                import torch
+                idbuf = C.create_string_buffer(128)
+                if rank == 0:
+                    rc = L.moshi_hot_depth_shard_rccl_unique_id(idbuf)
+                    if rc != 0:
+                        raise RuntimeError("ncclGetUniqueId failed (%d)" % rc)
+                if world > 1:
+                    t = torch.frombuffer(bytearray(idbuf.raw), dtype=torch.uint8).clone()
+                    if dist.get_backend(group) != "gloo":
+                        t = t.to(device)
+                    dist.broadcast(t, src=0, group=group)
+                    idbuf = C.create_string_buffer(bytes(t.cpu().numpy().tobytes()), 128)
+                rc = L.moshi_hot_depth_shard_rccl_init(model, rank, world, idbuf)
+                if rc != 0:
+                    raise RuntimeError("ncclCommInitRank failed (%d)" % rc)
+                self.transport = "rccl (ncclBroadcast called by the harness on the backend's stream)"
+            else:
+                import torch
+
+                def bcast(user, data, nbytes, root):
+                    if staged_device is not None:
+                        L.ggml_backend_synchronize(backend)
+                        dist.broadcast(_alias(torch, data, nbytes // 4, staged_device), src=root, group=group)
+                        torch.cuda.synchronize()
+                        return
+                    buf = (C.c_uint8 * nbytes).from_address(data)
+                    dist.broadcast(torch.frombuffer(buf, dtype=torch.uint8), src=root, group=group)
+                self._cb = hot.BCAST_FN(bcast)
+                L.moshi_hot_depth_shard_set_transport(model, C.cast(self._cb, C.c_void_p), None)
+                self.transport = "caller-supplied function (torch.distributed over host memory)"
+
+    def install(self):
+        """rank 0: the sharded frame becomes the Depth half of every LM step"""
+        self.L.moshi_hot_depth_shard_install(self.m)
+
+    def stop_workers(self):
+        self.L.moshi_hot_depth_shard_stop(self.m)
+
+    def serve(self):
+        """every other rank: returns the number of frames served when the owner says stop"""
+        return int(self.L.moshi_hot_depth_shard_serve(self.m))
+
+    @property
+    def hops(self):
+        return int(self.L.moshi_hot_depth_shard_hops(self.m))
+
+    def hop(self, root):
+        """one broadcast of the step message (latency probe; collective)"""
+        self.L.moshi_hot_depth_shard_broadcast(self.m, 0, root)
 
 
 class _DeviceBlock:
@@ -35,73 +97,7 @@ def _alias(torch, ptr, n_floats, device):
     return torch.as_tensor(_DeviceBlock(ptr, n_floats), device=device)  # device memory (MI355X backend + RCCL)
 
 
-class DepthShard:
-    def __init__(self, L, model, cfg, rank, world, dist, group=None, device=None, stream_ptr=None):
-        self.L, self.m, self.cfg, self.rank, self.world, self.dist, self.group, self.torch = L, model, cfg, rank, world, dist, group, None
-        self.msg = self.tout = self.stream = None
-        self.msg_floats = C.c_int64()
-        msg_ptr = L.moshi_hot_depth_shard_msg(model, C.byref(self.msg_floats))
-        if world > 1:                                  # torch is transport plumbing only: a single rank never imports it
-            import torch
-            self.torch = torch
-            n = C.c_int64()
-            self.msg = _alias(torch, msg_ptr, self.msg_floats.value, device)
-            self.tout = _alias(torch, L.moshi_hot_depth_shard_tout(model, C.byref(n)), n.value, device)
-            # collectives are enqueued behind the backend's own stream (and the backend's next kernels behind them): no host synchronisation per hop
-            self.stream = torch.cuda.ExternalStream(stream_ptr, device=device) if (device is not None and stream_ptr) else None
-        self.hops = 0
-
-    def _bcast(self, t, src):
-        if self.world == 1:
-            return
-        if self.stream is not None:
-            with self.torch.cuda.stream(self.stream):
-                self.dist.broadcast(t, src=src, group=self.group)
-            if _HOST_SYNC:
-                self.stream.synchronize()
-        else:
-            self.dist.broadcast(t, src=src, group=self.group)
-        self.hops += 1
-
-    def _chain(self):
-        L, m = self.L, self.m
-        for k in range(self.cfg.dep_q):
-            owner = k % self.world
-            if owner == self.rank:
-                L.moshi_hot_depth_shard_step(m, k)
-            self._bcast(self.msg, owner)
-            if owner != self.rank:
-                L.moshi_hot_depth_shard_import(m, k)
-
-    # ---- Temporal owner (rank 0): the hook moshi_hot_lm_step_n calls instead of the local chained Depth graph ---------------------------
-    def depth_hook(self, user, text_token, audio):
-        self.L.moshi_hot_depth_shard_begin_export(self.m, text_token, 1)
-        self._bcast(self.tout, 0)
-        self._chain()
-        out = (C.c_int32 * self.cfg.dep_q)()
-        self.L.moshi_hot_depth_shard_tokens(self.m, out, self.cfg.dep_q)
-        for i in range(self.cfg.dep_q):
-            audio[i] = out[i]
-
-    def install(self):
-        from . import hot
-        self._cb = hot.DEPTH_HOOK(self.depth_hook)
-        self.L.moshi_hot_set_depth_hook(self.m, C.cast(self._cb, C.c_void_p), None)
-
-    def stop_workers(self):
-        self.L.moshi_hot_depth_shard_begin_export(self.m, 0, 0)
-        self._bcast(self.tout, 0)
-
-    # ---- every other rank ----------------------------------------------------------------------------------------------------------------
-    def serve(self):
-        """returns the number of frames served when the owner says stop"""
-        frames = 0
-        while True:
-            self._bcast(self.tout, 0)
-            if not self.L.moshi_hot_depth_shard_begin_import(self.m):
-                return frames
-            self._chain()
-            frames += 1
+_HOST_SYNC = __import__("os").environ.get("MI355X_SHARD_HOST_SYNC", "0") not in ("", "0")
 
 
 class TemporalTP:

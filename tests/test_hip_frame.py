@@ -664,6 +664,31 @@ def test_depth_shard_step_graphs_match_the_chained_graph_on_the_device():
     m.free()
 
 
+def test_sharded_frame_behind_the_c_abi_with_rccl_on_the_backend_stream():
+    # the hop loop lives behind the C-ABI and the broadcasts are ncclBroadcast calls the harness makes itself (librccl.so opened at run
+    # time) on the backend's own HIP stream. One GPU = a world of one rank: every hop is still a real RCCL call, stream-ordered between the step graph
+    # that packs the message and the next graph - the tokens must be the chained graph's, 1 + dep_q broadcasts per frame, no Python between the hops.
+    import torch
+    from moshi_cpp_amd import shard
+    cfg = hu.hot.tiny(hu.L, linear_type=F32, embed_type=F32)
+    cfg.enable_mimi_encoder = cfg.enable_mimi_decoder = 0
+    chained, _ = run_lm("hip", cfg, 8)
+    cfg.dep_shard_world, cfg.dep_shard_rank = 1, 0
+    m = hu.Model("hip", cfg, seed=0)
+    sh = shard.DepthShard(hu.L, m.m, cfg, 0, 1, None, device=torch.device("cuda", 0))
+    assert sh.transport.startswith("rccl")
+    sh.install()
+    rng = np.random.default_rng(3)
+    for i in range(8):
+        r, txt, aud = m.lm_step(rng.integers(0, cfg.card, cfg.n_q - cfg.io_dep_q).tolist())
+        assert (r, txt, aud) == chained[i][:3], f"step {i}"
+    assert sh.hops == 8 * (1 + cfg.dep_q), sh.hops
+    for k in range(50):
+        sh.hop(0)                                     # back-to-back broadcasts on the stream (the latency probe of bench.py --shard depth)
+    hu.L.ggml_backend_synchronize(m.be)
+    m.free()
+
+
 def test_tensor_parallel_segments_on_the_device_match_the_oracle():
     # SURVEY.md 8f.2 plumbing on the MI355X backend, one rank (the two-rank sum is covered on CPU, tests/test_temporal_tp_cpu.py): the 2 L + 1 segment
     # graphs over sliced weights vs the oracle running the same segments, several stream positions
