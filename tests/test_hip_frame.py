@@ -263,6 +263,20 @@ def test_streaming_mimi_decoder_on_the_device_matches_the_offline_pytorch_restat
     assert tg._run_mimi_decoder_fixture("hip") < 3e-3
 
 
+def test_lm_step_on_the_device_matches_hugging_face_moshi():
+    # tests/golden/hf_moshi.npz: Hugging Face transformers' Moshi decoder layers + Depth decoder (independent implementation, float32) over the same synthetic weights
+    import test_oracle_golden as tg
+    e_out, e_txt, e_dep, agree = tg._run_hf_moshi_fixture("hip")
+    assert e_out < 5e-3 and e_txt < 5e-3 and e_dep < 1e-2 and agree == 1.0, (e_out, e_txt, e_dep, agree)
+
+
+def test_streaming_codec_on_the_device_matches_hugging_face_mimi():
+    # tests/golden/hf_mimi.npz: Hugging Face transformers' Mimi (independent implementation, float32, offline) over the same synthetic weights
+    import test_oracle_golden as tg
+    same, lat, pcm = tg._run_hf_mimi_fixture("hip")
+    assert same >= 46 / 48 and lat < 1e-2 and pcm < 5e-3, (same, lat, pcm)
+
+
 def test_mimi_codec_crosses_t2_mask_quirk():
     # Mimi transformers have T = 2, capacity 250: after 125 frames bias_pattern_index takes its second branch
     # (SURVEY.md §5 quirk). Codes in -> pcm out, 130 frames, decoder only.

@@ -305,6 +305,72 @@ def test_streaming_mimi_decoder_matches_the_offline_pytorch_restatement():
     assert _run_mimi_decoder_fixture("oracle") < 2e-3
 
 
+def _run_hf_moshi_fixture(kind):
+    """tests/golden/hf_moshi.npz (generator: tests/golden/make_hf_moshi_golden.py): Hugging Face `transformers`' Moshi - MoshiForCausalLM's decoder layers and
+    MoshiDepthDecoder, an independent implementation, nothing of it restated in this repo - run in float32 over the driver's synthetic F32 weights: 10 provided
+    frames over a ring of 6 (it wraps), the Temporal stack fed the driver's own embedding sums, the Depth decoder teacher-forced with the driver's tokens.
+    -> (worst transformer_out error, worst text-logit error, worst Depth-logit error, fraction of greedy tokens HF's logits reproduce)"""
+    import hot_util as hu
+    M = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "hf_moshi.npz"))
+    cfg = hu.hot.tiny(hu.L, linear_type=F32, embed_type=F32, layers=2, context=6)
+    cfg.enable_mimi_encoder = cfg.enable_mimi_decoder = 0
+    m = hu.Model(kind, cfg, seed=0)
+    e_out = e_txt = e_dep = 0.0
+    agree = total = 0
+    for step, tokens in enumerate(M["tokens"]):
+        m.lm_step_n(tokens.tolist())
+        assert np.array_equal(m.read("transformer_in", cfg.dim), M["x_in"][step]), f"step {step}: the stack's input differs from the fixture's"
+        e_out = max(e_out, hu.rel_err(M["transformer_out"][step], m.read("transformer_out", cfg.dim)))
+        e_txt = max(e_txt, hu.rel_err(M["text_logits"][step], m.read("text_logits", cfg.text_card)))
+        text_tok, audio = m.last_raw()
+        # HF's Depth decoder was fed the generating run's tokens: the comparison holds where this run sampled the same ones (it does, the logits being 1e-3 apart)
+        assert text_tok == int(M["text_tokens"][step]) and audio == M["dep_tokens"][step].tolist(), f"step {step}: tokens {text_tok} {audio}"
+        agree += int(int(np.argmax(M["text_logits"][step])) == text_tok); total += 1
+        for k in range(cfg.dep_q):
+            e_dep = max(e_dep, hu.rel_err(M["dep_logits"][step][k], m.read(f"dep_logits{k}", cfg.card)))
+            agree += int(int(np.argmax(M["dep_logits"][step][k])) == audio[k]); total += 1
+    m.free()
+    return e_out, e_txt, e_dep, agree / total
+
+
+def test_lm_step_matches_hugging_face_moshi():
+    # the architecture half of the oracle pin for the LM path (H4 - H12) from an INDEPENDENT source. HF keeps K / V rows and probabilities in float32 where
+    # ggml rounds them to BF16, so the bar is that rounding's reach (measured 1.1e-3 / 1.1e-3 / 2.6e-3), not summation noise; every greedy token is HF's arg-max
+    e_out, e_txt, e_dep, agree = _run_hf_moshi_fixture("oracle")
+    assert e_out < 5e-3 and e_txt < 5e-3 and e_dep < 1e-2 and agree == 1.0, (e_out, e_txt, e_dep, agree)
+
+
+def _run_hf_mimi_fixture(kind):
+    """tests/golden/hf_mimi.npz (generator: tests/golden/make_hf_mimi_golden.py): Hugging Face `transformers`' Mimi - an independent implementation of the
+    codec, nothing of it restated in this repo - run offline in float32 over the driver's synthetic weights: 6 frames of audio -> the two latents its RVQ
+    stacks quantise and its codes; 6 frames of codes -> audio. -> (fraction of encoder codes equal, worst latent error, worst decoded-PCM error) of the
+    driver's frame-by-frame STREAMING codec (compression.h:149-325)"""
+    import hot_util as hu
+    M = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "hf_mimi.npz"))
+    cfg = hu.hot.tiny(hu.L)
+    cfg.enable_lm = 0
+    cfg.mimi_n_q, cfg.mimi_codebook_size = 8, 2048
+    m = hu.Model(kind, cfg, seed=0)
+    n = M["enc_codes"].shape[0]
+    same, worst_lat, worst_pcm = 0, 0.0, 0.0
+    for i in range(n):
+        codes = m.mimi_encode(M["pcm"][i * 1920:(i + 1) * 1920])
+        same += int(sum(int(a == b) for a, b in zip(codes, M["enc_codes"][i].tolist())))
+        worst_lat = max(worst_lat, hu.rel_err(M["latent_first"][i], m.read("enc_latent_first", 256)), hu.rel_err(M["latent_rest"][i], m.read("enc_latent_rest", 256)))
+    for i, c in enumerate(M["codes"]):
+        worst_pcm = max(worst_pcm, hu.rel_err(M["pcm_out"][i * 1920:(i + 1) * 1920], m.mimi_decode(c.tolist())))
+    m.free()
+    return same / M["enc_codes"].size, worst_lat, worst_pcm
+
+
+def test_streaming_codec_matches_hugging_face_mimi():
+    # the architecture half of the oracle pin from an INDEPENDENT source: HF's module tree computes in plain float32 (no F16 im2col, no BF16 ring, erf-GELU
+    # where ggml goes through its F16 tanh table), so the bar is the codec's own sensitivity (cf. the 1e-2 of the restatement fixtures above), measured 3.5e-3
+    # (latents) / 1.2e-3 (PCM); every one of the 48 codes is equal
+    same, lat, pcm = _run_hf_mimi_fixture("oracle")
+    assert same == 1.0 and lat < 1e-2 and pcm < 5e-3, (same, lat, pcm)
+
+
 # ---- sampling with temperature (moshi_sample_token, sampling.h:4-64) vs a numpy restatement --------------------------------------------------------------
 def _sample_token_graph(g, logits, noise, temp, k):
     lg = g.input(logits)
