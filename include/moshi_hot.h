@@ -220,6 +220,12 @@ GGML_API void *  moshi_hot_tp_msg(moshi_hot_model_t * m, int64_t * n_floats);   
 GGML_API void    moshi_hot_tp_begin(moshi_hot_model_t * m, const float * x);            // stack input F32[dim]; advances the stream position (mask row, RoPE phase, ring slot)
 GGML_API void    moshi_hot_tp_segment(moshi_hot_model_t * m, int i);
 GGML_API void    moshi_hot_tp_end(moshi_hot_model_t * m, float * out);                  // stack output F32[dim]
+// the same loop behind the C-ABI: every segment and the all-reduce (sum) of the partial between two of them - ncclAllReduce on the backend's stream through
+// the model's communicator (moshi_hot_depth_shard_rccl_init), or a caller-supplied function over host memory (set_transport; CPU device / gloo tests)
+typedef void (*moshi_hot_allreduce_t)(void * user, float * data, int64_t n_floats);
+GGML_API void    moshi_hot_tp_set_transport(moshi_hot_model_t * m, moshi_hot_allreduce_t fn, void * user);
+GGML_API void    moshi_hot_tp_stack(moshi_hot_model_t * m, const float * x, float * out);
+GGML_API int64_t moshi_hot_tp_reductions(moshi_hot_model_t * m);
 GGML_API void    moshi_hot_tp_msg_read(moshi_hot_model_t * m, float * out);        // the partial-sum message, host copy out / in: lets ONE process sum the
 GGML_API void    moshi_hot_tp_msg_write(moshi_hot_model_t * m, const float * in);   // partials of several ranks' models (tests without a second GPU)
 // replaces the local chained Depth graph inside moshi_hot_lm_step_n: fn(user, text_token, audio[dep_q]) must fill all dep_q tokens

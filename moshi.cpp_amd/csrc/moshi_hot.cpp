@@ -749,6 +749,9 @@ struct moshi_hot_model {
     int64_t shard_hops = 0;   // broadcasts issued so far
     int (*rccl_broadcast)(const void *, void *, size_t, int, int, void *, void *) = nullptr;
     int (*rccl_comm_destroy)(void *) = nullptr;
+    int (*rccl_all_reduce)(const void *, void *, size_t, int, int, void *, void *) = nullptr;
+    moshi_hot_allreduce_t tp_allreduce = nullptr; void * tp_allreduce_user = nullptr;
+    int64_t tp_reductions = 0;
     // tensor-parallel Temporal stack (moshi_hot.h): this rank's sliced layers, the replicated stream x, the partial message, one graph per segment
     Transformer temporal_tp; T tp_x = nullptr, tp_msg = nullptr; std::vector<Builder *> g_tp;
     // delay ring (lm.h:715-743)
@@ -1370,6 +1373,27 @@ extern "C" void moshi_hot_tp_segment(moshi_hot_model_t * m, int i) {
 extern "C" void moshi_hot_tp_msg_read(moshi_hot_model_t * m, float * out) { GGML_ASSERT(m->tp_msg); ggml_backend_tensor_get(m->tp_msg, out, 0, ggml_nbytes(m->tp_msg)); }
 extern "C" void moshi_hot_tp_msg_write(moshi_hot_model_t * m, const float * in) { GGML_ASSERT(m->tp_msg); ggml_backend_tensor_set(m->tp_msg, in, 0, ggml_nbytes(m->tp_msg)); }
 extern "C" void moshi_hot_tp_end(moshi_hot_model_t * m, float * out) { ggml_backend_tensor_get(m->tp_x, out, 0, (size_t) m->cfg.dim * 4); }
+// The whole tensor-parallel stack pass behind the C-ABI: 2 L + 1 segment graphs with an in-place sum of the F32[dim] partial over the ranks between them -
+// ncclAllReduce called from here on the backend's own stream (the communicator of moshi_hot_depth_shard_rccl_init: one per model, both sharded modes use it),
+// or the caller's function (host memory on the CPU device: gloo in tests/test_temporal_tp_cpu.py). No interpreter between the segments.
+extern "C" void moshi_hot_tp_set_transport(moshi_hot_model_t * m, moshi_hot_allreduce_t fn, void * user) { m->tp_allreduce = fn; m->tp_allreduce_user = user; }
+extern "C" int64_t moshi_hot_tp_reductions(moshi_hot_model_t * m) { return m->tp_reductions; }
+extern "C" void moshi_hot_tp_stack(moshi_hot_model_t * m, const float * x, float * out) {
+    const moshi_hot_config & c = m->cfg;
+    moshi_hot_tp_begin(m, x);
+    const int last = 2 * c.num_layers;
+    for (int i = 0; i <= last; i++) {
+        moshi_hot_tp_segment(m, i);
+        if (i == last || (c.tp_world <= 1 && !m->rccl_comm && !m->tp_allreduce)) continue;
+        m->tp_reductions++;
+        const int64_t n = ggml_nelements(m->tp_msg);
+        if (m->tp_allreduce) { m->tp_allreduce(m->tp_allreduce_user, (float *) m->tp_msg->data, n); continue; }
+        GGML_ASSERT(m->rccl_comm && "moshi_hot tensor-parallel stack: no transport (moshi_hot_depth_shard_rccl_init or moshi_hot_tp_set_transport first)");
+        const int rc = m->rccl_all_reduce(m->tp_msg->data, m->tp_msg->data, (size_t) n, /* ncclFloat32 */ 7, /* ncclSum */ 0, m->rccl_comm, ggml_backend_mi355x_get_stream(m->be));
+        GGML_ASSERT(rc == 0 && "ncclAllReduce failed");
+    }
+    moshi_hot_tp_end(m, out);
+}
 
 // ---- Depth codebook shard ---------------------------------------------------------------------------------------
 namespace {
@@ -1533,7 +1557,8 @@ extern "C" int moshi_hot_depth_shard_rccl_init(moshi_hot_model_t * m, int rank, 
     auto init = (int (*)(void **, int, nccl_id, int)) dlsym(lib, "ncclCommInitRank");
     m->rccl_broadcast = (int (*)(const void *, void *, size_t, int, int, void *, void *)) dlsym(lib, "ncclBroadcast");
     m->rccl_comm_destroy = (int (*)(void *)) dlsym(lib, "ncclCommDestroy");
-    if (!init || !m->rccl_broadcast || !m->rccl_comm_destroy) return -2;
+    m->rccl_all_reduce = (int (*)(const void *, void *, size_t, int, int, void *, void *)) dlsym(lib, "ncclAllReduce");
+    if (!init || !m->rccl_broadcast || !m->rccl_comm_destroy || !m->rccl_all_reduce) return -2;
     if (ggml_backend_dev_type(ggml_backend_get_device(m->be)) != GGML_BACKEND_DEVICE_TYPE_GPU) return -3;   // (RCCL needs the MI355X backend's stream; the CPU device takes _set_transport)
     nccl_id id;
     memcpy(id.internal, id128, 128);

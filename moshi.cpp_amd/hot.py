@@ -86,11 +86,15 @@ SIGNATURES = {
     "moshi_hot_tp_begin": (None, [P, P]),
     "moshi_hot_tp_segment": (None, [P, C.c_int]),
     "moshi_hot_tp_end": (None, [P, P]),
+    "moshi_hot_tp_set_transport": (None, [P, C.c_void_p, C.c_void_p]),
+    "moshi_hot_tp_stack": (None, [P, P, P]),
+    "moshi_hot_tp_reductions": (C.c_int64, [P]),
     "moshi_hot_tp_msg_read": (None, [P, P]),
     "moshi_hot_tp_msg_write": (None, [P, P]),
 }
 DEPTH_HOOK = C.CFUNCTYPE(None, C.c_void_p, C.c_int32, C.POINTER(C.c_int32))
 BCAST_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_int64, C.c_int)
+ALLREDUCE_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_int64)
 NODE_VISITOR = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_void_p)
 
 

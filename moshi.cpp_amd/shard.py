@@ -94,46 +94,34 @@ def _alias(torch, ptr, n_floats, device):
     if device is None:                                                  # host memory (CPU device + gloo)
         buf = (C.c_float * n_floats).from_address(ptr)
         return torch.frombuffer(buf, dtype=torch.float32)
-    return torch.as_tensor(_DeviceBlock(ptr, n_floats), device=device)  # device memory (MI355X backend + RCCL)
-
-
-_HOST_SYNC = __import__("os").environ.get("MI355X_SHARD_HOST_SYNC", "0") not in ("", "0")
+    return torch.as_tensor(_DeviceBlock(ptr, n_floats), device=device)  # device memory (single-GPU dry runs under a gloo control plane)
 
 
 class TemporalTP:
     """Tensor-parallel Temporal stack (include/moshi_hot.h "tensor-parallel Temporal stack"): every rank holds its slices of each
-    layer and runs the 2 L + 1 segment graphs; between segments the F32[dim] partial is summed over the ranks in place (`all_reduce` on a tensor
-    aliasing the C side's message: RCCL over xGMI on devices, gloo on the host). Two all-reduces of 16 KB per layer."""
+    layer and runs the 2 L + 1 segment graphs; between segments the F32[dim] partial is summed over the ranks in place. The loop and the all-reduces run
+    behind the C-ABI (moshi_hot_tp_stack): ncclAllReduce on the backend's stream on devices (the model's communicator, set up by DepthShard / by
+    moshi_hot_depth_shard_rccl_init), or - host memory, the CPU device - a function this class supplies (torch.distributed.all_reduce over gloo)."""
 
     def __init__(self, L, model, cfg, rank, world, dist, group=None, device=None, stream_ptr=None):
-        self.L, self.m, self.cfg, self.rank, self.world, self.dist, self.group = L, model, cfg, rank, world, dist, group
-        self.msg = self.stream = self.torch = None
-        n = C.c_int64()
-        ptr = L.moshi_hot_tp_msg(model, C.byref(n))
-        if world > 1:
+        from . import hot
+        self.L, self.m, self.cfg, self.rank, self.world = L, model, cfg, rank, world
+        self._cb = None
+        if world > 1 and device is None:
             import torch
-            self.torch = torch
-            self.msg = _alias(torch, ptr, n.value, device)
-            self.stream = torch.cuda.ExternalStream(stream_ptr, device=device) if (device is not None and stream_ptr) else None
-        self.reductions = 0
+
+            def allreduce(user, data, n):
+                dist.all_reduce(_alias(torch, data, n, None), group=group)
+            self._cb = hot.ALLREDUCE_FN(allreduce)
+            L.moshi_hot_tp_set_transport(model, C.cast(self._cb, C.c_void_p), None)
+
+    @property
+    def reductions(self):
+        return int(self.L.moshi_hot_tp_reductions(self.m))
 
     def stack(self, x):
         import numpy as np
         x = np.ascontiguousarray(x, np.float32)
-        L, m = self.L, self.m
-        L.moshi_hot_tp_begin(m, x.ctypes.data)
-        last = 2 * self.cfg.num_layers
-        for i in range(last + 1):
-            L.moshi_hot_tp_segment(m, i)
-            if i < last and self.world > 1:
-                if self.stream is not None:
-                    with self.torch.cuda.stream(self.stream):
-                        self.dist.all_reduce(self.msg, group=self.group)
-                    if _HOST_SYNC:
-                        self.stream.synchronize()
-                else:
-                    self.dist.all_reduce(self.msg, group=self.group)
-                self.reductions += 1
         out = np.zeros(self.cfg.dim, np.float32)
-        L.moshi_hot_tp_end(m, out.ctypes.data)
+        self.L.moshi_hot_tp_stack(self.m, x.ctypes.data, out.ctypes.data)
         return out
