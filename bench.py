@@ -27,7 +27,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 from __graft_entry__ import load_oracle, load_package  # noqa: E402
 
-PMC_FILE = "r03_pmc_fetch_size.json"   # rocprofv3 --pmc FETCH_SIZE pass of this command (tests/microbench/take_profiles.sh), stamped with the kernel sources' hash
+PMC_FILE = "r04_pmc_fetch_size.json"   # rocprofv3 --pmc FETCH_SIZE pass of this command (tests/microbench/take_profiles.sh), stamped with the kernel sources' hash
 HBM_PEAK_GBPS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 
 

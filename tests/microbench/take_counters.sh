@@ -3,7 +3,7 @@
 # into gpurun_out/<round>_sq_counters.txt for copying to profiles/.
 set -x
 export TMPDIR=/tmp
-R=${1:-r03}
+R=${1:-r04}
 i=0
 for set in "SQ_INSTS_VMEM_RD SQ_INST_LEVEL_VMEM SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_INSTS_VALU" "SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_WAVES SQ_INSTS_SALU"; do
   i=$((i + 1))
