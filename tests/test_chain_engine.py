@@ -117,6 +117,12 @@ which = sys.argv[1]
 if which == "depth":
     cfg = tc.depth_at_real_width()
     rec, st = tc.run("hip", cfg, 6)
+elif which == "merged":   # 2048-wide Temporal stack over a long ring: in_proj + attention would be ONE launch of 256 workgroups whose head parts wait for each other
+    import test_attn_fold as tf
+    cfg = tf.temporal_cfg(1200)
+    rec5, st = tf.run("hip", cfg, 4, fill=700)
+    rec = [(r[0], r[1], r[2], r[3], [r[4]]) for r in rec5]
+    print(json.dumps({"folds": int(st.attention_folds_planned)}), file=sys.stderr)
 else:   # a long ring: the Temporal attention would be split over workgroups that wait for each other
     cfg = hu.hot.tiny(hu.L)
     cfg.dim, cfg.num_heads, cfg.context = 512, 4, 1200
@@ -165,6 +171,15 @@ def test_grids_that_cannot_be_resident_fall_back_to_plain_launches(which):
         assert "8 usable CUs -> grid 0" in log, log[-1500:]
     else:
         assert "one workgroup per head" in log, log[-1500:]
+
+
+def test_merged_attention_launch_is_not_planned_where_its_grid_cannot_be_resident():
+    # inproj_attn_kernel: 256 workgroups, the parts of a head wait for each other's q / k / v and scores. On 8 compute units the planner must keep the separate
+    # launches (and must not split the attention either) - same bits, no bounded-wait abort
+    full, log_full = _child("merged", {})
+    masked, log = _child("merged", {"MI355X_STREAM_CUS": "8"})
+    assert masked["digest"] == full["digest"], "results on the CU-masked stream differ"
+    assert '"folds": 2' in log_full and '"folds": 0' in log, (log_full[-300:], log[-300:])
 
 
 def test_a_smaller_chain_grid_is_chosen_when_only_that_fits():
