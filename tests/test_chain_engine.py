@@ -122,7 +122,7 @@ elif which == "merged":   # 2048-wide Temporal stack over a long ring: in_proj +
     cfg = tf.temporal_cfg(1200)
     rec5, st = tf.run("hip", cfg, 4, fill=700)
     rec = [(r[0], r[1], r[2], r[3], [r[4]]) for r in rec5]
-    print(json.dumps({"folds": int(st.attention_folds_planned)}), file=sys.stderr)
+    print(json.dumps({{"folds": int(st.attention_folds_planned)}}), file=sys.stderr)
 else:   # a long ring: the Temporal attention would be split over workgroups that wait for each other
     cfg = hu.hot.tiny(hu.L)
     cfg.dim, cfg.num_heads, cfg.context = 512, 4, 1200
