@@ -2257,7 +2257,7 @@ void k_attn_decode(hipStream_t s, const attn_args & a, void * ws, unsigned * err
 #define FOLD_NW 8
 #define FOLD_GRID 256
 #define FOLD_PMAX 4      // passes of 64 super-blocks a workgroup holds in registers: rows_wg * nb <= 256
-struct fold_ws { unsigned long long * gbuf; unsigned * seq; unsigned * arrive; unsigned * err; };
+struct fold_ws { unsigned long long * gbuf; unsigned long long * arrive; unsigned * err; };   // arrive: workgroups that have finished, over all launches so far
 #if defined(MV_LOG)
 #define FD_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) { unsigned long long t_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); g_fold_log[fd_id][i] = t_; } } while (0)
 __device__ unsigned long long g_fold_log[4096][8];
@@ -2293,7 +2293,7 @@ static bool fold_use_split(const attn_args & at) {
 // workgroups then enter attn_decode_body with the granules as their q / k / v source (AT_GQKV): the ring rows, the mask and the RoPE table are requested
 // first and land while the granules are polled, so the hand-off costs one round trip that the separate launch spent on its cold loads anyway. Split
 // geometry, hand-offs and arithmetic are the attention kernel's own (S = 256 / H parts per head, 8 waves). Workgroups without attention work leave at once.
-// tag = a launch counter in the workspace + 1, read first thing by every workgroup and bumped by the launch's last arriver - so the bump can never overtake a late starter's read.
+// tag = launches completed so far + 1, derived by every workgroup from ONE counter of finished workgroups (see the kernel's first lines).
 // The head's parts wait for each other: the grid must be resident (k_inproj_attn_supported).
 // ---------------------------------------------------------------------------------------------------
 template <bool SPLIT>
@@ -2312,8 +2312,10 @@ __global__ void __launch_bounds__(FOLD_NW * 64) inproj_attn_kernel(mv_args a, at
     const unsigned fd_id = b == 0 ? fd_id_s : 0u;
 #endif
     FD_STAMP(0);
-    const unsigned seq = __hip_atomic_load(f.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const unsigned tag = seq + 1u;
+    // The launch's tag: launches completed so far + 1 = (workgroups that have finished, over all launches) / grid + 1. Every workgroup adds itself to
+    // that count as its LAST act (a non-returning add: nothing waits for it), so whatever a workgroup of launch n reads - it has not added itself yet -
+    // lies in [n G, (n + 1) G): every workgroup of a launch derives the same tag, late starters included, and no word is ever bumped by anybody.
+    const unsigned tag = (unsigned) (__hip_atomic_load(f.arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) / (unsigned long long) gridDim.x) + 1u;
     const int nb = (int) (a.K / 256), K = (int) a.K;
     const int rows = 3 * seg_rows, nblk = rows * nb, ntiles = nblk >> 6, tiles_seg = (seg_rows * nb) >> 6;   // (whole tiles per segment: host-checked)
     xblk * xs = (xblk *) smem;
@@ -2418,13 +2420,8 @@ __global__ void __launch_bounds__(FOLD_NW * 64) inproj_attn_kernel(mv_args a, at
     // ---- the attention of head h, part part_i, its new rows taken from the granules
     attn_decode_body<SPLIT, NW, AT_GQKV>(at, w, smem, h, part_i, 0, tag, gq);
     FD_STAMP(4);
-    // this workgroup has read the launch counter (long ago): arrive; the launch's last arriver bumps it - nobody can still be about to read the old value.
-    // (Behind the attention stage: the add's round trip must not sit between the row sums and the hand-off.)
-    if (tid == 0) {
-        asm volatile("" :: "v"(seq) : "memory");
-        const unsigned arrived = __hip_atomic_fetch_add(f.arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (arrived + 1u == tag * (unsigned) gridDim.x) __hip_atomic_store(f.seq, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    // this workgroup is done: count it in (the tag was read at entry and is in use since - the asm pins that order for the compiler)
+    if (tid == 0) { asm volatile("" :: "v"(tag) : "memory"); (void) __hip_atomic_fetch_add(f.arrive, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
     FD_STAMP(5);
 }
 
@@ -2465,7 +2462,7 @@ size_t k_inproj_attn_ws_size(const mv_args & a, const attn_args & at) {
 void k_inproj_attn(hipStream_t s, const mv_args & a, const attn_args & at, void * ws, unsigned * err) {
     static const int single_max = env_int("MI355X_ATTN_SINGLE_MAX", ATTN_SINGLE_MAX), big_min = env_int("MI355X_ATTN_BIG_MIN", ATTN_SPLIT_BIG_MIN);
     char * p = (char *) ws;
-    fold_ws f = { (unsigned long long *) (p + 256), (unsigned *) p, (unsigned *) (p + 64), err };
+    fold_ws f = { (unsigned long long *) (p + 256), (unsigned long long *) p, err };
     p += 256 + (size_t) a.M * 8;
     const bool split = fold_use_split(at);
     attn_split_ws w = { nullptr, nullptr, nullptr, 1, err, ATTN_SPLIT_SLOTS, single_max, big_min };
