@@ -2315,7 +2315,7 @@ __global__ void __launch_bounds__(FOLD_NW * 64) inproj_attn_kernel(mv_args a, at
     // The launch's tag: launches completed so far + 1 = (workgroups that have finished, over all launches) / grid + 1. Every workgroup adds itself to
     // that count as its LAST act (a non-returning add: nothing waits for it), so whatever a workgroup of launch n reads - it has not added itself yet -
     // lies in [n G, (n + 1) G): every workgroup of a launch derives the same tag, late starters included, and no word is ever bumped by anybody.
-    const unsigned tag = (unsigned) (__hip_atomic_load(f.arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) / (unsigned long long) gridDim.x) + 1u;
+    const unsigned tag = (unsigned) (__hip_atomic_load(f.arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) / (unsigned long long) FOLD_GRID) + 1u;   // (the grid is FOLD_GRID workgroups, always)
     const int nb = (int) (a.K / 256), K = (int) a.K;
     const int rows = 3 * seg_rows, nblk = rows * nb, ntiles = nblk >> 6, tiles_seg = (seg_rows * nb) >> 6;   // (whole tiles per segment: host-checked)
     xblk * xs = (xblk *) smem;
