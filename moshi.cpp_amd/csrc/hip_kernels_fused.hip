@@ -2001,6 +2001,54 @@ __device__ __forceinline__ void attn_decode_body(const attn_args & a_in, const a
             }
         }
         AT_STAMP(10);
+#ifndef ATTN_QUICK
+#define ATTN_QUICK 1
+#endif
+        // Short context, one workgroup per head, one query row (the regime every frame of the benchmark window runs in): every live slot is among the
+        // rows requested at entry and there are at most 128 scores, so each WAVE can redo the soft-max statistics for itself from the scores in LDS -
+        // maximum, exponentials, double sum: the same values in every wave, same inputs, same instructions - and take the probabilities of its own slots
+        // from them. Two of the five workgroup barriers of the general path (block maximum, block sum) and its end-of-row barrier disappear; the
+        // arithmetic is the general path's except for the association of the exponentials' double sum (lane l adds slots l and l + 64 first).
+        if (ATTN_QUICK && !multi && T == 1 && n_end <= 128 && n_end <= NPRE * ATTN_NW * SPW) {
+            __syncthreads();                                   // every score is in LDS
+            AT_STAMP(3);
+            const float s0 = lane < n_end ? sc[lane] : -INFINITY, s1 = lane + 64 < n_end ? sc[lane + 64] : -INFINITY;
+            const float qmax = wave_allmax_f32(fmaxf(s0, s1));
+            const float e0 = s0 > -INFINITY ? expf(s0 - qmax) : 0.f, e1 = s1 > -INFINITY ? expf(s1 - qmax) : 0.f;
+            const double qsum = wave_allsum_f64((double) e0 + (double) e1);
+            const float qinv = (float) (1.0 / qsum);
+            AT_STAMP(4);
+            double q8[8];
+#pragma unroll
+            for (int i = 0; i < 8; i++) q8[i] = 0;
+#pragma unroll
+            for (int pi = 0; pi < NPRE; pi++) {
+                const int c0 = c_lo + wave * SPW + pi * ATTN_NW * SPW, c = c0 + sub;
+                if (c0 < c_hi) {
+                    const float sv = c < c_hi ? sc[c] : -INFINITY;
+                    const float e = sv > -INFINITY ? expf(sv - qmax) : 0.f;
+                    const float pq = c < c_hi ? bf2f(f2bf(e * qinv)) : 0.f;
+                    const uint32_t vw[4] = { vpre[pi].x, vpre[pi].y, vpre[pi].z, vpre[pi].w };
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        q8[2 * i]     += (double) (bf2f((uint16_t) (vw[i] & 0xffff)) * pq);
+                        q8[2 * i + 1] += (double) (bf2f((uint16_t) (vw[i] >> 16)) * pq);
+                    }
+                }
+            }
+            AT_STAMP(5);
+#pragma unroll
+            for (int i = 0; i < 8; i++) red[(wave * SPW + sub) * D + dl + i] = q8[i];
+            __syncthreads();
+            AT_STAMP(6);
+            for (int j = tid; j < D; j += ATTN_THREADS) {
+                double tot = 0;
+#pragma unroll 8
+                for (int g = 0; g < ATTN_NW * SPW; g++) tot += red[g * D + j];   // fixed order: wave-major, slot group minor
+                a.out[(int64_t) t * a.out_ts + (int64_t) h * D + j] = (float) tot;
+            }
+            continue;                                          // (T == 1: the row loop ends here; nothing reuses the LDS)
+        }
         lmax = wave_allmax_f32(lmax);
         if (lane == 0) sh_f[wave] = lmax;
         AT_STAMP(11);

@@ -122,7 +122,9 @@ def test_full_width_attention_over_a_prefilled_ring_node_by_node(model):
     if model != "moshika":
         cfg.context = 2000
     C_ = cfg.context
-    offsets = [161, 300, 1100, C_ - 1000, C_ - 100, C_ - 1, C_, C_ + 1, 2 * C_ + 37]
+    # (7 ... 127 live slots: the short-context path of the attention body - each wave redoes the soft-max statistics for itself; 128 ... 160: the general
+    # single-workgroup path; beyond: the split)
+    offsets = [6, 39, 99, 126, 127, 139, 161, 300, 1100, C_ - 1000, C_ - 100, C_ - 1, C_, C_ + 1, 2 * C_ + 37]
     pr = LayerProber(cfg)
     rng = np.random.default_rng(13)
     for layer in (0, cfg.num_layers // 2 - 3, cfg.num_layers - 1):
