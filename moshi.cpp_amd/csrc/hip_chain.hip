@@ -45,13 +45,16 @@ typedef unsigned long long u64;
 // diagnostic build only (-DCH_LOG, tests/microbench/chain_stamps.py): wave 0 of the first and the last workgroup log s_memrealtime (10 ns ticks)
 // at the stages of every phase of the last launch
 #if defined(CH_LOG)
-__device__ u64 g_ch_log[2][512][12];   // [0] workgroup 0 wave 0, [1] last workgroup wave 0
+__device__ u64 g_ch_log[2][512][16];   // [0] workgroup 0 wave 0, [1] last workgroup wave 0
 #define CH_STAMP(i) do { if (wave == 0 && lane == 0 && (wg == 0 || wg == grid - 1) && p < 512) { u64 t_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); g_ch_log[wg == 0 ? 0 : 1][p][i] = t_; } } while (0)
+// (inside chain_attn_wave: stamps 11 .. 15 by wave 0 of the logging workgroups)
+#define CH_ASTAMP(i) do { if (log_wg >= 0 && h0 == 0 && lane == 0 && log_p < 512) { u64 t_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); g_ch_log[log_wg][log_p][i] = t_; } } while (0)
 extern "C" __attribute__((visibility("default"))) int mi355x_chain_log_read(u64 * out) {
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ch_log), sizeof(g_ch_log)) == hipSuccess ? 0 : -1;
 }
 #else
 #define CH_STAMP(i) do {} while (0)
+#define CH_ASTAMP(i) do {} while (0)
 #endif
 
 struct chain_phase {
@@ -173,8 +176,9 @@ __device__ __forceinline__ void chain_attn_ring_loads(const attn_args & a, int h
 }
 __device__ __forceinline__ void chain_attn_wave(const attn_args & a, const float * qb, const float * kb, const float * vb, int h0, int lane, float * wbuf, float * xa,
                                                 const u32x4 kq[2], const u32x4 vq[2], bool write_cache, __amdgpu_buffer_rsrc_t kr, __amdgpu_buffer_rsrc_t vr,
-                                                int slot, float m, float rc, float rs) {
+                                                int slot, float m, float rc, float rs, int log_wg = -1, int log_p = 0) {
     constexpr int NH = 2, LPS = 8, half = 32;
+    CH_ASTAMP(11);
     const int C = a.C;
     const int sub = lane / LPS, dl = (lane % LPS) * 8;
     const int c = sub;
@@ -210,6 +214,7 @@ __device__ __forceinline__ void chain_attn_wave(const attn_args & a, const float
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     float * prod = wbuf + NH * 192;
+    CH_ASTAMP(12);
 #pragma unroll
     for (int hq = 0; hq < 2; hq++) {
         const int hh = hq;
@@ -258,7 +263,9 @@ __device__ __forceinline__ void chain_attn_wave(const attn_args & a, const float
         float * dst = prod + hq * 512 + sub * 64 + dl;
         *(float4 *) dst = make_float4(pf[0], pf[1], pf[2], pf[3]);
         *(float4 *) (dst + 4) = make_float4(pf[4], pf[5], pf[6], pf[7]);
+        if (hq == 0) CH_ASTAMP(13);
     }
+    CH_ASTAMP(14);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -269,6 +276,7 @@ __device__ __forceinline__ void chain_attn_wave(const attn_args & a, const float
         for (int c2 = 0; c2 < 8; c2++) tot += (double) prod[hq * 512 + c2 * 64 + lane];
         xa[hq * 64 + lane] = (float) tot;
     }
+    CH_ASTAMP(15);
 }
 
 // one field of a descriptor parked in LDS, as a wave-uniform (scalar) value
@@ -556,7 +564,11 @@ __global__ void __launch_bounds__(CH_THREADS) matvec_chain_kernel(chain_params P
             if (!wg_barrier(ctl)) return false;
             {
                 chain_attn_wave(ph.at, xf + ph.q_off, xf + ph.k_off, xf + ph.v_off, wave * 2, lane, attw + wave * CH_ATTW, xa + wave * 128, kq, vq, wg == 0, kr, vr,
-                                at_slot, at_m, at_rc, at_rs);
+                                at_slot, at_m, at_rc, at_rs
+#if defined(CH_LOG)
+                                , wg == 0 ? 0 : wg == grid - 1 ? 1 : -1, p
+#endif
+                                );
             }
             if (!wg_barrier(ctl)) return false;
             xsrc = xa;
