@@ -161,6 +161,26 @@ __device__ __forceinline__ bool gather_vector(__amdgpu_buffer_rsrc_t gb, unsigne
     }
 }
 
+// wave_allmax_f32 / wave_allsum_f64 (hip_device.h) for a value that is uniform inside every group of 8 lanes (for the sum: carried by ONE lane of the group,
+// zero in the others): their first three steps stay inside the group and leave such a value as it is
+__device__ __forceinline__ float wave_allmax_f32_groups8(float v) {
+    v = fmaxf(v, dpp_f32<DPP_ROW_MIRROR>(v));
+    const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
+    const float r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
+    const float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32));
+    const float r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+    return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
+}
+__device__ __forceinline__ double wave_allsum_f64_groups8(double v) {
+    v += dpp_f64<DPP_ROW_MIRROR>(v);
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    const double r0 = __hiloint2double(__builtin_amdgcn_readlane(hi, 0), __builtin_amdgcn_readlane(lo, 0));
+    const double r1 = __hiloint2double(__builtin_amdgcn_readlane(hi, 16), __builtin_amdgcn_readlane(lo, 16));
+    const double r2 = __hiloint2double(__builtin_amdgcn_readlane(hi, 32), __builtin_amdgcn_readlane(lo, 32));
+    const double r3 = __hiloint2double(__builtin_amdgcn_readlane(hi, 48), __builtin_amdgcn_readlane(lo, 48));
+    return (r0 + r1) + (r2 + r3);
+}
+
 // Attention of 2 consecutive heads by one wave for a single new token over a ring of <= 8 slots of 64: attn_small_wave<2> of hip_kernels_fused.hip
 // with the new token's q / k / v taken from LDS (the in_proj rows just gathered), the ring rows passed in (requested with agent-scope loads BEFORE
 // the hand-off wait: they were written by earlier phases) and the ring write done with agent-scope stores. Same arithmetic in the same order.
@@ -215,56 +235,57 @@ __device__ __forceinline__ void chain_attn_wave(const attn_args & a, const float
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     float * prod = wbuf + NH * 192;
     CH_ASTAMP(12);
+    // The two heads' chains - 8-dim partial dot, 8-lane sum, wave maximum, exponential, wave sum, reciprocal, P x V products - are independent and each is a
+    // string of dependent DPP reductions: written stage by stage over BOTH heads, without branches and with every LDS read in front, so that the scheduler
+    // interleaves them (one after the other they took 0.6 us each, profiles/r04_chain_stamps.txt). Per head the arithmetic and its order are unchanged.
+    float qv[2][8], kv[2][8], vv8[2][8];
 #pragma unroll
-    for (int hq = 0; hq < 2; hq++) {
-        const int hh = hq;
+    for (int hh = 0; hh < 2; hh++) {
         const float * qf = wbuf + hh * 192, * knew = qf + 64, * vnew = qf + 128;
-        float qv[8];
+        const uint32_t kw[4] = { kq[hh].x, kq[hh].y, kq[hh].z, kq[hh].w }, vw[4] = { vq[hh].x, vq[hh].y, vq[hh].z, vq[hh].w };
 #pragma unroll
-        for (int i = 0; i < 8; i++) qv[i] = qf[dl + i];
-        double acc = 0;
-        if (live) {
-            if (fresh) {
-#pragma unroll
-                for (int i = 0; i < 8; i++) acc += (double) (knew[dl + i] * qv[i]);
-            } else {
-                const uint32_t kw[4] = { kq[hh].x, kq[hh].y, kq[hh].z, kq[hh].w };
-#pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    acc += (double) (bf2f((uint16_t) (kw[i] & 0xffff)) * qv[2 * i]);
-                    acc += (double) (bf2f((uint16_t) (kw[i] >> 16)) * qv[2 * i + 1]);
-                }
-            }
+        for (int i = 0; i < 8; i++) {
+            qv[hh][i] = qf[dl + i];
+            const float kn = knew[dl + i], vn = vnew[dl + i];
+            const float kr8 = bf2f((uint16_t) ((i & 1) ? (kw[i >> 1] >> 16) : (kw[i >> 1] & 0xffff))), vr8 = bf2f((uint16_t) ((i & 1) ? (vw[i >> 1] >> 16) : (vw[i >> 1] & 0xffff)));
+            kv[hh][i] = fresh ? kn : kr8;
+            vv8[hh][i] = fresh ? vn : vr8;
         }
-        acc = group_allsum_f64(acc, LPS);
-        const float sv = live ? (float) acc * a.scale + m : -INFINITY;
-        const float gmax = wave_allmax_f32(sv);
-        const float e = sv > -INFINITY ? expf(sv - gmax) : 0.f;
-        double lsum = (lane % LPS) == 0 ? (double) e : 0.0;
-        lsum = wave_allsum_f64(lsum);
-        const float inv = (float) (1.0 / lsum);
-        const float pr = bf2f(f2bf(e * inv));
+    }
+    double acc[2];
+#pragma unroll
+    for (int hh = 0; hh < 2; hh++) {
+        double a2 = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) a2 += (double) (kv[hh][i] * qv[hh][i]);
+        acc[hh] = live ? a2 : 0.0;
+    }
+#pragma unroll
+    for (int hh = 0; hh < 2; hh++) acc[hh] = group_allsum_f64(acc[hh], LPS);
+    float sv[2], gmax[2], e[2];
+#pragma unroll
+    for (int hh = 0; hh < 2; hh++) sv[hh] = live ? (float) acc[hh] * a.scale + m : -INFINITY;
+    // (sv and e are the same in all 8 lanes of a slot group: the three in-group steps of wave_allmax_f32 / wave_allsum_f64 would return their input -
+    // max(v, v), and e + 0 + 0 + 0 with only lane 0 of a group carrying e - so the reductions start at the step that crosses groups; same values, same order)
+#pragma unroll
+    for (int hh = 0; hh < 2; hh++) gmax[hh] = wave_allmax_f32_groups8(sv[hh]);
+#pragma unroll
+    for (int hh = 0; hh < 2; hh++) e[hh] = sv[hh] > -INFINITY ? expf(sv[hh] - gmax[hh]) : 0.f;
+    double lsum[2];
+#pragma unroll
+    for (int hh = 0; hh < 2; hh++) lsum[hh] = wave_allsum_f64_groups8((double) e[hh]);
+#pragma unroll
+    for (int hh = 0; hh < 2; hh++) {
+        const float inv = (float) (1.0 / lsum[hh]);
+        const float pr = bf2f(f2bf(e[hh] * inv));
         float pf[8];
 #pragma unroll
-        for (int i = 0; i < 8; i++) pf[i] = 0.f;
-        if (pr != 0.f) {
-            if (fresh) {
-#pragma unroll
-                for (int i = 0; i < 8; i++) pf[i] = vnew[dl + i] * pr;
-            } else {
-                const uint32_t vw[4] = { vq[hh].x, vq[hh].y, vq[hh].z, vq[hh].w };
-#pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    pf[2 * i]     = bf2f((uint16_t) (vw[i] & 0xffff)) * pr;
-                    pf[2 * i + 1] = bf2f((uint16_t) (vw[i] >> 16)) * pr;
-                }
-            }
-        }
-        float * dst = prod + hq * 512 + sub * 64 + dl;
+        for (int i = 0; i < 8; i++) pf[i] = pr != 0.f ? vv8[hh][i] * pr : 0.f;
+        float * dst = prod + hh * 512 + sub * 64 + dl;
         *(float4 *) dst = make_float4(pf[0], pf[1], pf[2], pf[3]);
         *(float4 *) (dst + 4) = make_float4(pf[4], pf[5], pf[6], pf[7]);
-        if (hq == 0) CH_ASTAMP(13);
     }
+    CH_ASTAMP(13);
     CH_ASTAMP(14);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();

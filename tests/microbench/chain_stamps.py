@@ -40,8 +40,9 @@ for k in range(per):
     print(f"  phase {k:2d} of a step: {dur[sel].mean():6.2f} us  stages " + " ".join(f"{stage[sel, i].mean():5.2f}" for i in range(8)))
 
 
-# inside the attention of an attention phase (wave 0 of workgroup 0): gathered -> [barrier] -> entry, RoPE + staging, head 0 to its products, head 1, 8-slot sums -> [barrier] -> attention done
+# inside the attention of an attention phase (wave 0 of workgroup 0): gathered -> [barrier] -> entry, RoPE + staging, both heads' chains to their products (interleaved
+# since round 4; one after the other they were 0.61 + 0.58 us), 8-slot sums -> [barrier] -> attention done
 att = [p for p in range(n) if rec[0, p, 11] > 0]
 if att:
     a = np.array([[(rec[0, p, 11] - rec[0, p, 2]), (rec[0, p, 12] - rec[0, p, 11]), (rec[0, p, 13] - rec[0, p, 12]), (rec[0, p, 14] - rec[0, p, 13]), (rec[0, p, 15] - rec[0, p, 14]), (rec[0, p, 3] - rec[0, p, 15])] for p in att]) / 100.0
-    print(f"attention phases ({len(att)}), us: barrier in {a[:, 0].mean():.2f} | RoPE + staging {a[:, 1].mean():.2f} | head 0 -> products {a[:, 2].mean():.2f} | head 1 {a[:, 3].mean():.2f} | slot sums {a[:, 4].mean():.2f} | barrier out {a[:, 5].mean():.2f}")
+    print(f"attention phases ({len(att)}), us: barrier in {a[:, 0].mean():.2f} | RoPE + staging {a[:, 1].mean():.2f} | both heads -> products {a[:, 2].mean():.2f} | (-) {a[:, 3].mean():.2f} | slot sums {a[:, 4].mean():.2f} | barrier out {a[:, 5].mean():.2f}")
