@@ -2773,22 +2773,31 @@ void k_vq_level(hipStream_t s, const vq_level_args & a) {
 // One workgroup; every thread keeps n / 1024 probabilities in registers. The k-th largest value is found by a 4-pass radix select on the
 // float bits (p >= 0, so the bit patterns order like the values), the k survivors are rank-sorted in LDS.
 // ---------------------------------------------------------------------------------------------------
-#define SMP_NPT 32
-template <int SMP_THREADS>
+#if defined(SMP_LOG)   // diagnostic build (tests/microbench/sampler_bench.hip): thread 0 stamps s_memrealtime (10 ns ticks) at the kernel's stages
+__device__ unsigned long long g_smp_log[16];
+#define SMP_STAMP(i) do { if (threadIdx.x == 0) { unsigned long long t_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); g_smp_log[i] = t_; } } while (0)
+#else
+#define SMP_STAMP(i) do {} while (0)
+#endif
+// NPT: probabilities per thread (every loop over them is unrolled: the 2 048-logit audio heads get their own instantiation with 2 instead of 32)
+#define SMP_BIN_MAX 64   // the select stops as soon as the bin that holds the k-th largest value has at most this many members
+template <int SMP_THREADS, int SMP_NPT>
 __global__ void __launch_bounds__(SMP_THREADS) sample_topk_kernel(sample_args a) {
-    __shared__ float shf[SMP_THREADS / 64];
-    __shared__ double shd[SMP_THREADS / 64];
-    __shared__ int shi[SMP_THREADS / 64];
-    __shared__ unsigned hist[256];
-    __shared__ unsigned whist[SMP_THREADS / 64][256];
+    constexpr int NW = SMP_THREADS / 64;
+    __shared__ float shf[NW];
+    __shared__ double shd[NW];
+    __shared__ int shi[NW];
+    __shared__ __attribute__((aligned(16))) unsigned whist[2][NW][256];   // one private histogram per wave, two sets (the other one is cleared while one is scanned)
     __shared__ unsigned s_bin, s_remaining, s_ncand, s_eq, s_base;
-    __shared__ __attribute__((aligned(16))) float cand_p[SAMPLE_MAX_K + 8];
-    __shared__ __attribute__((aligned(16))) int cand_i[SAMPLE_MAX_K + 8];
+    // a candidate = (bits of p) << 32 | ~index: one unsigned 64-bit compare orders by value descending, then index ascending (p >= 0)
+    __shared__ __attribute__((aligned(16))) unsigned long long cand[SAMPLE_MAX_K + SMP_BIN_MAX + 40];
+    __shared__ int rank_acc[SAMPLE_MAX_K + SMP_BIN_MAX];
     __shared__ float sort_p[SAMPLE_MAX_K];
     __shared__ int sort_i[SAMPLE_MAX_K];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = a.n, k = a.k;
-    constexpr int NW = SMP_THREADS / 64;
     float p[SMP_NPT];
+    SMP_STAMP(0);
+    const float my_noise = a.noise[tid < k ? tid : 0];   // (k <= SAMPLE_MAX_K <= threads: rank j's noise sits in thread j from the start, not behind the sort)
     // ---- soft_max
     float mx = -INFINITY;
 #pragma unroll
@@ -2797,10 +2806,14 @@ __global__ void __launch_bounds__(SMP_THREADS) sample_topk_kernel(sample_args a)
         p[j] = i < n ? a.logits[i] * a.scale : -INFINITY;
         mx = fmaxf(mx, p[j]);
     }
+    for (int i = tid; i < NW * 256; i += SMP_THREADS) (&whist[0][0][0])[i] = 0u;   // (the first pass's histograms, behind the loads)
+    SMP_STAMP(6);
     mx = wave_allmax_f32(mx);
+    SMP_STAMP(7);
     if (lane == 0) shf[wave] = mx;
     if (tid == 0) { s_ncand = 0u; }
     __syncthreads();
+    SMP_STAMP(8);
     mx = shf[0];
 #pragma unroll
     for (int w = 1; w < NW; w++) mx = fmaxf(mx, shf[w]);
@@ -2813,38 +2826,49 @@ __global__ void __launch_bounds__(SMP_THREADS) sample_topk_kernel(sample_args a)
         p[j] = e;
         sum += (double) e;
     }
+    SMP_STAMP(9);
     sum = wave_allsum_f64(sum);
     if (lane == 0) shd[wave] = sum;
     __syncthreads();
+    SMP_STAMP(10);
     sum = 0;
 #pragma unroll
     for (int w = 0; w < NW; w++) sum += shd[w];
     const float inv = (float) (1.0 / sum);
 #pragma unroll
     for (int j = 0; j < SMP_NPT; j++) p[j] *= inv;
+    SMP_STAMP(1);
+    int total_c = k;   // candidates that reach the rank sort
     {
-    // ---- k-th largest by radix select over the bit patterns
+    // ---- k-th largest by radix select over the bit patterns (p >= 0: the patterns order like the values), most significant byte first. After a pass
+    // everything whose leading bytes exceed the selected prefix is in the top k for sure, the members of the selected bin are undecided. The select
+    // stops as soon as that bin has <= SMP_BIN_MAX members: they all go to the rank sort with the sure ones, which orders them (value descending,
+    // index ascending - the same rule the remaining passes and the tie handling below apply) and keeps ranks < k. Two passes are the rule.
     unsigned prefix = 0u, mask = 0u, remaining = (unsigned) k;
-    for (int shift = 24; shift >= 0; shift -= 8) {
+    bool early = false;
+    int buf = 0;
+    for (int shift = 24; shift >= 0; shift -= 8, buf ^= 1) {
         // one private histogram per wave (same-bin lanes of a wave-instruction are serialised by the LDS unit itself, a few cycles each; a shared
         // histogram costs ~18 us per pass in same-address atomics, a software match loop ~25 us on the text vocabulary's many exponent bins)
-        for (int i = tid; i < NW * 256; i += SMP_THREADS) (&whist[0][0])[i] = 0u;
-        __syncthreads();
 #pragma unroll
         for (int j = 0; j < SMP_NPT; j++) {
             if (j * SMP_THREADS >= n) break;
             const int i = tid + j * SMP_THREADS;
             const unsigned key = __float_as_uint(p[j]);
-            if (i < n && (key & mask) == prefix) atomicAdd(&whist[wave][(key >> shift) & 255u], 1u);
+            if (i < n && (key & mask) == prefix) atomicAdd(&whist[buf][wave][(key >> shift) & 255u], 1u);
         }
         __syncthreads();
-        if (tid < 256) { unsigned t = 0; for (int w2 = 0; w2 < NW; w2++) t += whist[w2][tid]; hist[tid] = t; }
-        __syncthreads();
         if (wave == 0) {
-            // lane l owns bins 255 - 4 l .. 252 - 4 l (descending); inclusive prefix over lanes, first lane reaching `remaining` resolves its bin
-            unsigned h[4], tot = 0;
+            // lane l owns bins 255 - 4 l .. 252 - 4 l (descending) and adds the waves' counts itself; inclusive prefix over lanes, the first lane
+            // reaching `remaining` resolves its bin
+            unsigned h[4] = { 0u, 0u, 0u, 0u }, tot = 0;
 #pragma unroll
-            for (int t = 0; t < 4; t++) { h[t] = hist[255 - (4 * lane + t)]; tot += h[t]; }
+            for (int w2 = 0; w2 < NW; w2++) {
+                const u32x4 v = *(const u32x4 *) &whist[buf][w2][252 - 4 * lane];
+                h[0] += v.w; h[1] += v.z; h[2] += v.y; h[3] += v.x;
+            }
+#pragma unroll
+            for (int t = 0; t < 4; t++) tot += h[t];
             unsigned inc = tot;
 #pragma unroll
             for (int o = 1; o < 64; o <<= 1) { const unsigned up = __shfl_up(inc, o, 64); if (lane >= o) inc += up; }
@@ -2858,30 +2882,35 @@ __global__ void __launch_bounds__(SMP_THREADS) sample_topk_kernel(sample_args a)
                 s_remaining = remaining - before;
                 s_eq = h[t];
             }
+        } else {
+            for (int i = tid - 64; i < NW * 256; i += SMP_THREADS - 64) (&whist[buf ^ 1][0][0])[i] = 0u;   // the next pass's histograms
         }
         __syncthreads();
         prefix |= s_bin << shift;
         mask |= 255u << shift;
         remaining = s_remaining;
+        if (shift > 0 && s_eq <= (unsigned) SMP_BIN_MAX) { early = true; break; }
     }
-    const unsigned T = prefix, need_eq = remaining, have_eq = s_eq;   // key of the k-th largest; how many of its ties belong to the top k
-    // ---- collect: everything above T, then the `need_eq` lowest-indexed ties
+    const unsigned T = prefix, need_eq = remaining, have_eq = s_eq;   // (all four passes:) key of the k-th largest; how many of its ties belong to the top k
+    SMP_STAMP(2);
+    if (early) total_c = k - (int) need_eq + (int) have_eq;          // the sure ones + the whole undecided bin
+    // ---- collect: everything above the prefix, then (early: the whole bin; else) the `need_eq` lowest-indexed ties
 #pragma unroll
     for (int j = 0; j < SMP_NPT; j++) {
         if (j * SMP_THREADS >= n) break;
         const int i = tid + j * SMP_THREADS;
-        const unsigned key = __float_as_uint(p[j]);
-        const bool take = i < n && (key > T || (key == T && have_eq == need_eq));
+        const unsigned key = __float_as_uint(p[j]) & mask;
+        const bool take = i < n && (key > T || (key == T && (early || have_eq == need_eq)));
         const unsigned long long tb = __ballot(take);   // one LDS atomic per wave-instruction, not per survivor
         if (tb) {
             unsigned base = 0;
             if (lane == __ffsll((long long) tb) - 1) base = atomicAdd(&s_ncand, (unsigned) __popcll(tb));
             base = (unsigned) __shfl((int) base, __ffsll((long long) tb) - 1, 64);
             const unsigned c = base + (unsigned) __popcll(tb & ((1ull << lane) - 1ull));
-            if (take && c < SAMPLE_MAX_K) { cand_p[c] = p[j]; cand_i[c] = i; }
+            if (take && c < SAMPLE_MAX_K + SMP_BIN_MAX) cand[c] = ((unsigned long long) __float_as_uint(p[j]) << 32) | (unsigned long long) (~(unsigned) i);
         }
     }
-    if (have_eq != need_eq) {   // more ties than places (rare: exact float ties at the cut): take them in index order, j-major / thread-minor
+    if (!early && have_eq != need_eq) {   // more ties than places (rare: exact float ties at the cut): take them in index order, j-major / thread-minor
         if (tid == 0) s_base = 0u;
         __syncthreads();
         for (int j = 0; j < SMP_NPT && j * SMP_THREADS < n; j++) {
@@ -2893,50 +2922,70 @@ __global__ void __launch_bounds__(SMP_THREADS) sample_topk_kernel(sample_args a)
             unsigned off = s_base;
             for (int w = 0; w < wave; w++) off += (unsigned) shi[w];
             off += (unsigned) __popcll(b & ((1ull << lane) - 1ull));
-            if (f && off < need_eq) { const unsigned c = atomicAdd(&s_ncand, 1u); if (c < SAMPLE_MAX_K) { cand_p[c] = p[j]; cand_i[c] = i; } }
+            if (f && off < need_eq) { const unsigned c = atomicAdd(&s_ncand, 1u); if (c < SAMPLE_MAX_K) cand[c] = ((unsigned long long) __float_as_uint(p[j]) << 32) | (unsigned long long) (~(unsigned) i); }
             __syncthreads();
             if (tid == 0) { unsigned tot = 0; for (int w = 0; w < NW; w++) tot += (unsigned) shi[w]; s_base += tot; }
             __syncthreads();
         }
     }
-    if (tid < 8) { cand_p[k + tid] = -1.f; cand_i[k + tid] = 0x7fffffff; }   // sentinels (p >= 0): the sort below reads eight candidates at a time
+    if (tid < total_c) rank_acc[tid] = 0;
+    if (tid < 40) cand[total_c + tid] = 0ull;   // sentinels (below every candidate) up to the end of the last quarter the sort below reads, eight at a time
     __syncthreads();
-    // ---- rank sort of the k survivors: value descending, index ascending
-    for (int c = tid; c < k; c += SMP_THREADS) {
-        const float pc = cand_p[c]; const int ic = cand_i[c];
+    SMP_STAMP(3);
+    // ---- rank sort of the candidates: value descending, index ascending; four threads per candidate, each counting a quarter of the list
+    // (a wave = 64 candidates x ONE quarter of the list: every lane reads the same eight keys at a time - LDS broadcasts, no bank conflicts; the four
+    // quarters' counts of a candidate meet in rank_acc)
+    const int quarter = ((total_c + 31) >> 5) << 3;   // multiple of 8, 4 * quarter in [total_c, total_c + 32): the overshoot reads sentinels
+    for (int c0 = 0; c0 < total_c; c0 += SMP_THREADS / 4) {
+        const int part = wave & 3, c = c0 + (wave >> 2) * 64 + lane;
+        if (c0 + (wave >> 2) * 64 >= total_c) break;   // (wave-uniform)
+        const bool live = c < total_c;
+        const unsigned long long kc = live ? cand[c] : ~0ull;
         int rank = 0;
-        for (int d0 = 0; d0 < k; d0 += 8) {
-            const float4 pa = *(const float4 *) (cand_p + d0), pb = *(const float4 *) (cand_p + d0 + 4);
-            const int4 ia = *(const int4 *) (cand_i + d0), ib = *(const int4 *) (cand_i + d0 + 4);
-            const float pd[8] = { pa.x, pa.y, pa.z, pa.w, pb.x, pb.y, pb.z, pb.w };
-            const int id[8] = { ia.x, ia.y, ia.z, ia.w, ib.x, ib.y, ib.z, ib.w };
+        for (int d0 = part * quarter; d0 < (part + 1) * quarter; d0 += 8) {
+            unsigned long long kd[8];
 #pragma unroll
-            for (int u = 0; u < 8; u++) rank += (pd[u] > pc || (pd[u] == pc && id[u] < ic)) ? 1 : 0;
+            for (int u = 0; u < 8; u += 2) { const u32x4 t = *(const u32x4 *) (cand + d0 + u); kd[u] = ((unsigned long long) t.y << 32) | t.x; kd[u + 1] = ((unsigned long long) t.w << 32) | t.z; }
+#pragma unroll
+            for (int u = 0; u < 8; u++) rank += kd[u] > kc ? 1 : 0;
         }
-        sort_p[rank] = pc; sort_i[rank] = ic;
+        if (live) atomicAdd(&rank_acc[c], rank);
     }
     __syncthreads();
+    for (int c = tid; c < total_c; c += SMP_THREADS) {
+        const int rank = rank_acc[c];
+        const unsigned long long kc = cand[c];
+        if (rank < k) { sort_p[rank] = __uint_as_float((unsigned) (kc >> 32)); sort_i[rank] = (int) ~(unsigned) kc; }
     }
-    // ---- q = p / noise, LAST maximum (ggml_vec_argmax_f32)
-    float best = -INFINITY; int bj = -1;
-    for (int j = tid; j < k; j += SMP_THREADS) { const float qv = sort_p[j] / a.noise[j]; if (qv >= best) { best = qv; bj = j; } }   // ascending j per thread: '>=' keeps the last
+    __syncthreads();
+    SMP_STAMP(4);
+    }
+    // ---- q = p / noise, LAST maximum (ggml_vec_argmax_f32): q >= 0, so (bits of q) << 32 | j orders by value, then by the later position - one max
+    // over the k <= 256 threads that hold a rank
+    __shared__ unsigned long long s_best[4];
+    if (wave < 4) {
+        unsigned long long key = tid < k ? ((unsigned long long) __float_as_uint(sort_p[tid] / my_noise) << 32) | (unsigned long long) tid : 0ull;
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const float ov = __shfl_xor(best, o, 64); const int oj = __shfl_xor(bj, o, 64);
-        if (ov > best || (ov == best && oj > bj)) { best = ov; bj = oj; }
+        for (int o = 32; o > 0; o >>= 1) {
+            const unsigned long long ok = ((unsigned long long) (unsigned) __shfl_xor((int) (key >> 32), o, 64) << 32) | (unsigned) __shfl_xor((int) key, o, 64);
+            key = ok > key ? ok : key;
+        }
+        if (lane == 0) s_best[wave] = key;
     }
-    if (lane == 0) { shf[wave] = best; shi[wave] = bj; }
     __syncthreads();
     if (tid == 0) {
-        for (int w = 1; w < NW; w++) if (shf[w] > best || (shf[w] == best && shi[w] > bj)) { best = shf[w]; bj = shi[w]; }
-        const int tok = sort_i[bj < 0 ? 0 : bj];
+        unsigned long long key = s_best[0];
+        for (int w = 1; w < 4; w++) key = s_best[w] > key ? s_best[w] : key;
+        const int tok = sort_i[(int) (unsigned) key];
         *a.out = tok;
         if (a.out2) *a.out2 = tok;
     }
+    SMP_STAMP(5);
 }
 void k_sample_topk(hipStream_t s, const sample_args & a) {
     GGML_ASSERT(a.n >= 1 && a.n <= SAMPLE_MAX_N && a.k >= 1 && a.k <= SAMPLE_MAX_K && a.k <= a.n);
-    sample_topk_kernel<1024><<<1, 1024, 0, s>>>(a);   // (256 threads for the 2 048-logit audio heads measured 13 us slower per call: fewer lanes for the rank sort)
+    if (a.n <= 2 * 1024) sample_topk_kernel<1024, 2><<<1, 1024, 0, s>>>(a);
+    else sample_topk_kernel<1024, 32><<<1, 1024, 0, s>>>(a);   // (256 threads for the 2 048-logit audio heads measured 13 us slower per call: fewer lanes for the rank sort)
 }
 
 __global__ void gather_scalars_kernel(gather_args a) {
