@@ -1076,28 +1076,48 @@ static bool match_embed_sum(const analysis & an, int pos, embed_group & grp) {
     const ggml_tensor * top = an.g->nodes[pos];
     if (top->op != GGML_OP_ADD || top->view_src || top->type != GGML_TYPE_F32 || !ggml_is_contiguous(top)) return false;
     if (!(top->ne[1] == 1 || top->ne[0] == 1) || top->ne[2] != 1 || top->ne[3] != 1) return false;
-    // must be the top of the chain: its consumer is not another link
-    std::vector<const ggml_tensor *> terms;
-    std::vector<int> members;
+    // walk down the left spine of the chain of adds: adds[d] = adds[d + 1] + terms[d]
+    std::vector<const ggml_tensor *> terms, adds;
     const ggml_tensor * cur = top;
     while (cur->op == GGML_OP_ADD && cur->view_src == NULL) {
         const ggml_tensor * l = cur->src[0], * r = cur->src[1];
-        if (cur != top && uses_of(an, cur) != 1) return false;
-        if (uses_of(an, r) != 1 || !ggml_are_same_shape(l, r) || !ggml_are_same_shape(cur, l)) return false;
+        if (cur != top && uses_of(an, cur) != 1) break;
+        if (uses_of(an, r) != 1 || !ggml_are_same_shape(l, r) || !ggml_are_same_shape(cur, l)) break;
+        if (pos_of(an, cur) < 0 || an.skip[(size_t) pos_of(an, cur)]) break;   // (claimed by another group: it is the base then)
         terms.push_back(r);
-        members.push_back(pos_of(an, cur));
+        adds.push_back(cur);
         cur = l;
     }
-    terms.push_back(cur);
-    if (uses_of(an, cur) != 1) return false;
-    if (terms.size() < 3 || terms.size() > EMBED_SUM_MAX) return false;
+    if (terms.size() < 2) return false;
+    // embedding rows from the top down; what is left below them - one more embedding row, or any F32 vector of the same shape that something else
+    // computes (tts: the demuxed text embedding's two projections, lm_utils.h:48-66) - is the sum's first term
+    std::vector<embed_src> srcs(terms.size());
+    std::vector<std::vector<int>> mem(terms.size());
+    size_t f = 0;
+    while (f < terms.size() && match_embed_term(an, terms[f], srcs[f], mem[f])) f++;
+    if (f < 2) return false;
+    const ggml_tensor * base = f == terms.size() ? cur : adds[f];   // adds[f] = the partial sum below the first f rows
+    embed_src base_src;
+    std::vector<int> base_mem;
+    bool base_is_row = false;
+    if (f == terms.size() && uses_of(an, cur) == 1 && match_embed_term(an, cur, base_src, base_mem)) base_is_row = true;
+    if (!base_is_row) {
+        if (base->type != GGML_TYPE_F32 || !ggml_is_contiguous(base) || !ggml_are_same_shape(base, top)) return false;
+        // row 0 of a one-row F32 "table": any index is clamped to it (embed_sum_kernel), so the first row's index pointer serves
+        base_src = { (const char *) base->data, 0, 1, (int) GGML_TYPE_F32, srcs[0].index, nullptr };
+    }
+    if (f + 1 < 3 || f + 1 > EMBED_SUM_MAX) return false;
     memset(&grp.a, 0, sizeof(grp.a));
-    grp.a.n = (int) terms.size();
+    grp.a.n = (int) f + 1;
     grp.a.K = ggml_nelements(top);
     grp.a.out = (float *) top->data;
-    for (size_t i = 0; i < terms.size(); i++) {
-        // terms were collected right-to-left; the kernel adds left-to-right
-        if (!match_embed_term(an, terms[terms.size() - 1 - i], grp.a.src[i], members)) return false;
+    grp.a.src[0] = base_src;
+    std::vector<int> members = base_mem;
+    for (size_t i = 0; i < f; i++) {
+        // rows were collected right-to-left (top down); the kernel adds left-to-right
+        grp.a.src[1 + i] = srcs[f - 1 - i];
+        members.insert(members.end(), mem[f - 1 - i].begin(), mem[f - 1 - i].end());
+        members.push_back(pos_of(an, adds[f - 1 - i]));
     }
     grp.members = members;
     return true;

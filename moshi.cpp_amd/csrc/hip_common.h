@@ -187,7 +187,7 @@ struct xattn_args { const float * q; const char * k; const char * v; int64_t k_n
 void k_cross_attn(hipStream_t s, const xattn_args & a);
 
 // sum of (scaled) embedding rows, left-to-right
-#define EMBED_SUM_MAX 24
+#define EMBED_SUM_MAX 40      // terms of one fused embedding sum (tts: 32 audio codebooks + the demuxed text pair); the kernel is instantiated for 24 and 40
 struct embed_sum_args { embed_src src[EMBED_SUM_MAX]; int n; int64_t K; float * out; };
 void k_embed_sum(hipStream_t s, const embed_sum_args & a);
 // one residual-VQ encode level (core_vq.h:27-56, 171-194): nearest centroid of `resid`, its index, and resid - centroid

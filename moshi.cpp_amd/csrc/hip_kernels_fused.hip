@@ -2623,14 +2623,14 @@ void k_cross_attn(hipStream_t s, const xattn_args & a) {
 // choice of a Q4_0 byte) made hipcc wait for each term's loads before it issued the next (24 x s_waitcnt vmcnt(0) in a row: 21 us at the head of every
 // Temporal graph, profiles/r03_bench_kernel_trace_summary.txt). With the type a template parameter the element of every term is ONE scale load + ONE
 // quant load whose addresses are plain arithmetic, all requested before the first is looked at. 64-thread workgroups: 64 of them for a 4096-wide row.
-template <int TYPE>
+template <int TYPE, int NMAX>
 __global__ void __launch_bounds__(64) embed_sum_kernel(embed_sum_args a) {
     const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= a.K) return;
-    int64_t r[EMBED_SUM_MAX];
-    float sc[EMBED_SUM_MAX], v[EMBED_SUM_MAX];
+    int64_t r[NMAX];
+    float sc[NMAX], v[NMAX];
 #pragma unroll
-    for (int t = 0; t < EMBED_SUM_MAX; t++) {
+    for (int t = 0; t < NMAX; t++) {
         const embed_src & e = a.src[t < a.n ? t : 0];
         r[t] = *e.index;
         sc[t] = e.scale ? *e.scale : 1.f;
@@ -2640,9 +2640,9 @@ __global__ void __launch_bounds__(64) embed_sum_kernel(embed_sum_args a) {
         const int64_t boff = (i >> 5) * BB;
         const int j = (int) (i & 31);
         const int64_t qoff = boff + 2 + (TYPE == GGML_TYPE_Q4_0 ? (j & 15) : j);
-        uint16_t dh[EMBED_SUM_MAX]; uint8_t qb[EMBED_SUM_MAX];
+        uint16_t dh[NMAX]; uint8_t qb[NMAX];
 #pragma unroll
-        for (int t = 0; t < EMBED_SUM_MAX; t++) {
+        for (int t = 0; t < NMAX; t++) {
             const embed_src & e = a.src[t < a.n ? t : 0];
             const int64_t row = (r[t] < 0 || r[t] >= e.n_rows) ? 0 : r[t];
             const char * base = e.table + row * e.row_bytes;
@@ -2651,13 +2651,13 @@ __global__ void __launch_bounds__(64) embed_sum_kernel(embed_sum_args a) {
         }
         __builtin_amdgcn_sched_barrier(0);   // every load above is requested before any is consumed
 #pragma unroll
-        for (int t = 0; t < EMBED_SUM_MAX; t++) {
+        for (int t = 0; t < NMAX; t++) {
             if (TYPE == GGML_TYPE_Q4_0) { const int q = j < 16 ? (qb[t] & 0x0F) : (qb[t] >> 4); v[t] = (q - 8) * h2f(dh[t]); }
             else v[t] = (int8_t) qb[t] * h2f(dh[t]);
         }
     } else {
 #pragma unroll
-        for (int t = 0; t < EMBED_SUM_MAX; t++) {
+        for (int t = 0; t < NMAX; t++) {
             const embed_src & e = a.src[t < a.n ? t : 0];
             if (r[t] < 0 || r[t] >= e.n_rows) r[t] = 0;
             v[t] = dequant_elem(e.table + r[t] * e.row_bytes, TYPE >= 0 ? TYPE : e.type, i);
@@ -2665,7 +2665,7 @@ __global__ void __launch_bounds__(64) embed_sum_kernel(embed_sum_args a) {
     }
     float acc = 0.f;
 #pragma unroll
-    for (int t = 0; t < EMBED_SUM_MAX; t++) {
+    for (int t = 0; t < NMAX; t++) {
         if (t < a.n) {
             const float x = a.src[t].scale ? v[t] * sc[t] : v[t];
             acc = t == 0 ? x : acc + x;
@@ -2677,14 +2677,17 @@ void k_embed_sum(hipStream_t s, const embed_sum_args & a) {
     int type = a.n > 0 ? a.src[0].type : -1;
     for (int t = 1; t < a.n; t++) if (a.src[t].type != type) type = -1;
     const int grid = (int) ((a.K + 63) / 64);
+    // (every loop over the terms is unrolled to the instantiation's bound: sums of up to 24 terms - moshika 17, PersonaPlex 17 - keep the 24-term kernel)
+#define EMBED_LAUNCH(T) do { if (a.n <= 24) embed_sum_kernel<T, 24><<<grid, 64, 0, s>>>(a); else embed_sum_kernel<T, EMBED_SUM_MAX><<<grid, 64, 0, s>>>(a); } while (0)
     switch (type) {
-        case GGML_TYPE_Q4_0: embed_sum_kernel<GGML_TYPE_Q4_0><<<grid, 64, 0, s>>>(a); break;
-        case GGML_TYPE_Q8_0: embed_sum_kernel<GGML_TYPE_Q8_0><<<grid, 64, 0, s>>>(a); break;
-        case GGML_TYPE_F32:  embed_sum_kernel<GGML_TYPE_F32><<<grid, 64, 0, s>>>(a); break;
-        case GGML_TYPE_BF16: embed_sum_kernel<GGML_TYPE_BF16><<<grid, 64, 0, s>>>(a); break;
-        case GGML_TYPE_F16:  embed_sum_kernel<GGML_TYPE_F16><<<grid, 64, 0, s>>>(a); break;
-        default:             embed_sum_kernel<-1><<<grid, 64, 0, s>>>(a); break;
+        case GGML_TYPE_Q4_0: EMBED_LAUNCH(GGML_TYPE_Q4_0); break;
+        case GGML_TYPE_Q8_0: EMBED_LAUNCH(GGML_TYPE_Q8_0); break;
+        case GGML_TYPE_F32:  EMBED_LAUNCH(GGML_TYPE_F32); break;
+        case GGML_TYPE_BF16: EMBED_LAUNCH(GGML_TYPE_BF16); break;
+        case GGML_TYPE_F16:  EMBED_LAUNCH(GGML_TYPE_F16); break;
+        default:             EMBED_LAUNCH(-1); break;
     }
+#undef EMBED_LAUNCH
 }
 
 // ---------------------------------------------------------------------------------------------------
