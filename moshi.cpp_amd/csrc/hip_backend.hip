@@ -1619,6 +1619,34 @@ static plan_t * build_plan(hip_ctx * c, ggml_cgraph * g, bool keep = true) {
             at_pos[xg.emit_pos].push_back([=](hipStream_t s) { k_cross_attn(s, xa); });
             p->n_fused += (int) xg.members.size();
         }
+        // one embedding row through a small Q8_0 projection (tts: low-rank Depth embeddings): get_rows -> mul_mat [-> cast] as one launch
+        static const bool no_lowrank = getenv("MI355X_NO_LOWRANK_FUSION") != nullptr;
+        for (int i = 0; i < g->n_nodes && !no_lowrank; i++) {
+            const ggml_tensor * mm = g->nodes[i];
+            if (an.skip[(size_t) i] || mm->op != GGML_OP_MUL_MAT || mm->type != GGML_TYPE_F32) continue;
+            const ggml_tensor * W = mm->src[0], * gr = mm->src[1];
+            if (W->type != GGML_TYPE_Q8_0 || !dense_rows(W) || W->ne[2] * W->ne[3] != 1 || gr->op != GGML_OP_GET_ROWS || gr->type != GGML_TYPE_F32) continue;
+            const int pg = pos_of(an, gr);
+            if (pg < 0 || an.skip[(size_t) pg] || uses_of(an, gr) != 1 || ggml_nelements(gr) != gr->ne[0] || gr->ne[0] != W->ne[0]) continue;
+            const ggml_tensor * tab = gr->src[0], * idx = gr->src[1];
+            if (ggml_nelements(idx) != 1 || idx->type != GGML_TYPE_I32 || !dense_rows(tab) || !idx->data) continue;
+            switch (tab->type) { case GGML_TYPE_F32: case GGML_TYPE_F16: case GGML_TYPE_BF16: case GGML_TYPE_Q4_0: case GGML_TYPE_Q8_0: break; default: continue; }
+            const int64_t K = W->ne[0], M = W->ne[1];
+            if (K % 32 != 0 || K > 2048 || ggml_nelements(mm) != M || !ggml_is_contiguous(mm)) continue;
+            std::vector<int> members = { pg, i };
+            float * out = (float *) mm->data;
+            int emit = i;
+            const ggml_tensor * cp = sole_consumer(an, mm);   // ggml_cast(.., F32) of an F32 tensor: a copy - write its storage directly
+            if (cp && cp->op == GGML_OP_CPY && uses_of(an, mm) == 1 && cp->type == GGML_TYPE_F32 && cp->src[0] == mm && ggml_is_contiguous(cp) && cp->view_src == NULL &&
+                ggml_are_same_shape(cp, mm) && pos_of(an, cp) >= 0 && !an.skip[(size_t) pos_of(an, cp)]) {
+                members.push_back(pos_of(an, cp)); out = (float *) cp->data; emit = pos_of(an, cp);
+            }
+            for (int m2 : members) an.skip[(size_t) m2] = 1;
+            const lowrank_embed_args la = { (const char *) tab->data, (int64_t) tab->nb[1], tab->ne[1], (int) tab->type, (const int32_t *) idx->data,
+                                            (const char *) W->data, (int64_t) W->nb[1], (int) K, (int) M, out };
+            at_pos[emit].push_back([=](hipStream_t s) { k_lowrank_embed(s, la); });
+            p->n_fused += (int) members.size();
+        }
         // embedding sums
         for (int i = g->n_nodes - 1; i >= 0; i--) {
             if (an.skip[(size_t) i] || g->nodes[i]->op != GGML_OP_ADD) continue;

@@ -206,6 +206,9 @@ void k_gather_scalars(hipStream_t s, const gather_args & a);
 // argmax -> the chosen index, as one launch (the node chain costs ~12 launches and a full argsort of up to 32 000 values)
 #define SAMPLE_MAX_N 32768
 #define SAMPLE_MAX_K 256
+// get_rows(table, index) -> mul_mat(W: Q8_0 [K, M], .) [-> cast to F32]: one embedding row through a small projection (lowrank_embed_kernel)
+struct lowrank_embed_args { const char * table; int64_t row_bytes, n_rows; int type; const int32_t * index; const char * w; int64_t w_row_bytes; int K, M; float * out; };
+void k_lowrank_embed(hipStream_t s, const lowrank_embed_args & a);
 struct sample_args { const float * logits; int n; float scale; int k; const float * noise; int32_t * out; int32_t * out2; };   // out2: optional copy (the token vector slot)
 void k_sample_topk(hipStream_t s, const sample_args & a);
 #define VQ_LEVEL_WS_BYTES 4096

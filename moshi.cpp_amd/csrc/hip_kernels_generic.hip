@@ -1044,6 +1044,36 @@ __global__ void mul_mat_f16_shortk_kernel(tdesc dst, tdesc a, tdesc b, int K, in
     *(float *) (dst.data + (int64_t) m * dst.nb[0] + (int64_t) n * dst.nb[1]) = r;
 }
 
+// One embedding row through a small Q8_0 projection (tts: the Depth transformer's low-rank embeddings, lm_utils.h:157-217 - get_rows of a 128-wide table,
+// a 128 -> 1024 linear, a cast): get_rows_kernel + convert_rows_kernel + mul_mat_kernel (+ the F32 -> F32 copy of the cast) as ONE launch with their
+// arithmetic - the row dequantised as get_rows does, re-quantised to Q8_0 blocks as convert_rows does (d = amax / 127 kept as F16, q = roundf(x / d)),
+// a wave per output element with block ib on lane ib and the same wave-wide float sum as mul_mat_kernel.
+__global__ void __launch_bounds__(256) lowrank_embed_kernel(lowrank_embed_args a) {
+    const int lane = threadIdx.x & 63;
+    const int m = (int) blockIdx.x * 4 + (int) (threadIdx.x >> 6);
+    if (m >= a.M) return;
+    const int64_t r = *a.index;
+    if (r < 0 || r >= a.n_rows) { if (lane == 0) a.out[m] = NAN; return; }   // (get_rows_kernel hands on a NaN row)
+    const char * row = a.table + r * a.row_bytes;
+    const char * w = a.w + (int64_t) m * a.w_row_bytes;
+    float acc = 0;
+    for (int ib = lane; ib < a.K / 32; ib += 64) {
+        float xv[32], amax = 0.f;
+#pragma unroll
+        for (int j = 0; j < 32; j++) { xv[j] = dequant_elem(row, a.type, (int64_t) ib * 32 + j); amax = fmaxf(amax, fabsf(xv[j])); }
+        const float d = amax / 127.f;
+        const float id = d ? 1.0f / d : 0.0f;
+        const block_q8_0 * xb = (const block_q8_0 *) w + ib;
+        int sumi = 0;
+#pragma unroll
+        for (int j = 0; j < 32; j++) sumi += xb->qs[j] * (int) (int8_t) roundf(xv[j] * id);
+        acc += sumi * (h2f(xb->d) * h2f(f2h(d)));
+    }
+    const float result = wave_sum_f32(acc);
+    if (lane == 0) a.out[m] = result;
+}
+void k_lowrank_embed(hipStream_t s, const lowrank_embed_args & a) { lowrank_embed_kernel<<<(a.M + 3) / 4, 256, 0, s>>>(a); }
+
 void k_mul_mat(hipStream_t s, tdesc dst, tdesc a, tdesc b, void * ws, const mm_epilogue * epi_) {
     const int64_t total = td_nelements(dst);
     if (total == 0) return;
