@@ -1850,6 +1850,34 @@ static plan_t * build_plan(hip_ctx * c, ggml_cgraph * g, bool keep = true) {
         }
         GGML_ASSERT(paired_consumed == paired_gate.size() && "a linear_in was redirected to the paired gate form but its linear_out did not pick the gate vector up");
     }
+    if (fuse) {
+        // LayerNorm with weight (and bias) over one row that no mat-vec prologue took (tts: norm_cross in front of the cross-attention's row-view projection):
+        // ggml_norm -> ggml_mul(., w) -> [ggml_add(., b)] as one launch with the three launches' float operations
+        for (int i = 0; i < g->n_nodes; i++) {
+            const ggml_tensor * nn = g->nodes[i];
+            if (an.skip[(size_t) i] || (nn->op != GGML_OP_NORM && nn->op != GGML_OP_RMS_NORM) || nn->type != GGML_TYPE_F32 || ggml_nelements(nn) != nn->ne[0] || uses_of(an, nn) != 1) continue;
+            if (nn->src[0]->type != GGML_TYPE_F32 || nn->src[0]->nb[0] != 4) continue;
+            const ggml_tensor * ml = sole_consumer(an, nn);
+            if (!ml || ml->op != GGML_OP_MUL || ml->view_src || pos_of(an, ml) < 0 || an.skip[(size_t) pos_of(an, ml)]) continue;
+            const ggml_tensor * wv = ml->src[0] == nn ? ml->src[1] : ml->src[0];
+            if (wv == nn || wv->type != GGML_TYPE_F32 || !ggml_is_contiguous(wv) || ggml_nelements(wv) != nn->ne[0] || !wv->data || !ggml_is_contiguous(ml)) continue;
+            std::vector<int> members = { i, pos_of(an, ml) };
+            const ggml_tensor * last = ml; const float * bp = nullptr;
+            const ggml_tensor * ad = uses_of(an, ml) == 1 ? sole_consumer(an, ml) : nullptr;
+            if (ad && ad->op == GGML_OP_ADD && !ad->view_src && pos_of(an, ad) >= 0 && !an.skip[(size_t) pos_of(an, ad)] && ggml_is_contiguous(ad)) {
+                const ggml_tensor * bv = ad->src[0] == ml ? ad->src[1] : ad->src[0];
+                if (bv != ml && bv->type == GGML_TYPE_F32 && ggml_is_contiguous(bv) && ggml_nelements(bv) == nn->ne[0] && bv->data && bv->op == GGML_OP_NONE && ad->src[0] == ml) {
+                    bp = (const float *) bv->data; last = ad; members.push_back(pos_of(an, ad));
+                }
+            }
+            // (the weight must be the second factor or the first: the product is the same float either way; the bias must be the second summand: v + b)
+            for (int m2 : members) an.skip[(size_t) m2] = 1;
+            const tdesc a = make_tdesc(nn->src[0]); const float eps = ggml_get_op_params_f32(nn, 0); const int rms = nn->op == GGML_OP_RMS_NORM;
+            const float * wp = (const float *) wv->data; float * out = (float *) last->data;
+            at_pos[pos_of(an, last)].push_back([=](hipStream_t s) { k_norm_affine(s, a, eps, rms, wp, bp, out); });
+            p->n_fused += (int) members.size();
+        }
+    }
     for (auto & ag : attn_groups) {
         if (ag.emit_pos < 0) continue;
         const attn_args a = ag.a;

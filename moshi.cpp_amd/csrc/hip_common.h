@@ -43,6 +43,7 @@ void k_sum_all(hipStream_t s, tdesc dst, tdesc a);
 void k_argmax(hipStream_t s, tdesc dst, tdesc a);
 void k_argsort(hipStream_t s, tdesc dst, tdesc a, int desc);
 void k_norm(hipStream_t s, tdesc dst, tdesc a, float eps, int rms);
+void k_norm_affine(hipStream_t s, tdesc a, float eps, int rms, const float * w, const float * b, float * out);   // one row: out = norm(a) * w (+ b), the three launches' float operations
 void k_soft_max(hipStream_t s, tdesc dst, tdesc a, tdesc mask, int has_mask, float scale);
 void k_get_rows(hipStream_t s, tdesc dst, tdesc a, tdesc idx);
 void k_set_rows(hipStream_t s, tdesc dst, tdesc src, tdesc idx);

@@ -421,7 +421,9 @@ void k_argsort(hipStream_t s, tdesc dst, tdesc a, int desc) {
     argsort_kernel<<<dim3(nblocks(a.ne[0]), (unsigned) rows), BLOCK, 0, s>>>(dst, a, desc);
 }
 
-__global__ void norm_kernel(tdesc dst, tdesc a, float eps, int rms) {
+// w / b (optional, [n]): the weight product and the bias sum that follow a LayerNorm (ggml_norm -> ggml_mul -> ggml_add, one row) applied in the same
+// launch - the same float operations in the same order as the three launches (y = (x - mean) * scale; y * w; + b)
+__global__ void norm_kernel(tdesc dst, tdesc a, float eps, int rms, const float * w = nullptr, const float * b = nullptr, float * out = nullptr) {
     __shared__ double sh[BLOCK / 64];
     int64_t i1, i2, i3;
     row_coords(a, blockIdx.x, i1, i2, i3);
@@ -438,12 +440,23 @@ __global__ void norm_kernel(tdesc dst, tdesc a, float eps, int rms) {
     for (int64_t i = threadIdx.x; i < n; i += blockDim.x) { const float v = x[i] - mean; acc2 += (double) (v * v); }
     const float var = (float) (block_sum_f64(acc2, sh) / (double) n);
     const float scale = 1.0f / sqrtf(var + eps);
-    for (int64_t i = threadIdx.x; i < n; i += blockDim.x) y[i] = (x[i] - mean) * scale;
+    if (w == nullptr) { for (int64_t i = threadIdx.x; i < n; i += blockDim.x) y[i] = (x[i] - mean) * scale; return; }
+    for (int64_t i = threadIdx.x; i < n; i += blockDim.x) {
+        float v = (x[i] - mean) * scale;
+        v = v * w[i];
+        if (b) v = v + b[i];
+        out[i] = v;
+    }
 }
 void k_norm(hipStream_t s, tdesc dst, tdesc a, float eps, int rms) {
     const int64_t rows = a.ne[1] * a.ne[2] * a.ne[3];
     GGML_ASSERT(a.nb[0] == 4 && dst.nb[0] == 4);
     if (rows) norm_kernel<<<(int) rows, BLOCK, 0, s>>>(dst, a, eps, rms);
+}
+// one row: out = norm(a) * w (+ b)
+void k_norm_affine(hipStream_t s, tdesc a, float eps, int rms, const float * w, const float * b, float * out) {
+    GGML_ASSERT(a.nb[0] == 4 && a.ne[1] * a.ne[2] * a.ne[3] == 1);
+    norm_kernel<<<1, BLOCK, 0, s>>>(a, a, eps, rms, w, b, out);
 }
 
 __global__ void soft_max_kernel(tdesc dst, tdesc a, tdesc mask, int has_mask, float scale) {
