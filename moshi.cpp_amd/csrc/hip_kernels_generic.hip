@@ -1060,7 +1060,8 @@ __global__ void mul_mat_f16_shortk_kernel(tdesc dst, tdesc a, tdesc b, int K, in
 // One embedding row through a small Q8_0 projection (tts: the Depth transformer's low-rank embeddings, lm_utils.h:157-217 - get_rows of a 128-wide table,
 // a 128 -> 1024 linear, a cast): get_rows_kernel + convert_rows_kernel + mul_mat_kernel (+ the F32 -> F32 copy of the cast) as ONE launch with their
 // arithmetic - the row dequantised as get_rows does, re-quantised to Q8_0 blocks as convert_rows does (d = amax / 127 kept as F16, q = roundf(x / d)),
-// a wave per output element with block ib on lane ib and the same wave-wide float sum as mul_mat_kernel.
+// a wave per output element with block ib on lane ib, the blocks' terms added in block order (vec_dot_q8_0_q8_0: bit-exact against the oracle, which the
+// generic kernel's butterfly sum is only to 1 ulp).
 __global__ void __launch_bounds__(256) lowrank_embed_kernel(lowrank_embed_args a) {
     const int lane = threadIdx.x & 63;
     const int m = (int) blockIdx.x * 4 + (int) (threadIdx.x >> 6);
@@ -1069,7 +1070,7 @@ __global__ void __launch_bounds__(256) lowrank_embed_kernel(lowrank_embed_args a
     if (r < 0 || r >= a.n_rows) { if (lane == 0) a.out[m] = NAN; return; }   // (get_rows_kernel hands on a NaN row)
     const char * row = a.table + r * a.row_bytes;
     const char * w = a.w + (int64_t) m * a.w_row_bytes;
-    float acc = 0;
+    float term = 0.f;   // (K <= 2048: at most one block per lane)
     for (int ib = lane; ib < a.K / 32; ib += 64) {
         float xv[32], amax = 0.f;
 #pragma unroll
@@ -1080,10 +1081,13 @@ __global__ void __launch_bounds__(256) lowrank_embed_kernel(lowrank_embed_args a
         int sumi = 0;
 #pragma unroll
         for (int j = 0; j < 32; j++) sumi += xb->qs[j] * (int) (int8_t) roundf(xv[j] * id);
-        acc += sumi * (h2f(xb->d) * h2f(f2h(d)));
+        term = sumi * (h2f(xb->d) * h2f(f2h(d)));
     }
-    const float result = wave_sum_f32(acc);
-    if (lane == 0) a.out[m] = result;
+    // vec_dot_q8_0_q8_0's order: sumf = 0; sumf += term_ib for ib = 0, 1, ... (mul_mat_kernel adds the lanes' terms as a butterfly, which differs in the
+    // last bit now and then; this launch keeps the reference's order)
+    float sumf = 0.f;
+    for (int ib = 0; ib < a.K / 32; ib++) sumf += __shfl(term, ib, 64);
+    if (lane == 0) a.out[m] = sumf;
 }
 void k_lowrank_embed(hipStream_t s, const lowrank_embed_args & a) { lowrank_embed_kernel<<<(a.M + 3) / 4, 256, 0, s>>>(a); }
 

@@ -744,3 +744,59 @@ print("OK", st.kernels_in_last_plan)
         assert r.returncode == 0 and "OK" in r.stdout, (r.stdout + r.stderr)[-2000:]
         out[flag] = int(r.stdout.split()[-1])
     assert out[None] == out["0"] - 1, f"paired form should save exactly the gate kernel: {out}"
+
+
+# ---- round 4: planner fusions found on the tts-shaped configuration ------------------------------------------------------------------------------------
+def test_embedding_sum_of_35_terms_starting_from_a_computed_vector():
+    # lm_utils.h:48-66 + lm.h:853-869 at tts shape: the demuxed text embedding (two projections, their sum) followed by 33 scaled codebook rows - the
+    # fused sum takes up to 40 terms and may start from any F32 vector; same left-to-right float additions as the node chain
+    r = np.random.default_rng(11)
+    K, rows, nterm = 512, 40, 33
+    tabs = [gu.random_q8_0(r, rows, K) for _ in range(nterm)]
+    idx = r.integers(0, rows, nterm).astype(np.int32)
+    scales = np.where(r.random(nterm) < 0.2, 0.0, 1.0).astype(np.float32)
+    w1, w2 = gu.random_q8_0(r, K, 256), gu.random_q8_0(r, K, 256)
+    x1, x2 = rnd(1, 256), rnd(1, 256)
+
+    def build(g):
+        base = g.add(g.mul_mat(g.input_raw(w1, Q8_0, 256, K), g.input(x1)), g.mul(g.mul_mat(g.input_raw(w2, Q8_0, 256, K), g.input(x2)), g.input(np.array([0.5], np.float32))))
+        acc = base
+        for t in range(nterm):
+            e = g.mul(g.get_rows(g.input_raw(tabs[t], Q8_0, K, rows), g.input(idx[t:t + 1], I32)), g.input(scales[t:t + 1]))
+            acc = g.add(acc, e)
+        return [acc]
+    ref, got, st = gu.compare(build, atol_rel=0, rtol=0)   # bit-exact against the oracle (the generic mul_mat of an unfused plan sums its blocks in another order)
+    assert st.fused_nodes_in_last_plan >= 3 * nterm, f"the embedding sum was not fused ({st.fused_nodes_in_last_plan} nodes)"
+
+
+@pytest.mark.parametrize("tab_type", [Q8_0, F32])
+def test_low_rank_embedding_row_through_a_small_q8_0_projection(tab_type):
+    # lm_utils.h:157-217: get_rows of a 128-wide table -> 128 -> 1024 Q8_0 linear -> cast to F32: one launch with the arithmetic of get_rows_kernel,
+    # convert_rows_kernel (Q8_0 re-quantisation of the row) and the reference's vec_dot_q8_0_q8_0 (block terms added in block order)
+    r = np.random.default_rng(5)
+    K, M, rows = 128, 1024, 50
+    tab = gu.random_q8_0(r, rows, K) if tab_type == Q8_0 else (r.standard_normal((rows, K)) * 0.3).astype(np.float32)
+    w = gu.random_q8_0(r, M, K)
+    for i in (0, 17, rows - 1):
+        def build(g):
+            t = g.input_raw(tab, Q8_0, K, rows) if tab_type == Q8_0 else g.input(tab)
+            y = g.mul_mat(g.input_raw(w, Q8_0, K, M), g.get_rows(t, g.input(np.array([i], np.int32), I32)))
+            return [g.add(g.cast(y, F32), g.input(np.ones((1, M), np.float32)))]
+        ref, got, st = gu.compare(build, atol_rel=0, rtol=0)   # bit-exact against the oracle: the blocks' terms are added in vec_dot_q8_0_q8_0's order
+        assert st.fused_nodes_in_last_plan >= 3
+        plain, _ = gu.run_graph("hip", build, flags=1)          # (the generic mul_mat_kernel sums them as a butterfly: 1 ulp)
+        assert np.abs(plain[0] - got[0]).max() <= 2e-6 * np.abs(got[0]).max()
+
+
+def test_layer_norm_with_weight_and_bias_as_one_launch():
+    # transformer.h:936-944 (norm_cross): ggml_norm -> mul(w) -> add(b) over one row that no mat-vec prologue takes (its consumer here is a plain scale)
+    r = np.random.default_rng(9)
+    x, w, b = rnd(1, 2048), (1 + 0.1 * r.standard_normal((1, 2048))).astype(np.float32), (0.02 * r.standard_normal((1, 2048))).astype(np.float32)
+
+    def build(g):
+        y = g.add(g.mul(g.norm(g.input(x), 1e-5), g.input(w)), g.input(b))
+        return [g.scale(y, 2.0)]
+    ref, got, st = gu.compare(build, atol_rel=0, rtol=0)
+    assert st.fused_nodes_in_last_plan >= 3
+    plain, _ = gu.run_graph("hip", build, flags=1)
+    assert np.array_equal(plain[0], got[0])
