@@ -117,6 +117,7 @@ struct ggml_mi355x_stats {
     int64_t uploads_batched;     // small tensor_set calls folded into one scatter launch
     int64_t chained_matvecs_in_last_plan;   // block mat-vecs of the last plan that run inside persistent chain launches (hip_chain.hip)
     int64_t attention_folds_planned;   // attention blocks running as the tail of their in_proj launch (inproj_attn_kernel), summed over every plan built so far
+    int64_t chain_step_programs_in_last_plan;   // chain launches of the last plan that run as the Depth transformer's compile-time step program (hip_chain_nest.h)
 };
 GGML_API void ggml_backend_mi355x_get_stats(ggml_backend_t backend, struct ggml_mi355x_stats * stats);
 // accumulated HIP-event timings of the dominant kernel (Q4_K mat-vec), collected while flag 8 is set
@@ -140,7 +141,8 @@ GGML_API void ggml_backend_mi355x_get_kernel_profile(ggml_backend_t backend, str
 // bit flags, default 0: 1 = disable fusion (one kernel per node), 2 = disable hipGraph capture, 4 = disable upload batching,
 // 8 = profile mode (eager launches, per-dispatch HIP events on matvec_q4k_kernel), 16 = no persistent chain launches (one launch per mat-vec),
 // 32 = persistent chain launches on even when the MI355X_CHAIN environment variable says 0 (default: on),
-// 512 = the Temporal attention stays a launch of its own (default: it runs as the tail of its in_proj launch, inproj_attn_kernel)
+// 512 = the Temporal attention stays a launch of its own (default: it runs as the tail of its in_proj launch, inproj_attn_kernel),
+// 1024 = chain launches always take the descriptor-driven kernel (default: the Depth transformer's steps run as a compile-time step program)
 GGML_API void ggml_backend_mi355x_set_flags(ggml_backend_t backend, int flags);
 // hipGraph capture of repeated graphs on / off without touching cached plans (off: a repeated graph still reuses its plan, launched eagerly -
 // for sequences of same-shaped one-off graphs such as prompt-prefill chunks, where a capture costs more than it saves). No-op on other backends.

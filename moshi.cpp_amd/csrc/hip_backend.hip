@@ -319,7 +319,7 @@ struct plan_t {
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
     uint64_t hash = 0;
-    int n_nodes = 0, n_fused = 0, n_chained = 0, n_attn_folded = 0;
+    int n_nodes = 0, n_fused = 0, n_chained = 0, n_attn_folded = 0, n_step_programs = 0;
 };
 
 static void plan_free(hip_ctx * c, plan_t * p) {
@@ -1932,8 +1932,9 @@ static plan_t * build_plan(hip_ctx * c, ggml_cgraph * g, bool keep = true) {
                     merged.push_back(std::move(p->steps[i + k])); k++; continue;
                 }
                 void * ws = em.ws(k_chain_ws_size(run.data() + k, len, c->usable_cus));
-                chain_plan * ch = k_chain_create(c->stream, run.data() + k, len, ws, c->err_dev, c->usable_cus);
+                chain_plan * ch = k_chain_create(c->stream, run.data() + k, len, ws, c->err_dev, c->usable_cus, !(c->flags & 1024));
                 p->chains.push_back(ch);
+                if (k_chain_is_step_program(ch)) p->n_step_programs++;
                 merged.push_back(pstep([ch](hipStream_t s) { k_chain_launch(s, ch); }));
                 merged.back().chain = ch;
                 p->n_chained += len;
@@ -2007,7 +2008,7 @@ static enum ggml_status hip_graph_compute(ggml_backend_t backend, struct ggml_cg
         c->stats.kernels_in_last_plan = (int64_t) p->steps.size();
         c->stats.nodes_in_last_plan = p->n_nodes;
         c->stats.fused_nodes_in_last_plan = p->n_fused;
-        c->stats.chained_matvecs_in_last_plan = p->n_chained;
+        c->stats.chained_matvecs_in_last_plan = p->n_chained; c->stats.chain_step_programs_in_last_plan = p->n_step_programs;
         plan_free(c, p);   // workspaces return to the pool; reuse is stream-ordered
         return GGML_STATUS_SUCCESS;
     }
@@ -2046,7 +2047,7 @@ static enum ggml_status hip_graph_compute(ggml_backend_t backend, struct ggml_cg
     c->stats.kernels_in_last_plan = (int64_t) p->steps.size();
     c->stats.nodes_in_last_plan = p->n_nodes;
     c->stats.fused_nodes_in_last_plan = p->n_fused;
-    c->stats.chained_matvecs_in_last_plan = p->n_chained;
+    c->stats.chained_matvecs_in_last_plan = p->n_chained; c->stats.chain_step_programs_in_last_plan = p->n_step_programs;
     return GGML_STATUS_SUCCESS;
 }
 

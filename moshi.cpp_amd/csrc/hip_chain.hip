@@ -104,6 +104,11 @@ template <typename T> __device__ __forceinline__ GLOBAL_AS T * gp(T * p) { retur
 template <typename T> __device__ __forceinline__ const GLOBAL_AS T * gp(const T * p) { return (const GLOBAL_AS T *) p; }
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
+// s_waitcnt vmcnt(0) as an instruction the compiler's wait-count bookkeeping SEES (the asm form above is opaque to it). Placed where a polling loop leaves:
+// the loop's loads are the youngest of the wave, so nothing younger is held up, and no path remains on which one of them counts as still in flight - a path
+// like that (a load issued and a use skipped under the same wave-uniform condition, or the give-up exit) makes the compiler open the NEXT phase with
+// vmcnt(0), i.e. behind the weights requested in between.
+__device__ __forceinline__ void settle_vmcnt() { __builtin_amdgcn_s_waitcnt(0x0F70); }
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void * p, unsigned bytes) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, (int) bytes, 0x00020000);
@@ -146,7 +151,7 @@ __device__ __forceinline__ bool gather_vector_n(__amdgpu_buffer_rsrc_t gb, unsig
             }
             return true;
         }
-        if (++spins > CH_SPIN_MAX || lds_load(&ctl->failed)) return false;
+        if (++spins > CH_SPIN_MAX || lds_load(&ctl->failed)) { settle_vmcnt(); return false; }
         __builtin_amdgcn_s_sleep(1);
     }
 }
@@ -316,23 +321,31 @@ __device__ __forceinline__ void am_wave(float & best, int & bi) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { const float ov = __shfl_xor(best, o, 64); const int oi = __shfl_xor(bi, o, 64); am_merge(best, bi, ov, oi); }
 }
-// one wave reads every workgroup's candidate of `tag` and merges them; false when the wait gave up
+// one wave reads every workgroup's candidate of `tag` and merges them; false when the wait gave up. (All of a sweep's loads are issued before the first
+// tag is looked at: written as load - compare - load the compiler serialises the four fabric round trips of a 256-workgroup grid.)
 __device__ __forceinline__ bool gather_token(__amdgpu_buffer_rsrc_t cb, unsigned base_bytes, int grid, unsigned tag, int lane, chain_ctl * ctl, int & token) {
     unsigned spins = 0;
     for (;;) {
+        u32x4 c[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int g = i * 64 + lane;
+            c[i] = ld16_agent(cb, base_bytes + (unsigned) (g < grid ? g : grid - 1) * 16u);
+        }
         float best = -INFINITY; int bi = -1;
         bool ok = true;
-        for (int g0 = 0; g0 < grid; g0 += 64) {
-            const int g = g0 + lane;
-            const u32x4 c = ld16_agent(cb, base_bytes + (unsigned) (g < grid ? g : grid - 1) * 16u);
-            ok = ok && c.y == tag && c.w == tag;
-            if (g < grid) am_merge(best, bi, __uint_as_float(c.x), (int) c.z);
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int g = i * 64 + lane;
+            ok = ok && c[i].y == tag && c[i].w == tag;
+            if (g < grid) am_merge(best, bi, __uint_as_float(c[i].x), (int) c[i].z);
         }
         if (__all(ok)) { am_wave(best, bi); token = bi < 0 ? 0 : bi; return true; }
-        if (++spins > CH_SPIN_MAX || lds_load(&ctl->failed)) return false;
+        if (++spins > CH_SPIN_MAX || lds_load(&ctl->failed)) { settle_vmcnt(); return false; }
         __builtin_amdgcn_s_sleep(1);
     }
 }
+static_assert(CH_NCW * 32 >= 256, "gather_token: four sweeps of a wave cover the largest grid");
 
 // one attention descriptor out of the constant-address-space table, field by field (scalar loads)
 __device__ __forceinline__ attn_args load_attn(cattn_ptr p) {
@@ -374,6 +387,54 @@ __device__ __forceinline__ float dequant_elem_g(const GLOBAL_AS char * row, int 
     }
 }
 
+// four consecutive elements i0 .. i0 + 3 (i0 a multiple of 4) of a row in global memory: dequant_elem_g's values with every load of a type issued before the
+// first is used (element by element through the per-type switch the compiler waits for each element's loads in turn: 8 dependent round trips)
+__device__ __forceinline__ void dequant4_g(const GLOBAL_AS char * row, int type, int i0, float out[4]) {
+    switch (type) {
+        case GGML_TYPE_F32: { const f32x4 t = *(const GLOBAL_AS f32x4 *) (row + (int64_t) i0 * 4); out[0] = t.x; out[1] = t.y; out[2] = t.z; out[3] = t.w; break; }
+        case GGML_TYPE_F16: case GGML_TYPE_BF16: {
+            typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+            const u32x2 t = *(const GLOBAL_AS u32x2 *) (row + (int64_t) i0 * 2);
+            const uint16_t h[4] = { (uint16_t) (t.x & 0xffff), (uint16_t) (t.x >> 16), (uint16_t) (t.y & 0xffff), (uint16_t) (t.y >> 16) };
+#pragma unroll
+            for (int k = 0; k < 4; k++) out[k] = type == GGML_TYPE_F16 ? h2f(h[k]) : bf2f(h[k]);
+            break;
+        }
+        case GGML_TYPE_Q8_0: {
+            const GLOBAL_AS char * b = row + (int64_t) (i0 / 32) * 34;
+            const uint16_t d = *(const GLOBAL_AS uint16_t *) b, q0 = *(const GLOBAL_AS uint16_t *) (b + 2 + (i0 % 32)), q1 = *(const GLOBAL_AS uint16_t *) (b + 4 + (i0 % 32));
+            const float df = h2f(d);
+            out[0] = (int) (int8_t) (q0 & 0xff) * df; out[1] = (int) (int8_t) (q0 >> 8) * df; out[2] = (int) (int8_t) (q1 & 0xff) * df; out[3] = (int) (int8_t) (q1 >> 8) * df;
+            break;
+        }
+        case GGML_TYPE_Q4_0: {
+            const GLOBAL_AS char * b = row + (int64_t) (i0 / 32) * 18;
+            const int j = i0 % 32;
+            const uint16_t d = *(const GLOBAL_AS uint16_t *) b, q0 = *(const GLOBAL_AS uint16_t *) (b + 2 + (j & 15)), q1 = *(const GLOBAL_AS uint16_t *) (b + 4 + (j & 15));
+            const float df = h2f(d);
+            const int sh = j < 16 ? 0 : 4;
+            const int q[4] = { (q0 >> sh) & 0xF, (q0 >> (8 + sh)) & 0xF, (q1 >> sh) & 0xF, (q1 >> (8 + sh)) & 0xF };
+#pragma unroll
+            for (int k = 0; k < 4; k++) out[k] = (q[k] - 8) * df;
+            break;
+        }
+        case GGML_TYPE_Q4_K: {
+            const GLOBAL_AS char * b = row + (int64_t) (i0 / 256) * 144;
+            const int j = i0 % 256, sub = j / 32, l = j % 32;
+            const GLOBAL_AS uint32_t * bw = (const GLOBAL_AS uint32_t *) b;
+            const uint32_t dd = bw[0], u0 = bw[1], u1 = bw[2], u2 = bw[3], qw = *(const GLOBAL_AS uint32_t *) (b + 16 + (sub >> 1) * 32 + l);
+            uint32_t sc[2], mn[2];
+            q4k_unpack_scales_w(u0, u1, u2, sc, mn);
+            const uint32_t s = (sc[sub >> 2] >> (8 * (sub & 3))) & 0xff, m = (mn[sub >> 2] >> (8 * (sub & 3))) & 0xff;
+            const float d = h2f((uint16_t) (dd & 0xffff)) * (float) s, mm = h2f((uint16_t) (dd >> 16)) * (float) m;
+#pragma unroll
+            for (int k = 0; k < 4; k++) { const int qb = (int) ((qw >> (8 * k)) & 0xff); const int q = (sub & 1) ? (qb >> 4) : (qb & 0xF); out[k] = d * (float) q - mm; }
+            break;
+        }
+        default: out[0] = out[1] = out[2] = out[3] = NAN; break;
+    }
+}
+
 // ---- the kernel -----------------------------------------------------------------------------------------------------------------
 // Workgroup rendezvous at the hardware barrier (LDS traffic only is waited for: loads and stores stay in flight across it). Returns false when some
 // wave has given up a bounded wait: everybody leaves together.
@@ -384,7 +445,7 @@ __device__ __forceinline__ bool wg_barrier(chain_ctl * ctl) {
 
 // Shape of a phase, either read from its descriptor (dyn_shape) or a compile-time constant (the six phase kinds of the Depth transformer of
 // moshika / PersonaPlex, lm.h:446-553 + tools/moshi-config.json: depformer_in 4096 -> 1024, in_proj 1024 -> 3072, out_proj 1024 -> 1024 behind the
-// attention, linear_in 1024 -> 2 x 2816 in the paired form, linear_out 2816 -> 1024, linears[k] 1024 -> 2048). With the shape known to the compiler
+// attention, linear_in 1024 -> 2 x 2816 in the paired form, linear_out 2816 -> 1024, linears[k] 1024 -> 2048 without a norm). With the shape known to the compiler
 // the phase body loses its generic loops, its shape-dependent branches and most of its descriptor reads: what stays in the descriptor is pointers.
 struct dyn_shape { static constexpr bool S = false; static constexpr int K = 0, M = 0, PAIR = 0, PRO = 0, XCH = 0, RES = 0, EMB = 0, SAVE = 0, AM = 0, PUB = 0; };
 template <int K_, int M_, int PAIR_, int PRO_, int XCH_, int RES_, int EMB_, int SAVE_, int AM_, int PUB_>
@@ -395,7 +456,7 @@ typedef fix_shape<1024, 3072,    0, MV_RMSNORM, 1, 0, 0, 0, 0, 3072> shape_inpro
 typedef fix_shape<1024, 1024,    0, MV_ATTN,    1, 1, 0, 1, 0, 1024> shape_outproj;
 typedef fix_shape<1024, 5632, 2816, MV_RMSNORM, 1, 0, 0, 0, 0, 2816> shape_linin;
 typedef fix_shape<2816, 1024,    0, MV_PLAIN,   1, 1, 0, 1, 0, 1024> shape_linout;
-typedef fix_shape<1024, 2048,    0, MV_RMSNORM, 1, 0, 0, 0, 1,    0> shape_head;
+typedef fix_shape<1024, 2048,    0, MV_PLAIN,   1, 0, 0, 0, 1,    0> shape_head;     // (linears[k] takes the last layer's output as it is: no norm in front, lm.h:527-531)
 
 template <int G>
 __global__ void __launch_bounds__(CH_THREADS) matvec_chain_kernel(chain_params P) {
@@ -802,6 +863,8 @@ __global__ void __launch_bounds__(CH_THREADS) matvec_chain_kernel(chain_params P
     if (wg == 0 && tid == 0) *gp(P.launch_seq) = launch + 1u;
 }
 
+#include "hip_chain_nest.h"
+
 // ---- host side -----------------------------------------------------------------------------------------------------------------
 static int chain_env(const char * name, int def) { const char * v = getenv(name); return v ? atoi(v) : def; }
 bool k_chain_default_on() { static const int on = chain_env("MI355X_CHAIN", 1); return on != 0; }
@@ -844,6 +907,12 @@ struct chain_plan {
     int grid; size_t smem;
     std::vector<chain_phase> phases;
     std::vector<attn_args> attns;
+    // the run as a compile-time step program (hip_chain_nest.h): the phases are steps x { din, L x { in_proj, out_proj, linear_in, linear_out }, head } at
+    // the Depth transformer's shapes
+    bool nest = false;
+    nest_params NP;
+    size_t nest_smem = 0;
+    std::vector<char> nest_tables;
 };
 
 static bool overlaps(const void * a, size_t an, const void * b, size_t bn) {
@@ -985,11 +1054,14 @@ int k_chain_accept(const mv_args * mv, int n, int usable_cus) {
 
 static size_t chain_tables_bytes(int n, int) { return GGML_PAD((size_t) n * sizeof(chain_phase), 256); }
 static size_t chain_state_bytes(int grid) { return 256 + 2 * (size_t) CH_XF_MAX * 8 + 2 * 2 * (size_t) grid * 8; }
+// what a step program adds: its compact tables and the [steps][1024] granules of the hoisted depformer_in products (upper bounds: reserved for every run)
+static size_t nest_tables_bytes(int n) { return GGML_PAD((size_t) n * (sizeof(nest_ph) + sizeof(nest_at)) + NEST_STEPS_MAX * sizeof(nest_st), 256); }
+static size_t nest_din_bytes() { return (size_t) NEST_STEPS_MAX * 1024 * 8; }
 size_t k_chain_ws_size(const mv_args * mv, int n, int usable_cus) {
     std::vector<chain_phase> ph; std::vector<attn_args> at;
     const int G = chain_grid_for(usable_cus);
     const int len = chain_analyse(mv, n, G, ph, at);
-    return chain_tables_bytes(len, (int) at.size()) + chain_state_bytes(G);
+    return chain_tables_bytes(len, (int) at.size()) + chain_state_bytes(G) + nest_tables_bytes(len) + nest_din_bytes();
 }
 
 // which compile-time shape (1..6, see shape_din .. shape_head) a phase matches exactly, 0: none - its shape is read from the descriptor
@@ -1013,7 +1085,101 @@ static int chain_shape_kind(const chain_phase & ph, int grid) {
     return (on >> k) & 1 ? k : 0;
 }
 
-chain_plan * k_chain_create(hipStream_t s, const mv_args * mv, int n, void * ws, unsigned * err, int usable_cus) {
+static size_t nest_smem_bytes(int n_steps, int L) {
+    const int n_ph = n_steps * (4 * L + 1), n_at = n_steps * L;
+    return 16 * XBLK_BYTES + (size_t) (NEST_XF + NEST_PART + 16 + 1024 + CH_NCW * CH_ATTW) * 4 + sizeof(chain_ctl) +
+           (size_t) n_ph * sizeof(nest_ph) + (size_t) n_at * sizeof(nest_at) + (size_t) n_steps * sizeof(nest_st) + (size_t) n_steps * 1024 * 4;
+}
+// Is the run (kinds assigned) a step program - steps x { din, L x { in_proj, out_proj, linear_in, linear_out }, head } at the compile-time shapes, one
+// transformer_out, one attention shape? Then fill c->NP / c->nest_tables (device addresses inside `tables_dev` / `din_dev`).
+static bool nest_no(int why) {
+    if (chain_env("MI355X_CHAIN_VERBOSE", 0)) fprintf(stderr, "chain engine: not a step program (rule %d of nest_build)\n", why);
+    return false;
+}
+static bool nest_build(chain_plan * c, char * tables_dev, char * din_dev, int usable_cus) {
+    static const int on = chain_env("MI355X_CHAIN_NEST", 1);
+    const int n = (int) c->phases.size();
+    if (chain_env("MI355X_CHAIN_VERBOSE", 0) > 1)
+        for (int i = 0; i < n && i < 60; i++) {
+            const chain_phase & ph = c->phases[(size_t) i];
+            fprintf(stderr, "  phase %3d kind %d K %d M %d pair %lld pro %d xch %d res %d emb %d save %d am %d pub %d n_in %d rows_wg %d\n", i, ph.kind, ph.K, ph.M, (long long) ph.pair_F, ph.prologue,
+                    ph.x_chain, ph.res, ph.emb.table != nullptr, ph.save, ph.argmax, ph.n_pub, ph.n_in, ph.rows_wg);
+        }
+    if (!on || c->grid != 256 || n < 6 || c->phases[0].kind != 1) return nest_no(1);
+    int per = 1;
+    while (per < n && c->phases[(size_t) per].kind != 1) per++;
+    if ((per - 2) % 4 != 0 || per < 6 || n % per != 0) return nest_no(2);
+    const int L = (per - 2) / 4, S = n / per;
+    if (S > NEST_STEPS_MAX) return nest_no(3);
+    const chain_phase & d0 = c->phases[0];
+    const attn_args * a0 = nullptr;
+    auto fits = [](int64_t v) { return v >= 0 && v < (1ll << 30); };
+    for (int s = 0; s < S; s++) {
+        const chain_phase * st = &c->phases[(size_t) s * per];
+        if (st[0].kind != 1 || st[0].x != d0.x || !st[0].save || st[0].res || (s == 0 && st[0].emb_chain)) return nest_no(4);
+        for (int l = 0; l < L; l++)
+            for (int i = 0; i < 4; i++) if (st[1 + 4 * l + i].kind != 2 + i) return nest_no(5);
+        if (st[per - 1].kind != 6) return nest_no(6);
+        if (s > 0 && !st[0].emb_chain) return nest_no(7);   // (a head's arg-max inside the run is consumed by the next step)
+        for (int l = 0; l < L; l++) {
+            const chain_phase & op = st[1 + 4 * l + 1], & lo = st[1 + 4 * l + 3];
+            if (!op.save || op.res != 1 || lo.res != 1) return nest_no(8);
+            if (l + 1 < L && !lo.save) return nest_no(9);
+            const attn_args & at = op.at;
+            if (!a0) a0 = &at;
+            if (at.H != a0->H || at.D != a0->D || at.C != a0->C || at.T != 1 || at.scale != a0->scale || at.q_hs != a0->q_hs || at.k_hs != a0->k_hs || at.v_hs != a0->v_hs ||
+                at.k_nb1 != a0->k_nb1 || at.k_nb2 != a0->k_nb2 || at.v_nb1 != a0->v_nb1 || at.v_nb2 != a0->v_nb2) return nest_no(10);
+            const chain_phase & o0 = c->phases[2];
+            if (op.q_off != o0.q_off || op.k_off != o0.k_off || op.v_off != o0.v_off) return nest_no(11);
+        }
+    }
+    if (!a0 || !fits(a0->q_hs) || !fits(a0->k_hs) || !fits(a0->v_hs) || !fits(a0->k_nb1) || !fits(a0->k_nb2) || !fits(a0->v_nb1) || !fits(a0->v_nb2)) return nest_no(12);
+    c->nest_smem = nest_smem_bytes(S, L);
+    if (c->nest_smem > 160 * 1024) return nest_no(13);
+    {   // the whole grid must be resident with THIS kernel's footprint too
+        static bool granted = false;
+        if (!granted) { HIP_CHECK(hipFuncSetAttribute((const void *) depth_nest_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); granted = true; }
+        static const int force = chain_env("MI355X_CHAIN_GRID_FORCE", 0);
+        int per_cu = 0;
+        if (!force && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *) depth_nest_kernel<256>, CH_THREADS, c->nest_smem) != hipSuccess ||
+                       (long long) per_cu * usable_cus < 256)) return nest_no(14);
+    }
+    const int n_ph = S * (4 * L + 1), n_at = S * L;
+    c->nest_tables.assign((size_t) n_ph * sizeof(nest_ph) + (size_t) n_at * sizeof(nest_at) + (size_t) S * sizeof(nest_st), 0);
+    nest_ph * tp = (nest_ph *) c->nest_tables.data();
+    nest_at * ta = (nest_at *) (tp + n_ph);
+    nest_st * ts = (nest_st *) (ta + n_at);
+    for (int s = 0; s < S; s++) {
+        const chain_phase * st = &c->phases[(size_t) s * per];
+        nest_st & r = ts[s];
+        r.din_w = st[0].w; r.din_y = st[0].y; r.emb = st[0].emb; r.emb_chain = st[0].emb_chain;
+        r.prev_out[0] = st[0].prev_out[0]; r.prev_out[1] = st[0].prev_out[1];
+        r.argmax_out[0] = st[per - 1].argmax_out[0]; r.argmax_out[1] = st[per - 1].argmax_out[1];
+        for (int i = 1; i < per; i++) {
+            nest_ph & q = tp[s * (4 * L + 1) + i - 1];
+            q.w = st[i].w; q.alpha = st[i].alpha; q.y = st[i].y; q.eps = st[i].eps;
+        }
+        for (int l = 0; l < L; l++) {
+            const attn_args & at = st[1 + 4 * l + 1].at;
+            nest_at & q = ta[s * L + l];
+            q.kcache = at.kcache; q.vcache = at.vcache; q.rot = at.rot; q.mask = at.mask; q.index = at.index;
+        }
+    }
+    nest_params & N = c->NP;
+    memset(&N, 0, sizeof(N));
+    N.P = c->P;
+    N.tables = (const u32x4 *) tables_dev;
+    N.n_steps = S; N.n_layers = L;
+    N.din_buf = (u64 *) din_dev; N.din_x = d0.x;
+    const chain_phase & o0 = c->phases[2];
+    N.q_off = o0.q_off; N.k_off = o0.k_off; N.v_off = o0.v_off;
+    N.q_hs = (int) a0->q_hs; N.k_hs = (int) a0->k_hs; N.v_hs = (int) a0->v_hs;
+    N.k_nb1 = (int) a0->k_nb1; N.k_nb2 = (int) a0->k_nb2; N.v_nb1 = (int) a0->v_nb1; N.v_nb2 = (int) a0->v_nb2; N.C = a0->C; N.scale = a0->scale;
+    if (chain_env("MI355X_CHAIN_VERBOSE", 0)) fprintf(stderr, "chain engine: step program, %d steps x %d layers, %zu bytes of LDS\n", S, L, c->nest_smem);
+    return true;
+}
+
+chain_plan * k_chain_create(hipStream_t s, const mv_args * mv, int n, void * ws, unsigned * err, int usable_cus, bool allow_step_program) {
     chain_plan * c = new chain_plan;
     c->grid = chain_grid_for(usable_cus);
     GGML_ASSERT(c->grid > 0 && n <= CH_MAX_PHASES);
@@ -1022,6 +1188,8 @@ chain_plan * k_chain_create(hipStream_t s, const mv_args * mv, int n, void * ws,
     char * base = (char *) ws;
     chain_phase * d_ph = (chain_phase *) base;
     char * state = base + chain_tables_bytes(n, (int) c->attns.size());
+    char * nest_tab = state + chain_state_bytes(c->grid);
+    char * nest_din = nest_tab + nest_tables_bytes(n);
     {
         int ai = 0;
         for (int i = 0; i < n; i++) {
@@ -1034,7 +1202,7 @@ chain_plan * k_chain_create(hipStream_t s, const mv_args * mv, int n, void * ws,
     }
     // the table is uploaded from the plan's own vector (pageable memory: the runtime stages it before returning); the host copy lives as long as the plan
     HIP_CHECK(hipMemcpyAsync(d_ph, c->phases.data(), (size_t) n * sizeof(chain_phase), hipMemcpyHostToDevice, s));
-    HIP_CHECK(hipMemsetAsync(state, 0, chain_state_bytes(c->grid), s));
+    HIP_CHECK(hipMemsetAsync(state, 0, chain_state_bytes(c->grid) + nest_tables_bytes(n) + nest_din_bytes(), s));
     c->P.phases = d_ph; c->P.n_phases = n;
     c->P.launch_seq = (unsigned *) state;
     c->P.gbuf = (u64 *) (state + 256);
@@ -1042,13 +1210,18 @@ chain_plan * k_chain_create(hipStream_t s, const mv_args * mv, int n, void * ws,
     c->P.err = err;
     c->smem = chain_smem();
     GGML_ASSERT(c->smem <= 160 * 1024);
+    c->nest = allow_step_program && nest_build(c, nest_tab, nest_din, usable_cus);
+    if (c->nest) HIP_CHECK(hipMemcpyAsync(nest_tab, c->nest_tables.data(), c->nest_tables.size(), hipMemcpyHostToDevice, s));
     return c;
 }
 void k_chain_free(chain_plan * c) { delete c; }
 int k_chain_length(const chain_plan * c) { return c->P.n_phases; }
 int64_t k_chain_weight_bytes(const chain_plan * c) { int64_t b = 0; for (auto & ph : c->phases) b += (int64_t) ph.M * ph.row_bytes; return b; }
 
+bool k_chain_is_step_program(const chain_plan * c) { return c->nest; }
+
 void k_chain_launch(hipStream_t s, const chain_plan * c) {
+    if (c->nest) { depth_nest_kernel<256><<<c->grid, CH_THREADS, c->nest_smem, s>>>(c->NP); return; }
     // (the template argument only matters to phases with a compile-time shape; any other grid runs every phase from its descriptor)
     if (c->grid == 256) matvec_chain_kernel<256><<<c->grid, CH_THREADS, c->smem, s>>>(c->P);
     else if (c->grid == 128) matvec_chain_kernel<128><<<c->grid, CH_THREADS, c->smem, s>>>(c->P);

@@ -1,0 +1,619 @@
+// hip_chain_nest.h — part of hip_chain.hip (included there, same translation unit): the chained Depth transformer of moshika / PersonaPlex
+// (/root/reference/src/moshi/models/lm.h:446-553, weights per step lm_default.h:136-146) as a COMPILE-TIME step program.
+//
+// matvec_chain_kernel reads a 400-byte descriptor per phase and switches over seven phase bodies inside one loop. Two things cost there
+// (profiles/r04_chain_stamps.txt, the disassembly): every body leaves the next phase's prefetched weights in registers of its own choice, so the
+// loop's back edge moves them - behind an s_waitcnt vmcnt(0): a phase cannot issue its hand-off poll before ITS weights have landed (0.63 us) -
+// and the descriptor fields are fetched from LDS one v_readfirstlane at a time at the head of every phase (0.22 us). Here the program is the
+// loop nest itself
+//     hoist: depformer_in[k] x transformer_out for ALL steps k (they do not depend on the chain, lm.h:505-512)
+//     step k:  x = din_k + emb_k(token)   ->  layers x { in_proj, attention + out_proj, linear_in (paired gate), linear_out }  ->  linears[k] (no norm) -> arg-max
+// with every shape a constant and one phase following another in straight-line code: the weights stay where the request put them, what a phase
+// reads from a table is three pointers (compact records parked in LDS once per launch), and the poll of phase p + 1 goes out right behind the
+// publication of phase p. The 8 (16) depformer_in products leave the chain: one wide phase at the head of the launch computes them for all steps,
+// all workgroups exchange them once, and "+ emb_k(token)" becomes the input stage of layer 0's in_proj - a step is 4 L + 1 hand-offs instead of
+// 4 L + 2, and the 4096-wide quantisation of transformer_out happens once per launch instead of once per step.
+// Arithmetic: the generic chain kernel's (= the unchained kernels') to the bit - same Q8_K rounding, same per-super-block float expression, same
+// 16-lane row sums, same attention, same last-maximum arg-max; tests/test_chain_engine.py compares the three plans bit for bit.
+#pragma once
+
+struct nest_ph { const char * w; const float * alpha; float * y; float eps; int pad; };                                  // one mat-vec phase
+struct nest_at { char * kcache; char * vcache; const float * rot; const float * mask; const int32_t * index; int64_t pad; };   // one attention
+struct nest_st {                                                                                                         // one step
+    const char * din_w; float * din_y;      // depformer_in[k] and the storage of the node din_k + emb_k
+    embed_src emb; int32_t * prev_out[2];   // the embedding row added to din_k; emb_chain: its index is the previous step's arg-max, stored to prev_out
+    int32_t * argmax_out[2];                // where the LAST step's token goes (the others are their successors' prev_out)
+    int emb_chain; int pad[3];
+};
+static_assert(sizeof(nest_ph) == 32 && sizeof(nest_at) == 48 && sizeof(nest_st) % 16 == 0, "nest tables are copied to LDS by 16-byte lanes");
+
+struct nest_params {
+    chain_params P;                         // hand-off buffers, launch counter, error word (phases / n_phases unused)
+    const u32x4 * tables;                   // device: nest_ph[n_steps * (4 L + 1)] | nest_at[n_steps * L] | nest_st[n_steps]
+    int n_steps, n_layers;
+    u64 * din_buf;                          // [n_steps][1024] granules: the hoisted depformer_in products
+    const float * din_x;                    // transformer_out (lm.h:434), x of every depformer_in
+    // the attention's shape, the same in every layer and step (checked when the plan is made)
+    int q_off, k_off, v_off; int q_hs, k_hs, v_hs; int k_nb1, k_nb2, v_nb1, v_nb2; int C; float scale;
+};
+
+#define NEST_XF      3072                   // floats: the in_proj vector an attention phase gathers
+#define NEST_PART    1024                   // super-block partial sums (the hoisted phase: 64 per step)
+#define NEST_STEPS_MAX 16
+
+// the shapes (K, M, pair) of the six mat-vec kinds at grid G: super-blocks of a workgroup and register passes of 64
+template <class SH, int G> struct nest_dim {
+    static constexpr int NB = SH::K / 256;
+    static constexpr int ROWS = (SH::PAIR ? SH::PAIR : SH::M) / G;     // rows of a workgroup (paired: of each half)
+    static constexpr int NSEG = ROWS * NB, NALL = SH::PAIR ? 2 * NSEG : NSEG;
+    static constexpr int PASSES = (NALL + CH_NCW * 8 - 1) / (CH_NCW * 8);
+    static_assert((SH::PAIR ? SH::PAIR : SH::M) % G == 0, "rows divide over the grid");
+};
+
+template <int G>
+__global__ void __launch_bounds__(CH_THREADS) depth_nest_kernel(nest_params N) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wg = blockIdx.x;
+    constexpr int grid = G;
+    const int L = N.n_layers, per_step = 4 * L + 1;
+    const int n_ph = N.n_steps * per_step, n_at = N.n_steps * L;
+
+    xblk * xs = (xblk *) smem;
+    float * xf = (float *) (xs + 16);
+    float * part = xf + NEST_XF;
+    float * xres = part + NEST_PART;
+    float * xa = xres + 16;
+    float * attw = xa + 1024;
+    chain_ctl * ctl = (chain_ctl *) (attw + CH_NCW * CH_ATTW);
+    const nest_ph * t_ph = (const nest_ph *) (ctl + 1);
+    const nest_at * t_at = (const nest_at *) (t_ph + n_ph);
+    const nest_st * t_st = (const nest_st *) (t_at + n_at);
+    float * din_all = (float *) (t_st + N.n_steps);                      // [n_steps][1024]
+
+    const chain_params & P = N.P;
+    // Workgroup rendezvous (LDS traffic only is waited for). There is NO early exit anywhere below: a wave that gives up a bounded wait raises ctl->failed (and
+    // the host-visible error word), every later poll of the workgroup then leaves at its first look, and the program runs to its end on whatever it has. An exit
+    // out of the loop nest would be cheap at run time but not at compile time: the compiler funnels all exits of a loop through one guard block that the normal
+    // path shares, and its wait-count bookkeeping then assumes at the head of a phase whatever was in flight at ANY exit - the phase opens with s_waitcnt vmcnt(0).
+    auto nbar = [&]() { lds_barrier(); };
+    if (tid == 0) { ctl->failed = 0; ctl->token = 0; }
+    {
+        const int n16 = (n_ph * (int) sizeof(nest_ph) + n_at * (int) sizeof(nest_at) + N.n_steps * (int) sizeof(nest_st)) / 16;
+        const GLOBAL_AS u32x4 * src = (const GLOBAL_AS u32x4 *) N.tables;
+        for (int i = tid; i < n16; i += CH_THREADS) ((u32x4 *) t_ph)[i] = src[i];
+    }
+    const unsigned launch = *gp(P.launch_seq);
+    const unsigned tag_base = launch << 12;
+    __syncthreads();
+
+    // ---- table reads: one record -> scalar registers (LDS broadcast reads, v_readfirstlane)
+    auto ld_ph = [&](int q) {
+        const u32x4 a = ((const u32x4 *) (t_ph + q))[0], b = ((const u32x4 *) (t_ph + q))[1];
+        nest_ph r;
+        unsigned w[8] = { a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w };
+#pragma unroll
+        for (int i = 0; i < 8; i++) w[i] = (unsigned) __builtin_amdgcn_readfirstlane((int) w[i]);
+        __builtin_memcpy(&r, w, sizeof(r));
+        return r;
+    };
+    auto ld_w = [&](int q) -> const char * {   // only the weight pointer (the next phase's, for the request)
+        const unsigned * s = (const unsigned *) (t_ph + q);
+        unsigned w[2] = { (unsigned) __builtin_amdgcn_readfirstlane((int) s[0]), (unsigned) __builtin_amdgcn_readfirstlane((int) s[1]) };
+        const char * r;
+        __builtin_memcpy(&r, w, 8);
+        return r;
+    };
+    auto ld_at = [&](int q) {
+        const u32x4 a = ((const u32x4 *) (t_at + q))[0], b = ((const u32x4 *) (t_at + q))[1], c = ((const u32x4 *) (t_at + q))[2];
+        nest_at r;
+        unsigned w[12] = { a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w };
+#pragma unroll
+        for (int i = 0; i < 12; i++) w[i] = (unsigned) __builtin_amdgcn_readfirstlane((int) w[i]);
+        __builtin_memcpy(&r, w, sizeof(r));
+        return r;
+    };
+    auto ld_st = [&](int q) {
+        nest_st r;
+        constexpr int NW = (int) sizeof(nest_st) / 4;
+        unsigned w[NW];
+        const unsigned * s = (const unsigned *) (t_st + q);
+#pragma unroll
+        for (int i = 0; i < NW; i++) w[i] = (unsigned) __builtin_amdgcn_readfirstlane((int) s[i]);
+        __builtin_memcpy(&r, w, sizeof(r));
+        return r;
+    };
+
+    const __amdgpu_buffer_rsrc_t gb = make_rsrc(P.gbuf, 2u * CH_XF_MAX * 8u);
+    const __amdgpu_buffer_rsrc_t cb = make_rsrc(P.cand, 2u * 2u * (unsigned) grid * 8u);
+    auto give_up = [&]() { if (lane == 0) { lds_store(&ctl->failed, 1u); *gp(P.err) = 2u; } };
+
+    // ---- the weights of ONE phase in registers: pass ps = super-blocks 64 ps .. 64 ps + 63 of the workgroup's rows, 8 lanes per super-block
+    // (16-byte header in every lane of the group + its own 16-byte nibble chunk), as matvec_chain_kernel holds them
+    u32x4 wh[2], wq[2];
+    auto request = [&](auto shape_tag, const char * w, int rows_rt) {   // rows_rt: rows of this workgroup when two shapes share the request (K = 1024, unpaired)
+        using SH = decltype(shape_tag);
+        using D = nest_dim<SH, G>;
+        constexpr long long row_bytes = (long long) D::NB * 144;
+        const int rows = rows_rt > 0 ? rows_rt : D::ROWS;
+        const int nseg = rows * D::NB, nall = SH::PAIR ? 2 * nseg : nseg;
+        const long long r0 = (long long) wg * rows;
+        const GLOBAL_AS u32x4 * w0 = (const GLOBAL_AS u32x4 *) (gp(w) + r0 * row_bytes);
+        const GLOBAL_AS u32x4 * w1 = (const GLOBAL_AS u32x4 *) (gp(w) + (r0 + SH::PAIR) * row_bytes);
+#pragma unroll
+        for (int ps = 0; ps < D::PASSES; ps++) {
+            const int sb = ps * (CH_NCW * 8) + wave * 8 + (lane >> 3);
+            const int sbc = sb < nall ? sb : nall - 1;
+            const GLOBAL_AS u32x4 * src = (!SH::PAIR || sbc < nseg) ? w0 + sbc * 9 : w1 + (sbc - nseg) * 9;
+            wh[ps] = __builtin_nontemporal_load(src);
+            wq[ps] = __builtin_nontemporal_load(src + 1 + (lane & 7));
+        }
+    };
+    // the first phase's weights go out before anything else
+    request(shape_inproj(), ld_w(0), 0);
+
+    // one super-block against its Q8_K block (the WS = 1 arithmetic of matvec_q4k_kernel): result in lane j8 == 0 of the group
+    auto sb_dot = [&](const u32x4 & h, const u32x4 & q, const xblk * xb, float & out) {
+        const int j8 = lane & 7, g32 = j8 >> 1, hf = j8 & 1;
+        const uint32_t hw[4] = { h.x, h.y, h.z, h.w };
+        uint32_t sc[2], mn[2];
+        q4k_unpack_scales_w(hw[1], hw[2], hw[3], sc, mn);
+        const u32x4 ylo = *(const u32x4 *) (xb->q + 64 * g32 + 16 * hf), yhi = *(const u32x4 *) (xb->q + 64 * g32 + 32 + 16 * hf);
+        const uint32_t qw[4] = { q.x, q.y, q.z, q.w }, yl[4] = { ylo.x, ylo.y, ylo.z, ylo.w }, yh[4] = { yhi.x, yhi.y, yhi.z, yhi.w };
+        int lo = 0, hi = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            lo = dot4_i8((int) (qw[k] & 0x0F0F0F0Fu), (int) yl[k], lo);
+            hi = dot4_i8((int) ((qw[k] >> 4) & 0x0F0F0F0Fu), (int) yh[k], hi);
+        }
+        const int i0 = 2 * g32, i1 = 2 * g32 + 1;
+        const int s0 = (int) ((sc[i0 >> 2] >> (8 * (i0 & 3))) & 0xff), s1 = (int) ((sc[i1 >> 2] >> (8 * (i1 & 3))) & 0xff);
+        int isum = __mul24(s0, lo) + __mul24(s1, hi);
+        const uint32_t bs2 = *(const uint32_t *) (xb->bsums + 2 * j8);
+        const int bs = (int) (int16_t) (bs2 & 0xffff) + (int) (int16_t) (bs2 >> 16);
+        int msum = __mul24((int) ((mn[j8 >> 2] >> (8 * (j8 & 3))) & 0xff), bs);
+        isum += dpp_i32<DPP_QUAD_XOR1>(isum); msum += dpp_i32<DPP_QUAD_XOR1>(msum);
+        isum += dpp_i32<DPP_QUAD_XOR2>(isum); msum += dpp_i32<DPP_QUAD_XOR2>(msum);
+        isum += dpp_i32<DPP_HALF_MIRROR>(isum); msum += dpp_i32<DPP_HALF_MIRROR>(msum);
+        const float d = h2f((uint16_t) (hw[0] & 0xffff)) * xb->d, dmin = h2f((uint16_t) (hw[0] >> 16)) * xb->d;
+        out = d * (float) isum - dmin * (float) msum;
+    };
+    // the dots of a phase out of wh / wq into part[]
+    auto dots = [&](auto shape_tag, int rows_rt) {
+        using SH = decltype(shape_tag);
+        using D = nest_dim<SH, G>;
+        const int rows = rows_rt > 0 ? rows_rt : D::ROWS;
+        const int nall = (SH::PAIR ? 2 : 1) * rows * D::NB;
+#pragma unroll
+        for (int ps = 0; ps < D::PASSES; ps++) {
+            if (ps * (CH_NCW * 8) + wave * 8 >= nall) break;   // (wave-uniform)
+            const int sb = ps * (CH_NCW * 8) + wave * 8 + (lane >> 3);
+            const int sbc = sb < nall ? sb : nall - 1;
+            float r;
+            sb_dot(wh[ps], wq[ps], xs + (sbc % D::NB), r);
+            if ((lane & 7) == 0 && sb < nall) part[sb] = r;
+        }
+    };
+
+    // ---- the values of a hand-off straight into registers: block b = 256 values = lane l's granules 4 l .. 4 l + 3 = two 16-byte agent-scope loads;
+    // waves take blocks w and w + 8. Only block-owning waves poll (every poll is a fabric read).
+    auto poll_blocks = [&](auto nbc, int p, float v[2][4]) {
+        constexpr int NB = decltype(nbc)::value;
+        const unsigned tag_in = tag_base | (unsigned) p;
+        const unsigned in_base = (unsigned) ((p - 1) & 1) * (CH_XF_MAX * 8u);
+        const bool has0 = wave < NB, has1 = wave + CH_NCW < NB;
+        u32x4 gq[2][2];
+        gq[0][0] = gq[0][1] = gq[1][0] = gq[1][1] = (u32x4) { 0u, tag_in, 0u, tag_in };
+        auto issue = [&]() {
+            if (has0) {
+                const unsigned o0 = in_base + ((unsigned) wave * 256u + (unsigned) lane * 4u) * 8u;
+                gq[0][0] = ld16_agent(gb, o0); gq[0][1] = ld16_agent(gb, o0 + 16u);
+                if (has1) {
+                    const unsigned o1 = o0 + CH_NCW * 256u * 8u;
+                    gq[1][0] = ld16_agent(gb, o1); gq[1][1] = ld16_agent(gb, o1 + 16u);
+                }
+            }
+        };
+        issue();
+        unsigned spins = 0;
+        for (;;) {
+            bool ok = true;
+#pragma unroll
+            for (int r = 0; r < 2; r++) ok = ok && gq[r][0].y == tag_in && gq[r][0].w == tag_in && gq[r][1].y == tag_in && gq[r][1].w == tag_in;
+            if (__all(ok)) break;
+            if (++spins > CH_SPIN_MAX || lds_load(&ctl->failed)) { give_up(); break; }
+            __builtin_amdgcn_s_sleep(1);
+            issue();
+        }
+        settle_vmcnt();
+        // (read unconditionally - a wave without the block holds the zeros it was initialised with: a use under the same condition as the load leaves, as far
+        // as the compiler's wait-count bookkeeping can tell, a path on which the load is never waited for, and the NEXT phase then starts behind vmcnt(0))
+#pragma unroll
+        for (int r = 0; r < 2; r++) {
+            v[r][0] = __uint_as_float(gq[r][0].x); v[r][1] = __uint_as_float(gq[r][0].z);
+            v[r][2] = __uint_as_float(gq[r][1].x); v[r][3] = __uint_as_float(gq[r][1].z);
+        }
+    };
+    // norm weights of the blocks a wave owns (requested before the poll: they do not depend on the chain)
+    auto load_alpha = [&](auto nbc, const float * alpha, f32x4 al[2]) {
+        constexpr int NB = decltype(nbc)::value;
+#pragma unroll
+        for (int r = 0; r < 2; r++) {
+            const int b = wave + r * CH_NCW;
+            al[r] = (f32x4) { 1.f, 1.f, 1.f, 1.f };
+            if (b < NB) al[r] = *(const GLOBAL_AS f32x4 *) (gp(alpha) + b * 256 + lane * 4);
+        }
+    };
+    // RMS norm (matvec_q4k_kernel's order: per-thread squares in double, wave butterfly, waves added in index order) + Q8_K blocks into xs.
+    // Ends behind the "blocks ready" barrier.
+    auto norm_quant = [&](auto nbc, auto rmsc, float v[2][4], const f32x4 al[2], float eps) {
+        constexpr int NB = decltype(nbc)::value;
+        constexpr bool RMS = decltype(rmsc)::value;
+        if (RMS) {
+            double acc = 0;
+#pragma unroll
+            for (int r = 0; r < 2; r++)
+                if (wave + r * CH_NCW < NB)
+#pragma unroll
+                    for (int k = 0; k < 4; k++) acc += (double) (v[r][k] * v[r][k]);
+            acc = wave_allsum_f64(acc);
+            if (lane == 0) ctl->sumsq[wave] = acc;
+            nbar();
+            double tot = 0;
+#pragma unroll
+            for (int w = 0; w < CH_NCW; w++) tot += ctl->sumsq[w];
+            constexpr int K = NB * 256;
+            static_assert(!RMS || (K & (K - 1)) == 0, "the mean is a product with 1 / K");
+            const float mean = (float) (tot * (1.0 / (double) K));
+            const float scale = 1.0f / sqrtf(mean + eps);
+#pragma unroll
+            for (int r = 0; r < 2; r++) {
+                if (r * CH_NCW >= NB) continue;   // (compile-time; a wave without the block scales its zeros by the ones al[] was initialised with - see poll_blocks)
+                const float a4[4] = { al[r].x, al[r].y, al[r].z, al[r].w };
+#pragma unroll
+                for (int k = 0; k < 4; k++) v[r][k] = a4[k] * (v[r][k] * scale);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 2; r++) {
+            const int b = wave + r * CH_NCW;
+            if (b < NB) quantize_block_q8k(xs + b, v[r], lane);
+        }
+        nbar();
+    };
+    // fixed-order row sums of an unpaired phase + epilogue + publication; rows_rt as in request()
+    auto rowsum = [&](auto shape_tag, int rows_rt, int p, float * y, float & best, int & bi) {
+        using SH = decltype(shape_tag);
+        using D = nest_dim<SH, G>;
+        const int rows = rows_rt > 0 ? rows_rt : D::ROWS;
+        const unsigned tag_out = tag_base | (unsigned) (p + 1);
+        const unsigned pub_base = (unsigned) (p & 1) * CH_XF_MAX;
+        const long long row0 = (long long) wg * rows;
+        for (int rr = tid >> 4; rr < rows; rr += CH_NCW * 4) {
+            float sum = 0.f;
+#pragma unroll
+            for (int j0 = 0; j0 < D::NB; j0 += 16) { const int j = j0 + (tid & 15); if (j < D::NB) sum += part[rr * D::NB + j]; }
+            sum = row16_allsum_f32(sum);
+            if ((tid & 15) == 0) {
+                const long long row = row0 + rr;
+                if (SH::RES == 1) sum = xres[rr] + sum;
+                if (SH::SAVE) xres[rr] = sum;
+                if (SH::PUB) st_granule(P.gbuf + pub_base + row, tag_out, __float_as_uint(sum));
+                gp(y)[row] = sum;
+                if (sum >= best) { best = sum; bi = (int) row; }   // rows ascend per thread: '>=' keeps the last maximum
+            }
+        }
+    };
+
+    // =================================================================================================================================
+    // hoist: din_k = depformer_in[k] x transformer_out for every step k (shape_din's dots: K = 4096, 4 rows of each matrix per workgroup = one
+    // register pass per step), published once, gathered by every workgroup into din_all
+    {
+        const int p = 0; (void) p;
+        CH_STAMP(10);
+        using DD = nest_dim<shape_din, G>;
+        static_assert(DD::NALL == 64 && DD::NB == 16, "the hoisted phase: one register pass of 64 super-blocks per step");
+        float v[2][4];
+#pragma unroll
+        for (int r = 0; r < 2; r++) {
+            const f32x4 t = *(const GLOBAL_AS f32x4 *) (gp(N.din_x) + (wave + r * CH_NCW) * 256 + lane * 4);
+            v[r][0] = t.x; v[r][1] = t.y; v[r][2] = t.z; v[r][3] = t.w;
+        }
+        const __amdgpu_buffer_rsrc_t db = make_rsrc(N.din_buf, (unsigned) N.n_steps * 1024u * 8u);
+        const unsigned tag_d = tag_base | 1u;
+        constexpr long long row_bytes = 16 * 144;
+#pragma unroll 1
+        for (int k0 = 0; k0 < N.n_steps; k0 += 8) {
+            u32x4 dh[8], dq[8];
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                const int k = k0 + i < N.n_steps ? k0 + i : N.n_steps - 1;
+                const char * w = *(const char * const *) &t_st[k].din_w;   // (LDS; uniform)
+                const GLOBAL_AS u32x4 * src = (const GLOBAL_AS u32x4 *) (gp(w) + (long long) wg * DD::ROWS * row_bytes) + (wave * 8 + (lane >> 3)) * 9;
+                dh[i] = __builtin_nontemporal_load(src);
+                dq[i] = __builtin_nontemporal_load(src + 1 + (lane & 7));
+            }
+            if (k0 == 0) {
+                const f32x4 one[2] = { (f32x4) { 1.f, 1.f, 1.f, 1.f }, (f32x4) { 1.f, 1.f, 1.f, 1.f } };
+                norm_quant(std::integral_constant<int, 16>(), std::false_type(), v, one, 0.f);
+            } else nbar();   // part[] of the previous round has been read
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                if (k0 + i >= N.n_steps) break;
+                const int sb = wave * 8 + (lane >> 3);
+                float r;
+                sb_dot(dh[i], dq[i], xs + (sb % 16), r);
+                if ((lane & 7) == 0) part[i * 64 + sb] = r;
+            }
+            nbar();
+            {   // 4 rows x (up to) 8 steps = 32 row sums of 16 partials: one per 16-lane row of the workgroup
+                const int r32 = tid >> 4, i = r32 >> 2, rr = r32 & 3;
+                float sum = part[i * 64 + rr * 16 + (tid & 15)];
+                sum = row16_allsum_f32(sum);
+                if ((tid & 15) == 0 && k0 + i < N.n_steps) st_granule(N.din_buf + (size_t) (k0 + i) * 1024 + (size_t) wg * 4 + rr, tag_d, __float_as_uint(sum));
+            }
+        }
+        CH_STAMP(0);
+        // everybody's products of every step -> din_all
+        const int npairs = N.n_steps * 512;
+        for (int base = 0; base < npairs; base += 8 * CH_THREADS) {
+            unsigned spins = 0;
+            for (;;) {
+                u32x4 g[8];
+#pragma unroll
+                for (int it = 0; it < 8; it++) {
+                    const int pi = base + it * CH_THREADS + tid;
+                    g[it] = ld16_agent(db, (unsigned) (pi < npairs ? pi : npairs - 1) * 16u);
+                }
+                bool ok = true;
+#pragma unroll
+                for (int it = 0; it < 8; it++) ok = ok && g[it].y == tag_d && g[it].w == tag_d;
+                if (__all(ok)) {
+#pragma unroll
+                    for (int it = 0; it < 8; it++) {
+                        const int pi = base + it * CH_THREADS + tid;
+                        if (pi < npairs) *(float2 *) (din_all + 2 * pi) = make_float2(__uint_as_float(g[it].x), __uint_as_float(g[it].z));
+                    }
+                    break;
+                }
+                if (++spins > CH_SPIN_MAX || lds_load(&ctl->failed)) { give_up(); break; }
+                __builtin_amdgcn_s_sleep(1);
+            }
+        }
+        CH_STAMP(9);
+        nbar();
+    }
+
+    // =================================================================================================================================
+    int p = 0;   // phase counter: phase p reads what carries tag p and publishes with tag p + 1, the two hand-off buffers alternate by parity
+#pragma unroll 1
+    for (int s = 0; s < N.n_steps; s++) {
+#pragma unroll 1
+        for (int l = 0; l < L; l++) {
+            // ---------------------------------------------------------------- in_proj: rms_norm -> 1024 -> 3072
+            {
+                CH_STAMP(10);
+                const nest_ph ph = ld_ph(p);
+                f32x4 al[2];
+                load_alpha(std::integral_constant<int, 4>(), ph.alpha, al);
+                CH_STAMP(0);
+                float v[2][4] = { { 0.f, 0.f, 0.f, 0.f }, { 0.f, 0.f, 0.f, 0.f } };
+                if (l > 0) {
+                    CH_STAMP(1);
+                    poll_blocks(std::integral_constant<int, 4>(), p, v);
+                    CH_STAMP(2);
+                } else {
+                    // layer 0: x = din_k + emb_k(token) (lm.h:512-526), the token being the previous step's arg-max (or an index in memory: step 0)
+                    const nest_st st = ld_st(s);
+                    int64_t r;
+                    if (st.emb_chain) {
+                        if (wave == 0) {
+                            int token = 0;
+                            if (!gather_token(cb, (unsigned) ((p - 1) & 1) * (2u * (unsigned) grid * 8u), grid, tag_base | (unsigned) p, lane, ctl, token)) give_up();
+                            if (lane == 0) {
+                                ctl->token = token;
+                                if (wg == 0) { if (st.prev_out[0]) *gp(st.prev_out[0]) = token; if (st.prev_out[1]) *gp(st.prev_out[1]) = token; }
+                            }
+                        }
+                        CH_STAMP(1);
+                        nbar();
+                        r = (int64_t) __builtin_amdgcn_readfirstlane(ctl->token);
+                    } else { CH_STAMP(1); r = (int64_t) *gp(st.emb.index); }
+                    CH_STAMP(2);
+                    if (r < 0 || r >= st.emb.n_rows) r = 0;
+                    const GLOBAL_AS char * emb_row = gp(st.emb.table) + r * st.emb.row_bytes;
+                    float emb_scale = 1.f;
+                    if (st.emb.scale) emb_scale = *gp(st.emb.scale);
+                    const float * dk = din_all + s * 1024;
+                    if (wave < 4) {
+                        const f32x4 d4 = *(const f32x4 *) (dk + wave * 256 + lane * 4);
+                        const float d[4] = { d4.x, d4.y, d4.z, d4.w };
+                        float e[4];
+                        dequant4_g(emb_row, st.emb.type, wave * 256 + lane * 4, e);
+#pragma unroll
+                        for (int k = 0; k < 4; k++) {
+                            if (st.emb.scale) e[k] = e[k] * emb_scale;
+                            v[0][k] = d[k] + e[k];
+                        }
+                        // rows 4 wg .. 4 wg + 3 are this workgroup's part of the residual stream (and of the node's own storage): exactly one lane's four values
+                        if (wave == (wg >> 6) && lane == (wg & 63)) {
+#pragma unroll
+                            for (int k = 0; k < 4; k++) { xres[k] = v[0][k]; gp(st.din_y)[wg * 4 + k] = v[0][k]; }
+                        }
+                    }
+                }
+                CH_STAMP(3);
+                norm_quant(std::integral_constant<int, 4>(), std::true_type(), v, al, ph.eps);
+                CH_STAMP(5);
+                dots(shape_inproj(), 0);
+                request(shape_outproj(), ld_w(p + 1), 0);
+                CH_STAMP(6);
+                nbar();
+                CH_STAMP(7);
+                float best = -INFINITY; int bi = -1;
+                rowsum(shape_inproj(), 0, p, ph.y, best, bi);
+                CH_STAMP(8);
+                CH_STAMP(9);
+                p = __builtin_amdgcn_readfirstlane(p + 1);
+            }
+            // ---------------------------------------------------------------- attention over the ring of <= 8 + out_proj 1024 -> 1024 + residual
+            {
+                CH_STAMP(10);
+                const nest_ph ph = ld_ph(p);
+                const nest_at ta = ld_at(s * L + l);
+                attn_args at;
+                at.q_hs = N.q_hs; at.k_hs = N.k_hs; at.v_hs = N.v_hs; at.rot = ta.rot; at.mask = ta.mask; at.index = ta.index; at.kcache = ta.kcache; at.vcache = ta.vcache;
+                at.k_nb1 = N.k_nb1; at.k_nb2 = N.k_nb2; at.v_nb1 = N.v_nb1; at.v_nb2 = N.v_nb2; at.H = 2 * CH_NCW; at.D = 64; at.C = N.C; at.T = 1; at.scale = N.scale;
+                CH_STAMP(0);
+                u32x4 kq[2], vq[2];
+                const __amdgpu_buffer_rsrc_t kr = make_rsrc(at.kcache, (unsigned) ((int64_t) at.H * at.k_nb2));
+                const __amdgpu_buffer_rsrc_t vr = make_rsrc(at.vcache, (unsigned) ((int64_t) at.H * at.v_nb2));
+                chain_attn_ring_loads(at, wave * 2, lane, kq, vq, kr, vr);
+                float at_rc = 1.f, at_rs = 0.f;
+                const int sub = lane / 8, cc = sub < at.C ? sub : at.C - 1, pp = lane < 32 ? lane : lane - 32;
+                const int at_slot = gp(at.index)[0];
+                const float at_m = gp(at.mask)[cc];
+                if (at.rot) { at_rc = gp(at.rot)[pp]; at_rs = gp(at.rot)[32 + pp]; }
+                CH_STAMP(1);
+                if (!gather_vector_n<3>(gb, (unsigned) ((p - 1) & 1) * (CH_XF_MAX * 8u), 3072 / 2, tag_base | (unsigned) p, xf, wave, lane, ctl)) give_up();
+                CH_STAMP(2);
+                nbar();
+                chain_attn_wave(at, xf + N.q_off, xf + N.k_off, xf + N.v_off, wave * 2, lane, attw + wave * CH_ATTW, xa + wave * 128, kq, vq, wg == 0, kr, vr,
+                                at_slot, at_m, at_rc, at_rs
+#if defined(CH_LOG)
+                                , wg == 0 ? 0 : wg == grid - 1 ? 1 : -1, p
+#endif
+                                );
+                nbar();
+                CH_STAMP(3);
+                float v[2][4] = { { 0.f, 0.f, 0.f, 0.f }, { 0.f, 0.f, 0.f, 0.f } };
+                if (wave < 4) { const f32x4 t = *(const f32x4 *) (xa + wave * 256 + lane * 4); v[0][0] = t.x; v[0][1] = t.y; v[0][2] = t.z; v[0][3] = t.w; }
+                const f32x4 one[2] = { (f32x4) { 1.f, 1.f, 1.f, 1.f }, (f32x4) { 1.f, 1.f, 1.f, 1.f } };
+                norm_quant(std::integral_constant<int, 4>(), std::false_type(), v, one, 0.f);
+                CH_STAMP(5);
+                dots(shape_outproj(), 0);
+                // workgroup 0 wrote the new K / V ring rows with agent-scope stores: drained here, in front of every later publication (Guideline 16 R1)
+                if (wg == 0) wait_vmcnt<0>();
+                request(shape_linin(), ld_w(p + 1), 0);
+                CH_STAMP(6);
+                nbar();
+                CH_STAMP(7);
+                float best = -INFINITY; int bi = -1;
+                rowsum(shape_outproj(), 0, p, ph.y, best, bi);
+                CH_STAMP(8);
+                CH_STAMP(9);
+                p = __builtin_amdgcn_readfirstlane(p + 1);
+            }
+            // ---------------------------------------------------------------- linear_in, paired: rms_norm -> 1024 -> 2 x 2816 -> silu(l) * r
+            {
+                CH_STAMP(10);
+                const nest_ph ph = ld_ph(p);
+                f32x4 al[2];
+                load_alpha(std::integral_constant<int, 4>(), ph.alpha, al);
+                CH_STAMP(0);
+                float v[2][4];
+                CH_STAMP(1);
+                poll_blocks(std::integral_constant<int, 4>(), p, v);
+                CH_STAMP(2);
+                CH_STAMP(3);
+                norm_quant(std::integral_constant<int, 4>(), std::true_type(), v, al, ph.eps);
+                CH_STAMP(5);
+                dots(shape_linin(), 0);
+                request(shape_linout(), ld_w(p + 1), 0);
+                CH_STAMP(6);
+                nbar();
+                CH_STAMP(7);
+                {
+                    using D = nest_dim<shape_linin, G>;
+                    const unsigned tag_out = tag_base | (unsigned) (p + 1);
+                    const unsigned pub_base = (unsigned) (p & 1) * CH_XF_MAX;
+                    const long long row0 = (long long) wg * D::ROWS;
+                    for (int rr = tid >> 4; rr < D::ROWS; rr += CH_NCW * 4) {
+                        float sl = 0.f, sr = 0.f;
+                        const int j = tid & 15;
+                        if (j < D::NB) { sl += part[rr * D::NB + j]; sr += part[(D::ROWS + rr) * D::NB + j]; }
+                        sl = row16_allsum_f32(sl); sr = row16_allsum_f32(sr);
+                        if ((tid & 15) == 0) {
+                            const float g = (sl / (1.0f + expf(-sl))) * sr;
+                            st_granule(P.gbuf + pub_base + row0 + rr, tag_out, __float_as_uint(g));
+                            gp(ph.y)[row0 + rr] = sl; gp(ph.y)[shape_linin::PAIR + row0 + rr] = sr;
+                        }
+                    }
+                }
+                CH_STAMP(8);
+                CH_STAMP(9);
+                p = __builtin_amdgcn_readfirstlane(p + 1);
+            }
+            // ---------------------------------------------------------------- linear_out 2816 -> 1024 + residual
+            {
+                CH_STAMP(10);
+                const nest_ph ph = ld_ph(p);
+                CH_STAMP(0);
+                float v[2][4];
+                CH_STAMP(1);
+                poll_blocks(std::integral_constant<int, 11>(), p, v);
+                CH_STAMP(2);
+                CH_STAMP(3);
+                const f32x4 one[2] = { (f32x4) { 1.f, 1.f, 1.f, 1.f }, (f32x4) { 1.f, 1.f, 1.f, 1.f } };
+                norm_quant(std::integral_constant<int, 11>(), std::false_type(), v, one, 0.f);
+                CH_STAMP(5);
+                dots(shape_linout(), 0);
+                // what follows: the next layer's in_proj (12 rows per workgroup) or this step's linears[k] (8 rows): both 1024 wide, one request
+                if (p + 1 < n_ph) request(shape_inproj(), ld_w(p + 1), l + 1 < L ? 0 : nest_dim<shape_head, G>::ROWS);
+                CH_STAMP(6);
+                nbar();
+                CH_STAMP(7);
+                float best = -INFINITY; int bi = -1;
+                rowsum(shape_linout(), 0, p, ph.y, best, bi);
+                CH_STAMP(8);
+                CH_STAMP(9);
+                p = __builtin_amdgcn_readfirstlane(p + 1);
+            }
+        }
+        // -------------------------------------------------------------------- linears[k]: 1024 -> 2048 -> arg-max candidate
+        {
+            CH_STAMP(10);
+            const nest_ph ph = ld_ph(p);
+            CH_STAMP(0);
+            float v[2][4];
+            CH_STAMP(1);
+            poll_blocks(std::integral_constant<int, 4>(), p, v);
+            CH_STAMP(2);
+            CH_STAMP(3);
+            const f32x4 one[2] = { (f32x4) { 1.f, 1.f, 1.f, 1.f }, (f32x4) { 1.f, 1.f, 1.f, 1.f } };
+            norm_quant(std::integral_constant<int, 4>(), std::false_type(), v, one, 0.f);
+            CH_STAMP(5);
+            constexpr int HR = nest_dim<shape_head, G>::ROWS;
+            dots(shape_inproj(), HR);
+            if (s + 1 < N.n_steps) request(shape_inproj(), ld_w(p + 1), 0);
+            CH_STAMP(6);
+            nbar();
+            CH_STAMP(7);
+            float best = -INFINITY; int bi = -1;
+            rowsum(shape_head(), 0, p, ph.y, best, bi);
+            CH_STAMP(8);
+            am_wave(best, bi);
+            if (lane == 0) { ctl->am_v[wave] = best; ctl->am_i[wave] = bi; }
+            nbar();
+            if (tid == 0) {
+                for (int w = 1; w < CH_NCW; w++) am_merge(best, bi, ctl->am_v[w], ctl->am_i[w]);
+                u64 * c = P.cand + (size_t) (p & 1) * 2 * grid + 2 * wg;
+                st_granule(c, tag_base | (unsigned) (p + 1), __float_as_uint(best));
+                st_granule(c + 1, tag_base | (unsigned) (p + 1), (unsigned) bi);
+            }
+            CH_STAMP(9);
+            p = __builtin_amdgcn_readfirstlane(p + 1);
+        }
+    }
+
+    // the run ends in an arg-max: workgroup 0 merges the candidates and writes the token
+    if (wg == 0 && wave == 0) {
+        const nest_st st = ld_st(N.n_steps - 1);
+        int token = 0;
+        if (gather_token(cb, (unsigned) ((p - 1) & 1) * (2u * (unsigned) grid * 8u), grid, tag_base | (unsigned) p, lane, ctl, token)) {
+            if (lane == 0) { if (st.argmax_out[0]) *gp(st.argmax_out[0]) = token; if (st.argmax_out[1]) *gp(st.argmax_out[1]) = token; }
+        } else give_up();
+    }
+    if (wg == 0 && tid == 0) *gp(P.launch_seq) = launch + 1u;
+}

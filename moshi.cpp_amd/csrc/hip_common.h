@@ -114,7 +114,9 @@ bool   k_chain_default_on();                         // MI355X_CHAIN (default 1;
 // other, so a chain is only taken when its whole grid is resident there (hipOccupancyMaxActiveBlocksPerMultiprocessor x usable_cus >= grid; 256 / 128 / 64)
 int    k_chain_accept(const mv_args * mv, int n, int usable_cus);     // how many of the n consecutive mat-vecs (in launch order) one chain launch can take (0: none)
 size_t k_chain_ws_size(const mv_args * mv, int n, int usable_cus);    // device workspace for exactly that run (tables + hand-off buffers)
-chain_plan * k_chain_create(hipStream_t s, const mv_args * mv, int n, void * ws, unsigned * err, int usable_cus);
+// allow_step_program: a run that is the Depth transformer's steps at their known shapes may execute as the compile-time step program (hip_chain_nest.h)
+chain_plan * k_chain_create(hipStream_t s, const mv_args * mv, int n, void * ws, unsigned * err, int usable_cus, bool allow_step_program);
+bool   k_chain_is_step_program(const chain_plan * c);
 void   k_chain_launch(hipStream_t s, const chain_plan * c);
 void   k_chain_free(chain_plan * c);
 int    k_chain_length(const chain_plan * c);

@@ -74,6 +74,12 @@ def test_full_size_depth_chain_is_bit_identical_to_launches(which):
     assert st.chained_matvecs_in_last_plan == cfg.dep_q * per_step, f"{st.chained_matvecs_in_last_plan} of {cfg.dep_q * per_step} Depth mat-vecs chained"
     plain, _ = run("hip", cfg, 6, flags=16)
     assert_bit_identical(plain, chained, which)
+    # the default plan runs the Depth graph as the compile-time step program (hip_chain_nest.h: depformer_in hoisted, shapes and order fixed at compile time);
+    # backend flag 1024 keeps the descriptor-driven chain kernel: all three plans must agree to the bit
+    assert st.chain_step_programs_in_last_plan == 1, "the Depth graph did not take the step program"
+    generic, st_g = run("hip", cfg, 6, flags=32 | 1024)
+    assert st_g.chain_step_programs_in_last_plan == 0 and st_g.chained_matvecs_in_last_plan == cfg.dep_q * per_step
+    assert_bit_identical(generic, chained, which + " (descriptor-driven chain vs step program)")
 
 
 def test_small_width_runs_between_attention_launches_are_chained_too():
