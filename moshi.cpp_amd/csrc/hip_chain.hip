@@ -1175,6 +1175,14 @@ static bool nest_build(chain_plan * c, char * tables_dev, char * din_dev, int us
     N.q_off = o0.q_off; N.k_off = o0.k_off; N.v_off = o0.v_off;
     N.q_hs = (int) a0->q_hs; N.k_hs = (int) a0->k_hs; N.v_hs = (int) a0->v_hs;
     N.k_nb1 = (int) a0->k_nb1; N.k_nb2 = (int) a0->k_nb2; N.v_nb1 = (int) a0->v_nb1; N.v_nb2 = (int) a0->v_nb2; N.C = a0->C; N.scale = a0->scale;
+    {   // MI355X_NEST_DELAY="a,b,c,d,e": s_sleep units before the first poll of in_proj / out_proj / linear_in / linear_out / linears[k]
+        static const int dflt[5] = { 20, 0, 20, 20, 20 };   // tests/microbench/nest_delay_sweep.sh: LM step 2 310 us with no delay, 2 120 - 2 135 with 20 - 24 units
+        for (int i = 0; i < 5; i++) N.delay[i] = dflt[i];
+        if (const char * e = getenv("MI355X_NEST_DELAY")) {
+            int d[5]; const int got = sscanf(e, "%d,%d,%d,%d,%d", &d[0], &d[1], &d[2], &d[3], &d[4]);
+            for (int i = 0; i < got && i < 5; i++) N.delay[i] = d[i] < 0 ? 0 : d[i] > 200 ? 200 : d[i];
+        }
+    }
     if (chain_env("MI355X_CHAIN_VERBOSE", 0)) fprintf(stderr, "chain engine: step program, %d steps x %d layers, %zu bytes of LDS\n", S, L, c->nest_smem);
     return true;
 }

@@ -35,6 +35,10 @@ struct nest_params {
     const float * din_x;                    // transformer_out (lm.h:434), x of every depformer_in
     // the attention's shape, the same in every layer and step (checked when the plan is made)
     int q_off, k_off, v_off; int q_hs, k_hs, v_hs; int k_nb1, k_nb2, v_nb1, v_nb2; int C; float scale;
+    // s_sleep units (64 cycles) a phase kind waits between its predecessor's publication and its first poll: [0] in_proj, [1] out_proj, [2] linear_in,
+    // [3] linear_out, [4] linears[k]. A poll that samples before the slowest producer's stores are visible comes back empty and costs a whole fabric round
+    // trip under the load of 256 workgroups all doing the same.
+    int delay[5];
 };
 
 #define NEST_XF      3072                   // floats: the in_proj vector an attention phase gathers
@@ -198,8 +202,9 @@ __global__ void __launch_bounds__(CH_THREADS) depth_nest_kernel(nest_params N) {
 
     // ---- the values of a hand-off straight into registers: block b = 256 values = lane l's granules 4 l .. 4 l + 3 = two 16-byte agent-scope loads;
     // waves take blocks w and w + 8. Only block-owning waves poll (every poll is a fabric read).
-    auto poll_blocks = [&](auto nbc, int p, float v[2][4]) {
+    auto poll_blocks = [&](auto nbc, int p, float v[2][4], int delay) {
         constexpr int NB = decltype(nbc)::value;
+        for (int i = 0; i < delay; i++) __builtin_amdgcn_s_sleep(1);
         const unsigned tag_in = tag_base | (unsigned) p;
         const unsigned in_base = (unsigned) ((p - 1) & 1) * (CH_XF_MAX * 8u);
         const bool has0 = wave < NB, has1 = wave + CH_NCW < NB;
@@ -310,7 +315,7 @@ __global__ void __launch_bounds__(CH_THREADS) depth_nest_kernel(nest_params N) {
     // hoist: din_k = depformer_in[k] x transformer_out for every step k (shape_din's dots: K = 4096, 4 rows of each matrix per workgroup = one
     // register pass per step), published once, gathered by every workgroup into din_all
     {
-        const int p = 0; (void) p;
+        const int p = 511; (void) p;   // (diagnostic build: the hoist logs into the last record)
         CH_STAMP(10);
         using DD = nest_dim<shape_din, G>;
         static_assert(DD::NALL == 64 && DD::NB == 16, "the hoisted phase: one register pass of 64 super-blocks per step");
@@ -401,7 +406,7 @@ __global__ void __launch_bounds__(CH_THREADS) depth_nest_kernel(nest_params N) {
                 float v[2][4] = { { 0.f, 0.f, 0.f, 0.f }, { 0.f, 0.f, 0.f, 0.f } };
                 if (l > 0) {
                     CH_STAMP(1);
-                    poll_blocks(std::integral_constant<int, 4>(), p, v);
+                    poll_blocks(std::integral_constant<int, 4>(), p, v, N.delay[0]);
                     CH_STAMP(2);
                 } else {
                     // layer 0: x = din_k + emb_k(token) (lm.h:512-526), the token being the previous step's arg-max (or an index in memory: step 0)
@@ -476,6 +481,7 @@ __global__ void __launch_bounds__(CH_THREADS) depth_nest_kernel(nest_params N) {
                 const float at_m = gp(at.mask)[cc];
                 if (at.rot) { at_rc = gp(at.rot)[pp]; at_rs = gp(at.rot)[32 + pp]; }
                 CH_STAMP(1);
+                for (int i = 0; i < N.delay[1]; i++) __builtin_amdgcn_s_sleep(1);
                 if (!gather_vector_n<3>(gb, (unsigned) ((p - 1) & 1) * (CH_XF_MAX * 8u), 3072 / 2, tag_base | (unsigned) p, xf, wave, lane, ctl)) give_up();
                 CH_STAMP(2);
                 nbar();
@@ -514,7 +520,7 @@ __global__ void __launch_bounds__(CH_THREADS) depth_nest_kernel(nest_params N) {
                 CH_STAMP(0);
                 float v[2][4];
                 CH_STAMP(1);
-                poll_blocks(std::integral_constant<int, 4>(), p, v);
+                poll_blocks(std::integral_constant<int, 4>(), p, v, N.delay[2]);
                 CH_STAMP(2);
                 CH_STAMP(3);
                 norm_quant(std::integral_constant<int, 4>(), std::true_type(), v, al, ph.eps);
@@ -552,7 +558,7 @@ __global__ void __launch_bounds__(CH_THREADS) depth_nest_kernel(nest_params N) {
                 CH_STAMP(0);
                 float v[2][4];
                 CH_STAMP(1);
-                poll_blocks(std::integral_constant<int, 11>(), p, v);
+                poll_blocks(std::integral_constant<int, 11>(), p, v, N.delay[3]);
                 CH_STAMP(2);
                 CH_STAMP(3);
                 const f32x4 one[2] = { (f32x4) { 1.f, 1.f, 1.f, 1.f }, (f32x4) { 1.f, 1.f, 1.f, 1.f } };
@@ -578,7 +584,7 @@ __global__ void __launch_bounds__(CH_THREADS) depth_nest_kernel(nest_params N) {
             CH_STAMP(0);
             float v[2][4];
             CH_STAMP(1);
-            poll_blocks(std::integral_constant<int, 4>(), p, v);
+            poll_blocks(std::integral_constant<int, 4>(), p, v, N.delay[4]);
             CH_STAMP(2);
             CH_STAMP(3);
             const f32x4 one[2] = { (f32x4) { 1.f, 1.f, 1.f, 1.f }, (f32x4) { 1.f, 1.f, 1.f, 1.f } };

@@ -18,10 +18,14 @@ buf = (C.c_ulonglong * (2 * 512 * 16))()
 assert lib.mi355x_chain_log_read(buf) == 0
 rec = np.frombuffer(buf, np.uint64).reshape(2, 512, 16).astype(np.int64)
 names = ["start", "pre-loads", "gathered", "attention", "blocks", "barrier", "dots+req", "dot sync", "published"]
+hoist = rec[0, 511].copy()   # the step program logs its hoisted depformer_in phase into the last record: 10 = entry, 0 = products published, 9 = everybody's gathered
+rec[:, 511] = 0
 n = int((rec[0, :, 0] > 0).sum())
 t0 = rec[0, 0, 0]
+if hoist[10]:
+    print(f"step program: hoisted depformer_in phase {(hoist[0] - hoist[10]) / 100.0:.2f} us to publication + {(hoist[9] - hoist[0]) / 100.0:.2f} us gather; first phase starts {(rec[0, 0, 10] - hoist[9]) / 100.0:.2f} us later")
 print(f"{n} phases; launch span (workgroup 0) {(rec[0, n - 1, 8] - t0) / 100.0:.1f} us")
-per = 26
+per = int(os.environ.get("PER", "25" if hoist[10] else "26"))
 show = int(sys.argv[1]) if len(sys.argv) > 1 else 2 * per
 print("phase |  start us | " + " | ".join(f"{x:>9s}" for x in names[1:]) + " | last wg start-lag")
 for p in range(min(n, show)):
