@@ -88,6 +88,8 @@ struct chain_params {
     u64 * cand;                // [2][2 * grid] arg-max candidates {tag, value bits}, {tag, index}
     unsigned * launch_seq;     // bumped by workgroup 0 at the end of every launch
     unsigned * err;            // host-visible error word (bounded waits)
+    int delay;                 // s_sleep units between a phase's start and its first look at a register hand-off (MI355X_CHAIN_DELAY): a poll that samples before
+                               // the slowest producer's stores are visible comes back empty and costs a whole fabric round trip under everybody's polling
 };
 
 // ---- small helpers ---------------------------------------------------------------------------------------------------------
@@ -601,7 +603,7 @@ __global__ void __launch_bounds__(CH_THREADS) matvec_chain_kernel(chain_params P
                 }
             }
         };
-        if (in_regs) issue_poll();
+        if (in_regs) { for (int i = 0; i < P.delay; i++) __builtin_amdgcn_s_sleep(1); issue_poll(); }
         f32x4 al[2], xm[2];
         u32x4 kq[2], vq[2];
         int at_slot = 0; float at_m = 0.f, at_rc = 1.f, at_rs = 0.f;
@@ -1216,6 +1218,10 @@ chain_plan * k_chain_create(hipStream_t s, const mv_args * mv, int n, void * ws,
     c->P.gbuf = (u64 *) (state + 256);
     c->P.cand = c->P.gbuf + 2 * CH_XF_MAX;
     c->P.err = err;
+    {
+        static const int delay = chain_env("MI355X_CHAIN_DELAY", 20);
+        c->P.delay = delay < 0 ? 0 : delay > 200 ? 200 : delay;
+    }
     c->smem = chain_smem();
     GGML_ASSERT(c->smem <= 160 * 1024);
     c->nest = allow_step_program && nest_build(c, nest_tab, nest_din, usable_cus);

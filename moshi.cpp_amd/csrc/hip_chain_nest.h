@@ -265,9 +265,13 @@ __global__ void __launch_bounds__(CH_THREADS) depth_nest_kernel(nest_params N) {
             acc = wave_allsum_f64(acc);
             if (lane == 0) ctl->sumsq[wave] = acc;
             nbar();
+            double sq[CH_NCW];   // (all eight read before the first add: one LDS round trip instead of four)
+#pragma unroll
+            for (int w = 0; w < CH_NCW; w += 2) { const double2 t = *(const double2 *) &ctl->sumsq[w]; sq[w] = t.x; sq[w + 1] = t.y; }
+            asm volatile("" : "+v"(sq[0]), "+v"(sq[1]), "+v"(sq[2]), "+v"(sq[3]), "+v"(sq[4]), "+v"(sq[5]), "+v"(sq[6]), "+v"(sq[7]));
             double tot = 0;
 #pragma unroll
-            for (int w = 0; w < CH_NCW; w++) tot += ctl->sumsq[w];
+            for (int w = 0; w < CH_NCW; w++) tot += sq[w];
             constexpr int K = NB * 256;
             static_assert(!RMS || (K & (K - 1)) == 0, "the mean is a product with 1 / K");
             const float mean = (float) (tot * (1.0 / (double) K));

@@ -15,11 +15,11 @@ static_assert(sizeof(xblk) == XBLK_BYTES && offsetof(xblk, bsums) == 256 && offs
 // quantise the 256 values held by one wave (4 per lane, contiguous) to a Q8_K block in LDS
 __device__ __forceinline__ void quantize_block_q8k(xblk * dst, const float v[4], int lane) {
     // the signed value of largest magnitude (ggml: iscale = -127 / max); when +a and -a tie the sign is immaterial
+    // (the sign comes from one ballot instead of a second wave-wide maximum: the largest signed value equals amax exactly when some element IS +amax)
     float amax = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
-    float smax = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
+    const float smax = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
     amax = wave_allmax_f32(amax);
-    smax = wave_allmax_f32(smax);
-    const float mx = smax == amax ? amax : -amax;
+    const float mx = __ballot(smax == amax) != 0ull ? amax : -amax;
     int q[4] = { 0, 0, 0, 0 };
     float d = 0.f;
     if (amax != 0.f) {
