@@ -1121,7 +1121,12 @@ static bool nest_build(chain_plan * c, char * tables_dev, char * din_dev, int us
         if (st[0].kind != 1 || st[0].x != d0.x || !st[0].save || st[0].res || (s == 0 && st[0].emb_chain)) return nest_no(4);
         for (int l = 0; l < L; l++)
             for (int i = 0; i < 4; i++) if (st[1 + 4 * l + i].kind != 2 + i) return nest_no(5);
-        if (st[per - 1].kind != 6) return nest_no(6);
+        {   // linears[k]: with the arg-max epilogue (greedy), or as plain logits for a sampler launch behind the run (temp > 0: one step per run)
+            const chain_phase & hd = st[per - 1];
+            const bool plain_head = hd.kind == 0 && hd.K == 1024 && hd.M == 2048 && hd.prologue == MV_PLAIN && hd.x_chain && !hd.res && !hd.emb.table && !hd.argmax &&
+                                    hd.n_pub == 0 && !hd.pair_F && hd.rows_wg == 8 && hd.row_bytes == 4 * 144 && S == 1;
+            if (hd.kind != 6 && !plain_head) return nest_no(6);
+        }
         if (s > 0 && !st[0].emb_chain) return nest_no(7);   // (a head's arg-max inside the run is consumed by the next step)
         for (int l = 0; l < L; l++) {
             const chain_phase & op = st[1 + 4 * l + 1], & lo = st[1 + 4 * l + 3];
@@ -1172,6 +1177,7 @@ static bool nest_build(chain_plan * c, char * tables_dev, char * din_dev, int us
     N.P = c->P;
     N.tables = (const u32x4 *) tables_dev;
     N.n_steps = S; N.n_layers = L;
+    N.head_argmax = c->phases[(size_t) per - 1].argmax;
     N.din_buf = (u64 *) din_dev; N.din_x = d0.x;
     const chain_phase & o0 = c->phases[2];
     N.q_off = o0.q_off; N.k_off = o0.k_off; N.v_off = o0.v_off;

@@ -31,6 +31,7 @@ struct nest_params {
     chain_params P;                         // hand-off buffers, launch counter, error word (phases / n_phases unused)
     const u32x4 * tables;                   // device: nest_ph[n_steps * (4 L + 1)] | nest_at[n_steps * L] | nest_st[n_steps]
     int n_steps, n_layers;
+    int head_argmax;                        // 0: linears[k] ends the run as plain logits (a sampler launch follows: temp > 0, one step per run)
     u64 * din_buf;                          // [n_steps][1024] granules: the hoisted depformer_in products
     const float * din_x;                    // transformer_out (lm.h:434), x of every depformer_in
     // the attention's shape, the same in every layer and step (checked when the plan is made)
@@ -603,14 +604,16 @@ __global__ void __launch_bounds__(CH_THREADS) depth_nest_kernel(nest_params N) {
             float best = -INFINITY; int bi = -1;
             rowsum(shape_head(), 0, p, ph.y, best, bi);
             CH_STAMP(8);
-            am_wave(best, bi);
-            if (lane == 0) { ctl->am_v[wave] = best; ctl->am_i[wave] = bi; }
-            nbar();
-            if (tid == 0) {
-                for (int w = 1; w < CH_NCW; w++) am_merge(best, bi, ctl->am_v[w], ctl->am_i[w]);
-                u64 * c = P.cand + (size_t) (p & 1) * 2 * grid + 2 * wg;
-                st_granule(c, tag_base | (unsigned) (p + 1), __float_as_uint(best));
-                st_granule(c + 1, tag_base | (unsigned) (p + 1), (unsigned) bi);
+            if (N.head_argmax) {
+                am_wave(best, bi);
+                if (lane == 0) { ctl->am_v[wave] = best; ctl->am_i[wave] = bi; }
+                nbar();
+                if (tid == 0) {
+                    for (int w = 1; w < CH_NCW; w++) am_merge(best, bi, ctl->am_v[w], ctl->am_i[w]);
+                    u64 * c = P.cand + (size_t) (p & 1) * 2 * grid + 2 * wg;
+                    st_granule(c, tag_base | (unsigned) (p + 1), __float_as_uint(best));
+                    st_granule(c + 1, tag_base | (unsigned) (p + 1), (unsigned) bi);
+                }
             }
             CH_STAMP(9);
             p = __builtin_amdgcn_readfirstlane(p + 1);
@@ -618,7 +621,7 @@ __global__ void __launch_bounds__(CH_THREADS) depth_nest_kernel(nest_params N) {
     }
 
     // the run ends in an arg-max: workgroup 0 merges the candidates and writes the token
-    if (wg == 0 && wave == 0) {
+    if (wg == 0 && wave == 0 && N.head_argmax) {
         const nest_st st = ld_st(N.n_steps - 1);
         int token = 0;
         if (gather_token(cb, (unsigned) ((p - 1) & 1) * (2u * (unsigned) grid * 8u), grid, tag_base | (unsigned) p, lane, ctl, token)) {

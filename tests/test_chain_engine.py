@@ -92,14 +92,21 @@ def test_small_width_runs_between_attention_launches_are_chained_too():
     assert_bit_identical(plain, chained, "tiny")
 
 
-def test_sampled_mode_chains_each_step_separately():
-    # temp > 0: a sampler launch sits between the steps, so each step is a chain of its own that ends in plain logits
+@pytest.mark.parametrize("which", ["real_width", "moshika"])
+def test_sampled_mode_chains_each_step_separately(which):
+    # temp > 0: a sampler launch sits between the steps, so each step is a chain of its own that ends in plain logits. At moshika's sizes each of those
+    # one-step runs takes the step program (its linears[k] then leaves plain logits, hip_chain_nest.h); flag 1024 keeps the descriptor-driven kernel
     import ctypes
     libc = ctypes.CDLL(None)
-    cfg = depth_at_real_width(dep_q=3, layers=1, n_q=6)
+    if which == "moshika":
+        cfg = hu.hot.moshika(hu.L)
+        cfg.num_layers, cfg.context = 2, 64
+        cfg.enable_mimi_encoder = cfg.enable_mimi_decoder = 0
+    else:
+        cfg = depth_at_real_width(dep_q=3, layers=1, n_q=6)
     cfg.temp, cfg.temp_text, cfg.top_k, cfg.top_k_text = 0.8, 0.7, 20, 10
     out = {}
-    for flags in (32, 16):
+    for flags in (32, 16) + ((32 | 1024,) if which == "moshika" else ()):
         m = hu.Model("hip", cfg, seed=0, flags=flags)
         rng = np.random.default_rng(7)
         rec = []
@@ -111,6 +118,9 @@ def test_sampled_mode_chains_each_step_separately():
         m.free()
     assert out[32][1].chained_matvecs_in_last_plan > 0
     assert_bit_identical(out[16][0], out[32][0], "sampled")
+    if which == "moshika":
+        assert out[32][1].chain_step_programs_in_last_plan == cfg.dep_q and out[32 | 1024][1].chain_step_programs_in_last_plan == 0
+        assert_bit_identical(out[32 | 1024][0], out[32][0], "sampled (descriptor-driven chain vs step program)")
 
 
 CHILD = r"""
