@@ -102,9 +102,11 @@ def main():
                     "text temperature 0.7, top-k 250 / 25) instead of greedy; host rand() noise uploaded per compute as src/context.h:456-480 does")
     ap.add_argument("--serial", action="store_true", help="the frame loop on ONE command stream (encode -> LM -> decode of the same frame, each waited for). Default: the same "
                     "graphs software-pipelined over two HIP streams (LM of frame k beside decode of k - 1 and encode of k + 1; identical tokens and PCM)")
-    ap.add_argument("--shard", default="none", choices=["none", "depth"],
+    ap.add_argument("--shard", default="none", choices=["none", "depth", "temporal"],
                     help="depth: ONE stream, the Depth transformer's per-codebook weight sets sharded over the ranks (SURVEY.md 8e: step k on rank k %% N, "
-                         "K/V rows + token broadcast per step over RCCL); strong scaling. Default: independent stream replicas (weak scaling)")
+                         "K/V rows + token broadcast per step over RCCL); temporal: ONE stream, every Temporal layer split over the ranks (SURVEY.md 8f.2: heads / "
+                         "KV ring / FFN units by rank, 2 all-reduces of F32[dim] per layer over RCCL; embeddings, text head, Depth chain and codec on rank 0); "
+                         "both strong scaling. Default: independent stream replicas (weak scaling)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -187,10 +189,14 @@ def main():
     # run-ahead: the LM stream never waits for the host (include/moshi_hot.h); tts / stt shapes (text hook, no Depth) overlap their codec half only
     cfg.chain_depth = 2 if pipelined and args.model in ("moshika", "personaplex") else 0
     shard = None
+    if args.shard != "none" and args.model not in ("moshika", "personaplex"):
+        raise SystemExit("--shard %s: moshika / personaplex only" % args.shard)
     if args.shard == "depth":
-        if args.model not in ("moshika", "personaplex"):
-            raise SystemExit("--shard depth: moshika / personaplex only")
         cfg.dep_shard_world, cfg.dep_shard_rank, cfg.depth_only = world, rank, int(rank != 0)
+        if rank != 0:
+            cfg.enable_mimi_encoder = cfg.enable_mimi_decoder = 0
+    if args.shard == "temporal":
+        cfg.tp_world, cfg.tp_rank = world, rank
         if rank != 0:
             cfg.enable_mimi_encoder = cfg.enable_mimi_decoder = 0
     t0 = time.time()
@@ -203,6 +209,16 @@ def main():
         # GPU) the same C loop calls back into torch.distributed over host memory
         use_rccl = dist is None or dist.get_backend(dist_group) != "gloo"
         shard = shard_mod.DepthShard(L, m, cfg, rank, world, dist, group=dist_group, device=torch.device("cuda", dev_index) if use_rccl else None,
+                                     staged_device=None if use_rccl else torch.device("cuda", dev_index), backend=be)
+        if rank == 0:
+            shard.install()
+    if args.shard == "temporal":
+        from moshi_cpp_amd import shard as shard_mod
+        import torch
+        # the frame's Temporal half = embedding-sum graph -> broadcast of x -> 2 L + 1 segment graphs with 2 L all-reduces -> head graph, all behind the C-ABI
+        # (include/moshi_hot.h "FRAME mode"); workers sit in moshi_hot_tp_serve
+        use_rccl = dist is None or dist.get_backend(dist_group) != "gloo"
+        shard = shard_mod.TemporalTP(L, m, cfg, rank, world, dist, group=dist_group, device=torch.device("cuda", dev_index) if use_rccl else None,
                                      staged_device=None if use_rccl else torch.device("cuda", dev_index), backend=be)
         if rank == 0:
             shard.install()
@@ -271,7 +287,8 @@ def main():
     if shard is not None and rank != 0:
         # a Depth-only rank: serve the owner's frames (warm-up, timed region, phase pass) until it says stop; the owner's clock is the job's
         shard.serve()
-        hop_us = shard_hop_latency(shard, dist, dist_group, L, be)
+        if args.shard == "depth":
+            hop_us = shard_hop_latency(shard, dist, dist_group, L, be)
         reduce_max_time(dist, 0.0, group=dist_group)
         L.moshi_hot_free(m)
         dist.barrier()
@@ -300,6 +317,8 @@ def main():
 
     # algorithmic HBM bytes per frame: every weight byte once + the filled KV slots
     wb = [L.moshi_hot_weight_bytes(m, p) for p in range(5)]
+    if args.shard == "temporal" and world == 1:
+        wb[0] //= 2    # a one-rank tensor-parallel model holds the unsplit stack AND its (whole) slices; a frame streams the slices only
     n_fill_avg = min(cfg.context, args.context_fill + args.warmup + args.steps / 2.0)
     kv_bytes = 2 * cfg.num_layers * n_fill_avg * cfg.dim * 2
     emb_rows = (cfg.n_q + 1) * cfg.dim * 18 / 32 + cfg.dep_q * cfg.dep_dim * 18 / 32
@@ -324,7 +343,9 @@ def main():
                                   if pipelined and not cfg.chain_depth else "") or "software-pipelined over 2 HIP streams with run-ahead: the LM step of frame k is queued behind the one of frame k-1 (sampled tokens reach "
                                  "the next Temporal graph through device memory; the host reads them one step late), mimi decode of frame k-1 and mimi encode of frame k+1 "
                                  "run beside it; same graphs, inputs, states and outputs as the serial loop (--serial), one LM step + one encode + one decode per step" if pipelined else "serial: encode -> LM -> decode of one frame per step",
-                   "parallelism": ("Depth codebook shard: step k on rank k %% %d, replicated 8-slot ring, 1 + dep_q broadcasts per frame" % world) if shard is not None
+                   "parallelism": ("Depth codebook shard: step k on rank k %% %d, replicated 8-slot ring, 1 + dep_q broadcasts per frame" % world) if args.shard == "depth"
+                                  else ("tensor-parallel Temporal stack over %d rank(s): heads, KV ring and FFN units by rank, 1 broadcast + %d all-reduces of F32[%d] per frame; "
+                                        "embeddings, text head, Depth chain and codec on rank 0" % (world, 2 * cfg.num_layers, cfg.dim)) if args.shard == "temporal"
                                   else "independent stream replica per GPU" if world > 1 else "1 GPU",
                    "device": dev_desc},
         "realtime_factor": round(fps / (world if shard is None else 1) / 12.5, 1),
@@ -366,7 +387,15 @@ def main():
             # the figure an UNCHANGED reference tool gets (tools/moshi-sts.cpp:770-808 keeps its serial call order); `value` needs the restructured caller
             result["value_serial"] = result["serial_loop"]["value"]
 
-    if shard is not None:
+    if shard is not None and args.shard == "temporal":
+        shard.stop_workers()
+        reduce_max_time(dist, dt, group=dist_group)
+        result["shard"] = {"kind": "tensor-parallel Temporal stack (SURVEY.md 8f.2)", "ranks": world, "all_reduces_per_frame": 2 * cfg.num_layers,
+                           "all_reduce_bytes": int(cfg.dim * 4), "broadcasts_per_frame": 1, "broadcast_bytes": int((cfg.dim + 8) * 4), "transport": shard.transport,
+                           "stack_passes": int(L.moshi_hot_tp_frames(m)), "temporal_weight_bytes_this_rank": int(L.moshi_hot_weight_bytes(m, 0))}
+        args.no_roofline = True
+        args.no_cpu_baseline = True
+    elif shard is not None:
         shard.stop_workers()
         hop_us = shard_hop_latency(shard, dist, dist_group, L, be)
         reduce_max_time(dist, dt, group=dist_group)

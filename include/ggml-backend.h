@@ -149,6 +149,9 @@ GGML_API void ggml_backend_mi355x_set_flags(ggml_backend_t backend, int flags);
 GGML_API void ggml_backend_mi355x_set_capture(ggml_backend_t backend, int enabled);
 // HIP stream the backend launches on (void* = hipStream_t) so callers can bracket it with HIP events
 GGML_API void * ggml_backend_mi355x_get_stream(ggml_backend_t backend);
+// Makes the backend's HIP device current on the calling thread. A caller that talks to another HIP-based library itself on this backend's stream (RCCL:
+// ncclCommInitRank binds the communicator to the thread's CURRENT device) calls this first; the backend's own entry points never rely on the current device.
+GGML_API void ggml_backend_mi355x_make_current(ggml_backend_t backend);
 // A second command stream on the same GPU: a backend handle with its own HIP stream, upload queue and plan cache. Graphs submitted through it run
 // concurrently with those of `base` (the codec of neighbouring frames beside the LM step, moshi_hot.h "software-pipelined frame loop"); buffers
 // allocated through either handle are ordinary device memory usable by both - ordering between the two streams is the caller's (host round trips

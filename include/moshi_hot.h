@@ -204,6 +204,8 @@ GGML_API void    moshi_hot_depth_shard_tokens(moshi_hot_model_t * m, int32_t * o
 typedef void (*moshi_hot_bcast_t)(void * user, void * data, int64_t bytes, int root);
 GGML_API void    moshi_hot_depth_shard_set_transport(moshi_hot_model_t * m, moshi_hot_bcast_t fn, void * user);
 GGML_API int     moshi_hot_depth_shard_rccl_unique_id(char * id128);                                            // 0 = ok (rank 0)
+// _rccl_init makes the model's backend device current on the calling thread before ncclCommInitRank (the communicator binds to the current device) and
+// replaces a communicator an earlier call made; the broadcasts / all-reduces return RCCL's code through GGML_ASSERT (a failed collective is not recoverable here).
 GGML_API int     moshi_hot_depth_shard_rccl_init(moshi_hot_model_t * m, int rank, int world, const char * id128); // 0 = ok; every rank, collectively
 GGML_API void    moshi_hot_depth_shard_rccl_free(moshi_hot_model_t * m);
 GGML_API void    moshi_hot_depth_shard_broadcast(moshi_hot_model_t * m, int which, int root);                    // one broadcast of the step (0) / frame (1) message through the transport (latency probes)
@@ -226,6 +228,15 @@ typedef void (*moshi_hot_allreduce_t)(void * user, float * data, int64_t n_float
 GGML_API void    moshi_hot_tp_set_transport(moshi_hot_model_t * m, moshi_hot_allreduce_t fn, void * user);
 GGML_API void    moshi_hot_tp_stack(moshi_hot_model_t * m, const float * x, float * out);
 GGML_API int64_t moshi_hot_tp_reductions(moshi_hot_model_t * m);
+// The tensor-parallel stack as a FRAME mode (bench.py --shard temporal): on rank 0, after _install, the Temporal half of every moshi_hot_lm_step* is
+//   embedding-sum graph -> broadcast of x (F32[dim] + a "more frames" flag; ncclBroadcast on the backend's stream, or the function of
+//   moshi_hot_depth_shard_set_transport) -> the 2 L + 1 segments with their 2 L all-reduces -> out_norm / text head / sampler graph,
+// and the Depth graph follows on rank 0 as in any LM step (lm.h:555-607, 659-677 around transformer.h:910-971). Every other rank sits in _serve: it takes the
+// broadcast, runs its segments and joins the all-reduces until rank 0 calls _stop. Models are created with tp_world = N (>= 1), tp_rank, chain_depth = 0.
+GGML_API void    moshi_hot_tp_install(moshi_hot_model_t * m);
+GGML_API int64_t moshi_hot_tp_serve(moshi_hot_model_t * m);     // returns the frames served
+GGML_API void    moshi_hot_tp_stop(moshi_hot_model_t * m);
+GGML_API int64_t moshi_hot_tp_frames(moshi_hot_model_t * m);    // stack passes this rank has run in frame mode
 GGML_API void    moshi_hot_tp_msg_read(moshi_hot_model_t * m, float * out);        // the partial-sum message, host copy out / in: lets ONE process sum the
 GGML_API void    moshi_hot_tp_msg_write(moshi_hot_model_t * m, const float * in);   // partials of several ranks' models (tests without a second GPU)
 // replaces the local chained Depth graph inside moshi_hot_lm_step_n: fn(user, text_token, audio[dep_q]) must fill all dep_q tokens

@@ -138,6 +138,7 @@ SIGNATURES = {
     "ggml_backend_graph_compute": (I, [P, P]), "ggml_backend_supports_op": (B, [P, TP]),
     "ggml_backend_mi355x_get_stats": (None, [P, C.POINTER(Stats)]), "ggml_backend_mi355x_set_flags": (None, [P, I]), "ggml_backend_mi355x_set_capture": (None, [P, I]),
     "ggml_backend_mi355x_get_stream": (P, [P]),
+    "ggml_backend_mi355x_make_current": (None, [P]),
     "ggml_backend_mi355x_init_stream": (P, [P]),
     "ggml_backend_tensor_get_async": (None, [P, TP, P, Z, Z]),
     "ggml_backend_event_new": (P, [P]), "ggml_backend_event_free": (None, [P]), "ggml_backend_event_record": (None, [P, P]),

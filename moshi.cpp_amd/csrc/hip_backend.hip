@@ -100,9 +100,11 @@ static void ctx_init_lazy(hip_ctx * c) {
         hipDeviceProp_t prop;
         HIP_CHECK(hipGetDeviceProperties(&prop, c->device));
         c->usable_cus = prop.multiProcessorCount;
-        // MI355X_STREAM_CUS=n: confine this backend's stream to n compute units, spread round-robin over the XCDs (hipExtStreamCreateWithCUMask) - the shape
-        // of a CU-masked or partitioned deployment. Kernels whose workgroups wait for each other (persistent chains, the fused attention + out_proj launch,
-        // split attention) are planned against this number and fall back to plain launches when their grid cannot be resident (build_plan).
+        // MI355X_STREAM_CUS=n: confine this backend's stream to n compute units (hipExtStreamCreateWithCUMask with bits 0 .. n - 1 of the mask set; which
+        // physical CUs / XCDs those bits name is the runtime's mapping and is not assumed here) - the shape of a CU-masked or partitioned deployment. Kernels
+        // whose workgroups wait for each other (persistent chains, the fused attention + out_proj launch, split attention) are planned against this NUMBER
+        // and fall back to plain launches when their grid cannot be resident (build_plan). Unlike the default stream below, a CU-masked stream is created
+        // WITHOUT hipStreamNonBlocking (the call takes no flags): it synchronises implicitly with the NULL stream - a diagnostic / test shape, not a fast path.
         const char * e = getenv("MI355X_STREAM_CUS");
         const int lim = e ? atoi(e) : 0;
         if (lim > 0 && lim < prop.multiProcessorCount) {
@@ -1769,13 +1771,19 @@ static plan_t * build_plan(hip_ctx * c, ggml_cgraph * g, bool keep = true) {
                     if (ag.emit_pos < 0 || at.q != a.y || ag.emit_pos < grp.emit_pos) continue;
                     if (!k_inproj_attn_supported(a, at, c->usable_cus)) continue;
                     // every reader of the projection's output must be inside the attention block
+                    // (followed through layout-only nodes - a view / reshape / permute / transpose of the output is the output: a reader of such an alias that is
+                    // not part of the attention block would run before the deferred projection has written anything)
                     bool private_y = true;
-                    const ggml_tensor * ynode = g->nodes[i];
+                    std::vector<const ggml_tensor *> aliases { g->nodes[i] };
                     for (int j = i + 1; j < g->n_nodes && private_y; j++) {
                         const ggml_tensor * nj = g->nodes[j];
                         bool reads = false;
-                        for (int sidx = 0; sidx < GGML_MAX_SRC; sidx++) if (nj->src[sidx] == ynode) reads = true;
-                        if (reads && std::find(ag.members.begin(), ag.members.end(), j) == ag.members.end()) private_y = false;
+                        for (int sidx = 0; sidx < GGML_MAX_SRC; sidx++)
+                            if (nj->src[sidx] && std::find(aliases.begin(), aliases.end(), nj->src[sidx]) != aliases.end()) reads = true;
+                        if (!reads) continue;
+                        const bool layout = nj->op == GGML_OP_VIEW || nj->op == GGML_OP_RESHAPE || nj->op == GGML_OP_PERMUTE || nj->op == GGML_OP_TRANSPOSE;
+                        if (layout) { aliases.push_back(nj); continue; }
+                        if (std::find(ag.members.begin(), ag.members.end(), j) == ag.members.end()) private_y = false;
                     }
                     if (!private_y || !spin_kernels_allowed(c)) continue;
                     const mv_args am = a; const attn_args aa = at;
@@ -2208,6 +2216,9 @@ extern "C" void ggml_backend_mi355x_get_kernel_profile(ggml_backend_t b, struct 
     out->chain_seconds = c->prof_chain_seconds; out->chain_launches = c->prof_chain_launches; out->chain_bytes = c->prof_chain_bytes; out->chain_phases = c->prof_chain_phases;
 }
 extern "C" void * ggml_backend_mi355x_get_stream(ggml_backend_t b) { hip_ctx * c = ctx_of(b); ctx_init_lazy(c); return (void *) c->stream; }
+// makes the backend's HIP device the calling thread's current one (what a caller that drives another HIP library itself - RCCL's ncclCommInitRank binds the
+// communicator to the CURRENT device - needs before it; the backend's own entry points do this internally)
+extern "C" void ggml_backend_mi355x_make_current(ggml_backend_t b) { hip_ctx * c = ctx_of(b); ctx_init_lazy(c); set_device(c); }
 extern "C" ggml_backend_t ggml_backend_mi355x_init_stream(ggml_backend_t base) {
     if (!base || base->iface.get_name != hip_backend_name) return NULL;   // any other backend: the caller keeps using `base`
     hip_ctx * b0 = (hip_ctx *) base->context;

@@ -76,10 +76,12 @@ struct chain_phase {
     int n_pub;                 // values handed to the next phase: 0, M, or pair_F
     int n_in;                  // values the previous phase handed on
     int kind;                  // 0: shape read from this descriptor; 1..6: one of the compile-time shapes (shape_din .. shape_head)
+    int fmt;                   // weight blocks: 0 Q4_K super-blocks (144 B / 256 weights, Q8_K activations), 1 Q8_0 (eight 34-byte blocks = 272 B / 256 weights, Q8_0 activations)
+    int pad_[3];
     int32_t * prev_out[2];     // emb_chain: where the previous phase's merged arg-max (the token) is stored
     attn_args at;              // MV_ATTN: the attention whose output is x
 };
-static_assert(sizeof(chain_phase) % 16 == 0 && sizeof(chain_phase) <= 26 * 16, "a descriptor is staged through LDS by 16-byte lanes");
+static_assert(sizeof(chain_phase) % 16 == 0 && sizeof(chain_phase) <= 27 * 16, "a descriptor is staged through LDS by 16-byte lanes");
 #define CH_DESC_DWORDS ((int) (sizeof(chain_phase) / 4))
 
 struct chain_params {
@@ -491,14 +493,14 @@ __global__ void __launch_bounds__(CH_THREADS) matvec_chain_kernel(chain_params P
 #define CH_LD(d, base, f) (d).f = desc_field<typename std::remove_reference<decltype((d).f)>::type>(base, (int) (offsetof(chain_phase, f) / 4))
     auto read_desc_weights = [&](int q, chain_phase & d) {   // what request_weights needs
         const unsigned * b = desc + (q % 3) * CH_DESC_DWORDS;
-        CH_LD(d, b, w); CH_LD(d, b, row_bytes); CH_LD(d, b, M); CH_LD(d, b, nb); CH_LD(d, b, rows_wg); CH_LD(d, b, pair_F);
+        CH_LD(d, b, w); CH_LD(d, b, row_bytes); CH_LD(d, b, M); CH_LD(d, b, nb); CH_LD(d, b, rows_wg); CH_LD(d, b, pair_F); CH_LD(d, b, fmt);
     };
     // head: what the prologue and the dot stage use; tail: what the epilogue uses, read where it starts (short-lived scalars: the kernel is at the
     // scalar-register limit, and a field kept from the head of the phase is a spill and a reload)
     auto read_desc = [&](int q, chain_phase & d) {
         const unsigned * b = desc + (q % 3) * CH_DESC_DWORDS;
         CH_LD(d, b, K); CH_LD(d, b, M); CH_LD(d, b, nb); CH_LD(d, b, rows_wg); CH_LD(d, b, pair_F); CH_LD(d, b, prologue); CH_LD(d, b, x_chain);
-        CH_LD(d, b, x); CH_LD(d, b, alpha); CH_LD(d, b, eps); CH_LD(d, b, n_in); CH_LD(d, b, emb_chain); CH_LD(d, b, argmax);
+        CH_LD(d, b, x); CH_LD(d, b, alpha); CH_LD(d, b, eps); CH_LD(d, b, n_in); CH_LD(d, b, emb_chain); CH_LD(d, b, argmax); CH_LD(d, b, fmt);
         if (d.prologue == MV_ATTN) {
             CH_LD(d, b, q_off); CH_LD(d, b, k_off); CH_LD(d, b, v_off);
             CH_LD(d, b, at.q_hs); CH_LD(d, b, at.k_hs); CH_LD(d, b, at.v_hs); CH_LD(d, b, at.rot); CH_LD(d, b, at.mask); CH_LD(d, b, at.index);
@@ -514,8 +516,34 @@ __global__ void __launch_bounds__(CH_THREADS) matvec_chain_kernel(chain_params P
     // The weights of ONE phase live in registers: pass ps covers super-blocks 64 ps .. 64 ps + 63 of the workgroup's rows, 8 lanes per super-block -
     // every lane of a group holds the 16-byte header (d, dmin, 6-bit scales: one fetch for the group) and its own 16-byte nibble chunk.
     constexpr int CH_PMAX = CH_PMAX_OF(G);
+    // Q8_0 (descriptor-driven phases only): 8 lanes per 272-byte chunk of 256 weights, lane j its own 34-byte block - d (F16) + 32 int8. The block starts
+    // 2 bytes off a dword for odd j, so the lane loads the 9 dwords from byte 34 j - (j odd ? 2 : 0) of the chunk (two 16-byte loads and one dword; dword
+    // alignment is all global loads need): wh = dwords 0..3, wq = 4..7, we = 8. Even j: d = low half of dword 0, q = bytes 2..33; odd j: d = high half
+    // of dword 0, q = dwords 1..8.
     u32x4 wh[CH_PMAX], wq[CH_PMAX];
+    uint32_t we[CH_PMAX];
     auto request_weights = [&](const chain_phase & pq) {   // that phase's super-blocks of this workgroup
+        if (pq.fmt == 1) {
+            const bool pr = pq.pair_F > 0;
+            const long long rt = pr ? pq.pair_F : (long long) pq.M;
+            const long long r0 = (long long) wg * pq.rows_wg;
+            const int rw = (int) (rt - r0 < pq.rows_wg ? (rt - r0 > 0 ? rt - r0 : 0) : pq.rows_wg);
+            const int nseg = rw * pq.nb, nall = pr ? 2 * nseg : nseg;
+            const GLOBAL_AS char * w0 = gp(pq.w) + r0 * pq.row_bytes, * w1 = gp(pq.w) + (r0 + pq.pair_F) * pq.row_bytes;
+            const int j = lane & 7, boff = 34 * j - ((j & 1) ? 2 : 0);
+#pragma unroll
+            for (int ps = 0; ps < CH_PMAX; ps++) {
+                if (ps * (CH_NCW * 8) < nall) {   // (wave-uniform)
+                    const int sb = ps * (CH_NCW * 8) + wave * 8 + (lane >> 3);
+                    const int sbc = sb < nall ? sb : nall - 1;
+                    const GLOBAL_AS char * src = (sbc < nseg ? w0 + (long long) sbc * 272 : w1 + (long long) (sbc - nseg) * 272) + boff;
+                    wh[ps] = __builtin_nontemporal_load((const GLOBAL_AS u32x4 *) src);
+                    wq[ps] = __builtin_nontemporal_load((const GLOBAL_AS u32x4 *) (src + 16));
+                    we[ps] = __builtin_nontemporal_load((const GLOBAL_AS uint32_t *) (src + 32));
+                }
+            }
+            return;
+        }
         const bool pr = pq.pair_F > 0;
         const long long rt = pr ? pq.pair_F : (long long) pq.M;
         const long long r0 = (long long) wg * pq.rows_wg;
@@ -701,7 +729,7 @@ __global__ void __launch_bounds__(CH_THREADS) matvec_chain_kernel(chain_params P
 #pragma unroll
             for (int r = 0; r < 2; r++) {
                 const int b = wave + r * CH_NCW;
-                if (b < nb) quantize_block_q8k(xs + b, v[r], lane);
+                if (b < nb) { if (!SH::S && ph.fmt == 1) quantize_block_q80((xblk80 *) (xs + b), v[r], lane); else quantize_block_q8k(xs + b, v[r], lane); }
             }
         }
         if (stage_next && lane < DL) ((u32x4 *) (desc + ((p + 1) % 3) * CH_DESC_DWORDS))[lane] = next_desc;
@@ -711,6 +739,35 @@ __global__ void __launch_bounds__(CH_THREADS) matvec_chain_kernel(chain_params P
 
         // ---- stage 2: super-block dots out of the registers (the WS = 1 arithmetic of matvec_q4k_kernel: 8 lanes per super-block)
         {
+            if (!SH::S && ph.fmt == 1) {
+                // Q8_0: lane j dots its 32-wide block against the activation's block j (vec_dot_q8_0_q8_0: sumi * (d_w * d_x)); the chunk's eight terms are
+                // then added in block order, starting from 0 - q80_q80_sb_dot's float sequence - by the group's first lane through row-shift DPP reads
+#pragma unroll
+                for (int ps = 0; ps < CH_PMAX; ps++) {
+                    if (ps * (CH_NCW * 8) >= nblk) break;
+                    const int sb = ps * (CH_NCW * 8) + wave * 8 + (lane >> 3);
+                    const int sbc = sb < nblk ? sb : nblk - 1;
+                    const int j8 = lane & 7;
+                    const bool odd = (j8 & 1) != 0;
+                    const xblk80 * xb = (const xblk80 *) (xs + (sbc % nb));
+                    const uint32_t D[9] = { wh[ps].x, wh[ps].y, wh[ps].z, wh[ps].w, wq[ps].x, wq[ps].y, wq[ps].z, wq[ps].w, we[ps] };
+                    const float dw = h2f((uint16_t) (odd ? (D[0] >> 16) : (D[0] & 0xffff)));
+                    const u32x4 y0 = *(const u32x4 *) (xb->q + 32 * j8), y1 = *(const u32x4 *) (xb->q + 32 * j8 + 16);
+                    const uint32_t y[8] = { y0.x, y0.y, y0.z, y0.w, y1.x, y1.y, y1.z, y1.w };
+                    int sumi = 0;
+#pragma unroll
+                    for (int t = 0; t < 8; t++) {
+                        const uint32_t qd = odd ? D[t + 1] : __builtin_amdgcn_alignbyte(D[t + 1], D[t], 2);
+                        sumi = dot4_i8((int) qd, (int) y[t], sumi);
+                    }
+                    const float term = (float) sumi * (dw * xb->d[j8]);
+                    float sumf = 0.f;
+                    sumf += term;
+                    sumf += dpp_f32<0x101>(term); sumf += dpp_f32<0x102>(term); sumf += dpp_f32<0x103>(term); sumf += dpp_f32<0x104>(term);
+                    sumf += dpp_f32<0x105>(term); sumf += dpp_f32<0x106>(term); sumf += dpp_f32<0x107>(term);
+                    if (j8 == 0 && sb < nblk) part[sb] = sumf;
+                }
+            } else
 #pragma unroll
             for (int ps = 0; ps < CH_PMAX; ps++) {
                 if (ps * (CH_NCW * 8) >= nblk) break;
@@ -927,6 +984,7 @@ static bool overlaps(const void * a, size_t an, const void * b, size_t bn) {
 // the run writes must travel by one of the in-launch mechanisms (hand-off vector, kept rows, arg-max candidates) or the run is cut there.
 static int chain_analyse(const mv_args * mv, int n, int G, std::vector<chain_phase> & out, std::vector<attn_args> & attns) {
     out.clear(); attns.clear();
+    static const int q80_on = chain_env("MI355X_CHAIN_Q80", 1);
     std::vector<int> res_from;   // phase whose rows a phase adds as its residual (-1: none / memory)
     auto ybytes = [&](int j) { return (size_t) out[(size_t) j].M * 4; };
     for (int i = 0; i < n && i < CH_MAX_PHASES; i++) {   // (the hand-off tag keeps 12 bits for the phase index + 1)
@@ -934,9 +992,11 @@ static int chain_analyse(const mv_args * mv, int n, int G, std::vector<chain_pha
         chain_phase ph;
         memset(&ph, 0, sizeof(ph));
         // ---- the mat-vec itself
-        if (a.wtype != GGML_TYPE_Q4_K || a.ncols != 1 || a.K % 256 != 0 || a.K > 4096 || a.pair_F != 0 || a.x_out || a.out_scale || a.out_act) break;
+        if ((a.wtype != GGML_TYPE_Q4_K && a.wtype != GGML_TYPE_Q8_0) || a.ncols != 1 || a.K % 256 != 0 || a.K > 4096 || a.pair_F != 0 || a.x_out || a.out_scale || a.out_act) break;
         if (!a.ticket && (a.argmax_out[0] || a.argmax_out[1])) break;
-        if (a.row_bytes != (a.K / 256) * 144 || ((uintptr_t) a.w & 15)) break;
+        if (a.row_bytes != (a.K / 256) * (a.wtype == GGML_TYPE_Q8_0 ? 272 : 144) || ((uintptr_t) a.w & 15)) break;
+        if (a.wtype == GGML_TYPE_Q8_0 && !q80_on) break;
+        ph.fmt = a.wtype == GGML_TYPE_Q8_0 ? 1 : 0;
         if (!(a.prologue == MV_PLAIN || a.prologue == MV_RMSNORM || a.prologue == MV_GATE_SILU || a.prologue == MV_ATTN)) break;
         if ((a.M * (a.K / 256) + 63) / 64 > 512) break;   // the large matrices keep their own LDS-tile kernel
         ph.w = a.w; ph.row_bytes = a.row_bytes; ph.K = (int) a.K; ph.M = (int) a.M; ph.nb = (int) (a.K / 256);
@@ -1051,6 +1111,13 @@ int k_chain_accept(const mv_args * mv, int n, int usable_cus) {
     if (G <= 0) return 0;   // the grid cannot be resident on this device / stream: one launch per mat-vec
     std::vector<chain_phase> ph; std::vector<attn_args> at;
     const int len = chain_analyse(mv, n, G, ph, at);
+    // Q8_0 runs pay off only when long: the four-phase runs between two attention LAUNCHES of the tts-shaped Depth transformer (32-slot ring: its attention
+    // is not recomputed inside out_proj) measured slower as chains than as launches - 198 vs 222 frames/s, the resident grid also starves the codec stream
+    // beside it (profiles/r05_ab_q8_0_chain_tts.txt). Whole Depth steps (short ring, attention inside the chain) are taken.
+    static const int min_q80 = chain_env("MI355X_CHAIN_MIN_Q80", 12);
+    bool any_q80 = false;
+    for (int i = 0; i < len; i++) any_q80 = any_q80 || ph[(size_t) i].fmt == 1;
+    if (any_q80 && len < min_q80) return 0;
     return len >= min_len ? len : 0;
 }
 
@@ -1072,7 +1139,7 @@ template <class SH> static bool shape_is(const chain_phase & ph, int grid) {
     return ph.K == SH::K && ph.M == SH::M && ph.pair_F == SH::PAIR && ph.prologue == SH::PRO && ph.x_chain == SH::XCH && ph.res == SH::RES &&
            (ph.emb.table != nullptr) == (SH::EMB != 0) && ph.save <= SH::SAVE && ph.argmax == SH::AM && ph.n_pub == SH::PUB &&
            rows_total % grid == 0 && ph.rows_wg == rows_total / grid && ph.n_in == (SH::XCH ? (SH::PRO == MV_ATTN ? 3 * SH::K : SH::K) : ph.n_in) &&
-           ph.row_bytes == (SH::K / 256) * 144;
+           ph.row_bytes == (SH::K / 256) * 144 && ph.fmt == 0;
 }
 static int chain_shape_kind(const chain_phase & ph, int grid) {
     static const int on = chain_env("MI355X_CHAIN_SHAPES", 0x7e);   // bit k: phase kind k may use its compile-time shape

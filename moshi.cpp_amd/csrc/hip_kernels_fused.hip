@@ -96,29 +96,6 @@ template <int FMT> struct mvfmt;
 template <> struct mvfmt<MVF_Q4K> { static constexpr int SB = 144, NLOAD = 9; };    // f16 d, f16 dmin, 12 B scales, 128 B nibbles
 template <> struct mvfmt<MVF_Q80> { static constexpr int SB = 272, NLOAD = 17; };   // 8 x (f16 d, 32 int8)
 template <> struct mvfmt<MVF_Q40> { static constexpr int SB = 144, NLOAD = 9; };    // 8 x (f16 d, 16 B nibbles)
-struct xblk80 { int8_t q[256]; float d[8]; int16_t bsums[8]; };   // d = the F16-rounded scale of each 32-wide block, bsums = sum of its q
-static_assert(sizeof(xblk80) == XBLK_BYTES, "xblk80 layout");
-
-// quantise the 256 values held by one wave (4 per lane, contiguous) to eight Q8_0 blocks in LDS (quantize_row_q8_0_ref:
-// d = amax / 127, q = roundf(x / d), d stored as F16)
-__device__ __forceinline__ void quantize_block_q80(xblk80 * dst, const float v[4], int lane) {
-    float amax = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
-    amax = fmaxf(amax, dpp_f32<DPP_QUAD_XOR1>(amax));
-    amax = fmaxf(amax, dpp_f32<DPP_QUAD_XOR2>(amax));
-    amax = fmaxf(amax, dpp_f32<DPP_HALF_MIRROR>(amax));   // the 8 lanes of one 32-wide block
-    const float d = amax / 127.f;
-    const float id = d != 0.f ? 1.0f / d : 0.0f;
-    int q[4];
-#pragma unroll
-    for (int k = 0; k < 4; k++) q[k] = (int) roundf(v[k] * id);
-    *(uint32_t *) (dst->q + lane * 4) = (uint32_t) (q[0] & 0xff) | ((uint32_t) (q[1] & 0xff) << 8) | ((uint32_t) (q[2] & 0xff) << 16) | ((uint32_t) (q[3] & 0xff) << 24);
-    int s = q[0] + q[1] + q[2] + q[3];
-    s += dpp_i32<DPP_QUAD_XOR1>(s);
-    s += dpp_i32<DPP_QUAD_XOR2>(s);
-    s += dpp_i32<DPP_HALF_MIRROR>(s);
-    if ((lane & 7) == 0) { dst->d[lane >> 3] = h2f(f2h(d)); dst->bsums[lane >> 3] = (int16_t) s; }
-}
-
 // dword `i` of a byte stream that starts 2 bytes into a 4-byte-aligned image (D = the aligned dwords)
 __device__ __forceinline__ uint32_t dword_at2(const uint32_t * D, int byte_off) {
     const int i = byte_off >> 2;
@@ -2492,6 +2469,10 @@ bool k_inproj_attn_supported(const mv_args & a, const attn_args & at, int usable
     if ((seg_rows * nb) % 64 != 0 || 3 * seg_rows * nb > 4096 || (at.D % seg_rows) != 0 || (seg_rows & 1)) return false;   // whole tiles per segment; a part holds whole RoPE pairs of ONE head
     // q | k | v are the three H x D segments of y, head-major, one token
     if (at.q != a.y || at.k != a.y + HD || at.v != a.y + 2 * HD || at.q_hs != at.D || at.k_hs != at.D || at.v_hs != at.D) return false;
+    // a ring the stand-alone kernel would split over workgroups (C >= ATTN_SPLIT_MIN_C) but the merged launch cannot (fold_use_split: more than 2 x S x slots,
+    // or an MI355X_FOLD_SLOTS / head-count combination that fails its test) would run here as ONE workgroup per head scanning the whole ring while the other
+    // 224 leave - correct, and a silent long-context slowdown: such rings keep the separate split attention launch
+    if (attn_use_split(at) && !fold_use_split(at)) return false;
     const size_t smem = inproj_attn_smem(a, at, seg_rows);
     if (smem > 160 * 1024) return false;
     const void * fn = fold_use_split(at) ? (const void *) inproj_attn_kernel<true> : (const void *) inproj_attn_kernel<false>;

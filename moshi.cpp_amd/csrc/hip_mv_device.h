@@ -33,3 +33,28 @@ __device__ __forceinline__ void quantize_block_q8k(xblk * dst, const float v[4],
     if ((lane & 3) == 0) dst->bsums[lane >> 2] = (int16_t) s4;
     if (lane == 0) dst->d = d;
 }
+
+// Q8_0 activations of the same 304-byte record (weights Q8_0 / Q4_0: ggml quantises the activation row to Q8_0 - 32-wide blocks, F16 scale)
+struct xblk80 { int8_t q[256]; float d[8]; int16_t bsums[8]; };   // d = the F16-rounded scale of each 32-wide block, bsums = sum of its q
+static_assert(sizeof(xblk80) == XBLK_BYTES, "xblk80 layout");
+
+// quantise the 256 values held by one wave (4 per lane, contiguous) to eight Q8_0 blocks in LDS (quantize_row_q8_0_ref:
+// d = amax / 127, q = roundf(x / d), d stored as F16)
+__device__ __forceinline__ void quantize_block_q80(xblk80 * dst, const float v[4], int lane) {
+    float amax = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
+    amax = fmaxf(amax, dpp_f32<DPP_QUAD_XOR1>(amax));
+    amax = fmaxf(amax, dpp_f32<DPP_QUAD_XOR2>(amax));
+    amax = fmaxf(amax, dpp_f32<DPP_HALF_MIRROR>(amax));   // the 8 lanes of one 32-wide block
+    const float d = amax / 127.f;
+    const float id = d != 0.f ? 1.0f / d : 0.0f;
+    int q[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) q[k] = (int) roundf(v[k] * id);
+    *(uint32_t *) (dst->q + lane * 4) = (uint32_t) (q[0] & 0xff) | ((uint32_t) (q[1] & 0xff) << 8) | ((uint32_t) (q[2] & 0xff) << 16) | ((uint32_t) (q[3] & 0xff) << 24);
+    int s = q[0] + q[1] + q[2] + q[3];
+    s += dpp_i32<DPP_QUAD_XOR1>(s);
+    s += dpp_i32<DPP_QUAD_XOR2>(s);
+    s += dpp_i32<DPP_HALF_MIRROR>(s);
+    if ((lane & 7) == 0) { dst->d[lane >> 3] = h2f(f2h(d)); dst->bsums[lane >> 3] = (int16_t) s; }
+}
+

@@ -18,6 +18,7 @@
 #include <deque>
 #include <functional>
 #include <map>
+#include <set>
 #include <string>
 #include <vector>
 
@@ -138,6 +139,7 @@ struct Weights {
     struct pending { T t; std::function<void(T, Rng &, std::vector<uint8_t> &)> gen; std::string name; };
     std::vector<pending> todo;
     std::map<std::string, T> by_name;
+    std::set<std::string> file_names;   // the names as a GGUF file carries them (file_name): unique, checked in add()
     size_t bytes[5] = { 0, 0, 0, 0, 0 };
     int part = 0;
 
@@ -171,7 +173,12 @@ struct Weights {
 
     T add(const std::string & name, enum ggml_type type, int64_t n0, int64_t n1, int64_t n2, std::function<void(T, Rng &, std::vector<uint8_t> &)> gen) {
         T t = ggml_new_tensor_3d(ctx, type, n0, n1, n2);
-        ggml_set_name(t, file_name(name).c_str());
+        const std::string fname = file_name(name);
+        // The reference keeps 16 bits of the CRC (loader.h:128-135), so two names of >= GGML_MAX_NAME characters share a file name once in 65 536 pairs:
+        // gguf_add_tensor refuses a duplicate name and ggml_get_tensor could not tell the two apart - fail here, by name, rather than at save time
+        if (!file_names.insert(fname).second)
+            GGML_ABORT("moshi_hot: tensor '%s' has the same GGUF name '%s' as an earlier tensor (the reference's 16-bit digest of long names collides)", name.c_str(), fname.c_str());
+        ggml_set_name(t, fname.c_str());
         todo.push_back({ t, gen, name });
         by_name[name] = t;   // full checkpoint name (ggml names are cut to GGML_MAX_NAME, which makes encoder/decoder tails collide)
         bytes[part] += ggml_nbytes(t);
@@ -234,9 +241,8 @@ void Weights::load_gguf() {
     const int n_tensors = (int) gguf_get_n_tensors(gg);
     std::vector<uint8_t> data;
     int found = 0;
-    // Only the tensors this load still has to fill count (tensor-parallel slices were cut from generated matrices above and are not in `todo`). Two long
-    // names can share a digest (the reference keeps 16 bits of the CRC, loader.h:128-135): tensors of one file name are then taken in file order,
-    // which is the order gguf_add_tensor saw them in, i.e. `todo` order - the round trip of a file written from this context stays exact.
+    // Only the tensors this load still has to fill count (tensor-parallel slices were cut from generated matrices above and are not in `todo`). File names
+    // are unique inside a model (Weights::add refuses the 1-in-65 536 case of two long names sharing the reference's 16-bit digest, loader.h:128-135).
     std::map<std::string, std::deque<T>> want;
     for (auto & p : todo) want[ggml_get_name(p.t)].push_back(p.t);
     for (int i = 0; i < n_tensors; i++) {
@@ -754,6 +760,8 @@ struct moshi_hot_model {
     int64_t tp_reductions = 0;
     // tensor-parallel Temporal stack (moshi_hot.h): this rank's sliced layers, the replicated stream x, the partial message, one graph per segment
     Transformer temporal_tp; T tp_x = nullptr, tp_msg = nullptr; std::vector<Builder *> g_tp;
+    // tensor-parallel FRAME mode (moshi_hot_tp_install): the Temporal half of an LM step = embedding-sum graph -> broadcast of x -> the stack above -> head graph
+    bool tp_frame = false; T tp_in = nullptr; Builder * g_tp_pre = nullptr, * g_tp_import = nullptr, * g_tp_post = nullptr; int64_t tp_frames = 0;
     // delay ring (lm.h:715-743)
     int offset = 0; std::vector<std::vector<int>> cache; std::vector<int> initial; int max_delay = 0;
 
@@ -878,10 +886,8 @@ void make_rvq(moshi_hot_model * m, Rvq & rvq, const std::string & name, int n_la
 }
 
 // moshi_lmmodel_forward_text_build + sampler (lm.h:555-584, 659-677, 853-869)
-void build_temporal_graph(moshi_hot_model * m) {
+T build_input_embedding(moshi_hot_model * m, Builder & g) {
     const moshi_hot_config & c = m->cfg;
-    m->g_temporal = new Builder(m->be, 256);
-    Builder & g = *m->g_temporal;
     auto embed = [&](T table) {   // moshi_scaled_embedding_build (lm_utils.h:157-170)
         const int i = (int) m->emb_idx.size();
         T idx = m->tok_state && i <= c.dep_q ? ggml_view_1d(g, m->tok_state, 1, (size_t) i * 4) : g.tensor(GGML_TYPE_I32, 1), scale = g.tensor(GGML_TYPE_F32, 1);
@@ -900,6 +906,13 @@ void build_temporal_graph(moshi_hot_model * m) {
     for (int k = 0; k < c.n_q; k++) input = ggml_add(g, input, embed(m->emb[(size_t) k]));
     if (c.condition_sum) input = ggml_add(g, m->cond_sum, input);   // lm.h:579-581
     m->g_transformer_in = input;
+    return input;
+}
+void build_temporal_graph(moshi_hot_model * m) {
+    const moshi_hot_config & c = m->cfg;
+    m->g_temporal = new Builder(m->be, 256);
+    Builder & g = *m->g_temporal;
+    T input = build_input_embedding(m, g);
     T x = transformer_graph_build(g, m->temporal, input);
     m->g_stack_out = x;
     x = apply_norm(g, m->out_norm, x);
@@ -1130,6 +1143,7 @@ static moshi_hot_model_t * create_model(ggml_backend_t backend, const struct mos
             }
             m->tp_x = state(m, GGML_TYPE_F32, c.dim);
             m->tp_msg = state(m, GGML_TYPE_F32, c.dim);
+            m->tp_in = state(m, GGML_TYPE_F32, (int64_t) c.dim + 8);   // frame mode: the stack input as rank 0 broadcasts it, then a "more frames" flag
             // the position inputs of transformer_graph_step are shared by all segment graphs: persistent tensors instead of per-graph inputs
             tp.g_bias = state(m, GGML_TYPE_F32, c.context);
             if (c.max_period) tp.g_offset = state(m, GGML_TYPE_F32, 1);
@@ -1378,9 +1392,10 @@ extern "C" void moshi_hot_tp_end(moshi_hot_model_t * m, float * out) { ggml_back
 // or the caller's function (host memory on the CPU device: gloo in tests/test_temporal_tp_cpu.py). No interpreter between the segments.
 extern "C" void moshi_hot_tp_set_transport(moshi_hot_model_t * m, moshi_hot_allreduce_t fn, void * user) { m->tp_allreduce = fn; m->tp_allreduce_user = user; }
 extern "C" int64_t moshi_hot_tp_reductions(moshi_hot_model_t * m) { return m->tp_reductions; }
-extern "C" void moshi_hot_tp_stack(moshi_hot_model_t * m, const float * x, float * out) {
+namespace {
+// the 2 L + 1 segment graphs with the in-place sum of the F32[dim] partial over the ranks between them
+void tp_run_segments(moshi_hot_model * m) {
     const moshi_hot_config & c = m->cfg;
-    moshi_hot_tp_begin(m, x);
     const int last = 2 * c.num_layers;
     for (int i = 0; i <= last; i++) {
         moshi_hot_tp_segment(m, i);
@@ -1392,8 +1407,90 @@ extern "C" void moshi_hot_tp_stack(moshi_hot_model_t * m, const float * x, float
         const int rc = m->rccl_all_reduce(m->tp_msg->data, m->tp_msg->data, (size_t) n, /* ncclFloat32 */ 7, /* ncclSum */ 0, m->rccl_comm, ggml_backend_mi355x_get_stream(m->be));
         GGML_ASSERT(rc == 0 && "ncclAllReduce failed");
     }
+}
+// ---- frame mode (SURVEY.md section 8f.2 as a whole LM step; lm.h:555-607, 659-677 around transformer.h:910-971) ----------------------------------------
+// rank 0: embedding sum -> tp_in ; broadcast(tp_in) ; every rank: tp_in -> tp_x, the stream position advances, segments + all-reduces ; rank 0: out_norm ->
+// transformer_out state, text_linear, sample. The Depth graph (rank 0) follows as in any other LM step.
+void tp_broadcast_in(moshi_hot_model * m) {
+    const moshi_hot_config & c = m->cfg;
+    if (c.tp_world <= 1 && !m->rccl_comm && !m->shard_bcast) return;
+    const size_t bytes = ggml_nbytes(m->tp_in);
+    if (m->shard_bcast) { m->shard_bcast(m->shard_bcast_user, m->tp_in->data, (int64_t) bytes, 0); return; }
+    GGML_ASSERT(m->rccl_comm && "moshi_hot tensor-parallel frame: no transport");
+    const int rc = m->rccl_broadcast(m->tp_in->data, m->tp_in->data, bytes, /* ncclUint8 */ 1, 0, m->rccl_comm, ggml_backend_mi355x_get_stream(m->be));
+    GGML_ASSERT(rc == 0 && "ncclBroadcast failed");
+}
+void tp_stack_from_in(moshi_hot_model * m) {
+    const moshi_hot_config & c = m->cfg;
+    if (!m->g_tp_import) {
+        m->g_tp_import = new Builder(m->be, 8);
+        Builder & g = *m->g_tp_import;
+        g.expand(ggml_cpy(g, ggml_view_1d(g, m->tp_in, c.dim, 0), m->tp_x));
+        g.alloc();
+    }
+    m->g_tp_import->compute();
+    transformer_graph_step(*m->scratch, m->temporal_tp, 1);
+    m->scratch->compute_scratch();
+    tp_run_segments(m);
+    m->tp_frames++;
+}
+void tp_build_frame_graphs(moshi_hot_model * m) {   // (before the step's token uploads: the embedding sum's index / scale inputs are made here)
+    const moshi_hot_config & c = m->cfg;
+    if (!m->g_tp_pre) {
+        m->g_tp_pre = new Builder(m->be, 256);
+        Builder & g = *m->g_tp_pre;
+        T input = build_input_embedding(m, g);
+        g.expand(ggml_cpy(g, input, ggml_view_1d(g, m->tp_in, c.dim, 0)));
+        g.alloc();
+        m->g_tp_post = new Builder(m->be, 64);
+        Builder & h = *m->g_tp_post;
+        T x = apply_norm(h, m->out_norm, m->tp_x);
+        m->g_transformer_out = x;
+        m->text_logits = linear(h, m->text_linear, x);
+        h.expand(ggml_cpy(h, x, m->transformer_out));
+        m->sampler_out = sample_token(h, m->text_logits, c.temp_text, c.top_k_text);
+        h.expand(m->sampler_out);
+        if (m->tok_state) h.expand(ggml_cpy(h, ggml_reshape_1d(h, m->sampler_out, 1), ggml_view_1d(h, m->tok_state, 1, 0)));
+        h.alloc();
+    }
+}
+void tp_temporal_frame(moshi_hot_model * m) {   // rank 0, inside moshi_hot_lm_step_n: the token inputs of the embedding sum are already uploaded
+    const moshi_hot_config & c = m->cfg;
+    m->g_tp_pre->compute();
+    const float more = 1.f;
+    ggml_backend_tensor_set(m->tp_in, &more, (size_t) c.dim * 4, 4);
+    tp_broadcast_in(m);
+    tp_stack_from_in(m);
+    m->g_tp_post->compute();
+}
+}  // namespace
+extern "C" void moshi_hot_tp_stack(moshi_hot_model_t * m, const float * x, float * out) {
+    moshi_hot_tp_begin(m, x);
+    tp_run_segments(m);
     moshi_hot_tp_end(m, out);
 }
+extern "C" void moshi_hot_tp_install(moshi_hot_model_t * m) {
+    GGML_ASSERT(m->tp_x && m->tp_in && !m->cfg.chain_depth && "moshi_hot_tp_install: a model created with tp_world >= 1 and chain_depth = 0");
+    m->tp_frame = true;
+}
+extern "C" void moshi_hot_tp_stop(moshi_hot_model_t * m) {
+    const float more = 0.f;
+    ggml_backend_tensor_set(m->tp_in, &more, (size_t) m->cfg.dim * 4, 4);
+    tp_broadcast_in(m);
+}
+extern "C" int64_t moshi_hot_tp_serve(moshi_hot_model_t * m) {
+    GGML_ASSERT(m->tp_x && m->tp_in);
+    int64_t frames = 0;
+    for (;;) {
+        tp_broadcast_in(m);
+        float more = 0.f;
+        ggml_backend_tensor_get(m->tp_in, &more, (size_t) m->cfg.dim * 4, 4);
+        if (more == 0.f) return frames;
+        tp_stack_from_in(m);
+        frames++;
+    }
+}
+extern "C" int64_t moshi_hot_tp_frames(moshi_hot_model_t * m) { return m->tp_frames; }
 
 // ---- Depth codebook shard ---------------------------------------------------------------------------------------
 namespace {
@@ -1563,10 +1660,14 @@ extern "C" int moshi_hot_depth_shard_rccl_init(moshi_hot_model_t * m, int rank, 
     nccl_id id;
     memcpy(id.internal, id128, 128);
     m->rccl_lib = lib;
+    // ncclCommInitRank binds the communicator to the calling thread's CURRENT HIP device: that must be this model's backend's, whatever the thread (or a
+    // torch in the same process) touched last. A second call replaces the communicator instead of leaking it.
+    ggml_backend_mi355x_make_current(m->be);
+    if (m->rccl_comm) { ggml_backend_synchronize(m->be); m->rccl_comm_destroy(m->rccl_comm); m->rccl_comm = nullptr; }
     return init(&m->rccl_comm, world, id, rank);
 }
 extern "C" void moshi_hot_depth_shard_rccl_free(moshi_hot_model_t * m) {
-    if (m->rccl_comm && m->rccl_comm_destroy) { ggml_backend_synchronize(m->be); m->rccl_comm_destroy(m->rccl_comm); }
+    if (m->rccl_comm && m->rccl_comm_destroy) { ggml_backend_mi355x_make_current(m->be); ggml_backend_synchronize(m->be); m->rccl_comm_destroy(m->rccl_comm); }
     m->rccl_comm = nullptr;
 }
 extern "C" void moshi_hot_depth_shard_broadcast(moshi_hot_model_t * m, int which, int root) { shard_broadcast(m, which ? m->shard_tout : m->shard_msg, root); }
@@ -1654,7 +1755,8 @@ extern "C" int moshi_hot_lm_step_n(moshi_hot_model_t * m, const int32_t * tokens
     std::vector<int> input((size_t) ncb);
     for (int i = 0; i < ncb; i++) input[(size_t) i] = m->offset <= c.delays[i] ? m->initial[(size_t) i] : m->cache[(size_t) pos][(size_t) i];
 
-    if (!m->g_temporal) build_temporal_graph(m);
+    if (m->tp_frame) tp_build_frame_graphs(m);
+    else if (!m->g_temporal) build_temporal_graph(m);
     int32_t text_token = 0;
     // chain_depth: the Depth graph reads the sampled text token on the device; it is queued right behind the Temporal graph and both results are read afterwards
     const bool chain = c.chain_depth && c.dep_q > 0 && !m->depth_hook;
@@ -1670,12 +1772,15 @@ extern "C" int moshi_hot_lm_step_n(moshi_hot_model_t * m, const int32_t * tokens
         ggml_backend_tensor_set(m->emb_idx[(size_t) i], &id, 0, 4);
         ggml_backend_tensor_set(m->emb_scale[(size_t) i], &sc, 0, 4);
     }
+    if (m->tp_frame) tp_temporal_frame(m);
+    else {
     if (m->temporal_staged) m->temporal_staged = false;
     else {
         transformer_graph_step(*m->scratch, m->temporal, 1);
         m->scratch->compute_scratch();
     }
     m->g_temporal->compute();
+    }
     if (m->after_temporal_launch) { m->after_temporal_launch(); m->after_temporal_launch = nullptr; }
     if (!chain) ggml_backend_tensor_get(m->sampler_out, &text_token, 0, 4);
     }

@@ -89,6 +89,7 @@ SIGNATURES = {
     "moshi_hot_tp_set_transport": (None, [P, C.c_void_p, C.c_void_p]),
     "moshi_hot_tp_stack": (None, [P, P, P]),
     "moshi_hot_tp_reductions": (C.c_int64, [P]),
+    "moshi_hot_tp_install": (None, [P]), "moshi_hot_tp_serve": (C.c_int64, [P]), "moshi_hot_tp_stop": (None, [P]), "moshi_hot_tp_frames": (C.c_int64, [P]),
     "moshi_hot_tp_msg_read": (None, [P, P]),
     "moshi_hot_tp_msg_write": (None, [P, P]),
 }

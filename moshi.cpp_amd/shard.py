@@ -18,6 +18,27 @@ with a world of ONE rank on the test box (tests/test_hip_frame.py); no multi-GPU
 import ctypes as C
 
 
+def _rccl_bootstrap(L, model, rank, world, dist, group, device):
+    """RCCL from inside the harness: rank 0 makes the 128-byte unique id, the caller's torch.distributed control group carries it to the other ranks, every
+    rank then joins the communicator behind the C-ABI (moshi_hot_depth_shard_rccl_init makes the backend's device current first). A C++ caller does the same
+    with its own wire (INTEGRATION.md "Multi-GPU bootstrap without torch")."""
+    import torch
+    idbuf = C.create_string_buffer(128)
+    if rank == 0:
+        rc = L.moshi_hot_depth_shard_rccl_unique_id(idbuf)
+        if rc != 0:
+            raise RuntimeError("ncclGetUniqueId failed (%d)" % rc)
+    if world > 1:
+        t = torch.frombuffer(bytearray(idbuf.raw), dtype=torch.uint8).clone()
+        if dist.get_backend(group) != "gloo":
+            t = t.to(device)
+        dist.broadcast(t, src=0, group=group)
+        idbuf = C.create_string_buffer(bytes(t.cpu().numpy().tobytes()), 128)
+    rc = L.moshi_hot_depth_shard_rccl_init(model, rank, world, idbuf)
+    if rc != 0:
+        raise RuntimeError("ncclCommInitRank failed (%d)" % rc)
+
+
 class DepthShard:
     def __init__(self, L, model, cfg, rank, world, dist, group=None, device=None, stream_ptr=None, staged_device=None, backend=None):
         """device: the torch device of this rank's GPU -> RCCL from inside the harness. device=None: the caller-supplied transport; the messages are host
@@ -31,22 +52,7 @@ class DepthShard:
         self._cb = None
         if world > 1 or device is not None:   # (a single rank WITH a device still sets RCCL up: every hop is then a real, if trivial, ncclBroadcast)
             if device is not None:
-                # RCCL from inside the harness: rank 0 makes the id, the control group carries it
-                import torch
-                idbuf = C.create_string_buffer(128)
-                if rank == 0:
-                    rc = L.moshi_hot_depth_shard_rccl_unique_id(idbuf)
-                    if rc != 0:
-                        raise RuntimeError("ncclGetUniqueId failed (%d)" % rc)
-                if world > 1:
-                    t = torch.frombuffer(bytearray(idbuf.raw), dtype=torch.uint8).clone()
-                    if dist.get_backend(group) != "gloo":
-                        t = t.to(device)
-                    dist.broadcast(t, src=0, group=group)
-                    idbuf = C.create_string_buffer(bytes(t.cpu().numpy().tobytes()), 128)
-                rc = L.moshi_hot_depth_shard_rccl_init(model, rank, world, idbuf)
-                if rc != 0:
-                    raise RuntimeError("ncclCommInitRank failed (%d)" % rc)
+                _rccl_bootstrap(L, model, rank, world, dist, group, device)
                 self.transport = "rccl (ncclBroadcast called by the harness on the backend's stream)"
             else:
                 import torch
@@ -103,17 +109,53 @@ class TemporalTP:
     behind the C-ABI (moshi_hot_tp_stack): ncclAllReduce on the backend's stream on devices (the model's communicator, set up by DepthShard / by
     moshi_hot_depth_shard_rccl_init), or - host memory, the CPU device - a function this class supplies (torch.distributed.all_reduce over gloo)."""
 
-    def __init__(self, L, model, cfg, rank, world, dist, group=None, device=None, stream_ptr=None):
+    def __init__(self, L, model, cfg, rank, world, dist, group=None, device=None, stream_ptr=None, staged_device=None, backend=None, have_comm=False):
+        """device: the torch device of this rank's GPU -> ncclAllReduce from inside the harness on the model's communicator (set up here unless have_comm says a
+        DepthShard of the same model already did). device=None: a caller-supplied transport - host memory on the CPU device, or (staged_device / backend given: a
+        GPU backend under a gloo control plane, single-GPU dry runs) the partial aliased as a device tensor with the backend synchronised around every reduction."""
         from . import hot
         self.L, self.m, self.cfg, self.rank, self.world = L, model, cfg, rank, world
         self._cb = None
-        if world > 1 and device is None:
+        self.transport = "none"
+        if device is not None:
+            if not have_comm:
+                _rccl_bootstrap(L, model, rank, world, dist, group, device)
+            self.transport = "rccl (ncclAllReduce called by the harness on the backend's stream)"
+        elif world > 1:
             import torch
 
             def allreduce(user, data, n):
+                if staged_device is not None:
+                    L.ggml_backend_synchronize(backend)
+                    dist.all_reduce(_alias(torch, data, n, staged_device), group=group)
+                    torch.cuda.synchronize()
+                    return
                 dist.all_reduce(_alias(torch, data, n, None), group=group)
             self._cb = hot.ALLREDUCE_FN(allreduce)
             L.moshi_hot_tp_set_transport(model, C.cast(self._cb, C.c_void_p), None)
+
+            def bcast(user, data, nbytes, root):   # frame mode: the stack input travels from rank 0 to the others
+                if staged_device is not None:
+                    L.ggml_backend_synchronize(backend)
+                    dist.broadcast(_alias(torch, data, nbytes // 4, staged_device), src=root, group=group)
+                    torch.cuda.synchronize()
+                    return
+                buf = (C.c_uint8 * nbytes).from_address(data)
+                dist.broadcast(torch.frombuffer(buf, dtype=torch.uint8), src=root, group=group)
+            self._bcb = hot.BCAST_FN(bcast)
+            L.moshi_hot_depth_shard_set_transport(model, C.cast(self._bcb, C.c_void_p), None)
+            self.transport = "caller-supplied function (torch.distributed)"
+
+    def install(self):
+        """rank 0: the tensor-parallel stack becomes the Temporal half of every LM step (include/moshi_hot.h "FRAME mode")"""
+        self.L.moshi_hot_tp_install(self.m)
+
+    def serve(self):
+        """every other rank: frames served until rank 0 stops"""
+        return int(self.L.moshi_hot_tp_serve(self.m))
+
+    def stop_workers(self):
+        self.L.moshi_hot_tp_stop(self.m)
 
     @property
     def reductions(self):

@@ -27,7 +27,12 @@ device = None
 if world > 1:
     import torch
     device = torch.device("cuda", dev)
-tp = shard.TemporalTP(L, m, cfg, rank, world, dist, device=device, stream_ptr=L.ggml_backend_mi355x_get_stream(be) if world > 1 else None)
+# nccl: RCCL from inside the harness on the backend's stream; gloo (single-GPU dry runs: --backend gloo --device 0): the partial aliased as a device tensor,
+# reduced through torch.distributed with the backend synchronised around it
+if world > 1 and args.backend == "gloo":
+    tp = shard.TemporalTP(L, m, cfg, rank, world, dist, staged_device=device, backend=be)
+else:
+    tp = shard.TemporalTP(L, m, cfg, rank, world, dist, device=device)
 x = (np.random.default_rng(0).standard_normal(cfg.dim) * 4).astype(np.float32)
 for _ in range(5):
     tp.stack(x)

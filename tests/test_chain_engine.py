@@ -54,6 +54,27 @@ def test_chained_depth_equals_one_launch_per_matvec_bit_for_bit_and_the_oracle()
     assert np.median(errs) < 1e-5 and errs.max() < 0.1, f"logit errors vs oracle {errs}"
 
 
+def test_q8_0_depth_chain_equals_one_launch_per_matvec_bit_for_bit_and_the_oracle():
+    # `-q q8_0` models (BASELINE.json configs[1]'s weight type): the descriptor-driven chain kernel takes Q8_0 mat-vecs too - 8 lanes per 272-byte chunk, one
+    # 34-byte block per lane, Q8_0 activations, the chunk's eight terms added in block order (vec_dot_q8_0_q8_0's float sequence). Same three-way check as Q4_K.
+    cfg = depth_at_real_width()
+    cfg.linear_type, cfg.embed_type = 8, 8
+    steps = 8
+    chained, st = run("hip", cfg, steps)
+    assert st.chained_matvecs_in_last_plan >= 4 * (1 + 4 * 2 + 1) - 1, f"the Q8_0 Depth graph was not chained ({st.chained_matvecs_in_last_plan} mat-vecs)"
+    plain, st0 = run("hip", cfg, steps, flags=16)
+    assert st0.chained_matvecs_in_last_plan == 0
+    assert_bit_identical(plain, chained, "q8_0 chain vs launches")
+    ref, _ = run("oracle", cfg, steps)
+    for i, (a, b) in enumerate(zip(ref, chained)):
+        assert a[:3] == b[:3], f"step {i}: greedy tokens differ from the oracle: {a[:3]} vs {b[:3]}"
+    # (the logits of this small NON-contractive model amplify single Q8_0 rounding flips - roundf(x / d) on a 1-ulp difference moves a block's term by 1 / 127 -
+    # through its layers: the per-op bar for Q8_0 is tests/test_hip_ops.py's 2e-6, the full-width bar tests/test_full_width_parity.py's contractive run; here the
+    # oracle guards the tokens and the order of magnitude, the bit-identity with one launch per mat-vec above is the chain's own gate)
+    errs = np.array([max(hu.rel_err(a[3], b[3]), max(hu.rel_err(u, v) for u, v in zip(a[4], b[4]))) for a, b in zip(ref[1:], chained[1:])])
+    assert np.median(errs) < 2e-2, f"logit errors vs oracle {errs}"
+
+
 def test_chain_replayed_from_a_hipgraph_many_times_stays_identical():
     # tags are derived from a launch counter kept on the device: 40 replays of the captured launch against 40 eager unchained runs
     cfg = depth_at_real_width(dep_q=3, layers=1, n_q=6)

@@ -175,12 +175,12 @@ def test_contractive_full_config_free_running_greedy_is_bit_exact():
     # tests/test_oracle_noise_floor.py); here they cannot compound, and what is left is the north_star bar for quantised weights itself, "1 ULP of
     # the q-block scale": when one of the 4096 Q8_K activation values of the LAST mat-vec rounds the other way, a logit moves by d_x * w_ij =
     # (max|x| / 127) * |w| ~ 4e-4 of max |logit| (measured floor over a frame: 1.1e-3 text / below that for Depth at this scale, against 6e-3 at
-    # update_scale 1/16). Asserted: logits within QSTEP_TOL = 3e-3 (eight such steps; measured max 1.8e-3, median 1.1e-3), greedy ids bit-exact. A sample may differ from the oracle's
-    # only where the ORACLE's own logits hold the two candidates closer than twice the observed disagreement (at most 4 such provable ties per
-    # run, each counted, after which both runs continue from the oracle's token).
+    # update_scale 1/16). Asserted: text logits within QSTEP_TOL = 2e-3 (five such steps; measured max 1.8e-3, median 1.1e-3), greedy ids bit-exact. A sample may differ from the oracle's
+    # only where the ORACLE's own logits hold the two candidates closer than twice the observed disagreement (at most 3 such provable ties in
+    # this run - 2 measured -, each counted, after which both runs continue from the oracle's token).
     cfg = lm_only(hu.hot.moshika(L))
     cfg.update_scale = 1.0 / 256
-    _contractive_free_run(cfg, 32)
+    _contractive_free_run(cfg, 32, max_ties=3)
 
 
 @pytest.mark.parametrize("lt", ["q8_0", "q4_0"])
@@ -221,7 +221,10 @@ def test_contractive_tts_shaped_free_running_greedy_is_bit_exact():
     _contractive_free_run(cfg, 24, setup=setup)
 
 
-def _contractive_free_run(cfg, steps, setup=None, QSTEP_TOL=3e-3):
+# Bars = what the runs measure (round 5, MI355X, `pytest -s -k contractive`: text logits max 0.78e-3 ... 1.81e-3 over the seven configurations, Depth logits max
+# 1.8e-3 ... 8.3e-3, 0 - 2 provable ties per run) + margin: text 2e-3 (north_star's logits bar is 1e-3 PER OP; this is a 16 - 32 frame free run through 32
+# layers), Depth 1.25e-2 (its two extra rounding sites, below), at most 2 ties (3 where a run measured 2).
+def _contractive_free_run(cfg, steps, setup=None, QSTEP_TOL=2e-3, DEPTH_TOL=1.25e-2, max_ties=2):
     rng = np.random.default_rng(21)
     inputs = [rng.integers(0, cfg.card, cfg.n_q - cfg.io_dep_q).tolist() for _ in range(steps)]
     ref, dev = hu.Model("oracle", cfg, seed=0), hu.Model("hip", cfg, seed=0)
@@ -246,8 +249,8 @@ def _contractive_free_run(cfg, steps, setup=None, QSTEP_TOL=3e-3):
             de.append(e)
             # Depth logits sit on two rounding sites of their own: the K = 4096 Q8_K image of transformer_out feeding depformer_in (a flip there
             # moves every element of the step's input by (max|x| / 127) * |w| ~ 2.5e-3 of its rms) and the K = 1024 head (one step weighs 4x more
-            # than at K = 4096): a handful of such steps per frame. Bound: 12 steps of the text bar; the median must stay within 4.
-            assert e < 12 * QSTEP_TOL, f"frame {i} depth step {k}: logits rel err {e:.2e}"
+            # than at K = 4096): a handful of such steps per frame. Bound: the measured maximum (8.3e-3) + 50 %; the median must stay within 4 text bars.
+            assert e < DEPTH_TOL, f"frame {i} depth step {k}: logits rel err {e:.2e}"
             if da[k] != db[k]:
                 assert float(xa[da[k]] - xa[db[k]]) <= 2 * e * float(np.abs(xa).max()), f"frame {i} depth {k}: token {db[k]} vs {da[k]} is not a tie in the oracle's logits"
                 ties += 1; diverged = True
@@ -258,7 +261,7 @@ def _contractive_free_run(cfg, steps, setup=None, QSTEP_TOL=3e-3):
         seen.update(t for t in da if t >= 0)
     assert dev.stats().graph_replays > 0
     ref.free(); dev.free()
-    assert ties <= 4, f"{ties} near-tie divergences in {steps} frames"
+    assert ties <= max_ties, f"{ties} near-tie divergences in {steps} frames"
     assert (not de or np.median(de) < 4 * QSTEP_TOL) and np.median(te) < QSTEP_TOL, f"median logit errors: depth {np.median(de) if de else 0:.2e} text {np.median(te):.2e}"
     assert len(seen) > 16 or cfg.dep_q == 0, "degenerate run: the sampled audio tokens barely vary"
     print(f"contractive full config, {steps} free-running frames: {ties} provable ties; text logits max {max(te):.2e} median {np.median(te):.2e}; depth max {max(de) if de else 0:.2e}")

@@ -722,6 +722,34 @@ def test_tensor_parallel_segments_on_the_device_match_the_oracle():
         assert hu.rel_err(a, b) < 1e-5, f"position {i}: {hu.rel_err(a, b):.2e}"
 
 
+def test_tensor_parallel_stack_with_rccl_all_reduce_on_the_backend_stream():
+    # TemporalTP given a device sets RCCL up itself (unique id -> moshi_hot_depth_shard_rccl_init, which makes the backend's device current first) and
+    # the 2 L all-reduces of moshi_hot_tp_stack are ncclAllReduce calls on the backend's stream. One GPU = a world of one rank: every reduction is still a real
+    # RCCL call between two segment graphs; the result must be the transport-less stack's, bit for bit.
+    import torch
+    from moshi_cpp_amd import shard
+    cfg = hu.hot.tiny(hu.L, linear_type=Q4_K, embed_type=Q4_0)
+    cfg.ffn_hidden = 1024
+    cfg.enable_mimi_encoder = cfg.enable_mimi_decoder = 0
+    cfg.tp_world, cfg.tp_rank = 1, 0
+    outs = {}
+    for how in ("plain", "rccl"):
+        m = hu.Model("hip", cfg, seed=0)
+        tp = shard.TemporalTP(hu.L, m.m, cfg, 0, 1, None, device=torch.device("cuda", 0) if how == "rccl" else None)
+        assert tp.transport.startswith("rccl") == (how == "rccl")
+        rng = np.random.default_rng(4)
+        outs[how] = [tp.stack((rng.standard_normal(cfg.dim) * 3).astype(np.float32)) for _ in range(6)]
+        if how == "rccl":
+            assert tp.reductions == 6 * 2 * cfg.num_layers, tp.reductions
+            # (a second init on the same model replaces the communicator instead of leaking it)
+            shard._rccl_bootstrap(hu.L, m.m, 0, 1, None, None, torch.device("cuda", 0))
+            again = tp.stack(outs["plain"][0] * 0 + 1)
+            assert np.isfinite(again).all()
+        m.free()
+    for i, (a, b) in enumerate(zip(outs["plain"], outs["rccl"])):
+        assert np.array_equal(a, b), f"position {i}"
+
+
 @pytest.mark.parametrize("dim,heads,ffn", [(2048, 16, 5632), (4096, 32, 11264)])
 def test_two_tensor_parallel_ranks_run_their_q4k_slices_on_the_device(dim, heads, ffn):
     # SURVEY.md 8f.2 with tp_world = 2 ON THE DEVICE: rank 0 and rank 1 each hold half of every Temporal matrix (their heads' in_proj rows, the matching

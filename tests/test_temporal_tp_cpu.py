@@ -102,3 +102,72 @@ def test_two_rank_tp_stack_q4k_matches_one_rank(tmp_path):
     out = run_two_ranks(tmp_path, "q4_k", 29632)
     # the activation rounding (Q8_K, BF16 ring) sits behind the summed partials: a 1e-7 difference in a sum can flip a rounded value, as anywhere else
     assert np.median(out["errs"]) < 1e-5 and max(out["errs"]) < 1e-2, out
+
+
+FRAME_WORKER = textwrap.dedent('''
+    import os, sys, json
+    sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "tests"))
+    import numpy as np, torch, torch.distributed as dist
+    import hot_util as hu
+    from ggml_util import F32
+    from moshi_cpp_amd import shard
+    import test_temporal_tp_cpu as t
+    L = hu.L
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    cfg = t.tp_config(F32)
+    cfg.tp_world, cfg.tp_rank = world, rank
+    m = hu.Model("oracle", cfg)
+    tp = shard.TemporalTP(L, m.m, cfg, rank, world, dist)
+    steps = 8
+    if rank != 0:
+        served = tp.serve()
+        assert served == steps, served
+    else:
+        tp.install()
+        rng = np.random.default_rng(5)
+        got = [m.lm_step(rng.integers(0, cfg.card, cfg.n_q - cfg.io_dep_q).tolist()) for _ in range(steps)]
+        logits = m.read("text_logits", cfg.text_card).copy()
+        tp.stop_workers()
+        c1 = t.tp_config(F32)                     # the unsplit model through the ordinary Temporal graph
+        m1 = hu.Model("oracle", c1)
+        rng = np.random.default_rng(5)
+        want = [m1.lm_step(rng.integers(0, c1.card, c1.n_q - c1.io_dep_q).tolist()) for _ in range(steps)]
+        ref_logits = m1.read("text_logits", c1.text_card)
+        print(json.dumps({"same_tokens": got == want, "logit_err": float(np.abs(logits - ref_logits).max() / np.abs(ref_logits).max()),
+                          "reductions": tp.reductions, "frames": int(L.moshi_hot_tp_frames(m.m))}))
+    dist.barrier()
+    dist.destroy_process_group()
+''') % (ROOT, ROOT)
+
+
+def test_two_rank_tensor_parallel_frames_give_the_one_rank_tokens(tmp_path):
+    # VERDICT r4 item 5: (f2) as a frame mode. Rank 0 runs whole LM steps whose Temporal half is embedding sum -> broadcast -> 2 L + 1 segments with all-reduces ->
+    # head graph, rank 1 serves; the greedy tokens of 8 frames must be the unsplit model's, the last text logits within the stack test's bar.
+    w = tmp_path / "frame_worker.py"
+    w.write_text(FRAME_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29633", str(w)],
+                       capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["same_tokens"], out
+    assert out["logit_err"] < 1e-5, out
+    assert out["frames"] == 8 and out["reductions"] == 8 * 2 * 2, out
+
+
+def test_one_rank_tensor_parallel_frames_are_the_ordinary_frames():
+    # frame mode with ONE rank and no transport: the segment graphs are the unsplit stack, so tokens and logits are the Temporal graph's, bit for bit
+    from moshi_cpp_amd import shard
+    cfg = tp_config(Q4_K)
+    cfg.tp_world, cfg.tp_rank = 1, 0
+    m = hu.Model("oracle", cfg)
+    tp = shard.TemporalTP(L, m.m, cfg, 0, 1, None)
+    tp.install()
+    m1 = hu.Model("oracle", tp_config(Q4_K))
+    rng = np.random.default_rng(2)
+    for i in range(6):
+        ia = rng.integers(0, cfg.card, cfg.n_q - cfg.io_dep_q).tolist()
+        assert m.lm_step(ia) == m1.lm_step(ia), f"frame {i}"
+        assert np.array_equal(m.read("text_logits", cfg.text_card), m1.read("text_logits", cfg.text_card)), f"frame {i}"
+    m.free(); m1.free()
