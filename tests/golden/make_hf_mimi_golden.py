@@ -23,7 +23,7 @@ from make_mimi_golden import tensor  # noqa: E402  (reads one weight tensor of t
 
 L = hu.L
 FRAMES = 6
-N_Q = 8
+N_Q = int(os.environ.get("HF_MIMI_N_Q", "32"))   # round 5: all 32 RVQ levels (BASELINE.json configs[1] / [2] decode / encode 32)
 
 
 def hf_model(m):

@@ -7,8 +7,15 @@ pairs), the per-step Depth weight sets stacked into HF's [codebook, out, in] ten
 The Temporal model is fed the driver's own stack inputs (`transformer_in`: the embedding sums) for 10 provided frames - more than the ring of 6 holds, so
 HF's sliding window and the driver's ring wrap are both exercised - and must reproduce `transformer_out` and the text logits; the Depth decoder is fed, per
 frame, the driver's transformer_out, its text token and its audio tokens (teacher forcing, as HF's training-style forward expects) and must reproduce the
-logits of every chained step. HF computes in plain float32 (no BF16 ring rows, no BF16 probabilities), so the bar is 1e-2 of max, not 1e-6.
-Run in the build container only: `python tests/golden/make_hf_moshi_golden.py`."""
+logits of every chained step.
+Round 5: (a) ggml's BF16 rounding sites of the attention are emulated - HF's plain-float32 attention keeps K / V rows and probabilities in float32 where ggml
+rounds the ring rows, the query and the probabilities to BF16 (mul_mat's activation operand takes the BF16 weight operand's type). They enter through
+transformers' own extension point, `AttentionInterface.register`: the registered function is HF's eager_attention_forward with q, k, v and the probabilities
+passed through `.bfloat16().float()` - four lines of soft_max(q k^T s + mask) v; projections, RoPE, norms, MLPs, residuals, the codebook-indexed linears
+and the heads stay HF's module code. The bar drops from 5e-3 / 1e-2 to north_star's own 1e-3. (b) `--wide` writes hf_moshi_wide.npz: the same pin at
+moshika's widths (dim 4096, 32 heads, FFN 11264, text vocabulary 32 000; Depth 1024 / 16 heads / 6 layers / 2816, 8 steps), 2 Temporal layers, a ring of 4
+slots over 7 frames (it wraps), F32 weights.
+Run in the build container only: `python tests/golden/make_hf_moshi_golden.py [--wide]`."""
 import os
 import sys
 
@@ -34,11 +41,40 @@ def deinterleave_rows(w, heads):
     return w[torch.cat([h * dh + perm for h in range(heads)])]
 
 
-def main():
-    from transformers import MoshiConfig
-    from transformers.models.moshi.modeling_moshi import MoshiDepthDecoder, MoshiForCausalLM
-    cfg = hu.hot.tiny(L, linear_type=F32, embed_type=F32, layers=2, context=6)
+def wide_config():
+    cfg = hu.hot.moshika(L)
+    cfg.linear_type = cfg.embed_type = F32
+    cfg.num_layers, cfg.context = 2, 4
     cfg.enable_mimi_encoder = cfg.enable_mimi_decoder = 0
+    return cfg
+
+
+def ggml_bf16_attention(module, query, key, value, attention_mask, scaling, dropout=0.0, **kwargs):
+    """transformers' eager_attention_forward with ggml's rounding sites: ring rows (K, V), the query and the probabilities are BF16 values"""
+    from transformers.models.moshi.modeling_moshi import repeat_kv
+    bf = lambda t: t.to(torch.bfloat16).to(torch.float32)
+    key_states, value_states = repeat_kv(key, module.num_key_value_groups), repeat_kv(value, module.num_key_value_groups)
+    attn_weights = torch.matmul(bf(query), bf(key_states).transpose(2, 3)) * scaling
+    if attention_mask is not None:
+        attn_weights = attn_weights + attention_mask[:, :, :, : key_states.shape[-2]]
+    attn_weights = torch.nn.functional.softmax(attn_weights, dim=-1, dtype=torch.float32)
+    attn_output = torch.matmul(bf(attn_weights), bf(value_states)).transpose(1, 2).contiguous()
+    return attn_output, attn_weights
+
+
+def main(wide=False):
+    from transformers import AttentionInterface, MoshiConfig
+    from transformers.models.moshi.modeling_moshi import MoshiDepthDecoder, MoshiForCausalLM
+    AttentionInterface.register("ggml_bf16_kv", ggml_bf16_attention)
+    from transformers import AttentionMaskInterface
+    from transformers.masking_utils import eager_mask
+    AttentionMaskInterface.register("ggml_bf16_kv", eager_mask)   # (the Depth decoder builds its causal mask itself: additive float, as for "eager")
+    global STEPS
+    if wide:
+        cfg, STEPS = wide_config(), 7
+    else:
+        cfg = hu.hot.tiny(L, linear_type=F32, embed_type=F32, layers=2, context=6)
+        cfg.enable_mimi_encoder = cfg.enable_mimi_decoder = 0
     m = hu.Model("oracle", cfg, seed=0)
     D, H, F, Q = cfg.dim, cfg.num_heads, cfg.ffn_hidden, cfg.dep_q
     DD, DH_, DF = cfg.dep_dim, cfg.dep_heads, cfg.dep_ffn_hidden
@@ -47,8 +83,8 @@ def main():
                      depth_decoder_config=dict(vocab_size=cfg.text_card, hidden_size=DD, num_hidden_layers=cfg.dep_layers, num_attention_heads=DH_, num_key_value_heads=DH_,
                                                audio_vocab_size=cfg.card, ffn_dim=2 * DF, num_codebooks=Q, input_size=D, sliding_window=Q, max_position_embeddings=Q,
                                                rms_norm_eps=1e-8))
-    hc._attn_implementation = "eager"
-    hc.depth_decoder_config._attn_implementation = "eager"
+    hc._attn_implementation = "ggml_bf16_kv"
+    hc.depth_decoder_config._attn_implementation = "ggml_bf16_kv"
     lm = MoshiForCausalLM(hc).eval().to(torch.float32)
     dd = MoshiDepthDecoder(hc.depth_decoder_config).eval().to(torch.float32)
     w = lambda n, r, c: mg.weight(m, n, r, c)
@@ -128,10 +164,10 @@ def main():
         e3 = max(hu.rel_err(hf_dep[step][k], dep_logits[step][k]) for k in range(Q))
         agree = [int(np.argmax(hf_dep[step][k])) for k in range(Q)] == dep_tokens[step]
         print(f"step {step}: transformer_out {e1:.2e}  text logits {e2:.2e} (argmax {int(np.argmax(hf_logits[step]))} vs {text_tokens[step]})  depth logits {e3:.2e}  depth tokens agree {agree}")
-    np.savez_compressed(os.path.join(HERE, "hf_moshi.npz"), tokens=np.array(toks, np.int32), x_in=np.array(xs), transformer_out=hf_out, text_logits=hf_logits,
+    np.savez_compressed(os.path.join(HERE, "hf_moshi_wide.npz" if wide else "hf_moshi.npz"), tokens=np.array(toks, np.int32), x_in=np.array(xs), transformer_out=hf_out, text_logits=hf_logits,
                         text_tokens=np.array(text_tokens, np.int32), dep_tokens=np.array(dep_tokens, np.int32), dep_logits=hf_dep)
-    print("wrote hf_moshi.npz")
+    print("wrote", "hf_moshi_wide.npz" if wide else "hf_moshi.npz")
 
 
 if __name__ == "__main__":
-    main()
+    main(wide="--wide" in sys.argv)

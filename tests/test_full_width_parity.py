@@ -32,8 +32,9 @@ class LayerProber:
     """One layer at a time, three ways - oracle, device with one kernel per node, device with the fused kernels bench.py times - fed the SAME input;
     rounding flips are counted, clean nodes held to 2e-6, fused outputs may not move without a flip the per-node run shows."""
 
-    def __init__(self, cfg):
+    def __init__(self, cfg, taint_scale=1.0):
         self.cfg = cfg
+        self.taint_scale = taint_scale   # > 1 for models whose Temporal FFN is as narrow as the Depth one (a flip weighs with 1 / K)
         self.ref = hu.Model("oracle", cfg, seed=0)
         self.dev = hu.Model("hip", cfg, seed=0)
         self.tot = {"nodes": 0, "clean": 0, "tainted": 0, "flips": 0, "sites": 0, "hidden": 0, "fused_nodes": 0, "fused_clean": 0}
@@ -55,7 +56,7 @@ class LayerProber:
         b, _ = pp.probe(dev, which, layer, ws, x, offset)           # ring row it leaves behind is the one whose rounding was just inspected
         # below a flip the bound is a few quantiser steps: one Q8_K step is 1/127 of a block's maximum, against dot products of K terms, so it
         # weighs ~4x more at the Depth width (K = 1024) than at the Temporal one (K = 4096 / 11264)
-        ttol = pp.TAINT_TOL if which == 0 else 5 * pp.TAINT_TOL
+        ttol = pp.TAINT_TOL * self.taint_scale if which == 0 else 5 * pp.TAINT_TOL
         tainted = self.ring_flipped.get((which, layer), False)
         st = pp.compare_layer(a, b, where + " per-node", taint_tol=ttol, cache_tainted=tainted)
         sf = pp.compare_layer(a, c, where + " fused", taint_tol=ttol, taint_in=st["taint"], hidden_flips=True, cache_tainted=tainted)
