@@ -309,6 +309,12 @@ struct pstep {
     chain_plan * chain = nullptr;   // a persistent chain launch (timed on its own in profile mode)
     template <typename F> pstep(F f) : fn(std::move(f)) { memset(&mv, 0, sizeof(mv)); }
     pstep(const mv_args & a) : fn([a](hipStream_t s) { k_matvec(s, a); }), is_mv(true), mv(a) {}
+    // a step that is not a mat-vec but may be taken into a persistent step program next to its neighbours (mv.special): it keeps its own launch otherwise
+    template <typename F> static pstep special_step(F f, int special, const attn_args * at, const lowrank_embed_args * lr) {
+        pstep st(std::move(f));
+        st.is_mv = true; st.mv.special = special; st.mv.attn = at; st.mv.lr = lr;
+        return st;
+    }
 };
 
 struct plan_t {
@@ -316,6 +322,7 @@ struct plan_t {
     std::vector<chain_plan *> chains;
     std::vector<std::pair<void *, size_t>> workspaces;
     std::vector<std::unique_ptr<attn_args>> attn_copies;
+    std::vector<std::unique_ptr<lowrank_embed_args>> lowrank_copies;
     std::vector<const ggml_backend_buffer *> buffers;   // every buffer a node / leaf of the planned graph lives in: freeing one orphans the plan
     uint64_t orphan_seq = 0;                            // != 0: a buffer of the planned graph has been freed since (see evict_plans_of_buffer)
     hipGraph_t graph = nullptr;
@@ -1646,7 +1653,8 @@ static plan_t * build_plan(hip_ctx * c, ggml_cgraph * g, bool keep = true) {
             for (int m2 : members) an.skip[(size_t) m2] = 1;
             const lowrank_embed_args la = { (const char *) tab->data, (int64_t) tab->nb[1], tab->ne[1], (int) tab->type, (const int32_t *) idx->data,
                                             (const char *) W->data, (int64_t) W->nb[1], (int) K, (int) M, out };
-            at_pos[emit].push_back([=](hipStream_t s) { k_lowrank_embed(s, la); });
+            p->lowrank_copies.emplace_back(new lowrank_embed_args(la));
+            at_pos[emit].push_back(pstep::special_step([=](hipStream_t s) { k_lowrank_embed(s, la); }, 2, nullptr, p->lowrank_copies.back().get()));
             p->n_fused += (int) members.size();
         }
         // embedding sums
@@ -1903,6 +1911,10 @@ static plan_t * build_plan(hip_ctx * c, ggml_cgraph * g, bool keep = true) {
         }
         void * ws = nullptr;
         if (const size_t n = k_attn_split_resident(a, c->usable_cus) ? k_attn_decode_ws_size(a) : 0) { ws = em.ws(n); HIP_CHECK(hipMemsetAsync(ws, 0, n, c->stream)); }   // sequence numbers start at zero
+        if (a.T == 1 && a.n_groups <= 1 && !ws) {
+            p->attn_copies.emplace_back(new attn_args(a));
+            at_pos[ag.emit_pos].insert(at_pos[ag.emit_pos].begin(), pstep::special_step([=](hipStream_t s) { k_attn_decode(s, a, ws, err); }, 1, p->attn_copies.back().get(), nullptr));
+        } else
         at_pos[ag.emit_pos].insert(at_pos[ag.emit_pos].begin(), [=](hipStream_t s) { k_attn_decode(s, a, ws, err); });
     }
     const bool dump = getenv("MI355X_DUMP_PLAN") != nullptr;

@@ -22,6 +22,7 @@
 #include "hip_common.h"
 #include "hip_device.h"
 #include "hip_mv_device.h"
+#include "hip_attn_body.h"
 
 #include <stdlib.h>
 #include <string.h>
@@ -923,6 +924,7 @@ __global__ void __launch_bounds__(CH_THREADS) matvec_chain_kernel(chain_params P
 }
 
 #include "hip_chain_nest.h"
+#include "hip_chain_nest80.h"
 
 // ---- host side -----------------------------------------------------------------------------------------------------------------
 static int chain_env(const char * name, int def) { const char * v = getenv(name); return v ? atoi(v) : def; }
@@ -972,6 +974,11 @@ struct chain_plan {
     nest_params NP;
     size_t nest_smem = 0;
     std::vector<char> nest_tables;
+    // ... or as the Q8_0 step program of the tts-shaped Depth transformer (hip_chain_nest80.h): the run then also holds attention and low-rank embedding steps
+    bool nest80 = false;
+    nest80_params N80;
+    int64_t n80_weight_bytes = 0;
+    int n80_len = 0;
 };
 
 static bool overlaps(const void * a, size_t an, const void * b, size_t bn) {
@@ -992,6 +999,7 @@ static int chain_analyse(const mv_args * mv, int n, int G, std::vector<chain_pha
         chain_phase ph;
         memset(&ph, 0, sizeof(ph));
         // ---- the mat-vec itself
+        if (a.special) break;   // (an attention / low-rank embedding step: only a step program takes those)
         if ((a.wtype != GGML_TYPE_Q4_K && a.wtype != GGML_TYPE_Q8_0) || a.ncols != 1 || a.K % 256 != 0 || a.K > 4096 || a.pair_F != 0 || a.x_out || a.out_scale || a.out_act) break;
         if (!a.ticket && (a.argmax_out[0] || a.argmax_out[1])) break;
         if (a.row_bytes != (a.K / 256) * (a.wtype == GGML_TYPE_Q8_0 ? 272 : 144) || ((uintptr_t) a.w & 15)) break;
@@ -1104,7 +1112,127 @@ static int chain_analyse(const mv_args * mv, int n, int G, std::vector<chain_pha
     return len;
 }
 
+// ---- the Q8_0 step program (hip_chain_nest80.h) --------------------------------------------------------------------------------------------------
+// Does the run START with whole steps of the tts-shaped Depth transformer - [low-rank embedding], depformer_in + last, L x { in_proj, attention, out_proj,
+// linear_in, linear_out (gated) }, linears[k] + arg-max - in Q8_0 at the instantiated widths? Returns the entries taken (0: no) and fills `d`.
+struct n80_desc {
+    int n_steps = 0, L = 0, KIN = 0, FF = 0, len = 0;
+    std::vector<nest_ph> ph; std::vector<n80_at> at; std::vector<n80_st> st; std::vector<const char *> dsets;
+    attn_args at0; int q_off = 0, k_off = 0, v_off = 0; const float * xin = nullptr; int64_t weight_bytes = 0;
+};
+static bool n80_is_mv(const mv_args & a, int64_t K, int64_t M, int pro) {
+    return !a.special && a.wtype == GGML_TYPE_Q8_0 && a.ncols == 1 && a.K == K && a.M == M && a.prologue == pro && a.row_bytes == (K / 256) * 272 && !((uintptr_t) a.w & 15) &&
+           !a.pair_F && !a.x_out && !a.out_scale && !a.out_act && !a.res_embed.table && !a.beta;
+}
+static int nest80_match(const mv_args * mv, int n, n80_desc & d) {
+    static const int on = chain_env("MI355X_CHAIN_NEST80", 1);
+    if (!on) return 0;
+    int i = 0;
+    const int32_t * prev_tok[2] = { nullptr, nullptr };
+    while (i < n && d.n_steps < N80_STEPS_MAX) {
+        const int i0 = i;
+        n80_st st; memset(&st, 0, sizeof(st));
+        auto fail = [&]() { i = i0; };
+        if (mv[i].special == 2) {
+            const lowrank_embed_args & lr = *mv[i].lr;
+            if (lr.K != 128 || lr.M != 1024 || lr.w_row_bytes != 136 || ((uintptr_t) lr.w & 7) || d.n_steps == 0) { fail(); break; }
+            if (!((const void *) lr.index == (const void *) prev_tok[0] || (const void *) lr.index == (const void *) prev_tok[1])) { fail(); break; }   // the token the previous step's arg-max wrote
+            st.lr_table = lr.table; st.lr_row_bytes = lr.row_bytes; st.lr_n_rows = lr.n_rows; st.lr_type = lr.type; st.lr_index = lr.index; st.lr_w = lr.w;
+            st.lr_w_row_bytes = lr.w_row_bytes; st.lr_out = lr.out; st.emb_chain = 1;
+            i++;
+        } else if (d.n_steps > 0) break;   // (later steps take their embedding from the chain)
+        if (i >= n) { fail(); break; }
+        const mv_args & din = mv[i];
+        if (din.special || din.wtype != GGML_TYPE_Q8_0 || din.M != 1024 || din.prologue != MV_PLAIN || !din.residual || din.ticket || din.K % 256 || din.K > 4096) { fail(); break; }
+        if (d.n_steps == 0) { d.KIN = (int) din.K; d.xin = din.x; }
+        if (!n80_is_mv(din, d.KIN, 1024, MV_PLAIN) || din.x != d.xin) { fail(); break; }
+        if (st.lr_table ? din.residual != st.lr_out : false) { fail(); break; }
+        if (!st.lr_table) st.res_mem = din.residual;
+        st.din_y = din.y;
+        {
+            size_t k = 0;
+            while (k < d.dsets.size() && d.dsets[k] != din.w) k++;
+            if (k == d.dsets.size()) { if (k >= N80_SETS_MAX) { fail(); break; } d.dsets.push_back(din.w); d.weight_bytes += din.M * din.row_bytes; }
+            st.din_set = (int) k;
+        }
+        i++;
+        const float * xprev = din.y;
+        int l = 0;
+        bool ok = true;
+        std::vector<nest_ph> ph; std::vector<n80_at> ats;
+        int64_t wb = 0;
+        for (;; l++) {
+            if (i >= n) { ok = false; break; }
+            if (n80_is_mv(mv[i], 1024, 2048, MV_PLAIN) && mv[i].ticket && mv[i].x == xprev && !mv[i].residual) break;   // linears[k]
+            if (i + 5 > n) { ok = false; break; }
+            const mv_args & ip = mv[i], & as = mv[i + 1], & op = mv[i + 2], & li = mv[i + 3], & lo = mv[i + 4];
+            if (!n80_is_mv(ip, 1024, 3072, MV_RMSNORM) || ip.x != xprev || ip.residual || ip.ticket) { ok = false; break; }
+            if (as.special != 1) { ok = false; break; }
+            const attn_args & at = *as.attn;
+            if (at.T != 1 || at.D != 64 || at.H != 16 || at.C < 1 || at.C > 64 || at.n_groups > 1) { ok = false; break; }
+            auto inside = [&](const float * qq, int64_t hs) { return hs >= 0 && qq >= ip.y && qq + 15 * hs + 64 <= ip.y + 3072; };
+            if (!inside(at.q, at.q_hs) || !inside(at.k, at.k_hs) || !inside(at.v, at.v_hs) || at.out_ts < 0) { ok = false; break; }
+            if (d.n_steps == 0 && l == 0) { d.at0 = at; d.q_off = (int) (at.q - ip.y); d.k_off = (int) (at.k - ip.y); d.v_off = (int) (at.v - ip.y); }
+            if ((int) (at.q - ip.y) != d.q_off || (int) (at.k - ip.y) != d.k_off || (int) (at.v - ip.y) != d.v_off || at.q_hs != d.at0.q_hs || at.k_hs != d.at0.k_hs ||
+                at.v_hs != d.at0.v_hs || at.C != d.at0.C || at.scale != d.at0.scale || at.k_nb1 != d.at0.k_nb1 || at.k_nb2 != d.at0.k_nb2 || at.v_nb1 != d.at0.v_nb1 ||
+                at.v_nb2 != d.at0.v_nb2 || (at.rot != nullptr) != (d.at0.rot != nullptr)) { ok = false; break; }
+            if (!n80_is_mv(op, 1024, 1024, MV_PLAIN) || op.x != at.out || op.residual != xprev || op.ticket) { ok = false; break; }
+            if (li.special || li.wtype != GGML_TYPE_Q8_0 || li.K != 1024 || li.prologue != MV_RMSNORM) { ok = false; break; }
+            const int FF = (int) (li.M / 2);
+            if (d.n_steps == 0 && l == 0) d.FF = FF;
+            if (FF != d.FF || !n80_is_mv(li, 1024, 2 * (int64_t) FF, MV_RMSNORM) || li.x != op.y || li.residual || li.ticket) { ok = false; break; }
+            if (!n80_is_mv(lo, FF, 1024, MV_GATE_SILU) || lo.x != li.y || lo.residual != op.y || lo.ticket) { ok = false; break; }
+            ph.push_back({ ip.w, ip.alpha, ip.y, ip.eps, 0 }); ph.push_back({ op.w, nullptr, op.y, 0.f, 0 });
+            ph.push_back({ li.w, li.alpha, li.y, li.eps, 0 }); ph.push_back({ lo.w, nullptr, lo.y, 0.f, 0 });
+            ats.push_back({ at.kcache, at.vcache, at.rot, at.mask, at.index, at.out });
+            wb += ip.M * ip.row_bytes + op.M * op.row_bytes + li.M * li.row_bytes + lo.M * lo.row_bytes;
+            xprev = lo.y;
+            i += 5;
+        }
+        if (!ok || l < 1 || (d.n_steps > 0 && l != d.L)) { fail(); break; }
+        const mv_args & hd = mv[i];
+        ph.push_back({ hd.w, nullptr, hd.y, 0.f, 0 });
+        wb += hd.M * hd.row_bytes;
+        st.argmax_out[0] = hd.argmax_out[0]; st.argmax_out[1] = hd.argmax_out[1];
+        st.prev_out[0] = const_cast<int32_t *>(prev_tok[0]); st.prev_out[1] = const_cast<int32_t *>(prev_tok[1]);
+        prev_tok[0] = hd.argmax_out[0]; prev_tok[1] = hd.argmax_out[1];
+        i++;
+        d.L = l;
+        d.ph.insert(d.ph.end(), ph.begin(), ph.end()); d.at.insert(d.at.end(), ats.begin(), ats.end()); d.st.push_back(st);
+        d.weight_bytes += wb;
+        d.n_steps++;
+    }
+    if (d.n_steps == 0) return 0;
+    if (!((d.KIN == 2048 && d.FF == 2048))) return 0;   // the instantiated widths (depth_nest80_kernel<KIN, FF>)
+    d.len = i;
+    return i;
+}
+static size_t nest80_attn_smem(const attn_args & at) {   // attn_smem_bytes (hip_kernels_fused.hip) at 8 waves, unsplit, one query row
+    return (size_t) at.C * 4 + (size_t) at.D * 4 * 3 + (size_t) CH_NCW * 64 * 8 * 8 + 16 + (size_t) at.C * 4 + 64;
+}
+static size_t nest80_smem_bytes(const n80_desc & d) {
+    return 16 * XBLK_BYTES + (size_t) (1024 + 16 + 1024) * 4 + 128 + 16 + sizeof(chain_ctl) + ((nest80_attn_smem(d.at0) + 15) & ~(size_t) 15) +
+           d.ph.size() * sizeof(nest_ph) + d.at.size() * sizeof(n80_at) + d.st.size() * sizeof(n80_st) + N80_SETS_MAX * 8 + d.dsets.size() * 1024 * 4;
+}
+static size_t nest80_tables_bytes(const n80_desc & d) { return GGML_PAD(d.ph.size() * sizeof(nest_ph) + d.at.size() * sizeof(n80_at) + d.st.size() * sizeof(n80_st) + N80_SETS_MAX * 8, 256); }
+static bool nest80_resident(const n80_desc & d, int usable_cus) {
+    const size_t smem = nest80_smem_bytes(d);
+    if (smem > 159 * 1024) return false;   // (the attention body brings a few hundred bytes of static LDS of its own)
+    static bool granted = false;
+    if (!granted) { HIP_CHECK(hipFuncSetAttribute((const void *) depth_nest80_kernel<2048, 2048>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024)); granted = true; }
+    static const int force = chain_env("MI355X_CHAIN_GRID_FORCE", 0);
+    int per_cu = 0;
+    return force || (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *) depth_nest80_kernel<2048, 2048>, CH_THREADS, smem) == hipSuccess &&
+                     (long long) per_cu * usable_cus >= 256);
+}
+
 int k_chain_accept(const mv_args * mv, int n, int usable_cus) {
+    if (n > 0 && (mv[0].special == 2 || (!mv[0].special && mv[0].wtype == GGML_TYPE_Q8_0)) && chain_grid_for(usable_cus) == 256) {
+        n80_desc d;
+        const int len = nest80_match(mv, n, d);
+        if (len > 0 && nest80_resident(d, usable_cus)) return len;
+    }
+    if (n > 0 && mv[0].special) return 0;
     static const int min_len = chain_env("MI355X_CHAIN_MIN", 4);
     if (n < min_len) return 0;
     const int G = chain_grid_for(usable_cus);
@@ -1127,6 +1255,11 @@ static size_t chain_state_bytes(int grid) { return 256 + 2 * (size_t) CH_XF_MAX 
 static size_t nest_tables_bytes(int n) { return GGML_PAD((size_t) n * (sizeof(nest_ph) + sizeof(nest_at)) + NEST_STEPS_MAX * sizeof(nest_st), 256); }
 static size_t nest_din_bytes() { return (size_t) NEST_STEPS_MAX * 1024 * 8; }
 size_t k_chain_ws_size(const mv_args * mv, int n, int usable_cus) {
+    {
+        n80_desc d;
+        if (n > 0 && (mv[0].special == 2 || (!mv[0].special && mv[0].wtype == GGML_TYPE_Q8_0)) && nest80_match(mv, n, d) == n)
+            return nest80_tables_bytes(d) + chain_state_bytes(256) + (size_t) N80_SETS_MAX * 1024 * 8;
+    }
     std::vector<chain_phase> ph; std::vector<attn_args> at;
     const int G = chain_grid_for(usable_cus);
     const int len = chain_analyse(mv, n, G, ph, at);
@@ -1265,6 +1398,49 @@ static bool nest_build(chain_plan * c, char * tables_dev, char * din_dev, int us
 chain_plan * k_chain_create(hipStream_t s, const mv_args * mv, int n, void * ws, unsigned * err, int usable_cus, bool allow_step_program) {
     chain_plan * c = new chain_plan;
     c->grid = chain_grid_for(usable_cus);
+    {
+        n80_desc d;
+        if (n > 0 && (mv[0].special == 2 || (!mv[0].special && mv[0].wtype == GGML_TYPE_Q8_0)) && c->grid == 256 && nest80_match(mv, n, d) == n) {
+            // the Q8_0 step program: tables | hand-off state | din granules
+            char * base = (char *) ws;
+            char * state = base + nest80_tables_bytes(d);
+            char * din = state + chain_state_bytes(256);
+            std::vector<char> tab(nest80_tables_bytes(d), 0);
+            char * t = tab.data();
+            memcpy(t, d.ph.data(), d.ph.size() * sizeof(nest_ph)); t += d.ph.size() * sizeof(nest_ph);
+            memcpy(t, d.at.data(), d.at.size() * sizeof(n80_at)); t += d.at.size() * sizeof(n80_at);
+            memcpy(t, d.st.data(), d.st.size() * sizeof(n80_st)); t += d.st.size() * sizeof(n80_st);
+            memcpy(t, d.dsets.data(), d.dsets.size() * 8);
+            c->nest_tables.swap(tab);
+            HIP_CHECK(hipMemcpyAsync(base, c->nest_tables.data(), c->nest_tables.size(), hipMemcpyHostToDevice, s));
+            HIP_CHECK(hipMemsetAsync(state, 0, chain_state_bytes(256) + (size_t) N80_SETS_MAX * 1024 * 8, s));
+            nest80_params & N = c->N80;
+            memset(&N, 0, sizeof(N));
+            N.P.phases = nullptr; N.P.n_phases = d.len;
+            N.P.launch_seq = (unsigned *) state; N.P.gbuf = (u64 *) (state + 256); N.P.cand = N.P.gbuf + 2 * CH_XF_MAX; N.P.err = err; N.P.delay = 0;
+            N.tables = (const u32x4 *) base;
+            N.n_steps = d.n_steps; N.n_layers = d.L; N.n_sets = (int) d.dsets.size();
+            N.din_buf = (u64 *) din; N.din_x = d.xin;
+            N.at = d.at0; N.at.q = N.at.k = N.at.v = nullptr; N.at.n_groups = 0; N.at.write_only = 0; N.at.row_split = 0;
+            N.q_off = d.q_off; N.k_off = d.k_off; N.v_off = d.v_off;
+            N.attn_smem = nest80_attn_smem(d.at0);
+            {   // MI355X_NEST80_DELAY="a,b,c": first-poll delays (s_sleep units) of the mat-vec phases / of out_proj on non-owner workgroups / of the head owners' granule poll
+                static const int dflt[4] = { 20, 60, 20, 0 };
+                for (int i = 0; i < 4; i++) N.delay[i] = dflt[i];
+                if (const char * e = getenv("MI355X_NEST80_DELAY")) {
+                    int v[3]; const int got = sscanf(e, "%d,%d,%d", &v[0], &v[1], &v[2]);
+                    for (int i = 0; i < got && i < 3; i++) N.delay[i] = v[i] < 0 ? 0 : v[i] > 400 ? 400 : v[i];
+                }
+            }
+            c->P = N.P;
+            c->smem = nest80_smem_bytes(d);
+            c->nest80 = true; c->n80_weight_bytes = d.weight_bytes; c->n80_len = d.len;
+            if (chain_env("MI355X_CHAIN_VERBOSE", 0))
+                fprintf(stderr, "chain engine: Q8_0 step program, %d steps x %d layers, %d depformer_in sets, ring of %d, %zu bytes of LDS, %d plan steps\n", d.n_steps, d.L, N.n_sets,
+                        d.at0.C, c->smem, d.len);
+            return c;
+        }
+    }
     GGML_ASSERT(c->grid > 0 && n <= CH_MAX_PHASES);
     const int len = chain_analyse(mv, n, c->grid, c->phases, c->attns);
     GGML_ASSERT(len == n && "k_chain_create: pass exactly the run k_chain_accept took");
@@ -1303,11 +1479,12 @@ chain_plan * k_chain_create(hipStream_t s, const mv_args * mv, int n, void * ws,
 }
 void k_chain_free(chain_plan * c) { delete c; }
 int k_chain_length(const chain_plan * c) { return c->P.n_phases; }
-int64_t k_chain_weight_bytes(const chain_plan * c) { int64_t b = 0; for (auto & ph : c->phases) b += (int64_t) ph.M * ph.row_bytes; return b; }
+int64_t k_chain_weight_bytes(const chain_plan * c) { if (c->nest80) return c->n80_weight_bytes; int64_t b = 0; for (auto & ph : c->phases) b += (int64_t) ph.M * ph.row_bytes; return b; }
 
-bool k_chain_is_step_program(const chain_plan * c) { return c->nest; }
+bool k_chain_is_step_program(const chain_plan * c) { return c->nest || c->nest80; }
 
 void k_chain_launch(hipStream_t s, const chain_plan * c) {
+    if (c->nest80) { depth_nest80_kernel<2048, 2048><<<256, CH_THREADS, c->smem, s>>>(c->N80); return; }
     if (c->nest) { depth_nest_kernel<256><<<c->grid, CH_THREADS, c->nest_smem, s>>>(c->NP); return; }
     // (the template argument only matters to phases with a compile-time shape; any other grid runs every phase from its descriptor)
     if (c->grid == 256) matvec_chain_kernel<256><<<c->grid, CH_THREADS, c->smem, s>>>(c->P);

@@ -105,6 +105,11 @@ struct mv_args {
     // left half AND the same rows of the right half, so it can finish g = silu(W_l x) * (W_r x) itself: y receives g[F] (M stays 2 F). The [2 F]
     // intermediate and the separate gate kernel disappear.
     int64_t     pair_F;         // 0 = off
+    // Entries of a launch-ordered run that are NOT mat-vecs but may become phases of a persistent step program (hip_chain.hip): special = 1 - a single-token
+    // attention step (`attn`, host pointer owned by the plan); special = 2 - one embedding row through a small Q8_0 projection (`lr`). The generic chain analysis
+    // stops at them; launched on their own they run k_attn_decode / k_lowrank_embed.
+    int         special;
+    const struct lowrank_embed_args * lr;
 };
 // Persistent chain engine (hip_chain.hip): a run of consecutive, dependent small Q4_K mat-vecs executed by ONE launch - resident workgroups,
 // a loader wave streaming every phase's weights through an LDS ring ahead of the dependency chain, data-tagged hand-offs between phases.

@@ -75,6 +75,43 @@ def test_q8_0_depth_chain_equals_one_launch_per_matvec_bit_for_bit_and_the_oracl
     assert np.median(errs) < 2e-2, f"logit errors vs oracle {errs}"
 
 
+def _tts_shaped(temporal_layers=2):
+    cfg = hu.hot.tts_like(hu.L)
+    cfg.num_layers = temporal_layers
+    cfg.enable_mimi_encoder = cfg.enable_mimi_decoder = 0
+    return cfg
+
+
+def _run_tts(kind, cfg, steps, flags=32):
+    m = hu.Model(kind, cfg, seed=0, flags=flags)
+    hu.set_conditions(m, cfg)
+    hu.set_text_hook(m, lambda offset, sampled: int((offset * 13) % cfg.text_card))
+    rec = []
+    for _ in range(steps):
+        r, txt, aud = m.lm_step([])
+        ta, da = m.last_raw()
+        ran = any(t != -1 for t in da)   # (the Depth transformer is held back for the first delay_steps frames, src/moshi.cpp:905)
+        rec.append((r, txt, aud, m.read("text_logits", cfg.text_card).copy(), [m.read(f"dep_logits{k}", cfg.card).copy() for k in range(cfg.dep_q)] if ran else [], da))
+    st = m.stats() if kind == "hip" else None
+    m.free()
+    return rec, st
+
+
+def test_tts_shaped_depth_program_is_bit_identical_to_launches():
+    # BASELINE.json configs[1]'s Depth transformer (32 steps on a weight schedule, 4 layers, 32-slot ring, low-rank embeddings, Q8_0) as ONE launch per frame:
+    # the Q8_0 step program (hip_chain_nest80.h) - hoisted depformer_in products of the 9 distinct matrices, the low-rank embedding behind the token hand-off,
+    # the attention as a phase on 16 head-owner workgroups running the stand-alone launch's own code. 22 frames: 16 with the Depth transformer held back
+    # (delay_steps), 6 with it running; tokens and every step's logits must be those of one launch per plan step, bit for bit.
+    cfg = _tts_shaped()
+    prog, st = _run_tts("hip", cfg, 22)
+    assert st.chain_step_programs_in_last_plan == 1, "the tts-shaped Depth graph did not take the Q8_0 step program"
+    plain, st0 = _run_tts("hip", cfg, 22, flags=16)
+    assert st0.chained_matvecs_in_last_plan == 0
+    assert sum(1 for r in plain if r[4]) >= 5, "the Depth transformer never ran"
+    assert [r[5] for r in plain] == [r[5] for r in prog], "raw Depth tokens differ"
+    assert_bit_identical(plain, prog, "tts-shaped Depth: step program vs launches")
+
+
 def test_chain_replayed_from_a_hipgraph_many_times_stays_identical():
     # tags are derived from a launch counter kept on the device: 40 replays of the captured launch against 40 eager unchained runs
     cfg = depth_at_real_width(dep_q=3, layers=1, n_q=6)
