@@ -599,3 +599,131 @@ __device__ __forceinline__ void attn_decode_body(const attn_args & a_in, const a
     AT_STAMP(7);
 }
 
+
+// ---- single-token attention of ONE head over a SHORT ring (C <= 64 slots of D = 64) by one workgroup of 8 waves -------------------------------------------
+// The tts-shaped Depth transformer's attention (16 heads x 64, a ring as long as its 32-step schedule, lm_default.h:86-90). attn_decode_body is built for
+// rings of hundreds of slots - mask scan, prefetch passes, batched streaming - and spends ~7 us on 32 slots; this is the direct form: wave w owns slots
+// 8 w .. 8 w + 7, lane = (slot, 8-dim chunk). ggml's CPU sequence for T = 1 (transformer.h:543-576, torch.h:225-237): q / k rotated (interleaved pairs in,
+// [re | im] out) and rounded to BF16, K / V written to the ring as BF16; score_c = <K_c, q> as float products summed in double; soft_max(score * scale +
+// mask) with the sum in double and p = e * float(1 / sum) rounded to BF16; out_d = sum over the slots IN SLOT ORDER of V_c[d] * p_c in double.
+// MODE: AT_GQKV - the new token's q / k / v come from {gtag, value} granules (gq), polled by the 64 threads that stage them; AT_GOUT - the 64 outputs also
+// leave as granules (go). smem: >= ATTN_RING64_SMEM bytes. Every thread of the 512 must call it (four workgroup barriers inside).
+#define ATTN_RING64_SMEM ((3 * 64 + 64 * 64 + 16 + 16) * 4)
+template <int MODE>
+__device__ __forceinline__ void attn_ring64_body(const attn_args & a, char * smem, const int h, const unsigned gtag = 0u, const attn_gqkv gq = attn_gqkv(), const attn_gout go = attn_gout()) {
+    constexpr bool GQKV = (MODE & AT_GQKV) != 0, GOUT = (MODE & AT_GOUT) != 0;
+    constexpr int D = 64, half = 32;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float * qf = (float *) smem, * knew = qf + 64, * vnew = knew + 64, * prod = vnew + 64;   // prod: [64 slots][64 dims]
+    float * wmax = prod + 64 * 64; double * wsum = (double *) (wmax + 16);
+    const int C = a.C;
+    const int sub = lane >> 3, dl = (lane & 7) * 8, c = wave * 8 + sub, cc = c < C ? c : C - 1;
+    // ---- entry loads: everything that does not depend on a computed value
+    const int slot = a.index[0];
+    const float m = a.mask[cc];
+    const char * kc = a.kcache + (int64_t) h * a.k_nb2, * vc = a.vcache + (int64_t) h * a.v_nb2;
+    const uint4 kq = *(const uint4 *) (kc + (int64_t) cc * a.k_nb1 + dl * 2);
+    const uint4 vq = *(const uint4 *) (vc + (int64_t) cc * a.v_nb1 + dl * 2);
+    if (wave == 0) {
+        const int j = lane, p = j < half ? j : j - half;
+        float rc = 1.f, rs = 0.f;
+        if (a.rot) { rc = a.rot[p]; rs = a.rot[half + p]; }
+        float q0, q1, k0, k1, vv;
+        if (GQKV) {
+            const int64_t eq = (int64_t) h * a.q_hs, ek = (int64_t) h * a.k_hs, ev = (int64_t) h * a.v_hs;
+            const unsigned long long * gp5[5] = { gq.in + gq.qoff + eq + (a.rot ? 2 * p : j), gq.in + gq.qoff + eq + (a.rot ? 2 * p + 1 : j),
+                                                  gq.in + gq.koff + ek + (a.rot ? 2 * p : j), gq.in + gq.koff + ek + (a.rot ? 2 * p + 1 : j), gq.in + gq.voff + ev + j };
+            unsigned long long g[5];
+            int spins = 0;
+            for (;;) {
+#pragma unroll
+                for (int i = 0; i < 5; i++) g[i] = __hip_atomic_load(gp5[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                bool ok = true;
+#pragma unroll
+                for (int i = 0; i < 5; i++) ok = ok && (unsigned) (g[i] >> 32) == gtag;
+                if (__all(ok)) break;
+                if (++spins >= (1 << 20)) { if (gq.err) *gq.err = 5u; break; }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            q0 = __uint_as_float((unsigned) g[0]); q1 = a.rot ? __uint_as_float((unsigned) g[1]) : 0.f;
+            k0 = __uint_as_float((unsigned) g[2]); k1 = a.rot ? __uint_as_float((unsigned) g[3]) : 0.f;
+            vv = __uint_as_float((unsigned) g[4]);
+        } else {
+            const float * q = a.q + (int64_t) h * a.q_hs, * k = a.k + (int64_t) h * a.k_hs, * v = a.v + (int64_t) h * a.v_hs;
+            if (a.rot) { q0 = q[2 * p]; q1 = q[2 * p + 1]; k0 = k[2 * p]; k1 = k[2 * p + 1]; }
+            else { q0 = q[j]; q1 = 0.f; k0 = k[j]; k1 = 0.f; }
+            vv = v[j];
+        }
+        float qo, ko;
+        if (a.rot) {
+            if (j < half) { qo = q0 * rc - q1 * rs; ko = k0 * rc - k1 * rs; }
+            else          { qo = q0 * rs + q1 * rc; ko = k0 * rs + k1 * rc; }
+        } else { qo = q0; ko = k0; }
+        const uint16_t kb = f2bf(ko), vb = f2bf(vv);
+        qf[j] = bf2f(f2bf(qo)); knew[j] = bf2f(kb); vnew[j] = bf2f(vb);
+        if (slot >= 0 && slot < C) {
+            ((uint16_t *) (a.kcache + (int64_t) h * a.k_nb2 + (int64_t) slot * a.k_nb1))[j] = kb;
+            ((uint16_t *) (a.vcache + (int64_t) h * a.v_nb2 + (int64_t) slot * a.v_nb1))[j] = vb;
+        }
+    }
+    __syncthreads();
+    // ---- scores
+    const bool live = c < C && m > -INFINITY, fresh = slot == c;
+    float kv[8], vv8[8];
+    {
+        const uint32_t kw[4] = { kq.x, kq.y, kq.z, kq.w }, vw[4] = { vq.x, vq.y, vq.z, vq.w };
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const float kr8 = bf2f((uint16_t) ((i & 1) ? (kw[i >> 1] >> 16) : (kw[i >> 1] & 0xffff))), vr8 = bf2f((uint16_t) ((i & 1) ? (vw[i >> 1] >> 16) : (vw[i >> 1] & 0xffff)));
+            kv[i] = fresh ? knew[dl + i] : kr8;
+            vv8[i] = fresh ? vnew[dl + i] : vr8;
+        }
+    }
+    double acc = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) acc += (double) (kv[i] * qf[dl + i]);
+    acc = group_allsum_f64(live ? acc : 0.0, 8);
+    const float sv = live ? (float) acc * a.scale + m : -INFINITY;
+    {
+        float wm = sv;
+        wm = fmaxf(wm, dpp_f32<DPP_ROW_MIRROR>(wm));   // (uniform inside a slot's 8 lanes: the in-group steps would return their input)
+        const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wm), 0)), r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wm), 16));
+        const float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wm), 32)), r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wm), 48));
+        if (lane == 0) wmax[wave] = fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
+    }
+    __syncthreads();
+    float gmax = wmax[0];
+#pragma unroll
+    for (int w = 1; w < 8; w++) gmax = fmaxf(gmax, wmax[w]);
+    const float e = sv > -INFINITY ? expf(sv - gmax) : 0.f;
+    {
+        double ws = (lane & 7) == 0 ? (double) e : 0.0;   // one representative per slot
+        ws += dpp_f64<DPP_QUAD_XOR1>(ws); ws += dpp_f64<DPP_QUAD_XOR2>(ws); ws += dpp_f64<DPP_HALF_MIRROR>(ws); ws += dpp_f64<DPP_ROW_MIRROR>(ws);
+        const int lo = __double2loint(ws), hi = __double2hiint(ws);
+        const double r0 = __hiloint2double(__builtin_amdgcn_readlane(hi, 0), __builtin_amdgcn_readlane(lo, 0)), r1 = __hiloint2double(__builtin_amdgcn_readlane(hi, 16), __builtin_amdgcn_readlane(lo, 16));
+        const double r2 = __hiloint2double(__builtin_amdgcn_readlane(hi, 32), __builtin_amdgcn_readlane(lo, 32)), r3 = __hiloint2double(__builtin_amdgcn_readlane(hi, 48), __builtin_amdgcn_readlane(lo, 48));
+        if (lane == 0) wsum[wave] = (r0 + r1) + (r2 + r3);
+    }
+    __syncthreads();
+    double lsum = 0;
+#pragma unroll
+    for (int w = 0; w < 8; w++) lsum += wsum[w];
+    const float inv = (float) (1.0 / lsum);
+    const float pr = bf2f(f2bf(e * inv));
+    {
+        float pf[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) pf[i] = pr != 0.f ? vv8[i] * pr : 0.f;
+        float * dst = prod + c * 64 + dl;
+        *(float4 *) dst = make_float4(pf[0], pf[1], pf[2], pf[3]);
+        *(float4 *) (dst + 4) = make_float4(pf[4], pf[5], pf[6], pf[7]);
+    }
+    __syncthreads();
+    if (tid < D) {
+        double tot = 0;
+        for (int c2 = 0; c2 < C; c2++) tot += (double) prod[c2 * 64 + tid];
+        a.out[(int64_t) h * D + tid] = (float) tot;
+        if (GOUT) __hip_atomic_store(go.out + (int64_t) h * D + tid, ((unsigned long long) go.tag << 32) | (unsigned long long) __float_as_uint((float) tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+}

@@ -1169,7 +1169,7 @@ static int nest80_match(const mv_args * mv, int n, n80_desc & d) {
             if (!n80_is_mv(ip, 1024, 3072, MV_RMSNORM) || ip.x != xprev || ip.residual || ip.ticket) { ok = false; break; }
             if (as.special != 1) { ok = false; break; }
             const attn_args & at = *as.attn;
-            if (at.T != 1 || at.D != 64 || at.H != 16 || at.C < 1 || at.C > 64 || at.n_groups > 1) { ok = false; break; }
+            if (at.T != 1 || at.D != 64 || at.H != 16 || at.C <= 8 || at.C > 64 || at.n_groups > 1 || at.out_ts < 0) { ok = false; break; }   // (attn_ring64_body's shapes: what the stand-alone launch runs there)
             auto inside = [&](const float * qq, int64_t hs) { return hs >= 0 && qq >= ip.y && qq + 15 * hs + 64 <= ip.y + 3072; };
             if (!inside(at.q, at.q_hs) || !inside(at.k, at.k_hs) || !inside(at.v, at.v_hs) || at.out_ts < 0) { ok = false; break; }
             if (d.n_steps == 0 && l == 0) { d.at0 = at; d.q_off = (int) (at.q - ip.y); d.k_off = (int) (at.k - ip.y); d.v_off = (int) (at.v - ip.y); }
@@ -1207,9 +1207,7 @@ static int nest80_match(const mv_args * mv, int n, n80_desc & d) {
     d.len = i;
     return i;
 }
-static size_t nest80_attn_smem(const attn_args & at) {   // attn_smem_bytes (hip_kernels_fused.hip) at 8 waves, unsplit, one query row
-    return (size_t) at.C * 4 + (size_t) at.D * 4 * 3 + (size_t) CH_NCW * 64 * 8 * 8 + 16 + (size_t) at.C * 4 + 64;
-}
+static size_t nest80_attn_smem(const attn_args &) { return ATTN_RING64_SMEM; }
 static size_t nest80_smem_bytes(const n80_desc & d) {
     return 16 * XBLK_BYTES + (size_t) (1024 + 16 + 1024) * 4 + 128 + 16 + sizeof(chain_ctl) + ((nest80_attn_smem(d.at0) + 15) & ~(size_t) 15) +
            d.ph.size() * sizeof(nest_ph) + d.at.size() * sizeof(n80_at) + d.st.size() * sizeof(n80_st) + N80_SETS_MAX * 8 + d.dsets.size() * 1024 * 4;
@@ -1425,7 +1423,7 @@ chain_plan * k_chain_create(hipStream_t s, const mv_args * mv, int n, void * ws,
             N.q_off = d.q_off; N.k_off = d.k_off; N.v_off = d.v_off;
             N.attn_smem = nest80_attn_smem(d.at0);
             {   // MI355X_NEST80_DELAY="a,b,c": first-poll delays (s_sleep units) of the mat-vec phases / of out_proj on non-owner workgroups / of the head owners' granule poll
-                static const int dflt[4] = { 20, 60, 20, 0 };
+                static const int dflt[4] = { 20, 60, 0, 0 };   // tests/microbench/nest80_delay_sweep.sh (gpurun_out/r05_nest80_delay_sweep.txt): flat between 20 and 30 / 40 and 100; the owners poll at once
                 for (int i = 0; i < 4; i++) N.delay[i] = dflt[i];
                 if (const char * e = getenv("MI355X_NEST80_DELAY")) {
                     int v[3]; const int got = sscanf(e, "%d,%d,%d", &v[0], &v[1], &v[2]);

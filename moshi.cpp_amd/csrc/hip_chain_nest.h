@@ -605,11 +605,12 @@ __global__ void __launch_bounds__(CH_THREADS) depth_nest_kernel(nest_params N) {
             rowsum(shape_head(), 0, p, ph.y, best, bi);
             CH_STAMP(8);
             if (N.head_argmax) {
-                am_wave(best, bi);
-                if (lane == 0) { ctl->am_v[wave] = best; ctl->am_i[wave] = bi; }
+                // (the 8 rows' values sit in the first lanes of 8 sixteen-lane groups: they meet through LDS - a wave-wide merge costs twelve ds_bpermute round trips)
+                static_assert(nest_dim<shape_head, G>::ROWS == 8 && CH_NCW >= 8, "one candidate slot per row");
+                if ((tid & 15) == 0 && (tid >> 4) < 8) { ctl->am_v[tid >> 4] = best; ctl->am_i[tid >> 4] = bi; }
                 nbar();
                 if (tid == 0) {
-                    for (int w = 1; w < CH_NCW; w++) am_merge(best, bi, ctl->am_v[w], ctl->am_i[w]);
+                    for (int w = 1; w < 8; w++) am_merge(best, bi, ctl->am_v[w], ctl->am_i[w]);
                     u64 * c = P.cand + (size_t) (p & 1) * 2 * grid + 2 * wg;
                     st_granule(c, tag_base | (unsigned) (p + 1), __float_as_uint(best));
                     st_granule(c + 1, tag_base | (unsigned) (p + 1), (unsigned) bi);

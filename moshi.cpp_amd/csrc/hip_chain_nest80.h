@@ -4,7 +4,7 @@
 // over to Q8_0 blocks, with the three things that shape brings:
 //   * the attention runs over a ring of up to 32 slots: recomputing it in every workgroup (what the 8-slot ring of moshika affords) measured slower than its own
 //     launch (profiles/r04_ab_tts_depth_attention_in_out_proj.txt). Here it is a PHASE: 16 head-owner workgroups (spread over the XCDs) take their head's q / k / v
-//     from the in_proj phase's granules, run attn_decode_body - the very code of the stand-alone launch, 8 waves - and publish the head's 64 outputs as granules;
+//     from the in_proj phase's granules, run attn_ring64_body (hip_attn_body.h) - the very code of the stand-alone launch - and publish the head's 64 outputs as granules;
 //     out_proj then is an ordinary phase that polls 1024 values. The other 240 workgroups skip the phase and wait in out_proj's poll;
 //   * step k's input is depformer_in[schedule[k]] x transformer_out + low_rank_k(emb_k[token]): the products of the DISTINCT depformer_in matrices (9 for 32
 //     steps) are hoisted to the head of the launch; the low-rank embedding - one 128-wide table row re-quantised to Q8_0 and sent through a 128 -> 1024 Q8_0
@@ -314,6 +314,7 @@ __global__ void __launch_bounds__(CH_THREADS) depth_nest80_kernel(nest80_params 
         for (int l = 0; l < L; l++) {
             // ---------------------------------------------------------------- in_proj: rms_norm -> 1024 -> 3072
             {
+                CH_STAMP(10);
                 const nest_ph ph = ld_ph(q);
                 const f32x4 al = load_alpha(ph.alpha);
                 float v[4] = { 0.f, 0.f, 0.f, 0.f };
@@ -398,16 +399,21 @@ __global__ void __launch_bounds__(CH_THREADS) depth_nest80_kernel(nest80_params 
                         for (int k = 0; k < 4; k++) { xres[k] = v[k]; gp(st.din_y)[wg * 4 + k] = v[k]; }
                     }
                 }
+                CH_STAMP(2);
                 norm_quant(std::integral_constant<int, 4>(), std::true_type(), v, al, ph.eps);
+                CH_STAMP(5);
                 dots(4, 48);
                 request(ld_w(q + 1), 4, 4, 0);                         // out_proj (the attention phase in between has no weights)
                 nbar();
+                CH_STAMP(6);
                 float best = -INFINITY; int bi = -1;
                 rowsum(4, 12, p, ph.y, false, false, true, best, bi);
+                CH_STAMP(8);
                 p = __builtin_amdgcn_readfirstlane(p + 1); q = __builtin_amdgcn_readfirstlane(q + 1);
             }
             // ---------------------------------------------------------------- attention: head h on workgroup 16 h + (h & 7), everybody else moves on
             {
+                CH_STAMP(10);
                 const int h = wg >> 4;
                 if ((wg & 15) == (h & 7)) {
                     const n80_at ta = ld_at(s * L + l);
@@ -415,39 +421,49 @@ __global__ void __launch_bounds__(CH_THREADS) depth_nest80_kernel(nest80_params 
                     at.kcache = ta.kcache; at.vcache = ta.vcache; at.rot = ta.rot; at.mask = ta.mask; at.index = ta.index; at.out = ta.out;
                     at.q = nullptr; at.k = nullptr; at.v = nullptr;   // (element offsets come through gq)
                     for (int i = 0; i < N.delay[2]; i++) __builtin_amdgcn_s_sleep(1);
-                    const attn_split_ws w0 = { nullptr, nullptr, nullptr, 1, P.err, 0, 1 << 30, 1 << 30 };
                     const attn_gqkv gq = { P.gbuf + (size_t) ((p - 1) & 1) * CH_XF_MAX, (int64_t) N.q_off, (int64_t) N.k_off, (int64_t) N.v_off, P.err };
                     const attn_gout go = { P.gbuf + (size_t) (p & 1) * CH_XF_MAX, tag_base | (unsigned) (p + 1) };
                     __syncthreads();
-                    attn_decode_body<false, CH_NCW, AT_GQKV | AT_GOUT>(at, w0, at_smem, h, 0, 0, tag_base | (unsigned) p, gq, go);
+                    CH_STAMP(2);
+                    attn_ring64_body<AT_GQKV | AT_GOUT>(at, at_smem, h, tag_base | (unsigned) p, gq, go);
                     __syncthreads();
+                    CH_STAMP(8);
                 }
                 p = __builtin_amdgcn_readfirstlane(p + 1);
             }
             // ---------------------------------------------------------------- out_proj 1024 -> 1024 + residual
             {
+                CH_STAMP(10);
                 const nest_ph ph = ld_ph(q);
                 float v[4];
                 const int h = wg >> 4;
                 poll_blocks(std::integral_constant<int, 4>(), p, v, (wg & 15) == (h & 7) ? 0 : N.delay[1]);
+                CH_STAMP(2);
                 norm_quant(std::integral_constant<int, 4>(), std::false_type(), v, (f32x4) { 1.f, 1.f, 1.f, 1.f }, 0.f);
+                CH_STAMP(5);
                 dots(4, 16);
                 request(ld_w(q + 1), 4, FROWS, FF);                    // linear_in, paired
                 nbar();
+                CH_STAMP(6);
                 float best = -INFINITY; int bi = -1;
                 rowsum(4, 4, p, ph.y, true, true, true, best, bi);
+                CH_STAMP(8);
                 p = __builtin_amdgcn_readfirstlane(p + 1); q = __builtin_amdgcn_readfirstlane(q + 1);
             }
             // ---------------------------------------------------------------- linear_in, paired: rms_norm -> 1024 -> 2 x FF -> silu(l) * r
             {
+                CH_STAMP(10);
                 const nest_ph ph = ld_ph(q);
                 const f32x4 al = load_alpha(ph.alpha);
                 float v[4];
                 poll_blocks(std::integral_constant<int, 4>(), p, v, N.delay[0]);
+                CH_STAMP(2);
                 norm_quant(std::integral_constant<int, 4>(), std::true_type(), v, al, ph.eps);
+                CH_STAMP(5);
                 dots(4, 2 * FROWS * 4);
                 request(ld_w(q + 1), NBF, 4, 0);                       // linear_out
                 nbar();
+                CH_STAMP(6);
                 {
                     const unsigned tag_out = tag_base | (unsigned) (p + 1);
                     const unsigned pub_base = (unsigned) (p & 1) * CH_XF_MAX;
@@ -464,42 +480,52 @@ __global__ void __launch_bounds__(CH_THREADS) depth_nest80_kernel(nest80_params 
                         }
                     }
                 }
+                CH_STAMP(8);
                 p = __builtin_amdgcn_readfirstlane(p + 1); q = __builtin_amdgcn_readfirstlane(q + 1);
             }
             // ---------------------------------------------------------------- linear_out FF -> 1024 + residual
             {
+                CH_STAMP(10);
                 const nest_ph ph = ld_ph(q);
                 float v[4];
                 poll_blocks(std::integral_constant<int, NBF>(), p, v, N.delay[0]);
+                CH_STAMP(2);
                 norm_quant(std::integral_constant<int, NBF>(), std::false_type(), v, (f32x4) { 1.f, 1.f, 1.f, 1.f }, 0.f);
+                CH_STAMP(5);
                 dots(NBF, 4 * NBF);
                 if (q + 1 < n_ph) request(ld_w(q + 1), 4, l + 1 < L ? 12 : 8, 0);   // the next layer's in_proj, or this step's linears[k]
                 nbar();
+                CH_STAMP(6);
                 float best = -INFINITY; int bi = -1;
                 rowsum(NBF, 4, p, ph.y, true, true, true, best, bi);
+                CH_STAMP(8);
                 p = __builtin_amdgcn_readfirstlane(p + 1); q = __builtin_amdgcn_readfirstlane(q + 1);
             }
         }
         // -------------------------------------------------------------------- linears[k]: 1024 -> 2048 -> arg-max candidate
         {
+            CH_STAMP(10);
             const nest_ph ph = ld_ph(q);
             float v[4];
             poll_blocks(std::integral_constant<int, 4>(), p, v, N.delay[0]);
+            CH_STAMP(2);
             norm_quant(std::integral_constant<int, 4>(), std::false_type(), v, (f32x4) { 1.f, 1.f, 1.f, 1.f }, 0.f);
+            CH_STAMP(5);
             dots(4, 32);
             if (s + 1 < N.n_steps) request(ld_w(q + 1), 4, 12, 0);
             nbar();
             float best = -INFINITY; int bi = -1;
             rowsum(4, 8, p, ph.y, false, false, false, best, bi);
-            am_wave(best, bi);
-            if (lane == 0) { ctl->am_v[wave] = best; ctl->am_i[wave] = bi; }
+            // (the 8 rows' values sit in the first lanes of 8 sixteen-lane groups: they meet through LDS - a wave-wide merge costs twelve ds_bpermute round trips)
+            if ((tid & 15) == 0 && (tid >> 4) < 8) { ctl->am_v[tid >> 4] = best; ctl->am_i[tid >> 4] = bi; }
             nbar();
             if (tid == 0) {
-                for (int w = 1; w < CH_NCW; w++) am_merge(best, bi, ctl->am_v[w], ctl->am_i[w]);
+                for (int w = 1; w < 8; w++) am_merge(best, bi, ctl->am_v[w], ctl->am_i[w]);
                 u64 * c = P.cand + (size_t) (p & 1) * 2 * grid + 2 * wg;
                 st_granule(c, tag_base | (unsigned) (p + 1), __float_as_uint(best));
                 st_granule(c + 1, tag_base | (unsigned) (p + 1), (unsigned) bi);
             }
+            CH_STAMP(8);
             p = __builtin_amdgcn_readfirstlane(p + 1); q = __builtin_amdgcn_readfirstlane(q + 1);
         }
     }

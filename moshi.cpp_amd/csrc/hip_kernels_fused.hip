@@ -1647,14 +1647,22 @@ bool k_attn_split_resident(const attn_args & a, int usable_cus) {
     if (env_int("MI355X_CHAIN_VERBOSE", 0)) fprintf(stderr, "split attention: grid %lld, %d per CU x %d CUs -> %s\n", grid, per_cu, usable_cus, ok ? "split" : "one workgroup per head");
     return ok;
 }
+// one head per workgroup of 8 waves, single token, ring of <= 64 slots of 64 (the tts-shaped Depth transformer): attn_ring64_body
+__global__ void __launch_bounds__(512) attn_ring64_kernel(attn_args a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    attn_ring64_body<AT_PLAIN>(a, smem, (int) blockIdx.x);
+}
+static bool attn_ring64_shape(const attn_args & a) {
+    static const int on = env_int("MI355X_ATTN_RING64", 1);
+    return on && a.D == 64 && a.T == 1 && a.n_groups <= 1 && !a.write_only && a.C > 8 && a.C <= 64 && a.out_ts >= 0;
+}
 void k_attn_decode(hipStream_t s, const attn_args & a, void * ws, unsigned * err) {
+    if (attn_ring64_shape(a)) { attn_ring64_kernel<<<a.H, 512, ATTN_RING64_SMEM, s>>>(a); return; }
     const int Tg = a.n_groups > 1 ? ATTN_MAX_T : a.T;   // rows per workgroup
     GGML_ASSERT(a.D % 8 == 0 && 64 % (a.D / 8) == 0 && a.D <= 512 && a.T >= 1 && Tg <= ATTN_MAX_T && Tg * a.D <= 2 * ATTN_NW_BASE * 64);
     GGML_ASSERT(a.n_groups <= 1 || a.n_groups == (a.T + 3) / 4);
     static const int wide_on = env_int("MI355X_ATTN_WIDE", 1);
-    // (8 waves also for single-token attention over rings of 9 .. 64 slots of 64 - the tts-shaped Depth transformer: the Q8_0 step program runs this very body
-    // with its workgroups' 8 waves as a phase of its launch, and the two must sum in the same order)
-    const bool wide = wide_on && a.D <= 64 && (a.C >= 128 || (a.D == 64 && a.T == 1 && a.n_groups <= 1 && a.C > 8 && a.C <= 64));
+    const bool wide = wide_on && a.D <= 64 && a.C >= 128;
     const bool split = ws && attn_use_split(a);
     const int split_nw = attn_split_nw();
     const size_t smem = attn_smem_bytes(a, split, wide);
