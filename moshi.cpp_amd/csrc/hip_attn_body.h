@@ -52,7 +52,7 @@ struct attn_split_ws { unsigned long long * gscores; unsigned long long * gpart;
 #define AT_GQKV  2
 #define AT_GOUT  4   // the output row also leaves as {tag, value} granules at go.out[h * D + j] (T = 1, unsplit): the next phase of a persistent launch polls it
 struct attn_gqkv { const unsigned long long * in; int64_t qoff, koff, voff; unsigned * err; };
-struct attn_gout { unsigned long long * out; unsigned tag; };
+struct attn_gout { unsigned long long * out; unsigned tag; int64_t ts; };   // granule (t, h, j) at out[t * ts + h * D + j]
 template <bool SPLIT, int NWA, int MODE>
 __device__ __forceinline__ void attn_decode_body(const attn_args & a_in, const attn_split_ws & w, char * smem, const int h, const int s_idx, const int group_y,
                                                  const unsigned gtag = 0u, const attn_gqkv gq = attn_gqkv(), const attn_gout go = attn_gout()) {
@@ -424,7 +424,7 @@ __device__ __forceinline__ void attn_decode_body(const attn_args & a_in, const a
 #pragma unroll 8
                 for (int g = 0; g < ATTN_NW * SPW; g++) tot += red[g * D + j];   // fixed order: wave-major, slot group minor
                 a.out[(int64_t) t * a.out_ts + (int64_t) h * D + j] = (float) tot;
-                if (GOUT) __hip_atomic_store(go.out + (int64_t) h * D + j, ((unsigned long long) go.tag << 32) | (unsigned long long) __float_as_uint((float) tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (GOUT) __hip_atomic_store(go.out + (int64_t) t * go.ts + (int64_t) h * D + j, ((unsigned long long) go.tag << 32) | (unsigned long long) __float_as_uint((float) tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             continue;                                          // (T == 1: the row loop ends here; nothing reuses the LDS)
         }
@@ -560,7 +560,7 @@ __device__ __forceinline__ void attn_decode_body(const attn_args & a_in, const a
                 __hip_atomic_store(gp + 1, ((unsigned long long) tag << 32) | (bits >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             } else {
                 a.out[(int64_t) t * a.out_ts + (int64_t) h * D + j] = (float) tot;
-                if (GOUT) __hip_atomic_store(go.out + (int64_t) h * D + j, ((unsigned long long) go.tag << 32) | (unsigned long long) __float_as_uint((float) tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (GOUT) __hip_atomic_store(go.out + (int64_t) t * go.ts + (int64_t) h * D + j, ((unsigned long long) go.tag << 32) | (unsigned long long) __float_as_uint((float) tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
         if (multi && s_idx == 0) {
@@ -724,6 +724,153 @@ __device__ __forceinline__ void attn_ring64_body(const attn_args & a, char * sme
         for (int c2 = 0; c2 < C; c2++) tot += (double) prod[c2 * 64 + tid];
         a.out[(int64_t) h * D + tid] = (float) tot;
         if (GOUT) __hip_atomic_store(go.out + (int64_t) h * D + tid, ((unsigned long long) go.tag << 32) | (unsigned long long) __float_as_uint((float) tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+}
+
+// ---- one query row of T <= 2 new tokens of ONE head over a ring of C <= 256 slots of D = 64, by one workgroup of 8 waves -----------------------------------
+// The codec transformers' shape (8 heads x 64, ring of 250, two 25 Hz frames per call; compression.h:173, 293). attn_decode_body spends ~8.7 us here; this is
+// the direct form of attn_ring64_body with four passes: wave w owns slots 32 w .. 32 w + 31, pass i its slots 8 i .. 8 i + 7, lane = (slot, 8-dim chunk); all
+// ring rows are requested at entry. Workgroup (h, t) computes row t: it rotates and rounds ALL T new rows (row 1 attends to row 0's K / V, which is not in the
+// ring yet - or is being written right now by workgroup (h, 0), the only one that writes), taking new rows from LDS wherever a slot is one of the new tokens'.
+// Arithmetic as attn_ring64_body; the P x V sums run per (wave, slot group) over the passes in double, then over the 64 groups in index order in double.
+#define ATTN_RING256_SMEM ((64 + 2 * 64 + 2 * 64 + 16) * 4 + 8 * 8 + 64 * 64 * 8)
+template <int MODE>
+__device__ __forceinline__ void attn_ring256_body(const attn_args & a, char * smem, const int h, const int t, const unsigned gtag = 0u, const attn_gqkv gq = attn_gqkv(), const attn_gout go = attn_gout()) {
+    constexpr bool GQKV = (MODE & AT_GQKV) != 0, GOUT = (MODE & AT_GOUT) != 0;
+    constexpr int D = 64, half = 32;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float * qf = (float *) smem, * knew = qf + 64, * vnew = knew + 128, * wmax = vnew + 128;
+    double * wsum = (double *) (wmax + 16), * red = wsum + 8;                                  // red: [64 groups][64 dims]
+    const int C = a.C, T = a.T;
+    const int sub = lane >> 3, dl = (lane & 7) * 8;
+    // ---- entry loads
+    const int slot0 = a.index[0], slot1 = T > 1 ? a.index[1] : -1;
+    const char * kc = a.kcache + (int64_t) h * a.k_nb2, * vc = a.vcache + (int64_t) h * a.v_nb2;
+    uint4 kq[4], vq[4]; float m[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int c = wave * 32 + i * 8 + sub, cc = c < C ? c : C - 1;
+        m[i] = a.mask[(int64_t) t * C + cc];
+        kq[i] = *(const uint4 *) (kc + (int64_t) cc * a.k_nb1 + dl * 2);
+        vq[i] = *(const uint4 *) (vc + (int64_t) cc * a.v_nb1 + dl * 2);
+    }
+    if (wave < T) {   // wave tt stages new row tt (its q only where it is THE query row)
+        const int tt = wave, j = lane, p = j < half ? j : j - half;
+        float rc = 1.f, rs = 0.f;
+        if (a.rot) { rc = a.rot[tt * D + p]; rs = a.rot[tt * D + half + p]; }
+        float q0, q1, k0, k1, vv;
+        if (GQKV) {
+            const int64_t eq = (int64_t) tt * a.q_ts + (int64_t) h * a.q_hs, ek = (int64_t) tt * a.k_ts + (int64_t) h * a.k_hs, ev = (int64_t) tt * a.v_ts + (int64_t) h * a.v_hs;
+            const unsigned long long * gp5[5] = { gq.in + gq.qoff + eq + (a.rot ? 2 * p : j), gq.in + gq.qoff + eq + (a.rot ? 2 * p + 1 : j),
+                                                  gq.in + gq.koff + ek + (a.rot ? 2 * p : j), gq.in + gq.koff + ek + (a.rot ? 2 * p + 1 : j), gq.in + gq.voff + ev + j };
+            unsigned long long g[5];
+            int spins = 0;
+            for (;;) {
+#pragma unroll
+                for (int i = 0; i < 5; i++) g[i] = __hip_atomic_load(gp5[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                bool ok = true;
+#pragma unroll
+                for (int i = 0; i < 5; i++) ok = ok && (unsigned) (g[i] >> 32) == gtag;
+                if (__all(ok)) break;
+                if (++spins >= (1 << 20)) { if (gq.err) *gq.err = 5u; break; }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            q0 = __uint_as_float((unsigned) g[0]); q1 = a.rot ? __uint_as_float((unsigned) g[1]) : 0.f;
+            k0 = __uint_as_float((unsigned) g[2]); k1 = a.rot ? __uint_as_float((unsigned) g[3]) : 0.f;
+            vv = __uint_as_float((unsigned) g[4]);
+        } else {
+            const float * q = a.q + (int64_t) tt * a.q_ts + (int64_t) h * a.q_hs, * k = a.k + (int64_t) tt * a.k_ts + (int64_t) h * a.k_hs, * v = a.v + (int64_t) tt * a.v_ts + (int64_t) h * a.v_hs;
+            if (a.rot) { q0 = q[2 * p]; q1 = q[2 * p + 1]; k0 = k[2 * p]; k1 = k[2 * p + 1]; }
+            else { q0 = q[j]; q1 = 0.f; k0 = k[j]; k1 = 0.f; }
+            vv = v[j];
+        }
+        float qo, ko;
+        if (a.rot) {
+            if (j < half) { qo = q0 * rc - q1 * rs; ko = k0 * rc - k1 * rs; }
+            else          { qo = q0 * rs + q1 * rc; ko = k0 * rs + k1 * rc; }
+        } else { qo = q0; ko = k0; }
+        const uint16_t kb = f2bf(ko), vb = f2bf(vv);
+        if (tt == t) qf[j] = bf2f(f2bf(qo));
+        knew[tt * 64 + j] = bf2f(kb); vnew[tt * 64 + j] = bf2f(vb);
+        const int slot = tt == 0 ? slot0 : slot1;
+        if (t == 0 && slot >= 0 && slot < C) {
+            ((uint16_t *) (a.kcache + (int64_t) h * a.k_nb2 + (int64_t) slot * a.k_nb1))[j] = kb;
+            ((uint16_t *) (a.vcache + (int64_t) h * a.v_nb2 + (int64_t) slot * a.v_nb1))[j] = vb;
+        }
+    }
+    __syncthreads();
+    // ---- scores of the four passes
+    float qv[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) qv[i] = qf[dl + i];
+    float sv[4], vv8[4][8];
+    bool live[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int c = wave * 32 + i * 8 + sub;
+        live[i] = c < C && m[i] > -INFINITY;
+        const int f = c == slot0 ? 0 : (T > 1 && c == slot1) ? 1 : -1;
+        const uint32_t kw[4] = { kq[i].x, kq[i].y, kq[i].z, kq[i].w }, vw[4] = { vq[i].x, vq[i].y, vq[i].z, vq[i].w };
+        double acc = 0;
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            const float kr8 = bf2f((uint16_t) ((e & 1) ? (kw[e >> 1] >> 16) : (kw[e >> 1] & 0xffff))), vr8 = bf2f((uint16_t) ((e & 1) ? (vw[e >> 1] >> 16) : (vw[e >> 1] & 0xffff)));
+            const float kk = f >= 0 ? knew[f * 64 + dl + e] : kr8;
+            vv8[i][e] = f >= 0 ? vnew[f * 64 + dl + e] : vr8;
+            acc += (double) (kk * qv[e]);
+        }
+        acc = group_allsum_f64(live[i] ? acc : 0.0, 8);
+        sv[i] = live[i] ? (float) acc * a.scale + m[i] : -INFINITY;
+    }
+    {
+        float wm = fmaxf(fmaxf(sv[0], sv[1]), fmaxf(sv[2], sv[3]));
+        wm = fmaxf(wm, dpp_f32<DPP_ROW_MIRROR>(wm));   // (uniform inside a slot's 8 lanes)
+        const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wm), 0)), r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wm), 16));
+        const float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wm), 32)), r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wm), 48));
+        if (lane == 0) wmax[wave] = fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
+    }
+    __syncthreads();
+    float gmax = wmax[0];
+#pragma unroll
+    for (int w = 1; w < 8; w++) gmax = fmaxf(gmax, wmax[w]);
+    float e4[4];
+    {
+        double ws = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) { e4[i] = sv[i] > -INFINITY ? expf(sv[i] - gmax) : 0.f; if ((lane & 7) == 0) ws += (double) e4[i]; }
+        ws += dpp_f64<DPP_QUAD_XOR1>(ws); ws += dpp_f64<DPP_QUAD_XOR2>(ws); ws += dpp_f64<DPP_HALF_MIRROR>(ws); ws += dpp_f64<DPP_ROW_MIRROR>(ws);
+        const int lo = __double2loint(ws), hi = __double2hiint(ws);
+        const double r0 = __hiloint2double(__builtin_amdgcn_readlane(hi, 0), __builtin_amdgcn_readlane(lo, 0)), r1 = __hiloint2double(__builtin_amdgcn_readlane(hi, 16), __builtin_amdgcn_readlane(lo, 16));
+        const double r2 = __hiloint2double(__builtin_amdgcn_readlane(hi, 32), __builtin_amdgcn_readlane(lo, 32)), r3 = __hiloint2double(__builtin_amdgcn_readlane(hi, 48), __builtin_amdgcn_readlane(lo, 48));
+        if (lane == 0) wsum[wave] = (r0 + r1) + (r2 + r3);
+    }
+    __syncthreads();
+    double lsum = 0;
+#pragma unroll
+    for (int w = 0; w < 8; w++) lsum += wsum[w];
+    const float inv = (float) (1.0 / lsum);
+    {
+        double o8[8];
+#pragma unroll
+        for (int e = 0; e < 8; e++) o8[e] = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const float pr = bf2f(f2bf(e4[i] * inv));
+#pragma unroll
+            for (int e = 0; e < 8; e++) o8[e] += (double) (pr != 0.f ? vv8[i][e] * pr : 0.f);
+        }
+        double * dst = red + (wave * 8 + sub) * 64 + dl;
+#pragma unroll
+        for (int e = 0; e < 8; e++) dst[e] = o8[e];
+    }
+    __syncthreads();
+    if (tid < D) {
+        double tot = 0;
+#pragma unroll 8
+        for (int g = 0; g < 64; g++) tot += red[g * 64 + tid];
+        a.out[(int64_t) t * a.out_ts + (int64_t) h * D + tid] = (float) tot;
+        if (GOUT) __hip_atomic_store(go.out + (int64_t) t * go.ts + (int64_t) h * D + tid, ((unsigned long long) go.tag << 32) | (unsigned long long) __float_as_uint((float) tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
 }

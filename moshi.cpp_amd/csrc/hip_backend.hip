@@ -1533,12 +1533,16 @@ static bool match_sampler(const analysis & an, int pos, step_group & grp) {
 // context per device plans them: the first that asks (the LM stream; the codec stream's graphs have no such runs today). Released with the context.
 static hip_ctx * g_spin_owner[64];
 // (asked only when a plan is about to CONTAIN such a launch: a context that never plans one never claims the device)
+static bool is_stream_context(const hip_ctx * c) { for (const hip_ctx * o : stream_contexts()) if (o == c) return true; return false; }
 static bool spin_kernels_allowed(hip_ctx * c) {
     if (c->device < 0 || c->device >= 64) return false;
+    // An ADDITIONAL command stream (ggml_backend_mi355x_init_stream: the codec stream of the two-stream frame loop) never claims the device: its graphs are the
+    // first a frame submits (the encode half), and a claim from there would take the persistent launches away from the LM stream they were built for.
+    if (is_stream_context(c)) return false;
     if (!g_spin_owner[c->device]) g_spin_owner[c->device] = c;
     return g_spin_owner[c->device] == c;
 }
-static bool spin_kernels_possible(const hip_ctx * c) { return c->device >= 0 && c->device < 64 && (!g_spin_owner[c->device] || g_spin_owner[c->device] == c); }
+static bool spin_kernels_possible(const hip_ctx * c) { return c->device >= 0 && c->device < 64 && !is_stream_context(c) && (!g_spin_owner[c->device] || g_spin_owner[c->device] == c); }
 
 static plan_t * build_plan(hip_ctx * c, ggml_cgraph * g, bool keep = true) {
     plan_t * p = new plan_t;
@@ -1911,7 +1915,7 @@ static plan_t * build_plan(hip_ctx * c, ggml_cgraph * g, bool keep = true) {
         }
         void * ws = nullptr;
         if (const size_t n = k_attn_split_resident(a, c->usable_cus) ? k_attn_decode_ws_size(a) : 0) { ws = em.ws(n); HIP_CHECK(hipMemsetAsync(ws, 0, n, c->stream)); }   // sequence numbers start at zero
-        if (a.T == 1 && a.n_groups <= 1 && !ws) {
+        if (a.T <= 4 && a.n_groups <= 1 && !ws) {
             p->attn_copies.emplace_back(new attn_args(a));
             at_pos[ag.emit_pos].insert(at_pos[ag.emit_pos].begin(), pstep::special_step([=](hipStream_t s) { k_attn_decode(s, a, ws, err); }, 1, p->attn_copies.back().get(), nullptr));
         } else

@@ -925,6 +925,7 @@ __global__ void __launch_bounds__(CH_THREADS) matvec_chain_kernel(chain_params P
 
 #include "hip_chain_nest.h"
 #include "hip_chain_nest80.h"
+#include "hip_chain_mimi.h"
 
 // ---- host side -----------------------------------------------------------------------------------------------------------------
 static int chain_env(const char * name, int def) { const char * v = getenv(name); return v ? atoi(v) : def; }
@@ -975,6 +976,8 @@ struct chain_plan {
     size_t nest_smem = 0;
     std::vector<char> nest_tables;
     // ... or as the Q8_0 step program of the tts-shaped Depth transformer (hip_chain_nest80.h): the run then also holds attention and low-rank embedding steps
+    bool mimi = false;           // a Mimi transformer as one launch (hip_chain_mimi.h)
+    mimi_params MM;
     bool nest80 = false;
     nest80_params N80;
     int64_t n80_weight_bytes = 0;
@@ -1224,7 +1227,98 @@ static bool nest80_resident(const n80_desc & d, int usable_cus) {
                      (long long) per_cu * usable_cus >= 256);
 }
 
+// ---- a Mimi transformer as one launch (hip_chain_mimi.h) -----------------------------------------------------------------------------------------------
+// Does the run START with L x { LN + in_proj, attention (T = 2), out_proj * scale + residual, LN + linear1 + GELU, linear2 * scale + residual } in F32 at
+// the codec's widths (512 / 8 heads of 64 / 2048)? Returns the entries taken (0: no).
+struct mimi_desc { int L = 0, len = 0; bool first_partial = false; attn_args at_first; std::vector<mimi_mv> mv; std::vector<mimi_at> at; attn_args at0; int q_off = 0, k_off = 0, v_off = 0; const float * x_in = nullptr; int64_t x_cs = 0, weight_bytes = 0; };
+static bool mimi_is_mv(const mv_args & a, int64_t K, int64_t M, int pro) {
+    return !a.special && a.wtype == GGML_TYPE_F32 && a.ncols == 2 && a.K == K && a.M == M && a.prologue == pro && a.row_bytes == K * 4 && !((uintptr_t) a.w & 15) && a.y_cs == M &&
+           !a.pair_F && !a.ticket && !a.res_embed.table && !a.argmax_out[0];
+}
+static int mimi_match(const mv_args * mv, int n, mimi_desc & d) {
+    static const int on = chain_env("MI355X_CHAIN_MIMI", 1);
+    if (!on) return 0;
+    const int D = MIMI_D, F = MIMI_F;
+    static const int verbose = chain_env("MI355X_CHAIN_VERBOSE", 0) > 1;
+    int i = 0;
+    const float * xprev = nullptr; int64_t xprev_cs = 0;
+    // The first layer's in_proj may have been launched already: the planner emits the RoPE table (a node the first attention depends on) between that mat-vec
+    // and its attention, which splits the run there. The program then starts at the attention phase of its first layer, q / k / v taken from memory.
+    static const mv_args none = {};
+    d.first_partial = n >= 4 && mv[0].special == 1;
+    while (i + (d.first_partial && d.L == 0 ? 4 : 5) <= n && d.L < 16) {
+        const bool part = d.first_partial && d.L == 0;
+        const mv_args & ip = part ? none : mv[i], & as = mv[i + (part ? 0 : 1)], & op = mv[i + (part ? 1 : 2)], & l1 = mv[i + (part ? 2 : 3)], & l2 = mv[i + (part ? 3 : 4)];
+        if (part) {
+            const attn_args & at = *as.attn;
+            if (at.T != 2 || at.D != 64 || at.H != 8 || at.C < 128 || at.C > 1024 || at.n_groups > 1 || at.out_ts != D || at.q_ts != 3 * D || at.k_ts != 3 * D || at.v_ts != 3 * D ||
+                at.q_hs != 64 || at.k_hs != 64 || at.v_hs != 64) break;
+            if (!mimi_is_mv(op, D, D, MV_PLAIN) || op.x != at.out || op.x_cs != D || !op.residual || op.out_act) break;
+            if (!mimi_is_mv(l1, D, F, MV_LAYERNORM) || !l1.alpha || l1.x != op.y || l1.x_cs != D || l1.residual || l1.out_scale || l1.out_act != 1) break;
+            if (!mimi_is_mv(l2, F, D, MV_PLAIN) || l2.x != l1.y || l2.x_cs != F || l2.residual != op.y || l2.r_cs != D || l2.out_act) break;
+            d.at0 = at; d.q_off = d.k_off = d.v_off = 0; d.at_first = at;
+            d.x_in = op.residual; d.x_cs = op.r_cs;
+            d.mv.push_back({ nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, { 0, 0, 0 } });
+            d.mv.push_back({ op.w, nullptr, nullptr, op.out_scale, op.y, nullptr, 0.f, { 0, 0, 0 } });
+            d.mv.push_back({ l1.w, l1.alpha, l1.beta, nullptr, l1.y, l1.x_out, l1.eps, { 0, 0, 0 } });
+            d.mv.push_back({ l2.w, nullptr, nullptr, l2.out_scale, l2.y, nullptr, 0.f, { 0, 0, 0 } });
+            d.at.push_back({ at.kcache, at.vcache, at.rot, at.mask, at.index, at.out });
+            d.weight_bytes += op.M * op.row_bytes + l1.M * l1.row_bytes + l2.M * l2.row_bytes;
+            xprev = l2.y; xprev_cs = D;
+            d.L++;
+            i += 4;
+            continue;
+        }
+        if (!mimi_is_mv(ip, D, 3 * D, MV_LAYERNORM) || !ip.alpha || ip.residual || ip.out_scale || ip.out_act) { if (verbose && d.L == 0) fprintf(stderr, "mimi_match: rule %d fails at layer 0\n", 1); break; }
+        if (d.L == 0) { d.x_in = ip.x; d.x_cs = ip.x_cs; } else if (ip.x != xprev || ip.x_cs != xprev_cs) { if (verbose && d.L == 0) fprintf(stderr, "mimi_match: rule %d fails at layer 0\n", 2); break; }
+        if (as.special != 1) { if (verbose && d.L == 0) fprintf(stderr, "mimi_match: rule %d fails at layer 0\n", 3); break; }
+        const attn_args & at = *as.attn;
+        if (at.T != 2 || at.D != 64 || at.H != 8 || at.C < 128 || at.C > 1024 || at.n_groups > 1 || at.out_ts != D) { if (verbose && d.L == 0) fprintf(stderr, "mimi_match: rule %d fails at layer 0\n", 4); break; }   // (C >= 128, D = 64: the stand-alone launch runs 8 waves there)
+        if (at.q_ts != 3 * D || at.k_ts != 3 * D || at.v_ts != 3 * D || at.q_hs != 64 || at.k_hs != 64 || at.v_hs != 64) { if (verbose && d.L == 0) fprintf(stderr, "mimi_match: rule %d fails at layer 0\n", 5); break; }
+        if (at.q < ip.y || at.k < ip.y || at.v < ip.y || at.q + 512 > ip.y + 3 * D || at.k + 512 > ip.y + 3 * D || at.v + 512 > ip.y + 3 * D) { if (verbose && d.L == 0) fprintf(stderr, "mimi_match: rule %d fails at layer 0\n", 6); break; }
+        if (d.L == 0 || (d.first_partial && d.L == 1)) { d.at0 = at; d.q_off = (int) (at.q - ip.y); d.k_off = (int) (at.k - ip.y); d.v_off = (int) (at.v - ip.y); }
+        if ((int) (at.q - ip.y) != d.q_off || (int) (at.k - ip.y) != d.k_off || (int) (at.v - ip.y) != d.v_off || at.C != d.at0.C || at.scale != d.at0.scale ||
+            at.k_nb1 != d.at0.k_nb1 || at.k_nb2 != d.at0.k_nb2 || at.v_nb1 != d.at0.v_nb1 || at.v_nb2 != d.at0.v_nb2 || (at.rot != nullptr) != (d.at0.rot != nullptr)) { if (verbose && d.L == 0) fprintf(stderr, "mimi_match: rule %d fails at layer 0\n", 7); break; }
+        const float * xin = d.L == 0 ? d.x_in : xprev; const int64_t xin_cs = d.L == 0 ? d.x_cs : xprev_cs;
+        if (!mimi_is_mv(op, D, D, MV_PLAIN) || op.x != at.out || op.x_cs != D || op.residual != xin || op.r_cs != xin_cs || op.out_act) { if (verbose && d.L == 0) fprintf(stderr, "mimi_match: rule %d fails at layer 0\n", 8); break; }
+        if (!mimi_is_mv(l1, D, F, MV_LAYERNORM) || !l1.alpha || l1.x != op.y || l1.x_cs != D || l1.residual || l1.out_scale || l1.out_act != 1) { if (verbose && d.L == 0) fprintf(stderr, "mimi_match: rule %d fails at layer 0\n", 9); break; }
+        if (!mimi_is_mv(l2, F, D, MV_PLAIN) || l2.x != l1.y || l2.x_cs != F || l2.residual != op.y || l2.r_cs != D || l2.out_act) { if (verbose && d.L == 0) fprintf(stderr, "mimi_match: rule %d fails at layer 0\n", 10); break; }
+        if (d.L == 0 && d.x_cs < D) { if (verbose && d.L == 0) fprintf(stderr, "mimi_match: rule %d fails at layer 0\n", 11); break; }
+        d.mv.push_back({ ip.w, ip.alpha, ip.beta, nullptr, ip.y, ip.x_out, ip.eps, { 0, 0, 0 } });
+        d.mv.push_back({ op.w, nullptr, nullptr, op.out_scale, op.y, nullptr, 0.f, { 0, 0, 0 } });
+        d.mv.push_back({ l1.w, l1.alpha, l1.beta, nullptr, l1.y, l1.x_out, l1.eps, { 0, 0, 0 } });
+        d.mv.push_back({ l2.w, nullptr, nullptr, l2.out_scale, l2.y, nullptr, 0.f, { 0, 0, 0 } });
+        d.at.push_back({ at.kcache, at.vcache, at.rot, at.mask, at.index, at.out });
+        d.weight_bytes += ip.M * ip.row_bytes + op.M * op.row_bytes + l1.M * l1.row_bytes + l2.M * l2.row_bytes;
+        xprev = l2.y; xprev_cs = D;
+        d.L++;
+        i += 5;
+    }
+    if (d.L < 2) return 0;
+    d.len = i;
+    return i;
+}
+static size_t mimi_attn_smem(const attn_args & at) { return ATTN_RING256_SMEM + (size_t) at.C * 4 + (size_t) at.T * at.D * 4 * 3 + (size_t) CH_NCW * 64 * 8 * 8 + 16 + (size_t) at.T * at.C * 4 + 64; }   // attn_smem_bytes, 8 waves
+static size_t mimi_smem_bytes(const mimi_desc & d) {
+    return (size_t) (2 * MIMI_F + 8) * 4 + 16 * 8 + sizeof(chain_ctl) + ((mimi_attn_smem(d.at0) + 15) & ~(size_t) 15) + d.mv.size() * sizeof(mimi_mv) + d.at.size() * sizeof(mimi_at);
+}
+static size_t mimi_tables_bytes(const mimi_desc & d) { return GGML_PAD(d.mv.size() * sizeof(mimi_mv) + d.at.size() * sizeof(mimi_at), 256); }
+static bool mimi_resident(const mimi_desc & d, int usable_cus) {
+    const size_t smem = mimi_smem_bytes(d);
+    if (smem > 159 * 1024) return false;
+    static bool granted = false;
+    if (!granted) { HIP_CHECK(hipFuncSetAttribute((const void *) mimi_tr_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024)); granted = true; }
+    static const int force = chain_env("MI355X_CHAIN_GRID_FORCE", 0);
+    int per_cu = 0;
+    return force || (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *) mimi_tr_kernel, CH_THREADS, smem) == hipSuccess && (long long) per_cu * usable_cus >= 256);
+}
+
 int k_chain_accept(const mv_args * mv, int n, int usable_cus) {
+    if (n >= 10 && ((!mv[0].special && mv[0].wtype == GGML_TYPE_F32 && mv[0].ncols == 2) || (mv[0].special == 1 && mv[0].attn->T == 2)) && chain_grid_for(usable_cus) == 256) {
+        mimi_desc d;
+        const int len = mimi_match(mv, n, d);
+        if (len > 0 && mimi_resident(d, usable_cus)) return len;
+    }
     if (n > 0 && (mv[0].special == 2 || (!mv[0].special && mv[0].wtype == GGML_TYPE_Q8_0)) && chain_grid_for(usable_cus) == 256) {
         n80_desc d;
         const int len = nest80_match(mv, n, d);
@@ -1253,6 +1347,10 @@ static size_t chain_state_bytes(int grid) { return 256 + 2 * (size_t) CH_XF_MAX 
 static size_t nest_tables_bytes(int n) { return GGML_PAD((size_t) n * (sizeof(nest_ph) + sizeof(nest_at)) + NEST_STEPS_MAX * sizeof(nest_st), 256); }
 static size_t nest_din_bytes() { return (size_t) NEST_STEPS_MAX * 1024 * 8; }
 size_t k_chain_ws_size(const mv_args * mv, int n, int usable_cus) {
+    if (n >= 10 && ((!mv[0].special && mv[0].wtype == GGML_TYPE_F32 && mv[0].ncols == 2) || (mv[0].special == 1 && mv[0].attn->T == 2))) {
+        mimi_desc d;
+        if (mimi_match(mv, n, d) == n) return mimi_tables_bytes(d) + chain_state_bytes(256);
+    }
     {
         n80_desc d;
         if (n > 0 && (mv[0].special == 2 || (!mv[0].special && mv[0].wtype == GGML_TYPE_Q8_0)) && nest80_match(mv, n, d) == n)
@@ -1396,6 +1494,41 @@ static bool nest_build(chain_plan * c, char * tables_dev, char * din_dev, int us
 chain_plan * k_chain_create(hipStream_t s, const mv_args * mv, int n, void * ws, unsigned * err, int usable_cus, bool allow_step_program) {
     chain_plan * c = new chain_plan;
     c->grid = chain_grid_for(usable_cus);
+    if (n >= 10 && ((!mv[0].special && mv[0].wtype == GGML_TYPE_F32 && mv[0].ncols == 2) || (mv[0].special == 1 && mv[0].attn->T == 2)) && c->grid == 256) {
+        mimi_desc d;
+        if (mimi_match(mv, n, d) == n) {
+            char * base = (char *) ws;
+            char * state = base + mimi_tables_bytes(d);
+            std::vector<char> tab(mimi_tables_bytes(d), 0);
+            memcpy(tab.data(), d.mv.data(), d.mv.size() * sizeof(mimi_mv));
+            memcpy(tab.data() + d.mv.size() * sizeof(mimi_mv), d.at.data(), d.at.size() * sizeof(mimi_at));
+            c->nest_tables.swap(tab);
+            HIP_CHECK(hipMemcpyAsync(base, c->nest_tables.data(), c->nest_tables.size(), hipMemcpyHostToDevice, s));
+            HIP_CHECK(hipMemsetAsync(state, 0, chain_state_bytes(256), s));
+            mimi_params & N = c->MM;
+            memset(&N, 0, sizeof(N));
+            N.P.phases = nullptr; N.P.n_phases = d.len;
+            N.P.launch_seq = (unsigned *) state; N.P.gbuf = (u64 *) (state + 256); N.P.cand = N.P.gbuf + 2 * CH_XF_MAX; N.P.err = err; N.P.delay = 0;
+            N.tables = (const u32x4 *) base;
+            N.n_layers = d.L; N.x_in = d.x_in; N.x_cs = d.x_cs;
+            N.at = d.at0; N.at.q = N.at.k = N.at.v = nullptr;
+            N.first_partial = d.first_partial ? 1 : 0;
+            if (d.first_partial) { N.q0 = d.at_first.q; N.k0 = d.at_first.k; N.v0 = d.at_first.v; }
+            N.q_off = d.q_off; N.k_off = d.k_off; N.v_off = d.v_off;
+            N.attn_smem = mimi_attn_smem(d.at0);
+            N.ring256 = chain_env("MI355X_ATTN_RING256", 1) && d.at0.C > 64 && d.at0.C <= 256 ? 1 : 0;   // (the stand-alone launch's choice, k_attn_decode)
+            {
+                static const int dflt[2] = { 30, 200 };   // tests/microbench/mimi_delay_sweep.sh (profiles/r05_mimi_delay_sweep.txt): flat from 20 / 100 up
+                N.delay[0] = dflt[0]; N.delay[1] = dflt[1];
+                if (const char * e = getenv("MI355X_MIMI_DELAY")) { int v[2]; const int got = sscanf(e, "%d,%d", &v[0], &v[1]); for (int i = 0; i < got && i < 2; i++) N.delay[i] = v[i] < 0 ? 0 : v[i] > 600 ? 600 : v[i]; }
+            }
+            c->P = N.P;
+            c->smem = mimi_smem_bytes(d);
+            c->mimi = true; c->n80_weight_bytes = d.weight_bytes; c->n80_len = d.len;
+            if (chain_env("MI355X_CHAIN_VERBOSE", 0)) fprintf(stderr, "chain engine: Mimi transformer program, %d layers, ring of %d, %zu bytes of LDS, %d plan steps\n", d.L, d.at0.C, c->smem, d.len);
+            return c;
+        }
+    }
     {
         n80_desc d;
         if (n > 0 && (mv[0].special == 2 || (!mv[0].special && mv[0].wtype == GGML_TYPE_Q8_0)) && c->grid == 256 && nest80_match(mv, n, d) == n) {
@@ -1477,11 +1610,12 @@ chain_plan * k_chain_create(hipStream_t s, const mv_args * mv, int n, void * ws,
 }
 void k_chain_free(chain_plan * c) { delete c; }
 int k_chain_length(const chain_plan * c) { return c->P.n_phases; }
-int64_t k_chain_weight_bytes(const chain_plan * c) { if (c->nest80) return c->n80_weight_bytes; int64_t b = 0; for (auto & ph : c->phases) b += (int64_t) ph.M * ph.row_bytes; return b; }
+int64_t k_chain_weight_bytes(const chain_plan * c) { if (c->nest80 || c->mimi) return c->n80_weight_bytes; int64_t b = 0; for (auto & ph : c->phases) b += (int64_t) ph.M * ph.row_bytes; return b; }
 
-bool k_chain_is_step_program(const chain_plan * c) { return c->nest || c->nest80; }
+bool k_chain_is_step_program(const chain_plan * c) { return c->nest || c->nest80 || c->mimi; }
 
 void k_chain_launch(hipStream_t s, const chain_plan * c) {
+    if (c->mimi) { mimi_tr_kernel<<<256, CH_THREADS, c->smem, s>>>(c->MM); return; }
     if (c->nest80) { depth_nest80_kernel<2048, 2048><<<256, CH_THREADS, c->smem, s>>>(c->N80); return; }
     if (c->nest) { depth_nest_kernel<256><<<c->grid, CH_THREADS, c->nest_smem, s>>>(c->NP); return; }
     // (the template argument only matters to phases with a compile-time shape; any other grid runs every phase from its descriptor)

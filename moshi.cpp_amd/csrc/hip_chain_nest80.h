@@ -422,7 +422,7 @@ __global__ void __launch_bounds__(CH_THREADS) depth_nest80_kernel(nest80_params 
                     at.q = nullptr; at.k = nullptr; at.v = nullptr;   // (element offsets come through gq)
                     for (int i = 0; i < N.delay[2]; i++) __builtin_amdgcn_s_sleep(1);
                     const attn_gqkv gq = { P.gbuf + (size_t) ((p - 1) & 1) * CH_XF_MAX, (int64_t) N.q_off, (int64_t) N.k_off, (int64_t) N.v_off, P.err };
-                    const attn_gout go = { P.gbuf + (size_t) (p & 1) * CH_XF_MAX, tag_base | (unsigned) (p + 1) };
+                    const attn_gout go = { P.gbuf + (size_t) (p & 1) * CH_XF_MAX, tag_base | (unsigned) (p + 1), 0 };
                     __syncthreads();
                     CH_STAMP(2);
                     attn_ring64_body<AT_GQKV | AT_GOUT>(at, at_smem, h, tag_base | (unsigned) p, gq, go);

@@ -1656,8 +1656,18 @@ static bool attn_ring64_shape(const attn_args & a) {
     static const int on = env_int("MI355X_ATTN_RING64", 1);
     return on && a.D == 64 && a.T == 1 && a.n_groups <= 1 && !a.write_only && a.C > 8 && a.C <= 64 && a.out_ts >= 0;
 }
+// one (head, query row) per workgroup of 8 waves, T <= 2 new tokens, ring of 65 .. 256 slots of 64 (the codec transformers): attn_ring256_body
+__global__ void __launch_bounds__(512) attn_ring256_kernel(attn_args a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    attn_ring256_body<AT_PLAIN>(a, smem, (int) blockIdx.x, (int) blockIdx.y);
+}
+static bool attn_ring256_shape(const attn_args & a) {
+    static const int on = env_int("MI355X_ATTN_RING256", 1);
+    return on && a.D == 64 && a.T >= 1 && a.T <= 2 && a.n_groups <= 1 && !a.write_only && a.C > 64 && a.C <= 256 && a.out_ts >= 0;
+}
 void k_attn_decode(hipStream_t s, const attn_args & a, void * ws, unsigned * err) {
     if (attn_ring64_shape(a)) { attn_ring64_kernel<<<a.H, 512, ATTN_RING64_SMEM, s>>>(a); return; }
+    if (attn_ring256_shape(a)) { attn_ring256_kernel<<<dim3((unsigned) a.H, (unsigned) a.T), 512, ATTN_RING256_SMEM, s>>>(a); return; }
     const int Tg = a.n_groups > 1 ? ATTN_MAX_T : a.T;   // rows per workgroup
     GGML_ASSERT(a.D % 8 == 0 && 64 % (a.D / 8) == 0 && a.D <= 512 && a.T >= 1 && Tg <= ATTN_MAX_T && Tg * a.D <= 2 * ATTN_NW_BASE * 64);
     GGML_ASSERT(a.n_groups <= 1 || a.n_groups == (a.T + 3) / 4);

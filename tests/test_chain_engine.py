@@ -112,6 +112,29 @@ def test_tts_shaped_depth_program_is_bit_identical_to_launches():
     assert_bit_identical(plain, prog, "tts-shaped Depth: step program vs launches")
 
 
+def test_mimi_transformer_program_is_bit_identical_to_launches():
+    # the codec's two 8-layer transformers (T = 2 latent frames per call, ring of 250) as one persistent launch each (hip_chain_mimi.h): LayerNorm + in_proj,
+    # attention on 16 owner workgroups running the stand-alone launch's own code, out_proj, LN + linear1 + GELU, linear2 as phases. 140 frames - the rings wrap at
+    # 125 and the mask's T = 2 quirk is crossed: encoder codes and decoder PCM must be those of one launch per node group, bit for bit.
+    cfg = hu.hot.moshika(hu.L)
+    cfg.enable_lm = 0
+    out = {}
+    for flags in (32, 16):
+        m = hu.Model("hip", cfg, seed=0, flags=flags)
+        rng = np.random.default_rng(2)
+        rec = []
+        for _ in range(140):
+            codes = m.mimi_encode((rng.standard_normal(1920) * 0.1).astype(np.float32))
+            rec.append((codes, m.mimi_decode(codes).copy()))
+        out[flags] = (rec, m.stats())
+        m.free()
+    assert out[32][1].chain_step_programs_in_last_plan == 1 and out[32][1].chained_matvecs_in_last_plan >= 35, "the decoder transformer did not take the program"
+    assert out[16][1].chained_matvecs_in_last_plan == 0
+    for i, (a, b) in enumerate(zip(out[32][0], out[16][0])):
+        assert a[0] == b[0], f"frame {i}: codes differ"
+        assert np.array_equal(a[1], b[1]), f"frame {i}: PCM differs by {np.abs(a[1] - b[1]).max():.3e}"
+
+
 def test_chain_replayed_from_a_hipgraph_many_times_stays_identical():
     # tags are derived from a launch counter kept on the device: 40 replays of the captured launch against 40 eager unchained runs
     cfg = depth_at_real_width(dep_q=3, layers=1, n_q=6)
