@@ -141,6 +141,7 @@ GGML_API void ggml_backend_mi355x_get_kernel_profile(ggml_backend_t backend, str
 // bit flags, default 0: 1 = disable fusion (one kernel per node), 2 = disable hipGraph capture, 4 = disable upload batching,
 // 8 = profile mode (eager launches, per-dispatch HIP events on matvec_q4k_kernel), 16 = no persistent chain launches (one launch per mat-vec),
 // 32 = persistent chain launches on even when the MI355X_CHAIN environment variable says 0 (default: on),
+// 64 = every codec convolution keeps its im2col launch (default: the launch producing a convolution's input also writes its F16 im2col panel),
 // 512 = the Temporal attention stays a launch of its own (default: it runs as the tail of its in_proj launch, inproj_attn_kernel),
 // 1024 = chain launches always take the descriptor-driven kernel (default: the Depth transformer's steps run as a compile-time step program)
 GGML_API void ggml_backend_mi355x_set_flags(ggml_backend_t backend, int flags);

@@ -52,7 +52,16 @@ struct attn_split_ws { unsigned long long * gscores; unsigned long long * gpart;
 #define AT_GQKV  2
 #define AT_GOUT  4   // the output row also leaves as {tag, value} granules at go.out[h * D + j] (T = 1, unsplit): the next phase of a persistent launch polls it
 struct attn_gqkv { const unsigned long long * in; int64_t qoff, koff, voff; unsigned * err; };
-struct attn_gout { unsigned long long * out; unsigned tag; int64_t ts; };   // granule (t, h, j) at out[t * ts + h * D + j]
+struct attn_gout { unsigned long long * out; unsigned tag; int64_t ts;      // granule (t, h, j) at out[t * ts + h * D + j]
+#if defined(CH_LOG)
+                   unsigned long long * log;                                  // diagnostic build: stage stamps of attn_ring256_body (10 ns ticks) at log[11 ..]
+#endif
+};
+#if defined(CH_LOG)
+#define R256_STAMP(i) do { if (GOUT && go.log && threadIdx.x == 0) { unsigned long long t_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); go.log[i] = t_; } } while (0)
+#else
+#define R256_STAMP(i) do {} while (0)
+#endif
 template <bool SPLIT, int NWA, int MODE>
 __device__ __forceinline__ void attn_decode_body(const attn_args & a_in, const attn_split_ws & w, char * smem, const int h, const int s_idx, const int group_y,
                                                  const unsigned gtag = 0u, const attn_gqkv gq = attn_gqkv(), const attn_gout go = attn_gout()) {
@@ -725,6 +734,7 @@ __device__ __forceinline__ void attn_ring64_body(const attn_args & a, char * sme
         a.out[(int64_t) h * D + tid] = (float) tot;
         if (GOUT) __hip_atomic_store(go.out + (int64_t) h * D + tid, ((unsigned long long) go.tag << 32) | (unsigned long long) __float_as_uint((float) tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    R256_STAMP(15);
     __syncthreads();
 }
 
@@ -798,8 +808,10 @@ __device__ __forceinline__ void attn_ring256_body(const attn_args & a, char * sm
             ((uint16_t *) (a.kcache + (int64_t) h * a.k_nb2 + (int64_t) slot * a.k_nb1))[j] = kb;
             ((uint16_t *) (a.vcache + (int64_t) h * a.v_nb2 + (int64_t) slot * a.v_nb1))[j] = vb;
         }
+        R256_STAMP(11);
     }
     __syncthreads();
+    R256_STAMP(12);
     // ---- scores of the four passes
     float qv[8];
 #pragma unroll
@@ -831,6 +843,7 @@ __device__ __forceinline__ void attn_ring256_body(const attn_args & a, char * sm
         if (lane == 0) wmax[wave] = fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
     }
     __syncthreads();
+    R256_STAMP(13);
     float gmax = wmax[0];
 #pragma unroll
     for (int w = 1; w < 8; w++) gmax = fmaxf(gmax, wmax[w]);
@@ -865,6 +878,7 @@ __device__ __forceinline__ void attn_ring256_body(const attn_args & a, char * sm
         for (int e = 0; e < 8; e++) dst[e] = o8[e];
     }
     __syncthreads();
+    R256_STAMP(14);
     if (tid < D) {
         double tot = 0;
 #pragma unroll 8
@@ -872,5 +886,6 @@ __device__ __forceinline__ void attn_ring256_body(const attn_args & a, char * sm
         a.out[(int64_t) t * a.out_ts + (int64_t) h * D + tid] = (float) tot;
         if (GOUT) __hip_atomic_store(go.out + (int64_t) t * go.ts + (int64_t) h * D + tid, ((unsigned long long) go.tag << 32) | (unsigned long long) __float_as_uint((float) tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    R256_STAMP(15);
     __syncthreads();
 }

@@ -323,6 +323,7 @@ struct plan_t {
     std::vector<std::pair<void *, size_t>> workspaces;
     std::vector<std::unique_ptr<attn_args>> attn_copies;
     std::vector<std::unique_ptr<lowrank_embed_args>> lowrank_copies;
+    std::vector<std::unique_ptr<conv_scatter>> scatter_slots;   // see emitter::scatter_of
     std::vector<const ggml_backend_buffer *> buffers;   // every buffer a node / leaf of the planned graph lives in: freeing one orphans the plan
     uint64_t orphan_seq = 0;                            // != 0: a buffer of the planned graph has been freed since (see evict_plans_of_buffer)
     hipGraph_t graph = nullptr;
@@ -513,6 +514,11 @@ struct emitter {
         return w;
     }
     void push(step_fn f) { p->steps.push_back(pstep(std::move(f))); }
+    // Codec convolutions without an im2col launch (match_conv): the output tensor of a conv / transposed-conv group -> a slot its launch reads when it runs.
+    // A later conv whose input that tensor is claims the slot (fills it in): the producing launch then also writes the consumer's F16 im2col panel
+    // (conv_scatter, hip_common.h), and the consumer starts from the panel.
+    std::map<const ggml_tensor *, conv_scatter *> scatter_of;
+    conv_scatter * scatter_slot(const ggml_tensor * out) { p->scatter_slots.emplace_back(new conv_scatter()); memset(p->scatter_slots.back().get(), 0, sizeof(conv_scatter)); scatter_of[out] = p->scatter_slots.back().get(); return scatter_of[out]; }
 };
 
 static bool is_qblock(enum ggml_type t) { return t == GGML_TYPE_Q4_K || t == GGML_TYPE_Q8_0 || t == GGML_TYPE_Q4_0; }
@@ -1138,7 +1144,7 @@ struct step_group { std::vector<step_fn> steps; int emit_pos; std::vector<int> m
 
 static bool is_elu(const ggml_tensor * t) { return t->op == GGML_OP_UNARY && t->op_params[0] == GGML_UNARY_OP_ELU && t->view_src == NULL; }
 
-static bool match_conv(const analysis & an, int pos, step_group & grp) {
+static bool match_conv(const analysis & an, int pos, step_group & grp, emitter & em) {
     const ggml_tensor * mm = an.g->nodes[pos];
     if (mm->op != GGML_OP_MUL_MAT) return false;
     const ggml_tensor * ra = mm->src[0], * rw = mm->src[1];
@@ -1198,12 +1204,31 @@ static bool match_conv(const analysis & an, int pos, step_group & grp) {
     d_out.ne[0] = OL; d_out.ne[1] = Cout; d_out.ne[2] = d_out.ne[3] = 1;
     float * pv = prev ? (float *) prev->data : nullptr;
     grp.steps.clear();
-    grp.steps.push_back([=](hipStream_t s) { k_stream_im2col(s, d_im, pv, TP, d_x, Kw, s0, pre_elu); });
     if (TP > 0) {   // the tail update rides on the product kernel (it must follow the im2col, which reads the old tail)
         epi.tail_prev = pv; epi.tail_TP = TP; epi.tail_pre_elu = pre_elu; epi.tail_L = (int) xin->ne[0]; epi.tail_C = Cin;
         epi.tail_x = (const char *) xin->data; epi.tail_nb0 = (int64_t) xin->nb[0]; epi.tail_nb1 = (int64_t) xin->nb[1];
     }
-    grp.steps.push_back([=](hipStream_t s) { k_mul_mat(s, d_out, d_im, d_w, nullptr, &epi); });
+    // Without an im2col launch: where x is the output of a conv / transposed-conv group planned before this one, THAT launch writes this conv's F16 operand
+    // (the values stream_im2col_kernel would store, at the same places of a plan-owned panel): same products in the same order, bit-identical. Flag 64 or
+    // MI355X_CONV_SCATTER=0 keep the im2col launch. (The gathering form - the product reading (tail | act(x)) itself - was built and measured slower than the
+    // launch it removes: profiles/r05_ab_implicit_im2col_gather.txt.)
+    static const int scatter_on = getenv("MI355X_CONV_SCATTER") ? atoi(getenv("MI355X_CONV_SCATTER")) : 1;
+    bool fused = false;
+    tdesc d_a = d_im;
+    if (scatter_on && !(em.c->flags & 64)) {
+        auto it = em.scatter_of.find(xin);
+        if (it != em.scatter_of.end() && it->second->panel == nullptr && xin->nb[0] == 4 && (int64_t) xin->nb[1] == xin->ne[0] * 4 && d_im.nb[0] == 2 && d_im.nb[1] == d_im.ne[0] * 2 &&
+            OL == d_im.ne[1] && (int64_t) Kw * Cin == d_im.ne[0] && (int64_t) (OL - 1) * s0 + Kw <= TP + xin->ne[0]) {
+            conv_scatter * sc = it->second;
+            sc->panel = (uint16_t *) em.ws((size_t) d_im.ne[0] * d_im.ne[1] * 2 + 256);
+            sc->prev = pv; sc->K = (int) d_im.ne[0]; sc->Kw = Kw; sc->s0 = s0; sc->TP = TP; sc->M = (int) OL; sc->C = Cin; sc->elu = pre_elu;
+            d_a.data = (char *) sc->panel;
+            fused = true;
+        }
+    }
+    if (!fused) grp.steps.push_back([=](hipStream_t s) { k_stream_im2col(s, d_im, pv, TP, d_x, Kw, s0, pre_elu); });
+    const conv_scatter * slot = em.scatter_slot(out);
+    grp.steps.push_back([=](hipStream_t s) { mm_epilogue e = epi; e.sc = *slot; k_mul_mat(s, d_out, d_a, d_w, nullptr, &e); });
     grp.members = members;
     grp.emit_pos = pos_of(an, out);
     return true;
@@ -1268,9 +1293,10 @@ static bool match_convtr(const analysis & an, int pos, step_group & grp, emitter
     float * pv = (float *) t.prev->data;
     const float * bias = t.bias;
     grp.steps.clear();
+    const conv_scatter * slot = ggml_is_contiguous(t.out) && t.out->type == GGML_TYPE_F32 ? em.scatter_slot(t.out) : nullptr;
     grp.steps.push_back([=](hipStream_t s) {
         const int nsplit = k_conv_transpose_1d_partial(s, d_w, d_x, ws, pre_elu);
-        k_convtr_finish(s, d_out, pv, bias, ws, K, OC, L, s0, nsplit);
+        k_convtr_finish(s, d_out, pv, bias, ws, K, OC, L, s0, nsplit, slot);
     });
     grp.members = members;
     grp.emit_pos = pos_of(an, t.out);
@@ -1581,7 +1607,7 @@ static plan_t * build_plan(hip_ctx * c, ggml_cgraph * g, bool keep = true) {
         for (int i = 0; i < g->n_nodes; i++) {
             if (an.skip[(size_t) i]) continue;
             step_group grp;
-            if (g->nodes[i]->op == GGML_OP_MUL_MAT) { if (!match_conv(an, i, grp)) continue; }
+            if (g->nodes[i]->op == GGML_OP_MUL_MAT) { if (!match_conv(an, i, grp, em)) continue; }
             else if (g->nodes[i]->op == GGML_OP_CONV_TRANSPOSE_1D) { if (!match_convtr(an, i, grp, em)) continue; }
             else if (g->nodes[i]->op == GGML_OP_ARGMAX) { if (!match_vq_level(an, i, grp, em)) continue; }
             else if (g->nodes[i]->op == GGML_OP_CONCAT) { if (!match_dw_convtr(an, i, grp)) continue; }

@@ -173,7 +173,7 @@ __global__ void __launch_bounds__(CH_THREADS) mimi_tr_kernel(mimi_params N) {
 #pragma unroll
         for (int c = 0; c < 2; c++) st_granule(go + (size_t) c * M + row, tag_out, __float_as_uint(v[c]));
     };
-    constexpr int grid = G;
+    [[maybe_unused]] constexpr int grid = G;   // (CH_STAMP)
     const int owner_idx = wg >> 4;
     const bool owner = (wg & 15) == (owner_idx & 7);   // workgroup 16 i + (i & 7) runs attention part i = 2 h + t
 
@@ -224,7 +224,10 @@ __global__ void __launch_bounds__(CH_THREADS) mimi_tr_kernel(mimi_params N) {
                 at.row_split = 1; at.n_groups = 0; at.write_only = 0;
                 const attn_split_ws w0 = { nullptr, nullptr, nullptr, 1, P.err, 0, 1 << 30, 1 << 30 };
                 const attn_gqkv gq = { P.gbuf + (size_t) ((p - 1) & 1) * CH_XF_MAX, (int64_t) N.q_off, (int64_t) N.k_off, (int64_t) N.v_off, P.err };
-                const attn_gout go = { P.gbuf + (size_t) (p & 1) * CH_XF_MAX, tag_base | (unsigned) (p + 1), (int64_t) D };
+                attn_gout go = { P.gbuf + (size_t) (p & 1) * CH_XF_MAX, tag_base | (unsigned) (p + 1), (int64_t) D };
+#if defined(CH_LOG)
+                go.log = wg == 0 && p < 512 ? &g_ch_log[0][p][0] : nullptr;
+#endif
                 __syncthreads();
                 if (l == 0 && N.first_partial) {
                     at.q = N.q0; at.k = N.k0; at.v = N.v0;

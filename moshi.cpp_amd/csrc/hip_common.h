@@ -55,17 +55,23 @@ void k_timestep_embedding(hipStream_t s, tdesc dst, tdesc ts, int dim, int max_p
 // (q8_K / q8_0 / f16 / bf16) into `ws` (size from k_mul_mat_ws_size), then dotted
 size_t k_mul_mat_ws_size(const struct ggml_tensor * a, const struct ggml_tensor * b);
 // optional fused epilogue of the dense product: dst[m, n] = residual[m, n] + (dot + bias[n])  (ggml order: add(y, bias) then add(u, y))
-//   side job of workgroup 0 (streaming conv): prev <- last TP samples of concat(prev, act(x)), which the preceding im2col has
-//   finished reading (moshi_streaming_conv_1d's tail copy, conv.h:60-75)
+//   side job of an extra workgroup (streaming conv): prev <- last TP samples of concat(prev, act(x)), which the preceding im2col (or the
+//   producer's scatter, conv_scatter) has finished reading (moshi_streaming_conv_1d's tail copy, conv.h:60-75)
+// The NEXT convolution's im2col panel filled by the launch that produces its input (no im2col launch between the two): every output element (position l,
+// channel c) of the producing launch also lands, as f16(act(value)), at panel[ow * K + c * Kw + kk] for each (ow, kk) with ow * s0 + kk == l + TP - what
+// stream_im2col_kernel would have written from the finished tensor - and the producing launch's extra workgroup writes the columns that come from the
+// consumer's carried tail (ow * s0 + kk < TP: f16(prev[..]), the tail as the consumer's previous launch left it). panel == nullptr: nothing to do.
+struct conv_scatter { uint16_t * panel; const float * prev; int K, Kw, s0, TP, M, C, elu, pad; };
 struct mm_epilogue { const float * bias; const char * residual; int64_t res_nb0, res_nb1;
-                     float * tail_prev; int tail_TP, tail_pre_elu, tail_L, tail_C; const char * tail_x; int64_t tail_nb0, tail_nb1; };
+                     float * tail_prev; int tail_TP, tail_pre_elu, tail_L, tail_C; const char * tail_x; int64_t tail_nb0, tail_nb1;
+                     conv_scatter sc; };
 void k_mul_mat(hipStream_t s, tdesc dst, tdesc a, tdesc b, void * ws, const mm_epilogue * epi = nullptr);
 // streaming conv1d helpers (moshi_streaming_conv_1d, conv.h:50-96): F16 im2col straight from (carried tail, new samples) with an
 // optional ELU on the new samples, and the tail update
 void k_stream_im2col(hipStream_t s, tdesc dst, const float * prev, int TP, tdesc x, int Kw, int s0, int pre_elu);
 void k_conv_tail(hipStream_t s, float * prev, int TP, tdesc x, int pre_elu);
 // streaming conv_transpose_1d tail (conv.h:282-309): overlap-add with the carried partial, state update, bias, window
-void k_convtr_finish(hipStream_t s, tdesc out, float * prev, const float * bias, const void * ws, int K, int OC, int L, int s0, int nsplit);
+void k_convtr_finish(hipStream_t s, tdesc out, float * prev, const float * bias, const void * ws, int K, int OC, int L, int s0, int nsplit, const conv_scatter * sc = nullptr);
 // depthwise transposed conv of one input frame + streaming tail: y[k, c] = x[c] * w[k, c]
 void k_dw_convtr_frame(hipStream_t s, float * out, float * prev, const float * bias, const char * x, int64_t x_cs, const char * w, int64_t w_cs, int K, int PT, int C);
 int  k_conv_transpose_1d_partial(hipStream_t s, tdesc w, tdesc x, void * ws, int pre_elu);   // returns the number of ic splits written to ws

@@ -6,6 +6,7 @@
 // for norms / soft_max / sums / float dots, activations rounded to the weight's dot type in mul_mat.
 #include "hip_common.h"
 #include "hip_device.h"
+#include <type_traits>
 
 #define BLOCK 256
 
@@ -637,11 +638,35 @@ void k_conv_transpose_1d(hipStream_t s, tdesc dst, tdesc w, tdesc x, int s0, voi
     convtr_overlap_add_kernel<<<nblocks(n_out), BLOCK, 0, s>>>(dst, (const double *) ws, OC * K, L, K, s0, nsplit, n_out);
 }
 
+// ---- conv_scatter (hip_common.h): the next convolution's im2col panel written by this launch ----
+// one finished output element (position l, channel c)
+__device__ __forceinline__ void conv_scatter_elem(const conv_scatter & sc, int l, int c, float v) {
+    if (sc.elu) v = v > 0.f ? v : expm1f(v);
+    const uint16_t h = f2h(v);
+    const int t = l + sc.TP;
+    for (int kk = t % sc.s0; kk < sc.Kw; kk += sc.s0) {
+        const int ow = (t - kk) / sc.s0;
+        if (kk <= t && ow < sc.M) sc.panel[(int64_t) ow * sc.K + c * sc.Kw + kk] = h;
+    }
+}
+// the panel columns that come from the consumer's carried tail: (ow, kk) with ow * s0 + kk < TP, every channel
+__device__ __forceinline__ void conv_scatter_tail(const conv_scatter & sc) {
+    const int n = sc.C * sc.TP;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const int c = i / sc.TP, t = i - c * sc.TP;
+        const uint16_t h = f2h(sc.prev[i]);
+        for (int kk = t % sc.s0; kk < sc.Kw; kk += sc.s0) {
+            const int ow = (t - kk) / sc.s0;
+            if (kk <= t && ow < sc.M) sc.panel[(int64_t) ow * sc.K + c * sc.Kw + kk] = h;
+        }
+    }
+}
 // streaming tail of conv_transpose_1d: y = convtr(x); y[:PT] += prev[-PT:]; prev = y; out = (y + bias)[: len - PT]
 // (moshi_streaming_conv_transpose_1d, conv.h:282-309). Thread t (< L*s0) also owns position t + L*s0 when t < PT, so the old
 // tail value it needs is read before the same thread overwrites it.
-__global__ void convtr_finish_kernel(tdesc out, float * prev, const float * bias, const double * P, int K, int OC, int L, int s0, int nsplit) {
+__global__ void convtr_finish_kernel(tdesc out, float * prev, const float * bias, const double * P, int K, int OC, int L, int s0, int nsplit, conv_scatter sc) {
     const int N = OC * K, OLf = (L - 1) * s0 + K, PT = K - s0, keep = OLf - PT;   // keep == L * s0
+    if (sc.panel && sc.TP > 0 && blockIdx.x == gridDim.x - 1) { conv_scatter_tail(sc); return; }   // (the extra workgroup)
     const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (int64_t) keep * OC) return;
     const int t = (int) (i % keep), oc = (int) (i / keep);
@@ -699,12 +724,17 @@ __global__ void convtr_finish_kernel(tdesc out, float * prev, const float * bias
     }
     pv[t] = y;
     if (has2) pv[t + keep] = y2;
-    *(float *) at(out, t, oc, 0, 0) = bias ? y + bias[oc] : y;
+    const float yo = bias ? y + bias[oc] : y;
+    *(float *) at(out, t, oc, 0, 0) = yo;
+    if (sc.panel) conv_scatter_elem(sc, t, oc, yo);   // the next conv's im2col panel (hip_common.h conv_scatter)
 }
-void k_convtr_finish(hipStream_t s, tdesc out, float * prev, const float * bias, const void * ws, int K, int OC, int L, int s0, int nsplit) {
+void k_convtr_finish(hipStream_t s, tdesc out, float * prev, const float * bias, const void * ws, int K, int OC, int L, int s0, int nsplit, const conv_scatter * sc) {
     GGML_ASSERT(K - s0 <= L * s0 && "tail longer than the new window is not expected on this path");
     const int64_t n = (int64_t) L * s0 * OC;
-    convtr_finish_kernel<<<nblocks(n), BLOCK, 0, s>>>(out, prev, bias, (const double *) ws, K, OC, L, s0, nsplit);
+    conv_scatter scv;
+    memset(&scv, 0, sizeof(scv));
+    if (sc) scv = *sc;
+    convtr_finish_kernel<<<nblocks(n) + (scv.panel && scv.TP > 0 ? 1 : 0), BLOCK, 0, s>>>(out, prev, bias, (const double *) ws, K, OC, L, s0, nsplit, scv);
 }
 
 // depthwise variant for one input frame: y[k, c] = x[c] * w[k, c]; y[:PT] += prev[K-PT:]; prev = y; out = (y + bias)[:K-PT]
@@ -870,28 +900,46 @@ __global__ void convert_rows_kernel(tdesc b, int vt, char * ws, int64_t row_byte
     }
 }
 
-// one wave per output element; lanes stride the K dimension (in blocks for quantised types)
-// streaming-conv tail update folded into the product kernel (workgroup 0 only; reads complete before the writes per channel)
-__device__ __forceinline__ void mm_tail_job(const mm_epilogue & e) {
-    if (e.tail_prev == nullptr || blockIdx.x != 0) return;
-    const int TP = e.tail_TP, L = e.tail_L;
-    for (int ci = threadIdx.x; ci < e.tail_C; ci += blockDim.x) {
-        float v[32];
-#pragma unroll
-        for (int j = 0; j < 32; j++) {
-            if (j < TP) {
-                const int l = L + j;   // index into the concatenation (prev | x)
-                if (l < TP) v[j] = e.tail_prev[l + (int64_t) ci * TP];
-                else { const float t = *(const float *) (e.tail_x + (int64_t) (l - TP) * e.tail_nb0 + (int64_t) ci * e.tail_nb1); v[j] = e.tail_pre_elu ? (t > 0.f ? t : expm1f(t)) : t; }
-            }
+// streaming-conv tail update folded into the product launch: prev <- last TP positions of (prev | act(x)), per channel. An EXTRA workgroup at the end of the
+// grid does it beside the tiles (the operand was materialised before this launch: nobody reads the old tail any more), element (channel, j) per thread
+// through LDS in rounds of whole channels - loads (no branch in front of any: the per-channel loop of 32 conditional loads this replaces was a chain of up
+// to TP serial round trips on workgroup 0, 8-12 us on the launch's critical path), barrier, ELU where the element is a new sample, stores.
+#define MM_TAIL_LDS 4096
+__device__ __forceinline__ void mm_tail_update(const mm_epilogue & e) {
+    __shared__ float mm_tail_buf[MM_TAIL_LDS];
+    const int TP = e.tail_TP, L = e.tail_L, C = e.tail_C, cpr = MM_TAIL_LDS / TP;
+    for (int c0 = 0; c0 < C; c0 += cpr) {
+        const int n = (C - c0 < cpr ? C - c0 : cpr) * TP;
+#pragma unroll 4
+        for (int i = threadIdx.x; i < n; i += blockDim.x) {
+            const int cl = i / TP, j = i - cl * TP, l = L + j;   // index into the concatenation (prev | x)
+            const int64_t ci = c0 + cl;
+            const float * src = l < TP ? e.tail_prev + l + ci * TP : (const float *) (e.tail_x + (int64_t) (l - TP) * e.tail_nb0 + ci * e.tail_nb1);
+            mm_tail_buf[i] = *src;
         }
-#pragma unroll
-        for (int j = 0; j < 32; j++) if (j < TP) e.tail_prev[j + (int64_t) ci * TP] = v[j];
+        __syncthreads();
+        for (int i = threadIdx.x; i < n; i += blockDim.x) {
+            const int cl = i / TP, j = i - cl * TP;
+            float v = mm_tail_buf[i];
+            if (e.tail_pre_elu && L + j >= TP) v = v > 0.f ? v : expm1f(v);
+            e.tail_prev[(int64_t) c0 * TP + i] = v;
+        }
+        __syncthreads();
     }
 }
+// true: this workgroup is the extra one (it has done the side jobs and must leave)
+__device__ __forceinline__ bool mm_tail_block(const mm_epilogue & e) {
+    const bool tail = e.tail_prev != nullptr, stail = e.sc.panel != nullptr && e.sc.TP > 0;
+    if (!(tail || stail) || blockIdx.x != gridDim.x - 1) return false;
+    if (stail) conv_scatter_tail(e.sc);
+    if (tail) mm_tail_update(e);
+    return true;
+}
+static int mm_tail_extra(const mm_epilogue & e) { return e.tail_prev != nullptr || (e.sc.panel != nullptr && e.sc.TP > 0) ? 1 : 0; }
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 __global__ void mul_mat_kernel(tdesc dst, tdesc a, tdesc b, const char * ws, int64_t ws_row_bytes, int vt, int64_t total, mm_epilogue epi) {
-    mm_tail_job(epi);
+    if (mm_tail_block(epi)) return;
     const int lane = threadIdx.x & 63;
     const int64_t o = (int64_t) blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (o >= total) return;
@@ -941,20 +989,20 @@ __global__ void mul_mat_kernel(tdesc dst, tdesc a, tdesc b, const char * ws, int
         if (epi.bias) result = result + epi.bias[n];
         if (epi.residual) result = *(const float *) (epi.residual + m * epi.res_nb0 + n * epi.res_nb1) + result;
         *(float *) at(dst, m, n, i2, i3) = result;
+        if (epi.sc.panel) conv_scatter_elem(epi.sc, (int) m, (int) n, result);
     }
 }
 
 // ---- dense f16 x f16 contraction on the matrix cores (Mimi conv stacks: dst[ow, co] = sum_k A[ow][k] * B[co][k]) ----
 // Both operands are K-contiguous, which is exactly the 16x16x32 MFMA fragment order: lane l holds 8 consecutive k
 // of row (l & 15), so fragments are plain 16-byte global loads - no LDS, one wave per 16x16 output tile.
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 // Few tiles (deep conv layers at 12.5-50 Hz) would leave the chip empty and the K loop latency-bound, so a tile can be split
 // over SK waves of the workgroup (contiguous K slices, partial tiles summed through LDS in slice order); the K loop requests
 // four fragment pairs before the first MFMA.
 __global__ void __launch_bounds__(1024) mul_mat_f16_mfma_kernel(tdesc dst, tdesc a, tdesc b, int mt, int nt, int SK, int TPW, mm_epilogue epi) {
     __shared__ f32x4 red[16][64];
-    mm_tail_job(epi);
+    if (mm_tail_block(epi)) return;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int slice = wave % SK, tw = wave / SK;
     const int tile = blockIdx.x * TPW + tw;
@@ -980,62 +1028,97 @@ __global__ void __launch_bounds__(1024) mul_mat_f16_mfma_kernel(tdesc dst, tdesc
         const f16x8 bv = *(const f16x8 *) (bp + st * 64);
         acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, bv, acc, 0, 0, 0);
     }
+    bool writer = live;
     if (SK > 1) {
         if (slice > 0) red[wave][lane] = acc;
         __syncthreads();
-        if (slice > 0) return;
-        for (int sl = 1; sl < SK; sl++) { const f32x4 o = red[wave + sl][lane]; acc[0] += o[0]; acc[1] += o[1]; acc[2] += o[2]; acc[3] += o[3]; }
+        if (slice > 0) writer = false;
+        else for (int sl = 1; sl < SK; sl++) { const f32x4 o = red[wave + sl][lane]; acc[0] += o[0]; acc[1] += o[1]; acc[2] += o[2]; acc[3] += o[3]; }
     }
-    if (!live) return;
-    // C[row = 4*(lane>>4) + j][col = lane & 15]: rows are `a` rows (dst dim 0), cols are `b` rows (dst dim 1)
-    float * out = (float *) (dst.data + (int64_t) (tn * 16 + r) * dst.nb[1]) + tm * 16 + kq * 4;
-    if (epi.bias) { const float bv = epi.bias[tn * 16 + r]; acc[0] = acc[0] + bv; acc[1] = acc[1] + bv; acc[2] = acc[2] + bv; acc[3] = acc[3] + bv; }
-    if (epi.residual) {
-        const char * rp = epi.residual + (int64_t) (tn * 16 + r) * epi.res_nb1 + (int64_t) (tm * 16 + kq * 4) * epi.res_nb0;
+    if (writer) {
+        // C[row = 4*(lane>>4) + j][col = lane & 15]: rows are `a` rows (dst dim 0), cols are `b` rows (dst dim 1)
+        float * out = (float *) (dst.data + (int64_t) (tn * 16 + r) * dst.nb[1]) + tm * 16 + kq * 4;
+        if (epi.bias) { const float bv = epi.bias[tn * 16 + r]; acc[0] = acc[0] + bv; acc[1] = acc[1] + bv; acc[2] = acc[2] + bv; acc[3] = acc[3] + bv; }
+        if (epi.residual) {
+            const char * rp = epi.residual + (int64_t) (tn * 16 + r) * epi.res_nb1 + (int64_t) (tm * 16 + kq * 4) * epi.res_nb0;
+    #pragma unroll
+            for (int j = 0; j < 4; j++) acc[j] = *(const float *) (rp + (int64_t) j * epi.res_nb0) + acc[j];
+        }
+        *(f32x4 *) out = acc;
+        if (epi.sc.panel) {
 #pragma unroll
-        for (int j = 0; j < 4; j++) acc[j] = *(const float *) (rp + (int64_t) j * epi.res_nb0) + acc[j];
+            for (int j = 0; j < 4; j++) conv_scatter_elem(epi.sc, tm * 16 + kq * 4 + j, tn * 16 + r, acc[j]);
+        }
     }
-    *(f32x4 *) out = acc;
 }
 
-// few activation rows (M = a.ne1 <= 8) against many weight rows in `b`: one wave per b row, b read once; four 16-byte chunks
-// of the b row are requested before any arithmetic
-__global__ void __launch_bounds__(256) mul_mat_smallm_kernel(tdesc dst, tdesc a, tdesc b, int M, int N, mm_epilogue epi) {
-    mm_tail_job(epi);
+// few activation rows (M = a.ne1 <= 8) against many weight rows in `b`: one wave per b row, b read once. The M activation rows (M x K halves, the im2col
+// matrix) are staged in LDS first, by loads that are all in flight together: read from memory
+// chunk by chunk inside the dot loop, behind `if (m < M)`, each was a serial round trip to a matrix another launch had just written (48 us for the encoder's
+// 512 -> 1024 stride-8 conv, r05 kernel trace). The row's first 8 weight chunks are requested before the staging. Per lane the products are added in the old
+// order (chunk c = k / 512 ascending, 8 halves each, in double; chunks past K contribute nothing), then the wave sum.
+#define SMALLM_NW 8
+__global__ void __launch_bounds__(SMALLM_NW * 64) mul_mat_smallm_kernel(tdesc dst, tdesc a, tdesc b, int M, int N, mm_epilogue epi) {
+    extern __shared__ __attribute__((aligned(16))) char smallm_lds[];
+    _Float16 * As = (_Float16 *) smallm_lds;   // [M][K]
+    if (mm_tail_block(epi)) return;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int n = blockIdx.x * 4 + wave;
-    if (n >= N) return;
-    const int K = (int) a.ne[0];
-    const char * bp = b.data + (int64_t) n * b.nb[1];
+    const int n = blockIdx.x * SMALLM_NW + wave, nc = n < N ? n : N - 1;
+    const int K = (int) a.ne[0], nchunks = (K + 511) / 512, K8 = K / 8;
+    const char * bp = b.data + (int64_t) nc * b.nb[1];
+    f16x8 bv[8];
+    auto request = [&](int c0) {
+#pragma unroll
+        for (int u = 0; u < 8; u++) { const int kk = (c0 + u) * 512 + lane * 8; bv[u] = *(const f16x8 *) (bp + (kk < K ? kk : lane * 8) * 2); }   // (no load behind a branch; chunks past K are skipped below)
+    };
+    request(0);
+    auto stage = [&](auto fetch) {
+        for (int i0 = threadIdx.x; i0 < M * K8; i0 += SMALLM_NW * 64 * 4) {
+            f16x8 t[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int idx = i0 + u * SMALLM_NW * 64;
+                const int ic = idx < M * K8 ? idx : M * K8 - 1, m = ic / K8, k8 = ic - m * K8;
+                t[u] = fetch(m, k8);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) { const int idx = i0 + u * SMALLM_NW * 64; if (idx < M * K8) *(f16x8 *) (As + (int64_t) idx * 8) = t[u]; }
+        }
+    };
+    stage([&](int m, int k8) { return *(const f16x8 *) (a.data + (int64_t) m * a.nb[1] + k8 * 16); });
+    __syncthreads();
     double acc[8];
 #pragma unroll
     for (int m = 0; m < 8; m++) acc[m] = 0;
-    for (int k0 = lane * 8; k0 < K; k0 += 2048) {
-        f16x8 bv[4];
-        int kk[4];
+    for (int c0 = 0; c0 < nchunks; c0 += 8) {
+        if (c0 > 0) request(c0);
 #pragma unroll
-        for (int u = 0; u < 4; u++) { kk[u] = k0 + u * 512; const bool ok = kk[u] < K; if (!ok) kk[u] = lane * 8; bv[u] = *(const f16x8 *) (bp + kk[u] * 2); if (!ok) bv[u] = (f16x8) (_Float16) 0; }
+        for (int u = 0; u < 8; u++) {
+            const int kk = (c0 + u) * 512 + lane * 8;
+            if (kk < K) {
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
+                for (int m = 0; m < 8; m++) {
+                    if (m < M) {
+                        const f16x8 av = *(const f16x8 *) (As + (int64_t) m * K + kk);
 #pragma unroll
-            for (int m = 0; m < 8; m++) {
-                if (m < M) {
-                    const f16x8 av = *(const f16x8 *) (a.data + (int64_t) m * a.nb[1] + kk[u] * 2);
-#pragma unroll
-                    for (int j = 0; j < 8; j++) acc[m] += (double) ((float) av[j] * (float) bv[u][j]);
+                        for (int j = 0; j < 8; j++) acc[m] += (double) ((float) av[j] * (float) bv[u][j]);
+                    }
                 }
             }
         }
     }
+    if (n < N) {
 #pragma unroll
-    for (int m = 0; m < 8; m++) {
-        if (m < M) {
-            const double v = wave_sum_f64(acc[m]);
-            if (lane == 0) {
-                float r = (float) v;
-                if (epi.bias) r = r + epi.bias[n];
-                if (epi.residual) r = *(const float *) (epi.residual + (int64_t) m * epi.res_nb0 + (int64_t) n * epi.res_nb1) + r;
-                *(float *) (dst.data + (int64_t) m * dst.nb[0] + (int64_t) n * dst.nb[1]) = r;
+        for (int m = 0; m < 8; m++) {
+            if (m < M) {
+                const double v = wave_sum_f64(acc[m]);
+                if (lane == 0) {
+                    float r = (float) v;
+                    if (epi.bias) r = r + epi.bias[n];
+                    if (epi.residual) r = *(const float *) (epi.residual + (int64_t) m * epi.res_nb0 + (int64_t) n * epi.res_nb1) + r;
+                    *(float *) (dst.data + (int64_t) m * dst.nb[0] + (int64_t) n * dst.nb[1]) = r;
+                    if (epi.sc.panel) conv_scatter_elem(epi.sc, m, n, r);
+                }
             }
         }
     }
@@ -1043,18 +1126,20 @@ __global__ void __launch_bounds__(256) mul_mat_smallm_kernel(tdesc dst, tdesc a,
 
 // short rows (K <= 64, e.g. the first SEANet conv: 1 input channel x 7 taps): one thread per output element
 __global__ void mul_mat_f16_shortk_kernel(tdesc dst, tdesc a, tdesc b, int K, int M, int64_t total, mm_epilogue epi) {
-    mm_tail_job(epi);
+    if (mm_tail_block(epi)) return;
     const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= total) return;
-    const uint32_t n = (uint32_t) i / (uint32_t) M, m = (uint32_t) i - n * (uint32_t) M;
-    const uint16_t * ap = (const uint16_t *) (a.data + (int64_t) m * a.nb[1]);
-    const uint16_t * bp = (const uint16_t *) (b.data + (int64_t) n * b.nb[1]);
-    double acc = 0;
-    for (int k = 0; k < K; k++) acc += (double) (h2f(ap[k]) * h2f(bp[k]));
-    float r = (float) acc;
-    if (epi.bias) r = r + epi.bias[n];
-    if (epi.residual) r = *(const float *) (epi.residual + (int64_t) m * epi.res_nb0 + (int64_t) n * epi.res_nb1) + r;
-    *(float *) (dst.data + (int64_t) m * dst.nb[0] + (int64_t) n * dst.nb[1]) = r;
+    if (i < total) {
+        const uint32_t n = (uint32_t) i / (uint32_t) M, m = (uint32_t) i - n * (uint32_t) M;
+        const uint16_t * ap = (const uint16_t *) (a.data + (int64_t) m * a.nb[1]);
+        const uint16_t * bp = (const uint16_t *) (b.data + (int64_t) n * b.nb[1]);
+        double acc = 0;
+        for (int k = 0; k < K; k++) acc += (double) (h2f(ap[k]) * h2f(bp[k]));
+        float r = (float) acc;
+        if (epi.bias) r = r + epi.bias[n];
+        if (epi.residual) r = *(const float *) (epi.residual + (int64_t) m * epi.res_nb0 + (int64_t) n * epi.res_nb1) + r;
+        *(float *) (dst.data + (int64_t) m * dst.nb[0] + (int64_t) n * dst.nb[1]) = r;
+        if (epi.sc.panel) conv_scatter_elem(epi.sc, (int) m, (int) n, r);
+    }
 }
 
 // One embedding row through a small Q8_0 projection (tts: the Depth transformer's low-rank embeddings, lm_utils.h:157-217 - get_rows of a 128-wide table,
@@ -1091,6 +1176,12 @@ __global__ void __launch_bounds__(256) lowrank_embed_kernel(lowrank_embed_args a
 }
 void k_lowrank_embed(hipStream_t s, const lowrank_embed_args & a) { lowrank_embed_kernel<<<(a.M + 3) / 4, 256, 0, s>>>(a); }
 
+static int mfma_split_k(int tiles, int steps) {
+    int SK = 1;
+    static const int sk_target = getenv("MI355X_MFMA_SK_TARGET") ? atoi(getenv("MI355X_MFMA_SK_TARGET")) : 512;
+    while (SK < 16 && tiles * SK < sk_target && steps / (SK * 2) >= 4) SK *= 2;
+    return SK;
+}
 void k_mul_mat(hipStream_t s, tdesc dst, tdesc a, tdesc b, void * ws, const mm_epilogue * epi_) {
     const int64_t total = td_nelements(dst);
     if (total == 0) return;
@@ -1099,20 +1190,24 @@ void k_mul_mat(hipStream_t s, tdesc dst, tdesc a, tdesc b, void * ws, const mm_e
     if (epi_) epi = *epi_;
     if (a.type == GGML_TYPE_F16 && b.type == GGML_TYPE_F16 && a.nb[0] == 2 && b.nb[0] == 2 && a.ne[2] * a.ne[3] * b.ne[2] * b.ne[3] == 1 &&
         a.ne[0] < 32 && a.ne[1] >= 256) {
-        mul_mat_f16_shortk_kernel<<<nblocks(total), BLOCK, 0, s>>>(dst, a, b, (int) a.ne[0], (int) a.ne[1], total, epi);
+        mul_mat_f16_shortk_kernel<<<nblocks(total) + mm_tail_extra(epi), BLOCK, 0, s>>>(dst, a, b, (int) a.ne[0], (int) a.ne[1], total, epi);
         return;
     }
     if (a.type == GGML_TYPE_F16 && b.type == GGML_TYPE_F16 && a.nb[0] == 2 && b.nb[0] == 2 && a.ne[2] * a.ne[3] * b.ne[2] * b.ne[3] == 1 &&
         dst.nb[0] == 4 && a.ne[0] % 8 == 0 && (a.nb[1] % 16) == 0 && (b.nb[1] % 16) == 0 && ((uintptr_t) a.data % 16) == 0 && ((uintptr_t) b.data % 16) == 0) {
         const int M = (int) a.ne[1], N = (int) b.ne[1];
-        if (M <= 8) { mul_mat_smallm_kernel<<<(N + 3) / 4, 256, 0, s>>>(dst, a, b, M, N, epi); return; }
+        if (M <= 8 && (size_t) M * a.ne[0] * 2 <= 128 * 1024) {
+            const size_t lds = (size_t) M * a.ne[0] * 2;
+            static bool granted = false;
+            if (!granted) { HIP_CHECK(hipFuncSetAttribute((const void *) mul_mat_smallm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024)); granted = true; }
+            mul_mat_smallm_kernel<<<(N + SMALLM_NW - 1) / SMALLM_NW + mm_tail_extra(epi), SMALLM_NW * 64, lds, s>>>(dst, a, b, M, N, epi);
+            return;
+        }
         if (M % 16 == 0 && N % 16 == 0 && a.ne[0] % 32 == 0 && (dst.nb[1] % 16) == 0 && ((uintptr_t) dst.data % 16) == 0) {
             const int mt = M / 16, nt = N / 16, tiles = mt * nt, steps = (int) a.ne[0] / 32;
-            int SK = 1;
-            static const int sk_target = getenv("MI355X_MFMA_SK_TARGET") ? atoi(getenv("MI355X_MFMA_SK_TARGET")) : 512;
-            while (SK < 16 && tiles * SK < sk_target && steps / (SK * 2) >= 4) SK *= 2;
+            const int SK = mfma_split_k(tiles, steps);
             const int TPW = SK >= 4 ? 1 : 4 / SK;
-            mul_mat_f16_mfma_kernel<<<(tiles + TPW - 1) / TPW, 64 * SK * TPW, 0, s>>>(dst, a, b, mt, nt, SK, TPW, epi);
+            mul_mat_f16_mfma_kernel<<<(tiles + TPW - 1) / TPW + mm_tail_extra(epi), 64 * SK * TPW, 0, s>>>(dst, a, b, mt, nt, SK, TPW, epi);
             return;
         }
     }
@@ -1128,7 +1223,7 @@ void k_mul_mat(hipStream_t s, tdesc dst, tdesc a, tdesc b, void * ws, const mm_e
                         b.nb[2] == row_bytes * b.ne[1] && b.nb[3] == b.nb[2] * b.ne[2];
     if (direct) y = b.data;
     else convert_rows_kernel<<<(int) rows, BLOCK, 0, s>>>(b, vt, (char *) ws, row_bytes);
-    mul_mat_kernel<<<nblocks(total, 4), 256, 0, s>>>(dst, a, b, y, row_bytes, vt, total, epi);
+    mul_mat_kernel<<<nblocks(total, 4) + mm_tail_extra(epi), 256, 0, s>>>(dst, a, b, y, row_bytes, vt, total, epi);
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -30,3 +30,11 @@ for who, name in ((0, "workgroup 0 (owner)"), (1, "workgroup 255")):
             return np.mean(v) / 100.0 if v else 0.0
         dur = np.mean([(r[p + 1, 10] - r[p, 10]) for p in sel if p + 1 < 40 and r[p + 1, 10]]) / 100.0
         print(f"  {kind:10s} {dur:6.2f} us | start -> input {seg(10, 2):5.2f} | -> xs ready {seg(2, 5):5.2f} | -> end {seg(5, 8):5.2f} | whole {seg(10, 8):5.2f}")
+# the attention phase on its owner (attn_ring256_body's stage stamps 11 .. 15 between the phase's start 10 and end 8)
+r = rec[0]
+sel = [p for p in range(5, 40) if p % 5 == 1 and r[p, 10] and r[p, 11]]
+names = [(10, 11, "q / k / v granules polled, rotated, ring rows stored"), (11, 12, "barrier"), (12, 13, "scores, wave maxima, barrier"), (13, 14, "exp, sums, barrier, P x V partials, barrier"),
+         (14, 15, "64-group reduction by one wave, output granules"), (15, 8, "exit barriers")]
+for a, b, what in names:
+    v = [(r[p, b] - r[p, a]) / 100.0 for p in sel if r[p, a] and r[p, b]]
+    print(f"  attention {what:60s} {np.mean(v) if v else 0.0:5.2f} us")

@@ -314,6 +314,28 @@ def test_mimi_encoder_codes_exact():
     assert codes["oracle"] == codes["hip"]
 
 
+@pytest.mark.parametrize("full", [False, True])
+def test_codec_convolutions_without_im2col_launches_are_bit_identical(full):
+    # default: the launch that produces a codec convolution's input (a conv product or a transposed conv's finishing launch) also writes that convolution's
+    # F16 im2col panel - f16(elu(.)) of every output element at its panel places, the carried-tail columns by the launch's extra workgroup - so no im2col
+    # launch runs between the two; flag 64 keeps one im2col launch per convolution. Same operand values at the same places, same products in the same order:
+    # codes and PCM equal bit for bit over 12 streaming frames, at the tiny and at moshika's codec widths.
+    cfg = hu.hot.moshika(hu.L) if full else hu.hot.tiny(hu.L)
+    cfg.enable_lm = 0
+    rng = np.random.default_rng(23)
+    frames = [rng.standard_normal(1920).astype(np.float32) * 0.2 for _ in range(12)]
+    res = {}
+    for flags in (0, 64):
+        m = hu.Model("hip", cfg, seed=0, flags=flags)
+        codes = [m.mimi_encode(f) for f in frames]
+        pcm = [m.mimi_decode(c).copy() for c in codes]
+        m.free()
+        res[flags] = (codes, pcm)
+    assert res[0][0] == res[64][0], "codes differ"
+    for i, (a, b) in enumerate(zip(res[0][1], res[64][1])):
+        assert np.array_equal(a, b), f"frame {i}: PCM differs by {np.abs(a - b).max():.3e}"
+
+
 def test_mimi_fused_equals_unfused():
     # the codec fusions (streaming conv / conv-transpose groups, RVQ levels and sums, scalar gather, fused transformer layers)
     # against one generic kernel per node on the same device: same codes, same samples up to summation order
