@@ -684,8 +684,9 @@ __device__ __forceinline__ void attn_ring64_body(const attn_args & a, char * sme
 #pragma unroll
         for (int i = 0; i < 8; i++) {
             const float kr8 = bf2f((uint16_t) ((i & 1) ? (kw[i >> 1] >> 16) : (kw[i >> 1] & 0xffff))), vr8 = bf2f((uint16_t) ((i & 1) ? (vw[i >> 1] >> 16) : (vw[i >> 1] & 0xffff)));
-            kv[i] = fresh ? knew[dl + i] : kr8;
-            vv8[i] = fresh ? vnew[dl + i] : vr8;
+            const float kn = knew[dl + i], vn = vnew[dl + i];   // (read by every lane, selected afterwards: no LDS read behind a per-lane branch)
+            kv[i] = fresh ? kn : kr8;
+            vv8[i] = fresh ? vn : vr8;
         }
     }
     double acc = 0;
@@ -734,7 +735,6 @@ __device__ __forceinline__ void attn_ring64_body(const attn_args & a, char * sme
         a.out[(int64_t) h * D + tid] = (float) tot;
         if (GOUT) __hip_atomic_store(go.out + (int64_t) h * D + tid, ((unsigned long long) go.tag << 32) | (unsigned long long) __float_as_uint((float) tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    R256_STAMP(15);
     __syncthreads();
 }
 
@@ -743,7 +743,7 @@ __device__ __forceinline__ void attn_ring64_body(const attn_args & a, char * sme
 // the direct form of attn_ring64_body with four passes: wave w owns slots 32 w .. 32 w + 31, pass i its slots 8 i .. 8 i + 7, lane = (slot, 8-dim chunk); all
 // ring rows are requested at entry. Workgroup (h, t) computes row t: it rotates and rounds ALL T new rows (row 1 attends to row 0's K / V, which is not in the
 // ring yet - or is being written right now by workgroup (h, 0), the only one that writes), taking new rows from LDS wherever a slot is one of the new tokens'.
-// Arithmetic as attn_ring64_body; the P x V sums run per (wave, slot group) over the passes in double, then over the 64 groups in index order in double.
+// Arithmetic as attn_ring64_body; the P x V sums run per (wave, slot group) over the passes in double, then over a wave's 8 groups and over the 8 waves in index order in double.
 #define ATTN_RING256_SMEM ((64 + 2 * 64 + 2 * 64 + 16) * 4 + 8 * 8 + 64 * 64 * 8)
 template <int MODE>
 __device__ __forceinline__ void attn_ring256_body(const attn_args & a, char * smem, const int h, const int t, const unsigned gtag = 0u, const attn_gqkv gq = attn_gqkv(), const attn_gout go = attn_gout()) {
@@ -822,19 +822,28 @@ __device__ __forceinline__ void attn_ring256_body(const attn_args & a, char * sm
     for (int i = 0; i < 4; i++) {
         const int c = wave * 32 + i * 8 + sub;
         live[i] = c < C && m[i] > -INFINITY;
-        const int f = c == slot0 ? 0 : (T > 1 && c == slot1) ? 1 : -1;
+        const int f = c == slot0 ? 0 : (T > 1 && c == slot1) ? 1 : -1, fc = f > 0 ? 1 : 0;
         const uint32_t kw[4] = { kq[i].x, kq[i].y, kq[i].z, kq[i].w }, vw[4] = { vq[i].x, vq[i].y, vq[i].z, vq[i].w };
+        // (the new rows are read from LDS by every lane and selected afterwards: behind the per-lane `f >= 0` each of the 16 reads was a branch with its
+        //  own wait - 64 serial LDS round trips over the four passes)
+        float kn8[8], vn8[8];
+#pragma unroll
+        for (int e = 0; e < 8; e += 4) {
+            const float4 k4 = *(const float4 *) (knew + fc * 64 + dl + e), v4 = *(const float4 *) (vnew + fc * 64 + dl + e);
+            kn8[e] = k4.x; kn8[e + 1] = k4.y; kn8[e + 2] = k4.z; kn8[e + 3] = k4.w; vn8[e] = v4.x; vn8[e + 1] = v4.y; vn8[e + 2] = v4.z; vn8[e + 3] = v4.w;
+        }
         double acc = 0;
 #pragma unroll
         for (int e = 0; e < 8; e++) {
             const float kr8 = bf2f((uint16_t) ((e & 1) ? (kw[e >> 1] >> 16) : (kw[e >> 1] & 0xffff))), vr8 = bf2f((uint16_t) ((e & 1) ? (vw[e >> 1] >> 16) : (vw[e >> 1] & 0xffff)));
-            const float kk = f >= 0 ? knew[f * 64 + dl + e] : kr8;
-            vv8[i][e] = f >= 0 ? vnew[f * 64 + dl + e] : vr8;
+            const float kk = f >= 0 ? kn8[e] : kr8;
+            vv8[i][e] = f >= 0 ? vn8[e] : vr8;
             acc += (double) (kk * qv[e]);
         }
         acc = group_allsum_f64(live[i] ? acc : 0.0, 8);
         sv[i] = live[i] ? (float) acc * a.scale + m[i] : -INFINITY;
     }
+    R256_STAMP(0);
     {
         float wm = fmaxf(fmaxf(sv[0], sv[1]), fmaxf(sv[2], sv[3]));
         wm = fmaxf(wm, dpp_f32<DPP_ROW_MIRROR>(wm));   // (uniform inside a slot's 8 lanes)
@@ -858,7 +867,9 @@ __device__ __forceinline__ void attn_ring256_body(const attn_args & a, char * sm
         const double r2 = __hiloint2double(__builtin_amdgcn_readlane(hi, 32), __builtin_amdgcn_readlane(lo, 32)), r3 = __hiloint2double(__builtin_amdgcn_readlane(hi, 48), __builtin_amdgcn_readlane(lo, 48));
         if (lane == 0) wsum[wave] = (r0 + r1) + (r2 + r3);
     }
+    R256_STAMP(3);
     __syncthreads();
+    R256_STAMP(4);
     double lsum = 0;
 #pragma unroll
     for (int w = 0; w < 8; w++) lsum += wsum[w];
@@ -873,16 +884,25 @@ __device__ __forceinline__ void attn_ring256_body(const attn_args & a, char * sm
 #pragma unroll
             for (int e = 0; e < 8; e++) o8[e] += (double) (pr != 0.f ? vv8[i][e] * pr : 0.f);
         }
+        R256_STAMP(6);
         double * dst = red + (wave * 8 + sub) * 64 + dl;
 #pragma unroll
         for (int e = 0; e < 8; e++) dst[e] = o8[e];
     }
+    R256_STAMP(7);
     __syncthreads();
     R256_STAMP(14);
+    {   // each wave adds its own 8 slot groups (into its first row), then one wave adds the 8 waves: two chains of 8 instead of one of 64 (1.3 -> ~0.6 us)
+        double tw = 0;
+#pragma unroll
+        for (int g = 0; g < 8; g++) tw += red[(wave * 8 + g) * 64 + lane];
+        red[(wave * 8) * 64 + lane] = tw;
+    }
+    __syncthreads();
     if (tid < D) {
         double tot = 0;
-#pragma unroll 8
-        for (int g = 0; g < 64; g++) tot += red[g * 64 + tid];
+#pragma unroll
+        for (int w = 0; w < 8; w++) tot += red[(w * 8) * 64 + tid];
         a.out[(int64_t) t * a.out_ts + (int64_t) h * D + tid] = (float) tot;
         if (GOUT) __hip_atomic_store(go.out + (int64_t) t * go.ts + (int64_t) h * D + tid, ((unsigned long long) go.tag << 32) | (unsigned long long) __float_as_uint((float) tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }

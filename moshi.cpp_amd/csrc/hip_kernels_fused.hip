@@ -329,6 +329,26 @@ __global__ void __launch_bounds__(NW * 64) matvec_q4k_kernel(mv_args a, int rows
             if (PRO == MV_GATE_SILU) aux[j] = *(const float4 *) (a.x + K + e);
         }
     };
+#if defined(MV_EXP_TILE_FIRST) || defined(MV_EXP_TILE0_DMA)
+    // Experiments of round 5 (tests/microbench/mv_bench.hip, never in the product build): the wave's first weight tile requested BEFORE the activation
+    // loads - into registers (MV_EXP_TILE_FIRST) or straight into its LDS staging area by LDS-DMA (MV_EXP_TILE0_DMA: global_load_lds_dwordx4, no VGPR hop).
+    u32x4 r_first[NLOAD];
+    if (WS == 0) {
+        const int t0 = wave;
+        const bool has_tile0 = t0 < ntiles;
+#pragma unroll
+        for (int i = 0; i < NLOAD; i++) {
+            const int g = t0 * (NLOAD * 64) + i * 64 + lane;
+            const u32x4 * src = (t0 >= tiles_half ? wsrc_r : wsrc) + (has_tile0 ? (g < nchunks ? g : nchunks - 1) : 0);
+#if defined(MV_EXP_TILE0_DMA)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *) src, (__attribute__((address_space(3))) void *) (stage + i * 1024), 16, 0, 2);
+#else
+            r_first[i] = __builtin_nontemporal_load(src);
+#endif
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#endif
     if (PRO != MV_PREQ8K && PRO != MV_ATTN) load_batch(0);
     // MV_PREQ8K: the activation arrives quantised (norm_quant / gate_quant kernels): nb padded Q8_K blocks of 304 B = nb * 19 chunks of 16 B,
     // at most 3 per thread (K <= 16384 at 256 threads); requested ahead of the weight tile for the same reason
@@ -350,11 +370,19 @@ __global__ void __launch_bounds__(NW * 64) matvec_q4k_kernel(mv_args a, int rows
     if (WS == 0) {   // unconditional (no branch around a load, see above): chunks past the end re-read the last valid chunk, and a wave without
         // a tile reads chunk 0 in every lane - one 16-byte request instead of a 9 KB tile in the CU's load queue; neither is consumed
         const bool has_tile = t < ntiles;
+#if defined(MV_EXP_TILE_FIRST)
+#pragma unroll
+        for (int i = 0; i < NLOAD; i++) r[i] = r_first[i];
+        (void) has_tile;
+#elif defined(MV_EXP_TILE0_DMA)
+        (void) has_tile; (void) r_first;
+#else
 #pragma unroll
         for (int i = 0; i < NLOAD; i++) {
             const int g = t * (NLOAD * 64) + i * 64 + lane;
             r[i] = __builtin_nontemporal_load((t >= tiles_half ? wsrc_r : wsrc) + (has_tile ? (g < nchunks ? g : nchunks - 1) : 0));
         }
+#endif
     } else {
 #pragma unroll
         for (int p = 0; p < MVD_PMAX; p++) {
@@ -490,8 +518,14 @@ __global__ void __launch_bounds__(NW * 64) matvec_q4k_kernel(mv_args a, int rows
         }
     }
     for (; WS == 0 && t < ntiles; t += nwaves) {
+#if defined(MV_EXP_TILE0_DMA)
+        if (t == wave) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the tile is in LDS once its LDS-DMA requests have returned)
+        else
+#endif
+        {
 #pragma unroll
-        for (int i = 0; i < NLOAD; i++) ((u32x4 *) stage)[i * 64 + lane] = r[i];
+            for (int i = 0; i < NLOAD; i++) ((u32x4 *) stage)[i * 64 + lane] = r[i];
+        }
         MV_STAMP(4);
         {
             const int tn = t + nwaves < ntiles ? t + nwaves : ntiles - 1;

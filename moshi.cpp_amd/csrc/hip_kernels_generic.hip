@@ -664,6 +664,9 @@ __device__ __forceinline__ void conv_scatter_tail(const conv_scatter & sc) {
 // streaming tail of conv_transpose_1d: y = convtr(x); y[:PT] += prev[-PT:]; prev = y; out = (y + bias)[: len - PT]
 // (moshi_streaming_conv_transpose_1d, conv.h:282-309). Thread t (< L*s0) also owns position t + L*s0 when t < PT, so the old
 // tail value it needs is read before the same thread overwrites it.
+// NS: the number of ic splits when it is a power of two <= 16 (the two-tap fast path then requests exactly 2 x 2 x NS partials: with NS fixed at 16 and the
+// surplus clamped to split 0, the 480-frame layer's threads each read 64 doubles where 16 carry information and the kernel spilled registers); 0: any
+template <int NS>
 __global__ void convtr_finish_kernel(tdesc out, float * prev, const float * bias, const double * P, int K, int OC, int L, int s0, int nsplit, conv_scatter sc) {
     const int N = OC * K, OLf = (L - 1) * s0 + K, PT = K - s0, keep = OLf - PT;   // keep == L * s0
     if (sc.panel && sc.TP > 0 && blockIdx.x == gridDim.x - 1) { conv_scatter_tail(sc); return; }   // (the extra workgroup)
@@ -687,10 +690,10 @@ __global__ void convtr_finish_kernel(tdesc out, float * prev, const float * bias
     float * pv = prev + (int64_t) oc * OLf;
     const bool has2 = t < PT;               // position t + keep lies in the carried tail
     float y, y2 = 0.f;
-    if (K <= 2 * s0 && nsplit <= 16) {
+    if (NS > 0 && K <= 2 * s0) {
         // at most two taps per output position: request every partial of both positions (2 x 2 taps x 16 splits) before the first
         // add - the partials were just written by other workgroups, so each dependent batch would cost a memory round trip
-        double v[2][2][16];
+        double v[2][2][NS > 0 ? NS : 1];
         bool ok[2][2];
 #pragma unroll
         for (int p = 0; p < 2; p++) {
@@ -703,7 +706,7 @@ __global__ void convtr_finish_kernel(tdesc out, float * prev, const float * bias
                 ok[p][q] = (p == 0 || has2) && l < L && k >= 0 && k < K;
                 const int lc = ok[p][q] ? l : 0, kc = ok[p][q] ? k : 0;
 #pragma unroll
-                for (int sp = 0; sp < 16; sp++) v[p][q][sp] = P[((int64_t) (sp < nsplit ? sp : 0) * L + lc) * N + oc * K + kc];
+                for (int sp = 0; sp < NS; sp++) v[p][q][sp] = P[((int64_t) sp * L + lc) * N + oc * K + kc];
             }
         }
         float r[2] = { 0.f, 0.f };
@@ -713,7 +716,7 @@ __global__ void convtr_finish_kernel(tdesc out, float * prev, const float * bias
             for (int q = 0; q < 2; q++) {
                 double sum = 0;
 #pragma unroll
-                for (int sp = 0; sp < 16; sp++) if (sp < nsplit) sum += v[p][q][sp];
+                for (int sp = 0; sp < NS; sp++) sum += v[p][q][sp];
                 if (ok[p][q]) r[p] += (float) sum;   // taps in ascending l, splits in ascending order: as conv_at
             }
         y = r[0]; y2 = r[1];
@@ -734,7 +737,15 @@ void k_convtr_finish(hipStream_t s, tdesc out, float * prev, const float * bias,
     conv_scatter scv;
     memset(&scv, 0, sizeof(scv));
     if (sc) scv = *sc;
-    convtr_finish_kernel<<<nblocks(n) + (scv.panel && scv.TP > 0 ? 1 : 0), BLOCK, 0, s>>>(out, prev, bias, (const double *) ws, K, OC, L, s0, nsplit, scv);
+    const int nb = nblocks(n) + (scv.panel && scv.TP > 0 ? 1 : 0);
+    switch (nsplit) {
+        case 1:  convtr_finish_kernel<1><<<nb, BLOCK, 0, s>>>(out, prev, bias, (const double *) ws, K, OC, L, s0, nsplit, scv); break;
+        case 2:  convtr_finish_kernel<2><<<nb, BLOCK, 0, s>>>(out, prev, bias, (const double *) ws, K, OC, L, s0, nsplit, scv); break;
+        case 4:  convtr_finish_kernel<4><<<nb, BLOCK, 0, s>>>(out, prev, bias, (const double *) ws, K, OC, L, s0, nsplit, scv); break;
+        case 8:  convtr_finish_kernel<8><<<nb, BLOCK, 0, s>>>(out, prev, bias, (const double *) ws, K, OC, L, s0, nsplit, scv); break;
+        case 16: convtr_finish_kernel<16><<<nb, BLOCK, 0, s>>>(out, prev, bias, (const double *) ws, K, OC, L, s0, nsplit, scv); break;
+        default: convtr_finish_kernel<0><<<nb, BLOCK, 0, s>>>(out, prev, bias, (const double *) ws, K, OC, L, s0, nsplit, scv); break;
+    }
 }
 
 // depthwise variant for one input frame: y[k, c] = x[c] * w[k, c]; y[:PT] += prev[K-PT:]; prev = y; out = (y + bias)[:K-PT]

@@ -33,7 +33,8 @@ for who, name in ((0, "workgroup 0 (owner)"), (1, "workgroup 255")):
 # the attention phase on its owner (attn_ring256_body's stage stamps 11 .. 15 between the phase's start 10 and end 8)
 r = rec[0]
 sel = [p for p in range(5, 40) if p % 5 == 1 and r[p, 10] and r[p, 11]]
-names = [(10, 11, "q / k / v granules polled, rotated, ring rows stored"), (11, 12, "barrier"), (12, 13, "scores, wave maxima, barrier"), (13, 14, "exp, sums, barrier, P x V partials, barrier"),
+names = [(10, 11, "q / k / v granules polled, rotated, ring rows stored"), (11, 12, "barrier"), (12, 0, "scores of the four passes"), (0, 13, "wave maxima, barrier"),
+         (13, 3, "exp, wave sums"), (3, 4, "barrier"), (4, 6, "total, P x V partials"), (6, 7, "partials to LDS"), (7, 14, "barrier"),
          (14, 15, "64-group reduction by one wave, output granules"), (15, 8, "exit barriers")]
 for a, b, what in names:
     v = [(r[p, b] - r[p, a]) / 100.0 for p in sel if r[p, a] and r[p, b]]

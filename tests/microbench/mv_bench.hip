@@ -1,7 +1,7 @@
 // Diagnostic microbenchmark of the Q4_K mat-vec kernel on the moshika shapes: kernel time (HIP events) and per-phase
 // s_memtime stamps of wave 0 (build with -DMV_STAMPS). Not part of the product.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -DMV_STAMPS -I../../include -I../../moshi.cpp_amd/csrc \
-//         mv_bench.hip -o mv_bench -L../../moshi.cpp_amd -lggml-mi355x -Wl,-rpath,'$ORIGIN/../../moshi.cpp_amd'
+//         mv_bench.hip -o mv_bench      (stand-alone: linked against the product library as well, the run takes the LIBRARY's kernels and records no stamps)
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -38,6 +38,7 @@ static void run(const char * name, int64_t K, int64_t M, int pro) {
         HIP_CHECK(hipMemsetAsync(junk, it, 512u << 20, st));
         HIP_CHECK(hipEventRecord(e0, st));
         k_matvec(st, a);
+        HIP_CHECK(hipGetLastError());
         HIP_CHECK(hipEventRecord(e1, st));
         HIP_CHECK(hipStreamSynchronize(st));
         float ms; HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
@@ -58,6 +59,7 @@ static void run(const char * name, int64_t K, int64_t M, int pro) {
     unsigned long long r0 = ~0ull, r1 = 0; std::vector<double> ends, starts;
     for (int b = 0; b < nwg; b++) { if (!hr[b][0]) continue; r0 = std::min(r0, hr[b][0]); r1 = std::max(r1, hr[b][1]); }
     for (int b = 0; b < nwg; b++) { if (!hr[b][0]) continue; starts.push_back((hr[b][0] - r0) / 100.0); ends.push_back((hr[b][1] - r0) / 100.0); }
+    if (starts.empty()) { printf(" | no stamps recorded (hs[0] = %llu %llu %llu, hr[0] = %llu %llu, nwg %d)\n", hs[0][0], hs[0][1], hs[0][7], hr[0][0], hr[0][1], nwg); return; }
     std::sort(starts.begin(), starts.end()); std::sort(ends.begin(), ends.end());
     printf(" | realtime us: start p50 %.2f p99 %.2f max %.2f; end p10 %.2f p50 %.2f p90 %.2f max %.2f", starts[starts.size() / 2], starts[starts.size() * 99 / 100], starts.back(),
            ends[ends.size() / 10], ends[ends.size() / 2], ends[ends.size() * 9 / 10], ends.back());
