@@ -307,6 +307,9 @@ typedef std::function<void(hipStream_t)> step_fn;
 struct pstep {
     step_fn fn; bool is_mv = false; mv_args mv;
     chain_plan * chain = nullptr;   // a persistent chain launch (timed on its own in profile mode)
+    // a step that reads nothing a launch of this graph writes (the RoPE table of add(positions, offset)) and writes [hoist_dst, + hoist_bytes): it may move in
+    // front of a neighbouring mat-vec whose operands it does not overlap, so that the mat-vec stays next to the steps it chains with
+    const char * hoist_dst = nullptr; size_t hoist_bytes = 0;
     template <typename F> pstep(F f) : fn(std::move(f)) { memset(&mv, 0, sizeof(mv)); }
     pstep(const mv_args & a) : fn([a](hipStream_t s) { k_matvec(s, a); }), is_mv(true), mv(a) {}
     // a step that is not a mat-vec but may be taken into a persistent step program next to its neighbours (mv.special): it keeps its own launch otherwise
@@ -1734,7 +1737,11 @@ static plan_t * build_plan(hip_ctx * c, ggml_cgraph * g, bool keep = true) {
             const tdesc d = make_tdesc(n), tx = make_tdesc(x);
             const float * yp = (const float *) y->data; const int yn = (int) ggml_nelements(y);
             const int dim = n->op_params[0], mp = n->op_params[1];
-            at_pos[i].push_back([=](hipStream_t s) { k_timestep_embedding(s, d, tx, dim, mp, yp, yn); });
+            {
+                pstep st([=](hipStream_t s) { k_timestep_embedding(s, d, tx, dim, mp, yp, yn); });
+                if (x->op == GGML_OP_NONE && y->op == GGML_OP_NONE && !x->view_src && !y->view_src) { st.hoist_dst = (const char *) n->data; st.hoist_bytes = ggml_nbytes(n); }   // (both operands are uploaded leaves)
+                at_pos[i].push_back(std::move(st));
+            }
             p->n_fused += 2;
         }
         // mat-vecs with prologue / epilogue
@@ -1966,6 +1973,18 @@ static plan_t * build_plan(hip_ctx * c, ggml_cgraph * g, bool keep = true) {
     // (only for plans that are kept - cached graphs, profile mode: a one-off plan is launched once and freed at once, a chain's tables would be built,
     // uploaded and torn down per compute)
     if (fuse && keep && !(c->flags & 16) && ((c->flags & 32) || k_chain_default_on()) && spin_kernels_possible(c)) {
+        // The codec transformers' RoPE table sits between layer 0's in_proj and its attention in node order: moved in front of that in_proj (whose operands it
+        // does not touch), the whole stack is one run (hip_chain_mimi.h takes it from in_proj 0; otherwise the program starts at layer 0's attention).
+        for (size_t i = 1; i + 1 < p->steps.size(); i++) {
+            pstep & h = p->steps[i];
+            const pstep & m = p->steps[i - 1];
+            if (!h.hoist_dst || !m.is_mv || m.mv.special || m.mv.wtype != GGML_TYPE_F32 || m.mv.ncols != 2 || !p->steps[i + 1].is_mv) continue;
+            auto clash = [&](const float * q, int64_t n_floats) { return q && (const char *) q < h.hoist_dst + h.hoist_bytes && h.hoist_dst < (const char *) (q + n_floats); };
+            const mv_args & a = m.mv;
+            if (clash(a.x, a.x_cs * (a.ncols - 1) + a.K) || clash(a.y, a.y_cs * (a.ncols - 1) + a.M) || clash(a.x_out, a.K * a.ncols) || clash(a.residual, a.r_cs * (a.ncols - 1) + a.M) ||
+                clash(a.alpha, a.K) || clash(a.beta, a.K)) continue;
+            std::swap(p->steps[i - 1], p->steps[i]);
+        }
         std::vector<pstep> merged;
         size_t i = 0;
         while (i < p->steps.size()) {

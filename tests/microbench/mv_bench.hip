@@ -45,6 +45,13 @@ static void run(const char * name, int64_t K, int64_t M, int pro) {
         times.push_back(ms * 1e3f);
     }
     std::sort(times.begin(), times.end());
+    {   // a digest of y: variants of the kernel built with -DMV_EXP_* must print the same one
+        std::vector<float> hy((size_t) M);
+        HIP_CHECK(hipMemcpy(hy.data(), y, M * 4, hipMemcpyDeviceToHost));
+        uint64_t h = 1469598103934665603ull;
+        for (float f : hy) { uint32_t u; memcpy(&u, &f, 4); h = (h ^ u) * 1099511628211ull; }
+        printf("[y %016llx] ", (unsigned long long) h);
+    }
     printf("%-10s K=%5ld M=%6ld pro=%d: median %.2f us (min %.2f) -> %.0f GB/s", name, (long) K, (long) M, pro, times[6], times[0], wbytes / times[6] / 1e3);
 #ifdef MV_STAMPS
     static unsigned long long hs[4096][8];
