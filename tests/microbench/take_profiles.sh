@@ -3,7 +3,7 @@
 # rocprofv3 cannot follow hipGraph replays here), condensed into gpurun_out/ for copying to profiles/.
 set -x
 export TMPDIR=/tmp
-R=${1:-r04}
+R=${1:-r05}
 rocprofv3 --kernel-trace --stats -d gpurun_out/${R}_trace -o t --output-format csv -- python3 bench.py --steps 20 --warmup 4 --no-cpu-baseline --no-extras --backend-flags 2 > gpurun_out/${R}_bench_eager_under_rocprof.json 2> gpurun_out/${R}_trace.err
 f=$(find gpurun_out/${R}_trace -name "*kernel_stats.csv" | head -1)
 python3 tests/profile_summary.py stats $f gpurun_out/${R}_bench_kernel_stats_eager.csv

@@ -46,7 +46,7 @@ def pmc(src, dst):
 
 
 def counters(dst, *srcs):
-    """per kernel (top 14 by total wave cycles): average of every collected counter per launch, plus the derived average vector-memory latency
+    """per kernel (top 22 by total wave cycles): average of every collected counter per launch, plus the derived average vector-memory latency
     SQ_INST_LEVEL_VMEM / SQ_INSTS_VMEM_RD (cycles an issued vector-memory read stays outstanding) where both were collected"""
     agg = collections.defaultdict(lambda: collections.defaultdict(lambda: [0, 0.0]))
     for src in srcs:
@@ -59,7 +59,7 @@ def counters(dst, *srcs):
     order = sorted(agg, key=lambda k: -(agg[k]["SQ_WAVE_CYCLES"][1] if "SQ_WAVE_CYCLES" in agg[k] else max(v[0] for v in agg[k].values())))   # by total wave cycles
     with open(dst, "w") as f:
         f.write("# per launch averages; counters collected in separate rocprofv3 --pmc passes of the same command (eager launches)\n")
-        for k in order[:14]:
+        for k in order[:22]:
             n = max(v[0] for v in agg[k].values())
             f.write(f"{k}  launches {n}\n")
             for c in names:
