@@ -290,10 +290,13 @@ __device__ __forceinline__ void attn_decode_body(const attn_args & a_in, const a
     const int c_lo = multi ? c_base : 0, c_hi = multi ? min(n_end, c_base + SLOTS) : n_end;   // slots whose K / V rows this workgroup reads
     const int c_last = c_hi > 0 ? c_hi - 1 : 0;   // last row of the range (address clamp of the batched requests)
     // a prefetched row may be the slot that was just rewritten (last writer wins, like set_rows): take it from LDS instead
-    auto pack_row = [&](const float * src) {
+    auto pack_row = [&](const float * src) {   // (two 16-byte LDS reads: eight scalar ones, each waited for on its own, were ~0.45 us on the one wave that holds the new slot)
+        float4 lo, hi;
+        if ((C & 3) == 0) { lo = *(const float4 *) src; hi = *(const float4 *) (src + 4); }   // (knew / vnew start C floats into the buffer: 16-byte aligned when C % 4 == 0)
+        else { lo = make_float4(src[0], src[1], src[2], src[3]); hi = make_float4(src[4], src[5], src[6], src[7]); }
         uint4 r;
-        r.x = (uint32_t) f2bf(src[0]) | ((uint32_t) f2bf(src[1]) << 16); r.y = (uint32_t) f2bf(src[2]) | ((uint32_t) f2bf(src[3]) << 16);
-        r.z = (uint32_t) f2bf(src[4]) | ((uint32_t) f2bf(src[5]) << 16); r.w = (uint32_t) f2bf(src[6]) | ((uint32_t) f2bf(src[7]) << 16);
+        r.x = (uint32_t) f2bf(lo.x) | ((uint32_t) f2bf(lo.y) << 16); r.y = (uint32_t) f2bf(lo.z) | ((uint32_t) f2bf(lo.w) << 16);
+        r.z = (uint32_t) f2bf(hi.x) | ((uint32_t) f2bf(hi.y) << 16); r.w = (uint32_t) f2bf(hi.z) | ((uint32_t) f2bf(hi.w) << 16);
         return r;   // knew / vnew hold bf16-representable floats: the round trip is exact
     };
     auto fresh_of = [&](int c) { int f = -1; for (int tt = 0; tt < T; tt++) if (slot_t[tt] == c) f = tt; return f; };
@@ -428,10 +431,19 @@ __device__ __forceinline__ void attn_decode_body(const attn_args & a_in, const a
             for (int i = 0; i < 8; i++) red[(wave * SPW + sub) * D + dl + i] = q8[i];
             __syncthreads();
             AT_STAMP(6);
+            // fixed order, two stages: every wave adds its own SPW slot groups (into its first row), then the waves are added in index order - two chains
+            // of SPW and ATTN_NW terms instead of one of ATTN_NW * SPW dependent LDS reads + double adds by two waves (round 5; attn_ring256_body: 1.3 -> 0.5 us)
+            for (int j = lane; j < D; j += 64) {
+                double tw = 0;
+#pragma unroll
+                for (int g = 0; g < 8; g++) if (g < SPW) tw += red[(wave * SPW + g) * D + j];
+                red[(wave * SPW) * D + j] = tw;
+            }
+            __syncthreads();
             for (int j = tid; j < D; j += ATTN_THREADS) {
                 double tot = 0;
-#pragma unroll 8
-                for (int g = 0; g < ATTN_NW * SPW; g++) tot += red[g * D + j];   // fixed order: wave-major, slot group minor
+#pragma unroll
+                for (int w = 0; w < ATTN_NW; w++) tot += red[(w * SPW) * D + j];
                 a.out[(int64_t) t * a.out_ts + (int64_t) h * D + j] = (float) tot;
                 if (GOUT) __hip_atomic_store(go.out + (int64_t) t * go.ts + (int64_t) h * D + j, ((unsigned long long) go.tag << 32) | (unsigned long long) __float_as_uint((float) tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
