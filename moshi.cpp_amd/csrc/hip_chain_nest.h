@@ -610,7 +610,11 @@ __global__ void __launch_bounds__(CH_THREADS) depth_nest_kernel(nest_params N) {
                 if ((tid & 15) == 0 && (tid >> 4) < 8) { ctl->am_v[tid >> 4] = best; ctl->am_i[tid >> 4] = bi; }
                 nbar();
                 if (tid == 0) {
-                    for (int w = 1; w < 8; w++) am_merge(best, bi, ctl->am_v[w], ctl->am_i[w]);
+                    float cv[8]; int ci[8];   // (all fourteen LDS reads in front of the merge: inside it each one was waited for on its own)
+#pragma unroll
+                    for (int w = 1; w < 8; w++) { cv[w] = ctl->am_v[w]; ci[w] = ctl->am_i[w]; }
+#pragma unroll
+                    for (int w = 1; w < 8; w++) am_merge(best, bi, cv[w], ci[w]);
                     u64 * c = P.cand + (size_t) (p & 1) * 2 * grid + 2 * wg;
                     st_granule(c, tag_base | (unsigned) (p + 1), __float_as_uint(best));
                     st_granule(c + 1, tag_base | (unsigned) (p + 1), (unsigned) bi);
