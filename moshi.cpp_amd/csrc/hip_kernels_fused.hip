@@ -2319,7 +2319,8 @@ __global__ void __launch_bounds__(SMP_THREADS) sample_topk_kernel(sample_args a)
 #pragma unroll
     for (int j = 0; j < SMP_NPT; j++) {
         const int i = tid + j * SMP_THREADS;
-        p[j] = i < n ? a.logits[i] * a.scale : -INFINITY;
+        const float lv = a.logits[i < n ? i : n - 1];   // (no load behind a per-lane branch: the text head's 32 loads per thread were 32 serial round trips)
+        p[j] = i < n ? lv * a.scale : -INFINITY;
         mx = fmaxf(mx, p[j]);
     }
     for (int i = tid; i < NW * 256; i += SMP_THREADS) (&whist[0][0][0])[i] = 0u;   // (the first pass's histograms, behind the loads)
