@@ -27,7 +27,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 from __graft_entry__ import load_oracle, load_package  # noqa: E402
 
-PMC_FILE = "r04_pmc_fetch_size.json"   # rocprofv3 --pmc FETCH_SIZE pass of this command (tests/microbench/take_profiles.sh), stamped with the kernel sources' hash
+PMC_FILE = "r05_pmc_fetch_size.json"   # rocprofv3 --pmc FETCH_SIZE pass of this command (tests/microbench/take_profiles.sh), stamped with the kernel sources' hash
 HBM_PEAK_GBPS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 
 
@@ -386,6 +386,28 @@ def main():
             result["serial_loop"] = {"value": round(ns / (time.perf_counter() - t1), 2), "unit": "frames/s", "steps": ns}
             # the figure an UNCHANGED reference tool gets (tools/moshi-sts.cpp:770-808 keeps its serial call order); `value` needs the restructured caller
             result["value_serial"] = result["serial_loop"]["value"]
+            if args.model in ("moshika", "personaplex") and world == 1:
+                # ... measured the way such a tool runs: ONE backend handle for every graph (a second instance of the model without the codec stream). The model
+                # above keeps its codec graphs on the second command stream, where the codec's transformers stay 40 launches each; on the LM's own handle they are
+                # one persistent launch each (DESIGN.md section 4 "Step programs").
+                cs, cd = cfg.codec_stream, cfg.chain_depth
+                cfg.codec_stream, cfg.chain_depth = 0, 0
+                m1 = L.moshi_hot_create(be, C.byref(cfg), 0)
+                cfg.codec_stream, cfg.chain_depth = cs, cd
+                if args.context_fill:
+                    L.moshi_hot_set_context_fill(m1, args.context_fill)
+                for _ in range(8):
+                    L.moshi_hot_sts_frame(m1, pcm.ctypes.data, C.byref(txt), aud, out.ctypes.data)
+                L.ggml_backend_synchronize(be); device_sync()
+                t1 = time.perf_counter()
+                for _ in range(ns):
+                    L.moshi_hot_sts_frame(m1, pcm.ctypes.data, C.byref(txt), aud, out.ctypes.data)
+                L.ggml_backend_synchronize(be); device_sync()
+                result["serial_loop"]["same_model_codec_on_second_stream"] = result["serial_loop"]["value"]
+                result["serial_loop"]["value"] = round(ns / (time.perf_counter() - t1), 2)
+                result["serial_loop"]["handles"] = 1
+                result["value_serial"] = result["serial_loop"]["value"]
+                L.moshi_hot_free(m1)
 
     if shard is not None and args.shard == "temporal":
         shard.stop_workers()
@@ -444,7 +466,7 @@ def main():
                                              for v in range(3) if kp.variant_launches[v]}
             if kp.chain_launches:
                 # the chained Depth transformer (lm.h:446-553) as persistent launches: weights streamed once per launch, ~208 dependent phases inside it
-                result["roofline_by_variant"]["persistent_chain: matvec_chain_kernel (Depth transformer, %d mat-vecs per launch)" % (kp.chain_phases // kp.chain_launches)] = {
+                result["roofline_by_variant"]["persistent_chain: step programs (depth_nest_kernel: the Depth transformer; serial loop also the codec's two mimi_tr_kernel), %d phases per launch" % (kp.chain_phases // kp.chain_launches)] = {
                     "achieved": round(kp.chain_bytes / kp.chain_seconds / 1e9, 1), "unit": "GB/s", "frac": round(kp.chain_bytes / kp.chain_seconds / 1e9 / HBM_PEAK_GBPS, 4),
                     "launches_per_frame": int(kp.chain_launches // 3), "avg_launch_us": round(1e6 * kp.chain_seconds / kp.chain_launches, 3),
                     "algorithmic_bytes_per_launch": int(kp.chain_bytes // kp.chain_launches), "us_per_phase": round(1e6 * kp.chain_seconds / kp.chain_phases, 3)}
