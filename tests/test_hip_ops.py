@@ -205,7 +205,9 @@ def test_mul_mat_batched_heads_bf16():
     gu.compare(build, atol_rel=2e-6)
 
 
-@pytest.mark.parametrize("Cin,Cout,K,s,L", [(1, 64, 7, 1, 40), (64, 128, 8, 4, 64), (512, 1024, 7, 1, 8), (256, 512, 1, 1, 3), (64, 32, 3, 1, 50), (128, 64, 3, 1, 482), (32, 64, 1, 1, 1920)])
+@pytest.mark.parametrize("Cin,Cout,K,s,L", [(1, 64, 7, 1, 40), (64, 128, 8, 4, 64), (512, 1024, 7, 1, 8), (256, 512, 1, 1, 3), (64, 32, 3, 1, 50), (128, 64, 3, 1, 482), (32, 64, 1, 1, 1920),
+                                           # few output positions (mul_mat_smallm_kernel: activation rows staged in LDS): M = 8 at K = 8192 fills its 128 KB, M = 2 / 1 at the codec's T = 2 layers
+                                           (512, 1024, 16, 8, 72), (1024, 512, 3, 1, 4), (512, 512, 4, 2, 4), (256, 48, 1, 1, 5)])
 def test_conv_1d(Cin, Cout, K, s, L):
     r = np.random.default_rng(Cin + K)
     w = (r.standard_normal((Cout, Cin, K)) / np.sqrt(Cin * K)).astype(np.float32)
