@@ -1202,9 +1202,22 @@ static bool match_conv(const analysis & an, int pos, step_group & grp, emitter &
         out = nx; members.push_back(pos_of(an, out));
     }
     if (!ggml_is_contiguous(out) || !out->data || !im->data) return false;
+    // cont(transpose(out)) behind a few-position conv (the encoder's last conv feeding the codec transformer): the product, which stores through its
+    // destination's strides at that shape, writes the transposed copy in place of its own output - one launch less, the same values
+    const ggml_tensor * tcont = nullptr;
+    {
+        const ggml_tensor * trn = uses_of(an, out) == 1 ? sole_consumer(an, out) : nullptr;
+        const ggml_tensor * ct = trn && trn->op == GGML_OP_TRANSPOSE && uses_of(an, trn) == 1 ? sole_consumer(an, trn) : nullptr;
+        if (ct && ct->op == GGML_OP_CONT && ct->type == GGML_TYPE_F32 && ggml_is_contiguous(ct) && ct->data && OL <= 8 && ct->ne[0] == Cout && ct->ne[1] == OL &&
+            ggml_nelements(ct) == OL * Cout && pos_of(an, trn) >= 0 && pos_of(an, ct) >= 0 && !(getenv("MI355X_NO_CONV_TRANSPOSE_FOLD"))) {
+            tcont = ct;
+            members.push_back(pos_of(an, trn)); members.push_back(pos_of(an, ct));
+        }
+    }
     for (int m : members) if (m < 0) return false;
     tdesc d_im = make_tdesc(ra), d_w = make_tdesc(rw), d_x = make_tdesc(xin), d_out = make_tdesc(out);
     d_out.ne[0] = OL; d_out.ne[1] = Cout; d_out.ne[2] = d_out.ne[3] = 1;
+    if (tcont) { d_out.data = (char *) tcont->data; d_out.nb[0] = (int64_t) tcont->nb[1]; d_out.nb[1] = (int64_t) tcont->nb[0]; }
     float * pv = prev ? (float *) prev->data : nullptr;
     grp.steps.clear();
     if (TP > 0) {   // the tail update rides on the product kernel (it must follow the im2col, which reads the old tail)
@@ -1229,11 +1242,16 @@ static bool match_conv(const analysis & an, int pos, step_group & grp, emitter &
             fused = true;
         }
     }
+    if (!fused && scatter_on && !(em.c->flags & 64) && Kw == 1 && s0 == 1 && TP == 0 && k_mul_mat_is_few_rows(d_im, d_w) && d_im.nb[1] == d_im.ne[0] * 2) {
+        // a 1-tap conv over a few positions fed by something else than a conv launch (the RVQ projections): the product converts its rows itself
+        epi.af_x = (const char *) xin->data; epi.af_nb0 = (int64_t) xin->nb[0]; epi.af_nb1 = (int64_t) xin->nb[1]; epi.af_elu = pre_elu;
+        fused = true;
+    }
     if (!fused) grp.steps.push_back([=](hipStream_t s) { k_stream_im2col(s, d_im, pv, TP, d_x, Kw, s0, pre_elu); });
     const conv_scatter * slot = em.scatter_slot(out);
     grp.steps.push_back([=](hipStream_t s) { mm_epilogue e = epi; e.sc = *slot; k_mul_mat(s, d_out, d_a, d_w, nullptr, &e); });
     grp.members = members;
-    grp.emit_pos = pos_of(an, out);
+    grp.emit_pos = pos_of(an, tcont ? tcont : out);
     return true;
 }
 
@@ -1343,10 +1361,22 @@ static bool match_dw_convtr(const analysis & an, int pos, step_group & grp) {
     const char * wp = (const char *) w->data; const int64_t w_cs = (int64_t) w->nb[2];
     float * pv = (float *) t.prev->data; const float * bias = t.bias; float * out = (float *) t.out->data;
     const int PT = t.PT, Cn = (int) C;
+    // cont(transpose(out)) behind it (the decoder's upsampler feeding the codec transformer): written directly, as above
+    int64_t out_cs = K - PT, out_ks = 1;
+    const ggml_tensor * emit = t.out;
+    {
+        const ggml_tensor * trn = uses_of(an, t.out) == 1 ? sole_consumer(an, t.out) : nullptr;
+        const ggml_tensor * ct = trn && trn->op == GGML_OP_TRANSPOSE && uses_of(an, trn) == 1 ? sole_consumer(an, trn) : nullptr;
+        if (ct && ct->op == GGML_OP_CONT && ct->type == GGML_TYPE_F32 && ggml_is_contiguous(ct) && ct->data && ct->ne[0] == C && ct->ne[1] == K - PT && ggml_nelements(ct) == C * (K - PT) &&
+            pos_of(an, trn) >= 0 && pos_of(an, ct) >= 0 && !(getenv("MI355X_NO_CONV_TRANSPOSE_FOLD"))) {
+            out = (float *) ct->data; out_cs = 1; out_ks = C; emit = ct;
+            members.push_back(pos_of(an, trn)); members.push_back(pos_of(an, ct));
+        }
+    }
     grp.steps.clear();
-    grp.steps.push_back([=](hipStream_t s) { k_dw_convtr_frame(s, out, pv, bias, xp, x_cs, wp, w_cs, K, PT, Cn); });
+    grp.steps.push_back([=](hipStream_t s) { k_dw_convtr_frame(s, out, pv, bias, xp, x_cs, wp, w_cs, K, PT, Cn, out_cs, out_ks); });
     grp.members = members;
-    grp.emit_pos = pos_of(an, t.out);
+    grp.emit_pos = pos_of(an, emit);
     return true;
 }
 

@@ -64,8 +64,13 @@ size_t k_mul_mat_ws_size(const struct ggml_tensor * a, const struct ggml_tensor 
 struct conv_scatter { uint16_t * panel; const float * prev; int K, Kw, s0, TP, M, C, elu, pad; };
 struct mm_epilogue { const float * bias; const char * residual; int64_t res_nb0, res_nb1;
                      float * tail_prev; int tail_TP, tail_pre_elu, tail_L, tail_C; const char * tail_x; int64_t tail_nb0, tail_nb1;
-                     conv_scatter sc; };
+                     conv_scatter sc;
+                     // a 1-tap convolution over a few positions whose input no conv launch produces (the RVQ projections): the few-row product converts its
+                     // activation rows from the F32 tensor itself while it stages them in LDS (af_x != nullptr: element (row m, k) at af_x + m * af_nb0 + k * af_nb1,
+                     // through the ELU if af_elu) - the F16 values the im2col launch would have stored - and that launch is not planned
+                     const char * af_x; int64_t af_nb0, af_nb1; int af_elu, af_pad; };
 void k_mul_mat(hipStream_t s, tdesc dst, tdesc a, tdesc b, void * ws, const mm_epilogue * epi = nullptr);
+bool k_mul_mat_is_few_rows(tdesc a, tdesc b);   // true: k_mul_mat runs this product as the few-row kernel (the only form that takes mm_epilogue::af_x)
 // streaming conv1d helpers (moshi_streaming_conv_1d, conv.h:50-96): F16 im2col straight from (carried tail, new samples) with an
 // optional ELU on the new samples, and the tail update
 void k_stream_im2col(hipStream_t s, tdesc dst, const float * prev, int TP, tdesc x, int Kw, int s0, int pre_elu);
@@ -73,7 +78,7 @@ void k_conv_tail(hipStream_t s, float * prev, int TP, tdesc x, int pre_elu);
 // streaming conv_transpose_1d tail (conv.h:282-309): overlap-add with the carried partial, state update, bias, window
 void k_convtr_finish(hipStream_t s, tdesc out, float * prev, const float * bias, const void * ws, int K, int OC, int L, int s0, int nsplit, const conv_scatter * sc = nullptr);
 // depthwise transposed conv of one input frame + streaming tail: y[k, c] = x[c] * w[k, c]
-void k_dw_convtr_frame(hipStream_t s, float * out, float * prev, const float * bias, const char * x, int64_t x_cs, const char * w, int64_t w_cs, int K, int PT, int C);
+void k_dw_convtr_frame(hipStream_t s, float * out, float * prev, const float * bias, const char * x, int64_t x_cs, const char * w, int64_t w_cs, int K, int PT, int C, int64_t out_cs = -1, int64_t out_ks = 1);   // out[c * out_cs + k * out_ks] (default: out_cs = K - PT)
 int  k_conv_transpose_1d_partial(hipStream_t s, tdesc w, tdesc x, void * ws, int pre_elu);   // returns the number of ic splits written to ws
 // scatter of batched small uploads: descs/blob live in pinned host memory mapped into the device
 struct upload_desc { char * dst; uint32_t offset; uint32_t size; };

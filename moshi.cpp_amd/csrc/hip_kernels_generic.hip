@@ -749,7 +749,7 @@ void k_convtr_finish(hipStream_t s, tdesc out, float * prev, const float * bias,
 }
 
 // depthwise variant for one input frame: y[k, c] = x[c] * w[k, c]; y[:PT] += prev[K-PT:]; prev = y; out = (y + bias)[:K-PT]
-__global__ void dw_convtr_frame_kernel(float * out, float * prev, const float * bias, const char * x, int64_t x_cs, const char * w, int64_t w_cs, int K, int PT, int C) {
+__global__ void dw_convtr_frame_kernel(float * out, float * prev, const float * bias, const char * x, int64_t x_cs, const char * w, int64_t w_cs, int K, int PT, int C, int64_t out_cs, int64_t out_ks) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
     const float xv = *(const float *) (x + (int64_t) c * x_cs);
@@ -759,11 +759,11 @@ __global__ void dw_convtr_frame_kernel(float * out, float * prev, const float * 
     float y[16];
     for (int k = 0; k < K; k++) { y[k] = xv * wc[k]; if (k < PT) y[k] = y[k] + pv[keep + k]; }
     for (int k = 0; k < K; k++) pv[k] = y[k];
-    for (int k = 0; k < keep; k++) out[(int64_t) c * keep + k] = bias ? y[k] + bias[c] : y[k];
+    for (int k = 0; k < keep; k++) out[(int64_t) c * out_cs + k * out_ks] = bias ? y[k] + bias[c] : y[k];
 }
-void k_dw_convtr_frame(hipStream_t s, float * out, float * prev, const float * bias, const char * x, int64_t x_cs, const char * w, int64_t w_cs, int K, int PT, int C) {
+void k_dw_convtr_frame(hipStream_t s, float * out, float * prev, const float * bias, const char * x, int64_t x_cs, const char * w, int64_t w_cs, int K, int PT, int C, int64_t out_cs, int64_t out_ks) {
     GGML_ASSERT(K <= 16);
-    dw_convtr_frame_kernel<<<(C + 63) / 64, 64, 0, s>>>(out, prev, bias, x, x_cs, w, w_cs, K, PT, C);
+    dw_convtr_frame_kernel<<<(C + 63) / 64, 64, 0, s>>>(out, prev, bias, x, x_cs, w, w_cs, K, PT, C, out_cs < 0 ? K - PT : out_cs, out_ks);
 }
 
 // F16 im2col of concat(prev, act(x)) without materialising the concat: dst[ci*Kw + k, ol] = xc[ol*s0 + k, ci]
@@ -1096,6 +1096,20 @@ __global__ void __launch_bounds__(SMALLM_NW * 64) mul_mat_smallm_kernel(tdesc ds
             for (int u = 0; u < 4; u++) { const int idx = i0 + u * SMALLM_NW * 64; if (idx < M * K8) *(f16x8 *) (As + (int64_t) idx * 8) = t[u]; }
         }
     };
+    if (epi.af_x) {   // (rows converted from F32 here: eight unconditional loads per fragment)
+        if (epi.af_elu) stage([&](int m, int k8) { f16x8 r; float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) v[j] = *(const float *) (epi.af_x + (int64_t) m * epi.af_nb0 + (int64_t) (k8 * 8 + j) * epi.af_nb1);
+#pragma unroll
+            for (int j = 0; j < 8; j++) r[j] = (_Float16) (v[j] > 0.f ? v[j] : expm1f(v[j]));
+            return r; });
+        else stage([&](int m, int k8) { f16x8 r; float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) v[j] = *(const float *) (epi.af_x + (int64_t) m * epi.af_nb0 + (int64_t) (k8 * 8 + j) * epi.af_nb1);
+#pragma unroll
+            for (int j = 0; j < 8; j++) r[j] = (_Float16) v[j];
+            return r; });
+    } else
     stage([&](int m, int k8) { return *(const f16x8 *) (a.data + (int64_t) m * a.nb[1] + k8 * 16); });
     __syncthreads();
     double acc[8];
@@ -1193,6 +1207,12 @@ static int mfma_split_k(int tiles, int steps) {
     while (SK < 16 && tiles * SK < sk_target && steps / (SK * 2) >= 4) SK *= 2;
     return SK;
 }
+// true: k_mul_mat runs this product as mul_mat_smallm_kernel (the only form that takes mm_epilogue::af_x)
+bool k_mul_mat_is_few_rows(tdesc a, tdesc b) {
+    return a.type == GGML_TYPE_F16 && b.type == GGML_TYPE_F16 && a.nb[0] == 2 && b.nb[0] == 2 && a.ne[2] * a.ne[3] * b.ne[2] * b.ne[3] == 1 && !(a.ne[0] < 32 && a.ne[1] >= 256) &&
+           a.ne[0] % 8 == 0 && (a.nb[1] % 16) == 0 && (b.nb[1] % 16) == 0 && ((uintptr_t) a.data % 16) == 0 && ((uintptr_t) b.data % 16) == 0 &&
+           a.ne[1] <= 8 && (size_t) a.ne[1] * a.ne[0] * 2 <= 128 * 1024;
+}
 void k_mul_mat(hipStream_t s, tdesc dst, tdesc a, tdesc b, void * ws, const mm_epilogue * epi_) {
     const int64_t total = td_nelements(dst);
     if (total == 0) return;
@@ -1205,8 +1225,9 @@ void k_mul_mat(hipStream_t s, tdesc dst, tdesc a, tdesc b, void * ws, const mm_e
         return;
     }
     if (a.type == GGML_TYPE_F16 && b.type == GGML_TYPE_F16 && a.nb[0] == 2 && b.nb[0] == 2 && a.ne[2] * a.ne[3] * b.ne[2] * b.ne[3] == 1 &&
-        dst.nb[0] == 4 && a.ne[0] % 8 == 0 && (a.nb[1] % 16) == 0 && (b.nb[1] % 16) == 0 && ((uintptr_t) a.data % 16) == 0 && ((uintptr_t) b.data % 16) == 0) {
+        a.ne[0] % 8 == 0 && (a.nb[1] % 16) == 0 && (b.nb[1] % 16) == 0 && ((uintptr_t) a.data % 16) == 0 && ((uintptr_t) b.data % 16) == 0) {
         const int M = (int) a.ne[1], N = (int) b.ne[1];
+        if (dst.nb[0] != 4 && !(M <= 8 && (size_t) M * a.ne[0] * 2 <= 128 * 1024)) goto generic_product;   // (only the few-row kernel stores through any destination strides)
         if (M <= 8 && (size_t) M * a.ne[0] * 2 <= 128 * 1024) {
             const size_t lds = (size_t) M * a.ne[0] * 2;
             static bool granted = false;
@@ -1222,6 +1243,7 @@ void k_mul_mat(hipStream_t s, tdesc dst, tdesc a, tdesc b, void * ws, const mm_e
             return;
         }
     }
+generic_product:
     const int vt = vec_dot_type(a.type);
     GGML_ASSERT(a.nb[0] == (int64_t) ggml_type_size((enum ggml_type) a.type));
     GGML_ASSERT(b.type == GGML_TYPE_F32 || b.type == vt);

@@ -336,6 +336,33 @@ def test_codec_convolutions_without_im2col_launches_are_bit_identical(full):
         assert np.array_equal(a, b), f"frame {i}: PCM differs by {np.abs(a - b).max():.3e}"
 
 
+def test_transposing_copies_in_front_of_the_codec_transformers_are_written_by_their_producers():
+    # the encoder's last conv and the decoder's upsampler feed the codec transformers through cont(transpose(.)): the producing launch stores through the
+    # copy's strides instead (one launch less per direction). MI355X_NO_CONV_TRANSPOSE_FOLD keeps the copy: same codes, same PCM, bit for bit, fewer kernels.
+    import os
+    cfg = hu.hot.moshika(hu.L)
+    cfg.enable_lm = 0
+    rng = np.random.default_rng(29)
+    frames = [rng.standard_normal(1920).astype(np.float32) * 0.2 for _ in range(6)]
+    res = {}
+    for keep_copy in (False, True):
+        if keep_copy:
+            os.environ["MI355X_NO_CONV_TRANSPOSE_FOLD"] = "1"
+        try:
+            m = hu.Model("hip", cfg, seed=0)
+            codes = [m.mimi_encode(f) for f in frames]
+            pcm = [m.mimi_decode(c).copy() for c in codes]
+            kernels = m.stats().kernels_in_last_plan
+            m.free()
+        finally:
+            os.environ.pop("MI355X_NO_CONV_TRANSPOSE_FOLD", None)
+        res[keep_copy] = (codes, pcm, kernels)
+    assert res[False][0] == res[True][0], "codes differ"
+    for i, (a, b) in enumerate(zip(res[False][1], res[True][1])):
+        assert np.array_equal(a, b), f"frame {i}: PCM differs by {np.abs(a - b).max():.3e}"
+    assert res[False][2] == res[True][2] - 1, (res[False][2], res[True][2])   # (the last plan is the decoder's)
+
+
 def test_mimi_fused_equals_unfused():
     # the codec fusions (streaming conv / conv-transpose groups, RVQ levels and sums, scalar gather, fused transformer layers)
     # against one generic kernel per node on the same device: same codes, same samples up to summation order
