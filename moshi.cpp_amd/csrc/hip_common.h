@@ -188,7 +188,7 @@ struct attn_args {
 #define ATTN_SPLIT_MIN_C 1024
 #define ATTN_SPLIT_SLOTS 128      // ring slots per workgroup once a head is split ...
 #define ATTN_SPLIT_BIG_MIN 1024   // ... doubled when more than this many slots are live (bench sweeps at 230 / 600 / 2900 live slots)
-#define ATTN_SINGLE_MAX 160       // up to this many live slots the head's first workgroup does everything alone
+#define ATTN_SINGLE_MAX 384       // up to this many live slots the head's first workgroup does everything alone (round 5 sweep, profiles/r05_sweep_attn_single_max.txt: 160 -> 384 is -85 / -50 us of Temporal at 190 / 270 live slots, neutral from 360 on; 768 loses at 510)
 size_t k_attn_decode_ws_size(const attn_args & a);
 bool k_attn_split_resident(const attn_args & a, int usable_cus);   // may a head be split over workgroups that wait for each other on this many compute units?
 void k_attn_decode(hipStream_t s, const attn_args & a, void * ws = nullptr, unsigned * err = nullptr);   // *err <- 1 if a head-wide wait timed out
