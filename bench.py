@@ -318,7 +318,7 @@ def main():
     # algorithmic HBM bytes per frame: every weight byte once + the filled KV slots
     wb = [L.moshi_hot_weight_bytes(m, p) for p in range(5)]
     if args.shard == "temporal" and world == 1:
-        wb[0] //= 2    # a one-rank tensor-parallel model holds the unsplit stack AND its (whole) slices; a frame streams the slices only
+        wb[0] -= L.moshi_hot_weight_bytes(m, 5)   # a one-rank tensor-parallel model holds the unsplit stack AND its (whole) slices; a frame streams one of the two
     n_fill_avg = min(cfg.context, args.context_fill + args.warmup + args.steps / 2.0)
     kv_bytes = 2 * cfg.num_layers * n_fill_avg * cfg.dim * 2
     emb_rows = (cfg.n_q + 1) * cfg.dim * 18 / 32 + cfg.dep_q * cfg.dep_dim * 18 / 32

@@ -146,7 +146,7 @@ GGML_API float moshi_hot_sts_pipeline_vad(moshi_hot_model_t * m);
 // introspection for tests / bench
 GGML_API int64_t moshi_hot_offset(moshi_hot_model_t * m);                      // frames stepped so far
 GGML_API void    moshi_hot_last_raw_tokens(moshi_hot_model_t * m, int32_t * text_token, int32_t * audio_tokens);  // sampled this step, before the delay ring
-GGML_API size_t  moshi_hot_weight_bytes(moshi_hot_model_t * m, int part);     // 0 temporal, 1 depth, 2 mimi enc, 3 mimi dec, 4 embeddings
+GGML_API size_t  moshi_hot_weight_bytes(moshi_hot_model_t * m, int part);     // 0 temporal, 1 depth, 2 mimi enc, 3 mimi dec, 4 embeddings, 5 tensor-parallel slices (a subset of 0)
 GGML_API int     moshi_hot_read_last(moshi_hot_model_t * m, const char * what, float * out, int64_t n);  // "text_logits", "transformer_out", "transformer_in", "stack_out", "dep_logits<k>", "enc_latent_first" / "enc_latent_rest" (F32[256]: what the RVQ stacks quantise)
 // a weight tensor by its checkpoint-style name (e.g. "lm.transformer.layers.0.self_attn.in_projs.weight"); tests/ref_link uses it
 // to hand the SAME tensors to the reference's own graph builders

@@ -1215,6 +1215,9 @@ static bool match_conv(const analysis & an, int pos, step_group & grp, emitter &
         }
     }
     for (int m : members) if (m < 0) return false;
+    // The panel hand-off below is a side effect on the emitter (this group registers a slot for its output and may claim its producer's): it must only happen
+    // for a group build_plan will accept, so the clash check it runs on the returned members is made here first.
+    for (int m : members) if (an.skip[(size_t) m]) return false;
     tdesc d_im = make_tdesc(ra), d_w = make_tdesc(rw), d_x = make_tdesc(xin), d_out = make_tdesc(out);
     d_out.ne[0] = OL; d_out.ne[1] = Cout; d_out.ne[2] = d_out.ne[3] = 1;
     if (tcont) { d_out.data = (char *) tcont->data; d_out.nb[0] = (int64_t) tcont->nb[1]; d_out.nb[1] = (int64_t) tcont->nb[0]; }
@@ -1309,6 +1312,7 @@ static bool match_convtr(const analysis & an, int pos, step_group & grp, emitter
     if (is_elu(xin) && uses_of(an, xin) == 1 && pos_of(an, xin) >= 0) { pre_elu = 1; members.push_back(pos_of(an, xin)); xin = xin->src[0]; }
     if (!xin->data) return false;
     for (int m : members) if (m < 0) return false;
+    for (int m : members) if (an.skip[(size_t) m]) return false;   // (as in match_conv: no slot is registered for a group build_plan would drop)
     void * ws = em.ws(k_conv_transpose_1d_ws_size(w, xin));
     const tdesc d_w = make_tdesc(w), d_x = make_tdesc(xin), d_out = make_tdesc(t.out);
     float * pv = (float *) t.prev->data;

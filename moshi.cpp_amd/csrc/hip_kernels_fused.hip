@@ -329,26 +329,6 @@ __global__ void __launch_bounds__(NW * 64) matvec_q4k_kernel(mv_args a, int rows
             if (PRO == MV_GATE_SILU) aux[j] = *(const float4 *) (a.x + K + e);
         }
     };
-#if defined(MV_EXP_TILE_FIRST) || defined(MV_EXP_TILE0_DMA)
-    // Experiments of round 5 (tests/microbench/mv_bench.hip, never in the product build): the wave's first weight tile requested BEFORE the activation
-    // loads - into registers (MV_EXP_TILE_FIRST) or straight into its LDS staging area by LDS-DMA (MV_EXP_TILE0_DMA: global_load_lds_dwordx4, no VGPR hop).
-    u32x4 r_first[NLOAD];
-    if (WS == 0) {
-        const int t0 = wave;
-        const bool has_tile0 = t0 < ntiles;
-#pragma unroll
-        for (int i = 0; i < NLOAD; i++) {
-            const int g = t0 * (NLOAD * 64) + i * 64 + lane;
-            const u32x4 * src = (t0 >= tiles_half ? wsrc_r : wsrc) + (has_tile0 ? (g < nchunks ? g : nchunks - 1) : 0);
-#if defined(MV_EXP_TILE0_DMA)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *) src, (__attribute__((address_space(3))) void *) (stage + i * 1024), 16, 0, 2);
-#else
-            r_first[i] = __builtin_nontemporal_load(src);
-#endif
-        }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-#endif
     if (PRO != MV_PREQ8K && PRO != MV_ATTN) load_batch(0);
     // MV_PREQ8K: the activation arrives quantised (norm_quant / gate_quant kernels): nb padded Q8_K blocks of 304 B = nb * 19 chunks of 16 B,
     // at most 3 per thread (K <= 16384 at 256 threads); requested ahead of the weight tile for the same reason
@@ -367,43 +347,17 @@ __global__ void __launch_bounds__(NW * 64) matvec_q4k_kernel(mv_args a, int rows
     u32x4 r[WS == 0 ? NLOAD : 1];
     u32x4 dh[WS == 1 ? MVD_PMAX : 1], dq[WS == 1 ? MVD_PMAX : 1];   // WS = 1: header / nibble chunk of this lane group's super-block, per pass
     int t = wave;
-#if defined(MV_EXP_LAST_DIRECT)
-    // Experiment (ii) of round 5 (mv_bench only): a wave's LAST tile in the 8-lanes-per-super-block form - 8 passes of {header chunk, nibble chunk} straight
-    // into registers, no LDS image - every other tile through LDS as before. Same integer sums, same float expression per super-block: same bits.
-    u32x4 lh[8], lq[8];
-    auto is_last = [&](int tt) { return tt < ntiles && tt + nwaves >= ntiles; };
-    auto direct_load = [&](int tt) {
-#pragma unroll
-        for (int p = 0; p < 8; p++) {
-            const int sb = tt * 64 + p * 8 + (lane >> 3);
-            const u32x4 * src = (tt >= tiles_half ? wsrc_r : wsrc) + (int64_t) (sb < nblk ? sb : nblk - 1) * 9;
-            lh[p] = __builtin_nontemporal_load(src);
-            lq[p] = __builtin_nontemporal_load(src + 1 + (lane & 7));
-        }
-    };
-    const bool first_is_last = WS == 0 && FMT == MVF_Q4K && is_last(t);
-    if (first_is_last) direct_load(t);
-#else
     constexpr bool first_is_last = false;
-#endif
     if (WS == 0 && first_is_last) {
     } else
     if (WS == 0) {   // unconditional (no branch around a load, see above): chunks past the end re-read the last valid chunk, and a wave without
         // a tile reads chunk 0 in every lane - one 16-byte request instead of a 9 KB tile in the CU's load queue; neither is consumed
         const bool has_tile = t < ntiles;
-#if defined(MV_EXP_TILE_FIRST)
-#pragma unroll
-        for (int i = 0; i < NLOAD; i++) r[i] = r_first[i];
-        (void) has_tile;
-#elif defined(MV_EXP_TILE0_DMA)
-        (void) has_tile; (void) r_first;
-#else
 #pragma unroll
         for (int i = 0; i < NLOAD; i++) {
             const int g = t * (NLOAD * 64) + i * 64 + lane;
             r[i] = __builtin_nontemporal_load((t >= tiles_half ? wsrc_r : wsrc) + (has_tile ? (g < nchunks ? g : nchunks - 1) : 0));
         }
-#endif
     } else {
 #pragma unroll
         for (int p = 0; p < MVD_PMAX; p++) {
@@ -538,25 +492,13 @@ __global__ void __launch_bounds__(NW * 64) matvec_q4k_kernel(mv_args a, int rows
             }
         }
     }
-#if defined(MV_EXP_LAST_DIRECT)
-#define MV_LOOP_MORE (FMT != MVF_Q4K || !is_last(t))
-#else
 #define MV_LOOP_MORE true
-#endif
     for (; WS == 0 && t < ntiles && MV_LOOP_MORE; t += nwaves) {
-#if defined(MV_EXP_TILE0_DMA)
-        if (t == wave) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the tile is in LDS once its LDS-DMA requests have returned)
-        else
-#endif
         {
 #pragma unroll
             for (int i = 0; i < NLOAD; i++) ((u32x4 *) stage)[i * 64 + lane] = r[i];
         }
         MV_STAMP(4);
-#if defined(MV_EXP_LAST_DIRECT)
-        if (FMT == MVF_Q4K && is_last(t + nwaves)) direct_load(t + nwaves);
-        else
-#endif
         {
             const int tn = t + nwaves < ntiles ? t + nwaves : ntiles - 1;
 #pragma unroll
@@ -578,41 +520,6 @@ __global__ void __launch_bounds__(NW * 64) matvec_q4k_kernel(mv_args a, int rows
         }
         __builtin_amdgcn_wave_barrier();
     }
-#if defined(MV_EXP_LAST_DIRECT)
-    if (WS == 0 && FMT == MVF_Q4K && t < ntiles) {   // the wave's last tile, from registers (the WS = 1 arithmetic)
-        MV_STAMP(4);
-#pragma unroll
-        for (int p = 0; p < 8; p++) {
-            const int sb = t * 64 + p * 8 + (lane >> 3);
-            const int j8 = lane & 7, g32 = j8 >> 1, hf = j8 & 1;
-            const xblk * xb = xs + ((sb < nblk ? sb : nblk - 1) % nb);
-            const uint32_t hw[4] = { lh[p].x, lh[p].y, lh[p].z, lh[p].w };
-            uint32_t sc[2], mn[2];
-            q4k_unpack_scales_w(hw[1], hw[2], hw[3], sc, mn);
-            const u32x4 ylo = *(const u32x4 *) (xb->q + 64 * g32 + 16 * hf), yhi = *(const u32x4 *) (xb->q + 64 * g32 + 32 + 16 * hf);
-            const uint32_t qw[4] = { lq[p].x, lq[p].y, lq[p].z, lq[p].w }, yl[4] = { ylo.x, ylo.y, ylo.z, ylo.w }, yh[4] = { yhi.x, yhi.y, yhi.z, yhi.w };
-            int lo = 0, hi = 0;
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                lo = dot4_i8((int) (qw[k] & 0x0F0F0F0Fu), (int) yl[k], lo);
-                hi = dot4_i8((int) ((qw[k] >> 4) & 0x0F0F0F0Fu), (int) yh[k], hi);
-            }
-            const int i0 = 2 * g32, i1 = 2 * g32 + 1;
-            const int s0 = (int) ((sc[i0 >> 2] >> (8 * (i0 & 3))) & 0xff), s1 = (int) ((sc[i1 >> 2] >> (8 * (i1 & 3))) & 0xff);
-            int isum = __mul24(s0, lo) + __mul24(s1, hi);
-            const uint32_t bs2 = *(const uint32_t *) (xb->bsums + 2 * j8);
-            const int bs = (int) (int16_t) (bs2 & 0xffff) + (int) (int16_t) (bs2 >> 16);
-            int msum = __mul24((int) ((mn[j8 >> 2] >> (8 * (j8 & 3))) & 0xff), bs);
-            isum += dpp_i32<DPP_QUAD_XOR1>(isum); msum += dpp_i32<DPP_QUAD_XOR1>(msum);
-            isum += dpp_i32<DPP_QUAD_XOR2>(isum); msum += dpp_i32<DPP_QUAD_XOR2>(msum);
-            isum += dpp_i32<DPP_HALF_MIRROR>(isum); msum += dpp_i32<DPP_HALF_MIRROR>(msum);
-            if (j8 == 0 && sb < nblk) {
-                const float d = h2f((uint16_t) (hw[0] & 0xffff)) * xb->d, dmin = h2f((uint16_t) (hw[0] >> 16)) * xb->d;
-                part[sb] = d * (float) isum - dmin * (float) msum;
-            }
-        }
-    }
-#endif
     MV_STAMP(5);
     __syncthreads();
     MV_STAMP(6);

@@ -1080,7 +1080,7 @@ __global__ void __launch_bounds__(SMALLM_NW * 64) mul_mat_smallm_kernel(tdesc ds
     f16x8 bv[8];
     auto request = [&](int c0) {
 #pragma unroll
-        for (int u = 0; u < 8; u++) { const int kk = (c0 + u) * 512 + lane * 8; bv[u] = *(const f16x8 *) (bp + (kk < K ? kk : lane * 8) * 2); }   // (no load behind a branch; chunks past K are skipped below)
+        for (int u = 0; u < 8; u++) { const int kk = (c0 + u) * 512 + lane * 8; bv[u] = *(const f16x8 *) (bp + (kk < K ? kk : 0) * 2); }   // (no load behind a branch; chunks past K are skipped below and re-read the row's first, in-bounds 16 bytes)
     };
     request(0);
     auto stage = [&](auto fetch) {

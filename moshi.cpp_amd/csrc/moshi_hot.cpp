@@ -140,7 +140,7 @@ struct Weights {
     std::vector<pending> todo;
     std::map<std::string, T> by_name;
     std::set<std::string> file_names;   // the names as a GGUF file carries them (file_name): unique, checked in add()
-    size_t bytes[5] = { 0, 0, 0, 0, 0 };
+    size_t bytes[6] = { 0, 0, 0, 0, 0, 0 };   // by part; [5] = the tensor-parallel slices (also counted in their part)
     int part = 0;
 
     // the name a tensor carries inside the context and inside a GGUF file: the checkpoint name when it fits ggml's name field, else an 8-digit hex
@@ -197,6 +197,7 @@ struct Weights {
         sliced.push_back({ t, gen, name, K, M, rows, k0 });
         by_name[nm] = t;
         bytes[part] += ggml_nbytes(t);
+        bytes[5] += ggml_nbytes(t);
         return t;
     }
     void load_gguf();
@@ -1254,6 +1255,7 @@ extern "C" void moshi_hot_free(moshi_hot_model_t * m) {
     for (auto * b : m->g_shard_step) delete b;
     for (auto * b : m->g_shard_import) delete b;
     for (auto * b : m->g_tp) delete b;
+    delete m->g_tp_pre; delete m->g_tp_import; delete m->g_tp_post;
     if (m->st_buf) ggml_backend_buffer_free(m->st_buf);
     ggml_free(m->st_ctx);
     delete m->W;
@@ -1456,9 +1458,12 @@ void tp_build_frame_graphs(moshi_hot_model * m) {   // (before the step's token 
 }
 void tp_temporal_frame(moshi_hot_model * m) {   // rank 0, inside moshi_hot_lm_step_n: the token inputs of the embedding sum are already uploaded
     const moshi_hot_config & c = m->cfg;
-    m->g_tp_pre->compute();
+    // The "more frames" flag rides behind the stack input. A small tensor_set is only QUEUED on the MI355X backend and reaches the stream with the next
+    // compute / get / synchronize, so it is set BEFORE the embedding-sum graph: that compute's upload flush puts it on the stream ahead of the broadcast
+    // (the graph itself writes elements [0, dim) only).
     const float more = 1.f;
     ggml_backend_tensor_set(m->tp_in, &more, (size_t) c.dim * 4, 4);
+    m->g_tp_pre->compute();
     tp_broadcast_in(m);
     tp_stack_from_in(m);
     m->g_tp_post->compute();
@@ -1471,12 +1476,16 @@ extern "C" void moshi_hot_tp_stack(moshi_hot_model_t * m, const float * x, float
 }
 extern "C" void moshi_hot_tp_install(moshi_hot_model_t * m) {
     GGML_ASSERT(m->tp_x && m->tp_in && !m->cfg.chain_depth && "moshi_hot_tp_install: a model created with tp_world >= 1 and chain_depth = 0");
+    // build_input_embedding appends to the model's embedding index / scale input lists: a Temporal graph built earlier would make them double
+    GGML_ASSERT(!m->g_temporal && "moshi_hot_tp_install: call before the first LM step (the ordinary Temporal graph already owns the embedding inputs)");
     m->tp_frame = true;
 }
 extern "C" void moshi_hot_tp_stop(moshi_hot_model_t * m) {
     const float more = 0.f;
     ggml_backend_tensor_set(m->tp_in, &more, (size_t) m->cfg.dim * 4, 4);
+    ggml_backend_synchronize(m->be);   // flushes the queued upload: the broadcast below must carry THIS flag, not the previous frame's
     tp_broadcast_in(m);
+    ggml_backend_synchronize(m->be);
 }
 extern "C" int64_t moshi_hot_tp_serve(moshi_hot_model_t * m) {
     GGML_ASSERT(m->tp_x && m->tp_in);
@@ -2110,7 +2119,7 @@ extern "C" void moshi_hot_last_raw_tokens(moshi_hot_model_t * m, int32_t * text_
     *text_token = m->last_text;
     for (size_t i = 0; i < m->last_audio.size(); i++) audio_tokens[i] = m->last_audio[i];
 }
-extern "C" size_t moshi_hot_weight_bytes(moshi_hot_model_t * m, int part) { return part >= 0 && part < 5 ? m->W->bytes[part] : 0; }
+extern "C" size_t moshi_hot_weight_bytes(moshi_hot_model_t * m, int part) { return part >= 0 && part < 6 ? m->W->bytes[part] : 0; }
 extern "C" int moshi_hot_read_last(moshi_hot_model_t * m, const char * what, float * out, int64_t n) {
     T t = nullptr;
     if (!strcmp(what, "text_logits")) t = m->text_logits;
@@ -2140,7 +2149,11 @@ extern "C" void moshi_hot_force_last(moshi_hot_model_t * m, int32_t text_token, 
     for (int q = 0; q < m->cfg.dep_q; q++) m->cache[(size_t) wpos][(size_t) (q + 1)] = audio_tokens[q];
     m->tok_state_for = -1;   // the device-side token state still holds the model's own samples
 }
-extern "C" void moshi_hot_set_context_fill(moshi_hot_model_t * m, int64_t offset) { unstage_temporal(m); m->temporal.offset = (int) offset; }
+extern "C" void moshi_hot_set_context_fill(moshi_hot_model_t * m, int64_t offset) {
+    unstage_temporal(m);
+    m->temporal.offset = (int) offset;
+    if (m->tp_x) m->temporal_tp.offset = (int) offset;   // tensor-parallel frame mode steps its own stack (head-sliced rings): same stream position
+}
 
 // identical pseudo-random BF16 rows in every slot of the K / V rings (tests: long-context attention against the oracle over a known cache)
 extern "C" void moshi_hot_fill_ring(moshi_hot_model_t * m, int which, int layer, uint64_t seed, float scale) {

@@ -1,4 +1,7 @@
 #!/bin/bash
+# The -DMV_EXP_* forms are NOT in the product kernel's source any more (round 6): they live in mv_exp_forms.patch (made against hip_kernels_fused.hip at
+# round 5's final commit 80f7b65). To rebuild the variants: `git show 80f7b65:moshi.cpp_amd/csrc/hip_kernels_fused.hip > /tmp/f.hip` (the file WITH the forms), point
+# mv_bench.hip's #include at it and build with -DMV_STAMPS -DMV_EXP_<FORM>; or `patch -p0 < mv_exp_forms.patch` on a checkout of that commit's successor.
 # round-5 Temporal experiment (ii): a wave's last tile in the 8-lanes-per-super-block form (-DMV_EXP_LAST_DIRECT) against the product kernel, mv_bench with stamps
 cd "$(dirname "$0")"
 for pass in 1 2 3; do
