@@ -54,3 +54,34 @@ def test_bench_prints_one_json_line_with_the_contract_fields(extra):
     if not extra:
         assert d["serial_loop"]["value"] < d["value"]          # the two-stream run-ahead loop beats the serial one on the same model
         assert d["value_serial"] == d["serial_loop"]["value"]  # what an unchanged reference tool gets, at the top level
+        # the serial legs run a fixed, warmed-up 125 frames whatever --steps is (6 here): the driver's --steps 20 must not shorten what value_serial rests on
+        assert d["serial_loop"]["steps"] == 125 and d["serial_loop"]["handles"] == 1 and d["serial_loop"]["warmup"] >= 30
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shard", ["depth", "temporal"])
+def test_two_rank_bench_line_on_one_gpu_over_a_gloo_control_plane(shard):
+    """The N > 1 JSON the driver would read from an 8-GPU node, exercised on the one GPU there is: two ranks launched the way the driver launches them
+    (python -m torch.distributed.run, one process per rank), both on device 0, gloo as the control plane and as the shard's transport (--dist-backend gloo;
+    with nccl the same C loop calls RCCL). Strong scaling (ONE stream over all ranks), a `shard` object, both ranks reporting."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dist-backend", "gloo", "--device", "0", "--shard", shard, "--steps", "4", "--warmup", "2",
+           "--no-cpu-baseline", "--no-extras"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=1500, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 4 and d["warmup"] == 2 and d["scaling"] == "strong" and d["unit"] == "frames/s" and d["value"] > 5
+    assert d["ranks_reporting"] == 2 and d["control_backend"] == "gloo" and d["rccl_world_size"] is None
+    sh = d["shard"]
+    assert sh["ranks"] == 2
+    if shard == "depth":
+        assert sh["messages_per_frame"] == 9 and sh["message_bytes"] > 24 * 1024 and 150e6 < sh["depth_weight_bytes_this_rank"] < 200e6
+    else:
+        assert sh["all_reduces_per_frame"] == 64 and sh["all_reduce_bytes"] == 16384 and sh["stack_passes"] >= 6
+        assert 1.7e9 < sh["temporal_weight_bytes_this_rank"] < 2.2e9
