@@ -1437,6 +1437,13 @@ static bool nest_build(chain_plan * c, char * tables_dev, char * din_dev, int us
         }
     }
     if (!a0 || !fits(a0->q_hs) || !fits(a0->k_hs) || !fits(a0->v_hs) || !fits(a0->k_nb1) || !fits(a0->k_nb2) || !fits(a0->v_nb1) || !fits(a0->v_nb2)) return nest_no(12);
+    {   // nest_attn_pair's layout: 16 heads of 64 straight out of the in_proj vector (q | k | v), no rotary embedding (depformer_pos_emb "none", lm_default.h:97-103),
+        // a ring of <= 8 slots whose rows are whole dwords
+        const chain_phase & o0 = c->phases[2];
+        if (a0->H != 2 * CH_NCW || a0->D != 64 || a0->C < 1 || a0->C > 8 || a0->q_hs != 64 || a0->k_hs != 64 || a0->v_hs != 64 || o0.q_off != 0 || o0.k_off != 1024 ||
+            o0.v_off != 2048 || a0->k_nb1 % 4 || a0->k_nb2 % 4 || a0->v_nb1 % 4 || a0->v_nb2 % 4 || (int64_t) a0->H * a0->k_nb2 >= (1ll << 30) || (int64_t) a0->H * a0->v_nb2 >= (1ll << 30)) return nest_no(15);
+        for (int s = 0; s < S; s++) for (int l = 0; l < L; l++) if (c->phases[(size_t) s * per + 1 + 4 * l + 1].at.rot) return nest_no(16);
+    }
     c->nest_smem = nest_smem_bytes(S, L);
     if (c->nest_smem > 160 * 1024) return nest_no(13);
     {   // the whole grid must be resident with THIS kernel's footprint too

@@ -55,6 +55,127 @@ template <class SH, int G> struct nest_dim {
     static_assert((SH::PAIR ? SH::PAIR : SH::M) % G == 0, "rows divide over the grid");
 };
 
+// Attention of a wave's TWO heads (h0, h0 + 1; 64 wide) for the one new token over the ring of <= 8 slots, both heads in ONE pass of the wave:
+// lane = (head of the pair: lane >> 5, slot: (lane >> 2) & 7, 16-dim chunk: lane & 3). chain_attn_wave gives a head the whole wave (slot x 8-dim chunk) and
+// runs the pair's two chains side by side - twice the soft-max chain, 16 per-element selects per head between ring row and new row - and the phase was bound by
+// VALU issue (~450 instructions per wave, two waves per SIMD: profiles/r05_chain_stamps.txt, 2.1 us on each of the 48 attention phases). Here the new
+// row's q / k / v come straight out of the hand-off poll's registers (lane l polled values 2 l, 2 l + 1 of the wave's 128 q, k and v values: no workgroup
+// staging, no barrier in front), the new K / V rows are staged as packed BF16 (ring row vs. new row is a select on 8 + 8 dwords), and max / exp / sum /
+// reciprocal run once for the pair.
+// Arithmetic and ORDER are chain_attn_wave's (= attn_small_wave's, = the unchained kernel's), value for value:
+//   * score: that function's lane sums 8 products sequentially in double, then butterflies over its 8 chunk lanes ((c0 + c1) + (c2 + c3)) + ((c4 + c5) + (c6 + c7));
+//     a lane here holds chunks 2 c', 2 c' + 1: two sequential 8-term sums, their sum (that butterfly's first step), then the two remaining steps over 4 lanes;
+//   * maximum: exact in any order; sum of the exponentials ((e0 + e1) + (e2 + e3)) + ((e4 + e5) + (e6 + e7)): half-mirror, row-mirror, the half's two rows;
+//   * P x V: products rounded to float, the 8 slots added in slot order in double.
+__device__ __forceinline__ void nest_attn_pair(float2 gq, float2 gk, float2 gv, const u32x4 kq[2], const u32x4 vq[2], int C, int slot_new, float m, float scale,
+                                               bool write_cache, __amdgpu_buffer_rsrc_t kr, __amdgpu_buffer_rsrc_t vr, int k_nb1, int k_nb2, int v_nb1, int v_nb2,
+                                               int h0, int lane, float * wbuf, float * xa, int log_wg = -1, int log_p = 0) {
+    CH_ASTAMP(11);
+    const int ah = lane >> 5, slot = (lane >> 2) & 7, chunk = lane & 3;
+    // ---- the new row: BF16 roundings as the ring stores them (q is rounded too: ggml multiplies BF16 rows by a BF16 copy of q)
+    float * wq = wbuf;                                   // [2][64] floats
+    unsigned * wk = (unsigned *) (wbuf + 128), * wv = wk + 64;     // [2][32] packed BF16 pairs each
+    float * prod = wbuf + 256;                           // [2][8][64] floats
+    const unsigned kpack = (unsigned) f2bf(gk.x) | ((unsigned) f2bf(gk.y) << 16), vpack = (unsigned) f2bf(gv.x) | ((unsigned) f2bf(gv.y) << 16);
+    *(float2 *) (wq + 2 * lane) = make_float2(bf2f(f2bf(gq.x)), bf2f(f2bf(gq.y)));
+    wk[lane] = kpack; wv[lane] = vpack;
+    if (write_cache && slot_new >= 0 && slot_new < C) {
+        const int h = h0 + ah, d2 = (lane & 31) * 4;
+        __builtin_amdgcn_raw_buffer_store_b32(kpack, kr, h * k_nb2 + slot_new * k_nb1 + d2, 0, 16);
+        __builtin_amdgcn_raw_buffer_store_b32(vpack, vr, h * v_nb2 + slot_new * v_nb1 + d2, 0, 16);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    CH_ASTAMP(12);
+    // ---- every LDS read in front
+    float qf[16];
+    u32x4 kn[2], vn[2];
+#pragma unroll
+    for (int u = 0; u < 4; u++) { const float4 t = *(const float4 *) (wq + ah * 64 + chunk * 16 + 4 * u); qf[4 * u] = t.x; qf[4 * u + 1] = t.y; qf[4 * u + 2] = t.z; qf[4 * u + 3] = t.w; }
+#pragma unroll
+    for (int u = 0; u < 2; u++) { kn[u] = *(const u32x4 *) (wk + ah * 32 + chunk * 8 + 4 * u); vn[u] = *(const u32x4 *) (wv + ah * 32 + chunk * 8 + 4 * u); }
+    const bool live = slot < C && m > -INFINITY;
+    const bool fresh = slot == slot_new;
+    unsigned kd[8], vd[8];
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+        const unsigned a4[4] = { kq[u].x, kq[u].y, kq[u].z, kq[u].w }, b4[4] = { kn[u].x, kn[u].y, kn[u].z, kn[u].w };
+        const unsigned c4[4] = { vq[u].x, vq[u].y, vq[u].z, vq[u].w }, d4[4] = { vn[u].x, vn[u].y, vn[u].z, vn[u].w };
+#pragma unroll
+        for (int i = 0; i < 4; i++) { kd[4 * u + i] = fresh ? b4[i] : a4[i]; vd[4 * u + i] = fresh ? d4[i] : c4[i]; }
+    }
+    // ---- scores
+    double part[2];
+#pragma unroll
+    for (int hx = 0; hx < 2; hx++) {
+        double a2 = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const int e = hx * 8 + i;
+            const float kf = __uint_as_float((e & 1) ? (kd[e >> 1] & 0xffff0000u) : (kd[e >> 1] << 16));
+            a2 += (double) (kf * qf[e]);
+        }
+        part[hx] = live ? a2 : 0.0;
+    }
+    double acc = part[0] + part[1];
+    acc += dpp_f64<DPP_QUAD_XOR1>(acc);
+    acc += dpp_f64<DPP_QUAD_XOR2>(acc);
+    const float sv = live ? (float) acc * scale + m : -INFINITY;
+    // ---- soft-max over the head's 8 slots (sv is uniform inside a slot's 4 lanes)
+    float gm = fmaxf(sv, dpp_f32<DPP_HALF_MIRROR>(sv));
+    gm = fmaxf(gm, dpp_f32<DPP_ROW_MIRROR>(gm));
+    {
+        const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(gm), 0)), r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(gm), 16));
+        const float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(gm), 32)), r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(gm), 48));
+        gm = ah ? fmaxf(r2, r3) : fmaxf(r0, r1);
+    }
+    const float e = sv > -INFINITY ? expf(sv - gm) : 0.f;
+    double ls = (double) e;
+    ls += dpp_f64<DPP_HALF_MIRROR>(ls);
+    ls += dpp_f64<DPP_ROW_MIRROR>(ls);
+    {
+        const int lo = __double2loint(ls), hi = __double2hiint(ls);
+        const double r0 = __hiloint2double(__builtin_amdgcn_readlane(hi, 0), __builtin_amdgcn_readlane(lo, 0));
+        const double r1 = __hiloint2double(__builtin_amdgcn_readlane(hi, 16), __builtin_amdgcn_readlane(lo, 16));
+        const double r2 = __hiloint2double(__builtin_amdgcn_readlane(hi, 32), __builtin_amdgcn_readlane(lo, 32));
+        const double r3 = __hiloint2double(__builtin_amdgcn_readlane(hi, 48), __builtin_amdgcn_readlane(lo, 48));
+        ls = ah ? r2 + r3 : r0 + r1;
+    }
+    const float inv = (float) (1.0 / ls);
+    const float pr = bf2f(f2bf(e * inv));
+    // ---- P x V products (a slot whose probability is zero contributes exact zeros whatever its row holds)
+    {
+        // (pr != 0 ? v * pr : 0, with the select on the 8 packed words: a zeroed row gives 0 * pr = +0 for pr = +0, the products otherwise)
+        float pf[16];
+#pragma unroll
+        for (int i = 0; i < 8; i++) vd[i] = pr != 0.f ? vd[i] : 0u;
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            const float vf = __uint_as_float((i & 1) ? (vd[i >> 1] & 0xffff0000u) : (vd[i >> 1] << 16));
+            pf[i] = vf * pr;
+        }
+        float * dst = prod + ah * 512 + slot * 64 + chunk * 16;
+#pragma unroll
+        for (int u = 0; u < 4; u++) *(float4 *) (dst + 4 * u) = make_float4(pf[4 * u], pf[4 * u + 1], pf[4 * u + 2], pf[4 * u + 3]);
+    }
+    CH_ASTAMP(13);
+    CH_ASTAMP(14);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    {   // lane l: dims 2 (l & 31), + 1 of head l >> 5, the 8 slots in slot order
+        float2 t[8];
+#pragma unroll
+        for (int c2 = 0; c2 < 8; c2++) t[c2] = *(const float2 *) (prod + ah * 512 + c2 * 64 + 2 * (lane & 31));
+        double t0 = 0, t1 = 0;
+#pragma unroll
+        for (int c2 = 0; c2 < 8; c2++) { t0 += (double) t[c2].x; t1 += (double) t[c2].y; }
+        *(float2 *) (xa + 2 * lane) = make_float2((float) t0, (float) t1);
+    }
+    CH_ASTAMP(15);
+}
+
 template <int G>
 __global__ void __launch_bounds__(CH_THREADS) depth_nest_kernel(nest_params N) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -472,30 +593,52 @@ __global__ void __launch_bounds__(CH_THREADS) depth_nest_kernel(nest_params N) {
                 CH_STAMP(10);
                 const nest_ph ph = ld_ph(p);
                 const nest_at ta = ld_at(s * L + l);
-                attn_args at;
-                at.q_hs = N.q_hs; at.k_hs = N.k_hs; at.v_hs = N.v_hs; at.rot = ta.rot; at.mask = ta.mask; at.index = ta.index; at.kcache = ta.kcache; at.vcache = ta.vcache;
-                at.k_nb1 = N.k_nb1; at.k_nb2 = N.k_nb2; at.v_nb1 = N.v_nb1; at.v_nb2 = N.v_nb2; at.H = 2 * CH_NCW; at.D = 64; at.C = N.C; at.T = 1; at.scale = N.scale;
                 CH_STAMP(0);
+                // what does not depend on the chain goes out before the wait: the ring rows of the wave's two heads as earlier steps of this frame (and earlier
+                // frames, where the ring holds them) left them - 16 dims of one (head, slot) per lane, see nest_attn_pair -, the ring slot, the mask row
+                const int a_h = lane >> 5, a_slot = (lane >> 2) & 7, a_cc = a_slot < N.C ? a_slot : N.C - 1;
+                const __amdgpu_buffer_rsrc_t kr = make_rsrc(ta.kcache, (unsigned) (2 * CH_NCW * N.k_nb2));
+                const __amdgpu_buffer_rsrc_t vr = make_rsrc(ta.vcache, (unsigned) (2 * CH_NCW * N.v_nb2));
                 u32x4 kq[2], vq[2];
-                const __amdgpu_buffer_rsrc_t kr = make_rsrc(at.kcache, (unsigned) ((int64_t) at.H * at.k_nb2));
-                const __amdgpu_buffer_rsrc_t vr = make_rsrc(at.vcache, (unsigned) ((int64_t) at.H * at.v_nb2));
-                chain_attn_ring_loads(at, wave * 2, lane, kq, vq, kr, vr);
-                float at_rc = 1.f, at_rs = 0.f;
-                const int sub = lane / 8, cc = sub < at.C ? sub : at.C - 1, pp = lane < 32 ? lane : lane - 32;
-                const int at_slot = gp(at.index)[0];
-                const float at_m = gp(at.mask)[cc];
-                if (at.rot) { at_rc = gp(at.rot)[pp]; at_rs = gp(at.rot)[32 + pp]; }
+                {
+                    const unsigned ko = (unsigned) ((wave * 2 + a_h) * N.k_nb2 + a_cc * N.k_nb1 + (lane & 3) * 32);
+                    const unsigned vo = (unsigned) ((wave * 2 + a_h) * N.v_nb2 + a_cc * N.v_nb1 + (lane & 3) * 32);
+                    kq[0] = ld16_agent(kr, ko); kq[1] = ld16_agent(kr, ko + 16u);
+                    vq[0] = ld16_agent(vr, vo); vq[1] = ld16_agent(vr, vo + 16u);
+                }
+                const int at_slot = gp(ta.index)[0];
+                const float at_m = gp(ta.mask)[a_cc];
                 CH_STAMP(1);
                 for (int i = 0; i < N.delay[1]; i++) __builtin_amdgcn_s_sleep(1);
-                if (!gather_vector_n<3>(gb, (unsigned) ((p - 1) & 1) * (CH_XF_MAX * 8u), 3072 / 2, tag_base | (unsigned) p, xf, wave, lane, ctl)) give_up();
+                // the in_proj rows of the wave's own two heads, straight into registers: pair lane of the wave's 128 q values, of its 128 k and of its 128 v values
+                float2 gq, gk, gv;
+                {
+                    const unsigned tag_in = tag_base | (unsigned) p;
+                    const unsigned base = (unsigned) ((p - 1) & 1) * (CH_XF_MAX * 8u) + (unsigned) (wave * 64 + lane) * 16u;
+                    u32x4 g[3];
+                    unsigned spins = 0;
+                    for (;;) {
+#pragma unroll
+                        for (int it = 0; it < 3; it++) g[it] = ld16_agent(gb, base + (unsigned) it * (512u * 16u));
+                        bool ok = true;
+#pragma unroll
+                        for (int it = 0; it < 3; it++) ok = ok && g[it].y == tag_in && g[it].w == tag_in;
+                        if (__all(ok)) break;
+                        if (++spins > CH_SPIN_MAX || lds_load(&ctl->failed)) { give_up(); break; }
+                        __builtin_amdgcn_s_sleep(1);
+                    }
+                    settle_vmcnt();
+                    gq = make_float2(__uint_as_float(g[0].x), __uint_as_float(g[0].z));
+                    gk = make_float2(__uint_as_float(g[1].x), __uint_as_float(g[1].z));
+                    gv = make_float2(__uint_as_float(g[2].x), __uint_as_float(g[2].z));
+                }
                 CH_STAMP(2);
-                nbar();
-                chain_attn_wave(at, xf + N.q_off, xf + N.k_off, xf + N.v_off, wave * 2, lane, attw + wave * CH_ATTW, xa + wave * 128, kq, vq, wg == 0, kr, vr,
-                                at_slot, at_m, at_rc, at_rs
+                nest_attn_pair(gq, gk, gv, kq, vq, N.C, at_slot, at_m, N.scale, wg == 0, kr, vr, N.k_nb1, N.k_nb2, N.v_nb1, N.v_nb2, wave * 2, lane,
+                               attw + wave * CH_ATTW, xa + wave * 128
 #if defined(CH_LOG)
-                                , wg == 0 ? 0 : wg == grid - 1 ? 1 : -1, p
+                               , wg == 0 ? 0 : wg == grid - 1 ? 1 : -1, p
 #endif
-                                );
+                               );
                 nbar();
                 CH_STAMP(3);
                 float v[2][4] = { { 0.f, 0.f, 0.f, 0.f }, { 0.f, 0.f, 0.f, 0.f } };

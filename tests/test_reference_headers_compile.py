@@ -45,8 +45,9 @@ TU = r'''
 #include "tools/common_ggml.h"
 int main() { return 0; }
 '''
-# src/moshi/models/lm.h is left out only because it needs `Entry` from include/moshi/moshi.h, which includes
-# <sentencepiece_processor.h> (absent from this image); its ggml calls are the same ones lm_utils.h/transformer.h make.
+# src/moshi/models/lm.h is left out HERE because it needs `Entry` from include/moshi/moshi.h, which includes <sentencepiece_processor.h> (absent from this
+# image); tests/test_reference_link_run.py::test_reference_lm_frame_driver_runs_token_identical_to_driver compiles AND runs it (with an empty header of that
+# name on the include path).
 
 
 @pytest.mark.skipif(not os.path.isdir(REF) or shutil.which("g++") is None, reason="reference checkout / g++ not available")
