@@ -313,9 +313,9 @@ struct pstep {
     template <typename F> pstep(F f) : fn(std::move(f)) { memset(&mv, 0, sizeof(mv)); }
     pstep(const mv_args & a) : fn([a](hipStream_t s) { k_matvec(s, a); }), is_mv(true), mv(a) {}
     // a step that is not a mat-vec but may be taken into a persistent step program next to its neighbours (mv.special): it keeps its own launch otherwise
-    template <typename F> static pstep special_step(F f, int special, const attn_args * at, const lowrank_embed_args * lr) {
+    template <typename F> static pstep special_step(F f, int special, const attn_args * at, const lowrank_embed_args * lr, const sample_args * smp = nullptr) {
         pstep st(std::move(f));
-        st.is_mv = true; st.mv.special = special; st.mv.attn = at; st.mv.lr = lr;
+        st.is_mv = true; st.mv.special = special; st.mv.attn = at; st.mv.lr = lr; st.mv.smp = smp;
         return st;
     }
 };
@@ -326,6 +326,7 @@ struct plan_t {
     std::vector<std::pair<void *, size_t>> workspaces;
     std::vector<std::unique_ptr<attn_args>> attn_copies;
     std::vector<std::unique_ptr<lowrank_embed_args>> lowrank_copies;
+    std::vector<std::unique_ptr<sample_args>> sampler_copies;
     std::vector<std::unique_ptr<conv_scatter>> scatter_slots;   // see emitter::scatter_of
     std::vector<const ggml_backend_buffer *> buffers;   // every buffer a node / leaf of the planned graph lives in: freeing one orphans the plan
     uint64_t orphan_seq = 0;                            // != 0: a buffer of the planned graph has been freed since (see evict_plans_of_buffer)
@@ -1143,7 +1144,7 @@ static bool match_embed_sum(const analysis & an, int pos, embed_group & grp) {
 
 // D. streaming / stateless conv1d (conv.h:50-96, 137-161): [elu] -> concat(prev, x) -> {tail cpy, im2col} -> mul_mat -> reshape
 //    [-> + bias] [-> residual + y]  becomes  stream_im2col + conv_tail + one product with the bias/residual epilogue.
-struct step_group { std::vector<step_fn> steps; int emit_pos; std::vector<int> members; };
+struct step_group { std::vector<step_fn> steps; int emit_pos; std::vector<int> members; sample_args smp; };   // smp: match_sampler's arguments (n = 0 otherwise)
 
 static bool is_elu(const ggml_tensor * t) { return t->op == GGML_OP_UNARY && t->op_params[0] == GGML_UNARY_OP_ELU && t->view_src == NULL; }
 
@@ -1587,6 +1588,7 @@ static bool match_sampler(const analysis & an, int pos, step_group & grp) {
     grp.steps.push_back([=](hipStream_t s) { k_sample_topk(s, a); });
     grp.members = members;
     grp.emit_pos = pos;
+    grp.smp = a;
     return true;
 }
 
@@ -1678,7 +1680,9 @@ static plan_t * build_plan(hip_ctx * c, ggml_cgraph * g, bool keep = true) {
             for (int m : grp.members) if (an.skip[(size_t) m]) clash = true;
             if (clash) continue;
             for (int m : grp.members) an.skip[(size_t) m] = 1;
-            for (auto & f : grp.steps) at_pos[grp.emit_pos].push_back(f);
+            // (a step of its own that a step program may take in: the Depth transformer's samplers sit between its steps' mat-vecs, mv_args::special = 3)
+            p->sampler_copies.emplace_back(new sample_args(grp.smp));
+            for (auto & f : grp.steps) at_pos[grp.emit_pos].push_back(pstep::special_step(f, 3, nullptr, nullptr, p->sampler_copies.back().get()));
             p->n_fused += (int) grp.members.size();
         }
         // cross-attention over cached conditions (tts)
@@ -2029,12 +2033,12 @@ static plan_t * build_plan(hip_ctx * c, ggml_cgraph * g, bool keep = true) {
             for (size_t k = i; k < e; k++) run.push_back(p->steps[k].mv);
             size_t k = 0;
             while (k < run.size()) {
-                int len = k_chain_accept(run.data() + k, (int) (run.size() - k), c->usable_cus);
+                int len = k_chain_accept(run.data() + k, (int) (run.size() - k), c->usable_cus, !(c->flags & 1024));
                 if (len > 0 && !spin_kernels_allowed(c)) len = 0;
                 if (len <= 0) {
                     merged.push_back(std::move(p->steps[i + k])); k++; continue;
                 }
-                void * ws = em.ws(k_chain_ws_size(run.data() + k, len, c->usable_cus));
+                void * ws = em.ws(k_chain_ws_size(run.data() + k, len, c->usable_cus, !(c->flags & 1024)));
                 chain_plan * ch = k_chain_create(c->stream, run.data() + k, len, ws, c->err_dev, c->usable_cus, !(c->flags & 1024));
                 p->chains.push_back(ch);
                 if (k_chain_is_step_program(ch)) p->n_step_programs++;

@@ -1313,7 +1313,51 @@ static bool mimi_resident(const mimi_desc & d, int usable_cus) {
     return force || (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *) mimi_tr_kernel, CH_THREADS, smem) == hipSuccess && (long long) per_cu * usable_cus >= 256);
 }
 
-int k_chain_accept(const mv_args * mv, int n, int usable_cus) {
+// ---- the Depth step program in the reference's sampling mode (tools/moshi-sts.cpp:106-107; moshi_sample_token, sampling.h:4-64) --------------------------
+// With temp > 0 a sampler sits between linears[k] and the next step's embedding row (mv_args::special = 3 in launch order). The run
+//     { depformer_in .. linears[k] (plain logits), sampler } x steps
+// is the greedy run - linears[k] with an arg-max epilogue whose token the next step embeds - up to the rule that picks the token, so it is analysed AS that
+// run: the sampler entries are taken out, each logits mat-vec in front of one gets the sampler's token outputs as its arg-max outputs, and chain_analyse /
+// nest_build do the rest. Only the step program implements the rule (hip_chain_nest.h, head_argmax = 2): there is no descriptor-driven fall-back, so such a
+// run is accepted only where nest_build succeeds; otherwise the samplers keep their launches and cut the run into per-step chains as before.
+struct smp_strip { std::vector<mv_args> mv; std::vector<const sample_args *> smp; std::vector<int> end_of; bool any = false; };
+static unsigned g_sampled_ticket;   // (never dereferenced: marks a logits mat-vec whose token a sampler picks)
+static void sampled_strip(const mv_args * mv, int n, smp_strip & o) {
+    for (int i = 0; i < n; i++) {
+        const mv_args & a = mv[i];
+        if (!a.special) { o.mv.push_back(a); o.smp.push_back(nullptr); o.end_of.push_back(i + 1); continue; }
+        if (a.special != 3 || o.mv.empty() || o.smp.back() || !a.smp) break;
+        mv_args & hd = o.mv.back();
+        const sample_args & sa = *a.smp;
+        if (hd.ticket || hd.argmax_out[0] || hd.argmax_out[1] || sa.logits != hd.y || sa.n != hd.M || sa.n != 2048 || sa.k < 1 || sa.k > 256 || !sa.noise || !sa.out) break;
+        hd.ticket = &g_sampled_ticket; hd.argmax_out[0] = sa.out; hd.argmax_out[1] = sa.out2;
+        o.smp.back() = a.smp; o.end_of.back() = i + 1; o.any = true;
+    }
+}
+static void chain_fill(chain_plan * c);
+static bool nest_build(chain_plan * c, char * tables_dev, char * din_dev, int usable_cus);
+// entries of the run a sampled step program takes (0: none); *st (optional) receives the stripped run cut to exactly that
+static int nest_sampled_try(const mv_args * mv, int n, int usable_cus, smp_strip * st) {
+    if (n < 7 || mv[0].special || chain_grid_for(usable_cus) != 256) return 0;
+    smp_strip o;
+    sampled_strip(mv, n, o);
+    if (!o.any) return 0;
+    chain_plan tmp;
+    tmp.grid = 256; tmp.smem = 0;
+    memset(&tmp.P, 0, sizeof(tmp.P));
+    int len = chain_analyse(o.mv.data(), (int) o.mv.size(), 256, tmp.phases, tmp.attns);
+    while (len > 0 && !o.smp[(size_t) len - 1]) len--;          // the run ends behind a sampled head
+    if (len <= 0) return 0;
+    if (chain_analyse(o.mv.data(), len, 256, tmp.phases, tmp.attns) != len) return 0;
+    for (int i = 0; i < len; i++) if ((tmp.phases[(size_t) i].argmax != 0) != (o.smp[(size_t) i] != nullptr)) return 0;   // every token of the run is a sampled one
+    chain_fill(&tmp);
+    if (!nest_build(&tmp, nullptr, nullptr, usable_cus)) return 0;
+    const int taken = o.end_of[(size_t) len - 1];
+    if (st) { o.mv.resize((size_t) len); o.smp.resize((size_t) len); o.end_of.resize((size_t) len); *st = std::move(o); }
+    return taken;
+}
+
+int k_chain_accept(const mv_args * mv, int n, int usable_cus, bool allow_step_program) {
     if (n >= 10 && ((!mv[0].special && mv[0].wtype == GGML_TYPE_F32 && mv[0].ncols == 2) || (mv[0].special == 1 && mv[0].attn->T == 2)) && chain_grid_for(usable_cus) == 256) {
         mimi_desc d;
         const int len = mimi_match(mv, n, d);
@@ -1325,6 +1369,7 @@ int k_chain_accept(const mv_args * mv, int n, int usable_cus) {
         if (len > 0 && nest80_resident(d, usable_cus)) return len;
     }
     if (n > 0 && mv[0].special) return 0;
+    if (allow_step_program) { const int len = nest_sampled_try(mv, n, usable_cus, nullptr); if (len > 0) return len; }
     static const int min_len = chain_env("MI355X_CHAIN_MIN", 4);
     if (n < min_len) return 0;
     const int G = chain_grid_for(usable_cus);
@@ -1346,7 +1391,7 @@ static size_t chain_state_bytes(int grid) { return 256 + 2 * (size_t) CH_XF_MAX 
 // what a step program adds: its compact tables and the [steps][1024] granules of the hoisted depformer_in products (upper bounds: reserved for every run)
 static size_t nest_tables_bytes(int n) { return GGML_PAD((size_t) n * (sizeof(nest_ph) + sizeof(nest_at)) + NEST_STEPS_MAX * sizeof(nest_st), 256); }
 static size_t nest_din_bytes() { return (size_t) NEST_STEPS_MAX * 1024 * 8; }
-size_t k_chain_ws_size(const mv_args * mv, int n, int usable_cus) {
+size_t k_chain_ws_size(const mv_args * mv, int n, int usable_cus, bool allow_step_program) {
     if (n >= 10 && ((!mv[0].special && mv[0].wtype == GGML_TYPE_F32 && mv[0].ncols == 2) || (mv[0].special == 1 && mv[0].attn->T == 2))) {
         mimi_desc d;
         if (mimi_match(mv, n, d) == n) return mimi_tables_bytes(d) + chain_state_bytes(256);
@@ -1358,6 +1403,8 @@ size_t k_chain_ws_size(const mv_args * mv, int n, int usable_cus) {
     }
     std::vector<chain_phase> ph; std::vector<attn_args> at;
     const int G = chain_grid_for(usable_cus);
+    smp_strip st;
+    if (allow_step_program && nest_sampled_try(mv, n, usable_cus, &st) == n) { mv = st.mv.data(); n = (int) st.mv.size(); }
     const int len = chain_analyse(mv, n, G, ph, at);
     return chain_tables_bytes(len, (int) at.size()) + chain_state_bytes(G) + nest_tables_bytes(len) + nest_din_bytes();
 }
@@ -1580,6 +1627,9 @@ chain_plan * k_chain_create(hipStream_t s, const mv_args * mv, int n, void * ws,
         }
     }
     GGML_ASSERT(c->grid > 0 && n <= CH_MAX_PHASES);
+    smp_strip sampled;   // (sampling mode: the run as the greedy run it is analysed as, see nest_sampled_try)
+    const bool is_sampled = allow_step_program && nest_sampled_try(mv, n, usable_cus, &sampled) == n;
+    if (is_sampled) { mv = sampled.mv.data(); n = (int) sampled.mv.size(); }
     const int len = chain_analyse(mv, n, c->grid, c->phases, c->attns);
     GGML_ASSERT(len == n && "k_chain_create: pass exactly the run k_chain_accept took");
     char * base = (char *) ws;
@@ -1587,16 +1637,7 @@ chain_plan * k_chain_create(hipStream_t s, const mv_args * mv, int n, void * ws,
     char * state = base + chain_tables_bytes(n, (int) c->attns.size());
     char * nest_tab = state + chain_state_bytes(c->grid);
     char * nest_din = nest_tab + nest_tables_bytes(n);
-    {
-        int ai = 0;
-        for (int i = 0; i < n; i++) {
-            chain_phase & ph = c->phases[(size_t) i];
-            if (ph.attn >= 0) ph.at = c->attns[(size_t) ai++];
-            ph.n_in = i > 0 ? c->phases[(size_t) i - 1].n_pub : 0;
-            ph.kind = chain_shape_kind(ph, c->grid);
-            if (ph.emb_chain) { ph.prev_out[0] = c->phases[(size_t) i - 1].argmax_out[0]; ph.prev_out[1] = c->phases[(size_t) i - 1].argmax_out[1]; }
-        }
-    }
+    chain_fill(c);
     // the table is uploaded from the plan's own vector (pageable memory: the runtime stages it before returning); the host copy lives as long as the plan
     HIP_CHECK(hipMemcpyAsync(d_ph, c->phases.data(), (size_t) n * sizeof(chain_phase), hipMemcpyHostToDevice, s));
     HIP_CHECK(hipMemsetAsync(state, 0, chain_state_bytes(c->grid) + nest_tables_bytes(n) + nest_din_bytes(), s));
@@ -1612,8 +1653,31 @@ chain_plan * k_chain_create(hipStream_t s, const mv_args * mv, int n, void * ws,
     c->smem = chain_smem();
     GGML_ASSERT(c->smem <= 160 * 1024);
     c->nest = allow_step_program && nest_build(c, nest_tab, nest_din, usable_cus);
+    if (is_sampled) {
+        GGML_ASSERT(c->nest && "k_chain_create: a sampled run is only ever accepted as a step program");
+        // the samplers' arguments, step by step: the token rule of the linears[k] phases (head_argmax = 2)
+        const int per = n / c->NP.n_steps;
+        nest_st * ts = (nest_st *) (c->nest_tables.data() + (size_t) c->NP.n_steps * ((4 * c->NP.n_layers + 1) * sizeof(nest_ph) + c->NP.n_layers * sizeof(nest_at)));
+        for (int st = 0; st < c->NP.n_steps; st++) {
+            const sample_args * sa = sampled.smp[(size_t) (st + 1) * per - 1];
+            GGML_ASSERT(sa);
+            ts[st].noise = sa->noise; ts[st].smp_scale = sa->scale; ts[st].smp_k = sa->k;
+        }
+        c->NP.head_argmax = 2;
+    }
     if (c->nest) HIP_CHECK(hipMemcpyAsync(nest_tab, c->nest_tables.data(), c->nest_tables.size(), hipMemcpyHostToDevice, s));
     return c;
+}
+// per-phase fields that follow from the analysed run: the attention a phase recomputes, what it is handed, its compile-time shape, where a chained token is stored
+static void chain_fill(chain_plan * c) {
+    int ai = 0;
+    for (size_t i = 0; i < c->phases.size(); i++) {
+        chain_phase & ph = c->phases[i];
+        if (ph.attn >= 0) ph.at = c->attns[(size_t) ai++];
+        ph.n_in = i > 0 ? c->phases[i - 1].n_pub : 0;
+        ph.kind = chain_shape_kind(ph, c->grid);
+        if (ph.emb_chain) { ph.prev_out[0] = c->phases[i - 1].argmax_out[0]; ph.prev_out[1] = c->phases[i - 1].argmax_out[1]; }
+    }
 }
 void k_chain_free(chain_plan * c) { delete c; }
 int k_chain_length(const chain_plan * c) { return c->P.n_phases; }

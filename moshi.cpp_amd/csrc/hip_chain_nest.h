@@ -24,6 +24,7 @@ struct nest_st {                                                                
     embed_src emb; int32_t * prev_out[2];   // the embedding row added to din_k; emb_chain: its index is the previous step's arg-max, stored to prev_out
     int32_t * argmax_out[2];                // where the LAST step's token goes (the others are their successors' prev_out)
     int emb_chain; int pad[3];
+    const float * noise; float smp_scale; int smp_k;   // head_argmax = 2: this step's sampler (Exp(1) noise F32[k] uploaded per compute, 1 / temp, top-k)
 };
 static_assert(sizeof(nest_ph) == 32 && sizeof(nest_at) == 48 && sizeof(nest_st) % 16 == 0, "nest tables are copied to LDS by 16-byte lanes");
 
@@ -31,7 +32,8 @@ struct nest_params {
     chain_params P;                         // hand-off buffers, launch counter, error word (phases / n_phases unused)
     const u32x4 * tables;                   // device: nest_ph[n_steps * (4 L + 1)] | nest_at[n_steps * L] | nest_st[n_steps]
     int n_steps, n_layers;
-    int head_argmax;                        // 0: linears[k] ends the run as plain logits (a sampler launch follows: temp > 0, one step per run)
+    int head_argmax;                        // 0: linears[k] ends the run as plain logits (a sampler launch follows: temp > 0, one step per run); 1: greedy arg-max;
+                                            // 2: the top-k sampler of sampling.h:4-64 as the tail of every linears[k] phase (nest_st::noise / smp_scale / smp_k)
     u64 * din_buf;                          // [n_steps][1024] granules: the hoisted depformer_in products
     const float * din_x;                    // transformer_out (lm.h:434), x of every depformer_in
     // the attention's shape, the same in every layer and step (checked when the plan is made)
@@ -54,6 +56,40 @@ template <class SH, int G> struct nest_dim {
     static constexpr int PASSES = (NALL + CH_NCW * 8 - 1) / (CH_NCW * 8);
     static_assert((SH::PAIR ? SH::PAIR : SH::M) % G == 0, "rows divide over the grid");
 };
+
+// Sampling mode: every workgroup's candidate of `tag` is a 64-bit key - (bits of q) << 32 | rank << 11 | token index, q = p / noise[rank] >= 0, 0 = none - whose
+// maximum is the sampler's choice (the LAST maximum of q over the ranks, sampling.h:15 / ggml_vec_argmax_f32). One wave reads and merges them like gather_token.
+__device__ __forceinline__ bool gather_sampled(__amdgpu_buffer_rsrc_t cb, unsigned base_bytes, int grid, unsigned tag, int lane, chain_ctl * ctl, int & token) {
+    unsigned spins = 0;
+    for (;;) {
+        u32x4 c[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int g = i * 64 + lane;
+            c[i] = ld16_agent(cb, base_bytes + (unsigned) (g < grid ? g : grid - 1) * 16u);
+        }
+        u64 key = 0;
+        bool ok = true;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int g = i * 64 + lane;
+            ok = ok && c[i].y == tag && c[i].w == tag;
+            const u64 kc = ((u64) c[i].x << 32) | (u64) c[i].z;
+            if (g < grid && kc > key) key = kc;
+        }
+        if (__all(ok)) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const u64 ok2 = ((u64) (unsigned) __shfl_xor((int) (key >> 32), o, 64) << 32) | (u64) (unsigned) __shfl_xor((int) (unsigned) key, o, 64);
+                key = ok2 > key ? ok2 : key;
+            }
+            token = (int) ((unsigned) key & 0x7ffu);
+            return true;
+        }
+        if (++spins > CH_SPIN_MAX || lds_load(&ctl->failed)) { settle_vmcnt(); return false; }
+        __builtin_amdgcn_s_sleep(1);
+    }
+}
 
 // Attention of a wave's TWO heads (h0, h0 + 1; 64 wide) for the one new token over the ring of <= 8 slots, both heads in ONE pass of the wave:
 // lane = (head of the pair: lane >> 5, slot: (lane >> 2) & 7, 16-dim chunk: lane & 3). chain_attn_wave gives a head the whole wave (slot x 8-dim chunk) and
@@ -414,7 +450,7 @@ __global__ void __launch_bounds__(CH_THREADS) depth_nest_kernel(nest_params N) {
         nbar();
     };
     // fixed-order row sums of an unpaired phase + epilogue + publication; rows_rt as in request()
-    auto rowsum = [&](auto shape_tag, int rows_rt, int p, float * y, float & best, int & bi) {
+    auto rowsum = [&](auto shape_tag, int rows_rt, int p, float * y, float & best, int & bi, bool pub_rt = false) {   // pub_rt: publish although the shape does not (sampled logits)
         using SH = decltype(shape_tag);
         using D = nest_dim<SH, G>;
         const int rows = rows_rt > 0 ? rows_rt : D::ROWS;
@@ -430,7 +466,7 @@ __global__ void __launch_bounds__(CH_THREADS) depth_nest_kernel(nest_params N) {
                 const long long row = row0 + rr;
                 if (SH::RES == 1) sum = xres[rr] + sum;
                 if (SH::SAVE) xres[rr] = sum;
-                if (SH::PUB) st_granule(P.gbuf + pub_base + row, tag_out, __float_as_uint(sum));
+                if (SH::PUB || pub_rt) st_granule(P.gbuf + pub_base + row, tag_out, __float_as_uint(sum));
                 gp(y)[row] = sum;
                 if (sum >= best) { best = sum; bi = (int) row; }   // rows ascend per thread: '>=' keeps the last maximum
             }
@@ -541,7 +577,9 @@ __global__ void __launch_bounds__(CH_THREADS) depth_nest_kernel(nest_params N) {
                     if (st.emb_chain) {
                         if (wave == 0) {
                             int token = 0;
-                            if (!gather_token(cb, (unsigned) ((p - 1) & 1) * (2u * (unsigned) grid * 8u), grid, tag_base | (unsigned) p, lane, ctl, token)) give_up();
+                            const bool got = N.head_argmax == 2 ? gather_sampled(cb, (unsigned) ((p - 1) & 1) * (2u * (unsigned) grid * 8u), grid, tag_base | (unsigned) p, lane, ctl, token)
+                                                                : gather_token(cb, (unsigned) ((p - 1) & 1) * (2u * (unsigned) grid * 8u), grid, tag_base | (unsigned) p, lane, ctl, token);
+                            if (!got) give_up();
                             if (lane == 0) {
                                 ctl->token = token;
                                 if (wg == 0) { if (st.prev_out[0]) *gp(st.prev_out[0]) = token; if (st.prev_out[1]) *gp(st.prev_out[1]) = token; }
@@ -729,6 +767,13 @@ __global__ void __launch_bounds__(CH_THREADS) depth_nest_kernel(nest_params N) {
         {
             CH_STAMP(10);
             const nest_ph ph = ld_ph(p);
+            // sampling mode: this step's noise vector goes out now (rank j's noise in thread j; uploaded by the host in front of the graph, src/context.h:465-480)
+            float smp_noise = 1.f, smp_scale = 1.f; int smp_k = 1;
+            if (N.head_argmax == 2) {
+                const nest_st sst = ld_st(s);
+                smp_scale = sst.smp_scale; smp_k = sst.smp_k;
+                smp_noise = gp(sst.noise)[tid < smp_k ? tid : 0];
+            }
             CH_STAMP(0);
             float v[2][4];
             CH_STAMP(1);
@@ -745,9 +790,112 @@ __global__ void __launch_bounds__(CH_THREADS) depth_nest_kernel(nest_params N) {
             nbar();
             CH_STAMP(7);
             float best = -INFINITY; int bi = -1;
-            rowsum(shape_head(), 0, p, ph.y, best, bi);
+            rowsum(shape_head(), 0, p, ph.y, best, bi, N.head_argmax == 2);
             CH_STAMP(8);
-            if (N.head_argmax) {
+            if (N.head_argmax == 2) {
+                // ---- the top-k sampler (moshi_sample_token, sampling.h:4-64) as the tail of the phase, spread over ALL workgroups: sample_topk_kernel's values
+                // (soft-max in its summation order, ranks by value descending / index ascending, q = p / noise[rank], last maximum) without its sort. Every
+                // workgroup gathers the 2 048 logits (published by rowsum above), computes the soft-max statistics itself, RANKS ITS OWN 8 ROWS by counting the
+                // probabilities ahead of each, and publishes its best (q, rank, index) candidate; the merge of the 256 candidates is the greedy path's.
+                float * own_l = xf; float * nz = xf + 16; float * shf = xf + 272; int * cnt = (int *) (xf + 288); double * shd = (double *) (xf + 352);
+                if ((tid & 15) == 0 && (tid >> 4) < 8) own_l[tid >> 4] = best;
+                if (tid < 256) nz[tid] = smp_noise;
+                CH_STAMP(11);
+                for (int i = 0; i < N.delay[4]; i++) __builtin_amdgcn_s_sleep(1);
+                float lg[4];
+                {   // thread T holds logits T, T + 512, T + 1024, T + 1536: sample_topk_kernel<1024, 2>'s thread t holds t and t + 1024 - T and T + 512 of them
+                    const unsigned tag_l = tag_base | (unsigned) (p + 1);
+                    const unsigned lbase = (unsigned) (p & 1) * (CH_XF_MAX * 8u) + (unsigned) tid * 8u;
+                    typedef unsigned u32x2_ __attribute__((ext_vector_type(2)));
+                    u32x2_ g[4];
+                    unsigned spins = 0;
+                    for (;;) {
+#pragma unroll
+                        for (int r = 0; r < 4; r++) g[r] = __builtin_amdgcn_raw_buffer_load_b64(gb, (int) (lbase + (unsigned) r * (512u * 8u)), 0, 16);
+                        bool ok = true;
+#pragma unroll
+                        for (int r = 0; r < 4; r++) ok = ok && g[r].y == tag_l;
+                        if (__all(ok)) break;
+                        if (++spins > CH_SPIN_MAX || lds_load(&ctl->failed)) { give_up(); break; }
+                        __builtin_amdgcn_s_sleep(1);
+                    }
+                    settle_vmcnt();
+#pragma unroll
+                    for (int r = 0; r < 4; r++) lg[r] = __uint_as_float(g[r].x);
+                }
+                CH_STAMP(12);
+                float px[4];
+                float mx = -INFINITY;
+#pragma unroll
+                for (int r = 0; r < 4; r++) { px[r] = lg[r] * smp_scale; mx = fmaxf(mx, px[r]); }
+                mx = wave_allmax_f32(mx);
+                if (lane == 0) shf[wave] = mx;
+                nbar();
+                mx = shf[0];
+#pragma unroll
+                for (int w = 1; w < CH_NCW; w++) mx = fmaxf(mx, shf[w]);
+#pragma unroll
+                for (int r = 0; r < 4; r++) px[r] = expf(px[r] - mx);
+                // that kernel's double sum: a thread adds its two terms, a wave butterflies, the 16 waves are added in index order
+                double sa = 0, sb = 0;
+                sa += (double) px[0]; sa += (double) px[2];
+                sb += (double) px[1]; sb += (double) px[3];
+                sa = wave_allsum_f64(sa); sb = wave_allsum_f64(sb);
+                if (lane == 0) { shd[wave] = sa; shd[CH_NCW + wave] = sb; }
+                nbar();
+                double tot = 0;
+#pragma unroll
+                for (int w = 0; w < 2 * CH_NCW; w++) tot += shd[w];
+                const float inv = (float) (1.0 / tot);
+                CH_STAMP(13);
+#pragma unroll
+                for (int r = 0; r < 4; r++) px[r] *= inv;
+                // the workgroup's own 8 rows (rows 8 wg .. 8 wg + 7), probability of row j in lane j of every wave
+                const float po = expf(own_l[lane & 7] * smp_scale - mx) * inv;
+                // "ahead of row j" = larger probability, or the same one at a lower index: ONE unsigned compare of (bits of p) << 32 | ~index (p >= 0: the bit
+                // patterns order like the values) - sample_topk_kernel's candidate key. (Written as p > pj || (p == pj && i < ij) the compiler branches per term
+                // and spills the 32 ballots it keeps alive.)
+                u64 kx[4];
+#pragma unroll
+                for (int r = 0; r < 4; r++) kx[r] = ((u64) __float_as_uint(px[r]) << 32) | (u64) ~(unsigned) (tid + r * 512);
+                int cn[8];
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const unsigned pjb = (unsigned) __builtin_amdgcn_readlane(__float_as_int(po), j);
+                    const u64 kj = ((u64) pjb << 32) | (u64) ~(unsigned) (wg * 8 + j);
+                    int n_ahead = 0;
+#pragma unroll
+                    for (int r = 0; r < 4; r++) n_ahead += __popcll(__ballot(kx[r] > kj));
+                    asm volatile("" : "+s"(n_ahead));   // (counted HERE: left alone the compiler sinks all 32 pop-counts into the lane-0 store below and spills the masks)
+                    cn[j] = n_ahead;
+                }
+                if (lane == 0) {
+#pragma unroll
+                    for (int j = 0; j < 8; j++) cnt[j * CH_NCW + wave] = cn[j];
+                }
+                nbar();
+                CH_STAMP(14);
+                if (wave == 0) {
+                    const int j = lane & 7;
+                    int rank = 0;
+#pragma unroll
+                    for (int w = 0; w < CH_NCW; w++) rank += cnt[j * CH_NCW + w];
+                    const float nzr = nz[rank < 256 ? rank : 255];
+                    u64 key = 0;
+                    if (rank < smp_k) key = ((u64) __float_as_uint(po / nzr) << 32) | (u64) ((unsigned) rank << 11) | (u64) (unsigned) (wg * 8 + j);
+#pragma unroll
+                    for (int o = 4; o > 0; o >>= 1) {
+                        const u64 ok2 = ((u64) (unsigned) __shfl_xor((int) (key >> 32), o, 64) << 32) | (u64) (unsigned) __shfl_xor((int) (unsigned) key, o, 64);
+                        key = ok2 > key ? ok2 : key;
+                    }
+                    if (lane == 0) {
+                        u64 * c = P.cand + (size_t) (p & 1) * 2 * grid + 2 * wg;
+                        st_granule(c, tag_base | (unsigned) (p + 1), (unsigned) (key >> 32));
+                        st_granule(c + 1, tag_base | (unsigned) (p + 1), (unsigned) key);
+                    }
+                }
+                CH_STAMP(15);
+            } else if (N.head_argmax) {
                 // (the 8 rows' values sit in the first lanes of 8 sixteen-lane groups: they meet through LDS - a wave-wide merge costs twelve ds_bpermute round trips)
                 static_assert(nest_dim<shape_head, G>::ROWS == 8 && CH_NCW >= 8, "one candidate slot per row");
                 if ((tid & 15) == 0 && (tid >> 4) < 8) { ctl->am_v[tid >> 4] = best; ctl->am_i[tid >> 4] = bi; }
@@ -772,7 +920,9 @@ __global__ void __launch_bounds__(CH_THREADS) depth_nest_kernel(nest_params N) {
     if (wg == 0 && wave == 0 && N.head_argmax) {
         const nest_st st = ld_st(N.n_steps - 1);
         int token = 0;
-        if (gather_token(cb, (unsigned) ((p - 1) & 1) * (2u * (unsigned) grid * 8u), grid, tag_base | (unsigned) p, lane, ctl, token)) {
+        const bool got = N.head_argmax == 2 ? gather_sampled(cb, (unsigned) ((p - 1) & 1) * (2u * (unsigned) grid * 8u), grid, tag_base | (unsigned) p, lane, ctl, token)
+                                            : gather_token(cb, (unsigned) ((p - 1) & 1) * (2u * (unsigned) grid * 8u), grid, tag_base | (unsigned) p, lane, ctl, token);
+        if (got) {
             if (lane == 0) { if (st.argmax_out[0]) *gp(st.argmax_out[0]) = token; if (st.argmax_out[1]) *gp(st.argmax_out[1]) = token; }
         } else give_up();
     }

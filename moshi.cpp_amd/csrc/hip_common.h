@@ -118,9 +118,11 @@ struct mv_args {
     int64_t     pair_F;         // 0 = off
     // Entries of a launch-ordered run that are NOT mat-vecs but may become phases of a persistent step program (hip_chain.hip): special = 1 - a single-token
     // attention step (`attn`, host pointer owned by the plan); special = 2 - one embedding row through a small Q8_0 projection (`lr`). The generic chain analysis
-    // stops at them; launched on their own they run k_attn_decode / k_lowrank_embed.
+    // stops at them; launched on their own they run k_attn_decode / k_lowrank_embed. special = 3 - a top-k sampler (`smp`: moshi_sample_token with temp > 0,
+    // sampling.h:4-64) behind a logits mat-vec: the Depth step program takes it as the tail of its linears[k] phase (hip_chain_nest.h), k_sample_topk otherwise.
     int         special;
     const struct lowrank_embed_args * lr;
+    const struct sample_args * smp;
 };
 // Persistent chain engine (hip_chain.hip): a run of consecutive, dependent small Q4_K mat-vecs executed by ONE launch - resident workgroups,
 // a loader wave streaming every phase's weights through an LDS ring ahead of the dependency chain, data-tagged hand-offs between phases.
@@ -128,8 +130,8 @@ struct chain_plan;
 bool   k_chain_default_on();                         // MI355X_CHAIN (default 1; 0 = one launch per mat-vec)
 // usable_cus: the compute units the launching stream may use (the device's count, or fewer on a CU-masked stream): the engine's workgroups wait for each
 // other, so a chain is only taken when its whole grid is resident there (hipOccupancyMaxActiveBlocksPerMultiprocessor x usable_cus >= grid; 256 / 128 / 64)
-int    k_chain_accept(const mv_args * mv, int n, int usable_cus);     // how many of the n consecutive mat-vecs (in launch order) one chain launch can take (0: none)
-size_t k_chain_ws_size(const mv_args * mv, int n, int usable_cus);    // device workspace for exactly that run (tables + hand-off buffers)
+int    k_chain_accept(const mv_args * mv, int n, int usable_cus, bool allow_step_program = true);     // how many of the n consecutive mat-vecs (in launch order) one chain launch can take (0: none)
+size_t k_chain_ws_size(const mv_args * mv, int n, int usable_cus, bool allow_step_program = true);    // device workspace for exactly that run (tables + hand-off buffers)
 // allow_step_program: a run that is the Depth transformer's steps at their known shapes may execute as the compile-time step program (hip_chain_nest.h)
 chain_plan * k_chain_create(hipStream_t s, const mv_args * mv, int n, void * ws, unsigned * err, int usable_cus, bool allow_step_program);
 bool   k_chain_is_step_program(const chain_plan * c);

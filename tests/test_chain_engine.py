@@ -174,9 +174,11 @@ def test_small_width_runs_between_attention_launches_are_chained_too():
 
 
 @pytest.mark.parametrize("which", ["real_width", "moshika"])
-def test_sampled_mode_chains_each_step_separately(which):
-    # temp > 0: a sampler launch sits between the steps, so each step is a chain of its own that ends in plain logits. At moshika's sizes each of those
-    # one-step runs takes the step program (its linears[k] then leaves plain logits, hip_chain_nest.h); flag 1024 keeps the descriptor-driven kernel
+def test_sampled_mode_is_one_step_program_with_the_sampler_as_a_phase(which):
+    # temp > 0 (the reference's own --bench mode, tools/moshi-sts.cpp:106-107): a sampler sits between the steps. At moshika's sizes the step program takes the
+    # samplers in as the tail of its linears[k] phases (hip_chain_nest.h, head_argmax = 2: soft-max statistics and ranks computed by every workgroup for its own
+    # rows, candidates merged like the arg-max) - ONE launch for the whole Depth graph, the same host rand() noise, the same tokens as one launch per plan step
+    # (flag 16: k_sample_topk). Flag 1024 keeps the descriptor-driven kernel: the sampler launches then cut the run into one chain per step as before.
     import ctypes
     libc = ctypes.CDLL(None)
     if which == "moshika":
@@ -200,7 +202,7 @@ def test_sampled_mode_chains_each_step_separately(which):
     assert out[32][1].chained_matvecs_in_last_plan > 0
     assert_bit_identical(out[16][0], out[32][0], "sampled")
     if which == "moshika":
-        assert out[32][1].chain_step_programs_in_last_plan == cfg.dep_q and out[32 | 1024][1].chain_step_programs_in_last_plan == 0
+        assert out[32][1].chain_step_programs_in_last_plan == 1 and out[32 | 1024][1].chain_step_programs_in_last_plan == 0
         assert_bit_identical(out[32 | 1024][0], out[32][0], "sampled (descriptor-driven chain vs step program)")
 
 
