@@ -569,6 +569,27 @@ def main():
                 child = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
                 line = [l for l in child.stdout.splitlines() if l.startswith("{")]
                 result["extras"][name + "_frames_per_s"] = json.loads(line[-1])["value"] if child.returncode == 0 and line else None
+            # the long-context line with its own roofline: this command from a ring holding 2 800 of 3 000 slots, in a child of its own (its phase pass and its
+            # event-timed launches belong to THAT fill). A session longer than 4 minutes lives there. K / V bytes = 2 x layers x live slots x dim x 2 B per frame.
+            cmd = [sys.executable, os.path.abspath(__file__), "--context-fill", "2800", "--steps", "40", "--warmup", "6", "--no-cpu-baseline", "--no-extras"]
+            child = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+            line = [l for l in child.stdout.splitlines() if l.startswith("{")]
+            if child.returncode == 0 and line:
+                d = json.loads(line[-1])
+                merged = lambda r: next((v for k, v in r.get("roofline_by_variant", {}).items() if k.startswith("merged")), None)
+                ml, ms = merged(d), merged(result)
+                kvb = 2 * cfg.num_layers * d["n_fill_avg"] * cfg.dim * 2
+                lc = {"frames_per_s": d["value"], "n_fill_avg": d["n_fill_avg"], "phase_us_temporal": d["phase_us"]["temporal"], "phase_us_temporal_at_the_headline_fill": result["phase_us"]["temporal"],
+                      "kv_bytes_per_frame": int(kvb)}
+                if ml and ms:
+                    # inproj_attn_kernel carries the layer's attention as its tail: what the 28.3 MB in_proj costs alone is the headline fill's figure (a handful of live slots)
+                    att = (ml["avg_launch_us"] - ms["avg_launch_us"]) * 1e-6
+                    lc.update({"merged_inproj_attn_launch_us": ml["avg_launch_us"], "merged_inproj_attn_launch_us_at_the_headline_fill": ms["avg_launch_us"],
+                               "kv_GBps_over_the_added_launch_time": round(kvb / cfg.num_layers / att / 1e9, 1) if att > 0 else None,
+                               "kv_frac_of_hbm_peak": round(kvb / cfg.num_layers / att / 1e9 / HBM_PEAK_GBPS, 4) if att > 0 else None})
+                dt_t = (d["phase_us"]["temporal"] - result["phase_us"]["temporal"]) * 1e-6
+                lc["kv_GBps_over_the_added_temporal_time"] = round(kvb / dt_t / 1e9, 1) if dt_t > 0 else None
+                result["extras"]["context_fill_2800"] = lc
         except Exception as e:
             result["extras"] = {"error": str(e)}
     if m is not None:

@@ -118,6 +118,7 @@ struct ggml_mi355x_stats {
     int64_t chained_matvecs_in_last_plan;   // block mat-vecs of the last plan that run inside persistent chain launches (hip_chain.hip)
     int64_t attention_folds_planned;   // attention blocks running as the tail of their in_proj launch (inproj_attn_kernel), summed over every plan built so far
     int64_t chain_step_programs_in_last_plan;   // chain launches of the last plan that run as the Depth transformer's compile-time step program (hip_chain_nest.h)
+    int64_t vq_levels_chained_in_last_plan;     // RVQ encode levels of the last plan that run inside multi-level launches (vq_chain_kernel)
 };
 GGML_API void ggml_backend_mi355x_get_stats(ggml_backend_t backend, struct ggml_mi355x_stats * stats);
 // accumulated HIP-event timings of the dominant kernel (Q4_K mat-vec), collected while flag 8 is set

@@ -172,6 +172,9 @@ GGML_API int     moshi_hot_tensor_file_name(const char * checkpoint_name, char *
 // test hook: the host-side delay ring (rows x (n_q + 1) int32, row-major) -> dst; returns the value count (dst NULL: just the count)
 GGML_API int     moshi_hot_host_ring(moshi_hot_model_t * m, int32_t * dst, int max_values);
 GGML_API void    moshi_hot_fill_ring(moshi_hot_model_t * m, int which, int layer, uint64_t seed, float scale);
+// the K (kv = 0) / V (kv = 1) ring of one layer as its bytes (BF16 [D, C, H]), read out (write = 0) or overwritten (write = 1): parity runs that restart every
+// frame from another executor's state. Returns the ring's size in bytes (-1: no such ring); buf may be NULL to ask for the size. which: 0 Temporal, 1 Depth.
+GGML_API int64_t moshi_hot_ring_bytes(moshi_hot_model_t * m, int which, int layer, int kv, void * buf, int64_t nbytes, int write);
 // Parity probe: ONE transformer layer (moshi_streaming_transformer_layer, transformer.h:910-1039) of the Temporal (which = 0) or Depth
 // (which = 1, with weight set `weight_set`) stack on the scratch context, fed x_in F32[dim] at stream position `offset` (mask row, RoPE
 // phase and ring slot as transformer.h:1182-1215 computes them), over the model's own weights and KV ring of that layer (the new K / V

@@ -57,7 +57,7 @@ class DevProps(C.Structure):
 class Stats(C.Structure):
     _fields_ = [(n, C.c_int64) for n in ("graphs_computed", "graph_replays", "kernels_in_last_plan",
                                          "fused_nodes_in_last_plan", "nodes_in_last_plan", "uploads_batched", "chained_matvecs_in_last_plan",
-                                         "attention_folds_planned", "chain_step_programs_in_last_plan")]
+                                         "attention_folds_planned", "chain_step_programs_in_last_plan", "vq_levels_chained_in_last_plan")]
 
 
 class KernelProfile(C.Structure):

@@ -307,6 +307,7 @@ typedef std::function<void(hipStream_t)> step_fn;
 struct pstep {
     step_fn fn; bool is_mv = false; mv_args mv;
     chain_plan * chain = nullptr;   // a persistent chain launch (timed on its own in profile mode)
+    const vq_level_args * vq = nullptr;   // one RVQ encode level (k_vq_level): consecutive levels of a stack may become one launch (k_vq_chain_*)
     // a step that reads nothing a launch of this graph writes (the RoPE table of add(positions, offset)) and writes [hoist_dst, + hoist_bytes): it may move in
     // front of a neighbouring mat-vec whose operands it does not overlap, so that the mat-vec stays next to the steps it chains with
     const char * hoist_dst = nullptr; size_t hoist_bytes = 0;
@@ -327,13 +328,15 @@ struct plan_t {
     std::vector<std::unique_ptr<attn_args>> attn_copies;
     std::vector<std::unique_ptr<lowrank_embed_args>> lowrank_copies;
     std::vector<std::unique_ptr<sample_args>> sampler_copies;
+    std::vector<std::unique_ptr<vq_level_args>> vq_copies;
+    std::vector<vq_chain_plan *> vq_chains;
     std::vector<std::unique_ptr<conv_scatter>> scatter_slots;   // see emitter::scatter_of
     std::vector<const ggml_backend_buffer *> buffers;   // every buffer a node / leaf of the planned graph lives in: freeing one orphans the plan
     uint64_t orphan_seq = 0;                            // != 0: a buffer of the planned graph has been freed since (see evict_plans_of_buffer)
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
     uint64_t hash = 0;
-    int n_nodes = 0, n_fused = 0, n_chained = 0, n_attn_folded = 0, n_step_programs = 0;
+    int n_nodes = 0, n_fused = 0, n_chained = 0, n_attn_folded = 0, n_step_programs = 0, n_vq_chained = 0;
 };
 
 static void plan_free(hip_ctx * c, plan_t * p) {
@@ -341,6 +344,7 @@ static void plan_free(hip_ctx * c, plan_t * p) {
     if (p->graph) (void) hipGraphDestroy(p->graph);
     for (auto & w : p->workspaces) pool_free(c, w.first, w.second);
     for (chain_plan * ch : p->chains) k_chain_free(ch);
+    for (vq_chain_plan * vc : p->vq_chains) k_vq_chain_free(vc);
     delete p;
 }
 
@@ -1144,7 +1148,7 @@ static bool match_embed_sum(const analysis & an, int pos, embed_group & grp) {
 
 // D. streaming / stateless conv1d (conv.h:50-96, 137-161): [elu] -> concat(prev, x) -> {tail cpy, im2col} -> mul_mat -> reshape
 //    [-> + bias] [-> residual + y]  becomes  stream_im2col + conv_tail + one product with the bias/residual epilogue.
-struct step_group { std::vector<step_fn> steps; int emit_pos; std::vector<int> members; sample_args smp; };   // smp: match_sampler's arguments (n = 0 otherwise)
+struct step_group { std::vector<step_fn> steps; int emit_pos; std::vector<int> members; sample_args smp; vq_level_args vq; bool has_vq = false; };   // smp / vq: match_sampler's / match_vq_level's arguments
 
 static bool is_elu(const ggml_tensor * t) { return t->op == GGML_OP_UNARY && t->op_params[0] == GGML_UNARY_OP_ELU && t->view_src == NULL; }
 
@@ -1471,6 +1475,7 @@ static bool match_vq_level(const analysis & an, int pos, step_group & grp, emitt
     grp.steps.push_back([=](hipStream_t s) { k_vq_level(s, a); });
     grp.members = members;
     grp.emit_pos = last;
+    grp.vq = a; grp.has_vq = true;
     return true;
 }
 
@@ -1655,7 +1660,10 @@ static plan_t * build_plan(hip_ctx * c, ggml_cgraph * g, bool keep = true) {
             for (int m : grp.members) if (an.skip[(size_t) m]) clash = true;
             if (clash) continue;
             for (int m : grp.members) an.skip[(size_t) m] = 1;
-            for (auto & f : grp.steps) at_pos[grp.emit_pos].push_back(f);
+            for (auto & f : grp.steps) {
+                at_pos[grp.emit_pos].push_back(f);
+                if (grp.has_vq) { p->vq_copies.emplace_back(new vq_level_args(grp.vq)); at_pos[grp.emit_pos].back().vq = p->vq_copies.back().get(); }
+            }
             p->n_fused += (int) grp.members.size();
         }
         // scalar gathers (top-most node first, so it claims the whole tree)
@@ -2026,6 +2034,25 @@ static plan_t * build_plan(hip_ctx * c, ggml_cgraph * g, bool keep = true) {
         std::vector<pstep> merged;
         size_t i = 0;
         while (i < p->steps.size()) {
+            if (p->steps[i].vq) {
+                // consecutive levels of one RVQ encode stack (vq.h:97-114): one persistent launch with a candidate hand-off per level (hip_chain.hip, vq_chain_kernel)
+                size_t e = i;
+                std::vector<vq_level_args> lv;
+                while (e < p->steps.size() && p->steps[e].vq && lv.size() < 32 && (lv.empty() || ((const void *) p->steps[e].vq->resid == (const void *) lv.back().resid_out && p->steps[e].vq->resid_stride == 4))) {
+                    lv.push_back(*p->steps[e].vq); e++;
+                }
+                if (lv.size() >= 2 && k_vq_chain_accept(lv.data(), (int) lv.size(), c->usable_cus) && spin_kernels_allowed(c)) {
+                    void * ws = em.ws(k_vq_chain_ws_size((int) lv.size()));
+                    vq_chain_plan * vc = k_vq_chain_create(c->stream, lv.data(), (int) lv.size(), ws, c->err_dev);
+                    p->vq_chains.push_back(vc);
+                    p->n_vq_chained += (int) lv.size();
+                    merged.push_back(pstep([vc](hipStream_t s) { k_vq_chain_launch(s, vc); }));
+                    if (dump) fprintf(stderr, "plan: %zu consecutive RVQ levels -> one launch\n", lv.size());
+                    i = e;
+                    continue;
+                }
+                merged.push_back(std::move(p->steps[i])); i++; continue;
+            }
             if (!p->steps[i].is_mv) { merged.push_back(std::move(p->steps[i])); i++; continue; }
             size_t e = i;
             while (e < p->steps.size() && p->steps[e].is_mv) e++;
@@ -2115,7 +2142,7 @@ static enum ggml_status hip_graph_compute(ggml_backend_t backend, struct ggml_cg
         c->stats.kernels_in_last_plan = (int64_t) p->steps.size();
         c->stats.nodes_in_last_plan = p->n_nodes;
         c->stats.fused_nodes_in_last_plan = p->n_fused;
-        c->stats.chained_matvecs_in_last_plan = p->n_chained; c->stats.chain_step_programs_in_last_plan = p->n_step_programs;
+        c->stats.chained_matvecs_in_last_plan = p->n_chained; c->stats.chain_step_programs_in_last_plan = p->n_step_programs; c->stats.vq_levels_chained_in_last_plan = p->n_vq_chained;
         plan_free(c, p);   // workspaces return to the pool; reuse is stream-ordered
         return GGML_STATUS_SUCCESS;
     }
@@ -2154,7 +2181,7 @@ static enum ggml_status hip_graph_compute(ggml_backend_t backend, struct ggml_cg
     c->stats.kernels_in_last_plan = (int64_t) p->steps.size();
     c->stats.nodes_in_last_plan = p->n_nodes;
     c->stats.fused_nodes_in_last_plan = p->n_fused;
-    c->stats.chained_matvecs_in_last_plan = p->n_chained; c->stats.chain_step_programs_in_last_plan = p->n_step_programs;
+    c->stats.chained_matvecs_in_last_plan = p->n_chained; c->stats.chain_step_programs_in_last_plan = p->n_step_programs; c->stats.vq_levels_chained_in_last_plan = p->n_vq_chained;
     return GGML_STATUS_SUCCESS;
 }
 

@@ -1694,3 +1694,145 @@ void k_chain_launch(hipStream_t s, const chain_plan * c) {
     else if (c->grid == 128) matvec_chain_kernel<128><<<c->grid, CH_THREADS, c->smem, s>>>(c->P);
     else matvec_chain_kernel<64><<<c->grid, CH_THREADS, c->smem, s>>>(c->P);
 }
+
+// ---- RVQ encode: the levels of one residual stack as one launch -----------------------------------------------------------------------------------------------
+// vq_level_kernel's arithmetic level by level (score = num[c] / (float(sum_j (double) ((e_cj - x_j)^2)) + add_c), the LAST maximum wins; x <- x - e_best), with the
+// level-to-level dependency kept inside the launch: every workgroup holds the residual (lane l: elements 4 l .. 4 l + 3, the same in every wave), scores its 16
+// centroids, publishes ONE candidate as two {tag, value} granules, merges all candidates itself and fetches the winning centroid row - no second hand-off, no
+// launch boundary. The next level's centroid rows are requested before the candidates are polled (they do not depend on the chain).
+#define VQC_CPW 4
+#define VQC_LEVELS_MAX 32
+struct vqc_level { const char * emb; long long emb_row_bytes; const float * add_c; const float * num; float * resid_out; float * idx_f; int32_t * idx_i; long long pad; };
+static_assert(sizeof(vqc_level) == 64, "level records are read by 16-byte lanes");
+struct vqc_params { const vqc_level * levels; int n_levels, NC; const char * resid; long long resid_stride; u64 * cand; unsigned * launch_seq; unsigned * err; int delay; };
+__global__ void __launch_bounds__(256) vq_chain_kernel(vqc_params P) {
+    __shared__ float sv[4];
+    __shared__ int si[4];
+    __shared__ int s_code;
+    __shared__ unsigned s_failed;
+    __shared__ __attribute__((aligned(16))) vqc_level s_lv[VQC_LEVELS_MAX];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, grid = (int) gridDim.x, wg = (int) blockIdx.x;
+    for (int i = tid; i < P.n_levels * 4; i += 256) ((u32x4 *) s_lv)[i] = ((const GLOBAL_AS u32x4 *) P.levels)[i];
+    if (tid == 0) s_failed = 0u;
+    const unsigned launch = *gp(P.launch_seq);
+    const unsigned tag_base = launch << 12;
+    float x[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) x[j] = *(const GLOBAL_AS float *) (gp(P.resid) + (long long) (lane * 4 + j) * P.resid_stride);
+    __syncthreads();
+    const __amdgpu_buffer_rsrc_t cb = make_rsrc(P.cand, 2u * 2u * (unsigned) grid * 8u);
+    const int c0 = (wg * 4 + wave) * VQC_CPW;
+    f32x4 e[VQC_CPW];
+    auto request = [&](int l) {
+        const char * emb = *(const char * const *) &s_lv[l].emb; const long long rb = *(const long long *) &s_lv[l].emb_row_bytes;
+#pragma unroll
+        for (int u = 0; u < VQC_CPW; u++) {
+            const int c = c0 + u < P.NC ? c0 + u : P.NC - 1;
+            e[u] = *(const GLOBAL_AS f32x4 *) (gp(emb) + (long long) c * rb + lane * 16);
+        }
+    };
+    request(0);
+#pragma unroll 1
+    for (int l = 0; l < P.n_levels; l++) {
+        const vqc_level lv = s_lv[l];
+        const float addc = gp(lv.add_c)[0];
+        float best = -INFINITY; int bi = -1;
+#pragma unroll
+        for (int u = 0; u < VQC_CPW; u++) {
+            double acc = 0;
+#pragma unroll
+            for (int j = 0; j < 4; j++) { const float d = e[u][j] - x[j]; acc += (double) (d * d); }
+            acc = wave_allsum_f64(acc);
+            const int c = c0 + u;
+            if (c < P.NC) {
+                const float v = gp(lv.num)[c] / ((float) acc + addc);
+                if (v >= best) { best = v; bi = c; }   // centroids ascend: '>=' keeps the last maximum (ggml_vec_argmax_f32)
+            }
+        }
+        if (l + 1 < P.n_levels) request(l + 1);
+        if (lane == 0) { sv[wave] = best; si[wave] = bi; }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local"); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+        const unsigned tag = tag_base | (unsigned) (l + 1);
+        if (tid == 0) {
+            for (int w = 1; w < 4; w++) if (sv[w] > best || (sv[w] == best && si[w] > bi)) { best = sv[w]; bi = si[w]; }
+            u64 * c = P.cand + (size_t) (l & 1) * 2 * grid + 2 * wg;
+            st_granule(c, tag, __float_as_uint(best));
+            st_granule(c + 1, tag, (unsigned) bi);
+        }
+        if (wave == 0) {
+            for (int i = 0; i < P.delay; i++) __builtin_amdgcn_s_sleep(1);
+            int token = 0;
+            unsigned spins = 0;
+            const unsigned base = (unsigned) (l & 1) * (2u * (unsigned) grid * 8u);
+            for (;;) {
+                u32x4 c[4];
+#pragma unroll
+                for (int i = 0; i < 4; i++) { const int g = i * 64 + lane; c[i] = ld16_agent(cb, base + (unsigned) (g < grid ? g : grid - 1) * 16u); }
+                float bv = -INFINITY; int bc = -1;
+                bool ok = true;
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const int g = i * 64 + lane;
+                    ok = ok && c[i].y == tag && c[i].w == tag;
+                    if (g < grid) am_merge(bv, bc, __uint_as_float(c[i].x), (int) c[i].z);
+                }
+                if (__all(ok)) { am_wave(bv, bc); token = bc < 0 ? 0 : bc; break; }
+                if (++spins > CH_SPIN_MAX || lds_load(&s_failed)) { if (lane == 0) { lds_store(&s_failed, 1u); *gp(P.err) = 2u; } break; }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            settle_vmcnt();
+            if (lane == 0) s_code = token;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local"); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+        const int code = __builtin_amdgcn_readfirstlane(s_code);
+        if (wg == 0 && tid == 0) { *gp(lv.idx_i) = code; *gp(lv.idx_f) = (float) code; }
+        if (lv.resid_out) {
+            const f32x4 q = *(const GLOBAL_AS f32x4 *) (gp(lv.emb) + (long long) code * lv.emb_row_bytes + lane * 16);
+#pragma unroll
+            for (int j = 0; j < 4; j++) x[j] = x[j] - q[j];
+            if (wg == 0 && wave == 0) *(GLOBAL_AS f32x4 *) (gp(lv.resid_out) + lane * 4) = (f32x4) { x[0], x[1], x[2], x[3] };
+        }
+    }
+    if (wg == 0 && tid == 0) *gp(P.launch_seq) = launch + 1u;
+}
+
+struct vq_chain_plan { vqc_params P; int grid; std::vector<vqc_level> levels; };
+static bool vq_chain_shape(const vq_level_args * lv, int n) {
+    if (n < 2 || n > VQC_LEVELS_MAX) return false;
+    for (int i = 0; i < n; i++) {
+        const vq_level_args & a = lv[i];
+        if (a.D != 256 || a.NC != lv[0].NC || a.NC < 16 || a.NC > 4096 || ((uintptr_t) a.emb & 15) || (a.emb_row_bytes & 15) || !a.idx_i || !a.idx_f) return false;
+        if (i > 0 && ((const void *) a.resid != (const void *) lv[i - 1].resid_out || a.resid_stride != 4)) return false;   // level i quantises what level i - 1 left
+        if (i + 1 < n && (!a.resid_out || ((uintptr_t) a.resid_out & 15))) return false;
+    }
+    return true;
+}
+bool k_vq_chain_accept(const vq_level_args * lv, int n, int usable_cus) {
+    static const int on = chain_env("MI355X_VQ_CHAIN", 1);
+    if (!on || !vq_chain_shape(lv, n)) return false;
+    const int grid = (lv[0].NC + 4 * VQC_CPW - 1) / (4 * VQC_CPW);
+    if (grid > 256) return false;
+    static const int force = chain_env("MI355X_CHAIN_GRID_FORCE", 0);
+    int per_cu = 0;   // the workgroups wait for each other: the whole grid must be resident on the stream's compute units
+    return force || (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *) vq_chain_kernel, 256, 0) == hipSuccess && (long long) per_cu * usable_cus >= grid);
+}
+size_t k_vq_chain_ws_size(int n) { return GGML_PAD((size_t) n * sizeof(vqc_level), 256) + 256 + 2 * 2 * 256 * 8; }
+vq_chain_plan * k_vq_chain_create(hipStream_t s, const vq_level_args * lv, int n, void * ws, unsigned * err) {
+    GGML_ASSERT(vq_chain_shape(lv, n));
+    vq_chain_plan * c = new vq_chain_plan;
+    c->grid = (lv[0].NC + 4 * VQC_CPW - 1) / (4 * VQC_CPW);
+    for (int i = 0; i < n; i++) c->levels.push_back({ lv[i].emb, (long long) lv[i].emb_row_bytes, lv[i].add_c, lv[i].num, lv[i].resid_out, lv[i].idx_f, lv[i].idx_i, 0 });
+    char * base = (char *) ws;
+    char * state = base + GGML_PAD((size_t) n * sizeof(vqc_level), 256);
+    HIP_CHECK(hipMemcpyAsync(base, c->levels.data(), (size_t) n * sizeof(vqc_level), hipMemcpyHostToDevice, s));   // (from the plan's own vector, which lives as long as the plan)
+    HIP_CHECK(hipMemsetAsync(state, 0, 256 + 2 * 2 * 256 * 8, s));
+    memset(&c->P, 0, sizeof(c->P));
+    c->P.levels = (const vqc_level *) base; c->P.n_levels = n; c->P.NC = lv[0].NC;
+    c->P.resid = lv[0].resid; c->P.resid_stride = (long long) lv[0].resid_stride;
+    c->P.launch_seq = (unsigned *) state; c->P.cand = (u64 *) (state + 256); c->P.err = err;
+    static const int delay = chain_env("MI355X_VQ_CHAIN_DELAY", 16);
+    c->P.delay = delay < 0 ? 0 : delay > 200 ? 200 : delay;
+    return c;
+}
+void k_vq_chain_launch(hipStream_t s, const vq_chain_plan * c) { vq_chain_kernel<<<c->grid, 256, 0, s>>>(c->P); }
+void k_vq_chain_free(vq_chain_plan * c) { delete c; }

@@ -234,3 +234,12 @@ struct sample_args { const float * logits; int n; float scale; int k; const floa
 void k_sample_topk(hipStream_t s, const sample_args & a);
 #define VQ_LEVEL_WS_BYTES 4096
 void k_vq_level(hipStream_t s, const vq_level_args & a);
+// Consecutive levels of one RVQ stack (each level's residual is the previous level's output: core_vq.h:27-56 inside vq.h:97-114's loop) as ONE persistent
+// launch (hip_chain.hip, vq_chain_kernel): the workgroups score their centroids of level l, exchange their candidates as tagged granules, every workgroup
+// merges them and subtracts the winning centroid from its own copy of the residual - one hand-off per level instead of a launch per level.
+struct vq_chain_plan;
+bool   k_vq_chain_accept(const vq_level_args * lv, int n, int usable_cus);      // n >= 2 chained levels of one shape whose grid is resident on this stream
+size_t k_vq_chain_ws_size(int n);
+vq_chain_plan * k_vq_chain_create(hipStream_t s, const vq_level_args * lv, int n, void * ws, unsigned * err);
+void   k_vq_chain_launch(hipStream_t s, const vq_chain_plan * c);
+void   k_vq_chain_free(vq_chain_plan * c);

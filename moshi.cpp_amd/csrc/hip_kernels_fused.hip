@@ -276,7 +276,11 @@ __device__ __forceinline__ void attn_small_wave(const attn_args & a, int h0, int
 // work per lane. The Depth mat-vecs are a few tiles in all: with a super-block per lane 192 waves did ~2 000 cycles of serial dot4 / unpack each
 // while 3/4 of the chip's SIMDs idled; this way the dot phase is ~300 cycles. Same integers, same per-super-block float expression.
 #define MVD_PMAX 4   // passes (super-blocks per lane group) a workgroup can hold in registers: rows * nb <= MVD_PMAX * NW * 8
-template <int PRO, int NW, int FMT = MVF_Q4K, int WS = 0>
+// XB: activation batches of NW * 256 values a load_batch requests per thread (4: K up to NW * 1024 per round; 2: K <= NW * 512 in ONE round); RL: the residual
+// pre-load. Until round 6 every launch issued four x + four alpha / gate loads and four residual loads per thread whatever it needed: at K = 4096 with 8 waves
+// (the Temporal linear_in, the text head) two of the four batches were clamped duplicates and there is no residual - 8 of a wave's 21 vector-memory
+// instructions, ~26 cycles of issue each, in front of the weight tile and of the workgroup barrier of the norm. <.., 2, false> is that launch without them.
+template <int PRO, int NW, int FMT = MVF_Q4K, int WS = 0, int XB = 4, bool RL = true>
 __global__ void __launch_bounds__(NW * 64) matvec_q4k_kernel(mv_args a, int rows_per_wg, attn_args at) {
     constexpr int SB = mvfmt<FMT>::SB, NLOAD = mvfmt<FMT>::NLOAD, TILE = 64 * SB;   // bytes per lane-chunk / 16-byte loads per lane per tile
     static_assert(WS == 0 || FMT == MVF_Q4K, "the direct layout is written for Q4_K super-blocks");
@@ -313,11 +317,11 @@ __global__ void __launch_bounds__(NW * 64) matvec_q4k_kernel(mv_args a, int rows
     const int K = (int) a.K;
     // activation loads of the first 16-block batch go out BEFORE the weight tile: vector-memory loads return in order,
     // so this lets the prologue finish while the (much larger, HBM-bound) weight tile is still in flight
-    float4 xv[4], aux[4];
-    bool ok[4];
+    float4 xv[XB], aux[XB];
+    bool ok[XB];
     auto load_batch = [&](int base) {
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
+        for (int j = 0; j < XB; j++) {
             // loads are unconditional (index clamped, result discarded through ok[]): a branch around a load makes hipcc
             // fall back to s_waitcnt vmcnt(0)-style waits, which would serialise the prologue behind the weight tile
             const int e0 = base + j * (NW * 256) + tid * 4;
@@ -368,8 +372,8 @@ __global__ void __launch_bounds__(NW * 64) matvec_q4k_kernel(mv_args a, int rows
         }
     }
     // the residual of this thread's rows (phase 4) rides behind the first weight loads: its round trip used to sit, exposed, at the very end
-    float res_pre[4];
-    {
+    float res_pre[4] = { 0.f, 0.f, 0.f, 0.f };
+    if (RL) {
         const float * rp = a.residual ? a.residual : a.y;   // (no branch around a load) y is valid memory of the same extent
 #pragma unroll
         for (int k = 0; k < 4; k++) {
@@ -407,18 +411,18 @@ __global__ void __launch_bounds__(NW * 64) matvec_q4k_kernel(mv_args a, int rows
             if (i < nchunk) ((u32x4 *) xs)[i] = pq[j];
         }
     } else {
-        for (int base = 0; base < K; base += NW * 1024) {
+        for (int base = 0; base < K; base += NW * 256 * XB) {
             if (base > 0) load_batch(base);
-            float v[4][4];
+            float v[XB][4];
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
+            for (int j = 0; j < XB; j++) {
                 const float z = ok[j] ? 1.f : 0.f;   // clamped (out-of-range) chunks contribute nothing to the norm
                 v[j][0] = xv[j].x * z; v[j][1] = xv[j].y * z; v[j][2] = xv[j].z * z; v[j][3] = xv[j].w * z;
             }
             if (PRO == MV_RMSNORM) {   // K <= 4096 (checked on the host): the whole vector is in registers
                 double acc = 0;
 #pragma unroll
-                for (int j = 0; j < 4; j++)
+                for (int j = 0; j < XB; j++)
 #pragma unroll
                     for (int k = 0; k < 4; k++) acc += (double) (v[j][k] * v[j][k]);
                 acc = wave_allsum_f64(acc);
@@ -430,7 +434,7 @@ __global__ void __launch_bounds__(NW * 64) matvec_q4k_kernel(mv_args a, int rows
                 const float mean = (float) (tot / (double) K);
                 const float scale = 1.0f / sqrtf(mean + a.eps);
 #pragma unroll
-                for (int j = 0; j < 4; j++) {
+                for (int j = 0; j < XB; j++) {
                     const float al[4] = { aux[j].x, aux[j].y, aux[j].z, aux[j].w };
 #pragma unroll
                     for (int k = 0; k < 4; k++) v[j][k] = al[k] * (v[j][k] * scale);
@@ -438,14 +442,14 @@ __global__ void __launch_bounds__(NW * 64) matvec_q4k_kernel(mv_args a, int rows
             }
             if (PRO == MV_GATE_SILU) {
 #pragma unroll
-                for (int j = 0; j < 4; j++) {
+                for (int j = 0; j < XB; j++) {
                     const float rr[4] = { aux[j].x, aux[j].y, aux[j].z, aux[j].w };
 #pragma unroll
                     for (int k = 0; k < 4; k++) { const float l = v[j][k]; v[j][k] = (l / (1.0f + expf(-l))) * rr[k]; }
                 }
             }
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
+            for (int j = 0; j < XB; j++) {
                 if (!ok[j]) continue;   // wave-uniform: a wave always holds one whole block
                 const int b = base / 256 + j * NW + wave;
                 if (a.x_out != nullptr && blockIdx.x == 0) *(float4 *) (a.x_out + base + j * (NW * 256) + tid * 4) = make_float4(v[j][0], v[j][1], v[j][2], v[j][3]);
@@ -1557,6 +1561,11 @@ void k_matvec(hipStream_t s, const mv_args & a) {
                   : a.prologue == MV_ATTN ? (nw == 8 ? matvec_q4k_kernel<MV_ATTN, 8, MVF_Q4K, 1> : matvec_q4k_kernel<MV_ATTN, 4, MVF_Q4K, 1>) \
                   : a.prologue == MV_PREQ8K ? matvec_q4k_kernel<MV_PREQ8K, 4, MVF_Q4K, 1> : matvec_q4k_kernel<MV_PLAIN, 4, MVF_Q4K, 1>)
         kern = direct ? MV_PICKD : nw == 12 ? MV_PICK(12) : nw == 8 ? MV_PICK(8) : MV_PICK(4);
+        // the 8-wave RMS-norm launches at K <= 2048 x 2 without a residual (the Temporal linear_in in its paired form, the text head): two activation batches instead of
+        // four, no residual pre-load (see the kernel's XB / RL parameters); same arithmetic
+        static const int lean_on = env_int("MI355X_MV_LEAN", 1);
+        if (lean_on && !direct && nw == 8 && fmt == MVF_Q4K && a.prologue == MV_RMSNORM && a.K <= 8 * 512 && !a.residual && !a.res_embed.table)
+            kern = matvec_q4k_kernel<MV_RMSNORM, 8, MVF_Q4K, 0, 2, false>;
         if (smem > 64 * 1024) {   // > 64 KB of dynamic LDS needs a one-time opt-in per kernel
             static std::map<const void *, size_t> granted;
             size_t & g = granted[(const void *) kern];
@@ -1760,7 +1769,10 @@ static bool fold_use_split(const attn_args & at) {
 // tag = launches completed so far + 1, derived by every workgroup from ONE counter of finished workgroups (see the kernel's first lines).
 // The head's parts wait for each other: the grid must be resident (k_inproj_attn_supported).
 // ---------------------------------------------------------------------------------------------------
-template <bool SPLIT>
+// NJ: activation batches of NW * 256 values a thread loads (K <= NJ * NW * 256: 2 at K = 4096, 1 at K = 2048). Until round 6 every thread issued four x and four
+// alpha loads whatever K was - at K = 4096 half of them clamped duplicates whose results were thrown away: 4 of a wave's 17 vector-memory instructions, ~26 cycles
+// of issue each in front of the weight tile, in every one of the frame's 32 launches.
+template <bool SPLIT, int NJ>
 __global__ void __launch_bounds__(FOLD_NW * 64) inproj_attn_kernel(mv_args a, attn_args at, attn_split_ws w, fold_ws f, attn_gqkv gq, int seg_rows, int64_t seg_stride) {
     constexpr int NW = FOLD_NW, NLOAD = 9, SB = 144, TILE = 64 * SB;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1790,10 +1802,10 @@ __global__ void __launch_bounds__(FOLD_NW * 64) inproj_attn_kernel(mv_args a, at
         return (const u32x4 *) (a.w + ((int64_t) sg * seg_stride + (int64_t) blk * seg_rows) * a.row_bytes) + (int64_t) (t - sg * tiles_seg) * (NLOAD * 64);
     };
     // ---- mat-vec, phase 1: activation loads, then the first weight tile (matvec_q4k_kernel's order)
-    float4 xv[4], aux[4];
-    bool ok[4];
+    float4 xv[NJ], aux[NJ];
+    bool ok[NJ];
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
+    for (int j = 0; j < NJ; j++) {
         const int e0 = j * (NW * 256) + tid * 4;
         ok[j] = e0 < K;
         const int e = ok[j] ? e0 : K - 4;
@@ -1812,15 +1824,15 @@ __global__ void __launch_bounds__(FOLD_NW * 64) inproj_attn_kernel(mv_args a, at
     __builtin_amdgcn_sched_barrier(0);
     // ---- phase 2: alpha * rms_norm(x) -> Q8_K blocks (K <= 4096: one batch, the whole vector in registers)
     {
-        float v[4][4];
+        float v[NJ][4];
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
+        for (int j = 0; j < NJ; j++) {
             const float z = ok[j] ? 1.f : 0.f;
             v[j][0] = xv[j].x * z; v[j][1] = xv[j].y * z; v[j][2] = xv[j].z * z; v[j][3] = xv[j].w * z;
         }
         double acc = 0;
 #pragma unroll
-        for (int j = 0; j < 4; j++)
+        for (int j = 0; j < NJ; j++)
 #pragma unroll
             for (int k = 0; k < 4; k++) acc += (double) (v[j][k] * v[j][k]);
         acc = wave_allsum_f64(acc);
@@ -1832,13 +1844,13 @@ __global__ void __launch_bounds__(FOLD_NW * 64) inproj_attn_kernel(mv_args a, at
         const float mean = (float) (tot / (double) K);
         const float scale = 1.0f / sqrtf(mean + a.eps);
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
+        for (int j = 0; j < NJ; j++) {
             const float al[4] = { aux[j].x, aux[j].y, aux[j].z, aux[j].w };
 #pragma unroll
             for (int k = 0; k < 4; k++) v[j][k] = al[k] * (v[j][k] * scale);
         }
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
+        for (int j = 0; j < NJ; j++) {
             if (!ok[j]) continue;
             const int bq = j * NW + wave;
             if (a.x_out != nullptr && b == 0) *(float4 *) (a.x_out + j * (NW * 256) + tid * 4) = make_float4(v[j][0], v[j][1], v[j][2], v[j][3]);
@@ -1889,6 +1901,13 @@ __global__ void __launch_bounds__(FOLD_NW * 64) inproj_attn_kernel(mv_args a, at
     FD_STAMP(5);
 }
 
+typedef void (*fold_kernel_t)(mv_args, attn_args, attn_split_ws, fold_ws, attn_gqkv, int, int64_t);
+static fold_kernel_t fold_kernel_fn(bool split, int K) {
+    const int nj = (K + FOLD_NW * 256 - 1) / (FOLD_NW * 256);
+    GGML_ASSERT(nj >= 1 && nj <= 2);   // K <= 4096 (k_inproj_attn_supported)
+    return split ? (nj == 1 ? inproj_attn_kernel<true, 1> : inproj_attn_kernel<true, 2>) : (nj == 1 ? inproj_attn_kernel<false, 1> : inproj_attn_kernel<false, 2>);
+}
+static const void * fold_kernel(bool split, int K) { return (const void *) fold_kernel_fn(split, K); }
 static size_t inproj_attn_smem(const mv_args & a, const attn_args & at, int seg_rows) {
     const size_t attn = (size_t) at.C * 4 + (size_t) at.T * at.D * 4 * 3 + (size_t) FOLD_NW * 64 * 8 * 8 + 16 + (size_t) at.T * at.C * 4;
     const size_t mv = (size_t) (a.K / 256) * XBLK_BYTES + (size_t) FOLD_NW * 64 * 144 + (size_t) 3 * seg_rows * (a.K / 256) * 4;
@@ -1914,7 +1933,7 @@ bool k_inproj_attn_supported(const mv_args & a, const attn_args & at, int usable
     if (attn_use_split(at) && !fold_use_split(at)) return false;
     const size_t smem = inproj_attn_smem(a, at, seg_rows);
     if (smem > 160 * 1024) return false;
-    const void * fn = fold_use_split(at) ? (const void *) inproj_attn_kernel<true> : (const void *) inproj_attn_kernel<false>;
+    const void * fn = fold_kernel(fold_use_split(at), (int) a.K);
     if (smem > 64 * 1024 && hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int) smem) != hipSuccess) return false;
     if (env_int("MI355X_FOLD_FORCE", 0)) return true;
     int per_cu = 0;
@@ -1945,16 +1964,15 @@ void k_inproj_attn(hipStream_t s, const mv_args & a, const attn_args & at, void 
     const int seg_rows = (int) (HD / FOLD_GRID);
     const attn_gqkv gq = { f.gbuf, 0, HD, 2 * HD, err };   // granule g holds row g of y; a.q / a.k / a.v start at rows 0 / HD / 2 HD
     const size_t smem = inproj_attn_smem(a, at, seg_rows);
+    const fold_kernel_t fold_fn = fold_kernel_fn(split, (int) a.K);
     if (g_mv_profile && g_mv_profile->used < g_mv_profile->capacity) {   // profile mode: events attached to the dispatch, like k_matvec's
         mv_profile::rec & r = g_mv_profile->recs[g_mv_profile->used++];
         r.bytes = a.M * a.row_bytes;
         r.variant = 2;
-        if (split) hipExtLaunchKernelGGL(inproj_attn_kernel<true>, dim3(FOLD_GRID), dim3(FOLD_NW * 64), smem, s, r.start, r.stop, 0, a, at, w, f, gq, seg_rows, HD);
-        else       hipExtLaunchKernelGGL(inproj_attn_kernel<false>, dim3(FOLD_GRID), dim3(FOLD_NW * 64), smem, s, r.start, r.stop, 0, a, at, w, f, gq, seg_rows, HD);
+        hipExtLaunchKernelGGL(fold_fn, dim3(FOLD_GRID), dim3(FOLD_NW * 64), smem, s, r.start, r.stop, 0, a, at, w, f, gq, seg_rows, HD);
         return;
     }
-    if (split) inproj_attn_kernel<true><<<FOLD_GRID, FOLD_NW * 64, smem, s>>>(a, at, w, f, gq, seg_rows, HD);
-    else       inproj_attn_kernel<false><<<FOLD_GRID, FOLD_NW * 64, smem, s>>>(a, at, w, f, gq, seg_rows, HD);
+    fold_fn<<<FOLD_GRID, FOLD_NW * 64, smem, s>>>(a, at, w, f, gq, seg_rows, HD);
 }
 
 // ---------------------------------------------------------------------------------------------------

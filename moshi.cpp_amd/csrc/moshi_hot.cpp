@@ -2155,6 +2155,22 @@ extern "C" void moshi_hot_set_context_fill(moshi_hot_model_t * m, int64_t offset
     if (m->tp_x) m->temporal_tp.offset = (int) offset;   // tensor-parallel frame mode steps its own stack (head-sliced rings): same stream position
 }
 
+// The K (kv = 0) / V (kv = 1) ring of one layer as the bytes it holds (BF16 [D, C, H]), out of / into the model: parity runs that restart every frame from
+// another executor's state (tests/test_full_width_parity.py: teacher forcing per frame on the benchmark's own weights). Returns the ring's size in bytes;
+// copies min(nbytes, size) when buf is not NULL. which: 0 Temporal, 1 Depth.
+extern "C" int64_t moshi_hot_ring_bytes(moshi_hot_model_t * m, int which, int layer, int kv, void * buf, int64_t nbytes, int write) {
+    Transformer & tr = which == 0 ? m->temporal : m->depth;
+    if (layer < 0 || layer >= (int) tr.layers.size()) return -1;
+    T t = kv == 0 ? tr.layers[(size_t) layer].kcache : tr.layers[(size_t) layer].vcache;
+    if (!t) return -1;
+    const int64_t size = (int64_t) ggml_nbytes(t);
+    if (buf) {
+        const size_t n = (size_t) (nbytes < size ? nbytes : size);
+        if (write) ggml_backend_tensor_set(t, buf, 0, n); else ggml_backend_tensor_get(t, buf, 0, n);
+    }
+    return size;
+}
+
 // identical pseudo-random BF16 rows in every slot of the K / V rings (tests: long-context attention against the oracle over a known cache)
 extern "C" void moshi_hot_fill_ring(moshi_hot_model_t * m, int which, int layer, uint64_t seed, float scale) {
     Transformer & tr = which == 0 ? m->temporal : m->depth;

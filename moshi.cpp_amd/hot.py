@@ -59,6 +59,7 @@ SIGNATURES = {
     "moshi_hot_graph": (P, [P, C.c_int]),
     "moshi_hot_set_context_fill": (None, [P, C.c_int64]),
     "moshi_hot_fill_ring": (None, [P, C.c_int, C.c_int, C.c_uint64, C.c_float]),
+    "moshi_hot_ring_bytes": (C.c_int64, [P, C.c_int, C.c_int, C.c_int, P, C.c_int64, C.c_int]),
     "moshi_hot_host_ring": (C.c_int, [P, P, C.c_int]),
     "moshi_hot_force_last": (None, [P, C.c_int32, P]),
     "moshi_hot_set_timing": (None, [P, C.c_int]),

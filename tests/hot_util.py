@@ -116,6 +116,24 @@ class Model:
         L.moshi_hot_last_raw_tokens(self.m, C.byref(txt), aud)
         return txt.value, list(aud)[:self.cfg.dep_q]
 
+    def rings(self, which=0):
+        """every K / V ring of a stack as raw bytes: [(layer, kv, bytes)]"""
+        out = []
+        layer = 0
+        while True:
+            n = L.moshi_hot_ring_bytes(self.m, which, layer, 0, None, 0, 0)
+            if n < 0:
+                return out
+            for kv in (0, 1):
+                buf = np.zeros(n, np.uint8)
+                assert L.moshi_hot_ring_bytes(self.m, which, layer, kv, buf.ctypes.data, n, 0) == n
+                out.append((layer, kv, buf))
+            layer += 1
+
+    def set_rings(self, rings, which=0):
+        for layer, kv, buf in rings:
+            assert L.moshi_hot_ring_bytes(self.m, which, layer, kv, buf.ctypes.data, buf.nbytes, 1) == buf.nbytes
+
     def force_last(self, txt, aud):
         L.moshi_hot_force_last(self.m, txt, (C.c_int32 * 32)(*aud))
 

@@ -135,6 +135,32 @@ def test_mimi_transformer_program_is_bit_identical_to_launches():
         assert np.array_equal(a[1], b[1]), f"frame {i}: PCM differs by {np.abs(a[1] - b[1]).max():.3e}"
 
 
+@pytest.mark.parametrize("which", ["moshika", "stt_like"])
+def test_rvq_levels_as_one_launch_are_bit_identical(which):
+    # the encoder's residual VQ (vq.h:97-114 around core_vq.h:27-56): the levels of a stack depend on each other through the residual and were one launch
+    # each; they run as ONE persistent launch per stack now (vq_chain_kernel: candidates handed on as tagged granules, every workgroup keeps the residual). moshika:
+    # 1 + 7 levels (the 7 of the second stack chained), the stt shape: 1 + 31. Codes and the latents the stacks quantise must be those of one launch per level
+    # (flag 16), bit for bit, over frames whose residuals differ widely.
+    cfg = hu.hot.moshika(hu.L) if which == "moshika" else hu.hot.stt_like(hu.L)
+    cfg.enable_lm = 0
+    cfg.enable_mimi_decoder = 0
+    out = {}
+    for flags in (32, 16):
+        m = hu.Model("hip", cfg, seed=0, flags=flags)
+        rng = np.random.default_rng(5)
+        rec = []
+        for i in range(24):
+            codes = m.mimi_encode((rng.standard_normal(1920) * (0.02 + 0.05 * i)).astype(np.float32))
+            rec.append((codes, m.read("enc_latent_first", 256).copy(), m.read("enc_latent_rest", 256).copy()))
+        out[flags] = (rec, m.stats())
+        m.free()
+    assert out[32][1].vq_levels_chained_in_last_plan == cfg.mimi_n_q - 1 and out[16][1].vq_levels_chained_in_last_plan == 0
+    assert len({tuple(r[0]) for r in out[32][0]}) > 20, "degenerate input: the codes barely vary"
+    for i, (a, b) in enumerate(zip(out[32][0], out[16][0])):
+        assert a[0] == b[0], f"frame {i}: codes differ: {a[0]} vs {b[0]}"
+        assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]), f"frame {i}: latents differ"
+
+
 def test_chain_replayed_from_a_hipgraph_many_times_stays_identical():
     # tags are derived from a launch counter kept on the device: 40 replays of the captured launch against 40 eager unchained runs
     cfg = depth_at_real_width(dep_q=3, layers=1, n_q=6)

@@ -169,6 +169,54 @@ def test_mimi_decoder_8_levels_133_frames_pcm():
     assert errs[125:].max() <= max(3 * errs[:125].max(), 1e-4), "the PCM error jumps once the decoder ring has wrapped (T = 2 mask quirk)"
 
 
+def test_benchmark_weights_teacher_forced_per_frame():
+    # The benchmark's OWN weights (update_scale 1: what bench.py times), as far as parity can honestly go there. Free-running, a rounding tie in one layer
+    # compounds chaotically on these random weights, so every frame starts from the ORACLE's state instead: its Temporal K / V rings (copied byte for byte,
+    # moshi_hot_ring_bytes) and its sampled tokens (force_last) - what a frame then shows is that frame's own arithmetic over 32 layers + 8 chained Depth steps,
+    # nothing inherited. What it shows (round 6, MI355X; printed, quoted in DESIGN.md section 5): NO frame meets north_star's 1e-3 text-logit bar outright -
+    # 0 of 40; median 2.6e-2, max 3.5e-2 - because no frame gets through 32 layers x ~14 rounding sites x 4 096 values without one Q8_K / BF16 tie (the
+    # node-by-node probe above counts ~1 flip in 9 000 values), and one flip, on these weights, grows to 2.3e-2 at the stack's output: exactly what the ORACLE
+    # does to itself when one norm weight is nudged by one float ulp (tests/test_oracle_noise_floor.py: 2.3e-2 after 32 layers, text logits 2.7e-2). The
+    # device is as close to the oracle as the oracle is to a one-ulp copy of itself; the tight bars live where they can be met (per layer, node by node: 2e-6
+    # on every clean node; free-running on contractive weights: 2e-3). Asserted here:
+    #   * every frame's text logits stay inside that self-sensitivity envelope (4 x the oracle's own 2.7e-2), the median inside 2 x;
+    #   * the greedy text id is the oracle's, or the oracle's own logits hold the two ids closer than twice the observed disagreement (a provable tie, counted);
+    #   * a frame whose stack output agrees to summation noise (1e-5: no flip anywhere) must meet 1e-3 outright (none occurred in 40 frames; the rule is kept for
+    #     the day a weight set produces one).
+    cfg = lm_only(hu.hot.moshika(L))
+    cfg.context = 48                       # (the copied rings stay small; 40 frames from an empty ring do not wrap it)
+    steps = 40
+    rng = np.random.default_rng(77)
+    inputs = [rng.integers(0, cfg.card, cfg.n_q - cfg.io_dep_q).tolist() for _ in range(steps)]
+    ref, dev = hu.Model("oracle", cfg, seed=0), hu.Model("hip", cfg, seed=0)
+    te, se, clean, within, ties, dep_same = [], [], 0, 0, 0, 0
+    for i, ia in enumerate(inputs):
+        ref.lm_step(ia); dev.lm_step(ia)
+        (ta, da), (tb, db) = ref.last_raw(), dev.last_raw()
+        sa, sb = ref.read("stack_out", cfg.dim), dev.read("stack_out", cfg.dim)
+        la, lb = ref.read("text_logits", cfg.text_card), dev.read("text_logits", cfg.text_card)
+        e_stack, e_log = hu.rel_err(sa, sb), hu.rel_err(la, lb)
+        se.append(e_stack); te.append(e_log)
+        is_clean = e_stack < 1e-5
+        clean += is_clean
+        within += e_log <= 1e-3
+        if is_clean:
+            assert e_log <= 1e-3, f"frame {i}: clean stack ({e_stack:.1e}) but text logits differ by {e_log:.2e}"
+        assert e_log < 4 * 2.7e-2, f"frame {i}: text logits rel err {e_log:.2e} is beyond what one rounding tie compounds to on these weights"
+        if ta != tb:
+            assert float(la[ta] - la[tb]) <= 2 * e_log * float(np.abs(la).max()), f"frame {i}: text token {tb} vs {ta} is not a tie in the oracle's logits"
+            ties += 1
+        elif da == db:
+            dep_same += 1
+        dev.set_rings(ref.rings(0), 0)      # the next frame starts from the oracle's Temporal rings ...
+        dev.force_last(ta, da)              # ... and its tokens (the Depth ring of 8 is rewritten by every frame's 8 steps)
+    ref.free(); dev.free()
+    print(f"benchmark weights, {steps} frames teacher-forced per frame: {within} of {steps} = {within / steps:.2f} meet the 1e-3 text-logit bar outright ({clean} frames without a "
+          f"rounding tie in the stack); text ids equal on {steps - ties}, {ties} provable ties; all 8 Depth ids equal on {dep_same}; text logits rel err median {np.median(te):.2e} "
+          f"max {max(te):.2e}; stack output median {np.median(se):.2e}")
+    assert np.median(te) < 2 * 2.7e-2 and ties <= steps // 8
+
+
 def test_contractive_full_config_free_running_greedy_is_bit_exact():
     # The benchmark configuration - every kernel shape / type / byte count bench.py times - with the residual updates scaled down 256x, stepped
     # free-running for 32 frames from an empty ring (each frame's sampled tokens feed the next through the delay ring). On the default
