@@ -1495,10 +1495,14 @@ static bool nest_build(chain_plan * c, char * tables_dev, char * din_dev, int us
     if (c->nest_smem > 160 * 1024) return nest_no(13);
     {   // the whole grid must be resident with THIS kernel's footprint too
         static bool granted = false;
-        if (!granted) { HIP_CHECK(hipFuncSetAttribute((const void *) depth_nest_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); granted = true; }
+        if (!granted) {
+            HIP_CHECK(hipFuncSetAttribute((const void *) depth_nest_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            HIP_CHECK(hipFuncSetAttribute((const void *) depth_nest_kernel<256, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            granted = true;
+        }
         static const int force = chain_env("MI355X_CHAIN_GRID_FORCE", 0);
         int per_cu = 0;
-        if (!force && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *) depth_nest_kernel<256>, CH_THREADS, c->nest_smem) != hipSuccess ||
+        if (!force && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *) depth_nest_kernel<256, true>, CH_THREADS, c->nest_smem) != hipSuccess ||   // (the larger of the two instances)
                        (long long) per_cu * usable_cus < 256)) return nest_no(14);
     }
     const int n_ph = S * (4 * L + 1), n_at = S * L;
@@ -1688,7 +1692,11 @@ bool k_chain_is_step_program(const chain_plan * c) { return c->nest || c->nest80
 void k_chain_launch(hipStream_t s, const chain_plan * c) {
     if (c->mimi) { mimi_tr_kernel<<<256, CH_THREADS, c->smem, s>>>(c->MM); return; }
     if (c->nest80) { depth_nest80_kernel<2048, 2048><<<256, CH_THREADS, c->smem, s>>>(c->N80); return; }
-    if (c->nest) { depth_nest_kernel<256><<<c->grid, CH_THREADS, c->nest_smem, s>>>(c->NP); return; }
+    if (c->nest) {
+        if (c->NP.head_argmax == 2) depth_nest_kernel<256, true><<<c->grid, CH_THREADS, c->nest_smem, s>>>(c->NP);
+        else depth_nest_kernel<256><<<c->grid, CH_THREADS, c->nest_smem, s>>>(c->NP);
+        return;
+    }
     // (the template argument only matters to phases with a compile-time shape; any other grid runs every phase from its descriptor)
     if (c->grid == 256) matvec_chain_kernel<256><<<c->grid, CH_THREADS, c->smem, s>>>(c->P);
     else if (c->grid == 128) matvec_chain_kernel<128><<<c->grid, CH_THREADS, c->smem, s>>>(c->P);

@@ -212,7 +212,9 @@ __device__ __forceinline__ void nest_attn_pair(float2 gq, float2 gk, float2 gv, 
     CH_ASTAMP(15);
 }
 
-template <int G>
+// SMP: the sampling-mode instance (head_argmax = 2). A template argument, not a run-time test: with the sampler's tail as a run-time branch of the one kernel the
+// greedy path measured 5 - 8 us per frame slower (more live registers across the head phase; same-box A/B profiles/r06_ab_lean_activation_loads.txt).
+template <int G, bool SMP = false>
 __global__ void __launch_bounds__(CH_THREADS) depth_nest_kernel(nest_params N) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -577,7 +579,7 @@ __global__ void __launch_bounds__(CH_THREADS) depth_nest_kernel(nest_params N) {
                     if (st.emb_chain) {
                         if (wave == 0) {
                             int token = 0;
-                            const bool got = N.head_argmax == 2 ? gather_sampled(cb, (unsigned) ((p - 1) & 1) * (2u * (unsigned) grid * 8u), grid, tag_base | (unsigned) p, lane, ctl, token)
+                            const bool got = SMP ? gather_sampled(cb, (unsigned) ((p - 1) & 1) * (2u * (unsigned) grid * 8u), grid, tag_base | (unsigned) p, lane, ctl, token)
                                                                 : gather_token(cb, (unsigned) ((p - 1) & 1) * (2u * (unsigned) grid * 8u), grid, tag_base | (unsigned) p, lane, ctl, token);
                             if (!got) give_up();
                             if (lane == 0) {
@@ -769,7 +771,7 @@ __global__ void __launch_bounds__(CH_THREADS) depth_nest_kernel(nest_params N) {
             const nest_ph ph = ld_ph(p);
             // sampling mode: this step's noise vector goes out now (rank j's noise in thread j; uploaded by the host in front of the graph, src/context.h:465-480)
             float smp_noise = 1.f, smp_scale = 1.f; int smp_k = 1;
-            if (N.head_argmax == 2) {
+            if (SMP) {
                 const nest_st sst = ld_st(s);
                 smp_scale = sst.smp_scale; smp_k = sst.smp_k;
                 smp_noise = gp(sst.noise)[tid < smp_k ? tid : 0];
@@ -790,9 +792,9 @@ __global__ void __launch_bounds__(CH_THREADS) depth_nest_kernel(nest_params N) {
             nbar();
             CH_STAMP(7);
             float best = -INFINITY; int bi = -1;
-            rowsum(shape_head(), 0, p, ph.y, best, bi, N.head_argmax == 2);
+            rowsum(shape_head(), 0, p, ph.y, best, bi, SMP);
             CH_STAMP(8);
-            if (N.head_argmax == 2) {
+            if (SMP) {
                 // ---- the top-k sampler (moshi_sample_token, sampling.h:4-64) as the tail of the phase, spread over ALL workgroups: sample_topk_kernel's values
                 // (soft-max in its summation order, ranks by value descending / index ascending, q = p / noise[rank], last maximum) without its sort. Every
                 // workgroup gathers the 2 048 logits (published by rowsum above), computes the soft-max statistics itself, RANKS ITS OWN 8 ROWS by counting the
@@ -920,7 +922,7 @@ __global__ void __launch_bounds__(CH_THREADS) depth_nest_kernel(nest_params N) {
     if (wg == 0 && wave == 0 && N.head_argmax) {
         const nest_st st = ld_st(N.n_steps - 1);
         int token = 0;
-        const bool got = N.head_argmax == 2 ? gather_sampled(cb, (unsigned) ((p - 1) & 1) * (2u * (unsigned) grid * 8u), grid, tag_base | (unsigned) p, lane, ctl, token)
+        const bool got = SMP ? gather_sampled(cb, (unsigned) ((p - 1) & 1) * (2u * (unsigned) grid * 8u), grid, tag_base | (unsigned) p, lane, ctl, token)
                                             : gather_token(cb, (unsigned) ((p - 1) & 1) * (2u * (unsigned) grid * 8u), grid, tag_base | (unsigned) p, lane, ctl, token);
         if (got) {
             if (lane == 0) { if (st.argmax_out[0]) *gp(st.argmax_out[0]) = token; if (st.argmax_out[1]) *gp(st.argmax_out[1]) = token; }

@@ -333,6 +333,22 @@ __global__ void __launch_bounds__(NW * 64) matvec_q4k_kernel(mv_args a, int rows
             if (PRO == MV_GATE_SILU) aux[j] = *(const float4 *) (a.x + K + e);
         }
     };
+    // a LATER round (K > XB * NW * 256: the Temporal linear_out, K = 11 264) is waited for at once, so here a wave simply skips the batches past the end of x
+    // (whole waves fall on either side: K is a multiple of 256) instead of issuing clamped duplicates - 2 of round two's 4 loads at K = 11 264
+    auto load_batch_tail = [&](int base) {
+#pragma unroll
+        for (int j = 0; j < XB; j++) {
+            const int e0 = base + j * (NW * 256) + tid * 4;
+            ok[j] = e0 < K;
+            xv[j] = make_float4(0.f, 0.f, 0.f, 0.f); aux[j] = xv[j];
+            if (__builtin_amdgcn_readfirstlane(e0 - lane * 4) < K) {
+                xv[j] = *(const float4 *) (a.x + e0);
+                aux[j] = xv[j];
+                if (PRO == MV_RMSNORM) aux[j] = *(const float4 *) (a.alpha + e0);
+                if (PRO == MV_GATE_SILU) aux[j] = *(const float4 *) (a.x + K + e0);
+            }
+        }
+    };
     if (PRO != MV_PREQ8K && PRO != MV_ATTN) load_batch(0);
     // MV_PREQ8K: the activation arrives quantised (norm_quant / gate_quant kernels): nb padded Q8_K blocks of 304 B = nb * 19 chunks of 16 B,
     // at most 3 per thread (K <= 16384 at 256 threads); requested ahead of the weight tile for the same reason
@@ -412,7 +428,7 @@ __global__ void __launch_bounds__(NW * 64) matvec_q4k_kernel(mv_args a, int rows
         }
     } else {
         for (int base = 0; base < K; base += NW * 256 * XB) {
-            if (base > 0) load_batch(base);
+            if (base > 0) load_batch_tail(base);
             float v[XB][4];
 #pragma unroll
             for (int j = 0; j < XB; j++) {
