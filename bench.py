@@ -27,7 +27,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 from __graft_entry__ import load_oracle, load_package  # noqa: E402
 
-PMC_FILE = "r05_pmc_fetch_size.json"   # rocprofv3 --pmc FETCH_SIZE pass of this command (tests/microbench/take_profiles.sh), stamped with the kernel sources' hash
+PMC_FILE = "r06_pmc_fetch_size.json"   # rocprofv3 --pmc FETCH_SIZE pass of this command (tests/microbench/take_profiles.sh), stamped with the kernel sources' hash
 HBM_PEAK_GBPS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 SERIAL_FRAMES, SERIAL_WARMUP = 125, 30   # the serial (unchanged-tool) legs: the reference's own --bench length (tools/moshi-sts.cpp:770-808), outside the timed region
 
@@ -413,6 +413,7 @@ def main():
                 result["serial_loop"]["handles"] = 1
                 result["serial_loop"]["warmup"] = nwarm
                 result["value_serial"] = result["serial_loop"]["value"]
+                result["serial_loop"]["frames_stepped_by_the_one_handle_model"] = int(L.moshi_hot_offset(m1))
                 L.moshi_hot_free(m1)
 
     if shard is not None and args.shard == "temporal":
@@ -518,7 +519,8 @@ def main():
             result["cpu_baseline"] = {"value": None, "unit": "frames/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e}"}
 
     if rank == 0 and m is not None:
-        result["frames_stepped_total"] = int(L.moshi_hot_offset(m))   # warm-up + timed + the phase / serial / roofline passes (profile summaries divide by it)
+        # warm-up + timed + the phase / serial / roofline passes, on both model instances (profile summaries divide by it)
+        result["frames_stepped_total"] = int(L.moshi_hot_offset(m)) + int(result.get("serial_loop", {}).get("frames_stepped_by_the_one_handle_model", 0))
     if rank == 0 and world == 1 and shard is None and not args.no_extras and args.model == "moshika" and args.quant == "q4_k" and not args.sampled and not args.context_fill:
         # not the headline: the same loop (a) with the reference's --bench sampling defaults, (b) from a nearly full ring, (c) at BASELINE configs[4]
         def quick(make_cfg, fill=0, steps=40):

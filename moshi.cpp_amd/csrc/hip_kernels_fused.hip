@@ -276,11 +276,12 @@ __device__ __forceinline__ void attn_small_wave(const attn_args & a, int h0, int
 // work per lane. The Depth mat-vecs are a few tiles in all: with a super-block per lane 192 waves did ~2 000 cycles of serial dot4 / unpack each
 // while 3/4 of the chip's SIMDs idled; this way the dot phase is ~300 cycles. Same integers, same per-super-block float expression.
 #define MVD_PMAX 4   // passes (super-blocks per lane group) a workgroup can hold in registers: rows * nb <= MVD_PMAX * NW * 8
-// XB: activation batches of NW * 256 values a load_batch requests per thread (4: K up to NW * 1024 per round; 2: K <= NW * 512 in ONE round); RL: the residual
-// pre-load. Until round 6 every launch issued four x + four alpha / gate loads and four residual loads per thread whatever it needed: at K = 4096 with 8 waves
-// (the Temporal linear_in, the text head) two of the four batches were clamped duplicates and there is no residual - 8 of a wave's 21 vector-memory
-// instructions, ~26 cycles of issue each, in front of the weight tile and of the workgroup barrier of the norm. <.., 2, false> is that launch without them.
-template <int PRO, int NW, int FMT = MVF_Q4K, int WS = 0, int XB = 4, bool RL = true>
+// XB: activation batches of NW * 256 values a load_batch requests per thread (4: K up to NW * 1024 per round; 2: K <= NW * 512 in ONE round); RN: residual values
+// pre-loaded per thread (row (tid >> 4) + k * NW * 4 for k < RN: 4 covers any workgroup, 1 covers rows <= NW * 4, 0 = no residual). Until round 6 every launch
+// issued four x + four alpha / gate loads and four residual loads per thread whatever it needed: at K = 4096 with 8 waves (the Temporal linear_in, the text head)
+// two of the four batches were clamped duplicates and there is no residual - 8 of a wave's 21 vector-memory instructions, ~26 cycles of issue each, in front of
+// the weight tile and of the workgroup barrier of the norm; out_proj / linear_out (16 rows per workgroup) used one of their four residual loads.
+template <int PRO, int NW, int FMT = MVF_Q4K, int WS = 0, int XB = 4, int RN = 4>
 __global__ void __launch_bounds__(NW * 64) matvec_q4k_kernel(mv_args a, int rows_per_wg, attn_args at) {
     constexpr int SB = mvfmt<FMT>::SB, NLOAD = mvfmt<FMT>::NLOAD, TILE = 64 * SB;   // bytes per lane-chunk / 16-byte loads per lane per tile
     static_assert(WS == 0 || FMT == MVF_Q4K, "the direct layout is written for Q4_K super-blocks");
@@ -389,10 +390,10 @@ __global__ void __launch_bounds__(NW * 64) matvec_q4k_kernel(mv_args a, int rows
     }
     // the residual of this thread's rows (phase 4) rides behind the first weight loads: its round trip used to sit, exposed, at the very end
     float res_pre[4] = { 0.f, 0.f, 0.f, 0.f };
-    if (RL) {
+    if (RN > 0) {
         const float * rp = a.residual ? a.residual : a.y;   // (no branch around a load) y is valid memory of the same extent
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
+        for (int k = 0; k < RN; k++) {
             const int rr = (tid >> 4) + k * (NW * 4);
             res_pre[k] = rp[row0 + (rr < (paired ? half_rows : rows) ? rr : 0)];
         }
@@ -564,7 +565,7 @@ __global__ void __launch_bounds__(NW * 64) matvec_q4k_kernel(mv_args a, int rows
         sum = row16_allsum_f32(sum);
         if ((tid & 15) == 0) {
             const int64_t row = row0 + rr;
-            if (a.residual) sum = (kq == 0 ? res_pre[0] : kq == 1 ? res_pre[1] : kq == 2 ? res_pre[2] : kq == 3 ? res_pre[3] : a.residual[row]) + sum;
+            if (a.residual) sum = (kq < RN ? (kq == 0 ? res_pre[0] : kq == 1 ? res_pre[1] : kq == 2 ? res_pre[2] : res_pre[3]) : a.residual[row]) + sum;
             else if (a.res_embed.table) {
                 int64_t r = *a.res_embed.index;
                 if (r < 0 || r >= a.res_embed.n_rows) r = 0;
@@ -1581,7 +1582,10 @@ void k_matvec(hipStream_t s, const mv_args & a) {
         // four, no residual pre-load (see the kernel's XB / RL parameters); same arithmetic
         static const int lean_on = env_int("MI355X_MV_LEAN", 1);
         if (lean_on && !direct && nw == 8 && fmt == MVF_Q4K && a.prologue == MV_RMSNORM && a.K <= 8 * 512 && !a.residual && !a.res_embed.table)
-            kern = matvec_q4k_kernel<MV_RMSNORM, 8, MVF_Q4K, 0, 2, false>;
+            kern = matvec_q4k_kernel<MV_RMSNORM, 8, MVF_Q4K, 0, 2, 0>;
+        // the plain launches with a residual whose workgroups hold <= NW * 4 rows (the Temporal out_proj: 4 waves x 16 rows; linear_out: 8 waves x 16 rows): one residual load per thread
+        if (lean_on && !direct && fmt == MVF_Q4K && a.prologue == MV_PLAIN && a.pair_F == 0 && a.residual && rows <= nw * 4 && (nw == 8 || nw == 4))
+            kern = nw == 8 ? matvec_q4k_kernel<MV_PLAIN, 8, MVF_Q4K, 0, 4, 1> : matvec_q4k_kernel<MV_PLAIN, 4, MVF_Q4K, 0, 4, 1>;
         if (smem > 64 * 1024) {   // > 64 KB of dynamic LDS needs a one-time opt-in per kernel
             static std::map<const void *, size_t> granted;
             size_t & g = granted[(const void *) kern];
@@ -2132,7 +2136,7 @@ void k_embed_sum(hipStream_t s, const embed_sum_args & a) {
     for (int t = 1; t < a.n; t++) if (a.src[t].type != type) type = -1;
     const int grid = (int) ((a.K + 63) / 64);
     // (every loop over the terms is unrolled to the instantiation's bound: sums of up to 24 terms - moshika 17, PersonaPlex 17 - keep the 24-term kernel)
-#define EMBED_LAUNCH(T) do { if (a.n <= 24) embed_sum_kernel<T, 24><<<grid, 64, 0, s>>>(a); else embed_sum_kernel<T, EMBED_SUM_MAX><<<grid, 64, 0, s>>>(a); } while (0)
+#define EMBED_LAUNCH(T) do { if (a.n <= 8) embed_sum_kernel<T, 8><<<grid, 64, 0, s>>>(a); else if (a.n <= 24) embed_sum_kernel<T, 24><<<grid, 64, 0, s>>>(a); else embed_sum_kernel<T, EMBED_SUM_MAX><<<grid, 64, 0, s>>>(a); } while (0)   // (8: the RVQ decode sums - 7 + 1 rows - ran 16 dead iterations per stage in the 24-term instance)
     switch (type) {
         case GGML_TYPE_Q4_0: EMBED_LAUNCH(GGML_TYPE_Q4_0); break;
         case GGML_TYPE_Q8_0: EMBED_LAUNCH(GGML_TYPE_Q8_0); break;
