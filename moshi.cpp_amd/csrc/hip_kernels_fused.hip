@@ -467,7 +467,8 @@ __global__ void __launch_bounds__(NW * 64) matvec_q4k_kernel(mv_args a, int rows
             }
 #pragma unroll
             for (int j = 0; j < XB; j++) {
-                if (!ok[j]) continue;   // wave-uniform: a wave always holds one whole block
+                if (!ok[j]) continue;   // wave-uniform: a wave always holds one whole block. (Passing ok[j] into a branch-free quantiser so that a wave's blocks
+                // interleave measured SLOWER: Temporal 1 400 -> 1 415 us, profiles/r06_ab_branch_free_quantiser.txt)
                 const int b = base / 256 + j * NW + wave;
                 if (a.x_out != nullptr && blockIdx.x == 0) *(float4 *) (a.x_out + base + j * (NW * 256) + tid * 4) = make_float4(v[j][0], v[j][1], v[j][2], v[j][3]);
                 quantize_block(xs + b, v[j]);
@@ -1586,6 +1587,11 @@ void k_matvec(hipStream_t s, const mv_args & a) {
         // the plain launches with a residual whose workgroups hold <= NW * 4 rows (the Temporal out_proj: 4 waves x 16 rows; linear_out: 8 waves x 16 rows): one residual load per thread
         if (lean_on && !direct && fmt == MVF_Q4K && a.prologue == MV_PLAIN && a.pair_F == 0 && a.residual && rows <= nw * 4 && (nw == 8 || nw == 4))
             kern = nw == 8 ? matvec_q4k_kernel<MV_PLAIN, 8, MVF_Q4K, 0, 4, 1> : matvec_q4k_kernel<MV_PLAIN, 4, MVF_Q4K, 0, 4, 1>;
+        // ... and with 8 192 < K <= 12 288 at 8 waves (the Temporal linear_out, K = 11 264): SIX activation batches requested at entry, one round - with four, the last
+        // 3 072 values were a second round whose loads went out only after the first round's blocks were quantised: a dependent L2 round trip inside every prologue
+        static const int one_round = env_int("MI355X_MV_ONE_ROUND", 1);
+        if (lean_on && one_round && !direct && fmt == MVF_Q4K && a.prologue == MV_PLAIN && a.pair_F == 0 && a.residual && rows <= nw * 4 && nw == 8 && a.K > 8 * 1024 && a.K <= 8 * 1536)
+            kern = matvec_q4k_kernel<MV_PLAIN, 8, MVF_Q4K, 0, 6, 1>;
         if (smem > 64 * 1024) {   // > 64 KB of dynamic LDS needs a one-time opt-in per kernel
             static std::map<const void *, size_t> granted;
             size_t & g = granted[(const void *) kern];
