@@ -93,15 +93,31 @@ __device__ __forceinline__ float apply_unary(int uop, float x) {
 #define DPP_QUAD_XOR2   0x4E   // quad_perm [2,3,0,1]
 #define DPP_HALF_MIRROR 0x141  // lane i <-> 7 - i inside each group of 8
 #define DPP_ROW_MIRROR  0x140  // lane i <-> 15 - i inside each row of 16
+// (bound_ctrl = true: every permutation used here reads a valid lane for every lane, so the flag changes no value - but with it, full row / bank masks and
+// an unused `old`, the compiler folds the move into the consuming VOP2: v_add_f32_dpp / v_max_u32_dpp ... instead of v_mov_b32_dpp + the op)
 template <int CTRL> __device__ __forceinline__ float dpp_f32(float v) {
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
 }
-template <int CTRL> __device__ __forceinline__ int dpp_i32(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, false); }
+template <int CTRL> __device__ __forceinline__ int dpp_i32(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true); }
 template <int CTRL> __device__ __forceinline__ double dpp_f64(double v) {
     int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, false);
-    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, false);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true);
     return __hiloint2double(hi, lo);
+}
+// maximum over the 64 lanes of a NON-NEGATIVE float (no NaN), result in every lane: non-negative floats order like their bit patterns, and an unsigned
+// integer maximum needs no canonicalisation of its operands (fmaxf costs three v_max_f32 per step: one per operand to quiet signalling NaNs, one for the
+// maximum) and folds into the DPP move: one v_max_u32_dpp per step
+__device__ __forceinline__ float wave_allmax_nonneg_f32(float v) {
+    unsigned u = __float_as_uint(v);
+    auto umax = [](unsigned a, unsigned b) { return a > b ? a : b; };
+    u = umax(u, (unsigned) dpp_i32<DPP_QUAD_XOR1>((int) u));
+    u = umax(u, (unsigned) dpp_i32<DPP_QUAD_XOR2>((int) u));
+    u = umax(u, (unsigned) dpp_i32<DPP_HALF_MIRROR>((int) u));
+    u = umax(u, (unsigned) dpp_i32<DPP_ROW_MIRROR>((int) u));
+    const unsigned r0 = (unsigned) __builtin_amdgcn_readlane((int) u, 0), r1 = (unsigned) __builtin_amdgcn_readlane((int) u, 16);
+    const unsigned r2 = (unsigned) __builtin_amdgcn_readlane((int) u, 32), r3 = (unsigned) __builtin_amdgcn_readlane((int) u, 48);
+    return __uint_as_float(umax(umax(r0, r1), umax(r2, r3)));
 }
 // max over the 64 lanes, result in every lane
 __device__ __forceinline__ float wave_allmax_f32(float v) {

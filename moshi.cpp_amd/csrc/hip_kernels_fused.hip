@@ -364,6 +364,11 @@ __global__ void __launch_bounds__(NW * 64) matvec_q4k_kernel(mv_args a, int rows
         }
     }
     __builtin_amdgcn_sched_barrier(0);   // keep the activation loads ahead of the weight tile in program (= return) order
+#if defined(MV_HEAD_EXP) && MV_HEAD_EXP == 1
+    __builtin_amdgcn_s_barrier();
+#elif defined(MV_HEAD_EXP) && MV_HEAD_EXP == 2
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
 
     u32x4 r[WS == 0 ? NLOAD : 1];
     u32x4 dh[WS == 1 ? MVD_PMAX : 1], dq[WS == 1 ? MVD_PMAX : 1];   // WS = 1: header / nibble chunk of this lane group's super-block, per pass
@@ -436,6 +441,10 @@ __global__ void __launch_bounds__(NW * 64) matvec_q4k_kernel(mv_args a, int rows
                 const float z = ok[j] ? 1.f : 0.f;   // clamped (out-of-range) chunks contribute nothing to the norm
                 v[j][0] = xv[j].x * z; v[j][1] = xv[j].y * z; v[j][2] = xv[j].z * z; v[j][3] = xv[j].w * z;
             }
+#if defined(MV_LOG)
+            asm volatile("" :: "v"(v[0][0]), "v"(v[XB - 1][3]));   // (diagnostic build: stamp 8 = this wave's x values have arrived)
+            MV_STAMP(8);
+#endif
             if (PRO == MV_RMSNORM) {   // K <= 4096 (checked on the host): the whole vector is in registers
                 double acc = 0;
 #pragma unroll
@@ -445,6 +454,7 @@ __global__ void __launch_bounds__(NW * 64) matvec_q4k_kernel(mv_args a, int rows
                 acc = wave_allsum_f64(acc);
                 if (lane == 0) sh_red[wave] = acc;
                 __syncthreads();
+                MV_STAMP(9);    // (every wave's sum of squares is in)
                 double tot = 0;
 #pragma unroll
                 for (int w = 0; w < NW; w++) tot += sh_red[w];
@@ -465,6 +475,10 @@ __global__ void __launch_bounds__(NW * 64) matvec_q4k_kernel(mv_args a, int rows
                     for (int k = 0; k < 4; k++) { const float l = v[j][k]; v[j][k] = (l / (1.0f + expf(-l))) * rr[k]; }
                 }
             }
+#if defined(MV_LOG)
+            asm volatile("" :: "v"(v[0][0]), "v"(v[XB - 1][3]));   // (stamp 10 = normalised / gated values ready, the quantiser starts)
+            MV_STAMP(10);
+#endif
 #pragma unroll
             for (int j = 0; j < XB; j++) {
                 if (!ok[j]) continue;   // wave-uniform: a wave always holds one whole block. (Passing ok[j] into a branch-free quantiser so that a wave's blocks
@@ -1839,6 +1853,11 @@ __global__ void __launch_bounds__(FOLD_NW * 64) inproj_attn_kernel(mv_args a, at
         aux[j] = *(const float4 *) (a.alpha + e);
     }
     __builtin_amdgcn_sched_barrier(0);
+#if defined(MV_HEAD_EXP) && MV_HEAD_EXP == 1
+    __builtin_amdgcn_s_barrier();
+#elif defined(MV_HEAD_EXP) && MV_HEAD_EXP == 2
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
     u32x4 r[NLOAD];
     int t = wave;
     {

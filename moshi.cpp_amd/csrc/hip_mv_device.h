@@ -16,9 +16,12 @@ static_assert(sizeof(xblk) == XBLK_BYTES && offsetof(xblk, bsums) == 256 && offs
 __device__ __forceinline__ void quantize_block_q8k(xblk * dst, const float v[4], int lane) {
     // the signed value of largest magnitude (ggml: iscale = -127 / max); when +a and -a tie the sign is immaterial
     // (the sign comes from one ballot instead of a second wave-wide maximum: the largest signed value equals amax exactly when some element IS +amax)
-    float amax = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
+    // (the magnitudes' maximum on their bit patterns: non-negative floats order like unsigned integers - one v_max_u32_dpp per reduction step where fmaxf
+    // costs a move and three v_max_f32. A NaN input would win here where fmaxf ignores it; the result is meaningless either way)
+    const unsigned a0 = __float_as_uint(v[0]) & 0x7fffffffu, a1 = __float_as_uint(v[1]) & 0x7fffffffu, a2 = __float_as_uint(v[2]) & 0x7fffffffu, a3 = __float_as_uint(v[3]) & 0x7fffffffu;
+    const unsigned a01 = a0 > a1 ? a0 : a1, a23 = a2 > a3 ? a2 : a3;
+    const float amax = wave_allmax_nonneg_f32(__uint_as_float(a01 > a23 ? a01 : a23));
     const float smax = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
-    amax = wave_allmax_f32(amax);
     const float mx = __ballot(smax == amax) != 0ull ? amax : -amax;
     int q[4] = { 0, 0, 0, 0 };
     float d = 0.f;

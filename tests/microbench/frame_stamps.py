@@ -42,7 +42,7 @@ for r in rows:
 print("   K      M  pro ws grid    n | in-kernel us (block 0) | gap before us | phase cycles: loads-issued, prologue, sync, staged, tiles, sync, end")
 for k, v in sorted(agg.items(), key=lambda kv: -len(kv[1]) * np.mean([x[6] + x[7] for x in kv[1]])):
     dur = np.median([x[6] for x in v]); gap = np.median([x[7] for x in v]); ph = np.median(np.array([x[8] for x in v]), axis=0)
-    print(f"{k[0]:5d} {k[1]:6d} {names.get(k[2], k[2]):>5} {k[3]:2d} {k[4]:4d} {len(v):4d} | {dur:8.2f}              | {gap:8.2f}      | " + " ".join(f"{int(p):6d}" for p in ph[:7]) + (" | extra " + " ".join(f"{int(p):6d}" for p in ph[7:11]) if k[2] == 0xA7 else ""))
+    print(f"{k[0]:5d} {k[1]:6d} {names.get(k[2], k[2]):>5} {k[3]:2d} {k[4]:4d} {len(v):4d} | {dur:8.2f}              | {gap:8.2f}      | " + " ".join(f"{int(p):6d}" for p in ph[:7]) + (" | extra " + " ".join(f"{int(p):6d}" for p in ph[7:11]) if k[2] == 0xA7 else " | x arrived, sumsq in, quantiser starts " + " ".join(f"{int(p):6d}" for p in ph[7:10])))
 tot_k = sum(x[6] for x in rows); tot_g = sum(x[7] for x in rows)
 print(f"sum of in-kernel {tot_k:.0f} us, sum of gaps {tot_g:.0f} us")
 if len(sys.argv) > 1:
