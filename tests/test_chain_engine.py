@@ -199,7 +199,7 @@ def test_small_width_runs_between_attention_launches_are_chained_too():
     assert_bit_identical(plain, chained, "tiny")
 
 
-@pytest.mark.parametrize("which", ["real_width", "moshika"])
+@pytest.mark.parametrize("which", ["real_width", "moshika", "personaplex"])
 def test_sampled_mode_is_one_step_program_with_the_sampler_as_a_phase(which):
     # temp > 0 (the reference's own --bench mode, tools/moshi-sts.cpp:106-107): a sampler sits between the steps. At moshika's sizes the step program takes the
     # samplers in as the tail of its linears[k] phases (hip_chain_nest.h, head_argmax = 2: soft-max statistics and ranks computed by every workgroup for its own
@@ -207,15 +207,15 @@ def test_sampled_mode_is_one_step_program_with_the_sampler_as_a_phase(which):
     # (flag 16: k_sample_topk). Flag 1024 keeps the descriptor-driven kernel: the sampler launches then cut the run into one chain per step as before.
     import ctypes
     libc = ctypes.CDLL(None)
-    if which == "moshika":
-        cfg = hu.hot.moshika(hu.L)
+    if which in ("moshika", "personaplex"):   # (PersonaPlex: 16 sampled steps whose ring of 8 wraps inside the launch; the reference's top-k = 250 there)
+        cfg = hu.hot.moshika(hu.L) if which == "moshika" else hu.hot.personaplex(hu.L)
         cfg.num_layers, cfg.context = 2, 64
         cfg.enable_mimi_encoder = cfg.enable_mimi_decoder = 0
     else:
         cfg = depth_at_real_width(dep_q=3, layers=1, n_q=6)
-    cfg.temp, cfg.temp_text, cfg.top_k, cfg.top_k_text = 0.8, 0.7, 20, 10
+    cfg.temp, cfg.temp_text, cfg.top_k, cfg.top_k_text = (0.8, 0.7, 20, 10) if which != "personaplex" else (0.8, 0.7, 250, 25)
     out = {}
-    for flags in (32, 16) + ((32 | 1024,) if which == "moshika" else ()):
+    for flags in (32, 16) + ((32 | 1024,) if which in ("moshika", "personaplex") else ()):
         m = hu.Model("hip", cfg, seed=0, flags=flags)
         rng = np.random.default_rng(7)
         rec = []
@@ -227,7 +227,7 @@ def test_sampled_mode_is_one_step_program_with_the_sampler_as_a_phase(which):
         m.free()
     assert out[32][1].chained_matvecs_in_last_plan > 0
     assert_bit_identical(out[16][0], out[32][0], "sampled")
-    if which == "moshika":
+    if which in ("moshika", "personaplex"):
         assert out[32][1].chain_step_programs_in_last_plan == 1 and out[32 | 1024][1].chain_step_programs_in_last_plan == 0
         assert_bit_identical(out[32 | 1024][0], out[32][0], "sampled (descriptor-driven chain vs step program)")
 
